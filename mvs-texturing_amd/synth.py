@@ -1,0 +1,116 @@
+"""ctypes binding of the synthetic scene generator (csrc/scene_synth.cpp).
+
+Input producer for tests and bench.py: icosphere mesh, pinhole
+cameras, procedural RGB8 images and the face adjacency CSR with the ordering
+semantics of libs/tex/build_adjacency_graph.cpp:16-53.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "csrc", "scene_synth.cpp")
+_LIB = os.path.join(_HERE, "csrc", "libmvs_synth.so")
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("n_verts", C.c_uint32), ("n_faces", C.c_uint32),
+                ("verts", C.POINTER(C.c_float)), ("faces", C.POINTER(C.c_uint32)),
+                ("normals", C.POINTER(C.c_float)), ("adj_ptr", C.POINTER(C.c_uint32)),
+                ("adj", C.POINTER(C.c_uint32))]
+
+
+class _Camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("viewdir", C.c_float * 3), ("K", C.c_float * 9),
+                ("w2c", C.c_float * 16), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+def build_synth(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC",
+                               "-std=c++17", "-shared", "-o", _LIB, _SRC])
+    return _LIB
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build_synth()
+        _lib = C.CDLL(_LIB)
+        _lib.synth_icosphere.argtypes = [C.c_uint32, C.c_float, C.c_uint32, C.POINTER(_Mesh)]
+        _lib.synth_build_adjacency.argtypes = [C.POINTER(_Mesh)]
+        _lib.synth_mesh_free.argtypes = [C.POINTER(_Mesh)]
+        _lib.synth_cameras.argtypes = [C.c_uint32, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(_Camera)]
+        _lib.synth_render.argtypes = [C.POINTER(_Camera), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    return _lib
+
+
+class Scene:
+    """verts (NV,3) f32, faces (F,3) u32, normals (F,3) f32, adj_ptr (F+1) u32, adj u32,
+    cams: dict of arrays (pos, viewdir, K, w2c, width, height), images: list of (H,W,3) u8."""
+
+    def __init__(self):
+        self.verts = self.faces = self.normals = self.adj_ptr = self.adj = None
+        self.cams = None
+        self.images = []
+
+    @property
+    def n_faces(self):
+        return int(self.faces.shape[0])
+
+    @property
+    def n_views(self):
+        return int(self.cams["pos"].shape[0])
+
+
+def make_scene(n, n_views, width, height, displacement=0.0, layout=1, seed=1234, image_seed=99,
+               radius=3.0, adjacency=True, render=True, black_corner=0):
+    lib = _load()
+    m = _Mesh()
+    rc = lib.synth_icosphere(n, displacement, seed, C.byref(m))
+    if rc:
+        raise RuntimeError("synth_icosphere failed: %d" % rc)
+    s = Scene()
+    nv, nf = m.n_verts, m.n_faces
+    s.verts = np.ctypeslib.as_array(m.verts, (nv, 3)).copy()
+    s.faces = np.ctypeslib.as_array(m.faces, (nf, 3)).copy()
+    s.normals = np.ctypeslib.as_array(m.normals, (nf, 3)).copy()
+    if adjacency:
+        lib.synth_build_adjacency(C.byref(m))
+        s.adj_ptr = np.ctypeslib.as_array(m.adj_ptr, (nf + 1,)).copy()
+        s.adj = np.ctypeslib.as_array(m.adj, (int(s.adj_ptr[-1]),)).copy()
+    lib.synth_mesh_free(C.byref(m))
+    cams = (_Camera * n_views)()
+    rc = lib.synth_cameras(n_views, layout, radius, width, height, cams)
+    if rc:
+        raise RuntimeError("synth_cameras failed: %d" % rc)
+    s.cams = {
+        "pos": np.array([list(c.pos) for c in cams], dtype=np.float32),
+        "viewdir": np.array([list(c.viewdir) for c in cams], dtype=np.float32),
+        "K": np.array([list(c.K) for c in cams], dtype=np.float32),
+        "w2c": np.array([list(c.w2c) for c in cams], dtype=np.float32),
+        "width": np.array([c.width for c in cams], dtype=np.int32),
+        "height": np.array([c.height for c in cams], dtype=np.int32),
+    }
+    if render:
+        for j in range(n_views):
+            img = np.empty((height, width, 3), dtype=np.uint8)
+            lib.synth_render(C.byref(cams[j]), j, image_seed, black_corner if j == 0 else 0,
+                             img.ctypes.data_as(C.c_void_p))
+            s.images.append(img)
+    return s
+
+
+# the five configurations as concrete inputs
+CONFIGS = {
+    1: dict(n=22, n_views=6, width=1024, height=768, displacement=0.0, layout=0),
+    2: dict(n=100, n_views=50, width=1024, height=768, displacement=0.05, layout=1),
+    3: dict(n=316, n_views=200, width=2048, height=1536, displacement=0.05, layout=1),
+    4: dict(n=316, n_views=200, width=2048, height=1536, displacement=0.05, layout=1),
+    5: dict(n=707, n_views=1000, width=2048, height=1536, displacement=0.05, layout=1),
+}

@@ -1,0 +1,140 @@
+/* CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C++ restatement of the reference's view-selection hot path
+ * (nmoehrle/mvs-texturing: libs/tex/calculate_data_costs.cpp,
+ * libs/tex/texture_view.{h,cpp}, libs/tex/tri.{h,cpp}, libs/tex/histogram.cpp,
+ * libs/tex/view_selection.cpp model construction).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the CHECKER.  The product (mvs-texturing_amd/) never
+ * links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
+ *  and its hot path cannot be compiled here because MVE,
+ * rayint, Eigen and mapMAP are un-vendored downloads (elibs/CMakeLists.txt:1-42).
+ * Where the arithmetic lives in those absent dependencies this file DEFINES the
+ * semantics (marked "DEFINED HERE" below) -- see DESIGN.md section "Oracle".
+ */
+#ifndef MVS_ORACLE_H
+#define MVS_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    uint32_t n_verts, n_faces;
+    const float* verts;        /* 3*n_verts   (mesh->get_vertices(),     calculate_data_costs.cpp:137) */
+    const uint32_t* faces;     /* 3*n_faces   (mesh->get_faces(),        calculate_data_costs.cpp:136) */
+    const float* face_normals; /* 3*n_faces   (mesh->get_face_normals(), calculate_data_costs.cpp:138) */
+} orc_mesh;
+
+/* the TextureView fields the path reads (texture_view.h:43-48) + decoded image */
+typedef struct {
+    float pos[3];
+    float viewdir[3];
+    float K[9];     /* 3x3 projection, row major */
+    float w2c[16];  /* 4x4 world_to_cam, row major */
+    int32_t width, height;
+    const uint8_t* rgb; /* width*height*3 */
+} orc_view;
+
+/* tex::Settings fields read by the path (settings.h:85,87,90) */
+typedef struct {
+    int32_t data_term;                 /* 0 = area, 1 = gmi            (settings.h:59-62) */
+    int32_t outlier_removal;           /* 0 none, 1 damping, 2 clamping (settings.h:70-74) */
+    int32_t geometric_visibility_test; /* bool */
+} orc_settings;
+
+/* tex::DataCosts == SparseTable<u32,u16,float> (sparse_table.h) as CSR by face */
+typedef struct {
+    uint32_t n_faces, n_views;
+    uint64_t nnz;
+    uint32_t* col_ptr;  /* n_faces + 1 */
+    uint16_t* view_id;  /* nnz, ascending within a face (calculate_data_costs.cpp:272) */
+    float* cost;        /* nnz */
+    float* quality;     /* nnz, un-normalised quality (diagnostic) */
+} orc_csr;
+
+typedef struct {
+    uint64_t pairs;           /* faces * views examined */
+    uint64_t cull_backface;   /* calculate_data_costs.cpp:183-185 */
+    uint64_t cull_angle;      /* :187-188 */
+    uint64_t cull_outside;    /* :191 */
+    uint64_t cull_occluded;   /* :194-215 */
+    uint64_t cull_zero_quality; /* :222 */
+    uint64_t nnz_pre;         /* FaceProjectionInfos emitted */
+    uint64_t rays;            /* rays actually cast (with the reference's break on first hit) */
+    uint64_t ray_nodes;       /* BVH nodes visited */
+    uint64_t ray_tris;        /* triangles tested */
+    float max_quality;        /* :278-281 */
+    float percentile;         /* :288 */
+    double t_prep, t_bvh, t_infos, t_post; /* seconds */
+} orc_dc_stats;
+
+/* ---- image preparation (texture_view.cpp:42-132) ---- */
+void orc_validity_mask(const uint8_t* rgb, int w, int h, uint8_t* mask);
+void orc_gradient_magnitude(const uint8_t* rgb, int w, int h, uint8_t* gmi);
+void orc_erode_validity_mask(uint8_t* mask, int w, int h);
+
+/* ---- data costs (calculate_data_costs.cpp:308-323) ----
+ * faces [face_begin, face_end) only (whole mesh is the occluder set);
+ * bvh_mode 0 = BVH, 1 = brute force over all triangles;
+ * n_threads <= 0 -> all cores.  Returns 0 on success, 1/2 for the
+ * "Exeeded maximal number of faces/views" guards (:315-318). */
+int orc_data_costs(const orc_mesh* mesh, const orc_view* views, uint32_t n_views,
+                   const orc_settings* settings, uint32_t face_begin, uint32_t face_end,
+                   int bvh_mode, int n_threads, orc_csr* out, orc_dc_stats* stats);
+void orc_csr_free(orc_csr* csr);
+
+/* ---- single (vertex, view) any-hit ray: calculate_data_costs.cpp:200-209 ---- */
+typedef struct orc_bvh orc_bvh;
+orc_bvh* orc_bvh_build(const orc_mesh* mesh);
+void orc_bvh_free(orc_bvh* b);
+int orc_ray_occluded(const orc_bvh* b, const orc_mesh* mesh, const float origin[3],
+                     const float view_pos[3], int brute);
+
+/* ---- histogram (histogram.cpp:22-63) ---- */
+float orc_percentile(const float* values, uint64_t n, float max_value, float percentile);
+
+/* ---- MRF view selection (view_selection.cpp:18-133; solver DEFINED HERE) ---- */
+typedef struct {
+    int32_t max_sweeps;      /* hard cap on message-passing sweeps */
+    int32_t min_sweeps;
+    int32_t window;          /* StopWhenReturnsDiminish(5, 0.01): window ...   (view_selection.cpp:84) */
+    float min_improvement;   /* ... and relative improvement                                            */
+    float damping;           /* message damping alpha in [0,1) */
+    float rho;               /* edge appearance probability (1 = max-product BP, <1 = tree-reweighted) */
+    int32_t icm_iters;       /* monotone ICM polish iterations after decoding */
+} orc_mrf_params;
+
+typedef struct {
+    uint64_t energy_fixed;   /* sum_i fix32(D_i(l_i)) + 2^32 * #cut edges */
+    double energy;           /* energy_fixed / 2^32 */
+    uint64_t cut_edges;
+    uint32_t sweeps;
+    uint32_t icm_iters;
+    uint32_t unseen;         /* faces with label 0 (view_selection.cpp:129,132) */
+    double t_setup, t_solve;
+} orc_mrf_stats;
+
+void orc_mrf_default_params(orc_mrf_params* p);
+/* experiments: per-sweep energies of the decoded labeling are written to buf[0..len) */
+void orc_mrf_set_trace(uint64_t* buf, int len);
+int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
+                       const orc_mrf_params* params, int n_threads, uint32_t* labels,
+                       orc_mrf_stats* stats);
+/* E(l) = sum_i D_i(l_i) + sum_{(i,j) in E'} [l_i != l_j]  (SURVEY.md 3.3), fixed point 32.32;
+ * returns UINT64_MAX if some label is not in its face's column (the
+ * "Incorrect labeling" contract of view_selection.cpp:125-128 and
+ * generate_texture_patches.cpp:105-109). */
+uint64_t orc_energy(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
+                    const uint32_t* labels, uint64_t* cut_edges);
+/* plain ICM from the per-face argmin-unary labeling (energy sanity baseline) */
+int orc_icm_baseline(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
+                     int max_iters, uint32_t* labels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
