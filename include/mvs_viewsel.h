@@ -1,0 +1,241 @@
+/* mvs_viewsel.h -- C ABI of the MI355X-native view-selection hot path.
+ *
+ * Drop-in boundary for nmoehrle/mvs-texturing's
+ *     tex::calculate_data_costs   (libs/tex/texturing.h:66-69,
+ *                                  libs/tex/calculate_data_costs.cpp:308-323)
+ *     tex::postprocess_face_infos (libs/tex/texturing.h:71-74)   [folded into the above]
+ *     tex::view_selection         (libs/tex/texturing.h:79-80,
+ *                                  libs/tex/view_selection.cpp:18-133)
+ * as called from apps/texrecon/texrecon.cpp:98-127.  Plain pointers and sizes
+ * only: no MVE / STL / torch types cross this boundary.  The header-only C++
+ * adapter include/tex_viewsel.hpp re-exposes the reference's own signatures
+ * on top of these entry points; INTEGRATION.md shows the texrecon-side patch.
+ *
+ * All kernels are hand-written HIP for gfx950; there is NO CPU fallback: every
+ * entry point fails with MVS_ERR_HIP when no usable device is present.
+ */
+#ifndef MVS_VIEWSEL_H
+#define MVS_VIEWSEL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MVS_OK = 0,
+    MVS_ERR_INVALID = 1,        /* bad argument */
+    MVS_ERR_TOO_MANY_FACES = 2, /* "Exeeded maximal number of faces"  calculate_data_costs.cpp:315-316 */
+    MVS_ERR_TOO_MANY_VIEWS = 3, /* "Exeeded maximal number of views"  calculate_data_costs.cpp:317-318 */
+    MVS_ERR_LABELING = 4,       /* "Incorrect labeling"               view_selection.cpp:126-128 */
+    MVS_ERR_HIP = 5,            /* HIP runtime / device failure (see mvs_last_error) */
+    MVS_ERR_STATE = 6,          /* call order violated (e.g. view selection before data costs) */
+    MVS_ERR_UNSUPPORTED = 7
+} mvs_status;
+
+/* mve::TriangleMesh fields read at calculate_data_costs.cpp:136-138 */
+typedef struct {
+    uint32_t n_verts;
+    uint32_t n_faces;
+    const float* verts;        /* 3 * n_verts, xyz                      mesh->get_vertices()     */
+    const uint32_t* faces;     /* 3 * n_faces, vertex indices           mesh->get_faces()        */
+    const float* face_normals; /* 3 * n_faces, unit normals             mesh->get_face_normals() */
+} mvs_mesh;
+
+/* tex::TextureView fields read by the path (texture_view.h:43-48) + the decoded
+ * image that TextureView::load_image() (texture_view.cpp:96-100) would hold. */
+typedef struct {
+    float pos[3];      /* TextureView::pos                      */
+    float viewdir[3];  /* TextureView::viewdir                  */
+    float K[9];        /* TextureView::projection, row major    */
+    float w2c[16];     /* TextureView::world_to_cam, row major  */
+    int32_t width;
+    int32_t height;
+    const uint8_t* rgb; /* width*height*3 interleaved RGB8 (mve::ByteImage layout) */
+} mvs_view;
+
+/* tex::Settings fields the path reads (settings.h:85,87,90; enums settings.h:59-74) */
+enum { MVS_DATA_TERM_AREA = 0, MVS_DATA_TERM_GMI = 1 };
+enum { MVS_OUTLIER_NONE = 0, MVS_OUTLIER_GAUSS_DAMPING = 1, MVS_OUTLIER_GAUSS_CLAMPING = 2 };
+typedef struct {
+    int32_t data_term;                 /* default MVS_DATA_TERM_GMI   (settings.h:85) */
+    int32_t outlier_removal;           /* default MVS_OUTLIER_NONE    (settings.h:87) */
+    int32_t geometric_visibility_test; /* default 1                   (settings.h:90) */
+} mvs_settings;
+
+/* tex::DataCosts = SparseTable<uint32_t, uint16_t, float> (texturing.h:36,
+ * sparse_table.h:29-110) as CSR over faces: column i of the table is
+ * view_id/cost[col_ptr[i] .. col_ptr[i+1]), view ids strictly ascending
+ * (calculate_data_costs.cpp:272), costs in [0,1] (:295-296). */
+typedef struct {
+    uint32_t n_faces;   /* SparseTable::cols() */
+    uint32_t n_views;   /* SparseTable::rows() */
+    uint64_t nnz;
+    uint32_t* col_ptr;  /* n_faces + 1 */
+    uint16_t* view_id;  /* nnz */
+    float* cost;        /* nnz */
+} mvs_csr;
+
+/* Solver controls.  The reference hard-codes its mapMAP configuration
+ * (view_selection.cpp:84,103-115); mapMAP is replaced by a GPU-resident
+ * tree-reweighted max-product sweep + monotone ICM polish, whose
+ * knobs are below.  mvs_mrf_default_params gives the shipped defaults. */
+typedef struct {
+    int32_t max_sweeps;
+    int32_t min_sweeps;
+    int32_t window;         /* cf. StopWhenReturnsDiminish(5, 0.01)   view_selection.cpp:84 */
+    float min_improvement;
+    float damping;
+    float rho;
+    int32_t icm_iters;
+} mvs_mrf_params;
+
+typedef struct {
+    uint64_t energy_fixed;  /* 32.32 fixed point: sum_i D_i(l_i) + #cut edges */
+    double energy;
+    uint64_t cut_edges;
+    uint32_t sweeps;
+    uint32_t icm_iters;
+    uint32_t unseen;        /* "faces have not been seen"  view_selection.cpp:129,132 */
+} mvs_mrf_stats;
+
+typedef struct {
+    uint64_t pairs;
+    uint64_t cull_backface;     /* calculate_data_costs.cpp:183-185 */
+    uint64_t cull_angle;        /* :187-188 */
+    uint64_t cull_outside;      /* :191 */
+    uint64_t cull_occluded;     /* :194-215 */
+    uint64_t cull_zero_quality; /* :222 */
+    uint64_t nnz_pre;           /* FaceProjectionInfos emitted (:227-228) */
+    uint64_t nnz;
+    uint64_t rays;              /* (vertex, view) rays traced -- each distinct ray once */
+    uint64_t ray_nodes;         /* BVH nodes fetched  (only with mvs_set_option("count_rays", 1)) */
+    uint64_t ray_tris;          /* triangles tested   (idem) */
+    float max_quality;          /* :278-281 */
+    float percentile;           /* :288 */
+} mvs_dc_stats;
+
+const char* mvs_last_error(void);
+const char* mvs_status_string(mvs_status s);
+void mvs_mrf_default_params(mvs_mrf_params* p);
+void mvs_default_settings(mvs_settings* s);
+
+/* ------------------------------------------------------------------------
+ * One-shot host entry points: what the tex:: adapter calls.  Inputs are host
+ * pointers borrowed for the duration of the call.
+ * ------------------------------------------------------------------------ */
+
+/* replaces tex::calculate_data_costs (texturing.h:66-69).  `out` is library
+ * allocated (nnz is unknown up front); release with mvs_csr_free. */
+mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views,
+                          const mvs_settings* settings, mvs_csr* out, mvs_dc_stats* stats);
+void mvs_csr_free(mvs_csr* csr);
+
+/* replaces tex::view_selection (texturing.h:79-80).  adj_ptr/adj: UniGraph
+ * adjacency lists (uni_graph.h:22) flattened in list order; labels_out[F] is
+ * caller allocated and receives UniGraph::labels (0 = unseen, else view+1). */
+mvs_status mvs_view_selection(const mvs_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
+                              const mvs_mrf_params* params, uint32_t* labels_out,
+                              mvs_mrf_stats* stats);
+
+/* File-level boundary against an UNMODIFIED texrecon (-D / -L flags):
+ * SparseTable::save_to_file (sparse_table.h:112-136) and
+ * vector_to_file<std::size_t> (util.h:104-113, texrecon.cpp:130-136). */
+mvs_status mvs_write_spt(const mvs_csr* csr, const char* path);
+mvs_status mvs_read_spt(const char* path, mvs_csr* out);
+mvs_status mvs_write_labeling_vec(const uint32_t* labels, uint32_t n_faces, const char* path);
+
+/* ------------------------------------------------------------------------
+ * Resident (context) API: inputs live in HBM across calls; used by bench.py,
+ * the GPU tests and the multi-GPU driver.  Pointers flagged *_on_device are
+ * device pointers owned by the caller (e.g. torch tensors) and must stay
+ * alive while the context uses them.
+ * ------------------------------------------------------------------------ */
+typedef struct mvs_ctx mvs_ctx;
+
+mvs_status mvs_ctx_create(int device, mvs_ctx** out);
+void mvs_ctx_destroy(mvs_ctx* ctx);
+/* hipStream_t to launch on (NULL = the context's own stream) */
+mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
+mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
+/* integer options: "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1) */
+mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
+
+mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device);
+/* views: HOST array of n structs; their rgb pointers are device pointers iff rgb_on_device */
+mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device);
+/* restrict the data-cost computation to faces [begin, end) (multi-GPU sharding);
+ * the whole mesh stays the occluder set.  Default: all faces. */
+mvs_status mvs_scene_set_face_range(mvs_ctx* ctx, uint32_t begin, uint32_t end);
+
+/* tex::calculate_data_costs on the resident scene; result stays on the device. */
+mvs_status mvs_ctx_data_costs(mvs_ctx* ctx, const mvs_settings* settings, mvs_dc_stats* stats);
+/* The same, split at the global barrier of postprocess_face_infos
+ * (calculate_data_costs.cpp:278-288) so that a multi-GPU driver can all-reduce
+ * the maximum quality and the 10000-bin histogram between the phases:
+ *   phase1: everything up to the per-face sorted infos + local max quality
+ *   phase2: histogram of local qualities against the (global) max
+ *   phase3: percentile from the (globally summed) histogram + cost write   */
+mvs_status mvs_ctx_dc_phase1(mvs_ctx* ctx, const mvs_settings* settings);
+/* copy the local max quality (1 float) to / from a caller-owned DEVICE buffer, stream-ordered */
+mvs_status mvs_ctx_dc_get_max(mvs_ctx* ctx, float* dst_device);
+mvs_status mvs_ctx_dc_set_max(mvs_ctx* ctx, const float* src_device);
+mvs_status mvs_ctx_dc_phase2(mvs_ctx* ctx);
+/* the same for the histogram: MVS_HIST_WORDS u32 = 10000 bins + [10000] = number of values */
+#define MVS_HIST_WORDS 10001
+mvs_status mvs_ctx_dc_get_histogram(mvs_ctx* ctx, uint32_t* dst_device);
+mvs_status mvs_ctx_dc_set_histogram(mvs_ctx* ctx, const uint32_t* src_device);
+mvs_status mvs_ctx_dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
+
+/* device-resident result of the last data-cost call (faces of the face range, local indices) */
+mvs_status mvs_ctx_costs_device(mvs_ctx* ctx, mvs_csr* device_view);
+/* copy it to freshly malloc'ed host arrays (release with mvs_csr_free); with
+ * quality_out != NULL also returns the un-normalised qualities (malloc'ed, nnz floats) */
+mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* host_out, float** quality_out);
+/* replace the resident costs by caller-provided ones (host or device pointers) */
+mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device);
+
+/* tex::view_selection on the resident costs.  adjacency: host or device pointers.
+ * labels_out (n_faces u32) may be a host or a device pointer (labels_on_device). */
+mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj,
+                                  int adj_on_device, const mvs_mrf_params* params,
+                                  uint32_t* labels_out, int labels_on_device, mvs_mrf_stats* stats);
+
+/* copy the resident costs into caller-owned DEVICE arrays (stream-ordered):
+ * counts[n_faces] = column lengths, view_id[nnz], cost[nnz] -- the pieces a multi-GPU
+ * driver all-gathers into the global table */
+mvs_status mvs_ctx_costs_export(mvs_ctx* ctx, uint32_t* counts_device, uint16_t* view_id_device, float* cost_device);
+
+/* ---- multi-GPU MRF building blocks (one context per rank; DESIGN.md "Multi-GPU") ----
+ * Every rank holds the FULL cost table and adjacency (288 GB of HBM make the
+ * metadata cheap to replicate) and owns a contiguous node range.  The sweep is
+ * synchronous (Jacobi), so a node's update depends only on the previous sweep:
+ * results are bit-identical for any partition.  One sweep on rank r:
+ *   mrf_sweep(own range) -> mrf_gather(MSG | SEL, boundary index lists) ->
+ *   RCCL all-to-all by the driver -> mrf_scatter -> mrf_energy(own range) ->
+ *   all-reduce of the two u64.  The index lists are planned on the host from
+ * col_ptr + adjacency alone (mvs-texturing_amd/multigpu.py). */
+enum { MVS_MRF_MSG = 0, MVS_MRF_SEL = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_SEL = 3 };
+mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
+                             const mvs_mrf_params* params);
+/* one sweep over nodes [node_begin, node_end): reads the current messages, writes the next ones, flips */
+mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
+/* dst[k] = array[idx[k]] / array[idx[k]] = src[k]; 4-byte elements; MSG = the buffer the last sweep wrote */
+mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, void* dst_device);
+mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, const void* src_device);
+/* partial energy (32.32 fixed point) + cut count of labeling SEL or BEST_SEL over own nodes -> dst_device[2] */
+mvs_status mvs_ctx_mrf_energy(mvs_ctx* ctx, int which_sel, uint32_t node_begin, uint32_t node_end, uint64_t* dst_device);
+/* BEST_SEL[all] = SEL[all] (call on every rank when the all-reduced energy improved) */
+mvs_status mvs_ctx_mrf_keep_best(mvs_ctx* ctx);
+/* ICM on BEST_SEL: gains of own nodes; then (after the GAIN halo exchange) apply in place */
+mvs_status mvs_ctx_mrf_icm_gain(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
+mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* moved_device);
+/* labels (view_selection.cpp:120-132) of own nodes from BEST_SEL into labels_device[node_end - node_begin] */
+mvs_status mvs_ctx_mrf_labels(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* labels_device,
+                              uint32_t* unseen_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_VIEWSEL_H */

@@ -1,0 +1,441 @@
+// api.hip -- the C ABI of include/mvs_viewsel.h: context management, the
+// host-pointer drop-ins for tex::calculate_data_costs / tex::view_selection,
+// the solver's host loop and the .spt / .vec writers.
+#include "ctx.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace mvs {
+void dc_phase1(mvs_ctx* ctx, const mvs_settings* st);
+void dc_phase2(mvs_ctx* ctx);
+void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
+void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
+void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_energy(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
+void mrf_icm_gain(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
+void mrf_icm_apply(mvs_ctx* ctx, const uint32_t* sel, uint32_t* nsel, uint32_t nb0, uint32_t ne0);
+void mrf_argmin_unary(mvs_ctx* ctx, uint32_t* sel);
+void mrf_labels(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+}  // namespace mvs
+
+using namespace mvs;
+
+static thread_local std::string g_last_error;
+
+static mvs_status fail(mvs_status st, const std::string& msg) { g_last_error = msg; return st; }
+namespace mvs { mvs_status api_fail(mvs_status st, const std::string& msg) { return fail(st, msg); } }
+
+#define MVS_API_BEGIN try {
+#define MVS_API_END                                                          \
+    } catch (const StatusError& e) { return fail(e.st, e.what()); }          \
+      catch (const HipError& e) { return fail(MVS_ERR_HIP, e.what()); }      \
+      catch (const std::exception& e) { return fail(MVS_ERR_HIP, e.what()); } \
+    return MVS_OK;
+
+static float compute_cos_limit() {
+    const float c = host_cos_limit();  // dmath.h
+    if (!(c == c)) throw StatusError(MVS_ERR_UNSUPPORTED, "host acosf is not monotone around cos(75 deg)");
+    return c;
+}
+
+namespace mvs {
+void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device) {
+    const size_t F = ctx->csr_faces;
+    if (on_device) { ctx->r_adj_ptr = adj_ptr; ctx->r_adj = adj; return; }
+    const size_t E = adj_ptr[F];
+    ctx->m_adj_ptr.ensure(F + 2); ctx->m_adj.ensure(E + 1);
+    MVS_HIP(hipMemcpyAsync(ctx->m_adj_ptr.p, adj_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (E) MVS_HIP(hipMemcpyAsync(ctx->m_adj.p, adj, E * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->r_adj_ptr = ctx->m_adj_ptr.p; ctx->r_adj = ctx->m_adj.p;
+}
+}  // namespace mvs
+
+extern "C" {
+
+const char* mvs_last_error(void) { return g_last_error.c_str(); }
+
+const char* mvs_status_string(mvs_status s) {
+    switch (s) {
+        case MVS_OK: return "ok";
+        case MVS_ERR_INVALID: return "invalid argument";
+        case MVS_ERR_TOO_MANY_FACES: return "Exeeded maximal number of faces";
+        case MVS_ERR_TOO_MANY_VIEWS: return "Exeeded maximal number of views";
+        case MVS_ERR_LABELING: return "Incorrect labeling";
+        case MVS_ERR_HIP: return "HIP error";
+        case MVS_ERR_STATE: return "invalid call order";
+        case MVS_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "?";
+}
+
+void mvs_mrf_default_params(mvs_mrf_params* p) {
+    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 10; p->min_improvement = 0.002f;
+    p->damping = 0.3f; p->rho = 0.8f; p->icm_iters = 50;
+}
+void mvs_default_settings(mvs_settings* s) {  /* settings.h:85-90 */
+    s->data_term = MVS_DATA_TERM_GMI; s->outlier_removal = MVS_OUTLIER_NONE; s->geometric_visibility_test = 1;
+}
+
+mvs_status mvs_ctx_create(int device, mvs_ctx** out) {
+    if (!out) return fail(MVS_ERR_INVALID, "out is null");
+    *out = nullptr;
+    MVS_API_BEGIN
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw HipError("no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) throw StatusError(MVS_ERR_INVALID, "bad device index");
+    MVS_HIP(hipSetDevice(device));
+    mvs_ctx* c = new mvs_ctx;
+    c->device = device;
+    MVS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    c->cos_limit = compute_cos_limit();
+    c->counters.ensure(64);
+    *out = c;
+    MVS_API_END
+}
+
+void mvs_ctx_destroy(mvs_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto* b : ctx->own_rgb) delete b;
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(MVS_ERR_INVALID, "ctx is null");
+    MVS_API_BEGIN
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) MVS_HIP(hipStreamDestroy(ctx->stream));
+    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+    else { MVS_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_synchronize(mvs_ctx* ctx) {
+    if (!ctx) return fail(MVS_ERR_INVALID, "ctx is null");
+    MVS_API_BEGIN
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    MVS_API_END
+}
+
+mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return fail(MVS_ERR_INVALID, "null argument");
+    const std::string n(name);
+    if (n == "count_rays") ctx->count_rays = value != 0;
+    else if (n == "lds_bvh_levels") ctx->lds_bvh_levels = (int)value;
+    else if (n == "verbose") ctx->verbose = value != 0;
+    else return fail(MVS_ERR_INVALID, "unknown option " + n);
+    return MVS_OK;
+}
+
+mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device) {
+    if (!ctx || !mesh || !mesh->verts || !mesh->faces || !mesh->face_normals) return fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    const size_t NV = mesh->n_verts, F = mesh->n_faces;
+    if (on_device) {
+        ctx->d_verts = mesh->verts; ctx->d_faces = mesh->faces; ctx->d_normals = mesh->face_normals;
+    } else {
+        ctx->own_verts.ensure(3 * NV + 4); ctx->own_faces.ensure(3 * F + 4); ctx->own_normals.ensure(3 * F + 4);
+        MVS_HIP(hipMemcpyAsync(ctx->own_verts.p, mesh->verts, 3 * NV * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        MVS_HIP(hipMemcpyAsync(ctx->own_faces.p, mesh->faces, 3 * F * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        MVS_HIP(hipMemcpyAsync(ctx->own_normals.p, mesh->face_normals, 3 * F * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->d_verts = ctx->own_verts.p; ctx->d_faces = ctx->own_faces.p; ctx->d_normals = ctx->own_normals.p;
+    }
+    ctx->n_verts = mesh->n_verts; ctx->n_faces = mesh->n_faces;
+    ctx->face_begin = 0; ctx->face_end = mesh->n_faces;
+    ctx->have_costs = false; ctx->dc_phase = 0;
+    MVS_API_END
+}
+
+mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device) {
+    if (!ctx || (!views && n_views)) return fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    for (auto* b : ctx->own_rgb) delete b;
+    ctx->own_rgb.clear();
+    ctx->h_views.assign(n_views, ViewParams{});
+    for (uint32_t j = 0; j < n_views; ++j) {
+        const mvs_view& v = views[j];
+        if (v.width < 2 || v.height < 2 || !v.rgb) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image");
+        ViewParams& p = ctx->h_views[j];
+        memcpy(p.pos, v.pos, sizeof(p.pos)); memcpy(p.viewdir, v.viewdir, sizeof(p.viewdir));
+        memcpy(p.K, v.K, sizeof(p.K)); memcpy(p.w2c, v.w2c, sizeof(p.w2c));
+        p.width = v.width; p.height = v.height;
+        if (rgb_on_device) p.rgb = v.rgb;
+        else {
+            auto* b = new DBuf<uint8_t>();
+            ctx->own_rgb.push_back(b);
+            const size_t bytes = (size_t)v.width * v.height * 3;
+            b->ensure(bytes + 16);
+            MVS_HIP(hipMemcpyAsync(b->p, v.rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+            p.rgb = b->p;
+        }
+    }
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_views = n_views;
+    ctx->have_costs = false; ctx->dc_phase = 0;
+    MVS_API_END
+}
+
+mvs_status mvs_scene_set_face_range(mvs_ctx* ctx, uint32_t begin, uint32_t end) {
+    if (!ctx) return fail(MVS_ERR_INVALID, "ctx is null");
+    if (begin > end || end > ctx->n_faces) return fail(MVS_ERR_INVALID, "bad face range");
+    ctx->face_begin = begin; ctx->face_end = end;
+    ctx->have_costs = false; ctx->dc_phase = 0;
+    return MVS_OK;
+}
+
+mvs_status mvs_ctx_dc_phase1(mvs_ctx* ctx, const mvs_settings* settings) {
+    if (!ctx || !settings) return fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    dc_phase1(ctx, settings);
+    MVS_API_END
+}
+mvs_status mvs_ctx_dc_phase2(mvs_ctx* ctx) {
+    if (!ctx) return fail(MVS_ERR_INVALID, "ctx is null");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    dc_phase2(ctx);
+    MVS_API_END
+}
+mvs_status mvs_ctx_dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
+    if (!ctx) return fail(MVS_ERR_INVALID, "ctx is null");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    dc_phase3(ctx, stats);
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_data_costs(mvs_ctx* ctx, const mvs_settings* settings, mvs_dc_stats* stats) {
+    if (!ctx || !settings) return fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    dc_phase1(ctx, settings);
+    dc_phase2(ctx);
+    dc_phase3(ctx, stats);
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_costs_device(mvs_ctx* ctx, mvs_csr* v) {
+    if (!ctx || !v) return fail(MVS_ERR_INVALID, "null argument");
+    if (!ctx->have_costs) return fail(MVS_ERR_STATE, "no data costs on the device");
+    v->n_faces = ctx->csr_faces; v->n_views = ctx->csr_views; v->nnz = ctx->csr_nnz;
+    v->col_ptr = const_cast<uint32_t*>(ctx->r_ptr); v->view_id = const_cast<uint16_t*>(ctx->r_view); v->cost = const_cast<float*>(ctx->r_cost);
+    return MVS_OK;
+}
+
+mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* out, float** quality_out) {
+    if (!ctx || !out) return fail(MVS_ERR_INVALID, "null argument");
+    if (!ctx->have_costs) return fail(MVS_ERR_STATE, "no data costs on the device");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    const size_t F = ctx->csr_faces, nnz = ctx->csr_nnz;
+    out->n_faces = ctx->csr_faces; out->n_views = ctx->csr_views; out->nnz = nnz;
+    out->col_ptr = (uint32_t*)malloc((F + 1) * sizeof(uint32_t));
+    out->view_id = (uint16_t*)malloc((nnz + 1) * sizeof(uint16_t));
+    out->cost = (float*)malloc((nnz + 1) * sizeof(float));
+    MVS_HIP(hipMemcpyAsync(out->col_ptr, ctx->r_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (nnz) {
+        MVS_HIP(hipMemcpyAsync(out->view_id, ctx->r_view, nnz * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(hipMemcpyAsync(out->cost, ctx->r_cost, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (quality_out) {
+        *quality_out = (float*)malloc((nnz + 1) * sizeof(float));
+        if (nnz && ctx->r_cost == ctx->csr_cost.p)
+            MVS_HIP(hipMemcpyAsync(*quality_out, ctx->csr_q.p, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    MVS_API_END
+}
+
+void mvs_csr_free(mvs_csr* csr) {
+    if (!csr) return;
+    free(csr->col_ptr); free(csr->view_id); free(csr->cost);
+    memset(csr, 0, sizeof(*csr));
+}
+
+mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device) {
+    if (!ctx || !csr || !csr->col_ptr) return fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    const size_t F = csr->n_faces, nnz = csr->nnz;
+    if (on_device) {
+        ctx->r_ptr = csr->col_ptr; ctx->r_view = csr->view_id; ctx->r_cost = csr->cost;
+    } else {
+        ctx->csr_ptr.ensure(F + 2); ctx->csr_view.ensure(nnz + 1); ctx->csr_cost.ensure(nnz + 1);
+        MVS_HIP(hipMemcpyAsync(ctx->csr_ptr.p, csr->col_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (nnz) {
+            MVS_HIP(hipMemcpyAsync(ctx->csr_view.p, csr->view_id, nnz * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+            MVS_HIP(hipMemcpyAsync(ctx->csr_cost.p, csr->cost, nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        }
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p;
+    }
+    ctx->csr_faces = csr->n_faces; ctx->csr_views = csr->n_views; ctx->csr_nnz = nnz;
+    ctx->have_costs = true;
+    MVS_API_END
+}
+
+
+static void read_energy(mvs_ctx* ctx, uint64_t out[2]) {
+    unsigned long long h[2];
+    MVS_HIP(hipMemcpyAsync(h, ctx->m_energy.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    out[0] = h[0]; out[1] = h[1];
+}
+
+// The solver's host loop (single GPU): sweeps with exact-energy tracking, the
+// stop rule mirroring StopWhenReturnsDiminish (view_selection.cpp:84), ICM polish.
+mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
+                                  const mvs_mrf_params* params, uint32_t* labels_out, int labels_on_device, mvs_mrf_stats* stats) {
+    if (!ctx || !adj_ptr || !adj || !labels_out) return fail(MVS_ERR_INVALID, "null argument");
+    if (!ctx->have_costs) return fail(MVS_ERR_STATE, "view selection needs data costs (mvs_ctx_data_costs or mvs_ctx_costs_upload)");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
+    const uint32_t F = ctx->csr_faces;
+    set_adjacency(ctx, adj_ptr, adj, adj_on_device);
+    mrf_setup(ctx, &P);
+    hipStream_t s = ctx->stream;
+    mvs_mrf_stats S; memset(&S, 0, sizeof(S));
+    uint64_t best_e = ~0ull;
+    std::vector<uint64_t> hist; hist.push_back(~0ull);
+    int sw = 1;
+    for (; sw <= P.max_sweeps; ++sw) {
+        mrf_sweep(ctx, 0, F);
+        mrf_energy(ctx, ctx->m_sel.p, 0, F);
+        uint64_t e[2]; read_energy(ctx, e);
+        if (e[0] < best_e) {
+            best_e = e[0];
+            MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        }
+        hist.push_back(best_e);
+        if (ctx->verbose) fprintf(stderr, "[mvs] sweep %d energy %.3f best %.3f\n", sw, (double)e[0] / 4294967296.0, (double)best_e / 4294967296.0);
+        if (sw >= P.min_sweeps && sw > P.window) {
+            const uint64_t prev = hist[sw - P.window];
+            if ((double)(prev - best_e) < (double)P.min_improvement * (double)prev) break;
+        }
+    }
+    S.sweeps = (uint32_t)std::min(sw, P.max_sweeps);
+    if (P.max_sweeps <= 0) { S.sweeps = 0; mrf_argmin_unary(ctx, ctx->m_best_sel.p); }
+    uint32_t* cur = ctx->m_best_sel.p;
+    int it = 0;
+    for (; it < P.icm_iters; ++it) {
+        mrf_icm_gain(ctx, cur, 0, F);
+        mrf_icm_apply(ctx, cur, cur, 0, F);  // in place: apply reads only the neighbours' gains
+        uint32_t moved = 0;
+        MVS_HIP(hipMemcpyAsync(&moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        if (moved == 0) break;
+    }
+    S.icm_iters = (uint32_t)it;
+    mrf_energy(ctx, cur, 0, F);
+    uint64_t e[2]; read_energy(ctx, e);
+    S.energy_fixed = e[0]; S.energy = (double)e[0] / 4294967296.0; S.cut_edges = e[1];
+    uint32_t* d_labels = labels_on_device ? labels_out : ctx->m_cand.p;
+    uint32_t bu[2];
+    mrf_labels(ctx, cur, 0, F, d_labels, bu);
+    S.unseen = bu[1];
+    if (bu[0]) throw StatusError(MVS_ERR_LABELING, "Incorrect labeling");  /* view_selection.cpp:126-128 */
+    if (!labels_on_device && F) {
+        MVS_HIP(hipMemcpyAsync(labels_out, d_labels, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+    }
+    if (stats) *stats = S;
+    MVS_API_END
+}
+
+// ---------------- one-shot host drop-ins ----------------
+mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_settings* settings,
+                          mvs_csr* out, mvs_dc_stats* stats) {
+    if (!mesh || !views || !settings || !out) return fail(MVS_ERR_INVALID, "null argument");
+    /* calculate_data_costs.cpp:315-318 */
+    if (n_views > 65535u) return fail(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");
+    mvs_ctx* ctx = nullptr;
+    mvs_status st = mvs_ctx_create(0, &ctx);
+    if (st != MVS_OK) return st;
+    st = mvs_scene_set_mesh(ctx, mesh, 0);
+    if (st == MVS_OK) st = mvs_scene_set_views(ctx, views, n_views, 0);
+    if (st == MVS_OK) st = mvs_ctx_data_costs(ctx, settings, stats);
+    if (st == MVS_OK) st = mvs_ctx_costs_download(ctx, out, nullptr);
+    mvs_ctx_destroy(ctx);
+    return st;
+}
+
+mvs_status mvs_view_selection(const mvs_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj, const mvs_mrf_params* params,
+                              uint32_t* labels_out, mvs_mrf_stats* stats) {
+    if (!costs || !adj_ptr || !adj || !labels_out) return fail(MVS_ERR_INVALID, "null argument");
+    mvs_ctx* ctx = nullptr;
+    mvs_status st = mvs_ctx_create(0, &ctx);
+    if (st != MVS_OK) return st;
+    st = mvs_ctx_costs_upload(ctx, costs, 0);
+    if (st == MVS_OK) st = mvs_ctx_view_selection(ctx, adj_ptr, adj, 0, params, labels_out, 0, stats);
+    mvs_ctx_destroy(ctx);
+    return st;
+}
+
+// ---------------- file-level boundary ----------------
+/* SparseTable::save_to_file (sparse_table.h:112-136): "SPT 0.2 <cols> <rows> <nnz>\n" then
+ * nnz records {u32 col; u16 row; f32 value}, column by column */
+mvs_status mvs_write_spt(const mvs_csr* csr, const char* path) {
+    if (!csr || !path) return fail(MVS_ERR_INVALID, "null argument");
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(MVS_ERR_INVALID, std::string("cannot open ") + path);
+    fprintf(f, "SPT 0.2 %u %u %llu\n", csr->n_faces, csr->n_views, (unsigned long long)csr->nnz);
+    for (uint32_t col = 0; col < csr->n_faces; ++col)
+        for (uint32_t k = csr->col_ptr[col]; k < csr->col_ptr[col + 1]; ++k) {
+            fwrite(&col, sizeof(uint32_t), 1, f); fwrite(&csr->view_id[k], sizeof(uint16_t), 1, f); fwrite(&csr->cost[k], sizeof(float), 1, f);
+        }
+    fclose(f);
+    return MVS_OK;
+}
+
+/* SparseTable::load_from_file (sparse_table.h:138-187) */
+mvs_status mvs_read_spt(const char* path, mvs_csr* out) {
+    if (!path || !out) return fail(MVS_ERR_INVALID, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(MVS_ERR_INVALID, std::string("cannot open ") + path);
+    char header[16] = {0}, version[16] = {0};
+    unsigned cols = 0, rows = 0; unsigned long long nnz = 0;
+    if (fscanf(f, "%15s %15s %u %u %llu", header, version, &cols, &rows, &nnz) != 5 || strcmp(header, "SPT") != 0) { fclose(f); return fail(MVS_ERR_INVALID, "Not a SparseTable file!"); }
+    if (strcmp(version, "0.2") != 0) { fclose(f); return fail(MVS_ERR_INVALID, "Incompatible version of SparseTable file!"); }
+    int ch; while ((ch = fgetc(f)) != EOF && ch != '\n') {}
+    out->n_faces = cols; out->n_views = rows; out->nnz = nnz;
+    out->col_ptr = (uint32_t*)calloc((size_t)cols + 1, sizeof(uint32_t));
+    out->view_id = (uint16_t*)malloc((nnz + 1) * sizeof(uint16_t));
+    out->cost = (float*)malloc((nnz + 1) * sizeof(float));
+    uint32_t prev = 0;
+    for (unsigned long long i = 0; i < nnz; ++i) {
+        uint32_t col; uint16_t row; float v;
+        if (fread(&col, 4, 1, f) != 1 || fread(&row, 2, 1, f) != 1 || fread(&v, 4, 1, f) != 1 || col >= cols || col < prev) { fclose(f); mvs_csr_free(out); return fail(MVS_ERR_INVALID, "corrupt SparseTable file"); }
+        prev = col;
+        out->col_ptr[col + 1]++; out->view_id[i] = row; out->cost[i] = v;
+    }
+    for (uint32_t c = 0; c < cols; ++c) out->col_ptr[c + 1] += out->col_ptr[c];
+    fclose(f);
+    return MVS_OK;
+}
+
+/* vector_to_file<std::size_t> (util.h:104-113) as used at texrecon.cpp:130-136 */
+mvs_status mvs_write_labeling_vec(const uint32_t* labels, uint32_t n_faces, const char* path) {
+    if (!labels || !path) return fail(MVS_ERR_INVALID, "null argument");
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(MVS_ERR_INVALID, std::string("cannot open ") + path);
+    for (uint32_t i = 0; i < n_faces; ++i) { const uint64_t v = labels[i]; fwrite(&v, sizeof(uint64_t), 1, f); }
+    fclose(f);
+    return MVS_OK;
+}
+
+// ---------------- multi-GPU MRF building blocks: see mgpu.hip ----------------
+
+}  // extern "C"

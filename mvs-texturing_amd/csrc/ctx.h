@@ -1,0 +1,142 @@
+// ctx.h -- context object, device buffers and launch helpers (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mvs_viewsel.h"
+#include "dmath.h"
+
+namespace mvs {
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string& m) : std::runtime_error(m) {}
+};
+struct StatusError : std::runtime_error {
+    mvs_status st;
+    StatusError(mvs_status s, const std::string& m) : std::runtime_error(m), st(s) {}
+};
+
+#define MVS_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            throw mvs::HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +     \
+                                __FILE__ + ":" + std::to_string(__LINE__) + ")");              \
+    } while (0)
+
+#define MVS_LAUNCH_CHECK() MVS_HIP(hipGetLastError())
+
+// Growable device buffer; capacity persists across calls so that a steady-state
+// step performs no hipMalloc.
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) MVS_HIP(hipFree(p));
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        MVS_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+        cap = want;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    ~DBuf() { release(); }
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+};
+
+// ---- implicit 4-ary BVH over Morton-sorted triangles (k_bvh.hip) ----
+struct alignas(128) Node4 {
+    float lo[3][4];
+    float hi[3][4];
+    uint32_t nchild;
+    uint32_t pad_[7];
+};
+static_assert(sizeof(Node4) == 128, "Node4 must be one 128-byte line");
+
+struct BvhDev {
+    const Node4* nodes;       // all levels, level L at nodes + level_off[L]
+    const float4* tris;       // 3 float4 per triangle: a, e1 = b - a, e2 = c - a  (Morton order, zero padded)
+    uint32_t level_off[16];
+    uint32_t level_cnt[16];
+    int32_t top;              // index of the root level (level_cnt[top] == 1)
+    uint32_t n_leaves;
+};
+
+struct MrfEdge {      // per directed edge e = (i <- j) in adjacency-CSR order
+    uint32_t in_off;  // offset of the message INTO i over e (K_i floats, aligned with i's labels)
+    uint32_t out_off; // offset of the message i sends over e, i.e. in_off of the reverse edge (K_j floats)
+    uint32_t kj;      // K_j if the edge is valid (both columns non-empty), else 0
+};
+
+}  // namespace mvs
+
+struct mvs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool verbose = false;
+    bool count_rays = false;
+    int lds_bvh_levels = 0;
+    float cos_limit = 0.0f;  // see dmath.h cull_pair
+
+    // ---- scene ----
+    uint32_t n_verts = 0, n_faces = 0, n_views = 0;
+    uint32_t face_begin = 0, face_end = 0;
+    const float* d_verts = nullptr; const uint32_t* d_faces = nullptr; const float* d_normals = nullptr;
+    mvs::DBuf<float> own_verts, own_normals; mvs::DBuf<uint32_t> own_faces;
+    std::vector<mvs::ViewParams> h_views;
+    mvs::DBuf<mvs::ViewParams> d_views;
+    std::vector<mvs::DBuf<uint8_t>*> own_rgb;
+    mvs::DBuf<uint8_t> gmi_all;      // all views' gradient-magnitude planes
+    mvs::DBuf<uint32_t> mask_all;    // all views' bit-packed validity masks
+    mvs::DBuf<uint32_t> mask_zero, mask_tmp;
+    std::vector<size_t> gmi_off, mask_off;
+    mvs::DBuf<size_t> view_off;
+    bool mesh_dirty = true, views_dirty = true;
+
+    // ---- BVH + incidence ----
+    mvs::DBuf<mvs::Node4> bvh_nodes; mvs::DBuf<float4> bvh_tris;
+    mvs::DBuf<uint32_t> morton_k, morton_k2, morton_v, morton_v2; mvs::DBuf<char> sort_tmp;
+    mvs::DBuf<float> lvl_box_a, lvl_box_b; mvs::DBuf<float> scene_box;
+    mvs::BvhDev bvh{};
+    mvs::DBuf<uint32_t> vf_ptr, vf_cursor, vf;
+
+    // ---- data costs work buffers ----
+    mvs::DBuf<unsigned long long> pass_bits, need_bits, occl_bits, surv_bits;
+    mvs::DBuf<uint32_t> pass_base;      // exclusive scan of popc(pass words)
+    mvs::DBuf<float> pq;                // quality per passing pair
+    mvs::DBuf<float> pcol;              // 3 floats per passing pair (outlier removal only)
+    mvs::DBuf<uint32_t> face_cnt, scan_tmp;
+    mvs::DBuf<unsigned long long> counters;  // see k_dc.hip
+    mvs::DBuf<float> max_q; mvs::DBuf<uint32_t> hist; mvs::DBuf<float> pctl;
+    // pre-outlier CSR (only when outlier removal is on)
+    mvs::DBuf<uint32_t> pre_ptr; mvs::DBuf<uint16_t> pre_view; mvs::DBuf<float> pre_q; mvs::DBuf<float> pre_col;
+    mvs::DBuf<uint8_t> pre_inl;
+    // result CSR
+    mvs::DBuf<uint32_t> csr_ptr; mvs::DBuf<uint16_t> csr_view; mvs::DBuf<float> csr_cost; mvs::DBuf<float> csr_q;
+    uint32_t csr_faces = 0, csr_views = 0; uint64_t csr_nnz = 0;
+    const uint32_t* r_ptr = nullptr; const uint16_t* r_view = nullptr; const float* r_cost = nullptr;  // active CSR
+    bool have_costs = false;
+    mvs_settings dc_settings{}; mvs_dc_stats dc_stats{}; int dc_phase = 0;
+
+    // ---- MRF ----
+    mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
+    mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
+    mvs::DBuf<float> m_msg_a, m_msg_b; mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
+    mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved;
+    uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0; bool m_flip = false;
+    mvs_mrf_params m_params{};
+};
+
+namespace mvs {
+// generic device exclusive scan (scan.hip): out[i] = sum_{k<i} in[i]; returns total via d_total (device, may be null)
+void exclusive_scan_u32(mvs_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* d_total);
+}  // namespace mvs

@@ -1,0 +1,324 @@
+// dmath.h -- per-(face, view) arithmetic of the data-cost path as
+// __host__ __device__ inline functions, shared by the HIP kernels.
+//
+// Each function states the reference lines it implements.  The float operation
+// order is part of the contract (the library is compiled with
+// -ffp-contract=off and correctly rounded fp32 divide / sqrt), so that results
+// are bit-identical to a scalar IEEE-754 evaluation of the same expressions.
+// The header also compiles as plain host C++ (MVS_HD empty) for the CPU-side
+// unit test of the kernels' arithmetic (csrc/dmath_host.cpp).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define MVS_HD __host__ __device__ __forceinline__
+#else
+#define MVS_HD inline
+#endif
+
+namespace mvs {
+
+struct V3 { float x, y, z; };
+struct V2 { float x, y; };
+
+MVS_HD V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+MVS_HD V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+MVS_HD V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+MVS_HD float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+MVS_HD float norm(V3 a) { return sqrtf(dot(a, a)); }
+MVS_HD V3 normalized(V3 a) { return a / norm(a); }
+MVS_HD V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// std::min / std::max semantics (matter only for NaN / signed zero)
+MVS_HD float smin(float a, float b) { return (b < a) ? b : a; }
+MVS_HD float smax(float a, float b) { return (a < b) ? b : a; }
+MVS_HD int imin(int a, int b) { return (b < a) ? b : a; }
+
+// Device-side mirror of the TextureView fields read by the path
+// (libs/tex/texture_view.h:43-48) plus the per-view derived images.
+struct ViewParams {
+    float pos[3];
+    float viewdir[3];
+    float K[9];
+    float w2c[12];  // first three rows of world_to_cam
+    int32_t width, height;
+    int32_t mask_stride;        // 32-bit words per mask row
+    int32_t pad_;
+    const uint8_t* rgb;         // width*height*3
+    const uint8_t* gmi;         // width*height (gradient magnitude), may be null
+    const uint32_t* mask;       // bit-packed validity mask, rows padded to 32-bit words
+};
+
+// TextureView::get_pixel_coords  (texture_view.h:161-166)
+MVS_HD V2 pixel_coords(const ViewParams& v, V3 p) {
+    const float* m = v.w2c;
+    const float c0 = ((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + 1.0f * m[3];
+    const float c1 = ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + 1.0f * m[7];
+    const float c2 = ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + 1.0f * m[11];
+    const float* k = v.K;
+    const float q0 = (k[0] * c0 + k[1] * c1) + k[2] * c2;
+    const float q1 = (k[3] * c0 + k[4] * c1) + k[5] * c2;
+    const float q2 = (k[6] * c0 + k[7] * c1) + k[8] * c2;
+    return {q0 / q2 - 0.5f, q1 / q2 - 0.5f};
+}
+
+MVS_HD bool mask_bit(const ViewParams& v, int x, int y) {
+    return (v.mask[(size_t)y * v.mask_stride + (x >> 5)] >> (x & 31)) & 1u;
+}
+
+// TextureView::valid_pixel  (texture_view.cpp:253-281)
+MVS_HD bool valid_pixel(const ViewParams& v, V2 px) {
+    const int width = v.width, height = v.height;
+    const float x = px.x, y = px.y;
+    bool valid = (x >= 0.0f && x < (float)(width - 1) && y >= 0.0f && y < (float)(height - 1));
+    if (valid && v.mask) {
+        const float cx = smax(0.0f, smin((float)(width - 1), x));
+        const float cy = smax(0.0f, smin((float)(height - 1), y));
+        const int floor_x = (int)cx, floor_y = (int)cy;
+        const int floor_xp1 = imin(floor_x + 1, width - 1), floor_yp1 = imin(floor_y + 1, height - 1);
+        valid = mask_bit(v, floor_x, floor_y) && mask_bit(v, floor_x, floor_yp1) &&
+                mask_bit(v, floor_xp1, floor_y) && mask_bit(v, floor_xp1, floor_yp1);
+    }
+    return valid;
+}
+
+// Culling tests of calculate_face_projection_infos (calculate_data_costs.cpp:171-191).
+// Returns 0 = passes, 1 = backface / behind camera (:183-185), 2 = angle (:187-188),
+// 3 = projects outside the valid image area (:191).
+// cos_limit replaces `std::acos(viewing_angle) > MATH_DEG2RAD(75.0f)`: it is the
+// smallest float c with !(acosf(c) > 75 deg), found on the host with the host's
+// acosf, so `viewing_angle < cos_limit` decides identically (acosf is monotone).
+MVS_HD int cull_pair(const ViewParams& v, V3 v1, V3 v2, V3 v3, V3 face_normal, float cos_limit) {
+    const V3 view_pos = {v.pos[0], v.pos[1], v.pos[2]};
+    const V3 viewing_direction = {v.viewdir[0], v.viewdir[1], v.viewdir[2]};
+    const V3 face_center = ((v1 + v2) + v3) / 3.0f;
+    const V3 view_to_face_vec = normalized(face_center - view_pos);
+    const V3 face_to_view_vec = normalized(view_pos - face_center);
+    const float viewing_angle = dot(face_to_view_vec, face_normal);
+    if (viewing_angle < 0.0f || dot(viewing_direction, view_to_face_vec) < 0.0f) return 1;
+    if (viewing_angle < cos_limit) return 2;
+    if (!(valid_pixel(v, pixel_coords(v, v1)) && valid_pixel(v, pixel_coords(v, v2)) &&
+          valid_pixel(v, pixel_coords(v, v3)))) return 3;
+    return 0;
+}
+
+// Visibility ray of calculate_data_costs.cpp:200-206: origin = vertex,
+// dir = normalised (view_pos - origin), tmax = |view_pos - origin|, tmin = 1e-4 tmax.
+// `pad` is the scene-scale slack of the hit predicate (see ray_tri).
+struct Ray { V3 o, d; float tmin, tmax, pad; };
+MVS_HD Ray make_ray(V3 origin, V3 view_pos, float pad) {
+    Ray r;
+    r.o = origin;
+    V3 dir = view_pos - origin;
+    r.tmax = norm(dir);
+    r.tmin = r.tmax * 0.0001f;
+    r.d = dir / norm(dir);
+    r.pad = pad;
+    return r;
+}
+// pad = 1e-5 * max(scene extent, largest |coordinate|) + 1e-30 (scene box = exact min/max of the vertices)
+MVS_HD float scene_pad(const float lo[3], const float hi[3]) {
+    float ext = 0.0f, mag = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        ext = fmaxf(ext, hi[a] - lo[a]);
+        mag = fmaxf(mag, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+    }
+    return 1e-5f * fmaxf(ext, mag) + 1e-30f;
+}
+
+// Ray / triangle any-hit test on a triangle given as {a, e1 = b - a, e2 = c - a}.
+// rayint (acc::BVHTree, calculate_data_costs.cpp:23,144,209) is not available and
+// the reference only uses the boolean, so the predicate is defined by this
+// library (DESIGN.md "Occlusion rays"): Moeller-Trumbore in fp32 with this exact
+// operation order, no barycentric slack, t in [tmin, tmax], AND the computed hit
+// point o + t d must lie inside the triangle's bounding box grown by `pad`.
+// The last clause makes box culling provably conservative (a grazing ray whose
+// rounded barycentrics are accepted although it misses the triangle's box is
+// rejected by every implementation alike), so the OR over all triangles does not
+// depend on the acceleration structure.
+MVS_HD bool ray_tri(const Ray& r, V3 a, V3 e1, V3 e2) {
+    const V3 pv = cross(r.d, e2);
+    const float det = dot(e1, pv);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const V3 tv = r.o - a;
+    const float u = dot(tv, pv) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const V3 qv = cross(tv, e1);
+    const float v = dot(r.d, qv) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    const float t = dot(e2, qv) * inv;
+    if (!(t >= r.tmin && t <= r.tmax)) return false;
+    const V3 b = a + e1, c = a + e2;
+    const float hx = r.o.x + t * r.d.x, hy = r.o.y + t * r.d.y, hz = r.o.z + t * r.d.z;
+    return hx >= fminf(a.x, fminf(b.x, c.x)) - r.pad && hx <= fmaxf(a.x, fmaxf(b.x, c.x)) + r.pad &&
+           hy >= fminf(a.y, fminf(b.y, c.y)) - r.pad && hy <= fmaxf(a.y, fmaxf(b.y, c.y)) + r.pad &&
+           hz >= fminf(a.z, fminf(b.z, c.z)) - r.pad && hz <= fmaxf(a.z, fmaxf(b.z, c.z)) + r.pad;
+}
+
+// mve::Image<uint8_t>::linear_at as used at texture_view.cpp:226-229,240-243
+// (MVE is not available: clamp, bilinear weights w0*w2, w1*w2, w0*w3, w1*w3,
+// round with +0.5f -- DESIGN.md "MVE semantics").
+MVS_HD uint8_t linear_at(const uint8_t* img, int w, int h, int chans, float x, float y, int c) {
+    x = smax(0.0f, smin((float)(w - 1), x));
+    y = smax(0.0f, smin((float)(h - 1), y));
+    const int floor_x = (int)x, floor_y = (int)y;
+    const int floor_xp1 = imin(floor_x + 1, w - 1), floor_yp1 = imin(floor_y + 1, h - 1);
+    const float w1 = x - (float)floor_x, w0 = 1.0f - w1;
+    const float w3 = y - (float)floor_y, w2 = 1.0f - w3;
+    const int rowstride = w * chans;
+    const size_t row1 = (size_t)floor_y * rowstride, row2 = (size_t)floor_yp1 * rowstride;
+    const int col1 = floor_x * chans, col2 = floor_xp1 * chans;
+    const float v1 = img[row1 + col1 + c], v2 = img[row1 + col2 + c];
+    const float v3 = img[row2 + col1 + c], v4 = img[row2 + col2 + c];
+    return (uint8_t)(((v1 * (w0 * w2) + v2 * (w1 * w2)) + v3 * (w0 * w3)) + v4 * (w1 * w3) + 0.5f);
+}
+
+struct FaceInfoOut { float quality; float mean_color[3]; };
+
+// TextureView::get_face_info (texture_view.cpp:134-251) with Tri (tri.cpp:12-24,
+// tri.h:58-84).  One sequential scan-line walk per (face, view): the fp64
+// accumulation order is the reference's, which is what makes qualities bit-exact.
+// DATA_TERM: 0 = area, 1 = gmi; OUTLIER: colours are accumulated iff true.
+template <int DATA_TERM, bool OUTLIER>
+MVS_HD void face_info(const ViewParams& view, V3 v1, V3 v2, V3 v3, FaceInfoOut* out) {
+    V2 p1 = pixel_coords(view, v1), p2 = pixel_coords(view, v2), p3 = pixel_coords(view, v3);
+    const V2 t1 = p1, t2 = p2, t3 = p3;  // Tri keeps the unsorted points
+    const float T0 = t1.x - t3.x, T1 = t2.x - t3.x, T2 = t1.y - t3.y, T3 = t2.y - t3.y;
+    const float detT = T0 * T3 - T2 * T1;
+    const float aabb_min_x = smin(t1.x, smin(t2.x, t3.x)), aabb_min_y = smin(t1.y, smin(t2.y, t3.y));
+    const float aabb_max_x = smax(t1.x, smax(t2.x, t3.x)), aabb_max_y = smax(t1.y, smax(t2.y, t3.y));
+    const float ux = t2.x - t1.x, uy = t2.y - t1.y, vx = t3.x - t1.x, vy = t3.y - t1.y;
+    const float area = 0.5f * fabsf(ux * vy - uy * vx);
+    out->quality = 0.0f;
+    out->mean_color[0] = out->mean_color[1] = out->mean_color[2] = 0.0f;
+    if (area < FLT_EPSILON) return;
+
+    uint32_t num_samples = 0;
+    double col0 = 0.0, col1 = 0.0, col2 = 0.0, gmi = 0.0;
+    const int w = view.width, h = view.height;
+    const uint8_t* image = view.rgb;
+    const uint8_t* gimg = view.gmi;
+    const bool sampling_necessary = (DATA_TERM != 0) || OUTLIER;
+
+    if (sampling_necessary && area > 0.5f) {
+        // sort by ascending y (texture_view.cpp:163-167)
+        while (true) {
+            if (p1.y <= p2.y) {
+                if (p2.y <= p3.y) break;
+                V2 t = p2; p2 = p3; p3 = t;
+            } else { V2 t = p1; p1 = p2; p2 = t; }
+        }
+        const float m1 = (p1.y - p3.y) / (p1.x - p3.x), b1 = p1.y - m1 * p1.x;
+        const float m2 = (p1.y - p2.y) / (p1.x - p2.x), b2 = p1.y - m2 * p1.x;
+        const float m3 = (p2.y - p3.y) / (p2.x - p3.x), b3 = p2.y - m3 * p2.x;
+        const bool fast = isfinite(m1) && m2 != 0.0f && isfinite(m2) && m3 != 0.0f && isfinite(m3);
+        const float y_end = ceilf(aabb_max_y);
+        for (int y = (int)floorf(aabb_min_y); (float)y < y_end; ++y) {
+            float min_x = aabb_min_x - 0.5f, max_x = aabb_max_x + 0.5f;
+            const float cy = (float)y + 0.5f;
+            if (fast) {
+                min_x = (cy - b1) / m1;
+                if (cy <= p2.y) max_x = (cy - b2) / m2;
+                else max_x = (cy - b3) / m3;
+                if (min_x >= max_x) { float t = min_x; min_x = max_x; max_x = t; }
+                if (min_x < aabb_min_x || min_x > aabb_max_x) continue;
+                if (max_x < aabb_min_x || max_x > aabb_max_x) continue;
+            }
+            const float x_end = ceilf(max_x - 0.5f);
+            for (int x = (int)floorf(min_x + 0.5f); (float)x < x_end; ++x) {
+                if (!fast) {  // Tri::inside (tri.h:58-77)
+                    const float cx = (float)x + 0.5f;
+                    const float dx = cx - t3.x, dy = cy - t3.y;
+                    const float alpha = ((t2.y - t3.y) * dx + (t3.x - t2.x) * dy) / detT;
+                    if (alpha < 0.0f || alpha > 1.0f) continue;
+                    const float beta = ((t3.y - t1.y) * dx + (t1.x - t3.x) * dy) / detT;
+                    if (beta < 0.0f || beta > 1.0f) continue;
+                    if (alpha + beta > 1.0f) continue;
+                }
+                const size_t pix = (size_t)x + (size_t)y * w;
+                if (OUTLIER) {
+                    col0 += (double)image[pix * 3 + 0] / 255.0;
+                    col1 += (double)image[pix * 3 + 1] / 255.0;
+                    col2 += (double)image[pix * 3 + 2] / 255.0;
+                }
+                if (DATA_TERM == 1) gmi += (double)gimg[pix] / 255.0;
+                ++num_samples;
+            }
+        }
+    }
+    if (DATA_TERM == 1) {
+        if (num_samples > 0) {
+            gmi = (gmi / (double)num_samples) * (double)area;
+        } else {
+            const double g1 = (double)linear_at(gimg, w, h, 1, p1.x, p1.y, 0) / 255.0;
+            const double g2 = (double)linear_at(gimg, w, h, 1, p2.x, p2.y, 0) / 255.0;
+            const double g3 = (double)linear_at(gimg, w, h, 1, p3.x, p3.y, 0) / 255.0;
+            gmi = (((g1 + g2) + g3) / 3.0) * (double)area;
+        }
+    }
+    if (OUTLIER) {
+        if (num_samples > 0) {
+            out->mean_color[0] = (float)(col0 / (double)num_samples);
+            out->mean_color[1] = (float)(col1 / (double)num_samples);
+            out->mean_color[2] = (float)(col2 / (double)num_samples);
+        } else {
+            for (int i = 0; i < 3; ++i) {
+                const double c1 = (double)linear_at(image, w, h, 3, p1.x, p1.y, i) / 255.0;
+                const double c2 = (double)linear_at(image, w, h, 3, p2.x, p2.y, i) / 255.0;
+                const double c3 = (double)linear_at(image, w, h, 3, p3.x, p3.y, i) / 255.0;
+                out->mean_color[i] = (float)(((c1 + c2) + c3) / 3.0);
+            }
+        }
+    }
+    out->quality = (DATA_TERM == 0) ? area : (float)gmi;
+}
+
+// mve::image::color_rgb_to_ycbcr<float> as applied at calculate_data_costs.cpp:225
+MVS_HD void rgb_to_ycbcr(float* v) {
+    const float r = v[0], g = v[1], b = v[2];
+    v[0] = r * 0.299f + g * 0.587f + b * 0.114f;
+    v[1] = r * -0.168736f + g * -0.331264f + b * 0.5f + 0.5f;
+    v[2] = r * 0.5f + g * -0.418688f + b * -0.081312f + 0.5f;
+}
+
+// Luminance + Sobel of TextureView::generate_gradient_magnitude (texture_view.cpp:102-107):
+// mve::image::desaturate<uint8_t>(DESATURATE_LUMINANCE) then sobel_edge<uint8_t>
+// (MVE not available -- DESIGN.md "MVE semantics").
+MVS_HD uint8_t luminance_u8(uint8_t r, uint8_t g, uint8_t b) {
+    return (uint8_t)(0.30 * (double)r + (double)(0.59f * (float)g) + (double)(0.11f * (float)b));
+}
+// floor(min(255, sqrt(n))) for 0 <= n < 2^24, exact
+MVS_HD uint8_t isqrt_clamp255(int n) {
+    if (n >= 255 * 255) return 255;
+    int r = (int)sqrtf((float)n);
+    while (r * r > n) --r;
+    while ((r + 1) * (r + 1) <= n) ++r;
+    return (uint8_t)r;
+}
+
+// Histogram::add_value bin index (histogram.cpp:28-30) for min = 0
+MVS_HD uint32_t hist_bin(float value, float maxv, uint32_t num_bins) {
+    const float clamped = smax(0.0f, smin(maxv, value));
+    return (uint32_t)floorf(((clamped - 0.0f) / (maxv - 0.0f)) * (float)(num_bins - 1));
+}
+
+// Host-side constant for cull_pair: the smallest float c with
+// !( (double)std::acos(c) > MATH_DEG2RAD(75.0f) ) -- calculate_data_costs.cpp:187 evaluated
+// with the HOST's acosf (the one a CPU build of the reference would call).  Returns NaN if
+// acosf is not monotone around the threshold.
+inline float host_cos_limit() {
+    const double limit = 75.0f * (3.14159265358979323846264338327950288 / 180.0);
+    auto f = [](uint32_t u) { float x; memcpy(&x, &u, 4); return x; };
+    auto culled = [&](uint32_t u) { return (double)acosf(f(u)) > limit; };
+    uint32_t lo = 0x3E000000u /* 0.125: culled */, hi = 0x3F000000u /* 0.5: kept */;
+    while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (culled(mid)) lo = mid; else hi = mid; }
+    for (uint32_t k = 1; k <= 4096; ++k) if (!culled(hi - k) || culled(hi + k - 1)) return NAN;
+    return f(hi);
+}
+
+}  // namespace mvs

@@ -1,0 +1,94 @@
+// dmath_host.cpp -- TEST SHIM: compiles dmath.h (the arithmetic the HIP kernels
+// execute per (face, view) pair) as plain host C++ so that tests/ can compare
+// each function with the oracle on a machine without a GPU.  Not a code path of
+// the product: nothing in the library or the Python package calls into this file.
+#include "dmath.h"
+
+using namespace mvs;
+
+extern "C" {
+
+struct dmh_view {
+    float pos[3], viewdir[3], K[9], w2c[16];
+    int32_t width, height;
+    const uint8_t* rgb;
+    const uint8_t* gmi;
+    const uint32_t* mask;  // bit-packed, rows padded to 32-bit words, may be null
+};
+
+static ViewParams to_vp(const dmh_view* v) {
+    ViewParams p;
+    memcpy(p.pos, v->pos, sizeof(p.pos)); memcpy(p.viewdir, v->viewdir, sizeof(p.viewdir));
+    memcpy(p.K, v->K, sizeof(p.K)); memcpy(p.w2c, v->w2c, sizeof(p.w2c));
+    p.width = v->width; p.height = v->height; p.mask_stride = (v->width + 31) / 32; p.pad_ = 0;
+    p.rgb = v->rgb; p.gmi = v->gmi; p.mask = v->mask;
+    return p;
+}
+
+float dmh_cos_limit(void) { return host_cos_limit(); }
+
+// reasons[f * n_views + j] = cull_pair(...) for every (face, view)
+void dmh_cull_all(const dmh_view* views, uint32_t n_views, const float* verts, const uint32_t* faces, const float* normals,
+                  uint32_t n_faces, float cos_limit, int8_t* reasons) {
+    for (uint32_t j = 0; j < n_views; ++j) {
+        const ViewParams vp = to_vp(views + j);
+        for (uint32_t f = 0; f < n_faces; ++f) {
+            const uint32_t* fv = faces + 3 * (size_t)f;
+            const V3 v1 = {verts[3 * fv[0]], verts[3 * fv[0] + 1], verts[3 * fv[0] + 2]};
+            const V3 v2 = {verts[3 * fv[1]], verts[3 * fv[1] + 1], verts[3 * fv[1] + 2]};
+            const V3 v3 = {verts[3 * fv[2]], verts[3 * fv[2] + 1], verts[3 * fv[2] + 2]};
+            const V3 n = {normals[3 * f], normals[3 * f + 1], normals[3 * f + 2]};
+            reasons[(size_t)f * n_views + j] = (int8_t)cull_pair(vp, v1, v2, v3, n, cos_limit);
+        }
+    }
+}
+
+// quality / YCbCr mean colour of one (face, view) pair
+void dmh_face_info(const dmh_view* view, int data_term, int outlier, const float* v1, const float* v2, const float* v3,
+                   float* quality, float* ycbcr) {
+    const ViewParams vp = to_vp(view);
+    FaceInfoOut fi;
+    const V3 a = {v1[0], v1[1], v1[2]}, b = {v2[0], v2[1], v2[2]}, c = {v3[0], v3[1], v3[2]};
+    if (data_term == 1) { if (outlier) face_info<1, true>(vp, a, b, c, &fi); else face_info<1, false>(vp, a, b, c, &fi); }
+    else { if (outlier) face_info<0, true>(vp, a, b, c, &fi); else face_info<0, false>(vp, a, b, c, &fi); }
+    *quality = fi.quality;
+    if (outlier) rgb_to_ycbcr(fi.mean_color);
+    ycbcr[0] = fi.mean_color[0]; ycbcr[1] = fi.mean_color[1]; ycbcr[2] = fi.mean_color[2];
+}
+
+// brute-force any-hit of the (origin -> view_pos) visibility ray over all triangles
+int dmh_ray_any_hit(const float* verts, const uint32_t* faces, uint32_t n_faces, uint32_t n_verts, const float* origin, const float* view_pos) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t v = 0; v < n_verts; ++v)
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], verts[3 * (size_t)v + a]); hi[a] = fmaxf(hi[a], verts[3 * (size_t)v + a]); }
+    const Ray r = make_ray(V3{origin[0], origin[1], origin[2]}, V3{view_pos[0], view_pos[1], view_pos[2]}, scene_pad(lo, hi));
+    for (uint32_t f = 0; f < n_faces; ++f) {
+        const uint32_t* fv = faces + 3 * (size_t)f;
+        const V3 a = {verts[3 * fv[0]], verts[3 * fv[0] + 1], verts[3 * fv[0] + 2]};
+        const V3 b = {verts[3 * fv[1]], verts[3 * fv[1] + 1], verts[3 * fv[1] + 2]};
+        const V3 c = {verts[3 * fv[2]], verts[3 * fv[2] + 1], verts[3 * fv[2] + 2]};
+        if (ray_tri(r, a, b - a, c - a)) return 1;
+    }
+    return 0;
+}
+
+// luminance + Sobel magnitude of a whole image with the kernels' integer arithmetic
+void dmh_gradient_magnitude(const uint8_t* rgb, int w, int h, uint8_t* gmi) {
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            if (y == 0 || y == h - 1 || x == 0 || x == w - 1) { gmi[(size_t)y * w + x] = 0; continue; }
+            int l[3][3];
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const uint8_t* p = rgb + ((size_t)(y + dy) * w + (x + dx)) * 3;
+                    l[dy + 1][dx + 1] = luminance_u8(p[0], p[1], p[2]);
+                }
+            const int sx = (l[0][2] - l[0][0]) + 2 * (l[1][2] - l[1][0]) + (l[2][2] - l[2][0]);
+            const int sy = (l[2][0] - l[0][0]) + 2 * (l[2][1] - l[0][1]) + (l[2][2] - l[0][2]);
+            gmi[(size_t)y * w + x] = isqrt_clamp255(sx * sx + sy * sy);
+        }
+}
+
+uint32_t dmh_hist_bin(float value, float maxv) { return hist_bin(value, maxv, 10000u); }
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+// k_bvh.hip -- occlusion rays of calculate_face_projection_infos
+// (libs/tex/calculate_data_costs.cpp:144 BVH build, :194-215 the three
+// vertex->camera any-hit rays per (face, view)).
+//
+// rayint's acc::BVHTree is replaced by an implicit 4-ary BVH built ON THE GPU
+// over Morton-sorted triangles (no pointers: node i of level L has children
+// 4i..4i+3 of level L-1; a level-0 node's children are leaves of 4 consecutive
+// triangles).  One node = one 128-byte line holding the four child boxes.
+// Traversal is stackless: one 4-bit pending-children mask per level packed in a
+// 64-bit register.  The hit predicate (dmath.h ray_tri) is evaluated on the same
+// triangles a brute-force loop would accept, boxes are padded and the slab test
+// widened, so the boolean does not depend on the tree.
+//
+// The reference casts 3 rays per (face, view); a ray depends only on
+// (vertex, view), so each distinct ray is traced ONCE (vertices are shared by
+// ~6 faces): need bits -> ray kernel -> occluded bits, view-major bit matrices.
+#include "ctx.h"
+#include <rocprim/rocprim.hpp>
+
+namespace mvs {
+
+namespace {
+
+__device__ __forceinline__ uint32_t f2ord(float f) {  // order-preserving float -> uint
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// scene_box: 6 ordered-uint words (min xyz, max xyz), initialised to 0xFFFFFFFF x3, 0 x3
+__global__ void bbox_kernel(const float* __restrict__ verts, uint32_t n_verts, uint32_t* __restrict__ box) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_verts; v += gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) { const float x = verts[3 * (size_t)v + a]; lo[a] = fminf(lo[a], x); hi[a] = fmaxf(hi[a], x); }
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&box[a], f2ord(lo[a])); atomicMax(&box[3 + a], f2ord(hi[a])); }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void morton_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t n_faces,
+                              const uint32_t* __restrict__ box, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_faces) return;
+    float lo[3], ext[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = ord2f(box[a]); ext[a] = ord2f(box[3 + a]) - lo[a]; }
+    const uint32_t* fv = faces + 3 * (size_t)f;
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        const float c = (verts[3 * (size_t)fv[0] + a] + verts[3 * (size_t)fv[1] + a] + verts[3 * (size_t)fv[2] + a]) * (1.0f / 3.0f);
+        float t = ext[a] > 0.0f ? (c - lo[a]) / ext[a] : 0.0f;
+        t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+        q[a] = (uint32_t)t;
+    }
+    keys[f] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    vals[f] = f;
+}
+
+// triangles in Morton order as {a, e1 = b - a, e2 = c - a}; slots >= n_faces are degenerate (never hit)
+__global__ void gather_tris_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const uint32_t* __restrict__ order,
+                                   uint32_t n_faces, uint32_t n_slots, float4* __restrict__ tris) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    float4 a = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+    if (s < n_faces) {
+        const uint32_t* fv = faces + 3 * (size_t)order[s];
+        const V3 pa = {verts[3 * (size_t)fv[0]], verts[3 * (size_t)fv[0] + 1], verts[3 * (size_t)fv[0] + 2]};
+        const V3 pb = {verts[3 * (size_t)fv[1]], verts[3 * (size_t)fv[1] + 1], verts[3 * (size_t)fv[1] + 2]};
+        const V3 pc = {verts[3 * (size_t)fv[2]], verts[3 * (size_t)fv[2] + 1], verts[3 * (size_t)fv[2] + 2]};
+        const V3 d1 = pb - pa, d2 = pc - pa;
+        a = {pa.x, pa.y, pa.z, 0.0f}; e1 = {d1.x, d1.y, d1.z, 0.0f}; e2 = {d2.x, d2.y, d2.z, 0.0f};
+    }
+    tris[3 * (size_t)s] = a; tris[3 * (size_t)s + 1] = e1; tris[3 * (size_t)s + 2] = e2;
+}
+
+// level 0: node n -> child c = leaf 4n + c = triangles 16n + 4c .. +3.  Also emits the node's own box.
+__global__ void build_level0_kernel(const float4* __restrict__ tris, uint32_t n_faces, uint32_t n_leaves, uint32_t n_nodes,
+                                    const uint32_t* __restrict__ scene_box, Node4* __restrict__ nodes, float* __restrict__ own_box) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    float slo[3], shi[3];
+    for (int a = 0; a < 3; ++a) { slo[a] = ord2f(scene_box[a]); shi[a] = ord2f(scene_box[3 + a]); }
+    const float pad = scene_pad(slo, shi);
+    Node4 nd;
+    float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t nchild = 0;
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t leaf = 4 * n + c;
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {1e30f, 1e30f, 1e30f};
+        if (leaf < n_leaves) {
+            nchild = c + 1;
+            for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+            for (uint32_t t = 4 * leaf; t < 4 * leaf + 4 && t < n_faces; ++t) {
+                const float4 A = tris[3 * (size_t)t], E1 = tris[3 * (size_t)t + 1], E2 = tris[3 * (size_t)t + 2];
+                const float pa[3] = {A.x, A.y, A.z};
+                const float pb[3] = {A.x + E1.x, A.y + E1.y, A.z + E1.z};
+                const float pc[3] = {A.x + E2.x, A.y + E2.y, A.z + E2.z};
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = fminf(lo[a], fminf(pa[a], fminf(pb[a], pc[a])));
+                    hi[a] = fmaxf(hi[a], fmaxf(pa[a], fmaxf(pb[a], pc[a])));
+                }
+            }
+            // ray_tri accepts only hit points inside (triangle box + pad): 4*pad keeps the slab test conservative
+            for (int a = 0; a < 3; ++a) { lo[a] -= 4.0f * pad; hi[a] += 4.0f * pad; nlo[a] = fminf(nlo[a], lo[a]); nhi[a] = fmaxf(nhi[a], hi[a]); }
+        }
+        for (int a = 0; a < 3; ++a) { nd.lo[a][c] = lo[a]; nd.hi[a][c] = hi[a]; }
+    }
+    nd.nchild = nchild;
+    for (int k = 0; k < 7; ++k) nd.pad_[k] = 0;
+    nodes[n] = nd;
+    for (int a = 0; a < 3; ++a) { own_box[6 * (size_t)n + a] = nlo[a]; own_box[6 * (size_t)n + 3 + a] = nhi[a]; }
+}
+
+__global__ void build_level_kernel(const float* __restrict__ child_box, uint32_t n_children, uint32_t n_nodes,
+                                   Node4* __restrict__ nodes, float* __restrict__ own_box) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    Node4 nd;
+    float nlo[3] = {INFINITY, INFINITY, INFINITY}, nhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t nchild = 0;
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t ch = 4 * n + c;
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {1e30f, 1e30f, 1e30f};
+        if (ch < n_children) {
+            nchild = c + 1;
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = child_box[6 * (size_t)ch + a]; hi[a] = child_box[6 * (size_t)ch + 3 + a];
+                nlo[a] = fminf(nlo[a], lo[a]); nhi[a] = fmaxf(nhi[a], hi[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) { nd.lo[a][c] = lo[a]; nd.hi[a][c] = hi[a]; }
+    }
+    nd.nchild = nchild;
+    for (int k = 0; k < 7; ++k) nd.pad_[k] = 0;
+    nodes[n] = nd;
+    for (int a = 0; a < 3; ++a) { own_box[6 * (size_t)n + a] = nlo[a]; own_box[6 * (size_t)n + 3 + a] = nhi[a]; }
+}
+
+// ---- vertex -> incident faces (for the need bits) ----
+__global__ void vf_count_kernel(const uint32_t* __restrict__ faces, uint32_t n_faces, uint32_t* __restrict__ deg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_faces) return;
+    atomicAdd(&deg[faces[i]], 1u);
+}
+__global__ void vf_fill_kernel(const uint32_t* __restrict__ faces, uint32_t n_faces, const uint32_t* __restrict__ vf_ptr,
+                               uint32_t* __restrict__ cursor, uint32_t* __restrict__ vf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_faces) return;
+    const uint32_t v = faces[i];
+    const uint32_t k = atomicAdd(&cursor[v], 1u);
+    vf[vf_ptr[v] + k] = i / 3;  // order within a vertex is irrelevant: only OR-ed
+}
+
+// ---- traversal ----
+__device__ __forceinline__ uint32_t node_hits(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1) {
+    // 6 x 16-byte loads of one 128-byte line
+    const float4* p = reinterpret_cast<const float4*>(nd);
+    const float4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5];
+    const uint32_t nchild = nd->nchild;
+    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
+    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float ta = (lox[c] - o.x) * inv.x, tb = (hix[c] - o.x) * inv.x;
+        float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
+        ta = (loy[c] - o.y) * inv.y; tb = (hiy[c] - o.y) * inv.y;
+        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+        ta = (loz[c] - o.z) * inv.z; tb = (hiz[c] - o.z) * inv.z;
+        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+        if (tn <= tf) m |= 1u << c;
+    }
+    return m & ((1u << nchild) - 1u);
+}
+
+__device__ __forceinline__ bool tri_pre_hit(const float4* __restrict__ tris, uint32_t t, const Ray& r) {
+    const float4 A = tris[3 * (size_t)t], E1 = tris[3 * (size_t)t + 1], E2 = tris[3 * (size_t)t + 2];
+    return ray_tri(r, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z});
+}
+
+__device__ __forceinline__ float pad_from_box(const uint32_t* __restrict__ box) {
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = ord2f(box[a]); hi[a] = ord2f(box[3 + a]); }
+    return scene_pad(lo, hi);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit(const BvhDev& bvh, const Ray& r, uint32_t& n_nodes, uint32_t& n_tris) {
+    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
+    int level = bvh.top;
+    uint32_t node = 0;
+    unsigned long long masks = (unsigned long long)node_hits(bvh.nodes + bvh.level_off[level], r.o, inv, t0, t1) << (4 * level);
+    if (COUNT) n_nodes++;
+    while (true) {
+        const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
+        if (m == 0) {
+            if (level == bvh.top) return false;
+            ++level; node >>= 2;
+            continue;
+        }
+        const int c = __builtin_ctz(m);
+        masks &= ~(1ull << (4 * level + c));
+        const uint32_t child = node * 4 + c;
+        if (level == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (COUNT) n_tris++;
+                if (tri_pre_hit(bvh.tris, child * 4 + k, r)) return true;
+            }
+        } else {
+            --level; node = child;
+            masks |= (unsigned long long)node_hits(bvh.nodes + bvh.level_off[level] + node, r.o, inv, t0, t1) << (4 * level);
+            if (COUNT) n_nodes++;
+        }
+    }
+}
+
+// one wave per (view, 64-vertex word); lanes whose need bit is clear idle
+template <bool COUNT>
+__global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float* __restrict__ verts, const ViewParams* __restrict__ views,
+                                                  const unsigned long long* __restrict__ need, unsigned long long* __restrict__ occl,
+                                                  uint32_t vwords, uint32_t n_verts, uint32_t n_views, const uint32_t* __restrict__ scene_box,
+                                                  unsigned long long* __restrict__ counters) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= (uint64_t)vwords * n_views) return;
+    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
+    const unsigned long long word = need[(size_t)j * vwords + vw];
+    if (word == 0ull) return;  // occl is pre-zeroed
+    const uint32_t v = vw * 64 + lane;
+    bool hit = false;
+    uint32_t nn = 0, nt = 0;
+    if (((word >> lane) & 1ull) && v < n_verts) {
+        const ViewParams& vp = views[j];
+        const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
+        const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad_from_box(scene_box));
+        hit = any_hit<COUNT>(bvh, r, nn, nt);
+    }
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) occl[(size_t)j * vwords + vw] = b;
+    if (COUNT) {
+        for (int o = 32; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, 64); nt += __shfl_xor(nt, o, 64); }
+        if (lane == 0) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
+    }
+}
+
+}  // namespace
+
+// Builds the BVH and the vertex->face incidence for the resident mesh.
+void build_bvh(mvs_ctx* ctx) {
+    const uint32_t F = ctx->n_faces, NV = ctx->n_verts;
+    hipStream_t s = ctx->stream;
+    const uint32_t n_leaves = (F + 3) / 4;
+    const uint32_t n_slots = ((n_leaves + 3) / 4) * 16;  // triangles padded to whole level-0 nodes
+    ctx->scene_box.ensure(8);
+    uint32_t* box = (uint32_t*)ctx->scene_box.p;
+    const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 2048u)), dim3(256), 0, s, ctx->d_verts, NV, box);
+    MVS_LAUNCH_CHECK();
+    ctx->morton_k.ensure(F); ctx->morton_k2.ensure(F); ctx->morton_v.ensure(F); ctx->morton_v2.ensure(F);
+    hipLaunchKernelGGL(morton_kernel, dim3((F + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, F, box, ctx->morton_k.p, ctx->morton_v.p);
+    MVS_LAUNCH_CHECK();
+    size_t tmp_bytes = 0;
+    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->morton_v2.p, F, 0, 30, s));
+    ctx->sort_tmp.ensure(tmp_bytes + 16);
+    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->morton_v2.p, F, 0, 30, s));
+    ctx->bvh_tris.ensure(3 * (size_t)n_slots);
+    hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->morton_v2.p, F, n_slots, ctx->bvh_tris.p);
+    MVS_LAUNCH_CHECK();
+    // level sizes
+    BvhDev b{};
+    uint32_t cnt = (n_leaves + 3) / 4, off = 0; int L = 0;
+    while (true) {
+        if (L >= 16) throw HipError("BVH too deep");
+        b.level_off[L] = off; b.level_cnt[L] = cnt; off += cnt;
+        if (cnt == 1) break;
+        cnt = (cnt + 3) / 4; ++L;
+    }
+    b.top = L; b.n_leaves = n_leaves;
+    ctx->bvh_nodes.ensure(off);
+    ctx->lvl_box_a.ensure(6 * (size_t)b.level_cnt[0]); ctx->lvl_box_b.ensure(6 * (size_t)std::max<uint32_t>(b.level_cnt[L > 0 ? 1 : 0], 1u));
+    hipLaunchKernelGGL(build_level0_kernel, dim3((b.level_cnt[0] + 127) / 128), dim3(128), 0, s, ctx->bvh_tris.p, F, n_leaves, b.level_cnt[0], box, ctx->bvh_nodes.p, ctx->lvl_box_a.p);
+    MVS_LAUNCH_CHECK();
+    float* cur = ctx->lvl_box_a.p; float* nxt = ctx->lvl_box_b.p;
+    for (int l = 1; l <= L; ++l) {
+        hipLaunchKernelGGL(build_level_kernel, dim3((b.level_cnt[l] + 127) / 128), dim3(128), 0, s, cur, b.level_cnt[l - 1], b.level_cnt[l], ctx->bvh_nodes.p + b.level_off[l], nxt);
+        MVS_LAUNCH_CHECK();
+        std::swap(cur, nxt);
+    }
+    b.nodes = ctx->bvh_nodes.p; b.tris = ctx->bvh_tris.p;
+    ctx->bvh = b;
+    // vertex -> faces
+    ctx->vf_ptr.ensure((size_t)NV + 1); ctx->vf_cursor.ensure((size_t)NV + 1); ctx->vf.ensure(3 * (size_t)F);
+    MVS_HIP(hipMemsetAsync(ctx->vf_cursor.p, 0, ((size_t)NV + 1) * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(vf_count_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, s, ctx->d_faces, F, ctx->vf_cursor.p);
+    MVS_LAUNCH_CHECK();
+    exclusive_scan_u32(ctx, ctx->vf_cursor.p, ctx->vf_ptr.p, (size_t)NV + 1, nullptr);
+    MVS_HIP(hipMemsetAsync(ctx->vf_cursor.p, 0, ((size_t)NV + 1) * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(vf_fill_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, s, ctx->d_faces, F, ctx->vf_ptr.p, ctx->vf_cursor.p, ctx->vf.p);
+    MVS_LAUNCH_CHECK();
+}
+
+void trace_rays(mvs_ctx* ctx) {
+    const uint32_t vwords = (ctx->n_verts + 63) / 64;
+    const uint64_t waves = (uint64_t)vwords * ctx->n_views;
+    const uint64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
+    if (ctx->count_rays)
+        hipLaunchKernelGGL(ray_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->d_views.p,
+                           ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p);
+    else
+        hipLaunchKernelGGL(ray_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->d_views.p,
+                           ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p);
+    MVS_LAUNCH_CHECK();
+}
+
+}  // namespace mvs

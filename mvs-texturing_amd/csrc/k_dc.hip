@@ -1,0 +1,522 @@
+// k_dc.hip -- tex::calculate_data_costs on the GPU
+// (libs/tex/calculate_data_costs.cpp:131-306).
+//
+// The reference walks view-by-view over all faces (:148-229) and scatters the
+// survivors into per-face vectors under a critical section (:241-249).  Here:
+//   cull_kernel       one thread per (face, view): culls of :171-191, 64 faces x 1 view per wave,
+//                     result = one ballot word in a view-major bit matrix (no atomics);
+//   need_kernel       which (vertex, view) rays are needed (OR over incident faces);
+//   [k_bvh.hip]       each distinct ray once -> occluded bits;
+//   info_kernel       get_face_info (:220) for the visible pairs, qualities written at the
+//                     pair's rank among the pass bits (coalesced);
+//   count/write       transposition view-major -> CSR by face (ascending view id = the
+//                     std::sort of :272);
+//   outlier_kernel    photometric_outlier_detection (:35-129) per face, fp64 in registers;
+//   max / histogram / percentile / cost  = postprocess_face_infos (:278-302).
+#include "ctx.h"
+
+namespace mvs {
+
+void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const size_t* d_mask_off);
+void build_bvh(mvs_ctx* ctx);
+void trace_rays(mvs_ctx* ctx);
+
+namespace {
+
+constexpr int VIEW_CHUNK = 32;
+constexpr uint32_t HIST_BINS = 10000;  // calculate_data_costs.cpp:283
+
+enum { C_BACK = 0, C_ANGLE = 1, C_OUTSIDE = 2, C_OCCL = 3, C_ZEROQ = 4, C_SURV = 5, C_RAYS = 6, C_PASS = 7, C_RNODES = 8, C_RTRIS = 9 };
+
+__device__ __forceinline__ V3 ld3(const float* __restrict__ p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- culls (calculate_data_costs.cpp:171-191) ----
+__global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const float* __restrict__ normals,
+                                                   const ViewParams* __restrict__ views, uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords,
+                                                   float cos_limit, unsigned long long* __restrict__ pass, unsigned long long* __restrict__ counters) {
+    const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
+    if ((lf >> 6) >= fwords) return;  // whole wave beyond the face range
+    const bool act = lf < nf;
+    const size_t f = (size_t)fb + (act ? lf : 0);
+    const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const V3 v1 = ld3(verts, i0), v2 = ld3(verts, i1), v3 = ld3(verts, i2), nrm = ld3(normals, f);
+    const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
+    const int lane = threadIdx.x & 63;
+    uint32_t c_back = 0, c_angle = 0, c_out = 0, c_pass = 0;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const int reason = act ? cull_pair(views[j], v1, v2, v3, nrm, cos_limit) : -1;
+        c_back += reason == 1; c_angle += reason == 2; c_out += reason == 3; c_pass += reason == 0;
+        const unsigned long long b = __ballot(reason == 0);
+        if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
+    }
+    c_back = wave_sum(c_back); c_angle = wave_sum(c_angle); c_out = wave_sum(c_out); c_pass = wave_sum(c_pass);
+    if (lane == 0) {
+        atomicAdd(&counters[C_BACK], (unsigned long long)c_back); atomicAdd(&counters[C_ANGLE], (unsigned long long)c_angle);
+        atomicAdd(&counters[C_OUTSIDE], (unsigned long long)c_out); atomicAdd(&counters[C_PASS], (unsigned long long)c_pass);
+    }
+}
+
+// ---- which (vertex, view) rays are needed: OR of the pass bits of the incident faces ----
+__global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, uint32_t n_verts, uint32_t n_views,
+                                                   uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
+                                                   const unsigned long long* __restrict__ pass, unsigned long long* __restrict__ need,
+                                                   unsigned long long* __restrict__ counters) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if ((v >> 6) >= vwords) return;  // whole wave beyond the vertex range
+    const bool act = v < n_verts;
+    const uint32_t p0 = act ? vf_ptr[v] : 0, p1 = act ? vf_ptr[v + 1] : 0;
+    const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
+    const int lane = threadIdx.x & 63;
+    uint32_t acc = 0;  // bit jj: some incident face passed for view j0 + jj
+    for (uint32_t p = p0; p < p1; ++p) {
+        const uint32_t lf = vf[p] - fb;  // wraps for faces below the range
+        if (lf >= nf) continue;
+        for (uint32_t j = j0; j < j1; ++j)
+            acc |= (uint32_t)((pass[(size_t)j * fwords + (lf >> 6)] >> (lf & 63)) & 1ull) << (j - j0);
+    }
+    uint32_t n_rays = 0;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const unsigned long long b = __ballot((acc >> (j - j0)) & 1u);
+        if (lane == 0) { need[(size_t)j * vwords + (v >> 6)] = b; n_rays += __popcll(b); }
+    }
+    if (lane == 0 && n_rays) atomicAdd(&counters[C_RAYS], (unsigned long long)n_rays);
+}
+
+__global__ void popc_kernel(const unsigned long long* __restrict__ words, uint32_t* __restrict__ cnt, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = (uint32_t)__popcll(words[i]);
+}
+
+// ---- get_face_info for the visible pairs (calculate_data_costs.cpp:194-228) ----
+template <int DATA_TERM, bool OUTLIER, bool VISTEST>
+__global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
+                                                   uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
+                                                   const unsigned long long* __restrict__ pass, const unsigned long long* __restrict__ occl,
+                                                   const uint32_t* __restrict__ pass_base, float* __restrict__ pq, float* __restrict__ pcol,
+                                                   unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters) {
+    const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
+    if ((lf >> 6) >= fwords) return;  // whole wave beyond the face range
+    const bool act = lf < nf;
+    const size_t f = (size_t)fb + (act ? lf : 0);
+    const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const V3 v1 = ld3(verts, i0), v2 = ld3(verts, i1), v3 = ld3(verts, i2);
+    const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t c_occ = 0, c_zero = 0, c_surv = 0;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const size_t widx = (size_t)j * fwords + (lf >> 6);
+        const unsigned long long word = pass[widx];  // wave-uniform
+        if (word == 0ull) { if (lane == 0) surv[widx] = 0ull; continue; }
+        bool keep = false;
+        if ((word >> lane) & 1ull) {
+            bool visible = true;
+            if (VISTEST) {
+                const unsigned long long* o = occl + (size_t)j * vwords;
+                visible = !(((o[i0 >> 6] >> (i0 & 63)) | (o[i1 >> 6] >> (i1 & 63)) | (o[i2 >> 6] >> (i2 & 63))) & 1ull);
+            }
+            FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
+            if (visible) {
+                face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi);
+                if (fi.quality == 0.0f) ++c_zero; else { keep = true; ++c_surv; }
+            } else ++c_occ;
+            const size_t r = (size_t)pass_base[widx] + __popcll(word & lt);
+            pq[r] = fi.quality;
+            if (OUTLIER) {
+                rgb_to_ycbcr(fi.mean_color);  // :225
+                pcol[3 * r] = fi.mean_color[0]; pcol[3 * r + 1] = fi.mean_color[1]; pcol[3 * r + 2] = fi.mean_color[2];
+            }
+        }
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) surv[widx] = b;
+    }
+    c_occ = wave_sum(c_occ); c_zero = wave_sum(c_zero); c_surv = wave_sum(c_surv);
+    if (lane == 0) {
+        atomicAdd(&counters[C_OCCL], (unsigned long long)c_occ); atomicAdd(&counters[C_ZEROQ], (unsigned long long)c_zero);
+        atomicAdd(&counters[C_SURV], (unsigned long long)c_surv);
+    }
+}
+
+// ---- view-major bits -> CSR by face ----
+__global__ void __launch_bounds__(256) csr_count_kernel(const unsigned long long* __restrict__ surv, uint32_t n_views, uint32_t nf, uint32_t fwords,
+                                                        uint32_t* __restrict__ cnt) {
+    const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
+    if ((lf >> 6) >= fwords) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t c = 0;
+    for (uint32_t j = 0; j < n_views; ++j) c += (uint32_t)((surv[(size_t)j * fwords + (lf >> 6)] >> lane) & 1ull);
+    if (lf < nf) cnt[lf] = c;
+    if (lf == 0) cnt[nf] = 0;  // sentinel so that the scan of nf + 1 entries yields col_ptr[nf] = nnz
+}
+
+template <bool OUTLIER>
+__global__ void __launch_bounds__(256) csr_write_kernel(const unsigned long long* __restrict__ surv, const unsigned long long* __restrict__ pass,
+                                                        const uint32_t* __restrict__ pass_base, const float* __restrict__ pq, const float* __restrict__ pcol,
+                                                        uint32_t n_views, uint32_t nf, uint32_t fwords, const uint32_t* __restrict__ col_ptr,
+                                                        uint16_t* __restrict__ view_id, float* __restrict__ quality, float* __restrict__ color) {
+    const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
+    if ((lf >> 6) >= fwords) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    size_t k = (lf < nf) ? col_ptr[lf] : 0;
+    for (uint32_t j = 0; j < n_views; ++j) {
+        const size_t widx = (size_t)j * fwords + (lf >> 6);
+        const unsigned long long s = surv[widx];
+        if (!((s >> lane) & 1ull)) continue;
+        const size_t r = (size_t)pass_base[widx] + __popcll(pass[widx] & lt);
+        view_id[k] = (uint16_t)j;
+        quality[k] = pq[r];
+        if (OUTLIER) { color[3 * k] = pcol[3 * r]; color[3 * k + 1] = pcol[3 * r + 1]; color[3 * k + 2] = pcol[3 * r + 2]; }
+        ++k;
+    }
+}
+
+// ---- photometric_outlier_detection (calculate_data_costs.cpp:35-129) ----
+// One thread per face, fp64.  Row order = the reference's single-thread order:
+// descending view id, i.e. the CSR run walked backwards.
+// Eigen's FullPivLU is replaced by a plain full-pivoting 3x3 LU with Eigen's
+// rank rule |pivot| > eps * 3 * |max pivot|; inverse = solve(I).
+struct Lu3 {
+    double lu[3][3]; int p[3], q[3]; double maxpivot; int nonzero;
+    __device__ explicit Lu3(const double m[3][3]) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lu[i][j] = m[i][j];
+        for (int i = 0; i < 3; ++i) { p[i] = i; q[i] = i; }
+        maxpivot = 0.0; nonzero = 3;
+        for (int k = 0; k < 3; ++k) {
+            int br = k, bc = k; double big = -1.0;
+            for (int c = k; c < 3; ++c) for (int r = k; r < 3; ++r)
+                if (fabs(lu[r][c]) > big) { big = fabs(lu[r][c]); br = r; bc = c; }
+            if (big == 0.0) { nonzero = k; break; }
+            if (big > maxpivot) maxpivot = big;
+            if (br != k) { for (int c = 0; c < 3; ++c) { double t = lu[k][c]; lu[k][c] = lu[br][c]; lu[br][c] = t; } int t = p[k]; p[k] = p[br]; p[br] = t; }
+            if (bc != k) { for (int r = 0; r < 3; ++r) { double t = lu[r][k]; lu[r][k] = lu[r][bc]; lu[r][bc] = t; } int t = q[k]; q[k] = q[bc]; q[bc] = t; }
+            for (int r = k + 1; r < 3; ++r) lu[r][k] /= lu[k][k];
+            for (int r = k + 1; r < 3; ++r) for (int c = k + 1; c < 3; ++c) lu[r][c] -= lu[r][k] * lu[k][c];
+        }
+    }
+    __device__ bool invertible() const {
+        const double thr = fabs(maxpivot) * (2.220446049250313e-16 * 3.0);
+        int rank = 0;
+        for (int i = 0; i < nonzero; ++i) rank += (fabs(lu[i][i]) > thr);
+        return rank == 3;
+    }
+    __device__ void inverse(double inv[3][3]) const {
+        for (int j = 0; j < 3; ++j) {
+            double y[3];
+            for (int i = 0; i < 3; ++i) y[i] = (p[i] == j) ? 1.0 : 0.0;
+            for (int i = 1; i < 3; ++i) for (int k = 0; k < i; ++k) y[i] -= lu[i][k] * y[k];
+            for (int i = 2; i >= 0; --i) { for (int k = i + 1; k < 3; ++k) y[i] -= lu[i][k] * y[k]; y[i] /= lu[i][i]; }
+            for (int i = 0; i < 3; ++i) inv[q[i]][j] = y[i];
+        }
+    }
+};
+
+// multi_gauss_unnormalized (util.h:60-66)
+__device__ __forceinline__ double multi_gauss(const double x[3], const double mu[3], const double ci[3][3]) {
+    double mr[3], w[3];
+    for (int a = 0; a < 3; ++a) mr[a] = x[a] - mu[a];
+    for (int b = 0; b < 3; ++b) w[b] = ((-0.5 * mr[0]) * ci[0][b] + (-0.5 * mr[1]) * ci[1][b]) + (-0.5 * mr[2]) * ci[2][b];
+    return exp((w[0] * mr[0] + w[1] * mr[1]) + w[2] * mr[2]);
+}
+
+__global__ void outlier_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, const float* __restrict__ color, float* __restrict__ quality,
+                               uint8_t* __restrict__ inl, int mode) {
+    const uint32_t lf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lf >= nf) return;
+    const int64_t p0 = col_ptr[lf], p1 = col_ptr[lf + 1];
+    const int64_t n = p1 - p0;
+    if (n == 0) return;
+    const double gauss_rejection_threshold = 6e-3, minimal_covariance = 5e-4;
+    const float factor = (mode == MVS_OUTLIER_GAUSS_CLAMPING) ? 1.0f : 0.2f;
+    for (int64_t k = p0; k < p1; ++k) inl[k] = 1;
+    int64_t n_in = n;
+    double mean[3] = {0, 0, 0}, cov[3][3], ci[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int it = 0; it < 10; ++it) {
+        if (n_in < 4) return;
+        for (int a = 0; a < 3; ++a) {
+            double s = 0.0;
+            for (int64_t k = p1 - 1; k >= p0; --k) if (inl[k]) s += (double)color[3 * k + a];
+            mean[a] = s / (double)n_in;
+        }
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+            double s = 0.0;
+            for (int64_t k = p1 - 1; k >= p0; --k) if (inl[k]) s += ((double)color[3 * k + a] - mean[a]) * ((double)color[3 * k + b] - mean[b]);
+            cov[a][b] = s / (double)(n_in - 1);
+        }
+        double mx = 0.0;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) mx = (mx < fabs(cov[a][b])) ? fabs(cov[a][b]) : mx;
+        if (mx < minimal_covariance) {
+            for (int64_t k = p0; k < p1; ++k) if (!inl[k]) quality[k] = 0.0f;
+            return;
+        }
+        Lu3 lu(cov);
+        if (!lu.invertible()) return;
+        lu.inverse(ci);
+        n_in = 0;
+        for (int64_t k = p1 - 1; k >= p0; --k) {
+            const double c[3] = {(double)color[3 * k], (double)color[3 * k + 1], (double)color[3 * k + 2]};
+            const double g = multi_gauss(c, mean, ci);
+            inl[k] = (g >= gauss_rejection_threshold) ? 1 : 0;
+            n_in += inl[k];
+        }
+    }
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) ci[a][b] *= (double)factor;
+    for (int64_t k = p0; k < p1; ++k) {
+        const double c[3] = {(double)color[3 * k], (double)color[3 * k + 1], (double)color[3 * k + 2]};
+        const double g = multi_gauss(c, mean, ci);
+        if (mode == MVS_OUTLIER_GAUSS_DAMPING) quality[k] = (float)((double)quality[k] * g);
+        else if (g < gauss_rejection_threshold) quality[k] = 0.0f;
+    }
+}
+
+// remove quality == 0 entries (calculate_data_costs.cpp:268-270)
+__global__ void nonzero_count_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, const float* __restrict__ quality, uint32_t* __restrict__ cnt) {
+    const uint32_t lf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lf > nf) return;
+    uint32_t c = 0;
+    if (lf < nf) for (uint32_t k = col_ptr[lf]; k < col_ptr[lf + 1]; ++k) c += quality[k] != 0.0f;
+    cnt[lf] = c;
+}
+__global__ void nonzero_copy_kernel(const uint32_t* __restrict__ src_ptr, const uint32_t* __restrict__ dst_ptr, uint32_t nf,
+                                    const uint16_t* __restrict__ sv, const float* __restrict__ sq, uint16_t* __restrict__ dv, float* __restrict__ dq) {
+    const uint32_t lf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lf >= nf) return;
+    uint32_t d = dst_ptr[lf];
+    for (uint32_t k = src_ptr[lf]; k < src_ptr[lf + 1]; ++k)
+        if (sq[k] != 0.0f) { dv[d] = sv[k]; dq[d] = sq[k]; ++d; }
+}
+
+// ---- postprocess_face_infos (calculate_data_costs.cpp:278-302) ----
+__global__ void max_kernel(const float* __restrict__ q, size_t n, uint32_t* __restrict__ max_bits) {
+    float m = 0.0f;  // :278 max_quality = 0.0f
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = smax(m, q[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));  // qualities are > 0: uint order = float order
+}
+
+// Histogram::add_value (histogram.cpp:27-35) with LDS-privatised integer bins; hist[HIST_BINS] = num_values
+__global__ void __launch_bounds__(1024) hist_kernel(const float* __restrict__ q, size_t n, const float* __restrict__ max_q, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t bins[HIST_BINS];
+    for (uint32_t b = threadIdx.x; b < HIST_BINS; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    const float mx = *max_q;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        atomicAdd(&bins[hist_bin(q[i], mx, HIST_BINS)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < HIST_BINS; b += blockDim.x) { const uint32_t c = bins[b]; if (c) atomicAdd(&hist[b], c); }
+}
+
+// Histogram::get_approx_percentile (histogram.cpp:49-63)
+__global__ void percentile_kernel(const uint32_t* __restrict__ hist, const float* __restrict__ max_q, float percentile, float* __restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    const float minv = 0.0f, maxv = *max_q;
+    const int num_values = (int)hist[HIST_BINS];
+    int num = 0;
+    float upper_bound = minv;
+    for (uint32_t i = 0; i < HIST_BINS; ++i) {
+        if ((float)num / (float)num_values > percentile) { *out = upper_bound; return; }
+        num += (int)hist[i];
+        upper_bound = ((float)i / (float)(HIST_BINS - 1)) * (maxv - minv) + minv;
+    }
+    *out = maxv;
+}
+
+// cost = 1 - min(1, quality / percentile)  (calculate_data_costs.cpp:295-297)
+__global__ void cost_kernel(const float* __restrict__ q, size_t n, const float* __restrict__ pctl, float* __restrict__ cost) {
+    const float p = *pctl;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        cost[i] = 1.0f - smin(1.0f, q[i] / p);
+}
+
+__global__ void set_count_kernel(uint32_t* __restrict__ hist, uint32_t n) { hist[HIST_BINS] = n; }
+
+}  // namespace
+
+static uint32_t read_u32(mvs_ctx* ctx, const uint32_t* d) {
+    uint32_t h = 0;
+    MVS_HIP(hipMemcpyAsync(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    return h;
+}
+
+// (re)compute per-view derived images and upload the view table
+static void upload_views_and_prepare(mvs_ctx* ctx, bool need_gmi) {
+    const uint32_t V = ctx->n_views;
+    ctx->gmi_off.assign(V + 1, 0); ctx->mask_off.assign(V + 1, 0);
+    for (uint32_t j = 0; j < V; ++j) {
+        auto& v = ctx->h_views[j];
+        v.mask_stride = (v.width + 31) / 32;
+        ctx->gmi_off[j + 1] = ctx->gmi_off[j] + (need_gmi ? (((size_t)v.width * v.height + 15) & ~(size_t)15) : 0);
+        ctx->mask_off[j + 1] = ctx->mask_off[j] + (size_t)v.mask_stride * v.height;
+    }
+    ctx->gmi_all.ensure(std::max<size_t>(ctx->gmi_off[V], 16));
+    ctx->mask_all.ensure(std::max<size_t>(ctx->mask_off[V], 16));
+    ctx->mask_zero.ensure(std::max<size_t>(ctx->mask_off[V], 16));
+    ctx->mask_tmp.ensure(std::max<size_t>(ctx->mask_off[V], 16));
+    for (uint32_t j = 0; j < V; ++j) {
+        ctx->h_views[j].gmi = need_gmi ? ctx->gmi_all.p + ctx->gmi_off[j] : nullptr;
+        ctx->h_views[j].mask = ctx->mask_all.p + ctx->mask_off[j];
+    }
+    ctx->d_views.ensure(V);
+    MVS_HIP(hipMemcpyAsync(ctx->d_views.p, ctx->h_views.data(), V * sizeof(ViewParams), hipMemcpyHostToDevice, ctx->stream));
+    ctx->view_off.ensure(2 * ((size_t)V + 1));
+    size_t* d_off = ctx->view_off.p;
+    MVS_HIP(hipMemcpyAsync(d_off, ctx->gmi_off.data(), (V + 1) * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(hipMemcpyAsync(d_off + V + 1, ctx->mask_off.data(), (V + 1) * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
+    prepare_views(ctx, need_gmi, d_off, d_off + V + 1);
+}
+
+// phase 1: everything up to the per-face sorted infos + local max quality
+void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
+    if (!ctx->d_verts || ctx->n_views == 0) throw StatusError(MVS_ERR_STATE, "scene not set (mesh + views)");
+    /* calculate_data_costs.cpp:315-318 -- F is a uint32 here, so only the view guard can fire */
+    if (ctx->n_views > 65535u) throw StatusError(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");
+    if (st->data_term != MVS_DATA_TERM_AREA && st->data_term != MVS_DATA_TERM_GMI) throw StatusError(MVS_ERR_INVALID, "bad data_term");
+    if (st->outlier_removal < 0 || st->outlier_removal > 2) throw StatusError(MVS_ERR_INVALID, "bad outlier_removal");
+    hipStream_t s = ctx->stream;
+    const uint32_t V = ctx->n_views, fb = ctx->face_begin, nf = ctx->face_end - ctx->face_begin;
+    const uint32_t fwords = (nf + 63) / 64, vwords = (ctx->n_verts + 63) / 64;
+    const bool gmi = st->data_term == MVS_DATA_TERM_GMI, outl = st->outlier_removal != MVS_OUTLIER_NONE, vis = st->geometric_visibility_test != 0;
+    ctx->dc_settings = *st; ctx->have_costs = false;
+    memset(&ctx->dc_stats, 0, sizeof(ctx->dc_stats));
+    ctx->dc_stats.pairs = (uint64_t)nf * V;
+    ctx->counters.ensure(64);
+    MVS_HIP(hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), s));
+
+    upload_views_and_prepare(ctx, gmi);                        /* :157-163 */
+    if (vis) build_bvh(ctx);                                   /* :144 */
+
+    const size_t pw = (size_t)V * fwords;
+    ctx->pass_bits.ensure(pw + 1); ctx->surv_bits.ensure(pw + 1); ctx->pass_base.ensure(pw + 2);
+    const dim3 fgrid((nf + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
+    if (nf == 0) {
+        ctx->csr_ptr.ensure(2); MVS_HIP(hipMemsetAsync(ctx->csr_ptr.p, 0, 2 * sizeof(uint32_t), s));
+        ctx->csr_faces = 0; ctx->csr_views = V; ctx->csr_nnz = 0; ctx->dc_phase = 1;
+        ctx->max_q.ensure(2); MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
+        return;
+    }
+    hipLaunchKernelGGL(cull_kernel, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
+                       ctx->cos_limit, ctx->pass_bits.p, ctx->counters.p);
+    MVS_LAUNCH_CHECK();
+    if (vis) {
+        const size_t vw = (size_t)V * vwords;
+        ctx->need_bits.ensure(vw + 1); ctx->occl_bits.ensure(vw + 1);
+        MVS_HIP(hipMemsetAsync(ctx->occl_bits.p, 0, vw * sizeof(unsigned long long), s));
+        const dim3 vgrid((ctx->n_verts + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
+        hipLaunchKernelGGL(need_kernel, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->n_verts, V, fb, nf, fwords, vwords,
+                           ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
+        MVS_LAUNCH_CHECK();
+        trace_rays(ctx);
+    }
+    // rank of every passing pair
+    hipLaunchKernelGGL(popc_kernel, dim3((unsigned)((pw + 255) / 256)), dim3(256), 0, s, ctx->pass_bits.p, ctx->pass_base.p, pw);
+    MVS_LAUNCH_CHECK();
+    ctx->max_q.ensure(4);
+    uint32_t* d_total = (uint32_t*)(ctx->max_q.p + 2);
+    exclusive_scan_u32(ctx, ctx->pass_base.p, ctx->pass_base.p, pw, d_total);
+    const uint32_t n_pass = read_u32(ctx, d_total);
+    ctx->pq.ensure((size_t)n_pass + 1);
+    if (outl) ctx->pcol.ensure(3 * ((size_t)n_pass + 1));
+
+#define LAUNCH_INFO(DT, OL, VT)                                                                                              \
+    hipLaunchKernelGGL((info_kernel<DT, OL, VT>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
+                       fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
+                       ctx->surv_bits.p, ctx->counters.p)
+    if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true); else LAUNCH_INFO(1, true, false); }
+               else      { if (vis) LAUNCH_INFO(1, false, true); else LAUNCH_INFO(1, false, false); } }
+    else     { if (outl) { if (vis) LAUNCH_INFO(0, true, true); else LAUNCH_INFO(0, true, false); }
+               else      { if (vis) LAUNCH_INFO(0, false, true); else LAUNCH_INFO(0, false, false); } }
+#undef LAUNCH_INFO
+    MVS_LAUNCH_CHECK();
+
+    // CSR by face
+    ctx->face_cnt.ensure((size_t)nf + 2);
+    hipLaunchKernelGGL(csr_count_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->surv_bits.p, V, nf, fwords, ctx->face_cnt.p);
+    MVS_LAUNCH_CHECK();
+    DBuf<uint32_t>& ptr = outl ? ctx->pre_ptr : ctx->csr_ptr;
+    ptr.ensure((size_t)nf + 2);
+    exclusive_scan_u32(ctx, ctx->face_cnt.p, ptr.p, (size_t)nf + 1, nullptr);
+    const uint32_t nnz_pre = read_u32(ctx, ptr.p + nf);
+    ctx->dc_stats.nnz_pre = nnz_pre;
+    if (outl) {
+        ctx->pre_view.ensure((size_t)nnz_pre + 1); ctx->pre_q.ensure((size_t)nnz_pre + 1); ctx->pre_col.ensure(3 * ((size_t)nnz_pre + 1));
+        ctx->pre_inl.ensure((size_t)nnz_pre + 1);
+        hipLaunchKernelGGL(csr_write_kernel<true>, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
+                           ctx->pq.p, ctx->pcol.p, V, nf, fwords, ctx->pre_ptr.p, ctx->pre_view.p, ctx->pre_q.p, ctx->pre_col.p);
+        MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(outlier_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, ctx->pre_ptr.p, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p,
+                           st->outlier_removal);
+        MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf + 256) / 256), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
+        MVS_LAUNCH_CHECK();
+        ctx->csr_ptr.ensure((size_t)nf + 2);
+        exclusive_scan_u32(ctx, ctx->face_cnt.p, ctx->csr_ptr.p, (size_t)nf + 1, nullptr);
+        const uint32_t nnz = read_u32(ctx, ctx->csr_ptr.p + nf);
+        ctx->csr_view.ensure((size_t)nnz + 1); ctx->csr_q.ensure((size_t)nnz + 1); ctx->csr_cost.ensure((size_t)nnz + 1);
+        hipLaunchKernelGGL(nonzero_copy_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->pre_ptr.p, ctx->csr_ptr.p, nf, ctx->pre_view.p, ctx->pre_q.p,
+                           ctx->csr_view.p, ctx->csr_q.p);
+        MVS_LAUNCH_CHECK();
+        ctx->csr_nnz = nnz;
+    } else {
+        ctx->csr_view.ensure((size_t)nnz_pre + 1); ctx->csr_q.ensure((size_t)nnz_pre + 1); ctx->csr_cost.ensure((size_t)nnz_pre + 1);
+        hipLaunchKernelGGL(csr_write_kernel<false>, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
+                           ctx->pq.p, (const float*)nullptr, V, nf, fwords, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_q.p, (float*)nullptr);
+        MVS_LAUNCH_CHECK();
+        ctx->csr_nnz = nnz_pre;
+    }
+    ctx->csr_faces = nf; ctx->csr_views = V;
+    // local max quality (:278-281)
+    MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
+    if (ctx->csr_nnz) {
+        hipLaunchKernelGGL(max_kernel, dim3(1024), dim3(256), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, (uint32_t*)ctx->max_q.p);
+        MVS_LAUNCH_CHECK();
+    }
+    ctx->dc_phase = 1;
+}
+
+// phase 2: histogram of the local qualities against the (possibly all-reduced) maximum (:283-286)
+void dc_phase2(mvs_ctx* ctx) {
+    if (ctx->dc_phase != 1) throw StatusError(MVS_ERR_STATE, "dc_phase2 needs dc_phase1");
+    hipStream_t s = ctx->stream;
+    ctx->hist.ensure(HIST_BINS + 8);
+    MVS_HIP(hipMemsetAsync(ctx->hist.p, 0, (HIST_BINS + 8) * sizeof(uint32_t), s));
+    if (ctx->csr_nnz) {
+        hipLaunchKernelGGL(hist_kernel, dim3(512), dim3(1024), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, ctx->max_q.p, ctx->hist.p);
+        MVS_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(1), 0, s, ctx->hist.p, (uint32_t)ctx->csr_nnz);
+    MVS_LAUNCH_CHECK();
+    ctx->dc_phase = 2;
+}
+
+// phase 3: percentile from the (possibly all-reduced) histogram, cost write (:288-298)
+void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
+    if (ctx->dc_phase != 2) throw StatusError(MVS_ERR_STATE, "dc_phase3 needs dc_phase2");
+    hipStream_t s = ctx->stream;
+    ctx->pctl.ensure(4);
+    hipLaunchKernelGGL(percentile_kernel, dim3(1), dim3(64), 0, s, ctx->hist.p, ctx->max_q.p, 0.995f, ctx->pctl.p);
+    MVS_LAUNCH_CHECK();
+    if (ctx->csr_nnz) {
+        hipLaunchKernelGGL(cost_kernel, dim3(2048), dim3(256), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, ctx->pctl.p, ctx->csr_cost.p);
+        MVS_LAUNCH_CHECK();
+    }
+    unsigned long long hc[16]; float mq = 0.0f, pc = 0.0f;
+    MVS_HIP(hipMemcpyAsync(hc, ctx->counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipMemcpyAsync(&mq, ctx->max_q.p, sizeof(float), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipMemcpyAsync(&pc, ctx->pctl.p, sizeof(float), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    mvs_dc_stats& S = ctx->dc_stats;
+    S.cull_backface = hc[C_BACK]; S.cull_angle = hc[C_ANGLE]; S.cull_outside = hc[C_OUTSIDE]; S.cull_occluded = hc[C_OCCL];
+    S.cull_zero_quality = hc[C_ZEROQ]; S.rays = hc[C_RAYS]; S.ray_nodes = hc[C_RNODES]; S.ray_tris = hc[C_RTRIS];
+    S.nnz = ctx->csr_nnz; S.max_quality = mq; S.percentile = pc;
+    ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p;
+    ctx->have_costs = true; ctx->dc_phase = 3;
+    if (stats) *stats = S;
+}
+
+}  // namespace mvs

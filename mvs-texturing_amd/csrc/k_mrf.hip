@@ -1,0 +1,427 @@
+// k_mrf.hip -- tex::view_selection on the GPU (libs/tex/view_selection.cpp:18-133).
+//
+// Model (restated from :27-82): node i = face, label set = {view_id + 1 : view_id
+// in column i} with unaries = column costs, or the single label 0 when the column
+// is empty; Potts edges of weight 1 between adjacent faces whose columns are both
+// non-empty.  mapMAP (:93-118) is replaced by a GPU-resident synchronous
+// tree-reweighted max-product sweep + monotone ICM polish; the algorithm is
+// specified to the float operation in DESIGN.md "MRF solver" and restated for
+// the CPU in oracle/oracle.cpp -- labels are bit-identical by construction:
+// min / argmin reductions are exact in any order, sums follow adjacency order,
+// energies are 32.32 fixed-point integers.
+//
+// Work mapping: G lanes per node (G = 8..64 chosen from the largest column), the
+// lanes of a group stride over the node's labels; per-edge cavity vectors go
+// through LDS for the label re-alignment gather; min / argmin are wave shuffles.
+#include "ctx.h"
+
+namespace mvs {
+
+namespace {
+
+constexpr uint16_t MAP_NONE = 0xFFFF;
+
+__device__ __forceinline__ unsigned long long fix32(float d) { return (unsigned long long)((double)d * 4294967296.0); }
+
+// ---- setup ----
+__global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                uint32_t F, uint32_t* __restrict__ size, uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = 0, deg = 0;
+    if (i < F) {
+        k = col_ptr[i + 1] - col_ptr[i];
+        const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+        deg = e1 - e0;
+        for (uint32_t e = e0; e < e1; ++e) {
+            const uint32_t j = adj[e];
+            const uint32_t kj = col_ptr[j + 1] - col_ptr[j];
+            size[e] = (k > 0 && kj > 0) ? k : 0u;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { k = max(k, (uint32_t)__shfl_xor(k, o, 64)); deg = max(deg, (uint32_t)__shfl_xor(deg, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&maxes[0], k); atomicMax(&maxes[1], deg); }
+}
+
+__global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                uint32_t F, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ size, MrfEdge* __restrict__ edge) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+        const uint32_t j = adj[e];
+        uint32_t r = adj_ptr[j];
+        const uint32_t r1 = adj_ptr[j + 1];
+        while (r < r1 && adj[r] != i) ++r;
+        MrfEdge m;
+        m.in_off = in_off[e];
+        m.out_off = (r < r1) ? in_off[r] : 0u;
+        m.kj = (size[e] > 0 && r < r1) ? (col_ptr[j + 1] - col_ptr[j]) : 0u;
+        edge[e] = m;
+    }
+}
+
+// map[in_off(e) + t] = position of L_i[t] in L_j (binary search; lists ascending, calculate_data_costs.cpp:272)
+__global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
+                               const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint16_t* __restrict__ map) {
+    // 16 lanes per node
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t gl = threadIdx.x & 15;
+    if (i >= F) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+        const MrfEdge m = edge[e];
+        if (m.kj == 0) continue;
+        const uint32_t q0 = col_ptr[adj[e]];
+        for (uint32_t t = gl; t < K; t += 16) {
+            const uint16_t key = view_id[p0 + t];
+            uint32_t lo = 0, hi = m.kj;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (view_id[q0 + mid] < key) lo = mid + 1; else hi = mid; }
+            map[m.in_off + t] = (lo < m.kj && view_id[q0 + lo] == key) ? (uint16_t)lo : MAP_NONE;
+        }
+    }
+}
+
+// ---- one synchronous sweep; fast path: degree <= 3, K <= G * R ----
+template <int G, int R, bool DAMP>
+__global__ void __launch_bounds__(256) mrf_sweep_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, const uint32_t* __restrict__ adj_ptr,
+                                                        const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
+                                                        const float* __restrict__ mo, float* __restrict__ mn, uint32_t* __restrict__ sel,
+                                                        uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
+    constexpr int NPB = 256 / G;
+    __shared__ float cs[NPB][G * R];
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const uint32_t i = node_begin + blockIdx.x * NPB + grp;
+    const bool node_ok = i < node_end;
+    const uint32_t p0 = node_ok ? col_ptr[i] : 0u;
+    const uint32_t K = node_ok ? col_ptr[i + 1] - p0 : 0u;
+    const uint32_t e0 = node_ok ? adj_ptr[i] : 0u;
+    const uint32_t deg = node_ok ? adj_ptr[i + 1] - e0 : 0u;
+    const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
+    MrfEdge em[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if ((uint32_t)d < deg) em[d] = edge[e0 + d];
+        else { em[d].in_off = 0; em[d].out_off = 0; em[d].kj = 0; }
+        if (K == 0) em[d].kj = 0;
+    }
+    float D[R], in[3][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t t = gl + r * G;
+        const bool ok = t < K;
+        D[r] = ok ? cost[p0 + t] : 0.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) in[d][r] = (ok && em[d].kj) ? mo[em[d].in_off + t] : 0.0f;
+    }
+    // decode: first argmin_t of b[t] = D[t] + rho * S[t]
+    {
+        float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t t = gl + r * G;
+            if (t < K) {
+                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
+                const float b = D[r] + rho * S;
+                if (b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
+            }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
+            if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
+        }
+        if (gl == 0 && K > 0) sel[i] = bt;
+    }
+    // outgoing messages
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
+        float c[R];
+        float cmin = INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t t = gl + r * G;
+            const float oth = (0.0f + in[a][r]) + in[b2][r];
+            c[r] = (D[r] + rho * oth) - omr * in[d][r];
+            if (t < K) { cmin = fminf(cmin, c[r]); cs[grp][t] = c[r]; }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
+        __syncthreads();
+        const uint32_t kj = em[d].kj, oo = em[d].out_off;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t t2 = gl + r * G;
+            if (t2 < kj) {
+                const uint16_t p = map[oo + t2];
+                const float raw = (p == MAP_NONE) ? lam : fminf(cs[grp][p] - cmin, lam);
+                mn[oo + t2] = DAMP ? (raw * oma + mo[oo + t2] * alpha) : raw;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// generic path: any degree, any K.  One wave per node, cavity vector through a global scratch row.
+template <bool DAMP>
+__global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, const uint32_t* __restrict__ adj_ptr,
+                                                               const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
+                                                               const float* __restrict__ mo, float* __restrict__ mn, uint32_t* __restrict__ sel,
+                                                               float* __restrict__ scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
+    const uint32_t i = node_begin + blockIdx.x;
+    const int lane = threadIdx.x;
+    if (i >= node_end) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    if (K == 0) return;
+    const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+    const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
+    float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+    for (uint32_t t = lane; t < K; t += 64) {
+        float S = 0.0f;
+        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) S = S + mo[m.in_off + t]; }
+        const float b = cost[p0 + t] + rho * S;
+        if (b < bb) { bb = b; bt = t; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(bb, o, 64); const uint32_t ot = __shfl_xor(bt, o, 64);
+        if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
+    }
+    if (lane == 0) sel[i] = bt;
+    for (uint32_t e = e0; e < e1; ++e) {
+        const MrfEdge m = edge[e];
+        if (!m.kj) continue;  // wave-uniform
+        float cmin = INFINITY;
+        for (uint32_t t = lane; t < K; t += 64) {
+            float oth = 0.0f;
+            for (uint32_t e2 = e0; e2 < e1; ++e2) { if (e2 == e) continue; const MrfEdge m2 = edge[e2]; if (m2.kj) oth = oth + mo[m2.in_off + t]; }
+            const float c = (cost[p0 + t] + rho * oth) - omr * mo[m.in_off + t];
+            scratch[p0 + t] = c;
+            cmin = fminf(cmin, c);
+        }
+        for (int o = 32; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, 64));
+        __syncthreads();
+        for (uint32_t t2 = lane; t2 < m.kj; t2 += 64) {
+            const uint16_t p = map[m.out_off + t2];
+            const float raw = (p == MAP_NONE) ? lam : fminf(scratch[p0 + p] - cmin, lam);
+            mn[m.out_off + t2] = DAMP ? (raw * oma + mo[m.out_off + t2] * alpha) : raw;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- exact energy of the decoded labeling (32.32 fixed point) over nodes [node_begin, node_end) ----
+__global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                         const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
+                                                         const uint32_t* __restrict__ sel, uint32_t node_begin, uint32_t node_end,
+                                                         unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
+    unsigned long long unary = 0, cuts = 0;
+    for (uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x; i < node_end; i += gridDim.x * blockDim.x) {
+        const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+        if (K == 0) { unary += fix32(1.0f); continue; }  /* view_selection.cpp:70-71 */
+        const uint32_t s = sel[i];
+        unary += fix32(cost[p0 + s]);
+        const uint16_t li = view_id[p0 + s];
+        for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+            const uint32_t j = adj[e];
+            if (edge[e].kj == 0 || j <= i) continue;      /* :38 uni directional */
+            cuts += (view_id[col_ptr[j] + sel[j]] != li);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { unary += __shfl_xor(unary, o, 64); cuts += __shfl_xor(cuts, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], unary + (cuts << 32)); atomicAdd(&out[1], cuts); }
+}
+
+// ---- ICM polish ----
+__global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                           const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
+                                                           const uint32_t* __restrict__ sel, uint32_t node_begin, uint32_t node_end,
+                                                           float* __restrict__ gain, uint32_t* __restrict__ cand) {
+    const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= node_end) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    float g = 0.0f; uint32_t bt = 0;
+    if (K > 0) {
+        const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1], cur_t = sel[i];
+        float best = 0.0f, cur = 0.0f;
+        for (uint32_t t = 0; t < K; ++t) {
+            const uint16_t l = view_id[p0 + t];
+            uint32_t diff = 0;
+            for (uint32_t e = e0; e < e1; ++e) {
+                if (edge[e].kj == 0) continue;
+                const uint32_t j = adj[e];
+                diff += (view_id[col_ptr[j] + sel[j]] != l);
+            }
+            const float en = cost[p0 + t] + (float)diff;
+            if (t == 0 || en < best) { best = en; bt = t; }
+            if (t == cur_t) cur = en;
+        }
+        g = cur - best;
+    }
+    gain[i] = g; cand[i] = bt;
+}
+
+__global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
+                                                            const float* __restrict__ gain, const uint32_t* __restrict__ cand, const uint32_t* sel,
+                                                            uint32_t* nsel, uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved) {
+    const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    bool mv = false;
+    if (i < node_end) {
+        const float gi = gain[i];
+        uint32_t s = sel[i];
+        if (gi > 0.0f) {
+            bool win = true;
+            for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1] && win; ++e) {
+                if (edge[e].kj == 0) continue;
+                const uint32_t j = adj[e];
+                const float gj = gain[j];
+                if (gj > gi || (gj == gi && j < i)) win = false;
+            }
+            if (win) { s = cand[i]; mv = true; }
+        }
+        nsel[i] = s;
+    }
+    const unsigned long long b = __ballot(mv);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(moved, (uint32_t)__popcll(b));
+}
+
+__global__ void mrf_argmin_unary_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, uint32_t F, uint32_t* __restrict__ sel) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    uint32_t bt = 0;
+    for (uint32_t t = 1; t < K; ++t) if (cost[p0 + t] < cost[p0 + bt]) bt = t;
+    sel[i] = bt;
+}
+
+/* label extraction (view_selection.cpp:120-132) */
+__global__ void mrf_labels_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ sel,
+                                  uint32_t node_begin, uint32_t node_end, uint32_t n_views, uint32_t* __restrict__ labels, uint32_t* __restrict__ bad_unseen /* [0] bad, [1] unseen */) {
+    const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= node_end) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    uint32_t label = 0;
+    if (K > 0) {
+        const uint32_t s = sel[i];
+        if (s >= K) { atomicAdd(&bad_unseen[0], 1u); } else label = (uint32_t)view_id[p0 + s] + 1u;
+        if (label > n_views) atomicAdd(&bad_unseen[0], 1u);   /* :126-128 "Incorrect labeling" */
+    } else atomicAdd(&bad_unseen[1], 1u);
+    labels[i - node_begin] = label;
+}
+
+}  // namespace
+
+// Builds the solver's edge tables for the active CSR (ctx->r_ptr / r_view / r_cost) and adjacency.
+void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
+    hipStream_t s = ctx->stream;
+    const uint32_t F = ctx->csr_faces;
+    ctx->m_params = *params;
+    if (!(params->rho > 0.0f && params->rho <= 1.0f) || !(params->damping >= 0.0f && params->damping < 1.0f))
+        throw StatusError(MVS_ERR_INVALID, "mrf params: need 0 < rho <= 1, 0 <= damping < 1");
+    uint32_t E = 0;
+    MVS_HIP(hipMemcpyAsync(&E, ctx->r_adj_ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    ctx->m_size.ensure((size_t)E + 2); ctx->m_edge.ensure((size_t)E + 1); ctx->m_moved.ensure(8);
+    uint32_t* maxes = ctx->m_moved.p + 4;
+    MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 8 * sizeof(uint32_t), s));
+    MVS_HIP(hipMemsetAsync(ctx->m_size.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
+    const unsigned nb = (F + 255) / 256;
+    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_size.p, maxes); MVS_LAUNCH_CHECK(); }
+    // in_off = exclusive scan of the sizes (E + 1 entries so that in_off[E] = total)
+    DBuf<uint32_t>& in_off = ctx->m_sel2;  // temporary home, re-ensured below
+    in_off.ensure(std::max<size_t>((size_t)E + 2, (size_t)F + 2));
+    exclusive_scan_u32(ctx, ctx->m_size.p, in_off.p, (size_t)E + 1, nullptr);
+    uint32_t h[3] = {0, 0, 0};
+    MVS_HIP(hipMemcpyAsync(&h[0], in_off.p + E, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipMemcpyAsync(&h[1], maxes, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    ctx->m_total = h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
+    if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
+    ctx->m_map.ensure(ctx->m_total + 1);
+    if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p); MVS_LAUNCH_CHECK(); }
+    ctx->m_msg_a.ensure(ctx->m_total + 1); ctx->m_msg_b.ensure(ctx->m_total + 1);
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1) * sizeof(float), s));
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 1) * sizeof(float), s));
+    MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
+    ctx->m_sel.ensure((size_t)F + 1); ctx->m_best_sel.ensure((size_t)F + 1); ctx->m_sel2.ensure((size_t)F + 1); ctx->m_cand.ensure((size_t)F + 1); ctx->m_gain.ensure((size_t)F + 1);
+    MVS_HIP(hipMemsetAsync(ctx->m_sel.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
+    MVS_HIP(hipMemsetAsync(ctx->m_best_sel.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
+    ctx->m_energy.ensure(4);
+    ctx->m_flip = false;
+}
+
+template <int G, int R>
+static void launch_sweep_gr(mvs_ctx* ctx, const float* mo, float* mn, uint32_t nb0, uint32_t ne0) {
+    constexpr int NPB = 256 / G;
+    const unsigned blocks = (ne0 - nb0 + NPB - 1) / NPB;
+    const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+    if (alpha != 0.0f)
+        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, nb0, ne0, rho, alpha);
+    else
+        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, nb0, ne0, rho, alpha);
+}
+
+// one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
+void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
+    const float* mo = ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p;
+    float* mn = ctx->m_flip ? ctx->m_msg_a.p : ctx->m_msg_b.p;
+    if (ne0 > nb0) {
+        const uint32_t K = ctx->m_kmax;
+        if (ctx->m_degmax <= 3 && K <= 256) {
+            if (K <= 8) launch_sweep_gr<8, 1>(ctx, mo, mn, nb0, ne0);
+            else if (K <= 16) launch_sweep_gr<16, 1>(ctx, mo, mn, nb0, ne0);
+            else if (K <= 32) launch_sweep_gr<32, 1>(ctx, mo, mn, nb0, ne0);
+            else if (K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
+            else if (K <= 128) launch_sweep_gr<64, 2>(ctx, mo, mn, nb0, ne0);
+            else launch_sweep_gr<64, 4>(ctx, mo, mn, nb0, ne0);
+        } else {
+            ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
+            const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+            if (alpha != 0.0f)
+                hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->pq.p, nb0, ne0, rho, alpha);
+            else
+                hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->pq.p, nb0, ne0, rho, alpha);
+        }
+        MVS_LAUNCH_CHECK();
+    }
+    ctx->m_flip = !ctx->m_flip;
+}
+
+// energy of labeling `sel` over nodes [nb0, ne0) -> ctx->m_energy (device, 2 x u64), asynchronous
+void mrf_energy(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0) {
+    MVS_HIP(hipMemsetAsync(ctx->m_energy.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    if (ne0 > nb0) {
+        const unsigned blocks = std::min<unsigned>((ne0 - nb0 + 255) / 256, 4096u);
+        hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, sel, nb0, ne0, ctx->m_energy.p);
+        MVS_LAUNCH_CHECK();
+    }
+}
+
+void mrf_icm_gain(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0) {
+    if (ne0 <= nb0) return;
+    hipLaunchKernelGGL(mrf_icm_gain_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, sel, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p);
+    MVS_LAUNCH_CHECK();
+}
+void mrf_icm_apply(mvs_ctx* ctx, const uint32_t* sel, uint32_t* nsel, uint32_t nb0, uint32_t ne0) {
+    MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, sizeof(uint32_t), ctx->stream));
+    if (ne0 <= nb0) return;
+    hipLaunchKernelGGL(mrf_icm_apply_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_gain.p, ctx->m_cand.p, sel, nsel, nb0, ne0, ctx->m_moved.p);
+    MVS_LAUNCH_CHECK();
+}
+void mrf_argmin_unary(mvs_ctx* ctx, uint32_t* sel) {
+    const uint32_t F = ctx->csr_faces;
+    if (!F) return;
+    hipLaunchKernelGGL(mrf_argmin_unary_kernel, dim3((F + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, F, sel);
+    MVS_LAUNCH_CHECK();
+}
+// labels of nodes [nb0, ne0) into d_labels[0 .. ne0 - nb0); returns {bad, unseen}
+void mrf_labels(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]) {
+    uint32_t* bu = ctx->m_moved.p + 2;
+    MVS_HIP(hipMemsetAsync(bu, 0, 2 * sizeof(uint32_t), ctx->stream));
+    if (ne0 > nb0) {
+        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, sel, nb0, ne0, ctx->csr_views, d_labels, bu);
+        MVS_LAUNCH_CHECK();
+    }
+    MVS_HIP(hipMemcpyAsync(out, bu, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+}  // namespace mvs

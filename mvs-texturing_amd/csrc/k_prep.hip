@@ -1,0 +1,208 @@
+// k_prep.hip -- per-view image preparation of calculate_face_projection_infos
+// (libs/tex/calculate_data_costs.cpp:157-163):
+//   generate_validity_mask      (texture_view.cpp:42-94)   flood fill of zero pixels from the corners
+//   generate_gradient_magnitude (texture_view.cpp:102-107) luminance + 3x3 Sobel magnitude
+//   erode_validity_mask         (texture_view.cpp:109-132)
+// All three are byte / bit arithmetic: HBM-bound streaming kernels, one launch
+// covers every view (grid.z = view).  Masks are bit-packed, rows padded to
+// 32-bit words, so that the flood fill and the erosion are word-parallel.
+#include "ctx.h"
+
+namespace mvs {
+
+namespace {
+
+// ---- gradient magnitude: fused luminance + Sobel through an LDS tile ----
+constexpr int GT_X = 64, GT_Y = 4;  // 256 threads, one output pixel each; rows are contiguous in memory
+
+__global__ void __launch_bounds__(GT_X * GT_Y) gmi_kernel(const ViewParams* __restrict__ views, uint8_t* __restrict__ gmi_all,
+                                                         const size_t* __restrict__ gmi_off) {
+    const ViewParams& vp = views[blockIdx.z];
+    const int w = vp.width, h = vp.height;
+    const int x0 = blockIdx.x * GT_X, y0 = blockIdx.y * GT_Y;
+    if (x0 >= w || y0 >= h) return;
+    __shared__ uint8_t lum[GT_Y + 2][GT_X + 2 + 2];
+    const uint8_t* __restrict__ rgb = vp.rgb;
+    const int tid = threadIdx.y * GT_X + threadIdx.x;
+    for (int i = tid; i < (GT_Y + 2) * (GT_X + 2); i += GT_X * GT_Y) {
+        const int ly = i / (GT_X + 2), lx = i - ly * (GT_X + 2);
+        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+        uint8_t l = 0;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+            const uint8_t* p = rgb + ((size_t)gy * w + gx) * 3;
+            l = luminance_u8(p[0], p[1], p[2]);
+        }
+        lum[ly][lx] = l;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    uint8_t out = 0;
+    if (!(y == 0 || y == h - 1 || x == 0 || x == w - 1)) {
+        const int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
+        const int a = lum[ly - 1][lx - 1], b = lum[ly - 1][lx], c = lum[ly - 1][lx + 1];
+        const int d = lum[ly][lx - 1], f = lum[ly][lx + 1];
+        const int g = lum[ly + 1][lx - 1], hh = lum[ly + 1][lx], i = lum[ly + 1][lx + 1];
+        const int sx = (c - a) + 2 * (f - d) + (i - g);
+        const int sy = (g - a) + 2 * (hh - b) + (i - c);
+        out = isqrt_clamp255(sx * sx + sy * sy);
+    }
+    gmi_all[gmi_off[blockIdx.z] + (size_t)y * w + x] = out;
+}
+
+// ---- validity mask ----
+// zero map: bit x of word (y, wx) set iff pixel (32 wx + x, y) has r + g + b == 0;
+// reach is seeded with the zero corners (texture_view.cpp:49-57).
+__global__ void mask_zero_kernel(const ViewParams* __restrict__ views, uint32_t* __restrict__ zero_all,
+                                 uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off) {
+    const ViewParams& vp = views[blockIdx.z];
+    const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
+    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (wx >= wpr || y >= h) return;
+    const uint8_t* __restrict__ row = vp.rgb + (size_t)y * w * 3;
+    uint32_t z = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int x = wx * 32 + b;
+        if (x < w) {
+            const uint8_t* p = row + (size_t)x * 3;
+            if ((int)p[0] + (int)p[1] + (int)p[2] == 0) z |= 1u << b;
+        }
+    }
+    uint32_t seed = 0;
+    if (y == 0 || y == h - 1) {
+        if (wx == 0) seed |= 1u;
+        if (wx == (w - 1) / 32) seed |= 1u << ((w - 1) & 31);
+    }
+    const size_t idx = mask_off[blockIdx.z] + (size_t)y * wpr + wx;
+    zero_all[idx] = z;
+    reach_all[idx] = seed & z;
+}
+
+// fill `r` through the set bits of `m` towards higher bit positions (Kogge-Stone), within a word
+__device__ __forceinline__ uint32_t fill_up(uint32_t r, uint32_t m) {
+    r |= m & (r << 1); m &= m << 1;
+    r |= m & (r << 2); m &= m << 2;
+    r |= m & (r << 4); m &= m << 4;
+    r |= m & (r << 8); m &= m << 8;
+    r |= m & (r << 16);
+    return r;
+}
+__device__ __forceinline__ uint32_t fill_down(uint32_t r, uint32_t m) {
+    r |= m & (r >> 1); m &= m >> 1;
+    r |= m & (r >> 2); m &= m >> 2;
+    r |= m & (r >> 4); m &= m >> 4;
+    r |= m & (r >> 8); m &= m >> 8;
+    r |= m & (r >> 16);
+    return r;
+}
+
+// one Jacobi step of the 4-connected flood fill (texture_view.cpp:59-93); sets *changed
+__global__ void mask_flood_kernel(const ViewParams* __restrict__ views, const uint32_t* __restrict__ zero_all,
+                                  const uint32_t* __restrict__ rin, uint32_t* __restrict__ rout,
+                                  const size_t* __restrict__ mask_off, uint32_t* __restrict__ changed) {
+    const ViewParams& vp = views[blockIdx.z];
+    const int h = vp.height, wpr = vp.mask_stride;
+    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (wx >= wpr || y >= h) return;
+    const size_t base = mask_off[blockIdx.z];
+    const size_t idx = base + (size_t)y * wpr + wx;
+    const uint32_t z = zero_all[idx];
+    const uint32_t r0 = rin[idx];
+    uint32_t r = r0;
+    if (z) {
+        if (y > 0) r |= rin[idx - wpr];
+        if (y < h - 1) r |= rin[idx + wpr];
+        if (wx > 0) r |= rin[idx - 1] >> 31;
+        if (wx < wpr - 1) r |= rin[idx + 1] << 31;
+        r &= z;
+        r = fill_up(r, z);
+        r = fill_down(r, z);
+    }
+    rout[idx] = r;
+    if (r != r0) *changed = 1u;
+}
+
+// mask = ~reach; with ERODE the literal semantics of erode_validity_mask:
+// every INTERIOR invalid pixel clears its 3x3 neighbourhood, border pixels keep
+// their own value otherwise (the reference clears them only in the discarded copy).
+template <bool ERODE>
+__global__ void mask_final_kernel(const ViewParams* __restrict__ views, const uint32_t* __restrict__ reach_all,
+                                  uint32_t* __restrict__ mask_all, const size_t* __restrict__ mask_off) {
+    const ViewParams& vp = views[blockIdx.z];
+    const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
+    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (wx >= wpr || y >= h) return;
+    const size_t base = mask_off[blockIdx.z];
+    auto inbounds = [&](int ww) -> uint32_t {  // bits of word ww that are real pixels
+        const int rem = w - ww * 32;
+        return rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+    };
+    auto invalid_interior = [&](int ww, int yy) -> uint32_t {
+        if (ww < 0 || ww >= wpr || yy <= 0 || yy >= h - 1) return 0u;
+        uint32_t inv = reach_all[base + (size_t)yy * wpr + ww] & inbounds(ww);
+        if (ww == 0) inv &= ~1u;                                    // x == 0 is border
+        if (ww == (w - 1) / 32) inv &= ~(1u << ((w - 1) & 31));     // x == w-1 is border
+        return inv;
+    };
+    uint32_t valid = ~reach_all[base + (size_t)y * wpr + wx] & inbounds(wx);
+    if (ERODE) {
+        uint32_t kill = 0;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const uint32_t c = invalid_interior(wx, y + dy);
+            const uint32_t l = invalid_interior(wx - 1, y + dy);
+            const uint32_t r = invalid_interior(wx + 1, y + dy);
+            kill |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+        }
+        valid &= ~kill;
+    }
+    mask_all[base + (size_t)y * wpr + wx] = valid;
+}
+
+}  // namespace
+
+// Runs the image preparation for all views; needs ctx->d_views uploaded with
+// rgb pointers, gmi/mask pointers pre-assigned into gmi_all / mask_all.
+void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const size_t* d_mask_off) {
+    const uint32_t V = ctx->n_views;
+    if (V == 0) return;
+    int maxw = 0, maxh = 0, maxwpr = 0;
+    for (auto& v : ctx->h_views) { maxw = std::max(maxw, v.width); maxh = std::max(maxh, v.height); maxwpr = std::max(maxwpr, v.mask_stride); }
+    hipStream_t s = ctx->stream;
+    if (need_gmi) {
+        dim3 grid((maxw + GT_X - 1) / GT_X, (maxh + GT_Y - 1) / GT_Y, V);
+        hipLaunchKernelGGL(gmi_kernel, grid, dim3(GT_X, GT_Y), 0, s, ctx->d_views.p, ctx->gmi_all.p, d_gmi_off);
+        MVS_LAUNCH_CHECK();
+    }
+    dim3 mgrid((maxwpr + 63) / 64, maxh, V);
+    uint32_t* zero = ctx->mask_zero.p;
+    uint32_t* ra = ctx->mask_all.p;   // ping
+    uint32_t* rb = ctx->mask_tmp.p;   // pong
+    hipLaunchKernelGGL(mask_zero_kernel, mgrid, dim3(64), 0, s, ctx->d_views.p, zero, ra, d_mask_off);
+    MVS_LAUNCH_CHECK();
+    // flood fill until a whole batch of steps changes nothing
+    uint32_t* d_changed = (uint32_t*)ctx->counters.p + 64;  // scratch word inside the counters block
+    for (int iter = 0;; ++iter) {
+        MVS_HIP(hipMemsetAsync(d_changed, 0, sizeof(uint32_t), s));
+        const int batch = (iter == 0) ? 1 : 16;
+        for (int b = 0; b < batch; ++b) {
+            hipLaunchKernelGGL(mask_flood_kernel, mgrid, dim3(64), 0, s, ctx->d_views.p, zero, ra, rb, d_mask_off, d_changed);
+            MVS_LAUNCH_CHECK();
+            std::swap(ra, rb);
+        }
+        uint32_t changed = 0;
+        MVS_HIP(hipMemcpyAsync(&changed, d_changed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        if (!changed) break;
+        if (iter > 100000) throw HipError("validity mask flood fill did not converge");
+    }
+    // ra holds the converged reach set; the final mask must land in mask_all
+    uint32_t* reach = ra;
+    uint32_t* out = (ra == ctx->mask_all.p) ? ctx->mask_tmp.p : ctx->mask_all.p;
+    if (need_gmi) hipLaunchKernelGGL(mask_final_kernel<true>, mgrid, dim3(64), 0, s, ctx->d_views.p, reach, out, d_mask_off);
+    else hipLaunchKernelGGL(mask_final_kernel<false>, mgrid, dim3(64), 0, s, ctx->d_views.p, reach, out, d_mask_off);
+    MVS_LAUNCH_CHECK();
+    if (out != ctx->mask_all.p)
+        MVS_HIP(hipMemcpyAsync(ctx->mask_all.p, out, ctx->mask_off.back() * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+}
+
+}  // namespace mvs

@@ -1,0 +1,169 @@
+// mgpu.hip -- multi-GPU building blocks of the C ABI (include/mvs_viewsel.h,
+// "multi-GPU MRF building blocks" and the data-cost reduce hooks).  The RCCL
+// calls themselves are issued by the driver (mvs-texturing_amd/multigpu.py)
+// on caller-owned device buffers; these entry points only move data between
+// those buffers and the solver's arrays and run the per-range kernels.
+#include "ctx.h"
+
+namespace mvs {
+void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
+void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_energy(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
+void mrf_icm_gain(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
+void mrf_icm_apply(mvs_ctx* ctx, const uint32_t* sel, uint32_t* nsel, uint32_t nb0, uint32_t ne0);
+void mrf_labels(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device);
+mvs_status api_fail(mvs_status st, const std::string& msg);
+
+namespace {
+__global__ void gather_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[k] = src[idx[k]];
+}
+__global__ void scatter_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = src[k];
+}
+__global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) counts[i] = col_ptr[i + 1] - col_ptr[i];
+}
+}  // namespace
+
+static uint32_t* mrf_array(mvs_ctx* ctx, int which) {
+    switch (which) {
+        case MVS_MRF_MSG: return (uint32_t*)(ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p);  // current = what the last sweep wrote
+        case MVS_MRF_SEL: return ctx->m_sel.p;
+        case MVS_MRF_GAIN: return (uint32_t*)ctx->m_gain.p;
+        case MVS_MRF_BEST_SEL: return ctx->m_best_sel.p;
+    }
+    throw StatusError(MVS_ERR_INVALID, "bad array selector");
+}
+}  // namespace mvs
+
+using namespace mvs;
+
+#define MVS_API_BEGIN try { MVS_HIP(hipSetDevice(ctx->device));
+#define MVS_API_END                                                               \
+    } catch (const StatusError& e) { return api_fail(e.st, e.what()); }           \
+      catch (const HipError& e) { return api_fail(MVS_ERR_HIP, e.what()); }       \
+      catch (const std::exception& e) { return api_fail(MVS_ERR_HIP, e.what()); } \
+    return MVS_OK;
+
+extern "C" {
+
+mvs_status mvs_ctx_dc_get_max(mvs_ctx* ctx, float* dst) {
+    if (!ctx || !dst) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (ctx->dc_phase < 1) return api_fail(MVS_ERR_STATE, "dc_phase1 first");
+    MVS_API_BEGIN
+    MVS_HIP(hipMemcpyAsync(dst, ctx->max_q.p, sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+mvs_status mvs_ctx_dc_set_max(mvs_ctx* ctx, const float* src) {
+    if (!ctx || !src) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (ctx->dc_phase < 1) return api_fail(MVS_ERR_STATE, "dc_phase1 first");
+    MVS_API_BEGIN
+    MVS_HIP(hipMemcpyAsync(ctx->max_q.p, src, sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+mvs_status mvs_ctx_dc_get_histogram(mvs_ctx* ctx, uint32_t* dst) {
+    if (!ctx || !dst) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (ctx->dc_phase < 2) return api_fail(MVS_ERR_STATE, "dc_phase2 first");
+    MVS_API_BEGIN
+    MVS_HIP(hipMemcpyAsync(dst, ctx->hist.p, MVS_HIST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+mvs_status mvs_ctx_dc_set_histogram(mvs_ctx* ctx, const uint32_t* src) {
+    if (!ctx || !src) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (ctx->dc_phase < 2) return api_fail(MVS_ERR_STATE, "dc_phase2 first");
+    MVS_API_BEGIN
+    MVS_HIP(hipMemcpyAsync(ctx->hist.p, src, MVS_HIST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_costs_export(mvs_ctx* ctx, uint32_t* counts, uint16_t* view_id, float* cost) {
+    if (!ctx || !counts) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (!ctx->have_costs) return api_fail(MVS_ERR_STATE, "no data costs on the device");
+    MVS_API_BEGIN
+    const uint32_t F = ctx->csr_faces;
+    if (F) { hipLaunchKernelGGL(counts_kernel, dim3((F + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, F, counts); MVS_LAUNCH_CHECK(); }
+    if (ctx->csr_nnz && view_id) MVS_HIP(hipMemcpyAsync(view_id, ctx->r_view, ctx->csr_nnz * sizeof(uint16_t), hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->csr_nnz && cost) MVS_HIP(hipMemcpyAsync(cost, ctx->r_cost, ctx->csr_nnz * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device, const mvs_mrf_params* params) {
+    if (!ctx || !adj_ptr || !adj) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (!ctx->have_costs) return api_fail(MVS_ERR_STATE, "mrf setup needs data costs");
+    MVS_API_BEGIN
+    mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
+    set_adjacency(ctx, adj_ptr, adj, adj_on_device);
+    mrf_setup(ctx, &P);
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
+    if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad node range");
+    MVS_API_BEGIN
+    mrf_sweep(ctx, nb0, ne0);
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx, uint64_t n, void* dst) {
+    if (!ctx || (n && (!idx || !dst))) return api_fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    if (n) {
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (uint32_t*)dst);
+        MVS_LAUNCH_CHECK();
+    }
+    MVS_API_END
+}
+mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx, uint64_t n, const void* src) {
+    if (!ctx || (n && (!idx || !src))) return api_fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    if (n) {
+        hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (const uint32_t*)src);
+        MVS_LAUNCH_CHECK();
+    }
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_energy(mvs_ctx* ctx, int which_sel, uint32_t nb0, uint32_t ne0, uint64_t* dst) {
+    if (!ctx || !dst || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad argument");
+    if (which_sel != MVS_MRF_SEL && which_sel != MVS_MRF_BEST_SEL) return api_fail(MVS_ERR_INVALID, "energy: SEL or BEST_SEL");
+    MVS_API_BEGIN
+    mrf_energy(ctx, mrf_array(ctx, which_sel), nb0, ne0);
+    MVS_HIP(hipMemcpyAsync(dst, ctx->m_energy.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_keep_best(mvs_ctx* ctx) {
+    if (!ctx) return api_fail(MVS_ERR_INVALID, "ctx is null");
+    MVS_API_BEGIN
+    if (ctx->csr_faces) MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, (size_t)ctx->csr_faces * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
+    if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad node range");
+    MVS_API_BEGIN
+    mrf_icm_gain(ctx, ctx->m_best_sel.p, nb0, ne0);
+    MVS_API_END
+}
+mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* moved) {
+    if (!ctx || !moved || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad argument");
+    MVS_API_BEGIN
+    mrf_icm_apply(ctx, ctx->m_best_sel.p, ctx->m_best_sel.p, nb0, ne0);  // in place: apply reads only gains of neighbours
+    MVS_HIP(hipMemcpyAsync(moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* labels, uint32_t* unseen_out) {
+    if (!ctx || !labels || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad argument");
+    MVS_API_BEGIN
+    uint32_t bu[2];
+    mrf_labels(ctx, ctx->m_best_sel.p, nb0, ne0, labels, bu);
+    if (unseen_out) *unseen_out = bu[1];
+    if (bu[0]) throw StatusError(MVS_ERR_LABELING, "Incorrect labeling");
+    MVS_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,307 @@
+"""ctypes binding of csrc/libmvs_viewsel.so (include/mvs_viewsel.h).
+
+Mirrors the reference interface for the path:
+    calculate_data_costs(mesh, texture_views, settings) -> DataCosts   (libs/tex/texturing.h:66-69)
+    view_selection(data_costs, graph, settings)  -> labels              (libs/tex/texturing.h:79-80)
+Arrays may be numpy arrays (host) or torch CUDA tensors (device-resident; torch
+is only used for the device memory and the stream).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_viewsel.so")
+
+
+class MvsError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s (status %d)" % (message, status))
+        self.status = status
+
+
+class CMesh(C.Structure):
+    _fields_ = [("n_verts", C.c_uint32), ("n_faces", C.c_uint32), ("verts", C.c_void_p), ("faces", C.c_void_p),
+                ("face_normals", C.c_void_p)]
+
+
+class CView(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("viewdir", C.c_float * 3), ("K", C.c_float * 9), ("w2c", C.c_float * 16),
+                ("width", C.c_int32), ("height", C.c_int32), ("rgb", C.c_void_p)]
+
+
+class Settings(C.Structure):
+    """tex::Settings fields read by the path (libs/tex/settings.h:85,87,90)."""
+    _fields_ = [("data_term", C.c_int32), ("outlier_removal", C.c_int32), ("geometric_visibility_test", C.c_int32)]
+
+    DATA_TERMS = {"area": 0, "gmi": 1}                                        # settings.h:113-116
+    OUTLIER = {"none": 0, "gauss_damping": 1, "gauss_clamping": 2}           # settings.h:123-126
+
+    def __init__(self, data_term="gmi", outlier_removal="none", geometric_visibility_test=True):
+        super().__init__(self.DATA_TERMS[data_term] if isinstance(data_term, str) else int(data_term),
+                         self.OUTLIER[outlier_removal] if isinstance(outlier_removal, str) else int(outlier_removal),
+                         1 if geometric_visibility_test else 0)
+
+
+class CCsr(C.Structure):
+    _fields_ = [("n_faces", C.c_uint32), ("n_views", C.c_uint32), ("nnz", C.c_uint64), ("col_ptr", C.c_void_p),
+                ("view_id", C.c_void_p), ("cost", C.c_void_p)]
+
+
+class MrfParams(C.Structure):
+    _fields_ = [("max_sweeps", C.c_int32), ("min_sweeps", C.c_int32), ("window", C.c_int32),
+                ("min_improvement", C.c_float), ("damping", C.c_float), ("rho", C.c_float), ("icm_iters", C.c_int32)]
+
+
+class MrfStats(C.Structure):
+    _fields_ = [("energy_fixed", C.c_uint64), ("energy", C.c_double), ("cut_edges", C.c_uint64), ("sweeps", C.c_uint32),
+                ("icm_iters", C.c_uint32), ("unseen", C.c_uint32)]
+
+
+class DcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("pairs", "cull_backface", "cull_angle", "cull_outside", "cull_occluded",
+                                           "cull_zero_quality", "nnz_pre", "nnz", "rays", "ray_nodes", "ray_tris")] + \
+               [("max_quality", C.c_float), ("percentile", C.c_float)]
+
+
+def _stats_dict(s):
+    return {f[0]: getattr(s, f[0]) for f in s._fields_}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MvsError(-1, "HIP library %s is missing: run `python mvs-texturing_amd/build.py` "
+                           "(or __graft_entry__.build()); there is no CPU fallback" % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    L.mvs_last_error.restype = C.c_char_p
+    L.mvs_status_string.restype = C.c_char_p
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    sig = {
+        "mvs_mrf_default_params": [C.POINTER(MrfParams)], "mvs_default_settings": [C.POINTER(Settings)],
+        "mvs_data_costs": [C.POINTER(CMesh), C.POINTER(CView), u32, C.POINTER(Settings), C.POINTER(CCsr), C.POINTER(DcStats)],
+        "mvs_csr_free": [C.POINTER(CCsr)],
+        "mvs_view_selection": [C.POINTER(CCsr), vp, vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
+        "mvs_write_spt": [C.POINTER(CCsr), C.c_char_p], "mvs_read_spt": [C.c_char_p, C.POINTER(CCsr)],
+        "mvs_write_labeling_vec": [vp, u32, C.c_char_p],
+        "mvs_ctx_create": [i32, C.POINTER(vp)], "mvs_ctx_destroy": [vp], "mvs_ctx_set_stream": [vp, vp],
+        "mvs_ctx_synchronize": [vp], "mvs_set_option": [vp, C.c_char_p, C.c_int64],
+        "mvs_scene_set_mesh": [vp, C.POINTER(CMesh), i32], "mvs_scene_set_views": [vp, C.POINTER(CView), u32, i32],
+        "mvs_scene_set_face_range": [vp, u32, u32],
+        "mvs_ctx_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats)],
+        "mvs_ctx_dc_phase1": [vp, C.POINTER(Settings)], "mvs_ctx_dc_get_max": [vp, vp], "mvs_ctx_dc_set_max": [vp, vp],
+        "mvs_ctx_dc_phase2": [vp], "mvs_ctx_dc_get_histogram": [vp, vp], "mvs_ctx_dc_set_histogram": [vp, vp],
+        "mvs_ctx_dc_phase3": [vp, C.POINTER(DcStats)],
+        "mvs_ctx_costs_device": [vp, C.POINTER(CCsr)], "mvs_ctx_costs_download": [vp, C.POINTER(CCsr), C.POINTER(vp)],
+        "mvs_ctx_costs_upload": [vp, C.POINTER(CCsr), i32], "mvs_ctx_costs_export": [vp, vp, vp, vp],
+        "mvs_ctx_view_selection": [vp, vp, vp, i32, C.POINTER(MrfParams), vp, i32, C.POINTER(MrfStats)],
+        "mvs_ctx_mrf_setup": [vp, vp, vp, i32, C.POINTER(MrfParams)], "mvs_ctx_mrf_sweep": [vp, u32, u32],
+        "mvs_ctx_mrf_gather": [vp, i32, vp, u64, vp], "mvs_ctx_mrf_scatter": [vp, i32, vp, u64, vp],
+        "mvs_ctx_mrf_energy": [vp, i32, u32, u32, vp], "mvs_ctx_mrf_keep_best": [vp],
+        "mvs_ctx_mrf_icm_gain": [vp, u32, u32], "mvs_ctx_mrf_icm_apply": [vp, u32, u32, vp],
+        "mvs_ctx_mrf_labels": [vp, u32, u32, vp, C.POINTER(u32)],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_ctx_destroy"):
+            fn.restype = C.c_int
+    L._declared = sorted(list(sig.keys()) + ["mvs_last_error", "mvs_status_string"])
+    _lib = L
+    return L
+
+
+def _check(L, st):
+    if st != 0:
+        raise MvsError(st, L.mvs_last_error().decode() or L.mvs_status_string(st).decode())
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    """(pointer, on_device) of a numpy array or torch tensor."""
+    if a is None:
+        return None, 0
+    if _is_torch(a):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr()), 1 if a.is_cuda else 0
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p), 0
+
+
+def default_mrf_params(**kw):
+    p = MrfParams()
+    load_library().mvs_mrf_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class DataCosts:
+    """tex::DataCosts (SparseTable<u32,u16,float>, libs/tex/sparse_table.h) as CSR by face."""
+
+    def __init__(self, n_faces, n_views, col_ptr, view_id, cost, quality=None):
+        self.n_faces, self.n_views = int(n_faces), int(n_views)
+        self.col_ptr, self.view_id, self.cost, self.quality = col_ptr, view_id, cost, quality
+
+    cols = property(lambda self: self.n_faces)   # SparseTable::cols()
+    rows = property(lambda self: self.n_views)   # SparseTable::rows()
+
+    @property
+    def nnz(self):
+        return int(self.col_ptr[-1])
+
+    def col(self, i):
+        """SparseTable::col(i): list of (view_id, cost)"""
+        a, b = int(self.col_ptr[i]), int(self.col_ptr[i + 1])
+        return list(zip(self.view_id[a:b].tolist(), self.cost[a:b].tolist()))
+
+    def _struct(self):
+        s = CCsr(self.n_faces, self.n_views, self.nnz, 0, 0, 0)
+        s.col_ptr, dev0 = _ptr(self.col_ptr)
+        s.view_id, dev1 = _ptr(self.view_id)
+        s.cost, dev2 = _ptr(self.cost)
+        assert dev0 == dev1 == dev2
+        return s, dev0
+
+    def save_to_file(self, path):
+        """SparseTable::save_to_file (libs/tex/sparse_table.h:112-136)"""
+        L = load_library()
+        s, dev = self._struct()
+        assert not dev, "download first"
+        _check(L, L.mvs_write_spt(C.byref(s), path.encode()))
+
+
+class Context:
+    """Resident scene + results on one GPU (mvs_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L, self.L.mvs_ctx_create(device, C.byref(h)))
+        self.h = h
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mvs_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_stream(self, stream_handle):
+        _check(self.L, self.L.mvs_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        _check(self.L, self.L.mvs_ctx_synchronize(self.h))
+
+    def set_option(self, name, value):
+        _check(self.L, self.L.mvs_set_option(self.h, name.encode(), int(value)))
+
+    def set_mesh(self, verts, faces, normals):
+        pv, d0 = _ptr(verts); pf, d1 = _ptr(faces); pn, d2 = _ptr(normals)
+        assert d0 == d1 == d2
+        m = CMesh(int(verts.shape[0]), int(faces.shape[0]), pv, pf, pn)
+        self._keep["mesh"] = (verts, faces, normals)
+        self.n_faces = int(faces.shape[0])
+        _check(self.L, self.L.mvs_scene_set_mesh(self.h, C.byref(m), d0))
+
+    def set_views(self, cams, images):
+        """cams: dict of arrays pos, viewdir, K, w2c, width, height; images: list of (H,W,3) u8 numpy / torch cuda"""
+        V = len(images)
+        arr = (CView * V)()
+        dev = None
+        for j in range(V):
+            v = arr[j]
+            v.pos[:] = np.asarray(cams["pos"][j], dtype=np.float32).tolist()
+            v.viewdir[:] = np.asarray(cams["viewdir"][j], dtype=np.float32).tolist()
+            v.K[:] = np.asarray(cams["K"][j], dtype=np.float32).ravel().tolist()
+            v.w2c[:] = np.asarray(cams["w2c"][j], dtype=np.float32).ravel().tolist()
+            v.width, v.height = int(cams["width"][j]), int(cams["height"][j])
+            p, d = _ptr(images[j])
+            v.rgb = p
+            assert dev is None or dev == d
+            dev = d
+        self._keep["views"] = images
+        self.n_views = V
+        _check(self.L, self.L.mvs_scene_set_views(self.h, arr, V, dev or 0))
+
+    def set_face_range(self, begin, end):
+        _check(self.L, self.L.mvs_scene_set_face_range(self.h, begin, end))
+
+    def data_costs(self, settings=None):
+        st = settings or Settings()
+        ds = DcStats()
+        _check(self.L, self.L.mvs_ctx_data_costs(self.h, C.byref(st), C.byref(ds)))
+        return _stats_dict(ds)
+
+    def costs_download(self):
+        out = CCsr(); q = C.c_void_p()
+        _check(self.L, self.L.mvs_ctx_costs_download(self.h, C.byref(out), C.byref(q)))
+        F, nnz = out.n_faces, out.nnz
+        def grab(ptr, ctype, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (max(n, 1),))[:n].copy()
+        res = DataCosts(F, out.n_views, grab(out.col_ptr, C.c_uint32, F + 1), grab(out.view_id, C.c_uint16, nnz),
+                        grab(out.cost, C.c_float, nnz), grab(q.value, C.c_float, nnz))
+        self.L.mvs_csr_free(C.byref(out))
+        C.CDLL(None).free(q)
+        return res
+
+    def costs_upload(self, dc):
+        s, dev = dc._struct()
+        self._keep["costs"] = dc
+        _check(self.L, self.L.mvs_ctx_costs_upload(self.h, C.byref(s), dev))
+
+    def view_selection(self, adj_ptr, adj, params=None, labels_out=None):
+        """tex::view_selection on the resident costs; returns (labels u32[F], stats)."""
+        p = params or default_mrf_params()
+        pa, d0 = _ptr(adj_ptr); pb, d1 = _ptr(adj)
+        assert d0 == d1
+        F = int(adj_ptr.shape[0]) - 1
+        if labels_out is None:
+            labels_out = np.zeros(F, dtype=np.uint32)
+        pl, dl = _ptr(labels_out)
+        ms = MrfStats()
+        self._keep["adj"] = (adj_ptr, adj)
+        _check(self.L, self.L.mvs_ctx_view_selection(self.h, pa, pb, d0, C.byref(p), pl, dl, C.byref(ms)))
+        return labels_out, _stats_dict(ms)
+
+
+def calculate_data_costs(scene, settings=None, ctx=None):
+    """tex::calculate_data_costs(mesh, &texture_views, settings, &data_costs) on a synth.Scene-like
+    object (verts, faces, normals, cams, images).  Returns (DataCosts on the host, stats)."""
+    own = ctx is None
+    ctx = ctx or Context()
+    try:
+        ctx.set_mesh(scene.verts, scene.faces, scene.normals)
+        ctx.set_views(scene.cams, scene.images)
+        stats = ctx.data_costs(settings)
+        return ctx.costs_download(), stats
+    finally:
+        if own:
+            ctx.close()
+
+
+def view_selection(data_costs, adj_ptr, adj, params=None, ctx=None):
+    """tex::view_selection(data_costs, &graph, settings): returns (UniGraph labels, stats)."""
+    own = ctx is None
+    ctx = ctx or Context()
+    try:
+        ctx.costs_upload(data_costs)
+        return ctx.view_selection(np.ascontiguousarray(adj_ptr, dtype=np.uint32), np.ascontiguousarray(adj, dtype=np.uint32), params)
+    finally:
+        if own:
+            ctx.close()

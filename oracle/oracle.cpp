@@ -223,10 +223,14 @@ inline void rgb_to_ycbcr(float* v) {
 // ---------------------------------------------------------------------------
 // Ray / triangle any-hit.  rayint's acc::BVHTree is absent and
 // the reference uses it purely as a boolean (calculate_data_costs.cpp:201-212),
-// so the test is DEFINED HERE: Moeller-Trumbore in fp32, fixed operation order,
-// no epsilon on the barycentrics, hit iff t in [tmin, tmax].  The result is the
-// OR over ALL triangles, i.e. independent of any acceleration structure.
-inline bool ray_tri(V3 orig, V3 dir, float tmin, float tmax, V3 a, V3 b, V3 c) {
+// so the test is DEFINED HERE: Moeller-Trumbore in fp32 on {a, e1 = b-a, e2 = c-a},
+// fixed operation order, no epsilon on the barycentrics, t in [tmin, tmax], and
+// the computed hit point must lie in the triangle's bounding box grown by `pad`
+// (pad = 1e-5 * max(scene extent, max |coordinate|) + 1e-30).  The last clause
+// makes any conservative box culling exact: the result is the OR over ALL
+// triangles, i.e. independent of the acceleration structure (tests compare the
+// BVH with the brute-force loop).
+inline bool ray_tri(V3 orig, V3 dir, float tmin, float tmax, float pad, V3 a, V3 b, V3 c) {
     const V3 e1 = b - a, e2 = c - a;
     const V3 pv = cross(dir, e2);
     const float det = dot(e1, pv);
@@ -239,7 +243,13 @@ inline bool ray_tri(V3 orig, V3 dir, float tmin, float tmax, V3 a, V3 b, V3 c) {
     const float v = dot(dir, qv) * inv;
     if (!(v >= 0.0f && u + v <= 1.0f)) return false;
     const float t = dot(e2, qv) * inv;
-    return t >= tmin && t <= tmax;
+    if (!(t >= tmin && t <= tmax)) return false;
+    const V3 bb = a + e1, cc = a + e2;
+    const float h[3] = {orig.x + t * dir.x, orig.y + t * dir.y, orig.z + t * dir.z};
+    const float lo[3] = {std::fmin(a.x, std::fmin(bb.x, cc.x)), std::fmin(a.y, std::fmin(bb.y, cc.y)), std::fmin(a.z, std::fmin(bb.z, cc.z))};
+    const float hi[3] = {std::fmax(a.x, std::fmax(bb.x, cc.x)), std::fmax(a.y, std::fmax(bb.y, cc.y)), std::fmax(a.z, std::fmax(bb.z, cc.z))};
+    for (int k = 0; k < 3; ++k) if (!(h[k] >= lo[k] - pad && h[k] <= hi[k] + pad)) return false;
+    return true;
 }
 
 }  // namespace
@@ -270,7 +280,7 @@ void bvh_build_rec(orc_bvh& b, const orc_mesh& m, std::vector<V3>& cent, uint32_
         const float c[3] = {cent[t].x, cent[t].y, cent[t].z};
         for (int a = 0; a < 3; ++a) { cmin[a] = std::min(cmin[a], c[a]); cmax[a] = std::max(cmax[a], c[a]); }
     }
-    for (int a = 0; a < 3; ++a) { b.nodes[node].bmin[a] = bmin[a] - b.pad; b.nodes[node].bmax[a] = bmax[a] + b.pad; }
+    for (int a = 0; a < 3; ++a) { b.nodes[node].bmin[a] = bmin[a] - 4.0f * b.pad; b.nodes[node].bmax[a] = bmax[a] + 4.0f * b.pad; }
     b.nodes[node].first = first; b.nodes[node].count = count; b.nodes[node].left = b.nodes[node].right = 0;
     if (count <= 4) return;
     int axis = 0;
@@ -303,7 +313,20 @@ inline bool ray_box(const orc_bvh::Node& n, V3 o, V3 inv, float tmin, float tmax
 
 struct RayCounters { uint64_t nodes = 0, tris = 0; };
 
-bool any_hit(const orc_bvh* b, const orc_mesh& m, V3 origin, V3 view_pos, bool brute, RayCounters* rc) {
+// pad = 1e-5 * max(scene extent, max |coordinate|) + 1e-30 over the exact vertex min/max
+float scene_pad(const orc_mesh& m) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t v = 0; v < m.n_verts; ++v)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], m.verts[3 * (size_t)v + a]); hi[a] = std::fmax(hi[a], m.verts[3 * (size_t)v + a]); }
+    float ext = 0.0f, mag = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        ext = std::fmax(ext, hi[a] - lo[a]);
+        mag = std::fmax(mag, std::fmax(std::abs(lo[a]), std::abs(hi[a])));
+    }
+    return 1e-5f * std::fmax(ext, mag) + 1e-30f;
+}
+
+bool any_hit(const orc_bvh* b, const orc_mesh& m, float pad, V3 origin, V3 view_pos, bool brute, RayCounters* rc) {
     /* calculate_data_costs.cpp:201-206 */
     V3 dir = view_pos - origin;
     const float tmax = norm(dir);
@@ -311,7 +334,7 @@ bool any_hit(const orc_bvh* b, const orc_mesh& m, V3 origin, V3 view_pos, bool b
     dir = dir / norm(dir);
     auto tri_hit = [&](uint32_t t) {
         const uint32_t* f = m.faces + 3 * (size_t)t;
-        return ray_tri(origin, dir, tmin, tmax, load3(m.verts + 3 * (size_t)f[0]),
+        return ray_tri(origin, dir, tmin, tmax, pad, load3(m.verts + 3 * (size_t)f[0]),
                        load3(m.verts + 3 * (size_t)f[1]), load3(m.verts + 3 * (size_t)f[2]));
     };
     if (brute) {
@@ -513,13 +536,7 @@ void orc_erode_validity_mask(uint8_t* mask, int w, int h) {
 orc_bvh* orc_bvh_build(const orc_mesh* mesh) {
     orc_bvh* b = new orc_bvh;
     const orc_mesh& m = *mesh;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t v = 0; v < m.n_verts; ++v)
-        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], m.verts[3 * (size_t)v + a]); hi[a] = std::max(hi[a], m.verts[3 * (size_t)v + a]); }
-    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-    float mag = 0.0f;
-    for (int a = 0; a < 3; ++a) mag = std::max(mag, std::max(std::abs(lo[a]), std::abs(hi[a])));
-    b->pad = 1e-5f * std::max(ext, mag) + 1e-30f;
+    b->pad = scene_pad(m);
     std::vector<V3> cent(m.n_faces);
     b->tri.resize(m.n_faces);
     for (uint32_t t = 0; t < m.n_faces; ++t) {
@@ -536,7 +553,7 @@ void orc_bvh_free(orc_bvh* b) { delete b; }
 
 int orc_ray_occluded(const orc_bvh* b, const orc_mesh* mesh, const float origin[3],
                      const float view_pos[3], int brute) {
-    return any_hit(b, *mesh, load3(origin), load3(view_pos), brute != 0, nullptr) ? 1 : 0;
+    return any_hit(b, *mesh, scene_pad(*mesh), load3(origin), load3(view_pos), brute != 0, nullptr) ? 1 : 0;
 }
 
 // Histogram (histogram.cpp:22-63): add_value + get_approx_percentile
@@ -583,6 +600,7 @@ int orc_data_costs(const orc_mesh* mesh, const orc_view* views, uint32_t n_views
     double t0 = now_s();
     orc_bvh* bvh = nullptr;
     if (st.geometric_visibility_test && bvh_mode == 0) bvh = orc_bvh_build(mesh);  /* :144 */
+    const float pad = scene_pad(m);
     S.t_bvh = now_s() - t0;
 
     // per-view lists of (face, info): the reference's thread-local vectors (:150,227-228)
@@ -631,7 +649,7 @@ int orc_data_costs(const orc_mesh* mesh, const orc_view* views, uint32_t n_views
                 const V3* samples[] = {&v1, &v2, &v3};
                 for (int k = 0; k < 3; ++k) {
                     c_rays++;
-                    if (any_hit(bvh, m, *samples[k], view_pos, bvh_mode != 0, &rc)) { visible = false; break; }
+                    if (any_hit(bvh, m, pad, *samples[k], view_pos, bvh_mode != 0, &rc)) { visible = false; break; }
                 }
                 if (!visible) { c_occ++; continue; }
             }
