@@ -287,7 +287,9 @@ static void make_camera(double px, double py, double pz, float focal_px, int w, 
 }
 
 // layout 0: the 6 axis directions (n_views must be 6); layout 1: Fibonacci sphere.
-int synth_cameras(uint32_t n_views, int layout, float radius, int w, int h, synth_camera* out) {
+// zoom_odd scales the focal length of odd-indexed cameras (> 1 crops the sphere, exercising the
+// valid_pixel cull of calculate_data_costs.cpp:191).
+int synth_cameras(uint32_t n_views, int layout, float radius, int w, int h, float zoom_odd, synth_camera* out) {
     // sphere of radius ~1.1 spans ~90 % of the short image side
     const float rs = 1.1f;
     const float tan_half = rs / std::sqrt(radius * radius - rs * rs);
@@ -296,7 +298,7 @@ int synth_cameras(uint32_t n_views, int layout, float radius, int w, int h, synt
         if (n_views != 6) return -1;
         const double ax[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
         for (int k = 0; k < 6; ++k)
-            make_camera(ax[k][0] * radius, ax[k][1] * radius, ax[k][2] * radius, focal, w, h, out + k);
+            make_camera(ax[k][0] * radius, ax[k][1] * radius, ax[k][2] * radius, (k & 1) ? focal * zoom_odd : focal, w, h, out + k);
         return 0;
     }
     const double golden = 2.399963229728653;  // pi * (3 - sqrt(5))
@@ -304,7 +306,7 @@ int synth_cameras(uint32_t n_views, int layout, float radius, int w, int h, synt
         double z = 1.0 - (2.0 * k + 1.0) / (double)n_views;
         double rr = std::sqrt(std::max(0.0, 1.0 - z * z));
         double phi = golden * (double)k;
-        make_camera(radius * rr * std::cos(phi), radius * rr * std::sin(phi), radius * z, focal, w, h, out + k);
+        make_camera(radius * rr * std::cos(phi), radius * rr * std::sin(phi), radius * z, (k & 1) ? focal * zoom_odd : focal, w, h, out + k);
     }
     return 0;
 }

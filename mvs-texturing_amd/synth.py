@@ -45,7 +45,7 @@ def _load():
         _lib.synth_icosphere.argtypes = [C.c_uint32, C.c_float, C.c_uint32, C.POINTER(_Mesh)]
         _lib.synth_build_adjacency.argtypes = [C.POINTER(_Mesh)]
         _lib.synth_mesh_free.argtypes = [C.POINTER(_Mesh)]
-        _lib.synth_cameras.argtypes = [C.c_uint32, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(_Camera)]
+        _lib.synth_cameras.argtypes = [C.c_uint32, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float, C.POINTER(_Camera)]
         _lib.synth_render.argtypes = [C.POINTER(_Camera), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     return _lib
 
@@ -69,7 +69,7 @@ class Scene:
 
 
 def make_scene(n, n_views, width, height, displacement=0.0, layout=1, seed=1234, image_seed=99,
-               radius=3.0, adjacency=True, render=True, black_corner=0):
+               radius=3.0, adjacency=True, render=True, black_corner=0, zoom_odd=1.0):
     lib = _load()
     m = _Mesh()
     rc = lib.synth_icosphere(n, displacement, seed, C.byref(m))
@@ -86,7 +86,7 @@ def make_scene(n, n_views, width, height, displacement=0.0, layout=1, seed=1234,
         s.adj = np.ctypeslib.as_array(m.adj, (int(s.adj_ptr[-1]),)).copy()
     lib.synth_mesh_free(C.byref(m))
     cams = (_Camera * n_views)()
-    rc = lib.synth_cameras(n_views, layout, radius, width, height, cams)
+    rc = lib.synth_cameras(n_views, layout, radius, width, height, zoom_odd, cams)
     if rc:
         raise RuntimeError("synth_cameras failed: %d" % rc)
     s.cams = {
