@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- faces/sec through view selection (data costs + MRF) on N MI355X.
+
+One "step" = one pass of the hot path over the whole synthetic scene with the inputs
+already resident in HBM: tex::calculate_data_costs (image prep, BVH build, culls, rays,
+footprint qualities, normalisation) followed by tex::view_selection (solver setup,
+sweeps to convergence, ICM polish, labels) -- the window the reference times at
+apps/texrecon/texrecon.cpp:96-127.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `value` = faces of the scene / max-over-ranks seconds per
+step.  N > 1 runs the SAME scene partitioned over the ranks (BASELINE.json config 4):
+"scaling": "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: the HIP runtime torch ships is the one the library binds to)
+
+import mvs_texturing_amd as M  # noqa: E402
+from mvs_texturing_amd import multigpu as G  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(scene, faces, normals, adj_ptr, adj, params_kw, budget_s=25.0):
+    """CPU oracle (-O3 -march=native build, OpenMP) on a bounded sample of the same workload:
+    the first F/S faces against the full occluder mesh + the MRF on their induced subgraph."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build_oracle()
+
+    class S:  # scene view with the renumbered faces
+        pass
+    s = S(); s.verts, s.faces, s.normals, s.cams, s.images = scene.verts, faces, normals, scene.cams, scene.images
+    s.n_views, s.n_faces = scene.n_views, len(faces)
+    ncpu = len(os.sched_getaffinity(0))
+    cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 64, 32, 16, 8) if 1 <= c <= ncpu}, reverse=True)
+    F = s.n_faces
+    probe = max(2000, F // 512)
+    best_nt, best_rate = cands[0], 0.0
+    for nt in cands:   # pick the thread count the host actually sustains
+        t = time.time(); _, st = O.data_costs(s, face_range=(0, probe), n_threads=nt, timing=True)
+        rate = probe / max(st["t_infos"] + st["t_post"], 1e-9)
+        if rate > best_rate:
+            best_rate, best_nt = rate, nt
+    n_sample = int(min(F, max(probe, best_rate * budget_s * 0.35)))
+    csr, st = O.data_costs(s, face_range=(0, n_sample), n_threads=best_nt, timing=True)
+    t_dc = st["t_infos"] + st["t_post"]
+    # induced subgraph of the sample
+    ap = adj_ptr[:n_sample + 1].astype(np.int64)
+    sub = adj[:ap[-1]]
+    keep = sub < n_sample
+    ck = np.zeros(len(keep) + 1, dtype=np.int64); ck[1:] = np.cumsum(keep)
+    deg = ck[ap[1:]] - ck[ap[:-1]]
+    sap = np.zeros(n_sample + 1, dtype=np.uint32); sap[1:] = np.cumsum(deg)
+    sadj = np.ascontiguousarray(sub[keep], dtype=np.uint32)
+    t = time.time(); labels, ms = O.view_selection(csr, sap, sadj, O.default_mrf_params(timing=True, **params_kw), n_threads=best_nt, timing=True)
+    t_mrf = ms["t_setup"] + ms["t_solve"]
+    return {"value": n_sample / (t_dc + t_mrf), "unit": "faces/s", "cores": best_nt, "kind": "port",
+            "sample": "first %d of %d faces (all %d views, full mesh as occluders) + MRF on their induced subgraph; "
+                      "oracle -O3 -march=native OpenMP; BVH build and per-view image prep excluded (favours the CPU); "
+                      "t_data_costs=%.2fs t_mrf=%.2fs sweeps=%d" % (n_sample, F, s.n_views, t_dc, t_mrf, ms["sweeps"]),
+            "host_cpus": ncpu}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.md config: 2 = 200k faces / 50 views, 3 = 2M faces / 200 views")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=25.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = dict(M.synth.CONFIGS[args.config])
+    t0 = time.time()
+    scene = M.synth.make_scene(**cfg)
+    perm = G.morton_order(scene.verts, scene.faces)   # contiguous parts = compact patches (METIS stand-in)
+    faces, normals, adj_ptr, adj, _ = G.renumber_faces(scene.faces, scene.normals, scene.adj_ptr, scene.adj, perm)
+    F, V = len(faces), scene.n_views
+    if rank == 0:
+        log("scene: %d faces, %d views %dx%d, built in %.1fs" % (F, V, cfg["width"], cfg["height"], time.time() - t0))
+    part = G.equal_parts(F, world)
+
+    # ---- inputs resident in HBM ----
+    t_v = torch.from_numpy(scene.verts).to(dev)
+    t_f = torch.from_numpy(faces.view(np.int32)).to(dev)
+    t_n = torch.from_numpy(normals).to(dev)
+    t_img = [torch.from_numpy(i).to(dev) for i in scene.images]
+    t_ap = torch.from_numpy(adj_ptr.view(np.int32)).to(dev)
+    t_ad = torch.from_numpy(adj.view(np.int32)).to(dev)
+    t_lab = torch.zeros(F, dtype=torch.int32, device=dev)
+    ctx = M.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("profile", 1)
+    ctx.set_mesh(t_v, t_f, t_n)
+    ctx.set_views(scene.cams, t_img)
+    settings = M.Settings()                      # reference defaults: gmi / none / visibility test on
+    params = M.viewsel.default_mrf_params()
+    info = {}
+
+    def step():
+        if world == 1:
+            st = ctx.data_costs(settings)
+            _, ms = ctx.view_selection(t_ap, t_ad, params, labels_out=t_lab)
+            info["nnz_global"] = int(st["nnz"])
+        else:
+            dc, st = G.sharded_data_costs(ctx, settings, part, rank, dist, device=dev)
+            if "plan" not in info:   # the sparsity pattern is identical every step: plan the halo once (host logic)
+                info["plan"] = G.HaloPlan(dc.col_ptr.cpu().numpy().view(np.uint32), adj_ptr, adj, part, rank)
+                info["hx"] = G.HaloExchange(info["plan"], dev, dist)
+                info["nnz_global"] = int(dc.col_ptr[-1].item())
+            ops = G.GpuShardOps(ctx, t_ap, t_ad, params)
+            labels, ms = G.ShardedViewSelection(ops, info["plan"], params, dev, dist, hx=info["hx"]).run()
+        info["dc"], info["mrf"] = st, ms
+
+    for _ in range(args.warmup):
+        step()
+    ctx.get_profile()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ctx.get_profile()
+    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
+    value = F / (ms_per_step / 1000.0)
+
+    # ---- roofline of the dominant kernel (algorithmic bytes: BASELINE.md section 5) ----
+    dc, mrf = info["dc"], info["mrf"]
+    nnz_global = info["nnz_global"]
+    stages = {k: {"ms_per_step": v[0] / max(args.steps, 1), "launches_per_step": v[1] / max(args.steps, 1)} for k, v in prof.items()}
+    roof = None
+    if "mrf_sweep" in prof and prof["mrf_sweep"][1] > 0:
+        sweep_ms = prof["mrf_sweep"][0] / prof["mrf_sweep"][1]
+        nf_own = int(part[rank + 1] - part[rank])
+        nnz_own = int(dc["nnz"])                             # entries of the nodes this rank sweeps
+        if nnz_own:
+            b_sweep = 30.0 * nnz_own + 12.0 * nf_own       # B_sweep = 30 nnz + 12 F (closed manifold, 3 neighbours)
+            ach = b_sweep / (sweep_ms * 1e-3) / 1e9
+            roof = {"kernel": "mrf_sweep_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sweep_ms, "algorithmic_bytes_per_launch": b_sweep}
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get("mrf_sweep_kernel", {}).get("config%d" % args.config)
+                except Exception:
+                    pass
+
+    out = {"metric": "faces/sec through view-selection (data-cost + MRF)", "value": value, "unit": "faces/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE config %d: displaced icosphere n=%d (%d faces), %d Fibonacci-sphere views %dx%d RGB8, "
+                                  "settings gmi/none/visibility-test (reference defaults)" % (args.config, cfg["n"], F, V, cfg["width"], cfg["height"]),
+                      "faces": F, "views": V, "nnz": nnz_global, "sweeps": int(mrf["sweeps"]), "icm_iters": int(mrf["icm_iters"]),
+                      "energy": float(mrf["energy"]), "partition": "morton-%d" % world},
+           "roofline": roof, "stages": stages}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(scene, faces, normals, adj_ptr, adj,
+                                               dict(max_sweeps=params.max_sweeps, min_sweeps=params.min_sweeps), args.cpu_budget)
+        except Exception as e:  # the baseline is reporting only; never lose the measurement
+            out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,8 +159,12 @@ void mvs_ctx_destroy(mvs_ctx* ctx);
 /* hipStream_t to launch on (NULL = the context's own stream) */
 mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
-/* integer options: "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1) */
+/* integer options: "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1) */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
+
+/* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,
+ * as a JSON object {"stage": [total_ms, launches], ...}; clears the record */
+mvs_status mvs_ctx_get_profile(mvs_ctx* ctx, char* buf, size_t buf_size);
 
 mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device);
 /* views: HOST array of n structs; their rgb pointers are device pointers iff rgb_on_device */

@@ -131,8 +131,37 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     if (n == "count_rays") ctx->count_rays = value != 0;
     else if (n == "lds_bvh_levels") ctx->lds_bvh_levels = (int)value;
     else if (n == "verbose") ctx->verbose = value != 0;
+    else if (n == "profile") ctx->profile = value != 0;
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
+}
+
+// JSON object {"stage": [total_ms, count], ...} of the spans recorded since the last call
+mvs_status mvs_ctx_get_profile(mvs_ctx* ctx, char* buf, size_t buf_size) {
+    if (!ctx || !buf || buf_size < 3) return fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<std::string> names; std::vector<double> ms; std::vector<int> cnt;
+    for (auto& sp : ctx->prof_spans) {
+        float t = 0.0f;
+        MVS_HIP(hipEventElapsedTime(&t, sp.a, sp.b));
+        size_t k = 0;
+        for (; k < names.size(); ++k) if (names[k] == sp.name) break;
+        if (k == names.size()) { names.push_back(sp.name); ms.push_back(0.0); cnt.push_back(0); }
+        ms[k] += t; cnt[k] += 1;
+        ctx->prof_pool.push_back(sp.a); ctx->prof_pool.push_back(sp.b);
+    }
+    ctx->prof_spans.clear();
+    std::string out = "{";
+    for (size_t k = 0; k < names.size(); ++k) {
+        char tmp[160];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": [%.6f, %d]", k ? ", " : "", names[k].c_str(), ms[k], cnt[k]);
+        out += tmp;
+    }
+    out += "}";
+    if (out.size() + 1 > buf_size) throw StatusError(MVS_ERR_INVALID, "profile buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    MVS_API_END
 }
 
 mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device) {
@@ -305,15 +334,15 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
     const uint32_t F = ctx->csr_faces;
     set_adjacency(ctx, adj_ptr, adj, adj_on_device);
-    mrf_setup(ctx, &P);
+    { Prof pr(ctx, "mrf_setup"); mrf_setup(ctx, &P); }
     hipStream_t s = ctx->stream;
     mvs_mrf_stats S; memset(&S, 0, sizeof(S));
     uint64_t best_e = ~0ull;
     std::vector<uint64_t> hist; hist.push_back(~0ull);
     int sw = 1;
     for (; sw <= P.max_sweeps; ++sw) {
-        mrf_sweep(ctx, 0, F);
-        mrf_energy(ctx, ctx->m_sel.p, 0, F);
+        { Prof pr(ctx, "mrf_sweep"); mrf_sweep(ctx, 0, F); }
+        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, ctx->m_sel.p, 0, F); }
         uint64_t e[2]; read_energy(ctx, e);
         if (e[0] < best_e) {
             best_e = e[0];
@@ -331,8 +360,10 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     uint32_t* cur = ctx->m_best_sel.p;
     int it = 0;
     for (; it < P.icm_iters; ++it) {
+        Prof pr(ctx, "mrf_icm");
         mrf_icm_gain(ctx, cur, 0, F);
-        mrf_icm_apply(ctx, cur, cur, 0, F);  // in place: apply reads only the neighbours' gains
+        mrf_icm_apply(ctx, cur, cur, 0, F);
+        pr.end();  // in place: apply reads only the neighbours' gains
         uint32_t moved = 0;
         MVS_HIP(hipMemcpyAsync(&moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MVS_HIP(hipStreamSynchronize(s));

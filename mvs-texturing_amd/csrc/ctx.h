@@ -70,6 +70,10 @@ struct BvhDev {
     uint32_t n_leaves;
 };
 
+// Stage profiler: hipEvent pairs recorded on the context's stream (enabled by
+// mvs_set_option("profile", 1)); read back with mvs_ctx_get_profile.
+struct ProfSpan { std::string name; hipEvent_t a, b; };
+
 struct MrfEdge {      // per directed edge e = (i <- j) in adjacency-CSR order
     uint32_t in_off;  // offset of the message INTO i over e (K_i floats, aligned with i's labels)
     uint32_t out_off; // offset of the message i sends over e, i.e. in_off of the reverse edge (K_j floats)
@@ -83,6 +87,8 @@ struct mvs_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool verbose = false;
+    bool profile = false;
+    std::vector<mvs::ProfSpan> prof_spans; std::vector<hipEvent_t> prof_pool;
     bool count_rays = false;
     int lds_bvh_levels = 0;
     float cos_limit = 0.0f;  // see dmath.h cull_pair
@@ -137,6 +143,19 @@ struct mvs_ctx {
 };
 
 namespace mvs {
+// RAII stage marker; no-op unless ctx->profile
+struct Prof {
+    mvs_ctx* c; size_t idx; bool on;
+    Prof(mvs_ctx* ctx, const char* name) : c(ctx), idx(0), on(ctx->profile) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); } else { MVS_HIP(hipEventCreate(&e)); } return e; };
+        ProfSpan sp{name, get(), get()};
+        MVS_HIP(hipEventRecord(sp.a, c->stream));
+        idx = c->prof_spans.size(); c->prof_spans.push_back(sp);
+    }
+    void end() { if (on) { MVS_HIP(hipEventRecord(c->prof_spans[idx].b, c->stream)); on = false; } }
+    ~Prof() { if (on) (void)hipEventRecord(c->prof_spans[idx].b, c->stream); }
+};
 // generic device exclusive scan (scan.hip): out[i] = sum_{k<i} in[i]; returns total via d_total (device, may be null)
 void exclusive_scan_u32(mvs_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* d_total);
 }  // namespace mvs

@@ -388,8 +388,8 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     ctx->counters.ensure(64);
     MVS_HIP(hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), s));
 
-    upload_views_and_prepare(ctx, gmi);                        /* :157-163 */
-    if (vis) build_bvh(ctx);                                   /* :144 */
+    { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }   /* :157-163 */
+    if (vis) { Prof pr(ctx, "dc_bvh_build"); build_bvh(ctx); }           /* :144 */
 
     const size_t pw = (size_t)V * fwords;
     ctx->pass_bits.ensure(pw + 1); ctx->surv_bits.ensure(pw + 1); ctx->pass_base.ensure(pw + 2);
@@ -400,29 +400,38 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         ctx->max_q.ensure(2); MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
         return;
     }
+    Prof pr_cull(ctx, "dc_cull");
     hipLaunchKernelGGL(cull_kernel, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
                        ctx->cos_limit, ctx->pass_bits.p, ctx->counters.p);
     MVS_LAUNCH_CHECK();
+    pr_cull.end();
     if (vis) {
         const size_t vw = (size_t)V * vwords;
         ctx->need_bits.ensure(vw + 1); ctx->occl_bits.ensure(vw + 1);
         MVS_HIP(hipMemsetAsync(ctx->occl_bits.p, 0, vw * sizeof(unsigned long long), s));
         const dim3 vgrid((ctx->n_verts + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
+        Prof pr_need(ctx, "dc_need");
         hipLaunchKernelGGL(need_kernel, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->n_verts, V, fb, nf, fwords, vwords,
                            ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
         MVS_LAUNCH_CHECK();
+        pr_need.end();
+        Prof pr_rays(ctx, "dc_rays");
         trace_rays(ctx);
+        pr_rays.end();
     }
     // rank of every passing pair
+    Prof pr_rank(ctx, "dc_rank_scan");
     hipLaunchKernelGGL(popc_kernel, dim3((unsigned)((pw + 255) / 256)), dim3(256), 0, s, ctx->pass_bits.p, ctx->pass_base.p, pw);
     MVS_LAUNCH_CHECK();
     ctx->max_q.ensure(4);
     uint32_t* d_total = (uint32_t*)(ctx->max_q.p + 2);
     exclusive_scan_u32(ctx, ctx->pass_base.p, ctx->pass_base.p, pw, d_total);
+    pr_rank.end();
     const uint32_t n_pass = read_u32(ctx, d_total);
     ctx->pq.ensure((size_t)n_pass + 1);
     if (outl) ctx->pcol.ensure(3 * ((size_t)n_pass + 1));
 
+    Prof pr_info(ctx, "dc_face_info");
 #define LAUNCH_INFO(DT, OL, VT)                                                                                              \
     hipLaunchKernelGGL((info_kernel<DT, OL, VT>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
                        fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
@@ -433,6 +442,8 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
                else      { if (vis) LAUNCH_INFO(0, false, true); else LAUNCH_INFO(0, false, false); } }
 #undef LAUNCH_INFO
     MVS_LAUNCH_CHECK();
+    pr_info.end();
+    Prof pr_csr(ctx, "dc_csr");
 
     // CSR by face
     ctx->face_cnt.ensure((size_t)nf + 2);
@@ -469,6 +480,8 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         MVS_LAUNCH_CHECK();
         ctx->csr_nnz = nnz_pre;
     }
+    pr_csr.end();
+    Prof pr_post(ctx, "dc_post");
     ctx->csr_faces = nf; ctx->csr_views = V;
     // local max quality (:278-281)
     MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
@@ -483,6 +496,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
 void dc_phase2(mvs_ctx* ctx) {
     if (ctx->dc_phase != 1) throw StatusError(MVS_ERR_STATE, "dc_phase2 needs dc_phase1");
     hipStream_t s = ctx->stream;
+    Prof pr(ctx, "dc_post");
     ctx->hist.ensure(HIST_BINS + 8);
     MVS_HIP(hipMemsetAsync(ctx->hist.p, 0, (HIST_BINS + 8) * sizeof(uint32_t), s));
     if (ctx->csr_nnz) {
@@ -499,12 +513,14 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     if (ctx->dc_phase != 2) throw StatusError(MVS_ERR_STATE, "dc_phase3 needs dc_phase2");
     hipStream_t s = ctx->stream;
     ctx->pctl.ensure(4);
+    Prof pr(ctx, "dc_post");
     hipLaunchKernelGGL(percentile_kernel, dim3(1), dim3(64), 0, s, ctx->hist.p, ctx->max_q.p, 0.995f, ctx->pctl.p);
     MVS_LAUNCH_CHECK();
     if (ctx->csr_nnz) {
         hipLaunchKernelGGL(cost_kernel, dim3(2048), dim3(256), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, ctx->pctl.p, ctx->csr_cost.p);
         MVS_LAUNCH_CHECK();
     }
+    pr.end();
     unsigned long long hc[16]; float mq = 0.0f, pc = 0.0f;
     MVS_HIP(hipMemcpyAsync(hc, ctx->counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipMemcpyAsync(&mq, ctx->max_q.p, sizeof(float), hipMemcpyDeviceToHost, s));

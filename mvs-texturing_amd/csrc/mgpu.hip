@@ -103,6 +103,7 @@ mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32
 mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad node range");
     MVS_API_BEGIN
+    Prof pr(ctx, "mrf_sweep");
     mrf_sweep(ctx, nb0, ne0);
     MVS_API_END
 }

@@ -1,0 +1,349 @@
+"""Multi-GPU driver for the view-selection path: one process per GPU,
+torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" for the CPU tests).
+
+Sharding (DESIGN.md "Multi-GPU"):
+  * faces are renumbered in Morton order of their centroids and cut into P
+    contiguous, equal parts (METIS is not available);
+  * data costs: rank r evaluates its own faces against the FULL scene (mesh,
+    BVH and images are replicated), then one all-reduce(MAX) of the maximum
+    quality and one all-reduce(SUM) of the 10000-bin histogram reproduce the
+    global barrier of postprocess_face_infos (calculate_data_costs.cpp:278-288);
+    the per-rank CSR pieces are all-gathered so every rank holds the whole table;
+  * MRF: every rank owns the nodes of its part and sweeps only those; after
+    each sweep the messages over cut edges and the decoded selections of
+    boundary nodes are exchanged with an all-to-all whose index lists are
+    planned here, on the host, from col_ptr + adjacency alone; the exact
+    fixed-point energy is all-reduced so that every rank takes the same
+    stop decision.  The schedule is synchronous, so labels are bit-identical
+    for any number of parts.
+
+Everything in this file is host logic (numpy / torch.distributed); the compute
+is behind the C ABI (viewsel.Context).
+"""
+import numpy as np
+
+MSG, SEL, GAIN, BEST_SEL = 0, 1, 2, 3
+
+
+# --------------------------------------------------------------------------
+# partitioning
+# --------------------------------------------------------------------------
+def _expand_bits_10(v):
+    v = v.astype(np.uint32) & 0x3FF
+    v = (v | (v << 16)) & 0x030000FF
+    v = (v | (v << 8)) & 0x0300F00F
+    v = (v | (v << 4)) & 0x030C30C3
+    v = (v | (v << 2)) & 0x09249249
+    return v
+
+
+def morton_order(verts, faces):
+    """Permutation of the faces by the 30-bit Morton code of their centroid (stable)."""
+    c = verts[faces].mean(axis=1)
+    lo, hi = c.min(axis=0), c.max(axis=0)
+    q = np.clip((c - lo) / np.maximum(hi - lo, 1e-30) * 1024.0, 0, 1023).astype(np.uint32)
+    code = (_expand_bits_10(q[:, 0]) << 2) | (_expand_bits_10(q[:, 1]) << 1) | _expand_bits_10(q[:, 2])
+    return np.argsort(code, kind="stable").astype(np.uint32)
+
+
+def renumber_faces(faces, normals, adj_ptr, adj, perm):
+    """Applies new_id = position in perm.  Adjacency LIST ORDER of every face is preserved
+    (the solver sums messages in list order)."""
+    F = faces.shape[0]
+    inv = np.empty(F, dtype=np.uint32); inv[perm] = np.arange(F, dtype=np.uint32)
+    deg = np.diff(adj_ptr).astype(np.int64)
+    new_deg = deg[perm]
+    new_ptr = np.zeros(F + 1, dtype=np.uint32); new_ptr[1:] = np.cumsum(new_deg)
+    src = np.repeat(adj_ptr[:-1].astype(np.int64)[perm], new_deg) + (np.arange(int(new_ptr[-1])) - np.repeat(new_ptr[:-1].astype(np.int64), new_deg))
+    new_adj = inv[adj[src]]
+    return np.ascontiguousarray(faces[perm]), np.ascontiguousarray(normals[perm]), new_ptr, np.ascontiguousarray(new_adj), inv
+
+
+def equal_parts(n, parts):
+    return np.array([(n * p) // parts for p in range(parts + 1)], dtype=np.uint32)
+
+
+# --------------------------------------------------------------------------
+# halo plan (pure numpy; identical on every rank)
+# --------------------------------------------------------------------------
+class HaloPlan:
+    """Index lists for rank `me`: for every peer p
+         msg_send[p] / msg_recv[p]   message words (offsets into the global message array)
+         node_send[p] / node_recv[p] node ids (selections / gains of boundary nodes)
+    ordered identically on both ends of every pair."""
+
+    def __init__(self, col_ptr, adj_ptr, adj, part_begin, me):
+        col_ptr = np.asarray(col_ptr, dtype=np.int64); adj_ptr = np.asarray(adj_ptr, dtype=np.int64); adj = np.asarray(adj, dtype=np.int64)
+        F = len(col_ptr) - 1
+        P = len(part_begin) - 1
+        K = np.diff(col_ptr)
+        deg = np.diff(adj_ptr)
+        dst = np.repeat(np.arange(F, dtype=np.int64), deg)      # i of edge e = (i <- j)
+        src = adj                                               # j
+        valid = (K[dst] > 0) & (K[src] > 0)
+        size = np.where(valid, K[dst], 0)
+        in_off = np.zeros(len(size) + 1, dtype=np.int64); in_off[1:] = np.cumsum(size)
+        if in_off[-1] >= 2 ** 32:
+            raise ValueError("message array exceeds 2^32 words")
+        pb = np.asarray(part_begin, dtype=np.int64)
+        own_dst = np.searchsorted(pb, dst, side="right") - 1
+        own_src = np.searchsorted(pb, src, side="right") - 1
+        cut = valid & (own_dst != own_src)
+        self.me, self.P, self.total_words = me, P, int(in_off[-1])
+        self.node_begin, self.node_end = int(pb[me]), int(pb[me + 1])
+        self.msg_send, self.msg_recv, self.node_send, self.node_recv = [], [], [], []
+        empty = np.zeros(0, dtype=np.uint32)
+
+        def expand(edges):
+            if len(edges) == 0:
+                return empty
+            ln = size[edges]
+            base = np.repeat(in_off[edges], ln)
+            within = np.arange(int(ln.sum())) - np.repeat(np.cumsum(ln) - ln, ln)
+            return (base + within).astype(np.uint32)
+
+        for p in range(P):
+            if p == me:
+                self.msg_send.append(empty); self.msg_recv.append(empty); self.node_send.append(empty); self.node_recv.append(empty)
+                continue
+            e_send = np.nonzero(cut & (own_src == me) & (own_dst == p))[0]   # produced here, consumed by p
+            e_recv = np.nonzero(cut & (own_dst == me) & (own_src == p))[0]   # produced by p, consumed here
+            self.msg_send.append(expand(e_send)); self.msg_recv.append(expand(e_recv))
+            self.node_send.append(np.unique(src[e_send]).astype(np.uint32))  # my nodes adjacent to p's nodes
+            self.node_recv.append(np.unique(src[e_recv]).astype(np.uint32))  # p's nodes adjacent to mine
+        self.cut_edges = int(cut.sum()) // 2
+
+    def counts(self, what):
+        s = self.msg_send if what == "msg" else self.node_send
+        r = self.msg_recv if what == "msg" else self.node_recv
+        return [len(x) for x in s], [len(x) for x in r]
+
+
+# --------------------------------------------------------------------------
+# exchange plumbing (torch tensors; CPU with gloo, CUDA with RCCL)
+# --------------------------------------------------------------------------
+class HaloExchange:
+    """all-to-all of [message words | node words] per peer, single collective per call."""
+
+    def __init__(self, plan, device, dist=None, group=None):
+        import torch
+        self.torch, self.dist, self.group, self.plan, self.device = torch, dist, group, plan, device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(device).to(torch.int32)  # noqa: E731
+        self.idx = {"msg_send": [t(a) for a in plan.msg_send], "msg_recv": [t(a) for a in plan.msg_recv],
+                    "node_send": [t(a) for a in plan.node_send], "node_recv": [t(a) for a in plan.node_recv]}
+
+    def _layout(self, kinds):
+        send_counts = [sum(len(self.idx[k + "_send"][p]) for k in kinds) for p in range(self.plan.P)]
+        recv_counts = [sum(len(self.idx[k + "_recv"][p]) for k in kinds) for p in range(self.plan.P)]
+        return send_counts, recv_counts
+
+    def exchange(self, kinds, gather, scatter):
+        """kinds: list of ("msg"|"node", which_array).  gather(which, idx_tensor, dst_view),
+        scatter(which, idx_tensor, src_view) move 4-byte words between the solver arrays and the buffers."""
+        torch = self.torch
+        names = [k for k, _ in kinds]
+        sc, rc = self._layout(names)
+        send = torch.empty(max(sum(sc), 1), dtype=torch.int32, device=self.device)
+        recv = torch.empty(max(sum(rc), 1), dtype=torch.int32, device=self.device)
+        off = 0
+        for p in range(self.plan.P):
+            for k, which in kinds:
+                idx = self.idx[k + "_send"][p]
+                if len(idx):
+                    gather(which, idx, send[off:off + len(idx)])
+                off += len(idx)
+        if self.dist is not None and self.plan.P > 1:
+            self.dist.all_to_all_single(recv[:sum(rc)], send[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        off = 0
+        for p in range(self.plan.P):
+            for k, which in kinds:
+                idx = self.idx[k + "_recv"][p]
+                if len(idx):
+                    scatter(which, idx, recv[off:off + len(idx)])
+                off += len(idx)
+
+
+# --------------------------------------------------------------------------
+# the per-rank solver loop (mirrors api.hip mvs_ctx_view_selection)
+# --------------------------------------------------------------------------
+def stop_rule(hist, sweep, params):
+    """StopWhenReturnsDiminish-style rule on the best exact energy (identical on every rank)."""
+    if sweep >= params.min_sweeps and sweep > params.window:
+        prev = hist[sweep - params.window]
+        return float(prev - hist[sweep]) < float(np.float32(params.min_improvement)) * float(prev)
+    return False
+
+
+class ShardedViewSelection:
+    """Runs tex::view_selection over `plan.P` parts.  `ops` provides the per-rank compute:
+         setup(), sweep(nb, ne), gather(which, idx, dst), scatter(which, idx, src),
+         energy(which_sel, nb, ne) -> int64 tensor[2], keep_best(), icm_gain(nb, ne),
+         icm_apply(nb, ne) -> int tensor[1], labels(nb, ne) -> uint32 labels of own nodes
+    (viewsel.Context for the GPU; a numpy stand-in in the CPU tests)."""
+
+    def __init__(self, ops, plan, params, device, dist=None, group=None, hx=None):
+        self.ops, self.plan, self.params, self.dist, self.group = ops, plan, params, dist, group
+        self.hx = hx or HaloExchange(plan, device, dist, group)
+
+    def _allreduce(self, t):
+        if self.dist is not None and self.plan.P > 1:
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
+    def run(self):
+        ops, plan, P = self.ops, self.plan, self.params
+        nb, ne = plan.node_begin, plan.node_end
+        ops.setup()
+        best = (1 << 64) - 1
+        hist = [best]
+        sweeps = 0
+        for sw in range(1, P.max_sweeps + 1):
+            ops.sweep(nb, ne)
+            self.hx.exchange([("msg", MSG), ("node", SEL)], ops.gather, ops.scatter)
+            e = self._allreduce(ops.energy(SEL, nb, ne))
+            e0 = int(e[0].item()) & ((1 << 64) - 1)
+            if e0 < best:
+                best = e0
+                ops.keep_best()
+            hist.append(best)
+            sweeps = sw
+            if stop_rule(hist, sw, P):
+                break
+        icm = 0
+        for icm in range(P.icm_iters):
+            ops.icm_gain(nb, ne)
+            self.hx.exchange([("node", GAIN)], ops.gather, ops.scatter)
+            moved = self._allreduce(ops.icm_apply(nb, ne))
+            self.hx.exchange([("node", BEST_SEL)], ops.gather, ops.scatter)
+            if int(moved[0].item()) == 0:
+                break
+        else:
+            icm = P.icm_iters
+        e = self._allreduce(ops.energy(BEST_SEL, nb, ne))
+        stats = {"energy_fixed": int(e[0].item()) & ((1 << 64) - 1), "cut_edges": int(e[1].item()), "sweeps": sweeps, "icm_iters": icm}
+        stats["energy"] = stats["energy_fixed"] / 2.0 ** 32
+        return ops.labels(nb, ne), stats
+
+
+class GpuShardOps:
+    """ShardedViewSelection ops on a viewsel.Context holding the FULL cost table + adjacency."""
+
+    def __init__(self, ctx, adj_ptr_dev, adj_dev, params):
+        import ctypes as C
+        import torch
+        self.C, self.torch, self.ctx, self.L, self.h = C, torch, ctx, ctx.L, ctx.h
+        self.adj_ptr, self.adj, self.params = adj_ptr_dev, adj_dev, params
+        # one stream for kernels, copies and (through torch's event ordering) RCCL: no host syncs needed
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.e_buf = torch.zeros(2, dtype=torch.int64, device=adj_dev.device)
+        self.m_buf = torch.zeros(1, dtype=torch.int32, device=adj_dev.device)
+
+    def _chk(self, st):
+        from .viewsel import _check
+        _check(self.L, st)
+
+    def _sync_in(self):
+        pass   # same stream as torch: ordered
+
+    def _sync_out(self):
+        pass
+
+    def setup(self):
+        C = self.C
+        self._chk(self.L.mvs_ctx_mrf_setup(self.h, C.c_void_p(self.adj_ptr.data_ptr()), C.c_void_p(self.adj.data_ptr()), 1, C.byref(self.params)))
+
+    def sweep(self, nb, ne):
+        self._chk(self.L.mvs_ctx_mrf_sweep(self.h, nb, ne))
+
+    def gather(self, which, idx, dst):
+        C = self.C
+        self._chk(self.L.mvs_ctx_mrf_gather(self.h, which, C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(dst.data_ptr())))
+        self._sync_out()
+
+    def scatter(self, which, idx, src):
+        C = self.C
+        self._sync_in()
+        self._chk(self.L.mvs_ctx_mrf_scatter(self.h, which, C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(src.data_ptr())))
+
+    def energy(self, which_sel, nb, ne):
+        self._chk(self.L.mvs_ctx_mrf_energy(self.h, which_sel, nb, ne, self.C.c_void_p(self.e_buf.data_ptr())))
+        self._sync_out()
+        return self.e_buf
+
+    def keep_best(self):
+        self._chk(self.L.mvs_ctx_mrf_keep_best(self.h))
+
+    def icm_gain(self, nb, ne):
+        self._chk(self.L.mvs_ctx_mrf_icm_gain(self.h, nb, ne))
+
+    def icm_apply(self, nb, ne):
+        self._chk(self.L.mvs_ctx_mrf_icm_apply(self.h, nb, ne, self.C.c_void_p(self.m_buf.data_ptr())))
+        self._sync_out()
+        return self.m_buf
+
+    def labels(self, nb, ne):
+        out = self.torch.zeros(max(ne - nb, 1), dtype=self.torch.int32, device=self.adj.device)
+        unseen = self.C.c_uint32(0)
+        self._chk(self.L.mvs_ctx_mrf_labels(self.h, nb, ne, self.C.c_void_p(out.data_ptr()), self.C.byref(unseen)))
+        return out[:ne - nb]
+
+
+def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, device="cuda"):
+    """tex::calculate_data_costs over P ranks; afterwards every rank's context holds the GLOBAL
+    cost table (device-resident).  Returns (col_ptr, view_id, cost) torch tensors and local stats."""
+    import ctypes as C
+    import torch
+    from .viewsel import DcStats, _check, _stats_dict, DataCosts
+    L, h = ctx.L, ctx.h
+    P = len(part_begin) - 1
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels, copies and RCCL ordered on one stream
+    ctx.set_face_range(int(part_begin[me]), int(part_begin[me + 1]))
+    _check(L, L.mvs_ctx_dc_phase1(h, C.byref(settings)))
+    mx = torch.zeros(1, dtype=torch.float32, device=device)
+    _check(L, L.mvs_ctx_dc_get_max(h, C.c_void_p(mx.data_ptr())))
+    if dist is not None and P > 1:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    _check(L, L.mvs_ctx_dc_set_max(h, C.c_void_p(mx.data_ptr())))
+    _check(L, L.mvs_ctx_dc_phase2(h))
+    hist = torch.zeros(10001, dtype=torch.int32, device=device)
+    _check(L, L.mvs_ctx_dc_get_histogram(h, C.c_void_p(hist.data_ptr())))
+    if dist is not None and P > 1:
+        dist.all_reduce(hist, group=group)
+    _check(L, L.mvs_ctx_dc_set_histogram(h, C.c_void_p(hist.data_ptr())))
+    ds = DcStats()
+    _check(L, L.mvs_ctx_dc_phase3(h, C.byref(ds)))
+    stats = _stats_dict(ds)
+    nf, nnz = int(part_begin[me + 1] - part_begin[me]), int(stats["nnz"])
+    counts = torch.zeros(max(nf, 1), dtype=torch.int32, device=device)
+    vid = torch.zeros(max(nnz, 1), dtype=torch.int16, device=device)
+    cost = torch.zeros(max(nnz, 1), dtype=torch.float32, device=device)
+    _check(L, L.mvs_ctx_costs_export(h, C.c_void_p(counts.data_ptr()), C.c_void_p(vid.data_ptr()), C.c_void_p(cost.data_ptr())))
+    ctx.synchronize()
+    if dist is not None and P > 1:
+        sizes = torch.tensor([nf, nnz], dtype=torch.int64, device=device)
+        all_sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(P)]
+        dist.all_gather(all_sizes, sizes, group=group)
+        all_sizes = [[int(x) for x in s.tolist()] for s in all_sizes]
+        mf, mn = max(s[0] for s in all_sizes), max(max(s[1] for s in all_sizes), 1)
+
+        def gather_padded(t, n, m):
+            pad = torch.zeros(m, dtype=t.dtype, device=device); pad[:n] = t[:n]
+            outs = [torch.zeros(m, dtype=t.dtype, device=device) for _ in range(P)]
+            dist.all_gather(outs, pad, group=group)
+            return outs
+        cs = gather_padded(counts, nf, max(mf, 1)); vs = gather_padded(vid, nnz, mn); fs = gather_padded(cost, nnz, mn)
+        counts = torch.cat([cs[p][:all_sizes[p][0]] for p in range(P)])
+        vid = torch.cat([vs[p][:all_sizes[p][1]] for p in range(P)])
+        cost = torch.cat([fs[p][:all_sizes[p][1]] for p in range(P)])
+    else:
+        counts, vid, cost = counts[:nf], vid[:nnz], cost[:nnz]
+    F = counts.numel()
+    col_ptr = torch.zeros(F + 1, dtype=torch.int64, device=device)
+    col_ptr[1:] = torch.cumsum(counts.to(torch.int64), 0)
+    col_ptr = col_ptr.to(torch.int32).contiguous()
+    vid = vid.contiguous() if vid.numel() else torch.zeros(1, dtype=torch.int16, device=device)
+    cost = cost.contiguous() if cost.numel() else torch.zeros(1, dtype=torch.float32, device=device)
+    torch.cuda.current_stream().synchronize()
+    dc = DataCosts(F, ctx.n_views, col_ptr, vid, cost)
+    ctx.costs_upload(dc)
+    return dc, stats

@@ -97,6 +97,7 @@ def load_library():
         "mvs_write_labeling_vec": [vp, u32, C.c_char_p],
         "mvs_ctx_create": [i32, C.POINTER(vp)], "mvs_ctx_destroy": [vp], "mvs_ctx_set_stream": [vp, vp],
         "mvs_ctx_synchronize": [vp], "mvs_set_option": [vp, C.c_char_p, C.c_int64],
+        "mvs_ctx_get_profile": [vp, C.c_char_p, C.c_size_t],
         "mvs_scene_set_mesh": [vp, C.POINTER(CMesh), i32], "mvs_scene_set_views": [vp, C.POINTER(CView), u32, i32],
         "mvs_scene_set_face_range": [vp, u32, u32],
         "mvs_ctx_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats)],
@@ -210,6 +211,13 @@ class Context:
 
     def set_option(self, name, value):
         _check(self.L, self.L.mvs_set_option(self.h, name.encode(), int(value)))
+
+    def get_profile(self):
+        """{"stage": [total_ms, launches]} since the last call (needs set_option("profile", 1))"""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        _check(self.L, self.L.mvs_ctx_get_profile(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def set_mesh(self, verts, faces, normals):
         pv, d0 = _ptr(verts); pf, d1 = _ptr(faces); pn, d2 = _ptr(normals)

@@ -805,9 +805,11 @@ void mrf_setup(Mrf& g) {
         }
 }
 
-uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t* cuts_out) {
+uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t* cuts_out, int n_threads = 1) {
     uint64_t unary = 0, cuts = 0;
-    for (uint32_t i = 0; i < g.F; ++i) {
+#pragma omp parallel for schedule(static) num_threads(n_threads) reduction(+ : unary, cuts)
+    for (int64_t ii = 0; ii < (int64_t)g.F; ++ii) {
+        const uint32_t i = (uint32_t)ii;
         if (g.K(i) == 0) { unary += fix32(1.0f); continue; }   /* view_selection.cpp:70-71 */
         unary += fix32(g.cost[g.col_ptr[i] + sel[i]]);
         const uint16_t li = g.view_id[g.col_ptr[i] + sel[i]];
@@ -942,7 +944,7 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     for (s = 1; (int)s <= P.max_sweeps; ++s) {
         mrf_sweep(g, P, ma, mb, sel, n_threads);
         ma.swap(mb);
-        uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts);
+        uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts, n_threads);
         if (e < best_e) { best_e = e; best_cuts = cuts; best_sel = sel; }
         hist.push_back(best_e);
         if (g_trace && (int)s <= g_trace_len) g_trace[s - 1] = e;

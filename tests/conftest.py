@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Build the checker (oracle) and the host-side libraries once per session.
+    The HIP library is built by __graft_entry__.build() / build.py and travels prebuilt."""
+    import oracle_py
+    oracle_py.build_oracle()
+    import mvs_texturing_amd as M
+    M.synth.build_synth()
+    yield
+
+
+SCENES = {
+    # plain icosphere n=22, 6 axis cameras, 1024x768
+    "c1": dict(n=22, n_views=6, width=1024, height=768, displacement=0.0, layout=0),
+    # bumpy sphere with cropped views and a black image corner: every cull of
+    # calculate_data_costs.cpp:183-222, the mask flood fill and the rays decide something
+    "bumpy": dict(n=22, n_views=12, width=640, height=480, displacement=0.15, layout=1, black_corner=40, zoom_odd=1.6),
+    "tiny": dict(n=6, n_views=8, width=320, height=240, displacement=0.2, layout=1, zoom_odd=1.4),
+}
+
+_scene_cache = {}
+
+
+def get_scene(name):
+    import mvs_texturing_amd as M
+    if name not in _scene_cache:
+        _scene_cache[name] = M.synth.make_scene(**SCENES[name])
+    return _scene_cache[name]

@@ -1,0 +1,170 @@
+"""CPU tests of the multi-GPU host logic (mvs-texturing_amd/multigpu.py): partitioning,
+the halo plan, and the exchange over torch.distributed with the gloo backend at
+world_size 2.  The per-rank compute is replaced by a numpy stand-in whose updates
+depend on neighbours' messages, so a wrong or incomplete halo changes the result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import mvs_texturing_amd as M
+from mvs_texturing_amd import multigpu as G
+from conftest import ROOT, get_scene
+from util_cases import random_mrf
+
+
+def _graph():
+    s = get_scene("tiny")
+    perm = G.morton_order(s.verts, s.faces)
+    faces, normals, adj_ptr, adj, inv = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)
+    rng = np.random.default_rng(3)
+    K = rng.integers(0, 5, size=len(faces))
+    col_ptr = np.zeros(len(faces) + 1, dtype=np.uint32); col_ptr[1:] = np.cumsum(K)
+    return s, faces, adj_ptr, adj, col_ptr, inv, perm
+
+
+def test_renumbering_preserves_adjacency_lists():
+    s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
+    for new in range(0, len(faces), 7):
+        old = perm[new]
+        assert (inv[s.adj[s.adj_ptr[old]:s.adj_ptr[old + 1]]] == adj[adj_ptr[new]:adj_ptr[new + 1]]).all()   # same order
+        assert (s.faces[old] == faces[new]).all()
+    assert G.equal_parts(10, 3).tolist() == [0, 3, 6, 10]
+
+
+@pytest.mark.parametrize("P", [2, 3, 5])
+def test_halo_plans_are_pairwise_consistent(P):
+    s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
+    pb = G.equal_parts(len(faces), P)
+    plans = [G.HaloPlan(col_ptr, adj_ptr, adj, pb, r) for r in range(P)]
+    K = np.diff(col_ptr.astype(np.int64))
+    for r in range(P):
+        for q in range(P):
+            assert np.array_equal(plans[r].msg_send[q], plans[q].msg_recv[r])
+            assert np.array_equal(plans[r].node_send[q], plans[q].node_recv[r])
+            assert ((plans[r].node_send[q] >= pb[r]) & (plans[r].node_send[q] < pb[r + 1])).all()
+        # every valid cut edge into r is covered exactly once
+        n = 0
+        for i in range(int(pb[r]), int(pb[r + 1])):
+            for j in adj[adj_ptr[i]:adj_ptr[i + 1]]:
+                if not (pb[r] <= j < pb[r + 1]) and K[i] > 0 and K[j] > 0:
+                    n += K[i]
+        assert n == sum(len(x) for x in plans[r].msg_recv)
+    assert all(p.total_words == plans[0].total_words for p in plans)
+
+
+class _FakeOps:
+    """numpy stand-in for the per-rank compute with the SAME data dependencies as the solver:
+    a node's outgoing message words are a hash of all its incoming words of the previous sweep."""
+
+    def __init__(self, col_ptr, adj_ptr, adj, torch):
+        self.torch = torch
+        col_ptr = col_ptr.astype(np.int64); adj_ptr = adj_ptr.astype(np.int64)
+        self.col_ptr, self.adj_ptr, self.adj = col_ptr, adj_ptr, adj.astype(np.int64)
+        F = len(col_ptr) - 1
+        K = np.diff(col_ptr); deg = np.diff(adj_ptr)
+        dst = np.repeat(np.arange(F), deg)
+        self.valid = (K[dst] > 0) & (K[self.adj] > 0)
+        size = np.where(self.valid, K[dst], 0)
+        self.in_off = np.zeros(len(size) + 1, dtype=np.int64); self.in_off[1:] = np.cumsum(size)
+        self.size = size
+        self.rev = np.zeros(len(size), dtype=np.int64)
+        for e in range(len(size)):
+            j = self.adj[e]; i = dst[e]
+            self.rev[e] = adj_ptr[j] + np.nonzero(self.adj[adj_ptr[j]:adj_ptr[j + 1]] == i)[0][0]
+        self.F = F
+        self.arr = {G.MSG: np.zeros(int(self.in_off[-1]) + 1, np.uint32), G.SEL: np.zeros(F, np.uint32),
+                    G.GAIN: np.zeros(F, np.uint32), G.BEST_SEL: np.zeros(F, np.uint32)}
+        self.prev = self.arr[G.MSG].copy()
+
+    def setup(self):
+        pass
+
+    def sweep(self, nb, ne):
+        old = self.arr[G.MSG].copy(); new = self.arr[G.MSG]
+        for i in range(nb, ne):
+            acc = np.uint32(i * 2654435761 % 2 ** 32)
+            for e in range(self.adj_ptr[i], self.adj_ptr[i + 1]):
+                if self.valid[e]:
+                    acc = np.uint32((int(acc) * 31 + int(old[self.in_off[e]:self.in_off[e] + self.size[e]].astype(np.uint64).sum())) % 2 ** 32)
+            self.arr[G.SEL][i] = acc % 7
+            for e in range(self.adj_ptr[i], self.adj_ptr[i + 1]):
+                if self.valid[e]:
+                    r = self.rev[e]
+                    new[self.in_off[r]:self.in_off[r] + self.size[r]] = (int(acc) + np.arange(self.size[r])) % 2 ** 32
+
+    def gather(self, which, idx, dst):
+        dst.copy_(self.torch.from_numpy(self.arr[which][idx.numpy().astype(np.int64) & 0xFFFFFFFF].astype(np.int64)).to(self.torch.int32))
+
+    def scatter(self, which, idx, src):
+        self.arr[which][idx.numpy().astype(np.int64) & 0xFFFFFFFF] = src.numpy().astype(np.int64) & 0xFFFFFFFF
+
+    def energy(self, which, nb, ne):
+        sel = self.arr[which]
+        cuts = 0
+        for i in range(nb, ne):
+            for e in range(self.adj_ptr[i], self.adj_ptr[i + 1]):
+                j = self.adj[e]
+                if self.valid[e] and j > i and sel[j] != sel[i]:
+                    cuts += 1
+        return self.torch.tensor([int(sel[nb:ne].astype(np.int64).sum()) + (cuts << 32), cuts], dtype=self.torch.int64)
+
+    def keep_best(self):
+        self.arr[G.BEST_SEL][:] = self.arr[G.SEL]
+
+    def icm_gain(self, nb, ne):
+        self.arr[G.GAIN][nb:ne] = (self.arr[G.BEST_SEL][nb:ne] * 3 + 1) % 5
+
+    def icm_apply(self, nb, ne):
+        moved = 0
+        for i in range(nb, ne):
+            g = [self.arr[G.GAIN][self.adj[e]] for e in range(self.adj_ptr[i], self.adj_ptr[i + 1]) if self.valid[e]]
+            if g and self.arr[G.GAIN][i] > max(g):
+                self.arr[G.BEST_SEL][i] = (self.arr[G.BEST_SEL][i] + 1) % 7; moved += 1
+        return self.torch.tensor([moved], dtype=self.torch.int32)
+
+    def labels(self, nb, ne):
+        return self.arr[G.BEST_SEL][nb:ne].copy()
+
+
+def _run_rank(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
+    pb = G.equal_parts(len(faces), world)
+    plan = G.HaloPlan(col_ptr, adj_ptr, adj, pb, rank)
+    params = M.viewsel.MrfParams(6, 6, 3, 0.0, 0.0, 1.0, 3)
+    solver = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch), plan, params, "cpu", dist)
+    labels, stats = solver.run()
+    np.save(os.path.join(out_dir, "labels_%d.npy" % rank), labels)
+    np.save(os.path.join(out_dir, "stats_%d.npy" % rank), np.array([stats["energy_fixed"], stats["cut_edges"], stats["sweeps"], stats["icm_iters"]], dtype=np.uint64))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_equals_single_rank(tmp_path):
+    """world_size 2 over gloo gives the labels / energies of the unsharded run"""
+    import torch
+    import torch.multiprocessing as mp
+    s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
+    plan1 = G.HaloPlan(col_ptr, adj_ptr, adj, G.equal_parts(len(faces), 1), 0)
+    params = M.viewsel.MrfParams(6, 6, 3, 0.0, 0.0, 1.0, 3)
+    ref_labels, ref_stats = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch), plan1, params, "cpu", None).run()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_run_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(2)])
+    assert np.array_equal(got, ref_labels)
+    for r in range(2):
+        st = np.load(tmp_path / ("stats_%d.npy" % r)).tolist()
+        assert st == [ref_stats["energy_fixed"], ref_stats["cut_edges"], ref_stats["sweeps"], ref_stats["icm_iters"]]
+
+
+def test_stop_rule_is_the_library_rule():
+    """same decision as api.hip: (prev - best) < min_improvement * prev over `window` sweeps"""
+    p = M.viewsel.MrfParams(200, 3, 2, 0.01, 0.3, 0.8, 0)
+    hist = [2 ** 64 - 1, 1000 << 32, 995 << 32, 994 << 32, 993 << 32]
+    assert not G.stop_rule(hist, 2, p)
+    assert G.stop_rule(hist, 4, p) == ((995 << 32) - (993 << 32) < float(np.float32(0.01)) * (995 << 32))

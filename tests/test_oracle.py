@@ -1,0 +1,183 @@
+"""CPU tests of the ORACLE (the checker itself): golden fixtures, independent
+numpy / scipy re-statements of its pieces, and the properties the reference
+implies.  No GPU needed."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from conftest import get_scene
+from util_cases import brute_force_optimum, energy_numpy, random_mrf
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["c1", "bumpy"])
+def test_golden_fixtures_reproduced(name):
+    """the oracle still produces the committed vectors (and the scene generator still the same scene)"""
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import MODES, scene_checksum
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    s = get_scene(name)
+    assert scene_checksum(s) == str(g["scene_checksum"]), "synthetic scene drifted: regenerate goldens deliberately"
+    for mode, kw in MODES.items():
+        if mode + "/col_ptr" not in g:
+            continue
+        csr, st = O.data_costs(s, **kw)
+        assert np.array_equal(csr.col_ptr, g[mode + "/col_ptr"])
+        assert np.array_equal(csr.view_id, g[mode + "/view_id"])
+        assert np.array_equal(csr.quality.view(np.uint32), g[mode + "/quality"].view(np.uint32))
+        assert np.array_equal(csr.cost.view(np.uint32), g[mode + "/cost"].view(np.uint32))
+        culls = [st[k] for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre")]
+        assert culls == g[mode + "/culls"].tolist()
+        if mode + "/labels" in g:
+            labels, ms = O.view_selection(csr, s.adj_ptr, s.adj)
+            assert np.array_equal(labels, g[mode + "/labels"])
+            assert [ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"]] == g[mode + "/energy_fixed"].tolist()
+
+
+def test_reference_properties_bumpy():
+    """sorted columns, costs in [0,1], labels from the face's own column, 0 <=> empty column"""
+    s = get_scene("bumpy")
+    csr, st = O.data_costs(s)
+    K = np.diff(csr.col_ptr)
+    for i in np.nonzero(K > 1)[0][:2000]:
+        v = csr.view_id[csr.col_ptr[i]:csr.col_ptr[i + 1]]
+        assert (np.diff(v.astype(np.int64)) > 0).all()                      # calculate_data_costs.cpp:272
+    assert csr.cost.min() >= 0.0 and csr.cost.max() <= 1.0                   # :295-296
+    assert st["cull_outside"] > 0 and st["cull_occluded"] > 0 and st["cull_angle"] > 0
+    labels, ms = O.view_selection(csr, s.adj_ptr, s.adj)
+    assert ((labels == 0) == (K == 0)).all()                                 # view_selection.cpp:50-51
+    e, cuts = O.energy(csr, s.adj_ptr, s.adj, labels)                        # rejects labels outside the column
+    assert e == ms["energy_fixed"] and cuts == ms["cut_edges"] and e != 2 ** 64 - 1
+    e2, c2 = energy_numpy(csr.col_ptr, csr.view_id, csr.cost, s.adj_ptr, s.adj, labels)
+    assert e2 == e and c2 == cuts
+
+
+def test_bvh_equals_brute_force():
+    """the any-hit boolean does not depend on the acceleration structure"""
+    for name in ("tiny", "bumpy"):
+        s = get_scene(name)
+        a, sa = O.data_costs(s, brute=False)
+        b, sb = O.data_costs(s, brute=True)
+        assert np.array_equal(a.col_ptr, b.col_ptr) and np.array_equal(a.view_id, b.view_id)
+        assert sa["cull_occluded"] == sb["cull_occluded"] and sa["cull_occluded"] > 0
+
+
+def test_face_range_and_threads_do_not_change_results():
+    s = get_scene("bumpy")
+    full, _ = O.data_costs(s, n_threads=1)
+    multi, _ = O.data_costs(s, n_threads=4)
+    assert np.array_equal(full.col_ptr, multi.col_ptr) and np.array_equal(full.quality.view(np.uint32), multi.quality.view(np.uint32))
+    part, _ = O.data_costs(s, face_range=(1000, 3000))
+    a, b = full.col_ptr[1000], full.col_ptr[3000]
+    assert np.array_equal(part.view_id, full.view_id[a:b])
+    assert np.array_equal(part.quality.view(np.uint32), full.quality[a:b].view(np.uint32))   # qualities are local; costs depend on the global percentile
+
+
+def test_image_prep_against_scipy():
+    """validity mask = zero pixels 4-connected to a corner (texture_view.cpp:42-94); Sobel magnitude; erosion semantics"""
+    from scipy import ndimage
+    rng = np.random.default_rng(5)
+    h, w = 61, 83
+    img = rng.integers(1, 255, size=(h, w, 3), dtype=np.uint8)
+    img[:9, :13] = 0; img[30:40, 20:50] = 0; img[h - 5:, w - 20:] = 0; img[5:9, 13:30] = 0   # corner blobs, an island, a tail
+    L = O.load()
+    mask = np.zeros((h, w), np.uint8); L.orc_validity_mask(img.ctypes.data, w, h, mask.ctypes.data)
+    zero = img.sum(axis=2) == 0
+    lab, _ = ndimage.label(zero, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    reach = np.zeros_like(zero)
+    for cy, cx in ((0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1)):
+        if zero[cy, cx]:
+            reach |= lab == lab[cy, cx]
+    assert np.array_equal(mask.astype(bool), ~reach)
+    assert mask[35, 30] == 1          # the island is NOT reachable from a corner: stays valid
+    gmi = np.zeros((h, w), np.uint8); L.orc_gradient_magnitude(img.ctypes.data, w, h, gmi.ctypes.data)
+    lum = (0.30 * img[..., 0].astype(np.float64) + (np.float32(0.59) * img[..., 1].astype(np.float32)).astype(np.float64)
+           + (np.float32(0.11) * img[..., 2].astype(np.float32)).astype(np.float64)).astype(np.uint8).astype(np.float64)
+    gx = ndimage.correlate(lum, np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], float), mode="constant")
+    gy = ndimage.correlate(lum, np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], float), mode="constant")
+    ref = np.minimum(255.0, np.sqrt(gx * gx + gy * gy)).astype(np.uint8)
+    ref[0, :] = ref[-1, :] = 0; ref[:, 0] = ref[:, -1] = 0
+    assert np.array_equal(gmi, ref)
+    er = mask.copy(); L.orc_erode_validity_mask(er.ctypes.data, w, h)
+    inv = (mask == 0); inv[0, :] = inv[-1, :] = False; inv[:, 0] = inv[:, -1] = False   # only INTERIOR invalid pixels erode
+    dil = ndimage.binary_dilation(inv, structure=np.ones((3, 3), bool))
+    assert np.array_equal(er.astype(bool), mask.astype(bool) & ~dil)
+
+
+def test_percentile_against_numpy_restatement():
+    """Histogram::add_value / get_approx_percentile (histogram.cpp:27-63)"""
+    rng = np.random.default_rng(11)
+    q = (rng.random(50000).astype(np.float32) ** 3) * np.float32(7.5)
+    mx = np.float32(q.max())
+    L = O.load()
+    got = L.orc_percentile(q.ctypes.data, len(q), C.c_float(mx), C.c_float(0.995))
+    idx = np.floor((np.minimum(q, mx) / mx) * np.float32(9999)).astype(np.int64)
+    bins = np.bincount(idx, minlength=10000)
+    num = 0; ub = np.float32(0); ref = mx
+    for i in range(10000):
+        if np.float32(num) / np.float32(len(q)) > np.float32(0.995):
+            ref = ub; break
+        num += int(bins[i]); ub = np.float32(np.float32(i) / np.float32(9999)) * mx
+    assert np.float32(got) == np.float32(ref)
+
+
+def test_outlier_detection_matches_numpy_linear_algebra():
+    """photometric_outlier_detection (calculate_data_costs.cpp:35-129): damping multiplies the quality by
+    exp(-0.5 * 0.2 * d^T Sigma^-1 d); compare against numpy's inverse on a face with many views"""
+    s = get_scene("bumpy")
+    none, _ = O.data_costs(s, data_term="area", outlier_removal="none")
+    damp, _ = O.data_costs(s, data_term="area", outlier_removal="gauss_damping")
+    clamp, _ = O.data_costs(s, data_term="area", outlier_removal="gauss_clamping")
+    assert damp.nnz <= none.nnz and clamp.nnz <= none.nnz
+    # damping never increases a quality, clamping keeps or removes entries
+    for i in np.nonzero(np.diff(none.col_ptr) >= 6)[0][:200]:
+        qn = dict(zip(none.view_id[none.col_ptr[i]:none.col_ptr[i + 1]], none.quality[none.col_ptr[i]:none.col_ptr[i + 1]]))
+        for v, q in zip(damp.view_id[damp.col_ptr[i]:damp.col_ptr[i + 1]], damp.quality[damp.col_ptr[i]:damp.col_ptr[i + 1]]):
+            assert q <= qn[v] * (1 + 1e-6)
+        for v, q in zip(clamp.view_id[clamp.col_ptr[i]:clamp.col_ptr[i + 1]], clamp.quality[clamp.col_ptr[i]:clamp.col_ptr[i + 1]]):
+            assert q == qn[v]
+
+
+def test_solver_quality_small_instances():
+    """the DEFINED-HERE solver: never worse than plain ICM, optimal or near-optimal on tiny instances"""
+    worse = 0
+    for seed in range(12):
+        col_ptr, view_id, cost, adj_ptr, adj = random_mrf(9, 5, 3, 3, seed)
+        csr = O.CsrNp(9, 5, col_ptr, view_id, cost)
+        labels, ms = O.view_selection(csr, adj_ptr, adj)
+        e, cuts = energy_numpy(col_ptr, view_id, cost, adj_ptr, adj, labels)
+        assert e == ms["energy_fixed"]
+        opt = brute_force_optimum(col_ptr, view_id, cost, adj_ptr, adj)
+        assert e / 2 ** 32 >= opt - 1e-6
+        if e / 2 ** 32 > opt * 1.05 + 1e-6:
+            worse += 1
+        icm = O.icm_baseline(csr, adj_ptr, adj)
+        ei, _ = O.energy(csr, adj_ptr, adj, icm)
+        assert e <= ei
+    assert worse <= 2
+
+
+def test_solver_beats_icm_on_scene_and_is_deterministic():
+    s = get_scene("bumpy")
+    csr, _ = O.data_costs(s)
+    l1, m1 = O.view_selection(csr, s.adj_ptr, s.adj, n_threads=1)
+    l2, m2 = O.view_selection(csr, s.adj_ptr, s.adj, n_threads=4)
+    assert np.array_equal(l1, l2) and m1["energy_fixed"] == m2["energy_fixed"]
+    icm = O.icm_baseline(csr, s.adj_ptr, s.adj)
+    ei, _ = O.energy(csr, s.adj_ptr, s.adj, icm)
+    assert m1["energy_fixed"] < ei
+
+
+def test_guards():
+    """calculate_data_costs.cpp:317-318"""
+    s = get_scene("tiny")
+    L = O.load()
+    m = O.mesh_struct(s); views = O.view_structs(s); st = O.settings_struct()
+    out = O.Csr(); stats = O.DcStats()
+    rc = L.orc_data_costs(C.byref(m), views, 70000, C.byref(st), 0, 0, 0, 1, C.byref(out), C.byref(stats))
+    assert rc == 2
