@@ -85,17 +85,23 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.md config: 2 = 200k faces / 50 views, 3 = 2M faces / 200 views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MVS_BENCH_ONE_GPU"):   # test mode: every rank on cuda:0 (use with --backend gloo)
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     dev = torch.device("cuda", local_rank)
@@ -122,6 +128,8 @@ def main():
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_option("profile", 1)
+    if os.environ.get("MVS_RAY_MODE"):
+        ctx.set_option("ray_mode", int(os.environ["MVS_RAY_MODE"]))
     ctx.set_mesh(t_v, t_f, t_n)
     ctx.set_views(scene.cams, t_img)
     settings = M.Settings()                      # reference defaults: gmi / none / visibility test on
@@ -134,13 +142,10 @@ def main():
             _, ms = ctx.view_selection(t_ap, t_ad, params, labels_out=t_lab)
             info["nnz_global"] = int(st["nnz"])
         else:
-            dc, st = G.sharded_data_costs(ctx, settings, part, rank, dist, device=dev)
-            if "plan" not in info:   # the sparsity pattern is identical every step: plan the halo once (host logic)
-                info["plan"] = G.HaloPlan(dc.col_ptr.cpu().numpy().view(np.uint32), adj_ptr, adj, part, rank)
-                info["hx"] = G.HaloExchange(info["plan"], dev, dist)
-                info["nnz_global"] = int(dc.col_ptr[-1].item())
-            ops = G.GpuShardOps(ctx, t_ap, t_ad, params)
-            labels, ms = G.ShardedViewSelection(ops, info["plan"], params, dev, dist, hx=info["hx"]).run()
+            if "pipe" not in info:
+                info["pipe"] = G.ShardedPipeline(ctx, part, rank, dist, dev, adj_ptr, adj, t_ap, t_ad, settings, params)
+            labels, st, ms, dc = info["pipe"].step()
+            info["nnz_global"] = info["pipe"].nnz_global
         info["dc"], info["mrf"] = st, ms
 
     for _ in range(args.warmup):

@@ -159,7 +159,8 @@ void mvs_ctx_destroy(mvs_ctx* ctx);
 /* hipStream_t to launch on (NULL = the context's own stream) */
 mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
-/* integer options: "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1) */
+/* integer options: "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1),
+ * "ray_mode" (0 = one BVH traversal per ray, 1 = one shared traversal per 64-ray wave; same results) */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 
 /* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,
@@ -216,11 +217,13 @@ mvs_status mvs_ctx_costs_export(mvs_ctx* ctx, uint32_t* counts_device, uint16_t*
  * metadata cheap to replicate) and owns a contiguous node range.  The sweep is
  * synchronous (Jacobi), so a node's update depends only on the previous sweep:
  * results are bit-identical for any partition.  One sweep on rank r:
- *   mrf_sweep(own range) -> mrf_gather(MSG | SEL, boundary index lists) ->
+ *   mrf_sweep(own range) -> mrf_gather(MSG | LAB, boundary index lists) ->
  *   RCCL all-to-all by the driver -> mrf_scatter -> mrf_energy(own range) ->
  *   all-reduce of the two u64.  The index lists are planned on the host from
  * col_ptr + adjacency alone (mvs-texturing_amd/multigpu.py). */
-enum { MVS_MRF_MSG = 0, MVS_MRF_SEL = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_SEL = 3 };
+/* solver arrays addressable by the halo exchange: messages, decoded labels (view + 1) of the current
+ * sweep, ICM gains, labels of the best labeling so far */
+enum { MVS_MRF_MSG = 0, MVS_MRF_LAB = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_LAB = 3 };
 mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
                              const mvs_mrf_params* params);
 /* one sweep over nodes [node_begin, node_end): reads the current messages, writes the next ones, flips */
@@ -228,14 +231,14 @@ mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_en
 /* dst[k] = array[idx[k]] / array[idx[k]] = src[k]; 4-byte elements; MSG = the buffer the last sweep wrote */
 mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, void* dst_device);
 mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, const void* src_device);
-/* partial energy (32.32 fixed point) + cut count of labeling SEL or BEST_SEL over own nodes -> dst_device[2] */
+/* partial energy (32.32 fixed point) + cut count of labeling LAB or BEST_LAB over own nodes -> dst_device[2] */
 mvs_status mvs_ctx_mrf_energy(mvs_ctx* ctx, int which_sel, uint32_t node_begin, uint32_t node_end, uint64_t* dst_device);
-/* BEST_SEL[all] = SEL[all] (call on every rank when the all-reduced energy improved) */
+/* best labeling := current decode (call on every rank when the all-reduced energy improved) */
 mvs_status mvs_ctx_mrf_keep_best(mvs_ctx* ctx);
-/* ICM on BEST_SEL: gains of own nodes; then (after the GAIN halo exchange) apply in place */
+/* ICM on the best labeling: gains of own nodes; then (after the GAIN halo exchange) apply in place */
 mvs_status mvs_ctx_mrf_icm_gain(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
 mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* moved_device);
-/* labels (view_selection.cpp:120-132) of own nodes from BEST_SEL into labels_device[node_end - node_begin] */
+/* labels (view_selection.cpp:120-132) of own nodes of the best labeling into labels_device[node_end - node_begin] */
 mvs_status mvs_ctx_mrf_labels(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* labels_device,
                               uint32_t* unseen_out);
 

@@ -15,11 +15,11 @@ void dc_phase2(mvs_ctx* ctx);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
-void mrf_energy(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
-void mrf_icm_gain(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
-void mrf_icm_apply(mvs_ctx* ctx, const uint32_t* sel, uint32_t* nsel, uint32_t nb0, uint32_t ne0);
-void mrf_argmin_unary(mvs_ctx* ctx, uint32_t* sel);
-void mrf_labels(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0);
+void mrf_keep_best(mvs_ctx* ctx);
+void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
 }  // namespace mvs
 
 using namespace mvs;
@@ -132,6 +132,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lds_bvh_levels") ctx->lds_bvh_levels = (int)value;
     else if (n == "verbose") ctx->verbose = value != 0;
     else if (n == "profile") ctx->profile = value != 0;
+    else if (n == "ray_mode") ctx->ray_mode = (int)value;
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
 }
@@ -342,11 +343,11 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     int sw = 1;
     for (; sw <= P.max_sweeps; ++sw) {
         { Prof pr(ctx, "mrf_sweep"); mrf_sweep(ctx, 0, F); }
-        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, ctx->m_sel.p, 0, F); }
+        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, false, 0, F); }
         uint64_t e[2]; read_energy(ctx, e);
         if (e[0] < best_e) {
             best_e = e[0];
-            MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            mrf_keep_best(ctx);
         }
         hist.push_back(best_e);
         if (ctx->verbose) fprintf(stderr, "[mvs] sweep %d energy %.3f best %.3f\n", sw, (double)e[0] / 4294967296.0, (double)best_e / 4294967296.0);
@@ -356,26 +357,25 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
         }
     }
     S.sweeps = (uint32_t)std::min(sw, P.max_sweeps);
-    if (P.max_sweeps <= 0) { S.sweeps = 0; mrf_argmin_unary(ctx, ctx->m_best_sel.p); }
-    uint32_t* cur = ctx->m_best_sel.p;
+    if (P.max_sweeps <= 0) S.sweeps = 0;   // best labeling = the argmin-unary start state of mrf_setup
     int it = 0;
     for (; it < P.icm_iters; ++it) {
         Prof pr(ctx, "mrf_icm");
-        mrf_icm_gain(ctx, cur, 0, F);
-        mrf_icm_apply(ctx, cur, cur, 0, F);
-        pr.end();  // in place: apply reads only the neighbours' gains
+        mrf_icm_gain(ctx, 0, F);
+        mrf_icm_apply(ctx, 0, F);   // in place: winners form an independent set
+        pr.end();
         uint32_t moved = 0;
         MVS_HIP(hipMemcpyAsync(&moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MVS_HIP(hipStreamSynchronize(s));
         if (moved == 0) break;
     }
     S.icm_iters = (uint32_t)it;
-    mrf_energy(ctx, cur, 0, F);
+    mrf_energy(ctx, true, 0, F);
     uint64_t e[2]; read_energy(ctx, e);
     S.energy_fixed = e[0]; S.energy = (double)e[0] / 4294967296.0; S.cut_edges = e[1];
     uint32_t* d_labels = labels_on_device ? labels_out : ctx->m_cand.p;
     uint32_t bu[2];
-    mrf_labels(ctx, cur, 0, F, d_labels, bu);
+    mrf_labels(ctx, 0, F, d_labels, bu);
     S.unseen = bu[1];
     if (bu[0]) throw StatusError(MVS_ERR_LABELING, "Incorrect labeling");  /* view_selection.cpp:126-128 */
     if (!labels_on_device && F) {

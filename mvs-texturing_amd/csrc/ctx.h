@@ -90,6 +90,7 @@ struct mvs_ctx {
     bool profile = false;
     std::vector<mvs::ProfSpan> prof_spans; std::vector<hipEvent_t> prof_pool;
     bool count_rays = false;
+    int ray_mode = 1;        // 0 = one traversal per ray, 1 = one shared traversal per wave (packet)
     int lds_bvh_levels = 0;
     float cos_limit = 0.0f;  // see dmath.h cull_pair
 
@@ -114,6 +115,7 @@ struct mvs_ctx {
     mvs::DBuf<float> lvl_box_a, lvl_box_b; mvs::DBuf<float> scene_box;
     mvs::BvhDev bvh{};
     mvs::DBuf<uint32_t> vf_ptr, vf_cursor, vf;
+    mvs::DBuf<uint32_t> vperm, vpos;   // vertices in Morton order and the inverse map
 
     // ---- data costs work buffers ----
     mvs::DBuf<unsigned long long> pass_bits, need_bits, occl_bits, surv_bits;
@@ -137,6 +139,7 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
     mvs::DBuf<float> m_msg_a, m_msg_b; mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
+    mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved;
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0; bool m_flip = false;
     mvs_mrf_params m_params{};

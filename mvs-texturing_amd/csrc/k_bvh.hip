@@ -67,6 +67,27 @@ __global__ void morton_kernel(const float* __restrict__ verts, const uint32_t* _
     vals[f] = f;
 }
 
+// Morton code of a vertex (rays are launched in Morton order of their origin: 64 neighbouring
+// vertices per wave = a compact patch of nearly parallel rays)
+__global__ void vmorton_kernel(const float* __restrict__ verts, uint32_t n_verts, const uint32_t* __restrict__ box,
+                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_verts) return;
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        const float lo = ord2f(box[a]), ext = ord2f(box[3 + a]) - lo;
+        float t = ext > 0.0f ? (verts[3 * (size_t)v + a] - lo) / ext : 0.0f;
+        t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+        q[a] = (uint32_t)t;
+    }
+    keys[v] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    vals[v] = v;
+}
+__global__ void invert_perm_kernel(const uint32_t* __restrict__ perm, uint32_t n, uint32_t* __restrict__ inv) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) inv[perm[s]] = s;
+}
+
 // triangles in Morton order as {a, e1 = b - a, e2 = c - a}; slots >= n_faces are degenerate (never hit)
 __global__ void gather_tris_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const uint32_t* __restrict__ order,
                                    uint32_t n_faces, uint32_t n_slots, float4* __restrict__ tris) {
@@ -229,7 +250,8 @@ __device__ __forceinline__ bool any_hit(const BvhDev& bvh, const Ray& r, uint32_
 
 // one wave per (view, 64-vertex word); lanes whose need bit is clear idle
 template <bool COUNT>
-__global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float* __restrict__ verts, const ViewParams* __restrict__ views,
+__global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
+                                                  const ViewParams* __restrict__ views,
                                                   const unsigned long long* __restrict__ need, unsigned long long* __restrict__ occl,
                                                   uint32_t vwords, uint32_t n_verts, uint32_t n_views, const uint32_t* __restrict__ scene_box,
                                                   unsigned long long* __restrict__ counters) {
@@ -239,10 +261,11 @@ __global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float*
     const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
-    const uint32_t v = vw * 64 + lane;
+    const uint32_t sp = vw * 64 + lane;
     bool hit = false;
     uint32_t nn = 0, nt = 0;
-    if (((word >> lane) & 1ull) && v < n_verts) {
+    if (((word >> lane) & 1ull) && sp < n_verts) {
+        const uint32_t v = vperm[sp];
         const ViewParams& vp = views[j];
         const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
         const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad_from_box(scene_box));
@@ -253,6 +276,85 @@ __global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float*
     if (COUNT) {
         for (int o = 32; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, 64); nt += __shfl_xor(nt, o, 64); }
         if (lane == 0) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
+    }
+}
+
+// ---- packet traversal: one wave = 64 nearly parallel rays sharing ONE traversal ----
+// A node is visited when ANY still-active lane hits its box, so node and triangle addresses are
+// wave-uniform (scalar / broadcast loads instead of 64 divergent gathers).  Lanes test every
+// triangle of a visited leaf; testing a superset of triangles cannot change an any-hit result
+// (the predicate is exact per triangle), so the booleans equal the per-ray traversal's.
+__device__ __forceinline__ uint32_t node_hits_uniform(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1, bool active) {
+    uint32_t m = 0;
+    const uint32_t nchild = nd->nchild;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float ta = (nd->lo[0][c] - o.x) * inv.x, tb = (nd->hi[0][c] - o.x) * inv.x;
+        float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
+        ta = (nd->lo[1][c] - o.y) * inv.y; tb = (nd->hi[1][c] - o.y) * inv.y;
+        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+        ta = (nd->lo[2][c] - o.z) * inv.z; tb = (nd->hi[2][c] - o.z) * inv.z;
+        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+        if (__ballot(active && tn <= tf) != 0ull) m |= 1u << c;
+    }
+    return m & ((1u << nchild) - 1u);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
+                                                         const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
+                                                         unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
+                                                         const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= (uint64_t)vwords * n_views) return;
+    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
+    const unsigned long long word = need[(size_t)j * vwords + vw];
+    if (word == 0ull) return;  // occl is pre-zeroed
+    const uint32_t s = vw * 64 + lane;
+    bool active = ((word >> lane) & 1ull) && s < n_verts;
+    const uint32_t v = vperm[s < n_verts ? s : 0];
+    const ViewParams& vp = views[j];
+    const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
+    const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad_from_box(scene_box));
+    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
+    bool hit = false;
+    uint32_t nn = 0, nt = 0;
+    int level = bvh.top;
+    uint32_t node = 0;
+    unsigned long long masks = (unsigned long long)node_hits_uniform(bvh.nodes + bvh.level_off[level], r.o, inv, t0, t1, active) << (4 * level);
+    if (COUNT) nn++;
+    while (true) {
+        const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
+        if (m == 0) {
+            if (level == bvh.top) break;
+            ++level; node >>= 2;
+            continue;
+        }
+        const int c = __builtin_ctz(m);
+        masks &= ~(1ull << (4 * level + c));
+        const uint32_t child = node * 4 + c;   // wave-uniform
+        if (level == 0) {
+            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 A = tp[3 * k], E1 = tp[3 * k + 1], E2 = tp[3 * k + 2];
+                if (active && ray_tri(r, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z})) hit = true;
+            }
+            if (COUNT) nt += 4;
+            active = active && !hit;
+            if (__ballot(active) == 0ull) break;
+        } else {
+            --level; node = child;
+            masks |= (unsigned long long)node_hits_uniform(bvh.nodes + bvh.level_off[level] + node, r.o, inv, t0, t1, active) << (4 * level);
+            if (COUNT) nn++;
+        }
+    }
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) {
+        occl[(size_t)j * vwords + vw] = b;
+        if (COUNT) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
     }
 }
 
@@ -270,7 +372,7 @@ void build_bvh(mvs_ctx* ctx) {
     MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 2048u)), dim3(256), 0, s, ctx->d_verts, NV, box);
     MVS_LAUNCH_CHECK();
-    ctx->morton_k.ensure(F); ctx->morton_k2.ensure(F); ctx->morton_v.ensure(F); ctx->morton_v2.ensure(F);
+    ctx->morton_k.ensure(std::max<size_t>(F, NV)); ctx->morton_k2.ensure(std::max<size_t>(F, NV)); ctx->morton_v.ensure(std::max<size_t>(F, NV)); ctx->morton_v2.ensure(F);
     hipLaunchKernelGGL(morton_kernel, dim3((F + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, F, box, ctx->morton_k.p, ctx->morton_v.p);
     MVS_LAUNCH_CHECK();
     size_t tmp_bytes = 0;
@@ -302,6 +404,16 @@ void build_bvh(mvs_ctx* ctx) {
     }
     b.nodes = ctx->bvh_nodes.p; b.tris = ctx->bvh_tris.p;
     ctx->bvh = b;
+    // vertices in Morton order (ray launch order)
+    ctx->vperm.ensure((size_t)NV + 1); ctx->vpos.ensure((size_t)NV + 1);
+    ctx->morton_k.ensure(std::max<size_t>(F, NV)); ctx->morton_k2.ensure(std::max<size_t>(F, NV)); ctx->morton_v.ensure(std::max<size_t>(F, NV));
+    hipLaunchKernelGGL(vmorton_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->d_verts, NV, box, ctx->morton_k.p, ctx->morton_v.p);
+    MVS_LAUNCH_CHECK();
+    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->vperm.p, NV, 0, 30, s));
+    ctx->sort_tmp.ensure(tmp_bytes + 16);
+    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->vperm.p, NV, 0, 30, s));
+    hipLaunchKernelGGL(invert_perm_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->vperm.p, NV, ctx->vpos.p);
+    MVS_LAUNCH_CHECK();
     // vertex -> faces
     ctx->vf_ptr.ensure((size_t)NV + 1); ctx->vf_cursor.ensure((size_t)NV + 1); ctx->vf.ensure(3 * (size_t)F);
     MVS_HIP(hipMemsetAsync(ctx->vf_cursor.p, 0, ((size_t)NV + 1) * sizeof(uint32_t), s));
@@ -318,12 +430,14 @@ void trace_rays(mvs_ctx* ctx) {
     const uint64_t waves = (uint64_t)vwords * ctx->n_views;
     const uint64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
-    if (ctx->count_rays)
-        hipLaunchKernelGGL(ray_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->d_views.p,
-                           ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p);
-    else
-        hipLaunchKernelGGL(ray_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->d_views.p,
-                           ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p);
+#define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
+                 vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
+    if (ctx->ray_mode == 1) {
+        if (ctx->count_rays) hipLaunchKernelGGL(ray_packet_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_packet_kernel<false>, RAY_ARGS);
+    } else {
+        if (ctx->count_rays) hipLaunchKernelGGL(ray_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_kernel<false>, RAY_ARGS);
+    }
+#undef RAY_ARGS
     MVS_LAUNCH_CHECK();
 }
 

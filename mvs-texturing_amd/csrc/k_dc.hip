@@ -62,14 +62,16 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
 }
 
 // ---- which (vertex, view) rays are needed: OR of the pass bits of the incident faces ----
-__global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, uint32_t n_verts, uint32_t n_views,
+// (thread s handles the s-th vertex in Morton order: need / occluded bits are indexed by that position)
+__global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, const uint32_t* __restrict__ vperm, uint32_t n_verts, uint32_t n_views,
                                                    uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
                                                    const unsigned long long* __restrict__ pass, unsigned long long* __restrict__ need,
                                                    unsigned long long* __restrict__ counters) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if ((v >> 6) >= vwords) return;  // whole wave beyond the vertex range
     const bool act = v < n_verts;
-    const uint32_t p0 = act ? vf_ptr[v] : 0, p1 = act ? vf_ptr[v + 1] : 0;
+    const uint32_t vid = act ? vperm[v] : 0;
+    const uint32_t p0 = act ? vf_ptr[vid] : 0, p1 = act ? vf_ptr[vid + 1] : 0;
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     uint32_t acc = 0;  // bit jj: some incident face passed for view j0 + jj
@@ -97,6 +99,7 @@ template <int DATA_TERM, bool OUTLIER, bool VISTEST>
 __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
                                                    uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
                                                    const unsigned long long* __restrict__ pass, const unsigned long long* __restrict__ occl,
+                                                   const uint32_t* __restrict__ vpos,
                                                    const uint32_t* __restrict__ pass_base, float* __restrict__ pq, float* __restrict__ pcol,
                                                    unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters) {
     const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
@@ -105,6 +108,7 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
     const size_t f = (size_t)fb + (act ? lf : 0);
     const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const V3 v1 = ld3(verts, i0), v2 = ld3(verts, i1), v3 = ld3(verts, i2);
+    const uint32_t s0 = VISTEST ? vpos[i0] : 0u, s1 = VISTEST ? vpos[i1] : 0u, s2 = VISTEST ? vpos[i2] : 0u;  // bit positions of the 3 rays
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -118,7 +122,7 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
             bool visible = true;
             if (VISTEST) {
                 const unsigned long long* o = occl + (size_t)j * vwords;
-                visible = !(((o[i0 >> 6] >> (i0 & 63)) | (o[i1 >> 6] >> (i1 & 63)) | (o[i2 >> 6] >> (i2 & 63))) & 1ull);
+                visible = !(((o[s0 >> 6] >> (s0 & 63)) | (o[s1 >> 6] >> (s1 & 63)) | (o[s2 >> 6] >> (s2 & 63))) & 1ull);
             }
             FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
             if (visible) {
@@ -411,7 +415,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         MVS_HIP(hipMemsetAsync(ctx->occl_bits.p, 0, vw * sizeof(unsigned long long), s));
         const dim3 vgrid((ctx->n_verts + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
         Prof pr_need(ctx, "dc_need");
-        hipLaunchKernelGGL(need_kernel, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->n_verts, V, fb, nf, fwords, vwords,
+        hipLaunchKernelGGL(need_kernel, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
                            ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
         MVS_LAUNCH_CHECK();
         pr_need.end();
@@ -434,7 +438,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     Prof pr_info(ctx, "dc_face_info");
 #define LAUNCH_INFO(DT, OL, VT)                                                                                              \
     hipLaunchKernelGGL((info_kernel<DT, OL, VT>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
-                       fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
+                       fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->vpos.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
                        ctx->surv_bits.p, ctx->counters.p)
     if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true); else LAUNCH_INFO(1, true, false); }
                else      { if (vis) LAUNCH_INFO(1, false, true); else LAUNCH_INFO(1, false, false); } }

@@ -81,13 +81,18 @@ __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint1
 }
 
 // ---- one synchronous sweep; fast path: degree <= 3, K <= G * R ----
+// All global loads of a node (unaries, the 3 incoming messages, the 3 re-alignment maps and, with
+// damping, the 3 previous outgoing messages) are issued up front; the label re-alignment gather
+// c[p] is a ds_bpermute (__shfl) inside the node's lane group: no LDS memory, no barrier.
+// Besides sel (label index) the decode also leaves the label itself (view id + 1) and its unary
+// cost, which is all the energy / ICM kernels need of a neighbour.
 template <int G, int R, bool DAMP>
-__global__ void __launch_bounds__(256) mrf_sweep_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, const uint32_t* __restrict__ adj_ptr,
-                                                        const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
+__global__ void __launch_bounds__(256) mrf_sweep_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                        const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
                                                         const float* __restrict__ mo, float* __restrict__ mn, uint32_t* __restrict__ sel,
+                                                        uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     constexpr int NPB = 256 / G;
-    __shared__ float cs[NPB][G * R];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const uint32_t i = node_begin + blockIdx.x * NPB + grp;
     const bool node_ok = i < node_end;
@@ -103,14 +108,20 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const uint32_t* __restri
         else { em[d].in_off = 0; em[d].out_off = 0; em[d].kj = 0; }
         if (K == 0) em[d].kj = 0;
     }
-    float D[R], in[3][R];
+    float D[R], in[3][R], old[3][R];
+    uint32_t mp[3][R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t t = gl + r * G;
         const bool ok = t < K;
         D[r] = ok ? cost[p0 + t] : 0.0f;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) in[d][r] = (ok && em[d].kj) ? mo[em[d].in_off + t] : 0.0f;
+        for (int d = 0; d < 3; ++d) {
+            in[d][r] = (ok && em[d].kj) ? mo[em[d].in_off + t] : 0.0f;
+            const bool ok2 = t < em[d].kj;
+            mp[d][r] = ok2 ? (uint32_t)map[em[d].out_off + t] : 0u;
+            old[d][r] = (DAMP && ok2) ? mo[em[d].out_off + t] : 0.0f;
+        }
     }
     // decode: first argmin_t of b[t] = D[t] + rho * S[t]
     {
@@ -118,18 +129,19 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const uint32_t* __restri
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t t = gl + r * G;
-            if (t < K) {
-                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
-                const float b = D[r] + rho * S;
-                if (b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
-            }
+            const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
+            const float b = D[r] + rho * S;
+            if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
         }
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) {
             const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
             if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
         }
-        if (gl == 0 && K > 0) sel[i] = bt;
+        if (gl == 0 && node_ok) {
+            if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
+            else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
+        }
     }
     // outgoing messages
 #pragma unroll
@@ -142,36 +154,40 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const uint32_t* __restri
             const uint32_t t = gl + r * G;
             const float oth = (0.0f + in[a][r]) + in[b2][r];
             c[r] = (D[r] + rho * oth) - omr * in[d][r];
-            if (t < K) { cmin = fminf(cmin, c[r]); cs[grp][t] = c[r]; }
+            if (t < K) cmin = fminf(cmin, c[r]);
         }
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
-        __syncthreads();
         const uint32_t kj = em[d].kj, oo = em[d].out_off;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t t2 = gl + r * G;
-            if (t2 < kj) {
-                const uint16_t p = map[oo + t2];
-                const float raw = (p == MAP_NONE) ? lam : fminf(cs[grp][p] - cmin, lam);
-                mn[oo + t2] = DAMP ? (raw * oma + mo[oo + t2] * alpha) : raw;
+            const uint32_t p = mp[d][r];
+            const uint32_t pl = p & (uint32_t)(G - 1), ps = (p & 0xFFFFu) / (uint32_t)G;
+            float cp = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < R; ++s2) {   // every lane executes the shuffles (no divergence around ds_bpermute)
+                const float v = __shfl(c[s2], (int)pl, G);
+                cp = (ps == (uint32_t)s2) ? v : cp;
             }
+            const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
+            if (t2 < kj) mn[oo + t2] = DAMP ? (raw * oma + old[d][r] * alpha) : raw;
         }
-        __syncthreads();
     }
 }
 
 // generic path: any degree, any K.  One wave per node, cavity vector through a global scratch row.
 template <bool DAMP>
-__global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, const uint32_t* __restrict__ adj_ptr,
-                                                               const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
+__global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                               const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
                                                                const float* __restrict__ mo, float* __restrict__ mn, uint32_t* __restrict__ sel,
+                                                               uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                                float* __restrict__ scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     const uint32_t i = node_begin + blockIdx.x;
     const int lane = threadIdx.x;
     if (i >= node_end) return;
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-    if (K == 0) return;
+    if (K == 0) { if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; } return; }
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
     float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
@@ -185,7 +201,7 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         const float ob = __shfl_xor(bb, o, 64); const uint32_t ot = __shfl_xor(bt, o, 64);
         if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
     }
-    if (lane == 0) sel[i] = bt;
+    if (lane == 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
     for (uint32_t e = e0; e < e1; ++e) {
         const MrfEdge m = edge[e];
         if (!m.kj) continue;  // wave-uniform
@@ -208,102 +224,111 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
     }
 }
 
-// ---- exact energy of the decoded labeling (32.32 fixed point) over nodes [node_begin, node_end) ----
-__global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                         const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
-                                                         const uint32_t* __restrict__ sel, uint32_t node_begin, uint32_t node_end,
-                                                         unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
+// ---- exact energy of a labeling (32.32 fixed point) over nodes [node_begin, node_end) ----
+// needs only the labels and selected unary costs: an edge is in the model iff both labels are
+// non-zero (both columns non-empty, view_selection.cpp:29-42)
+__global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                                         const uint32_t* __restrict__ lab, const float* __restrict__ selcost,
+                                                         uint32_t node_begin, uint32_t node_end, unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
     unsigned long long unary = 0, cuts = 0;
     for (uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x; i < node_end; i += gridDim.x * blockDim.x) {
-        const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-        if (K == 0) { unary += fix32(1.0f); continue; }  /* view_selection.cpp:70-71 */
-        const uint32_t s = sel[i];
-        unary += fix32(cost[p0 + s]);
-        const uint16_t li = view_id[p0 + s];
+        unary += fix32(selcost[i]);
+        const uint32_t li = lab[i];
+        if (li == 0u) continue;
         for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
             const uint32_t j = adj[e];
-            if (edge[e].kj == 0 || j <= i) continue;      /* :38 uni directional */
-            cuts += (view_id[col_ptr[j] + sel[j]] != li);
+            if (j <= i) continue;                          /* :38 uni directional */
+            const uint32_t lj = lab[j];
+            cuts += (lj != 0u && lj != li);
         }
     }
     for (int o = 32; o > 0; o >>= 1) { unary += __shfl_xor(unary, o, 64); cuts += __shfl_xor(cuts, o, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], unary + (cuts << 32)); atomicAdd(&out[1], cuts); }
 }
 
-// ---- ICM polish ----
+// ---- ICM polish: G lanes per node over its labels ----
+template <int G>
 __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                           const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
-                                                           const uint32_t* __restrict__ sel, uint32_t node_begin, uint32_t node_end,
-                                                           float* __restrict__ gain, uint32_t* __restrict__ cand) {
-    const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= node_end) return;
-    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-    float g = 0.0f; uint32_t bt = 0;
-    if (K > 0) {
-        const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1], cur_t = sel[i];
-        float best = 0.0f, cur = 0.0f;
-        for (uint32_t t = 0; t < K; ++t) {
-            const uint16_t l = view_id[p0 + t];
-            uint32_t diff = 0;
-            for (uint32_t e = e0; e < e1; ++e) {
-                if (edge[e].kj == 0) continue;
-                const uint32_t j = adj[e];
-                diff += (view_id[col_ptr[j] + sel[j]] != l);
-            }
-            const float en = cost[p0 + t] + (float)diff;
-            if (t == 0 || en < best) { best = en; bt = t; }
-            if (t == cur_t) cur = en;
-        }
-        g = cur - best;
+                                                           const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                                           const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
+                                                           uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand) {
+    constexpr int NPB = 256 / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const uint32_t i = node_begin + blockIdx.x * NPB + grp;
+    const bool node_ok = i < node_end;
+    const uint32_t p0 = node_ok ? col_ptr[i] : 0u;
+    const uint32_t K = node_ok ? col_ptr[i + 1] - p0 : 0u;
+    const uint32_t e0 = node_ok ? adj_ptr[i] : 0u, e1 = node_ok ? adj_ptr[i + 1] : 0u;
+    const uint32_t cur_t = (K > 0) ? sel[i] : 0u;
+    float best = INFINITY, cur = 0.0f; uint32_t bt = 0xFFFFFFFFu;
+    for (uint32_t t = gl; t < K; t += G) {
+        const uint32_t l = (uint32_t)view_id[p0 + t] + 1u;
+        uint32_t diff = 0;
+        for (uint32_t e = e0; e < e1; ++e) { const uint32_t lj = lab[adj[e]]; diff += (lj != 0u && lj != l); }
+        const float en = cost[p0 + t] + (float)diff;
+        if (en < best) { best = en; bt = t; }
+        if (t == cur_t) cur = en;
     }
-    gain[i] = g; cand[i] = bt;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
+        if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+        cur += __shfl_xor(cur, o, G);   // exactly one lane holds a non-zero term (or none: 0)
+    }
+    if (gl == 0 && node_ok) { gain[i] = (K > 0) ? (cur - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; }
 }
 
-__global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
-                                                            const float* __restrict__ gain, const uint32_t* __restrict__ cand, const uint32_t* sel,
-                                                            uint32_t* nsel, uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved) {
+__global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                            const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                                            const float* __restrict__ gain, const uint32_t* __restrict__ cand,
+                                                            uint32_t* sel, uint32_t* lab, float* selcost,
+                                                            uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     bool mv = false;
     if (i < node_end) {
         const float gi = gain[i];
-        uint32_t s = sel[i];
-        if (gi > 0.0f) {
+        if (gi > 0.0f) {   // only nodes with a non-empty column have a positive gain
             bool win = true;
             for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1] && win; ++e) {
-                if (edge[e].kj == 0) continue;
                 const uint32_t j = adj[e];
+                if (lab[j] == 0u) continue;               // edge not in the model (gain[j] is 0 anyway)
                 const float gj = gain[j];
                 if (gj > gi || (gj == gi && j < i)) win = false;
             }
-            if (win) { s = cand[i]; mv = true; }
+            if (win) mv = true;
         }
-        nsel[i] = s;
+    }
+    // all reads of neighbours' labels happen before any write: a winner's neighbours never win in the same
+    // iteration (independent set), and lab[j] == 0 never changes
+    if (mv) {
+        const uint32_t p0 = col_ptr[i], t = cand[i];
+        sel[i] = t; lab[i] = (uint32_t)view_id[p0 + t] + 1u; selcost[i] = cost[p0 + t];
     }
     const unsigned long long b = __ballot(mv);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(moved, (uint32_t)__popcll(b));
 }
 
-__global__ void mrf_argmin_unary_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, uint32_t F, uint32_t* __restrict__ sel) {
+// argmin-unary start (max_sweeps == 0): sel / lab / selcost of every node
+__global__ void mrf_argmin_unary_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost, uint32_t F,
+                                        uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     uint32_t bt = 0;
     for (uint32_t t = 1; t < K; ++t) if (cost[p0 + t] < cost[p0 + bt]) bt = t;
     sel[i] = bt;
+    lab[i] = K ? (uint32_t)view_id[p0 + bt] + 1u : 0u;
+    selcost[i] = K ? cost[p0 + bt] : 1.0f;
 }
 
-/* label extraction (view_selection.cpp:120-132) */
-__global__ void mrf_labels_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ sel,
-                                  uint32_t node_begin, uint32_t node_end, uint32_t n_views, uint32_t* __restrict__ labels, uint32_t* __restrict__ bad_unseen /* [0] bad, [1] unseen */) {
+/* label extraction (view_selection.cpp:120-132): labels are already decoded; range check + unseen count */
+__global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t node_begin, uint32_t node_end, uint32_t n_views,
+                                  uint32_t* __restrict__ labels, uint32_t* __restrict__ bad_unseen /* [0] bad, [1] unseen */) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= node_end) return;
-    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-    uint32_t label = 0;
-    if (K > 0) {
-        const uint32_t s = sel[i];
-        if (s >= K) { atomicAdd(&bad_unseen[0], 1u); } else label = (uint32_t)view_id[p0 + s] + 1u;
-        if (label > n_views) atomicAdd(&bad_unseen[0], 1u);   /* :126-128 "Incorrect labeling" */
-    } else atomicAdd(&bad_unseen[1], 1u);
+    const uint32_t label = lab[i];
+    if (label > n_views) atomicAdd(&bad_unseen[0], 1u);       /* :126-128 "Incorrect labeling" */
+    if (label == 0u) atomicAdd(&bad_unseen[1], 1u);            /* :129 */
     labels[i - node_begin] = label;
 }
 
@@ -342,8 +367,16 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 1) * sizeof(float), s));
     MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
     ctx->m_sel.ensure((size_t)F + 1); ctx->m_best_sel.ensure((size_t)F + 1); ctx->m_sel2.ensure((size_t)F + 1); ctx->m_cand.ensure((size_t)F + 1); ctx->m_gain.ensure((size_t)F + 1);
-    MVS_HIP(hipMemsetAsync(ctx->m_sel.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
-    MVS_HIP(hipMemsetAsync(ctx->m_best_sel.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
+    ctx->m_lab.ensure((size_t)F + 1); ctx->m_best_lab.ensure((size_t)F + 1); ctx->m_cost.ensure((size_t)F + 1); ctx->m_best_cost.ensure((size_t)F + 1);
+    // start state = argmin-unary decode everywhere (also gives halo nodes of a sharded run defined labels)
+    if (F) {
+        hipLaunchKernelGGL(mrf_argmin_unary_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, F, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p);
+        MVS_LAUNCH_CHECK();
+        MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        MVS_HIP(hipMemcpyAsync(ctx->m_best_lab.p, ctx->m_lab.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        MVS_HIP(hipMemcpyAsync(ctx->m_best_cost.p, ctx->m_cost.p, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    MVS_HIP(hipMemsetAsync(ctx->m_gain.p, 0, ((size_t)F + 1) * sizeof(float), s));
     ctx->m_energy.ensure(4);
     ctx->m_flip = false;
 }
@@ -354,9 +387,9 @@ static void launch_sweep_gr(mvs_ctx* ctx, const float* mo, float* mn, uint32_t n
     const unsigned blocks = (ne0 - nb0 + NPB - 1) / NPB;
     const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
     if (alpha != 0.0f)
-        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, nb0, ne0, rho, alpha);
+        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
     else
-        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, nb0, ne0, rho, alpha);
+        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
 }
 
 // one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
@@ -376,48 +409,58 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
             ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
             const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
             if (alpha != 0.0f)
-                hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->pq.p, nb0, ne0, rho, alpha);
+                hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, nb0, ne0, rho, alpha);
             else
-                hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->pq.p, nb0, ne0, rho, alpha);
+                hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, nb0, ne0, rho, alpha);
         }
         MVS_LAUNCH_CHECK();
     }
     ctx->m_flip = !ctx->m_flip;
 }
 
-// energy of labeling `sel` over nodes [nb0, ne0) -> ctx->m_energy (device, 2 x u64), asynchronous
-void mrf_energy(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0) {
+// energy of the current decode (best == false) or of the best labeling over nodes [nb0, ne0)
+// -> ctx->m_energy (device, 2 x u64), asynchronous
+void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0) {
     MVS_HIP(hipMemsetAsync(ctx->m_energy.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     if (ne0 > nb0) {
         const unsigned blocks = std::min<unsigned>((ne0 - nb0 + 255) / 256, 4096u);
-        hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, sel, nb0, ne0, ctx->m_energy.p);
+        hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj,
+                           best ? ctx->m_best_lab.p : ctx->m_lab.p, best ? ctx->m_best_cost.p : ctx->m_cost.p, nb0, ne0, ctx->m_energy.p);
         MVS_LAUNCH_CHECK();
     }
 }
 
-void mrf_icm_gain(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0) {
+void mrf_keep_best(mvs_ctx* ctx) {
+    const size_t F = ctx->csr_faces;
+    if (!F) return;
+    MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, F * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_HIP(hipMemcpyAsync(ctx->m_best_lab.p, ctx->m_lab.p, F * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    MVS_HIP(hipMemcpyAsync(ctx->m_best_cost.p, ctx->m_cost.p, F * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+// ICM on the best labeling (in place): gains of nodes [nb0, ne0)
+void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 <= nb0) return;
-    hipLaunchKernelGGL(mrf_icm_gain_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, sel, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p);
+    const uint32_t K = ctx->m_kmax, n = ne0 - nb0;
+#define ICM_G(GG) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3((n + (256 / GG) - 1) / (256 / GG)), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
+                                     ctx->r_adj_ptr, ctx->r_adj, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
+    if (K <= 8) ICM_G(8); else if (K <= 16) ICM_G(16); else if (K <= 32) ICM_G(32); else ICM_G(64);
+#undef ICM_G
     MVS_LAUNCH_CHECK();
 }
-void mrf_icm_apply(mvs_ctx* ctx, const uint32_t* sel, uint32_t* nsel, uint32_t nb0, uint32_t ne0) {
+void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, sizeof(uint32_t), ctx->stream));
     if (ne0 <= nb0) return;
-    hipLaunchKernelGGL(mrf_icm_apply_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_gain.p, ctx->m_cand.p, sel, nsel, nb0, ne0, ctx->m_moved.p);
+    hipLaunchKernelGGL(mrf_icm_apply_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
+                       ctx->m_gain.p, ctx->m_cand.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, nb0, ne0, ctx->m_moved.p);
     MVS_LAUNCH_CHECK();
 }
-void mrf_argmin_unary(mvs_ctx* ctx, uint32_t* sel) {
-    const uint32_t F = ctx->csr_faces;
-    if (!F) return;
-    hipLaunchKernelGGL(mrf_argmin_unary_kernel, dim3((F + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, F, sel);
-    MVS_LAUNCH_CHECK();
-}
-// labels of nodes [nb0, ne0) into d_labels[0 .. ne0 - nb0); returns {bad, unseen}
-void mrf_labels(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]) {
+// labels of nodes [nb0, ne0) of the best labeling into d_labels[0 .. ne0 - nb0); out = {bad, unseen}
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]) {
     uint32_t* bu = ctx->m_moved.p + 2;
     MVS_HIP(hipMemsetAsync(bu, 0, 2 * sizeof(uint32_t), ctx->stream));
     if (ne0 > nb0) {
-        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, sel, nb0, ne0, ctx->csr_views, d_labels, bu);
+        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->m_best_lab.p, nb0, ne0, ctx->csr_views, d_labels, bu);
         MVS_LAUNCH_CHECK();
     }
     MVS_HIP(hipMemcpyAsync(out, bu, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

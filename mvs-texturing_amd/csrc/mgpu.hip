@@ -8,10 +8,11 @@
 namespace mvs {
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
-void mrf_energy(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
-void mrf_icm_gain(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0);
-void mrf_icm_apply(mvs_ctx* ctx, const uint32_t* sel, uint32_t* nsel, uint32_t nb0, uint32_t ne0);
-void mrf_labels(mvs_ctx* ctx, const uint32_t* sel, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0);
+void mrf_keep_best(mvs_ctx* ctx);
+void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
 void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device);
 mvs_status api_fail(mvs_status st, const std::string& msg);
 
@@ -31,9 +32,9 @@ __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, 
 static uint32_t* mrf_array(mvs_ctx* ctx, int which) {
     switch (which) {
         case MVS_MRF_MSG: return (uint32_t*)(ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p);  // current = what the last sweep wrote
-        case MVS_MRF_SEL: return ctx->m_sel.p;
+        case MVS_MRF_LAB: return ctx->m_lab.p;
         case MVS_MRF_GAIN: return (uint32_t*)ctx->m_gain.p;
-        case MVS_MRF_BEST_SEL: return ctx->m_best_sel.p;
+        case MVS_MRF_BEST_LAB: return ctx->m_best_lab.p;
     }
     throw StatusError(MVS_ERR_INVALID, "bad array selector");
 }
@@ -129,9 +130,9 @@ mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx, uin
 
 mvs_status mvs_ctx_mrf_energy(mvs_ctx* ctx, int which_sel, uint32_t nb0, uint32_t ne0, uint64_t* dst) {
     if (!ctx || !dst || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad argument");
-    if (which_sel != MVS_MRF_SEL && which_sel != MVS_MRF_BEST_SEL) return api_fail(MVS_ERR_INVALID, "energy: SEL or BEST_SEL");
+    if (which_sel != MVS_MRF_LAB && which_sel != MVS_MRF_BEST_LAB) return api_fail(MVS_ERR_INVALID, "energy: LAB or BEST_LAB");
     MVS_API_BEGIN
-    mrf_energy(ctx, mrf_array(ctx, which_sel), nb0, ne0);
+    mrf_energy(ctx, which_sel == MVS_MRF_BEST_LAB, nb0, ne0);
     MVS_HIP(hipMemcpyAsync(dst, ctx->m_energy.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     MVS_API_END
 }
@@ -139,20 +140,20 @@ mvs_status mvs_ctx_mrf_energy(mvs_ctx* ctx, int which_sel, uint32_t nb0, uint32_
 mvs_status mvs_ctx_mrf_keep_best(mvs_ctx* ctx) {
     if (!ctx) return api_fail(MVS_ERR_INVALID, "ctx is null");
     MVS_API_BEGIN
-    if (ctx->csr_faces) MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, (size_t)ctx->csr_faces * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    mrf_keep_best(ctx);
     MVS_API_END
 }
 
 mvs_status mvs_ctx_mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad node range");
     MVS_API_BEGIN
-    mrf_icm_gain(ctx, ctx->m_best_sel.p, nb0, ne0);
+    mrf_icm_gain(ctx, nb0, ne0);
     MVS_API_END
 }
 mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* moved) {
     if (!ctx || !moved || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad argument");
     MVS_API_BEGIN
-    mrf_icm_apply(ctx, ctx->m_best_sel.p, ctx->m_best_sel.p, nb0, ne0);  // in place: apply reads only gains of neighbours
+    mrf_icm_apply(ctx, nb0, ne0);  // in place: winners form an independent set
     MVS_HIP(hipMemcpyAsync(moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     MVS_API_END
 }
@@ -161,7 +162,7 @@ mvs_status mvs_ctx_mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t
     if (!ctx || !labels || nb0 > ne0 || ne0 > ctx->csr_faces) return api_fail(MVS_ERR_INVALID, "bad argument");
     MVS_API_BEGIN
     uint32_t bu[2];
-    mrf_labels(ctx, ctx->m_best_sel.p, nb0, ne0, labels, bu);
+    mrf_labels(ctx, nb0, ne0, labels, bu);
     if (unseen_out) *unseen_out = bu[1];
     if (bu[0]) throw StatusError(MVS_ERR_LABELING, "Incorrect labeling");
     MVS_API_END

@@ -22,7 +22,7 @@ is behind the C ABI (viewsel.Context).
 """
 import numpy as np
 
-MSG, SEL, GAIN, BEST_SEL = 0, 1, 2, 3
+MSG, LAB, GAIN, BEST_LAB = 0, 1, 2, 3
 
 
 # --------------------------------------------------------------------------
@@ -153,7 +153,13 @@ class HaloExchange:
                     gather(which, idx, send[off:off + len(idx)])
                 off += len(idx)
         if self.dist is not None and self.plan.P > 1:
-            self.dist.all_to_all_single(recv[:sum(rc)], send[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+            if send.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # test configuration (several ranks sharing one GPU): gloo has no CUDA all-to-all, stage through the host
+                hs, hr = send[:sum(sc)].cpu(), torch.empty(sum(rc), dtype=torch.int32)
+                self.dist.all_to_all_single(hr, hs, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+                recv[:sum(rc)].copy_(hr)
+            else:
+                self.dist.all_to_all_single(recv[:sum(rc)], send[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc, group=self.group)
         off = 0
         for p in range(self.plan.P):
             for k, which in kinds:
@@ -199,8 +205,8 @@ class ShardedViewSelection:
         sweeps = 0
         for sw in range(1, P.max_sweeps + 1):
             ops.sweep(nb, ne)
-            self.hx.exchange([("msg", MSG), ("node", SEL)], ops.gather, ops.scatter)
-            e = self._allreduce(ops.energy(SEL, nb, ne))
+            self.hx.exchange([("msg", MSG), ("node", LAB)], ops.gather, ops.scatter)
+            e = self._allreduce(ops.energy(LAB, nb, ne))
             e0 = int(e[0].item()) & ((1 << 64) - 1)
             if e0 < best:
                 best = e0
@@ -214,12 +220,12 @@ class ShardedViewSelection:
             ops.icm_gain(nb, ne)
             self.hx.exchange([("node", GAIN)], ops.gather, ops.scatter)
             moved = self._allreduce(ops.icm_apply(nb, ne))
-            self.hx.exchange([("node", BEST_SEL)], ops.gather, ops.scatter)
+            self.hx.exchange([("node", BEST_LAB)], ops.gather, ops.scatter)
             if int(moved[0].item()) == 0:
                 break
         else:
             icm = P.icm_iters
-        e = self._allreduce(ops.energy(BEST_SEL, nb, ne))
+        e = self._allreduce(ops.energy(BEST_LAB, nb, ne))
         stats = {"energy_fixed": int(e[0].item()) & ((1 << 64) - 1), "cut_edges": int(e[1].item()), "sweeps": sweeps, "icm_iters": icm}
         stats["energy"] = stats["energy_fixed"] / 2.0 ** 32
         return ops.labels(nb, ne), stats
@@ -347,3 +353,24 @@ def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, dev
     dc = DataCosts(F, ctx.n_views, col_ptr, vid, cost)
     ctx.costs_upload(dc)
     return dc, stats
+
+
+class ShardedPipeline:
+    """calculate_data_costs + view_selection over `world` ranks (what bench.py times per step for N > 1)."""
+
+    def __init__(self, ctx, part_begin, rank, dist, device, adj_ptr_np, adj_np, adj_ptr_dev, adj_dev, settings, params):
+        self.ctx, self.part, self.rank, self.dist, self.device = ctx, part_begin, rank, dist, device
+        self.adj_ptr_np, self.adj_np, self.adj_ptr_dev, self.adj_dev = adj_ptr_np, adj_np, adj_ptr_dev, adj_dev
+        self.settings, self.params = settings, params
+        self.plan = self.hx = None
+        self.nnz_global = 0
+
+    def step(self):
+        dc, st = sharded_data_costs(self.ctx, self.settings, self.part, self.rank, self.dist, device=self.device)
+        if self.plan is None:   # the sparsity pattern is the same every step: plan the halo once (host logic)
+            self.plan = HaloPlan(dc.col_ptr.cpu().numpy().view(np.uint32), self.adj_ptr_np, self.adj_np, self.part, self.rank)
+            self.hx = HaloExchange(self.plan, self.device, self.dist)
+            self.nnz_global = int(dc.col_ptr[-1].item())
+        ops = GpuShardOps(self.ctx, self.adj_ptr_dev, self.adj_dev, self.params)
+        labels, ms = ShardedViewSelection(ops, self.plan, self.params, self.device, self.dist, hx=self.hx).run()
+        return labels, st, ms, dc

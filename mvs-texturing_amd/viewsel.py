@@ -81,6 +81,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # When torch is installed, load it first: it ships its own HIP runtime (same soname as the system
+        # one) and the process must end up with a single runtime shared by torch and this library.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_LIB_PATH):
         raise MvsError(-1, "HIP library %s is missing: run `python mvs-texturing_amd/build.py` "
                            "(or __graft_entry__.build()); there is no CPU fallback" % _LIB_PATH)

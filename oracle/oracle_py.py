@@ -94,6 +94,12 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _threads(n):
+    """0 -> a moderate default: OpenMP with every hardware thread of a 256-thread host is far slower
+    than 16 threads on these small test problems (bench.py calibrates its own count)."""
+    return n if n > 0 else max(1, min(16, len(os.sched_getaffinity(0))))
+
+
 def mesh_struct(scene):
     m = Mesh(scene.verts.shape[0], scene.faces.shape[0], _ptr(scene.verts), _ptr(scene.faces), _ptr(scene.normals))
     return m
@@ -146,7 +152,7 @@ def data_costs(scene, data_term="gmi", outlier_removal="none", geometric_visibil
     st = settings_struct(data_term, outlier_removal, geometric_visibility_test)
     fb, fe = face_range if face_range else (0, scene.n_faces)
     out = Csr(); stats = DcStats()
-    rc = L.orc_data_costs(C.byref(m), views, scene.n_views, C.byref(st), fb, fe, 1 if brute else 0, n_threads,
+    rc = L.orc_data_costs(C.byref(m), views, scene.n_views, C.byref(st), fb, fe, 1 if brute else 0, _threads(n_threads),
                           C.byref(out), C.byref(stats))
     if rc:
         raise RuntimeError({1: "Exeeded maximal number of faces", 2: "Exeeded maximal number of views"}[rc])
@@ -172,7 +178,7 @@ def view_selection(csr, adj_ptr, adj, params=None, n_threads=0, timing=False):
     labels = np.zeros(csr.n_faces, dtype=np.uint32)
     st = MrfStats(); cs = csr.as_struct()
     adj_ptr = np.ascontiguousarray(adj_ptr, dtype=np.uint32); adj = np.ascontiguousarray(adj, dtype=np.uint32)
-    L.orc_view_selection(C.byref(cs), _ptr(adj_ptr), _ptr(adj), C.byref(p), n_threads, _ptr(labels), C.byref(st))
+    L.orc_view_selection(C.byref(cs), _ptr(adj_ptr), _ptr(adj), C.byref(p), _threads(n_threads), _ptr(labels), C.byref(st))
     return labels, {f[0]: getattr(st, f[0]) for f in MrfStats._fields_}
 
 

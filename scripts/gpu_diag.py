@@ -83,6 +83,21 @@ def stage_c2():
     ref, got, ctx, ok = compare_dc(s, "C2"); compare_mrf(s, ref, got, ctx, "C2"); ctx.close()
 
 
+def stage_raymodes():
+    """ray statistics and parity of both traversal modes on config 2"""
+    s = synth.make_scene(**synth.CONFIGS[2])
+    res = {}
+    for mode in (0, 1):
+        ctx = M.Context(); ctx.set_option("count_rays", 1); ctx.set_option("ray_mode", mode); ctx.set_option("profile", 1)
+        ctx.set_mesh(s.verts, s.faces, s.normals); ctx.set_views(s.cams, s.images)
+        ctx.data_costs(M.Settings()); ctx.get_profile()
+        st = ctx.data_costs(M.Settings()); prof = ctx.get_profile()
+        res[mode] = ctx.costs_download()
+        print(f"ray_mode {mode}: rays {st['rays']} nodes {st['ray_nodes']} tris {st['ray_tris']} occluded {st['cull_occluded']} dc_rays {prof['dc_rays'][0]:.3f} ms")
+        ctx.close()
+    print("modes equal:", np.array_equal(res[0].col_ptr, res[1].col_ptr) and np.array_equal(res[0].cost.view(np.uint32), res[1].cost.view(np.uint32)))
+
+
 def stage_c3_time():
     t = time.time(); s = synth.make_scene(**synth.CONFIGS[3]); print("C3 scene", time.time() - t, flush=True)
     ctx = M.Context(); ctx.set_mesh(s.verts, s.faces, s.normals); ctx.set_views(s.cams, s.images)

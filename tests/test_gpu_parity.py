@@ -279,8 +279,8 @@ def test_logical_shards_on_one_gpu_equal_single(P):
     best = 2 ** 64 - 1; hist_e = [best]; sweeps = 0
     for sw in range(1, params.max_sweeps + 1):
         for r in range(P): ops[r].sweep(int(pb[r]), int(pb[r + 1]))
-        exchange([("msg", G.MSG), ("node", G.SEL)])
-        e = sum(int(ops[r].energy(G.SEL, int(pb[r]), int(pb[r + 1]))[0].item()) for r in range(P)) & (2 ** 64 - 1)
+        exchange([("msg", G.MSG), ("node", G.LAB)])
+        e = sum(int(ops[r].energy(G.LAB, int(pb[r]), int(pb[r + 1]))[0].item()) for r in range(P)) & (2 ** 64 - 1)
         if e < best:
             best = e
             for o in ops: o.keep_best()
@@ -291,13 +291,64 @@ def test_logical_shards_on_one_gpu_equal_single(P):
         for r in range(P): ops[r].icm_gain(int(pb[r]), int(pb[r + 1]))
         exchange([("node", G.GAIN)])
         moved = sum(int(ops[r].icm_apply(int(pb[r]), int(pb[r + 1]))[0].item()) for r in range(P))
-        exchange([("node", G.BEST_SEL)])
+        exchange([("node", G.BEST_LAB)])
         if moved == 0: break
     labels = np.concatenate([ops[r].labels(int(pb[r]), int(pb[r + 1])).cpu().numpy().view(np.uint32) for r in range(P)])
-    e = sum(int(ops[r].energy(G.BEST_SEL, int(pb[r]), int(pb[r + 1]))[0].item()) for r in range(P)) & (2 ** 64 - 1)
+    e = sum(int(ops[r].energy(G.BEST_LAB, int(pb[r]), int(pb[r + 1]))[0].item()) for r in range(P)) & (2 ** 64 - 1)
     assert np.array_equal(labels, lab0), "labels depend on the partition"
     assert (e, sweeps, icm) == (st0["energy_fixed"], st0["sweeps"], st0["icm_iters"])
     for c in ctxs + [c0]: c.close()
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from mvs_texturing_amd import multigpu as G
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    s = get_scene("bumpy")
+    perm = G.morton_order(s.verts, s.faces)
+    faces, normals, adj_ptr, adj, inv = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)
+    part = G.equal_parts(len(faces), world)
+    c = M.Context(0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_mesh(s.verts, faces, normals); c.set_views(s.cams, s.images)
+    tap, tad = torch.from_numpy(adj_ptr.view(np.int32)).to(dev), torch.from_numpy(adj.view(np.int32)).to(dev)
+    pipe = G.ShardedPipeline(c, part, rank, dist, dev, adj_ptr, adj, tap, tad, M.Settings(), M.viewsel.default_mrf_params())
+    for _ in range(2):   # second step exercises the cached plan
+        labels, st, ms, dc = pipe.step()
+    np.save(os.path.join(out_dir, "labels_%d.npy" % rank), labels.cpu().numpy().view(np.uint32))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "global.npz"), col_ptr=dc.col_ptr.cpu().numpy(), cost=dc.cost.cpu().numpy(),
+                 stats=np.array([ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"]], dtype=np.uint64))
+    c.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_torch_distributed_equal_single(tmp_path):
+    """the real driver (multigpu.ShardedPipeline over torch.distributed) with 2 ranks; both ranks share cuda:0 and
+    use gloo here because a 1-GPU box cannot host two RCCL ranks -- the collectives' call pattern is the N-GPU one"""
+    import torch.multiprocessing as mp
+    from mvs_texturing_amd import multigpu as G
+    s = get_scene("bumpy")
+    perm = G.morton_order(s.verts, s.faces)
+    faces, normals, adj_ptr, adj, inv = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)
+    c0 = M.Context(0); c0.set_mesh(s.verts, faces, normals); c0.set_views(s.cams, s.images)
+    c0.data_costs(M.Settings()); full = c0.costs_download()
+    lab0, st0 = c0.view_selection(adj_ptr, adj)
+    c0.close()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(2)])
+    g = np.load(tmp_path / "global.npz")
+    assert np.array_equal(g["col_ptr"].view(np.uint32), full.col_ptr)
+    assert np.array_equal(g["cost"].view(np.uint32), full.cost.view(np.uint32))
+    assert np.array_equal(got, lab0)
+    assert g["stats"].tolist() == [st0["energy_fixed"], st0["cut_edges"], st0["sweeps"], st0["icm_iters"]]
 
 
 def test_config2_size_properties(ctx):

@@ -74,8 +74,8 @@ class _FakeOps:
             j = self.adj[e]; i = dst[e]
             self.rev[e] = adj_ptr[j] + np.nonzero(self.adj[adj_ptr[j]:adj_ptr[j + 1]] == i)[0][0]
         self.F = F
-        self.arr = {G.MSG: np.zeros(int(self.in_off[-1]) + 1, np.uint32), G.SEL: np.zeros(F, np.uint32),
-                    G.GAIN: np.zeros(F, np.uint32), G.BEST_SEL: np.zeros(F, np.uint32)}
+        self.arr = {G.MSG: np.zeros(int(self.in_off[-1]) + 1, np.uint32), G.LAB: np.zeros(F, np.uint32),
+                    G.GAIN: np.zeros(F, np.uint32), G.BEST_LAB: np.zeros(F, np.uint32)}
         self.prev = self.arr[G.MSG].copy()
 
     def setup(self):
@@ -88,7 +88,7 @@ class _FakeOps:
             for e in range(self.adj_ptr[i], self.adj_ptr[i + 1]):
                 if self.valid[e]:
                     acc = np.uint32((int(acc) * 31 + int(old[self.in_off[e]:self.in_off[e] + self.size[e]].astype(np.uint64).sum())) % 2 ** 32)
-            self.arr[G.SEL][i] = acc % 7
+            self.arr[G.LAB][i] = acc % 7
             for e in range(self.adj_ptr[i], self.adj_ptr[i + 1]):
                 if self.valid[e]:
                     r = self.rev[e]
@@ -111,21 +111,21 @@ class _FakeOps:
         return self.torch.tensor([int(sel[nb:ne].astype(np.int64).sum()) + (cuts << 32), cuts], dtype=self.torch.int64)
 
     def keep_best(self):
-        self.arr[G.BEST_SEL][:] = self.arr[G.SEL]
+        self.arr[G.BEST_LAB][:] = self.arr[G.LAB]
 
     def icm_gain(self, nb, ne):
-        self.arr[G.GAIN][nb:ne] = (self.arr[G.BEST_SEL][nb:ne] * 3 + 1) % 5
+        self.arr[G.GAIN][nb:ne] = (self.arr[G.BEST_LAB][nb:ne] * 3 + 1) % 5
 
     def icm_apply(self, nb, ne):
         moved = 0
         for i in range(nb, ne):
             g = [self.arr[G.GAIN][self.adj[e]] for e in range(self.adj_ptr[i], self.adj_ptr[i + 1]) if self.valid[e]]
             if g and self.arr[G.GAIN][i] > max(g):
-                self.arr[G.BEST_SEL][i] = (self.arr[G.BEST_SEL][i] + 1) % 7; moved += 1
+                self.arr[G.BEST_LAB][i] = (self.arr[G.BEST_LAB][i] + 1) % 7; moved += 1
         return self.torch.tensor([moved], dtype=self.torch.int32)
 
     def labels(self, nb, ne):
-        return self.arr[G.BEST_SEL][nb:ne].copy()
+        return self.arr[G.BEST_LAB][nb:ne].copy()
 
 
 def _run_rank(rank, world, port, out_dir):
