@@ -128,6 +128,8 @@ def main():
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_option("profile", 1)
+    if os.environ.get("MVS_MRF_SHAPE"):
+        ctx.set_option("mrf_shape", int(os.environ["MVS_MRF_SHAPE"]))
     if os.environ.get("MVS_RAY_MODE"):
         ctx.set_option("ray_mode", int(os.environ["MVS_RAY_MODE"]))
     ctx.set_mesh(t_v, t_f, t_n)

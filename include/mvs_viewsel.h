@@ -102,6 +102,7 @@ typedef struct {
 
 typedef struct {
     uint64_t pairs;
+    /* the five cull counters and `rays` are filled only with mvs_set_option("stats", 1) */
     uint64_t cull_backface;     /* calculate_data_costs.cpp:183-185 */
     uint64_t cull_angle;        /* :187-188 */
     uint64_t cull_outside;      /* :191 */
@@ -159,7 +160,7 @@ void mvs_ctx_destroy(mvs_ctx* ctx);
 /* hipStream_t to launch on (NULL = the context's own stream) */
 mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
-/* integer options: "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1),
+/* integer options: "stats" (0/1: fill the cull-reason counters of mvs_dc_stats; default 0), "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1),
  * "ray_mode" (0 = one BVH traversal per ray, 1 = one shared traversal per 64-ray wave; same results) */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 

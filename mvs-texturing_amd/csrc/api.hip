@@ -129,10 +129,12 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(MVS_ERR_INVALID, "null argument");
     const std::string n(name);
     if (n == "count_rays") ctx->count_rays = value != 0;
+    else if (n == "stats") ctx->stats = value != 0;
     else if (n == "lds_bvh_levels") ctx->lds_bvh_levels = (int)value;
     else if (n == "verbose") ctx->verbose = value != 0;
     else if (n == "profile") ctx->profile = value != 0;
     else if (n == "ray_mode") ctx->ray_mode = (int)value;
+    else if (n == "mrf_shape") ctx->mrf_shape = (int)value;
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
 }

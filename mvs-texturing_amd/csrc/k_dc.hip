@@ -34,35 +34,47 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Diagnostic counters (cull reasons etc.): same-address atomics serialise at ~12 ns each, so they are
+// optional (mvs_set_option "stats") and reduced per 256-thread block before touching memory.
+template <int N>
+__device__ __forceinline__ void block_count_add(const uint32_t (&c)[N], unsigned long long* __restrict__ counters, const int (&slot)[N]) {
+    __shared__ uint32_t acc[N];
+    if (threadIdx.x < N) acc[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) { const uint32_t w = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && w) atomicAdd(&acc[k], w); }
+    __syncthreads();
+    if (threadIdx.x < N && acc[threadIdx.x]) atomicAdd(&counters[slot[threadIdx.x]], (unsigned long long)acc[threadIdx.x]);
+}
 
 // ---- culls (calculate_data_costs.cpp:171-191) ----
+template <bool STATS>
 __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const float* __restrict__ normals,
                                                    const ViewParams* __restrict__ views, uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords,
                                                    float cos_limit, unsigned long long* __restrict__ pass, unsigned long long* __restrict__ counters) {
     const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
-    if ((lf >> 6) >= fwords) return;  // whole wave beyond the face range
+    const bool wave_ok = (lf >> 6) < fwords;  // false: whole wave beyond the face range
     const bool act = lf < nf;
     const size_t f = (size_t)fb + (act ? lf : 0);
     const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const V3 v1 = ld3(verts, i0), v2 = ld3(verts, i1), v3 = ld3(verts, i2), nrm = ld3(normals, f);
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
-    uint32_t c_back = 0, c_angle = 0, c_out = 0, c_pass = 0;
-    for (uint32_t j = j0; j < j1; ++j) {
-        const int reason = act ? cull_pair(views[j], v1, v2, v3, nrm, cos_limit) : -1;
-        c_back += reason == 1; c_angle += reason == 2; c_out += reason == 3; c_pass += reason == 0;
-        const unsigned long long b = __ballot(reason == 0);
-        if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    if (wave_ok) {
+        for (uint32_t j = j0; j < j1; ++j) {
+            const int reason = act ? cull_pair(views[j], v1, v2, v3, nrm, cos_limit) : -1;
+            if (STATS) { cnt[0] += reason == 1; cnt[1] += reason == 2; cnt[2] += reason == 3; cnt[3] += reason == 0; }
+            const unsigned long long b = __ballot(reason == 0);
+            if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
+        }
     }
-    c_back = wave_sum(c_back); c_angle = wave_sum(c_angle); c_out = wave_sum(c_out); c_pass = wave_sum(c_pass);
-    if (lane == 0) {
-        atomicAdd(&counters[C_BACK], (unsigned long long)c_back); atomicAdd(&counters[C_ANGLE], (unsigned long long)c_angle);
-        atomicAdd(&counters[C_OUTSIDE], (unsigned long long)c_out); atomicAdd(&counters[C_PASS], (unsigned long long)c_pass);
-    }
+    if (STATS) { const int slot[4] = {C_BACK, C_ANGLE, C_OUTSIDE, C_PASS}; block_count_add<4>(cnt, counters, slot); }
 }
 
 // ---- which (vertex, view) rays are needed: OR of the pass bits of the incident faces ----
 // (thread s handles the s-th vertex in Morton order: need / occluded bits are indexed by that position)
+template <bool STATS>
 __global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, const uint32_t* __restrict__ vperm, uint32_t n_verts, uint32_t n_views,
                                                    uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
                                                    const unsigned long long* __restrict__ pass, unsigned long long* __restrict__ need,
@@ -86,7 +98,7 @@ __global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ 
         const unsigned long long b = __ballot((acc >> (j - j0)) & 1u);
         if (lane == 0) { need[(size_t)j * vwords + (v >> 6)] = b; n_rays += __popcll(b); }
     }
-    if (lane == 0 && n_rays) atomicAdd(&counters[C_RAYS], (unsigned long long)n_rays);
+    if (STATS && lane == 0 && n_rays) atomicAdd(&counters[C_RAYS], (unsigned long long)n_rays);
 }
 
 __global__ void popc_kernel(const unsigned long long* __restrict__ words, uint32_t* __restrict__ cnt, size_t n) {
@@ -95,7 +107,7 @@ __global__ void popc_kernel(const unsigned long long* __restrict__ words, uint32
 }
 
 // ---- get_face_info for the visible pairs (calculate_data_costs.cpp:194-228) ----
-template <int DATA_TERM, bool OUTLIER, bool VISTEST>
+template <int DATA_TERM, bool OUTLIER, bool VISTEST, bool STATS>
 __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
                                                    uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
                                                    const unsigned long long* __restrict__ pass, const unsigned long long* __restrict__ occl,
@@ -103,7 +115,7 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
                                                    const uint32_t* __restrict__ pass_base, float* __restrict__ pq, float* __restrict__ pcol,
                                                    unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters) {
     const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
-    if ((lf >> 6) >= fwords) return;  // whole wave beyond the face range
+    const bool wave_ok = (lf >> 6) < fwords;  // false: whole wave beyond the face range
     const bool act = lf < nf;
     const size_t f = (size_t)fb + (act ? lf : 0);
     const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
@@ -112,8 +124,8 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t c_occ = 0, c_zero = 0, c_surv = 0;
-    for (uint32_t j = j0; j < j1; ++j) {
+    uint32_t cnt[3] = {0, 0, 0};  // occluded, zero quality, survivors
+    for (uint32_t j = j0; wave_ok && j < j1; ++j) {
         const size_t widx = (size_t)j * fwords + (lf >> 6);
         const unsigned long long word = pass[widx];  // wave-uniform
         if (word == 0ull) { if (lane == 0) surv[widx] = 0ull; continue; }
@@ -127,8 +139,8 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
             FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
             if (visible) {
                 face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi);
-                if (fi.quality == 0.0f) ++c_zero; else { keep = true; ++c_surv; }
-            } else ++c_occ;
+                if (fi.quality == 0.0f) ++cnt[1]; else { keep = true; ++cnt[2]; }
+            } else ++cnt[0];
             const size_t r = (size_t)pass_base[widx] + __popcll(word & lt);
             pq[r] = fi.quality;
             if (OUTLIER) {
@@ -139,11 +151,7 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
         const unsigned long long b = __ballot(keep);
         if (lane == 0) surv[widx] = b;
     }
-    c_occ = wave_sum(c_occ); c_zero = wave_sum(c_zero); c_surv = wave_sum(c_surv);
-    if (lane == 0) {
-        atomicAdd(&counters[C_OCCL], (unsigned long long)c_occ); atomicAdd(&counters[C_ZEROQ], (unsigned long long)c_zero);
-        atomicAdd(&counters[C_SURV], (unsigned long long)c_surv);
-    }
+    if (STATS) { const int slot[3] = {C_OCCL, C_ZEROQ, C_SURV}; block_count_add<3>(cnt, counters, slot); }
 }
 
 // ---- view-major bits -> CSR by face ----
@@ -405,8 +413,12 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         return;
     }
     Prof pr_cull(ctx, "dc_cull");
-    hipLaunchKernelGGL(cull_kernel, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
-                       ctx->cos_limit, ctx->pass_bits.p, ctx->counters.p);
+    if (ctx->stats)
+        hipLaunchKernelGGL(cull_kernel<true>, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
+                           ctx->cos_limit, ctx->pass_bits.p, ctx->counters.p);
+    else
+        hipLaunchKernelGGL(cull_kernel<false>, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
+                           ctx->cos_limit, ctx->pass_bits.p, ctx->counters.p);
     MVS_LAUNCH_CHECK();
     pr_cull.end();
     if (vis) {
@@ -415,8 +427,12 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         MVS_HIP(hipMemsetAsync(ctx->occl_bits.p, 0, vw * sizeof(unsigned long long), s));
         const dim3 vgrid((ctx->n_verts + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
         Prof pr_need(ctx, "dc_need");
-        hipLaunchKernelGGL(need_kernel, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
-                           ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
+        if (ctx->stats)
+            hipLaunchKernelGGL(need_kernel<true>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
+                               ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
+        else
+            hipLaunchKernelGGL(need_kernel<false>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
+                               ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
         MVS_LAUNCH_CHECK();
         pr_need.end();
         Prof pr_rays(ctx, "dc_rays");
@@ -437,7 +453,9 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
 
     Prof pr_info(ctx, "dc_face_info");
 #define LAUNCH_INFO(DT, OL, VT)                                                                                              \
-    hipLaunchKernelGGL((info_kernel<DT, OL, VT>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
+    do { if (ctx->stats) LAUNCH_INFO2(DT, OL, VT, true); else LAUNCH_INFO2(DT, OL, VT, false); } while (0)
+#define LAUNCH_INFO2(DT, OL, VT, ST)                                                                                         \
+    hipLaunchKernelGGL((info_kernel<DT, OL, VT, ST>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
                        fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->vpos.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
                        ctx->surv_bits.p, ctx->counters.p)
     if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true); else LAUNCH_INFO(1, true, false); }
@@ -445,6 +463,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     else     { if (outl) { if (vis) LAUNCH_INFO(0, true, true); else LAUNCH_INFO(0, true, false); }
                else      { if (vis) LAUNCH_INFO(0, false, true); else LAUNCH_INFO(0, false, false); } }
 #undef LAUNCH_INFO
+#undef LAUNCH_INFO2
     MVS_LAUNCH_CHECK();
     pr_info.end();
     Prof pr_csr(ctx, "dc_csr");

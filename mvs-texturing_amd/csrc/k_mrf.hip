@@ -80,6 +80,24 @@ __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint1
     }
 }
 
+// One 48-byte descriptor per node (fast path, degree <= 3): everything a sweep needs to know about
+// the node in a single 3 x 16-byte load instead of the col_ptr -> adj_ptr -> edge[] dependent chain.
+__global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge,
+                                uint32_t F, NodeDesc* __restrict__ desc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    NodeDesc nd;
+    nd.p0 = col_ptr[i]; nd.k = col_ptr[i + 1] - nd.p0;
+    const uint32_t e0 = adj_ptr[i], deg = adj_ptr[i + 1] - e0;
+    for (int d = 0; d < 3; ++d) {
+        MrfEdge m; m.in_off = 0; m.out_off = 0; m.kj = 0;
+        if ((uint32_t)d < deg && nd.k > 0) m = edge[e0 + d];
+        nd.in_off[d] = m.in_off; nd.out_off[d] = m.out_off; nd.kj[d] = m.kj;
+    }
+    nd.pad_ = 0;
+    desc[i] = nd;
+}
+
 // ---- one synchronous sweep; fast path: degree <= 3, K <= G * R ----
 // All global loads of a node (unaries, the 3 incoming messages, the 3 re-alignment maps and, with
 // damping, the 3 previous outgoing messages) are issued up front; the label re-alignment gather
@@ -87,91 +105,92 @@ __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint1
 // Besides sel (label index) the decode also leaves the label itself (view id + 1) and its unary
 // cost, which is all the energy / ICM kernels need of a neighbour.
 template <int G, int R, bool DAMP>
-__global__ void __launch_bounds__(256) mrf_sweep_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                        const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
-                                                        const float* __restrict__ mo, float* __restrict__ mn, uint32_t* __restrict__ sel,
-                                                        uint32_t* __restrict__ lab, float* __restrict__ selcost,
+__global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                        const uint16_t* __restrict__ map, const float* __restrict__ mo, float* __restrict__ mn,
+                                                        uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     constexpr int NPB = 256 / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const uint32_t i = node_begin + blockIdx.x * NPB + grp;
-    const bool node_ok = i < node_end;
-    const uint32_t p0 = node_ok ? col_ptr[i] : 0u;
-    const uint32_t K = node_ok ? col_ptr[i + 1] - p0 : 0u;
-    const uint32_t e0 = node_ok ? adj_ptr[i] : 0u;
-    const uint32_t deg = node_ok ? adj_ptr[i + 1] - e0 : 0u;
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
-    MrfEdge em[3];
+    const uint32_t stride = gridDim.x * NPB;
+    // persistent groups: every lane group walks nodes first, first + stride, ...; the next node's
+    // descriptor is requested before the current node is processed
+    uint32_t i = node_begin + blockIdx.x * NPB + grp;
+    NodeDesc nd = {};
+    if (i < node_end) nd = desc[i];
+    const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;   // uniform trip count (shuffles need all lanes)
+    for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
+        const bool node_ok = i < node_end;
+        const NodeDesc cur = nd;
+        const uint32_t inext = i + stride;
+        if (inext < node_end) nd = desc[inext];
+        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
+        float D[R], in[3][R], old[3][R];
+        uint32_t mp[3][R];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        if ((uint32_t)d < deg) em[d] = edge[e0 + d];
-        else { em[d].in_off = 0; em[d].out_off = 0; em[d].kj = 0; }
-        if (K == 0) em[d].kj = 0;
-    }
-    float D[R], in[3][R], old[3][R];
-    uint32_t mp[3][R];
+        for (int r = 0; r < R; ++r) {
+            const uint32_t t = gl + r * G;
+            const bool ok = t < K;
+            D[r] = ok ? cost[p0 + t] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t t = gl + r * G;
-        const bool ok = t < K;
-        D[r] = ok ? cost[p0 + t] : 0.0f;
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t kj = node_ok ? cur.kj[d] : 0u;
+                in[d][r] = (ok && kj) ? mo[cur.in_off[d] + t] : 0.0f;
+                const bool ok2 = t < kj;
+                mp[d][r] = ok2 ? (uint32_t)map[cur.out_off[d] + t] : 0u;
+                old[d][r] = (DAMP && ok2) ? mo[cur.out_off[d] + t] : 0.0f;
+            }
+        }
+        // decode: first argmin_t of b[t] = D[t] + rho * S[t]
+        {
+            float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t t = gl + r * G;
+                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
+                const float b = D[r] + rho * S;
+                if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
+            }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
+                if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
+            }
+            if (gl == 0 && node_ok) {
+                if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
+                else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
+            }
+        }
+        // outgoing messages
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            in[d][r] = (ok && em[d].kj) ? mo[em[d].in_off + t] : 0.0f;
-            const bool ok2 = t < em[d].kj;
-            mp[d][r] = ok2 ? (uint32_t)map[em[d].out_off + t] : 0u;
-            old[d][r] = (DAMP && ok2) ? mo[em[d].out_off + t] : 0.0f;
-        }
-    }
-    // decode: first argmin_t of b[t] = D[t] + rho * S[t]
-    {
-        float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+            const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
+            float c[R];
+            float cmin = INFINITY;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t t = gl + r * G;
-            const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
-            const float b = D[r] + rho * S;
-            if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
-        }
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
-            if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
-        }
-        if (gl == 0 && node_ok) {
-            if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
-            else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
-        }
-    }
-    // outgoing messages
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
-        float c[R];
-        float cmin = INFINITY;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t t = gl + r * G;
-            const float oth = (0.0f + in[a][r]) + in[b2][r];
-            c[r] = (D[r] + rho * oth) - omr * in[d][r];
-            if (t < K) cmin = fminf(cmin, c[r]);
-        }
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
-        const uint32_t kj = em[d].kj, oo = em[d].out_off;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t t2 = gl + r * G;
-            const uint32_t p = mp[d][r];
-            const uint32_t pl = p & (uint32_t)(G - 1), ps = (p & 0xFFFFu) / (uint32_t)G;
-            float cp = 0.0f;
-#pragma unroll
-            for (int s2 = 0; s2 < R; ++s2) {   // every lane executes the shuffles (no divergence around ds_bpermute)
-                const float v = __shfl(c[s2], (int)pl, G);
-                cp = (ps == (uint32_t)s2) ? v : cp;
+            for (int r = 0; r < R; ++r) {
+                const uint32_t t = gl + r * G;
+                const float oth = (0.0f + in[a][r]) + in[b2][r];
+                c[r] = (D[r] + rho * oth) - omr * in[d][r];
+                if (t < K) cmin = fminf(cmin, c[r]);
             }
-            const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
-            if (t2 < kj) mn[oo + t2] = DAMP ? (raw * oma + old[d][r] * alpha) : raw;
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
+            const uint32_t kj = node_ok ? cur.kj[d] : 0u, oo = cur.out_off[d];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t t2 = gl + r * G;
+                const uint32_t p = mp[d][r];
+                const uint32_t pl = p & (uint32_t)(G - 1), ps = (p & 0xFFFFu) / (uint32_t)G;
+                float cp = 0.0f;
+#pragma unroll
+                for (int s2 = 0; s2 < R; ++s2) {   // every lane executes the shuffles (no divergence around ds_bpermute)
+                    const float v = __shfl(c[s2], (int)pl, G);
+                    cp = (ps == (uint32_t)s2) ? v : cp;
+                }
+                const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
+                if (t2 < kj) mn[oo + t2] = DAMP ? (raw * oma + old[d][r] * alpha) : raw;
+            }
         }
     }
 }
@@ -242,8 +261,15 @@ __global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restr
             cuts += (lj != 0u && lj != li);
         }
     }
+    // one atomic pair per block (same-address atomics serialise): wave shuffle, then LDS across the 4 waves
+    __shared__ unsigned long long su[4], sc[4];
     for (int o = 32; o > 0; o >>= 1) { unary += __shfl_xor(unary, o, 64); cuts += __shfl_xor(cuts, o, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], unary + (cuts << 32)); atomicAdd(&out[1], cuts); }
+    if ((threadIdx.x & 63) == 0) { su[threadIdx.x >> 6] = unary; sc[threadIdx.x >> 6] = cuts; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long u = su[0] + su[1] + su[2] + su[3], c = sc[0] + sc[1] + sc[2] + sc[3];
+        atomicAdd(&out[0], u + (c << 32)); atomicAdd(&out[1], c);
+    }
 }
 
 // ---- ICM polish: G lanes per node over its labels ----
@@ -360,6 +386,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipStreamSynchronize(s));
     ctx->m_total = h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
     if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
+    ctx->m_desc.ensure((size_t)F + 1);
+    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
     ctx->m_map.ensure(ctx->m_total + 1);
     if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p); MVS_LAUNCH_CHECK(); }
     ctx->m_msg_a.ensure(ctx->m_total + 1); ctx->m_msg_b.ensure(ctx->m_total + 1);
@@ -384,12 +412,15 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
 template <int G, int R>
 static void launch_sweep_gr(mvs_ctx* ctx, const float* mo, float* mn, uint32_t nb0, uint32_t ne0) {
     constexpr int NPB = 256 / G;
-    const unsigned blocks = (ne0 - nb0 + NPB - 1) / NPB;
+    const unsigned need = (ne0 - nb0 + NPB - 1) / NPB;
+    const unsigned blocks = std::min<unsigned>(need, 256u * 8u);   // persistent: 8 blocks of 256 threads per CU
     const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
     if (alpha != 0.0f)
-        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
+        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn,
+                           ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
     else
-        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
+        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn,
+                           ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
 }
 
 // one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
@@ -399,9 +430,20 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 > nb0) {
         const uint32_t K = ctx->m_kmax;
         if (ctx->m_degmax <= 3 && K <= 256) {
-            if (K <= 8) launch_sweep_gr<8, 1>(ctx, mo, mn, nb0, ne0);
-            else if (K <= 16) launch_sweep_gr<16, 1>(ctx, mo, mn, nb0, ne0);
-            else if (K <= 32) launch_sweep_gr<32, 1>(ctx, mo, mn, nb0, ne0);
+            // lanes per node (G) x labels per lane (R); several nodes per wave keep more loads in flight
+            const int shape = ctx->mrf_shape;   // 0 = auto
+            if (shape == 0) {
+                if (K <= 8) launch_sweep_gr<8, 1>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 16) launch_sweep_gr<16, 1>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 32) launch_sweep_gr<16, 2>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 64) launch_sweep_gr<16, 4>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 128) launch_sweep_gr<32, 4>(ctx, mo, mn, nb0, ne0);
+                else launch_sweep_gr<64, 4>(ctx, mo, mn, nb0, ne0);
+            } else if (shape == 641 && K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
+            else if (shape == 322 && K <= 64) launch_sweep_gr<32, 2>(ctx, mo, mn, nb0, ne0);
+            else if (shape == 164 && K <= 64) launch_sweep_gr<16, 4>(ctx, mo, mn, nb0, ne0);
+            else if (shape == 321 && K <= 32) launch_sweep_gr<32, 1>(ctx, mo, mn, nb0, ne0);
+            else if (shape == 162 && K <= 32) launch_sweep_gr<16, 2>(ctx, mo, mn, nb0, ne0);
             else if (K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
             else if (K <= 128) launch_sweep_gr<64, 2>(ctx, mo, mn, nb0, ne0);
             else launch_sweep_gr<64, 4>(ctx, mo, mn, nb0, ne0);
@@ -423,7 +465,7 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0) {
     MVS_HIP(hipMemsetAsync(ctx->m_energy.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     if (ne0 > nb0) {
-        const unsigned blocks = std::min<unsigned>((ne0 - nb0 + 255) / 256, 4096u);
+        const unsigned blocks = std::min<unsigned>((ne0 - nb0 + 255) / 256, 1024u);
         hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj,
                            best ? ctx->m_best_lab.p : ctx->m_lab.p, best ? ctx->m_best_cost.p : ctx->m_cost.p, nb0, ne0, ctx->m_energy.p);
         MVS_LAUNCH_CHECK();

@@ -333,10 +333,12 @@ def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, dev
         mf, mn = max(s[0] for s in all_sizes), max(max(s[1] for s in all_sizes), 1)
 
         def gather_padded(t, n, m):
+            # as raw bytes: RCCL / gloo have no 16-bit integer type
             pad = torch.zeros(m, dtype=t.dtype, device=device); pad[:n] = t[:n]
-            outs = [torch.zeros(m, dtype=t.dtype, device=device) for _ in range(P)]
-            dist.all_gather(outs, pad, group=group)
-            return outs
+            pad8 = pad.view(torch.uint8)
+            outs = [torch.zeros(pad8.numel(), dtype=torch.uint8, device=device) for _ in range(P)]
+            dist.all_gather(outs, pad8, group=group)
+            return [o.view(t.dtype) for o in outs]
         cs = gather_padded(counts, nf, max(mf, 1)); vs = gather_padded(vid, nnz, mn); fs = gather_padded(cost, nnz, mn)
         counts = torch.cat([cs[p][:all_sizes[p][0]] for p in range(P)])
         vid = torch.cat([vs[p][:all_sizes[p][1]] for p in range(P)])

@@ -14,7 +14,7 @@ def compare_dc(scene, tag, **kw):
     t = time.time(); ref, rst = O.data_costs(scene, **kw); t_cpu = time.time() - t
     st = M.Settings(**kw)
     ctx = M.Context()
-    ctx.set_option("count_rays", 1)
+    ctx.set_option("count_rays", 1); ctx.set_option("stats", 1)
     ctx.set_mesh(scene.verts, scene.faces, scene.normals); ctx.set_views(scene.cams, scene.images)
     t = time.time(); gst = ctx.data_costs(st); ctx.synchronize(); t_gpu = time.time() - t
     t = time.time(); gst = ctx.data_costs(st); ctx.synchronize(); t_gpu2 = time.time() - t
@@ -88,7 +88,7 @@ def stage_raymodes():
     s = synth.make_scene(**synth.CONFIGS[2])
     res = {}
     for mode in (0, 1):
-        ctx = M.Context(); ctx.set_option("count_rays", 1); ctx.set_option("ray_mode", mode); ctx.set_option("profile", 1)
+        ctx = M.Context(); ctx.set_option("count_rays", 1); ctx.set_option("stats", 1); ctx.set_option("ray_mode", mode); ctx.set_option("profile", 1)
         ctx.set_mesh(s.verts, s.faces, s.normals); ctx.set_views(s.cams, s.images)
         ctx.data_costs(M.Settings()); ctx.get_profile()
         st = ctx.data_costs(M.Settings()); prof = ctx.get_profile()

@@ -31,6 +31,7 @@ MODES = {
 @pytest.fixture(scope="module")
 def ctx():
     c = M.Context(0)
+    c.set_option("stats", 1)        # fill the cull-reason counters (diagnostics, off by default)
     yield c
     c.close()
 
