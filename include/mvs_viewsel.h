@@ -157,7 +157,7 @@ typedef struct mvs_ctx mvs_ctx;
 
 mvs_status mvs_ctx_create(int device, mvs_ctx** out);
 void mvs_ctx_destroy(mvs_ctx* ctx);
-/* hipStream_t to launch on (NULL = the context's own stream) */
+/* hipStream_t to launch on from now on (NULL = the device's default stream); a fresh context owns a private stream */
 mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
 /* integer options: "stats" (0/1: fill the cull-reason counters of mvs_dc_stats; default 0), "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1),

@@ -1,0 +1,269 @@
+// tex_viewsel.hpp -- header-only C++ mirror of the reference's interface for the
+// view-selection path, on top of the C ABI of mvs_viewsel.h.
+//
+// Same names, argument meaning and error behaviour as nmoehrle/mvs-texturing:
+//   tex::Settings / DataTerm / OutlierRemoval        libs/tex/settings.h:59-95
+//   tex::TextureView (the members the path reads)    libs/tex/texture_view.h:39-117
+//   SparseTable<C,R,T>, tex::DataCosts               libs/tex/sparse_table.h:29-187, texturing.h:36
+//   UniGraph, tex::Graph                             libs/tex/uni_graph.h:20-138, texturing.h:35
+//   tex::calculate_data_costs                        libs/tex/texturing.h:66-69
+//   tex::view_selection                              libs/tex/texturing.h:79-80
+// so that the call sequence of apps/texrecon/texrecon.cpp:88-136 compiles against
+// this header unchanged.  MVE is not required: the mesh is any object with
+// get_faces() / get_vertices() / get_face_normals() (mve::TriangleMesh has them;
+// tex::SimpleMesh below is a stand-in), images are plain RGB8 buffers.
+// INTEGRATION.md shows how the same marshalling replaces the bodies of
+// calculate_data_costs.cpp / view_selection.cpp inside an upstream checkout.
+#ifndef TEX_VIEWSEL_HPP
+#define TEX_VIEWSEL_HPP
+
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mvs_viewsel.h"
+
+/* ---------------- SparseTable (libs/tex/sparse_table.h) ---------------- */
+#define TEX_SPARSE_TABLE_HEADER "SPT"
+#define TEX_SPARSE_TABLE_VERSION "0.2"
+
+template <typename C, typename R, typename T>
+class SparseTable {
+public:
+    typedef std::vector<std::pair<R, T> > Column;
+    typedef std::vector<std::pair<C, T> > Row;
+
+private:
+    std::vector<Column> column_wise_data;
+    std::vector<Row> row_wise_data;
+    std::size_t nnz;
+
+public:
+    SparseTable() : nnz(0) {}
+    SparseTable(C cols, R rows) : nnz(0) { column_wise_data.resize(cols); row_wise_data.resize(rows); }
+    C cols() const { return static_cast<C>(column_wise_data.size()); }
+    R rows() const { return static_cast<R>(row_wise_data.size()); }
+    Column const& col(C id) const { return column_wise_data[id]; }
+    Row const& row(R id) const { return row_wise_data[id]; }
+    void set_value(C col, R row, T value) {
+        column_wise_data[col].push_back(std::pair<R, T>(row, value));
+        row_wise_data[row].push_back(std::pair<C, T>(col, value));
+        nnz++;
+    }
+    std::size_t get_nnz(void) const { return nnz; }
+
+    /* sparse_table.h:112-136 */
+    static void save_to_file(SparseTable const& t, std::string const& filename) {
+        std::ofstream out(filename.c_str(), std::ios::binary);
+        if (!out.good()) throw std::runtime_error("Could not open " + filename);
+        out << TEX_SPARSE_TABLE_HEADER << " " << TEX_SPARSE_TABLE_VERSION << " " << t.cols() << " " << t.rows() << " " << t.get_nnz() << std::endl;
+        for (C col = 0; col < t.cols(); ++col)
+            for (auto const& e : t.col(col)) {
+                out.write((char const*)&col, sizeof(C)); out.write((char const*)&e.first, sizeof(R)); out.write((char const*)&e.second, sizeof(T));
+            }
+    }
+    /* sparse_table.h:138-187 */
+    static void load_from_file(std::string const& filename, SparseTable* t) {
+        std::ifstream in(filename.c_str(), std::ios::binary);
+        if (!in.good()) throw std::runtime_error("Could not open " + filename);
+        std::string header, version;
+        in >> header;
+        if (header != TEX_SPARSE_TABLE_HEADER) throw std::runtime_error("Not a SparseTable file!");
+        in >> version;
+        if (version != TEX_SPARSE_TABLE_VERSION) throw std::runtime_error("Incompatible version of SparseTable file!");
+        C cols; R rows; std::size_t n;
+        in >> cols >> rows >> n;
+        if (cols != t->cols() || rows != t->rows()) throw std::runtime_error("SparseTable has different dimension!");
+        std::string rest; std::getline(in, rest);
+        for (std::size_t i = 0; i < n; ++i) {
+            C col; R row; T value;
+            in.read((char*)&col, sizeof(C)); in.read((char*)&row, sizeof(R)); in.read((char*)&value, sizeof(T));
+            t->set_value(col, row, value);
+        }
+    }
+};
+
+/* ---------------- UniGraph (libs/tex/uni_graph.h) ---------------- */
+class UniGraph {
+    std::vector<std::vector<std::size_t> > adj_lists;
+    std::vector<std::size_t> labels;
+    std::size_t edges;
+
+public:
+    explicit UniGraph(std::size_t nodes) : edges(0) { adj_lists.resize(nodes); labels.resize(nodes); }
+    bool has_edge(std::size_t n1, std::size_t n2) const {
+        auto const& l = adj_lists[n1];
+        return std::find(l.begin(), l.end(), n2) != l.end();
+    }
+    void add_edge(std::size_t n1, std::size_t n2) {
+        if (!has_edge(n1, n2)) { adj_lists[n1].push_back(n2); adj_lists[n2].push_back(n1); ++edges; }
+    }
+    std::size_t num_edges() const { return edges; }
+    std::size_t num_nodes() const { return adj_lists.size(); }
+    void set_label(std::size_t n, std::size_t label) { labels[n] = label; }
+    std::size_t get_label(std::size_t n) const { return labels[n]; }
+    std::vector<std::size_t> const& get_adj_nodes(std::size_t node) const { return adj_lists[node]; }
+};
+
+namespace tex {
+
+/* ---------------- settings (libs/tex/settings.h:59-95) ---------------- */
+enum DataTerm { DATA_TERM_AREA = 0, DATA_TERM_GMI = 1 };
+enum SmoothnessTerm { SMOOTHNESS_TERM_POTTS = 0 };
+enum OutlierRemoval { OUTLIER_REMOVAL_NONE = 0, OUTLIER_REMOVAL_GAUSS_DAMPING = 1, OUTLIER_REMOVAL_GAUSS_CLAMPING = 2 };
+
+struct Settings {
+    bool verbose = false;
+    DataTerm data_term = DATA_TERM_GMI;
+    SmoothnessTerm smoothness_term = SMOOTHNESS_TERM_POTTS;
+    OutlierRemoval outlier_removal = OUTLIER_REMOVAL_NONE;
+    bool geometric_visibility_test = true;
+    bool global_seam_leveling = true;
+    bool local_seam_leveling = true;
+    bool hole_filling = true;
+    bool keep_unseen_faces = false;
+};
+
+/* ---------------- TextureView: the members the path reads (texture_view.h:39-117) ---------------- */
+class TextureView {
+    std::size_t id;
+    std::array<float, 3> pos, viewdir;
+    std::array<float, 9> projection;      // math::Matrix3f, row major
+    std::array<float, 16> world_to_cam;   // math::Matrix4f, row major
+    int width, height;
+    std::shared_ptr<std::vector<std::uint8_t> > image;   // RGB8, width * height * 3 (mve::ByteImage layout)
+
+public:
+    TextureView(std::size_t id, const float pos_[3], const float viewdir_[3], const float K[9], const float w2c[16], int width, int height)
+        : id(id), width(width), height(height) {
+        std::copy(pos_, pos_ + 3, pos.begin()); std::copy(viewdir_, viewdir_ + 3, viewdir.begin());
+        std::copy(K, K + 9, projection.begin()); std::copy(w2c, w2c + 16, world_to_cam.begin());
+    }
+    std::size_t get_id(void) const { return id; }
+    const float* get_pos(void) const { return pos.data(); }
+    const float* get_viewing_direction(void) const { return viewdir.data(); }
+    const float* get_projection(void) const { return projection.data(); }
+    const float* get_world_to_cam(void) const { return world_to_cam.data(); }
+    int get_width(void) const { return width; }
+    int get_height(void) const { return height; }
+    /* bind_image / get_image / release_image: texture_view.h:147-151,187-189,203-206 */
+    void bind_image(std::shared_ptr<std::vector<std::uint8_t> > new_image) { image = std::move(new_image); }
+    std::shared_ptr<std::vector<std::uint8_t> > get_image(void) const { return image; }
+    void release_image(void) { image.reset(); }
+};
+
+typedef std::vector<TextureView> TextureViews;
+typedef UniGraph Graph;
+typedef SparseTable<std::uint32_t, std::uint16_t, float> DataCosts;
+
+/** Stand-in for mve::TriangleMesh::ConstPtr with the three getters of calculate_data_costs.cpp:136-138. */
+struct SimpleMesh {
+    std::vector<unsigned int> faces;     // 3 per face
+    std::vector<float> vertices;         // xyz per vertex
+    std::vector<float> face_normals;     // xyz per face
+    std::vector<unsigned int> const& get_faces() const { return faces; }
+    std::vector<float> const& get_vertices() const { return vertices; }
+    std::vector<float> const& get_face_normals() const { return face_normals; }
+    typedef std::shared_ptr<const SimpleMesh> ConstPtr;
+};
+
+namespace detail {
+inline void throw_status(mvs_status st) {
+    /* the reference throws std::runtime_error with these texts (calculate_data_costs.cpp:315-318, view_selection.cpp:126-128) */
+    switch (st) {
+        case MVS_OK: return;
+        case MVS_ERR_TOO_MANY_FACES: throw std::runtime_error("Exeeded maximal number of faces");
+        case MVS_ERR_TOO_MANY_VIEWS: throw std::runtime_error("Exeeded maximal number of views");
+        case MVS_ERR_LABELING: throw std::runtime_error("Incorrect labeling");
+        default: throw std::runtime_error(std::string("mvs_viewsel: ") + mvs_last_error());
+    }
+}
+template <class V> const float* flat(V const& v) { return reinterpret_cast<const float*>(v.data()); }  // vector<float> or vector<math::Vec3f>
+}  // namespace detail
+
+/**
+ * Calculates the data costs for each face and texture view combination,
+ * if the face is visible within the texture view.   (libs/tex/texturing.h:62-69)
+ * `data_costs` must be pre-sized by the caller to (faces, views) as at texrecon.cpp:98.
+ * Views must have their image bound (the reference loads it from disk at calculate_data_costs.cpp:157 and
+ * releases it at :231; this adapter likewise leaves the views released).
+ */
+template <class MeshConstPtr>
+void calculate_data_costs(MeshConstPtr mesh, TextureViews* texture_views, Settings const& settings, DataCosts* data_costs) {
+    std::size_t const num_faces = mesh->get_faces().size() / 3;
+    std::size_t const num_views = texture_views->size();
+    if (num_faces > std::numeric_limits<std::uint32_t>::max()) throw std::runtime_error("Exeeded maximal number of faces");
+    if (num_views > std::numeric_limits<std::uint16_t>::max()) throw std::runtime_error("Exeeded maximal number of views");
+
+    mvs_mesh m;
+    m.n_faces = static_cast<std::uint32_t>(num_faces);
+    m.n_verts = static_cast<std::uint32_t>(mesh->get_vertices().size() * sizeof(mesh->get_vertices()[0]) / (3 * sizeof(float)));
+    m.verts = detail::flat(mesh->get_vertices());
+    m.faces = mesh->get_faces().data();
+    m.face_normals = detail::flat(mesh->get_face_normals());
+    std::vector<mvs_view> views(num_views);
+    for (std::size_t j = 0; j < num_views; ++j) {
+        TextureView const& tv = texture_views->at(j);
+        if (!tv.get_image()) throw std::runtime_error("TextureView without image");
+        std::memcpy(views[j].pos, tv.get_pos(), sizeof(float) * 3);
+        std::memcpy(views[j].viewdir, tv.get_viewing_direction(), sizeof(float) * 3);
+        std::memcpy(views[j].K, tv.get_projection(), sizeof(float) * 9);
+        std::memcpy(views[j].w2c, tv.get_world_to_cam(), sizeof(float) * 16);
+        views[j].width = tv.get_width(); views[j].height = tv.get_height();
+        views[j].rgb = tv.get_image()->data();
+    }
+    mvs_settings st;
+    st.data_term = settings.data_term; st.outlier_removal = settings.outlier_removal;
+    st.geometric_visibility_test = settings.geometric_visibility_test ? 1 : 0;
+    mvs_csr csr; std::memset(&csr, 0, sizeof(csr));
+    mvs_dc_stats stats;
+    detail::throw_status(mvs_data_costs(&m, views.data(), static_cast<std::uint32_t>(num_views), &st, &csr, &stats));
+    for (std::uint32_t i = 0; i < csr.n_faces; ++i)          /* calculate_data_costs.cpp:291-298 */
+        for (std::uint32_t k = csr.col_ptr[i]; k < csr.col_ptr[i + 1]; ++k) data_costs->set_value(i, csr.view_id[k], csr.cost[k]);
+    mvs_csr_free(&csr);
+    for (TextureView& tv : *texture_views) tv.release_image();  /* :231 */
+    std::cout << "\tMaximum quality of a face within an image: " << stats.max_quality << std::endl;     /* :304-305 */
+    std::cout << "\tClamping qualities to " << stats.percentile << " within normalization." << std::endl;
+}
+
+/** Runs the view selection procedure and saves the labeling in the graph   (libs/tex/texturing.h:76-80) */
+inline void view_selection(DataCosts const& data_costs, UniGraph* graph, Settings const&) {
+    std::uint32_t const F = data_costs.cols();
+    std::vector<std::uint32_t> col_ptr(F + 1, 0);
+    std::vector<std::uint16_t> view_id; std::vector<float> cost;
+    view_id.reserve(data_costs.get_nnz()); cost.reserve(data_costs.get_nnz());
+    for (std::uint32_t i = 0; i < F; ++i) {
+        for (auto const& e : data_costs.col(i)) { view_id.push_back(e.first); cost.push_back(e.second); }
+        col_ptr[i + 1] = static_cast<std::uint32_t>(view_id.size());
+    }
+    std::vector<std::uint32_t> adj_ptr(F + 1, 0), adj;
+    for (std::uint32_t i = 0; i < F; ++i) {
+        for (std::size_t n : graph->get_adj_nodes(i)) adj.push_back(static_cast<std::uint32_t>(n));
+        adj_ptr[i + 1] = static_cast<std::uint32_t>(adj.size());
+    }
+    if (view_id.empty()) { view_id.push_back(0); cost.push_back(0.0f); }
+    if (adj.empty()) adj.push_back(0);
+    mvs_csr csr;
+    csr.n_faces = F; csr.n_views = data_costs.rows(); csr.nnz = col_ptr[F];
+    csr.col_ptr = col_ptr.data(); csr.view_id = view_id.data(); csr.cost = cost.data();
+    std::vector<std::uint32_t> labels(F, 0);
+    mvs_mrf_stats stats;
+    std::cout << "\tOptimizing:" << std::endl;
+    detail::throw_status(mvs_view_selection(&csr, adj_ptr.data(), adj.data(), nullptr, labels.data(), &stats));
+    std::cout << "\t\t" << stats.sweeps << " sweeps\t" << stats.energy << std::endl;
+    for (std::uint32_t i = 0; i < F; ++i) graph->set_label(i, labels[i]);                  /* view_selection.cpp:130 */
+    std::cout << '\t' << stats.unseen << " faces have not been seen" << std::endl;      /* :132 */
+}
+
+}  // namespace tex
+
+#endif  // TEX_VIEWSEL_HPP

@@ -113,8 +113,9 @@ mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream) {
     MVS_API_BEGIN
     MVS_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) MVS_HIP(hipStreamDestroy(ctx->stream));
-    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
-    else { MVS_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    // NULL is a valid handle: the (legacy) default stream, which is what torch.cuda.current_stream() is
+    // unless the caller switched streams
+    ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false;
     MVS_API_END
 }
 

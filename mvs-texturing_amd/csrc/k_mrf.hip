@@ -287,10 +287,14 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
     const uint32_t e0 = node_ok ? adj_ptr[i] : 0u, e1 = node_ok ? adj_ptr[i + 1] : 0u;
     const uint32_t cur_t = (K > 0) ? sel[i] : 0u;
     float best = INFINITY, cur = 0.0f; uint32_t bt = 0xFFFFFFFFu;
+    // neighbour labels: the first three once (the manifold case), any further ones inside the loop
+    uint32_t nl[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && e0 + d < e1) ? lab[adj[e0 + d]] : 0u;
     for (uint32_t t = gl; t < K; t += G) {
         const uint32_t l = (uint32_t)view_id[p0 + t] + 1u;
-        uint32_t diff = 0;
-        for (uint32_t e = e0; e < e1; ++e) { const uint32_t lj = lab[adj[e]]; diff += (lj != 0u && lj != l); }
+        uint32_t diff = (nl[0] != 0u && nl[0] != l) + (nl[1] != 0u && nl[1] != l) + (nl[2] != 0u && nl[2] != l);
+        for (uint32_t e = e0 + 3; e < e1; ++e) { const uint32_t lj = lab[adj[e]]; diff += (lj != 0u && lj != l); }
         const float en = cost[p0 + t] + (float)diff;
         if (en < best) { best = en; bt = t; }
         if (t == cur_t) cur = en;
