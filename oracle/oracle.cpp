@@ -759,7 +759,8 @@ void orc_csr_free(orc_csr* c) {
 namespace {
 
 const uint16_t MAP_NONE = 0xFFFF;
-uint64_t* g_trace = nullptr; int g_trace_len = 0;  // optional per-sweep energy trace (experiments)
+uint64_t* g_trace = nullptr; int g_trace_len = 0;
+uint64_t* g_quiet = nullptr;  // optional: per sweep, nodes that a lazy sweep could skip (experiments)  // optional per-sweep energy trace (experiments)
 
 inline uint64_t fix32(float d) { return (uint64_t)((double)d * 4294967296.0); }
 
@@ -914,6 +915,7 @@ uint32_t mrf_icm_iter(const Mrf& g, std::vector<uint32_t>& sel, std::vector<floa
 extern "C" {
 
 void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = len; }
+void orc_mrf_set_quiet_trace(uint64_t* buf) { g_quiet = buf; }
 
 void orc_mrf_default_params(orc_mrf_params* p) {
     p->max_sweeps = 200; p->min_sweeps = 20; p->window = 10; p->min_improvement = 0.002f;
@@ -948,6 +950,23 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
         if (e < best_e) { best_e = e; best_cuts = cuts; best_sel = sel; }
         hist.push_back(best_e);
         if (g_trace && (int)s <= g_trace_len) g_trace[s - 1] = e;
+        if (g_quiet && (int)s <= g_trace_len) {
+            // after the swap: ma = messages of this sweep, mb = previous sweep's.  c(i) = any outgoing word of i changed
+            static std::vector<uint8_t> chg_prev; std::vector<uint8_t> chg(g.F, 0);
+            for (uint32_t i = 0; i < g.F; ++i)
+                for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) {
+                    if (!g.valid[e]) continue;
+                    const uint32_t r = g.rev[e]; const uint64_t o = g.moff[r]; const uint32_t kj = g.K(g.adj[e]);
+                    if (memcmp(&ma[o], &mb[o], kj * sizeof(float)) != 0) { chg[i] = 1; break; }
+                }
+            uint64_t quiet = 0;
+            for (uint32_t i = 0; i < g.F; ++i) {
+                bool q = !chg[i];
+                for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1] && q; ++e) if (g.valid[e] && chg[g.adj[e]]) q = false;
+                quiet += q;
+            }
+            g_quiet[s - 1] = quiet;
+        }
         if ((int)s >= P.min_sweeps && (int)s > P.window) {
             const uint64_t prev = hist[s - P.window];
             if ((double)(prev - best_e) < (double)P.min_improvement * (double)prev) break;

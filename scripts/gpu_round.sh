@@ -14,3 +14,11 @@ if [ -n "$DO_PROF" ]; then
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o bench -- python $REPO/bench.py --config ${BENCH_CONFIG:-3} --steps 2 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_bench.log 2>&1
   cd $REPO; find gpurun_out/prof -type f | head
 fi
+if [ -n "$DO_PMC" ]; then
+  echo "== rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE separately)"
+  REPO=$PWD; cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o pmc -- python $REPO/bench.py --config ${BENCH_CONFIG:-3} --steps 1 --warmup 0 --no-cpu-baseline > $REPO/gpurun_out/pmc_$c.log 2>&1
+  done
+  cd $REPO; find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -type f | head; du -sh gpurun_out
+fi
