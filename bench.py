@@ -128,8 +128,9 @@ def main():
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_option("profile", 1)
-    if os.environ.get("MVS_MRF_SHAPE"):
-        ctx.set_option("mrf_shape", int(os.environ["MVS_MRF_SHAPE"]))
+    for env, opt in (("MVS_MRF_SHAPE", "mrf_shape"), ("MVS_MRF_UNROLL", "mrf_unroll"), ("MVS_MRF_NT", "mrf_nt"), ("MVS_MRF_BPC", "mrf_blocks_per_cu")):
+        if os.environ.get(env):   # tuning knobs for experiments
+            ctx.set_option(opt, int(os.environ[env]))
     if os.environ.get("MVS_RAY_MODE"):
         ctx.set_option("ray_mode", int(os.environ["MVS_RAY_MODE"]))
     ctx.set_mesh(t_v, t_f, t_n)

@@ -80,14 +80,15 @@ struct MrfEdge {      // per directed edge e = (i <- j) in adjacency-CSR order
     uint32_t kj;      // K_j if the edge is valid (both columns non-empty), else 0
 };
 
-struct alignas(16) NodeDesc {   // fast-path (degree <= 3) per-node descriptor, 48 bytes
+struct alignas(16) NodeDesc {   // fast-path (degree <= 3) per-node descriptor, 64 bytes = 4 x 16-byte loads
     uint32_t p0, k;           // column start / length
     uint32_t in_off[3];       // incoming message offsets
     uint32_t out_off[3];      // outgoing message offsets (= in_off of the reverse edges)
-    uint32_t kj[3];           // neighbour column lengths, 0 = edge not in the model
-    uint32_t pad_;
+    uint32_t kj[3];           // neighbour column lengths (0 = edge not in the model); top bit = identical label lists
+    uint32_t nbr[3];          // neighbour node ids (0xFFFFFFFF = none)
+    uint32_t pad_[2];
 };
-static_assert(sizeof(NodeDesc) == 48, "NodeDesc must be 48 bytes");
+static_assert(sizeof(NodeDesc) == 64, "NodeDesc must be 64 bytes");
 
 }  // namespace mvs
 
@@ -147,7 +148,7 @@ struct mvs_ctx {
 
     // ---- MRF ----
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
-    mvs::DBuf<mvs::NodeDesc> m_desc; int mrf_shape = 0;
+    mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_shape = 0, mrf_unroll = 1, mrf_nt = 0, mrf_blocks_per_cu = 8;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
     mvs::DBuf<float> m_msg_a, m_msg_b; mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
     mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best

@@ -60,8 +60,10 @@ __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint
 }
 
 // map[in_off(e) + t] = position of L_i[t] in L_j (binary search; lists ascending, calculate_data_costs.cpp:272)
+// ident[e] = 1 iff the two label lists of edge e are identical (map == identity), i.e. the sender's out-edge rev(e) can skip it
 __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
-                               const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint16_t* __restrict__ map) {
+                               const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint16_t* __restrict__ map,
+                               uint8_t* __restrict__ ident) {
     // 16 lanes per node
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
@@ -71,19 +73,24 @@ __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint1
         const MrfEdge m = edge[e];
         if (m.kj == 0) continue;
         const uint32_t q0 = col_ptr[adj[e]];
+        uint32_t same = (K == m.kj) ? 1u : 0u;
         for (uint32_t t = gl; t < K; t += 16) {
             const uint16_t key = view_id[p0 + t];
             uint32_t lo = 0, hi = m.kj;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (view_id[q0 + mid] < key) lo = mid + 1; else hi = mid; }
-            map[m.in_off + t] = (lo < m.kj && view_id[q0 + lo] == key) ? (uint16_t)lo : MAP_NONE;
+            const uint16_t pos = (lo < m.kj && view_id[q0 + lo] == key) ? (uint16_t)lo : MAP_NONE;
+            map[m.in_off + t] = pos;
+            same &= (pos == t) ? 1u : 0u;
         }
+        for (int o = 8; o > 0; o >>= 1) same &= __shfl_xor(same, o, 16);
+        if (gl == 0) ident[e] = (uint8_t)same;
     }
 }
 
 // One 48-byte descriptor per node (fast path, degree <= 3): everything a sweep needs to know about
 // the node in a single 3 x 16-byte load instead of the col_ptr -> adj_ptr -> edge[] dependent chain.
-__global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge,
-                                uint32_t F, NodeDesc* __restrict__ desc) {
+__global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ ident, uint32_t F, NodeDesc* __restrict__ desc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
     NodeDesc nd;
@@ -91,10 +98,17 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
     const uint32_t e0 = adj_ptr[i], deg = adj_ptr[i + 1] - e0;
     for (int d = 0; d < 3; ++d) {
         MrfEdge m; m.in_off = 0; m.out_off = 0; m.kj = 0;
-        if ((uint32_t)d < deg && nd.k > 0) m = edge[e0 + d];
-        nd.in_off[d] = m.in_off; nd.out_off[d] = m.out_off; nd.kj[d] = m.kj;
+        uint32_t flag = 0, nb = 0xFFFFFFFFu;
+        if ((uint32_t)d < deg) nb = adj[e0 + d];
+        if ((uint32_t)d < deg && nd.k > 0) {
+            m = edge[e0 + d];
+            // the message written over out-edge d is aligned with the neighbour's list: identity iff the lists are equal
+            // (a symmetric property, so the in-edge's flag serves)
+            if (m.kj && ident[e0 + d]) flag = 0x80000000u;
+        }
+        nd.in_off[d] = m.in_off; nd.out_off[d] = m.out_off; nd.kj[d] = m.kj | flag; nd.nbr[d] = nb;
     }
-    nd.pad_ = 0;
+    nd.pad_[0] = nd.pad_[1] = 0;
     desc[i] = nd;
 }
 
@@ -104,92 +118,111 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // c[p] is a ds_bpermute (__shfl) inside the node's lane group: no LDS memory, no barrier.
 // Besides sel (label index) the decode also leaves the label itself (view id + 1) and its unary
 // cost, which is all the energy / ICM kernels need of a neighbour.
-template <int G, int R, bool DAMP>
+// U = nodes per lane group per loop iteration (loads of all U nodes are issued before any is consumed);
+// NT = non-temporal stores for the outgoing messages (they are not re-read before the next sweep).
+// kj's top bit marks an edge whose two label lists are identical: no map load, no re-alignment shuffle.
+template <int G, int R, bool DAMP, int U, bool NT>
 __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                         const uint16_t* __restrict__ map, const float* __restrict__ mo, float* __restrict__ mn,
                                                         uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     constexpr int NPB = 256 / G;
+    constexpr uint32_t IDENT = 0x80000000u;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
-    const uint32_t stride = gridDim.x * NPB;
-    // persistent groups: every lane group walks nodes first, first + stride, ...; the next node's
-    // descriptor is requested before the current node is processed
-    uint32_t i = node_begin + blockIdx.x * NPB + grp;
-    NodeDesc nd = {};
-    if (i < node_end) nd = desc[i];
-    const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;   // uniform trip count (shuffles need all lanes)
-    for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
-        const bool node_ok = i < node_end;
-        const NodeDesc cur = nd;
-        const uint32_t inext = i + stride;
-        if (inext < node_end) nd = desc[inext];
-        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
-        float D[R], in[3][R], old[3][R];
-        uint32_t mp[3][R];
+    const uint32_t stride = gridDim.x * NPB;           // nodes per "row" of groups
+    // persistent groups: group g handles nodes g + stride * (U * it + u); next iteration's descriptors are prefetched
+    const uint32_t first = node_begin + blockIdx.x * NPB + grp;
+    NodeDesc nd[U];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t t = gl + r * G;
-            const bool ok = t < K;
-            D[r] = ok ? cost[p0 + t] : 0.0f;
+    for (int u = 0; u < U; ++u) { nd[u] = NodeDesc{}; const uint32_t i = first + u * stride; if (i < node_end) nd[u] = desc[i]; }
+    const uint32_t n_iter = (node_end - node_begin + stride * U - 1) / (stride * U);   // uniform trip count (shuffles need all lanes)
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        uint32_t ii[U]; bool okn[U]; NodeDesc cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ii[u] = first + (it * U + u) * stride; okn[u] = ii[u] < node_end; cur[u] = nd[u];
+            const uint32_t inext = ii[u] + U * stride;
+            if (inext < node_end) nd[u] = desc[inext];
+        }
+        float D[U][R], in[U][3][R], old[U][3][R];
+        uint32_t mp[U][3][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p0 = cur[u].p0, K = okn[u] ? cur[u].k : 0u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t t = gl + r * G;
+                const bool ok = t < K;
+                D[u][r] = ok ? cost[p0 + t] : 0.0f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const uint32_t kjf = okn[u] ? cur[u].kj[d] : 0u, kj = kjf & ~IDENT;
+                    in[u][d][r] = (ok && kj) ? mo[cur[u].in_off[d] + t] : 0.0f;
+                    const bool ok2 = t < kj;
+                    mp[u][d][r] = (kjf & IDENT) ? t : (ok2 ? (uint32_t)map[cur[u].out_off[d] + t] : 0u);
+                    old[u][d][r] = (DAMP && ok2) ? mo[cur[u].out_off[d] + t] : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = ii[u], p0 = cur[u].p0, K = okn[u] ? cur[u].k : 0u;
+            // decode: first argmin_t of b[t] = D[t] + rho * S[t]
+            {
+                float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t t = gl + r * G;
+                    const float S = ((0.0f + in[u][0][r]) + in[u][1][r]) + in[u][2][r];
+                    const float b = D[u][r] + rho * S;
+                    if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
+                }
+#pragma unroll
+                for (int o = G / 2; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
+                    if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
+                }
+                if (gl == 0 && okn[u]) {
+                    if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
+                    else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
+                }
+            }
+            // outgoing messages
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const uint32_t kj = node_ok ? cur.kj[d] : 0u;
-                in[d][r] = (ok && kj) ? mo[cur.in_off[d] + t] : 0.0f;
-                const bool ok2 = t < kj;
-                mp[d][r] = ok2 ? (uint32_t)map[cur.out_off[d] + t] : 0u;
-                old[d][r] = (DAMP && ok2) ? mo[cur.out_off[d] + t] : 0.0f;
-            }
-        }
-        // decode: first argmin_t of b[t] = D[t] + rho * S[t]
-        {
-            float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+                const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
+                float c[R];
+                float cmin = INFINITY;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t t = gl + r * G;
-                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
-                const float b = D[r] + rho * S;
-                if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
-            }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
-                if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
-            }
-            if (gl == 0 && node_ok) {
-                if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
-                else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
-            }
-        }
-        // outgoing messages
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
-            float c[R];
-            float cmin = INFINITY;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t t = gl + r * G;
-                const float oth = (0.0f + in[a][r]) + in[b2][r];
-                c[r] = (D[r] + rho * oth) - omr * in[d][r];
-                if (t < K) cmin = fminf(cmin, c[r]);
-            }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
-            const uint32_t kj = node_ok ? cur.kj[d] : 0u, oo = cur.out_off[d];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t t2 = gl + r * G;
-                const uint32_t p = mp[d][r];
-                const uint32_t pl = p & (uint32_t)(G - 1), ps = (p & 0xFFFFu) / (uint32_t)G;
-                float cp = 0.0f;
-#pragma unroll
-                for (int s2 = 0; s2 < R; ++s2) {   // every lane executes the shuffles (no divergence around ds_bpermute)
-                    const float v = __shfl(c[s2], (int)pl, G);
-                    cp = (ps == (uint32_t)s2) ? v : cp;
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t t = gl + r * G;
+                    const float oth = (0.0f + in[u][a][r]) + in[u][b2][r];
+                    c[r] = (D[u][r] + rho * oth) - omr * in[u][d][r];
+                    if (t < K) cmin = fminf(cmin, c[r]);
                 }
-                const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
-                if (t2 < kj) mn[oo + t2] = DAMP ? (raw * oma + old[d][r] * alpha) : raw;
+#pragma unroll
+                for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
+                const uint32_t kjf = okn[u] ? cur[u].kj[d] : 0u, kj = kjf & ~IDENT, oo = cur[u].out_off[d];
+                // G == 64: one node per wave, so "identical label lists" is wave-uniform and the shuffle can be skipped
+                const bool skip_shuffle = (G == 64) && (kjf & IDENT);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t t2 = gl + r * G;
+                    const uint32_t p = mp[u][d][r];
+                    float cp = c[r];
+                    if (!skip_shuffle) {
+                        const uint32_t pl = p & (uint32_t)(G - 1), ps = (p & 0xFFFFu) / (uint32_t)G;
+#pragma unroll
+                        for (int s2 = 0; s2 < R; ++s2) {   // every lane executes the shuffles (no divergence around ds_bpermute)
+                            const float v = __shfl(c[s2], (int)pl, G);
+                            cp = (ps == (uint32_t)s2) ? v : cp;
+                        }
+                    }
+                    const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
+                    const float outv = DAMP ? (raw * oma + old[u][d][r] * alpha) : raw;
+                    if (t2 < kj) { if (NT) __builtin_nontemporal_store(outv, &mn[oo + t2]); else mn[oo + t2] = outv; }
+                }
             }
         }
     }
@@ -308,6 +341,45 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
     if (gl == 0 && node_ok) { gain[i] = (K > 0) ? (cur - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; }
 }
 
+// fast path (degree <= 3): persistent lane groups over the node descriptors, next descriptor prefetched
+template <int G>
+__global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                                const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
+                                                                uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand) {
+    constexpr int NPB = 256 / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const uint32_t stride = gridDim.x * NPB;
+    uint32_t i = node_begin + blockIdx.x * NPB + grp;
+    NodeDesc nd = {};
+    if (i < node_end) nd = desc[i];
+    const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
+    for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
+        const bool node_ok = i < node_end;
+        const NodeDesc cur = nd;
+        if (i + stride < node_end) nd = desc[i + stride];
+        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
+        const uint32_t cur_t = (K > 0) ? sel[i] : 0u;
+        uint32_t nl[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && (cur.kj[d] & 0x7FFFFFFFu)) ? lab[cur.nbr[d]] : 0u;
+        float best = INFINITY, cur_e = 0.0f; uint32_t bt = 0xFFFFFFFFu;
+        for (uint32_t t = gl; t < K; t += G) {
+            const uint32_t l = (uint32_t)view_id[p0 + t] + 1u;
+            const uint32_t diff = (nl[0] != 0u && nl[0] != l) + (nl[1] != 0u && nl[1] != l) + (nl[2] != 0u && nl[2] != l);
+            const float en = cost[p0 + t] + (float)diff;
+            if (en < best) { best = en; bt = t; }
+            if (t == cur_t) cur_e = en;
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
+            if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+            cur_e += __shfl_xor(cur_e, o, G);   // exactly one lane holds a non-zero term (or none: 0)
+        }
+        if (gl == 0 && node_ok) { gain[i] = (K > 0) ? (cur_e - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; }
+    }
+}
+
 __global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                             const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                                             const float* __restrict__ gain, const uint32_t* __restrict__ cand,
@@ -390,18 +462,22 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipStreamSynchronize(s));
     ctx->m_total = h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
     if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
+    ctx->m_map.ensure(ctx->m_total + 1); ctx->m_ident.ensure((size_t)E + 1);
+    MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
+    if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p); MVS_LAUNCH_CHECK(); }
     ctx->m_desc.ensure((size_t)F + 1);
-    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
-    ctx->m_map.ensure(ctx->m_total + 1);
-    if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p); MVS_LAUNCH_CHECK(); }
+    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
     ctx->m_msg_a.ensure(ctx->m_total + 1); ctx->m_msg_b.ensure(ctx->m_total + 1);
     MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1) * sizeof(float), s));
     MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 1) * sizeof(float), s));
     MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
     ctx->m_sel.ensure((size_t)F + 1); ctx->m_best_sel.ensure((size_t)F + 1); ctx->m_sel2.ensure((size_t)F + 1); ctx->m_cand.ensure((size_t)F + 1); ctx->m_gain.ensure((size_t)F + 1);
     ctx->m_lab.ensure((size_t)F + 1); ctx->m_best_lab.ensure((size_t)F + 1); ctx->m_cost.ensure((size_t)F + 1); ctx->m_best_cost.ensure((size_t)F + 1);
-    // start state = argmin-unary decode everywhere (also gives halo nodes of a sharded run defined labels)
-    if (F) {
+    // start state = argmin-unary decode everywhere: only needed when no sweep runs (ICM-only); otherwise the first
+    // sweep (and, when sharded, the halo exchange that follows it) defines every label that is ever read
+    MVS_HIP(hipMemsetAsync(ctx->m_lab.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
+    MVS_HIP(hipMemsetAsync(ctx->m_best_lab.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
+    if (F && params->max_sweeps <= 0) {
         hipLaunchKernelGGL(mrf_argmin_unary_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, F, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p);
         MVS_LAUNCH_CHECK();
         MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
@@ -413,18 +489,21 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_flip = false;
 }
 
+template <int G, int R, int U>
+static void launch_sweep_gru(mvs_ctx* ctx, const float* mo, float* mn, uint32_t nb0, uint32_t ne0) {
+    constexpr int NPB = 256 / G;
+    const unsigned need = (ne0 - nb0 + NPB * U - 1) / (NPB * U);
+    const unsigned blocks = std::max(1u, std::min<unsigned>(need, 256u * (unsigned)ctx->mrf_blocks_per_cu));   // persistent lane groups
+    const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+#define SWEEP_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
+    if (alpha != 0.0f) { if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, true>), SWEEP_ARGS); else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, false>), SWEEP_ARGS); }
+    else { if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, true>), SWEEP_ARGS); else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, false>), SWEEP_ARGS); }
+#undef SWEEP_ARGS
+}
 template <int G, int R>
 static void launch_sweep_gr(mvs_ctx* ctx, const float* mo, float* mn, uint32_t nb0, uint32_t ne0) {
-    constexpr int NPB = 256 / G;
-    const unsigned need = (ne0 - nb0 + NPB - 1) / NPB;
-    const unsigned blocks = std::min<unsigned>(need, 256u * 8u);   // persistent: 8 blocks of 256 threads per CU
-    const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
-    if (alpha != 0.0f)
-        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn,
-                           ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
-    else
-        hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false>), dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn,
-                           ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha);
+    if (ctx->mrf_unroll >= 2 && R <= 2) launch_sweep_gru<G, R, 2>(ctx, mo, mn, nb0, ne0);
+    else launch_sweep_gru<G, R, 1>(ctx, mo, mn, nb0, ne0);
 }
 
 // one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
@@ -439,9 +518,9 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
             if (shape == 0) {
                 if (K <= 8) launch_sweep_gr<8, 1>(ctx, mo, mn, nb0, ne0);
                 else if (K <= 16) launch_sweep_gr<16, 1>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 32) launch_sweep_gr<16, 2>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 64) launch_sweep_gr<16, 4>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 128) launch_sweep_gr<32, 4>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 32) launch_sweep_gr<32, 1>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 128) launch_sweep_gr<64, 2>(ctx, mo, mn, nb0, ne0);
                 else launch_sweep_gr<64, 4>(ctx, mo, mn, nb0, ne0);
             } else if (shape == 641 && K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
             else if (shape == 322 && K <= 64) launch_sweep_gr<32, 2>(ctx, mo, mn, nb0, ne0);
@@ -488,6 +567,14 @@ void mrf_keep_best(mvs_ctx* ctx) {
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 <= nb0) return;
     const uint32_t K = ctx->m_kmax, n = ne0 - nb0;
+    if (ctx->m_degmax <= 3) {
+#define ICM_D(GG) hipLaunchKernelGGL(mrf_icm_gain_desc_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((n + (256 / GG) - 1) / (256 / GG), 256u * 8u))), dim3(256), 0, ctx->stream, \
+                                     ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
+        if (K <= 8) ICM_D(8); else if (K <= 16) ICM_D(16); else if (K <= 48) ICM_D(16); else ICM_D(32);
+#undef ICM_D
+        MVS_LAUNCH_CHECK();
+        return;
+    }
 #define ICM_G(GG) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3((n + (256 / GG) - 1) / (256 / GG)), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
                                      ctx->r_adj_ptr, ctx->r_adj, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
     if (K <= 8) ICM_G(8); else if (K <= 16) ICM_G(16); else if (K <= 32) ICM_G(32); else ICM_G(64);
