@@ -358,6 +358,108 @@ __global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const
     }
 }
 
+// ---- packet traversal with leaf work redistribution (ray_mode 2) ----
+// Same shared traversal, but at a leaf only the lanes whose OWN ray hits the leaf box are candidates
+// (5-6 of 64 on average), so instead of 64 lanes x 4 triangles the wave tests (candidate, triangle)
+// PAIRS: lane L takes candidate L/4 and triangle L%4 (16 candidates per round).  Rays are parked in
+// LDS once; the candidate list goes through LDS; results return to the owning lanes through a ballot.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
+                                                          const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
+                                                          unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
+                                                          const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
+    __shared__ float4 s_ray[4][64][2];
+    __shared__ uint8_t s_src[4][64];
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wave >= (uint64_t)vwords * n_views) return;
+    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
+    const unsigned long long word = need[(size_t)j * vwords + vw];
+    if (word == 0ull) return;  // occl is pre-zeroed
+    const uint32_t s = vw * 64 + lane;
+    bool active = ((word >> lane) & 1ull) && s < n_verts;
+    const uint32_t v = vperm[s < n_verts ? s : 0];
+    const ViewParams& vp = views[j];
+    const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
+    const float pad = pad_from_box(scene_box);
+    const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad);
+    s_ray[wv][lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmin);
+    s_ray[wv][lane][1] = make_float4(r.d.x, r.d.y, r.d.z, r.tmax);
+    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    bool hit = false;
+    uint32_t nn = 0, nt = 0;
+    int level = bvh.top;
+    uint32_t node = 0, lm0 = 0;   // lm0: this lane's own hit bits for the children (leaves) of the current level-0 node
+    // per-lane + wave-level child masks of one node
+    auto visit = [&](const Node4* __restrict__ nd, uint32_t& lane_mask) -> uint32_t {
+        uint32_t m = 0, lm = 0;
+        const uint32_t nchild = nd->nchild;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float ta = (nd->lo[0][c] - r.o.x) * inv.x, tb = (nd->hi[0][c] - r.o.x) * inv.x;
+            float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
+            ta = (nd->lo[1][c] - r.o.y) * inv.y; tb = (nd->hi[1][c] - r.o.y) * inv.y;
+            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+            ta = (nd->lo[2][c] - r.o.z) * inv.z; tb = (nd->hi[2][c] - r.o.z) * inv.z;
+            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+            const bool h = active && tn <= tf;
+            if (h) lm |= 1u << c;
+            if (__ballot(h) != 0ull) m |= 1u << c;
+        }
+        lane_mask = lm;
+        return m & ((1u << nchild) - 1u);
+    };
+    uint32_t lm_tmp;
+    unsigned long long masks = (unsigned long long)visit(bvh.nodes + bvh.level_off[level], lm_tmp) << (4 * level);
+    if (level == 0) lm0 = lm_tmp;
+    if (COUNT) nn++;
+    while (true) {
+        const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
+        if (m == 0) {
+            if (level == bvh.top) break;
+            ++level; node >>= 2;
+            continue;
+        }
+        const int c = __builtin_ctz(m);
+        masks &= ~(1ull << (4 * level + c));
+        const uint32_t child = node * 4 + c;   // wave-uniform
+        if (level == 0) {
+            const bool cand = active && ((lm0 >> c) & 1u);
+            const unsigned long long cb = __ballot(cand);
+            const int n = __popcll(cb);
+            const int rank = __popcll(cb & lt);
+            if (cand) s_src[wv][rank] = (uint8_t)lane;
+            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * 4 + (lane & 3));
+            const float4 A = tp[0], E1 = tp[1], E2 = tp[2];
+            for (int base = 0; base < n; base += 16) {
+                const int q = base + (lane >> 2);
+                const bool valid = q < n;
+                const int sl = valid ? (int)s_src[wv][q] : lane;
+                const float4 r0 = s_ray[wv][sl][0], r1 = s_ray[wv][sl][1];
+                Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
+                const bool h = valid && ray_tri(rr, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z});
+                const unsigned long long hb = __ballot(h);
+                if (cand && rank >= base && rank < base + 16 && ((hb >> (4 * (rank - base))) & 0xFull)) hit = true;
+                if (COUNT) nt += 1;
+            }
+            active = active && !hit;
+            if (__ballot(active) == 0ull) break;
+        } else {
+            --level; node = child;
+            masks |= (unsigned long long)visit(bvh.nodes + bvh.level_off[level] + node, lm_tmp) << (4 * level);
+            if (level == 0) lm0 = lm_tmp;
+            if (COUNT) nn++;
+        }
+    }
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) {
+        occl[(size_t)j * vwords + vw] = b;
+        if (COUNT) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
+    }
+}
+
 }  // namespace
 
 // Builds the BVH and the vertex->face incidence for the resident mesh.
@@ -432,7 +534,9 @@ void trace_rays(mvs_ctx* ctx) {
     if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
 #define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
                  vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
-    if (ctx->ray_mode == 1) {
+    if (ctx->ray_mode == 2) {
+        if (ctx->count_rays) hipLaunchKernelGGL(ray_packet2_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_packet2_kernel<false>, RAY_ARGS);
+    } else if (ctx->ray_mode == 1) {
         if (ctx->count_rays) hipLaunchKernelGGL(ray_packet_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_packet_kernel<false>, RAY_ARGS);
     } else {
         if (ctx->count_rays) hipLaunchKernelGGL(ray_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_kernel<false>, RAY_ARGS);

@@ -121,7 +121,7 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // U = nodes per lane group per loop iteration (loads of all U nodes are issued before any is consumed);
 // NT = non-temporal stores for the outgoing messages (they are not re-read before the next sweep).
 // kj's top bit marks an edge whose two label lists are identical: no map load, no re-alignment shuffle.
-template <int G, int R, bool DAMP, int U, bool NT>
+template <int G, int R, bool DAMP, int U, bool NT, bool XCD>
 __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                         const uint16_t* __restrict__ map, const float* __restrict__ mo, float* __restrict__ mn,
                                                         uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
@@ -131,8 +131,13 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
     const uint32_t stride = gridDim.x * NPB;           // nodes per "row" of groups
+    // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed; used for speed only), so give every XCD a
+    // CONTIGUOUS eighth of each row: a node and its mesh neighbours (adjacent in Morton order) then share one L2, and
+    // a message read twice per sweep (as "in" by the receiver, as "old" by the sender) is fetched once.
+    uint32_t vb = blockIdx.x;
+    if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // persistent groups: group g handles nodes g + stride * (U * it + u); next iteration's descriptors are prefetched
-    const uint32_t first = node_begin + blockIdx.x * NPB + grp;
+    const uint32_t first = node_begin + vb * NPB + grp;
     NodeDesc nd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { nd[u] = NodeDesc{}; const uint32_t i = first + u * stride; if (i < node_end) nd[u] = desc[i]; }
@@ -493,11 +498,18 @@ template <int G, int R, int U>
 static void launch_sweep_gru(mvs_ctx* ctx, const float* mo, float* mn, uint32_t nb0, uint32_t ne0) {
     constexpr int NPB = 256 / G;
     const unsigned need = (ne0 - nb0 + NPB * U - 1) / (NPB * U);
-    const unsigned blocks = std::max(1u, std::min<unsigned>(need, 256u * (unsigned)ctx->mrf_blocks_per_cu));   // persistent lane groups
+    unsigned blocks = std::max(1u, std::min<unsigned>(need, 256u * (unsigned)ctx->mrf_blocks_per_cu));   // persistent lane groups
+    if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
     const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
 #define SWEEP_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
-    if (alpha != 0.0f) { if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, true>), SWEEP_ARGS); else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, false>), SWEEP_ARGS); }
-    else { if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, true>), SWEEP_ARGS); else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, false>), SWEEP_ARGS); }
+    if (alpha != 0.0f) {
+        if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, true, true>), SWEEP_ARGS);
+        else if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, false, true>), SWEEP_ARGS);
+        else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, false, false>), SWEEP_ARGS);
+    } else {
+        if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, false, true>), SWEEP_ARGS);
+        else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, false, false>), SWEEP_ARGS);
+    }
 #undef SWEEP_ARGS
 }
 template <int G, int R>

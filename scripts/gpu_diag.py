@@ -87,7 +87,7 @@ def stage_raymodes():
     """ray statistics and parity of both traversal modes on config 2"""
     s = synth.make_scene(**synth.CONFIGS[2])
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         ctx = M.Context(); ctx.set_option("count_rays", 1); ctx.set_option("stats", 1); ctx.set_option("ray_mode", mode); ctx.set_option("profile", 1)
         ctx.set_mesh(s.verts, s.faces, s.normals); ctx.set_views(s.cams, s.images)
         ctx.data_costs(M.Settings()); ctx.get_profile()
@@ -95,7 +95,7 @@ def stage_raymodes():
         res[mode] = ctx.costs_download()
         print(f"ray_mode {mode}: rays {st['rays']} nodes {st['ray_nodes']} tris {st['ray_tris']} occluded {st['cull_occluded']} dc_rays {prof['dc_rays'][0]:.3f} ms")
         ctx.close()
-    print("modes equal:", np.array_equal(res[0].col_ptr, res[1].col_ptr) and np.array_equal(res[0].cost.view(np.uint32), res[1].cost.view(np.uint32)))
+    print("modes equal:", all(np.array_equal(res[0].col_ptr, res[m].col_ptr) and np.array_equal(res[0].cost.view(np.uint32), res[m].cost.view(np.uint32)) for m in (1, 2)))
 
 
 def stage_c3_time():

@@ -89,6 +89,20 @@ def test_data_costs_against_live_oracle(ctx, mode):
         assert 0 < st["rays"] < rst["rays"]
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_ray_traversal_modes_give_the_oracle_booleans(mode):
+    """per-ray traversal, shared (packet) traversal and packet + leaf work redistribution: same occlusion decisions"""
+    s = get_scene("bumpy")
+    ref, rst = O.data_costs(s)
+    c = M.Context(0); c.set_option("stats", 1); c.set_option("ray_mode", mode)
+    _load_scene(c, s)
+    st = c.data_costs(M.Settings())
+    got = c.costs_download()
+    assert st["cull_occluded"] == rst["cull_occluded"] > 0
+    assert np.array_equal(got.col_ptr, ref.col_ptr) and np.array_equal(got.cost.view(np.uint32), ref.cost.view(np.uint32))
+    c.close()
+
+
 def test_face_range_sharding_of_data_costs(ctx):
     """faces [a, b) against the full occluder set == the same rows of the full run (qualities; the
     percentile of a shard is local until the driver all-reduces max + histogram)"""
