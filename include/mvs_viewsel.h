@@ -225,7 +225,9 @@ mvs_status mvs_ctx_costs_export(mvs_ctx* ctx, uint32_t* counts_device, uint16_t*
  * col_ptr + adjacency alone (mvs-texturing_amd/multigpu.py). */
 /* solver arrays addressable by the halo exchange: messages, decoded labels (view + 1) of the current
  * sweep, ICM gains, labels of the best labeling so far */
-enum { MVS_MRF_MSG = 0, MVS_MRF_LAB = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_LAB = 3 };
+enum { MVS_MRF_MSG = 0, MVS_MRF_LAB = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_LAB = 3,
+       /* combined addressing for one exchange per sweep: index < 2^31 -> MSG[index], else LAB[index & 0x7FFFFFFF] */
+       MVS_MRF_MSG_LAB = 4 };
 mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
                              const mvs_mrf_params* params);
 /* one sweep over nodes [node_begin, node_end): reads the current messages, writes the next ones, flips */

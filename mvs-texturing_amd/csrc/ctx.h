@@ -101,7 +101,7 @@ struct mvs_ctx {
     std::vector<mvs::ProfSpan> prof_spans; std::vector<hipEvent_t> prof_pool;
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
-    int ray_mode = 1;        // 0 = one traversal per ray, 1 = one shared traversal per wave (packet)
+    int ray_mode = 2;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution
     int lds_bvh_levels = 0;
     float cos_limit = 0.0f;  // see dmath.h cull_pair
 
@@ -114,6 +114,7 @@ struct mvs_ctx {
     mvs::DBuf<mvs::ViewParams> d_views;
     std::vector<mvs::DBuf<uint8_t>*> own_rgb;
     mvs::DBuf<uint8_t> gmi_all;      // all views' gradient-magnitude planes
+    mvs::DBuf<uint8_t> lum_all;      // luminance planes (vectorised prep path)
     mvs::DBuf<uint32_t> mask_all;    // all views' bit-packed validity masks
     mvs::DBuf<uint32_t> mask_zero, mask_tmp;
     std::vector<size_t> gmi_off, mask_off;

@@ -158,6 +158,75 @@ __global__ void mask_final_kernel(const ViewParams* __restrict__ views, const ui
     mask_all[base + (size_t)y * wpr + wx] = valid;
 }
 
+// ---- vectorised fast path (image width a multiple of 32, 4-byte aligned rows) ----
+// One pass over the RGB image does the luminance plane (4 pixels = three 32-bit loads per thread) AND
+// the zero map + corner seeds of the validity flood fill; a second pass does the Sobel magnitude on
+// the luminance plane with one aligned 32-bit load per row.
+__global__ void __launch_bounds__(256) lum_zero_kernel(const ViewParams* __restrict__ views, uint8_t* __restrict__ lum_all, const size_t* __restrict__ gmi_off,
+                                                       uint32_t* __restrict__ zero_all, uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off,
+                                                       int need_lum) {
+    const ViewParams& vp = views[blockIdx.z];
+    const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    const bool ok = x4 < w && y < h;   // w % 32 == 0: a group of 8 lanes (32 pixels) is entirely in or out
+    uint32_t zbits = 0, lum4 = 0;
+    if (ok) {
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(vp.rgb + ((size_t)y * w + x4) * 3);
+        const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+        const uint8_t px[4][3] = {{(uint8_t)d0, (uint8_t)(d0 >> 8), (uint8_t)(d0 >> 16)}, {(uint8_t)(d0 >> 24), (uint8_t)d1, (uint8_t)(d1 >> 8)},
+                                  {(uint8_t)(d1 >> 16), (uint8_t)(d1 >> 24), (uint8_t)d2}, {(uint8_t)(d2 >> 8), (uint8_t)(d2 >> 16), (uint8_t)(d2 >> 24)}};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((int)px[k][0] + (int)px[k][1] + (int)px[k][2] == 0) zbits |= 1u << k;
+            if (need_lum) lum4 |= (uint32_t)luminance_u8(px[k][0], px[k][1], px[k][2]) << (8 * k);
+        }
+        if (need_lum) *reinterpret_cast<uint32_t*>(lum_all + gmi_off[blockIdx.z] + (size_t)y * w + x4) = lum4;
+    }
+    uint32_t word = zbits << (4 * (threadIdx.x & 7));
+    word |= __shfl_xor(word, 1, 8); word |= __shfl_xor(word, 2, 8); word |= __shfl_xor(word, 4, 8);
+    if (ok && (threadIdx.x & 7) == 0) {
+        const int wx = x4 >> 5;
+        uint32_t seed = 0;
+        if (y == 0 || y == h - 1) {
+            if (wx == 0) seed |= 1u;
+            if (wx == (w - 1) / 32) seed |= 1u << ((w - 1) & 31);
+        }
+        const size_t idx = mask_off[blockIdx.z] + (size_t)y * wpr + wx;
+        zero_all[idx] = word;
+        reach_all[idx] = seed & word;
+    }
+}
+
+__global__ void __launch_bounds__(256) sobel4_kernel(const ViewParams* __restrict__ views, const uint8_t* __restrict__ lum_all, uint8_t* __restrict__ gmi_all,
+                                                     const size_t* __restrict__ gmi_off) {
+    const ViewParams& vp = views[blockIdx.z];
+    const int w = vp.width, h = vp.height;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= w || y >= h) return;
+    const uint8_t* __restrict__ lum = lum_all + gmi_off[blockIdx.z];
+    uint32_t out = 0;
+    if (y > 0 && y < h - 1) {
+        int l[3][6];   // rows y-1..y+1, columns x4-1..x4+4
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint8_t* __restrict__ row = lum + (size_t)(y - 1 + r) * w;
+            const uint32_t d = *reinterpret_cast<const uint32_t*>(row + x4);
+            l[r][0] = x4 > 0 ? row[x4 - 1] : 0;
+            l[r][1] = d & 0xFF; l[r][2] = (d >> 8) & 0xFF; l[r][3] = (d >> 16) & 0xFF; l[r][4] = d >> 24;
+            l[r][5] = x4 + 4 < w ? row[x4 + 4] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x4 + k;
+            if (x == 0 || x == w - 1) continue;
+            const int sx = (l[0][k + 2] - l[0][k]) + 2 * (l[1][k + 2] - l[1][k]) + (l[2][k + 2] - l[2][k]);
+            const int sy = (l[2][k] - l[0][k]) + 2 * (l[2][k + 1] - l[0][k + 1]) + (l[2][k + 2] - l[0][k + 2]);
+            out |= (uint32_t)isqrt_clamp255(sx * sx + sy * sy) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(gmi_all + gmi_off[blockIdx.z] + (size_t)y * w + x4) = out;
+}
+
 }  // namespace
 
 // Runs the image preparation for all views; needs ctx->d_views uploaded with
@@ -168,17 +237,30 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
     int maxw = 0, maxh = 0, maxwpr = 0;
     for (auto& v : ctx->h_views) { maxw = std::max(maxw, v.width); maxh = std::max(maxh, v.height); maxwpr = std::max(maxwpr, v.mask_stride); }
     hipStream_t s = ctx->stream;
-    if (need_gmi) {
-        dim3 grid((maxw + GT_X - 1) / GT_X, (maxh + GT_Y - 1) / GT_Y, V);
-        hipLaunchKernelGGL(gmi_kernel, grid, dim3(GT_X, GT_Y), 0, s, ctx->d_views.p, ctx->gmi_all.p, d_gmi_off);
-        MVS_LAUNCH_CHECK();
-    }
+    bool fast = true;   // vectorised path: widths multiple of 32, 4-byte aligned pixel rows
+    for (auto& v : ctx->h_views) fast = fast && (v.width % 32 == 0) && ((reinterpret_cast<uintptr_t>(v.rgb) & 3u) == 0);
     dim3 mgrid((maxwpr + 63) / 64, maxh, V);
     uint32_t* zero = ctx->mask_zero.p;
     uint32_t* ra = ctx->mask_all.p;   // ping
     uint32_t* rb = ctx->mask_tmp.p;   // pong
-    hipLaunchKernelGGL(mask_zero_kernel, mgrid, dim3(64), 0, s, ctx->d_views.p, zero, ra, d_mask_off);
-    MVS_LAUNCH_CHECK();
+    if (fast) {
+        dim3 g4((maxw / 4 + 255) / 256, maxh, V);
+        if (need_gmi) ctx->lum_all.ensure(ctx->gmi_off.back() + 16);
+        hipLaunchKernelGGL(lum_zero_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, d_gmi_off, zero, ra, d_mask_off, need_gmi ? 1 : 0);
+        MVS_LAUNCH_CHECK();
+        if (need_gmi) {
+            hipLaunchKernelGGL(sobel4_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, ctx->gmi_all.p, d_gmi_off);
+            MVS_LAUNCH_CHECK();
+        }
+    } else {
+        if (need_gmi) {
+            dim3 grid((maxw + GT_X - 1) / GT_X, (maxh + GT_Y - 1) / GT_Y, V);
+            hipLaunchKernelGGL(gmi_kernel, grid, dim3(GT_X, GT_Y), 0, s, ctx->d_views.p, ctx->gmi_all.p, d_gmi_off);
+            MVS_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(mask_zero_kernel, mgrid, dim3(64), 0, s, ctx->d_views.p, zero, ra, d_mask_off);
+        MVS_LAUNCH_CHECK();
+    }
     // flood fill until a whole batch of steps changes nothing
     uint32_t* d_changed = (uint32_t*)ctx->counters.p + 64;  // scratch word inside the counters block
     for (int iter = 0;; ++iter) {

@@ -23,6 +23,20 @@ __global__ void gather_kernel(const uint32_t* __restrict__ src, const uint32_t* 
 __global__ void scatter_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = src[k];
 }
+// combined addressing: index < 2^31 -> array a (messages), else array b[index & 0x7FFFFFFF] (labels):
+// one gather / scatter per sweep moves cut-edge messages AND boundary labels
+__global__ void gather2_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = idx[k];
+        dst[k] = (i & 0x80000000u) ? b[i & 0x7FFFFFFFu] : a[i];
+    }
+}
+__global__ void scatter2_kernel(uint32_t* __restrict__ a, uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = idx[k];
+        if (i & 0x80000000u) b[i & 0x7FFFFFFFu] = src[k]; else a[i] = src[k];
+    }
+}
 __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, uint32_t* __restrict__ counts) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) counts[i] = col_ptr[i + 1] - col_ptr[i];
@@ -112,7 +126,11 @@ mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
 mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx, uint64_t n, void* dst) {
     if (!ctx || (n && (!idx || !dst))) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
-    if (n) {
+    if (n && which == MVS_MRF_MSG_LAB) {
+        if (ctx->m_total >= 0x80000000ull) throw StatusError(MVS_ERR_UNSUPPORTED, "combined addressing needs < 2^31 message words");
+        hipLaunchKernelGGL(gather2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, MVS_MRF_MSG), ctx->m_lab.p, idx, n, (uint32_t*)dst);
+        MVS_LAUNCH_CHECK();
+    } else if (n) {
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (uint32_t*)dst);
         MVS_LAUNCH_CHECK();
     }
@@ -121,7 +139,10 @@ mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx, uint
 mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx, uint64_t n, const void* src) {
     if (!ctx || (n && (!idx || !src))) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
-    if (n) {
+    if (n && which == MVS_MRF_MSG_LAB) {
+        hipLaunchKernelGGL(scatter2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, MVS_MRF_MSG), ctx->m_lab.p, idx, n, (const uint32_t*)src);
+        MVS_LAUNCH_CHECK();
+    } else if (n) {
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (const uint32_t*)src);
         MVS_LAUNCH_CHECK();
     }

@@ -22,7 +22,7 @@ is behind the C ABI (viewsel.Context).
 """
 import numpy as np
 
-MSG, LAB, GAIN, BEST_LAB = 0, 1, 2, 3
+MSG, LAB, GAIN, BEST_LAB, MSG_LAB = 0, 1, 2, 3, 4
 
 
 # --------------------------------------------------------------------------
@@ -123,50 +123,49 @@ class HaloPlan:
 # exchange plumbing (torch tensors; CPU with gloo, CUDA with RCCL)
 # --------------------------------------------------------------------------
 class HaloExchange:
-    """all-to-all of [message words | node words] per peer, single collective per call."""
+    """Per exchanged array ONE gather kernel, ONE all-to-all and ONE scatter kernel: the per-peer index
+    lists are concatenated in peer order, so the gathered buffer is already laid out peer by peer."""
 
     def __init__(self, plan, device, dist=None, group=None):
         import torch
         self.torch, self.dist, self.group, self.plan, self.device = torch, dist, group, plan, device
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(device).to(torch.int32)  # noqa: E731
-        self.idx = {"msg_send": [t(a) for a in plan.msg_send], "msg_recv": [t(a) for a in plan.msg_recv],
-                    "node_send": [t(a) for a in plan.node_send], "node_recv": [t(a) for a in plan.node_recv]}
 
-    def _layout(self, kinds):
-        send_counts = [sum(len(self.idx[k + "_send"][p]) for k in kinds) for p in range(self.plan.P)]
-        recv_counts = [sum(len(self.idx[k + "_recv"][p]) for k in kinds) for p in range(self.plan.P)]
-        return send_counts, recv_counts
+        def cat(lists):
+            a = np.concatenate([np.asarray(x, dtype=np.uint32) for x in lists]) if len(lists) else np.zeros(0, np.uint32)
+            return torch.from_numpy(a.astype(np.int64)).to(device).to(torch.int32)
+        # "both": per peer [message words | boundary labels] with the label indices tagged by bit 31
+        # (MSG_LAB combined addressing): ONE gather, all-to-all and scatter per sweep
+        tag = lambda lists: [np.asarray(x, dtype=np.uint32) | np.uint32(0x80000000) for x in lists]  # noqa: E731
+        both_send = [np.concatenate([np.asarray(a, np.uint32), b]) for a, b in zip(plan.msg_send, tag(plan.node_send))]
+        both_recv = [np.concatenate([np.asarray(a, np.uint32), b]) for a, b in zip(plan.msg_recv, tag(plan.node_recv))]
+        self.idx = {"msg_send": cat(plan.msg_send), "msg_recv": cat(plan.msg_recv), "node_send": cat(plan.node_send), "node_recv": cat(plan.node_recv),
+                    "both_send": cat(both_send), "both_recv": cat(both_recv)}
+        self.splits = {"msg_send": [len(x) for x in plan.msg_send], "msg_recv": [len(x) for x in plan.msg_recv],
+                       "node_send": [len(x) for x in plan.node_send], "node_recv": [len(x) for x in plan.node_recv],
+                       "both_send": [len(x) for x in both_send], "both_recv": [len(x) for x in both_recv]}
+        self.buf = {k: torch.empty(max(int(v.numel()), 1), dtype=torch.int32, device=device) for k, v in self.idx.items()}
 
     def exchange(self, kinds, gather, scatter):
-        """kinds: list of ("msg"|"node", which_array).  gather(which, idx_tensor, dst_view),
-        scatter(which, idx_tensor, src_view) move 4-byte words between the solver arrays and the buffers."""
+        """kinds: list of ("msg"|"node", which_array).  gather(which, idx_tensor, dst) / scatter(which, idx_tensor, src)
+        move 4-byte words between the solver arrays and the exchange buffers."""
         torch = self.torch
-        names = [k for k, _ in kinds]
-        sc, rc = self._layout(names)
-        send = torch.empty(max(sum(sc), 1), dtype=torch.int32, device=self.device)
-        recv = torch.empty(max(sum(rc), 1), dtype=torch.int32, device=self.device)
-        off = 0
-        for p in range(self.plan.P):
-            for k, which in kinds:
-                idx = self.idx[k + "_send"][p]
-                if len(idx):
-                    gather(which, idx, send[off:off + len(idx)])
-                off += len(idx)
-        if self.dist is not None and self.plan.P > 1:
-            if send.is_cuda and self.dist.get_backend(self.group) == "gloo":
-                # test configuration (several ranks sharing one GPU): gloo has no CUDA all-to-all, stage through the host
-                hs, hr = send[:sum(sc)].cpu(), torch.empty(sum(rc), dtype=torch.int32)
-                self.dist.all_to_all_single(hr, hs, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-                recv[:sum(rc)].copy_(hr)
-            else:
-                self.dist.all_to_all_single(recv[:sum(rc)], send[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-        off = 0
-        for p in range(self.plan.P):
-            for k, which in kinds:
-                idx = self.idx[k + "_recv"][p]
-                if len(idx):
-                    scatter(which, idx, recv[off:off + len(idx)])
-                off += len(idx)
+        for k, which in kinds:
+            sidx, ridx = self.idx[k + "_send"], self.idx[k + "_recv"]
+            ns, nr = int(sidx.numel()), int(ridx.numel())
+            send, recv = self.buf[k + "_send"], self.buf[k + "_recv"]
+            if ns:
+                gather(which, sidx, send[:ns])
+            if self.dist is not None and self.plan.P > 1:
+                sc, rc = self.splits[k + "_send"], self.splits[k + "_recv"]
+                if send.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                    # test configuration (several ranks sharing one GPU): gloo has no CUDA all-to-all, stage through the host
+                    hs, hr = send[:ns].cpu(), torch.empty(nr, dtype=torch.int32)
+                    self.dist.all_to_all_single(hr, hs, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+                    recv[:nr].copy_(hr)
+                else:
+                    self.dist.all_to_all_single(recv[:nr], send[:ns], output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+            if nr:
+                scatter(which, ridx, recv[:nr])
 
 
 # --------------------------------------------------------------------------
@@ -205,7 +204,10 @@ class ShardedViewSelection:
         sweeps = 0
         for sw in range(1, P.max_sweeps + 1):
             ops.sweep(nb, ne)
-            self.hx.exchange([("msg", MSG), ("node", LAB)], ops.gather, ops.scatter)
+            if plan.total_words < 2 ** 31:
+                self.hx.exchange([("both", MSG_LAB)], ops.gather, ops.scatter)      # one collective per sweep
+            else:
+                self.hx.exchange([("msg", MSG), ("node", LAB)], ops.gather, ops.scatter)
             e = self._allreduce(ops.energy(LAB, nb, ne))
             e0 = int(e[0].item()) & ((1 << 64) - 1)
             if e0 < best:

@@ -30,6 +30,8 @@ SCENES = {
     # bumpy sphere with cropped views and a black image corner: every cull of
     # calculate_data_costs.cpp:183-222, the mask flood fill and the rays decide something
     "bumpy": dict(n=22, n_views=12, width=640, height=480, displacement=0.15, layout=1, black_corner=40, zoom_odd=1.6),
+    # image width not a multiple of 32 / odd sizes: the generic (non-vectorised) image-prep kernels
+    "oddw": dict(n=10, n_views=6, width=333, height=251, displacement=0.2, layout=1, zoom_odd=1.3, black_corner=19),
     "tiny": dict(n=6, n_views=8, width=320, height=240, displacement=0.2, layout=1, zoom_odd=1.4),
 }
 

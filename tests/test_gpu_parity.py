@@ -89,6 +89,18 @@ def test_data_costs_against_live_oracle(ctx, mode):
         assert 0 < st["rays"] < rst["rays"]
 
 
+@pytest.mark.parametrize("name", ["oddw", "tiny"])
+def test_other_image_shapes_against_live_oracle(ctx, name):
+    """odd image sizes take the generic image-prep kernels; tiny scene = few, large footprints"""
+    s = get_scene(name)
+    _load_scene(ctx, s)
+    for kw in (dict(), dict(data_term="area", outlier_removal="gauss_clamping")):
+        ref, rst = O.data_costs(s, **kw)
+        st = ctx.data_costs(M.Settings(**kw))
+        _assert_costs(ctx.costs_download(), ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        assert st["cull_outside"] == rst["cull_outside"] and st["cull_occluded"] == rst["cull_occluded"]
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_ray_traversal_modes_give_the_oracle_booleans(mode):
     """per-ray traversal, shared (packet) traversal and packet + leaf work redistribution: same occlusion decisions"""
@@ -270,7 +282,9 @@ def test_logical_shards_on_one_gpu_equal_single(P):
     for r, c in enumerate(ctxs):
         c.costs_upload(M.viewsel.DataCosts(full.n_faces, full.n_views, full.col_ptr, full.view_id, full.cost))
         o = G.GpuShardOps(c, tap, tad, params); o.setup(); ops.append(o)
-    hx = [G.HaloExchange(plans[r], dev) for r in range(P)]
+    def dev_idx(a):
+        return torch.from_numpy(np.asarray(a, dtype=np.uint32).astype(np.int64)).to(dev).to(torch.int32)
+    hx_idx = [{k: [dev_idx(x) for x in getattr(plans[r], k)] for k in ("msg_send", "msg_recv", "node_send", "node_recv")} for r in range(P)]
 
     def exchange(kinds):
         bufs = {}
@@ -278,7 +292,7 @@ def test_logical_shards_on_one_gpu_equal_single(P):
             for q in range(P):
                 parts = []
                 for k, which in kinds:
-                    idx = hx[r].idx[k + "_send"][q]
+                    idx = hx_idx[r][k + "_send"][q]
                     t = torch.zeros(len(idx), dtype=torch.int32, device=dev)
                     if len(idx): ops[r].gather(which, idx, t)
                     parts.append(t)
@@ -287,7 +301,7 @@ def test_logical_shards_on_one_gpu_equal_single(P):
         for r in range(P):
             for q in range(P):
                 for (k, which), t in zip(kinds, bufs[(q, r)]):
-                    idx = hx[r].idx[k + "_recv"][q]
+                    idx = hx_idx[r][k + "_recv"][q]
                     if len(idx): ops[r].scatter(which, idx, t)
         torch.cuda.synchronize()
 
@@ -392,3 +406,39 @@ def test_config2_size_properties(ctx):
     icm = O.icm_baseline(O.CsrNp(dc.n_faces, dc.n_views, dc.col_ptr, dc.view_id, dc.cost), s.adj_ptr, s.adj)
     ei, _ = O.energy(O.CsrNp(dc.n_faces, dc.n_views, dc.col_ptr, dc.view_id, dc.cost), s.adj_ptr, s.adj, icm)
     assert ms["energy_fixed"] < ei
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 (1 997 120 faces, 200 views 2048x1536 -- the bench workload): size-independent properties.
+    The per-entry oracle comparison happens at the small sizes above; here: conservation of pairs, sorted columns,
+    cost = f(quality, percentile) recomputed on the host, identical results across ray traversal modes and runs,
+    exact energy re-evaluated by the oracle's independent evaluator, labels drawn from the face's own column."""
+    s = M.synth.make_scene(**M.synth.CONFIGS[3])
+    c = M.Context(0); c.set_option("stats", 1)
+    _load_scene(c, s)
+    st = c.data_costs(M.Settings())
+    dc = c.costs_download()
+    F, V = s.n_faces, s.n_views
+    assert (F, V) == (1997120, 200) and st["pairs"] == F * V
+    assert st["cull_backface"] + st["cull_angle"] + st["cull_outside"] + st["cull_occluded"] + st["cull_zero_quality"] + st["nnz_pre"] == st["pairs"]
+    assert dc.nnz == st["nnz"] == st["nnz_pre"] > 50_000_000
+    K = np.diff(dc.col_ptr.astype(np.int64))
+    rows = np.repeat(np.arange(F, dtype=np.int32), K)
+    same_row = rows[1:] == rows[:-1]
+    assert (np.diff(dc.view_id.astype(np.int32))[same_row] > 0).all()
+    del rows, same_row
+    assert np.float32(st["max_quality"]) == dc.quality.max()
+    pct = np.float32(O.load().orc_percentile(dc.quality.ctypes.data, dc.nnz, C.c_float(st["max_quality"]), C.c_float(0.995)))
+    assert np.float32(st["percentile"]) == pct
+    assert np.array_equal(dc.cost.view(np.uint32), (np.float32(1.0) - np.minimum(np.float32(1.0), dc.quality / pct)).view(np.uint32))
+    c.set_option("ray_mode", 0)
+    st0 = c.data_costs(M.Settings()); dc0 = c.costs_download()
+    assert st0["cull_occluded"] == st["cull_occluded"] and np.array_equal(dc0.col_ptr, dc.col_ptr) and np.array_equal(dc0.cost.view(np.uint32), dc.cost.view(np.uint32))
+    del dc0
+    labels, ms = c.view_selection(s.adj_ptr, s.adj)
+    labels2, ms2 = c.view_selection(s.adj_ptr, s.adj)
+    assert np.array_equal(labels, labels2) and ms["energy_fixed"] == ms2["energy_fixed"]
+    assert ((labels == 0) == (K == 0)).all()
+    e, cuts = O.energy(O.CsrNp(F, V, dc.col_ptr, dc.view_id, dc.cost), s.adj_ptr, s.adj, labels)   # rejects labels outside the column
+    assert e == ms["energy_fixed"] and cuts == ms["cut_edges"]
+    c.close()

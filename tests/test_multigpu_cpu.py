@@ -95,10 +95,22 @@ class _FakeOps:
                     new[self.in_off[r]:self.in_off[r] + self.size[r]] = (int(acc) + np.arange(self.size[r])) % 2 ** 32
 
     def gather(self, which, idx, dst):
-        dst.copy_(self.torch.from_numpy(self.arr[which][idx.numpy().astype(np.int64) & 0xFFFFFFFF].astype(np.int64)).to(self.torch.int32))
+        i = idx.numpy().astype(np.int64) & 0xFFFFFFFF
+        if which == G.MSG_LAB:   # combined addressing: bit 31 selects the label array
+            hi = i >= 2 ** 31
+            v = np.where(hi, self.arr[G.LAB][np.where(hi, i - 2 ** 31, 0)], self.arr[G.MSG][np.where(hi, 0, i)])
+        else:
+            v = self.arr[which][i]
+        dst.copy_(self.torch.from_numpy(v.astype(np.int64)).to(self.torch.int32))
 
     def scatter(self, which, idx, src):
-        self.arr[which][idx.numpy().astype(np.int64) & 0xFFFFFFFF] = src.numpy().astype(np.int64) & 0xFFFFFFFF
+        i = idx.numpy().astype(np.int64) & 0xFFFFFFFF
+        v = src.numpy().astype(np.int64) & 0xFFFFFFFF
+        if which == G.MSG_LAB:
+            hi = i >= 2 ** 31
+            self.arr[G.LAB][i[hi] - 2 ** 31] = v[hi]; self.arr[G.MSG][i[~hi]] = v[~hi]
+        else:
+            self.arr[which][i] = v
 
     def energy(self, which, nb, ne):
         sel = self.arr[which]
