@@ -232,7 +232,8 @@ mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32
                              const mvs_mrf_params* params);
 /* one sweep over nodes [node_begin, node_end): reads the current messages, writes the next ones, flips */
 mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
-/* dst[k] = array[idx[k]] / array[idx[k]] = src[k]; 4-byte elements; MSG = the buffer the last sweep wrote */
+/* dst[k] = array[idx[k]] / array[idx[k]] = src[k] in 4-byte exchange words (message elements are binary16 and travel
+ * zero-extended); MSG = the buffer the last sweep wrote */
 mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, void* dst_device);
 mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, const void* src_device);
 /* partial energy (32.32 fixed point) + cut count of labeling LAB or BEST_LAB over own nodes -> dst_device[2] */

@@ -151,7 +151,8 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
     mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_shape = 0, mrf_unroll = 1, mrf_nt = 0, mrf_blocks_per_cu = 8, mrf_xcd = 1;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
-    mvs::DBuf<float> m_msg_a, m_msg_b; mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
+    mvs::DBuf<uint16_t> m_msg_a, m_msg_b;   // messages as IEEE binary16 bit patterns, double buffered
+    mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
     mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved;
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0; bool m_flip = false;

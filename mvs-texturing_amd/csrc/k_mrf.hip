@@ -21,6 +21,12 @@ namespace {
 
 constexpr uint16_t MAP_NONE = 0xFFFF;
 
+// Messages live in HBM as IEEE binary16 (round to nearest even on store), arithmetic is fp32:
+// half the bytes per sweep of an fp32 layout at the same solution quality.
+typedef _Float16 msg_t;
+__device__ __forceinline__ float msg_load(const msg_t* __restrict__ p, size_t i) { return (float)p[i]; }
+__device__ __forceinline__ msg_t msg_pack(float v) { return (msg_t)v; }
+
 __device__ __forceinline__ unsigned long long fix32(float d) { return (unsigned long long)((double)d * 4294967296.0); }
 
 // ---- setup ----
@@ -123,7 +129,7 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // kj's top bit marks an edge whose two label lists are identical: no map load, no re-alignment shuffle.
 template <int G, int R, bool DAMP, int U, bool NT, bool XCD>
 __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                        const uint16_t* __restrict__ map, const float* __restrict__ mo, float* __restrict__ mn,
+                                                        const uint16_t* __restrict__ map, const msg_t* __restrict__ mo, msg_t* __restrict__ mn,
                                                         uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     constexpr int NPB = 256 / G;
@@ -163,10 +169,10 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     const uint32_t kjf = okn[u] ? cur[u].kj[d] : 0u, kj = kjf & ~IDENT;
-                    in[u][d][r] = (ok && kj) ? mo[cur[u].in_off[d] + t] : 0.0f;
+                    in[u][d][r] = (ok && kj) ? msg_load(mo, cur[u].in_off[d] + t) : 0.0f;
                     const bool ok2 = t < kj;
                     mp[u][d][r] = (kjf & IDENT) ? t : (ok2 ? (uint32_t)map[cur[u].out_off[d] + t] : 0u);
-                    old[u][d][r] = (DAMP && ok2) ? mo[cur[u].out_off[d] + t] : 0.0f;
+                    old[u][d][r] = (DAMP && ok2) ? msg_load(mo, cur[u].out_off[d] + t) : 0.0f;
                 }
             }
         }
@@ -225,7 +231,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
                         }
                     }
                     const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
-                    const float outv = DAMP ? (raw * oma + old[u][d][r] * alpha) : raw;
+                    const msg_t outv = msg_pack(DAMP ? (raw * oma + old[u][d][r] * alpha) : raw);
                     if (t2 < kj) { if (NT) __builtin_nontemporal_store(outv, &mn[oo + t2]); else mn[oo + t2] = outv; }
                 }
             }
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
 template <bool DAMP>
 __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                                const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
-                                                               const float* __restrict__ mo, float* __restrict__ mn, uint32_t* __restrict__ sel,
+                                                               const msg_t* __restrict__ mo, msg_t* __restrict__ mn, uint32_t* __restrict__ sel,
                                                                uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                                float* __restrict__ scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     const uint32_t i = node_begin + blockIdx.x;
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
     float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
     for (uint32_t t = lane; t < K; t += 64) {
         float S = 0.0f;
-        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) S = S + mo[m.in_off + t]; }
+        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) S = S + msg_load(mo, m.in_off + t); }
         const float b = cost[p0 + t] + rho * S;
         if (b < bb) { bb = b; bt = t; }
     }
@@ -265,8 +271,8 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         float cmin = INFINITY;
         for (uint32_t t = lane; t < K; t += 64) {
             float oth = 0.0f;
-            for (uint32_t e2 = e0; e2 < e1; ++e2) { if (e2 == e) continue; const MrfEdge m2 = edge[e2]; if (m2.kj) oth = oth + mo[m2.in_off + t]; }
-            const float c = (cost[p0 + t] + rho * oth) - omr * mo[m.in_off + t];
+            for (uint32_t e2 = e0; e2 < e1; ++e2) { if (e2 == e) continue; const MrfEdge m2 = edge[e2]; if (m2.kj) oth = oth + msg_load(mo, m2.in_off + t); }
+            const float c = (cost[p0 + t] + rho * oth) - omr * msg_load(mo, m.in_off + t);
             scratch[p0 + t] = c;
             cmin = fminf(cmin, c);
         }
@@ -275,7 +281,7 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         for (uint32_t t2 = lane; t2 < m.kj; t2 += 64) {
             const uint16_t p = map[m.out_off + t2];
             const float raw = (p == MAP_NONE) ? lam : fminf(scratch[p0 + p] - cmin, lam);
-            mn[m.out_off + t2] = DAMP ? (raw * oma + mo[m.out_off + t2] * alpha) : raw;
+            mn[m.out_off + t2] = msg_pack(DAMP ? (raw * oma + msg_load(mo, m.out_off + t2) * alpha) : raw);
         }
         __syncthreads();
     }
@@ -473,8 +479,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_desc.ensure((size_t)F + 1);
     if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
     ctx->m_msg_a.ensure(ctx->m_total + 1); ctx->m_msg_b.ensure(ctx->m_total + 1);
-    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1) * sizeof(float), s));
-    MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 1) * sizeof(float), s));
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1) * sizeof(uint16_t), s));   // binary16 zeros
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 1) * sizeof(uint16_t), s));
     MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
     ctx->m_sel.ensure((size_t)F + 1); ctx->m_best_sel.ensure((size_t)F + 1); ctx->m_sel2.ensure((size_t)F + 1); ctx->m_cand.ensure((size_t)F + 1); ctx->m_gain.ensure((size_t)F + 1);
     ctx->m_lab.ensure((size_t)F + 1); ctx->m_best_lab.ensure((size_t)F + 1); ctx->m_cost.ensure((size_t)F + 1); ctx->m_best_cost.ensure((size_t)F + 1);
@@ -495,7 +501,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
 }
 
 template <int G, int R, int U>
-static void launch_sweep_gru(mvs_ctx* ctx, const float* mo, float* mn, uint32_t nb0, uint32_t ne0) {
+static void launch_sweep_gru(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
     constexpr int NPB = 256 / G;
     const unsigned need = (ne0 - nb0 + NPB * U - 1) / (NPB * U);
     unsigned blocks = std::max(1u, std::min<unsigned>(need, 256u * (unsigned)ctx->mrf_blocks_per_cu));   // persistent lane groups
@@ -513,15 +519,15 @@ static void launch_sweep_gru(mvs_ctx* ctx, const float* mo, float* mn, uint32_t 
 #undef SWEEP_ARGS
 }
 template <int G, int R>
-static void launch_sweep_gr(mvs_ctx* ctx, const float* mo, float* mn, uint32_t nb0, uint32_t ne0) {
+static void launch_sweep_gr(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
     if (ctx->mrf_unroll >= 2 && R <= 2) launch_sweep_gru<G, R, 2>(ctx, mo, mn, nb0, ne0);
     else launch_sweep_gru<G, R, 1>(ctx, mo, mn, nb0, ne0);
 }
 
 // one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
-    const float* mo = ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p;
-    float* mn = ctx->m_flip ? ctx->m_msg_a.p : ctx->m_msg_b.p;
+    const msg_t* mo = reinterpret_cast<const msg_t*>(ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p);
+    msg_t* mn = reinterpret_cast<msg_t*>(ctx->m_flip ? ctx->m_msg_a.p : ctx->m_msg_b.p);
     if (ne0 > nb0) {
         const uint32_t K = ctx->m_kmax;
         if (ctx->m_degmax <= 3 && K <= 256) {

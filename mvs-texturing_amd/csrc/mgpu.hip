@@ -25,16 +25,23 @@ __global__ void scatter_kernel(uint32_t* __restrict__ dst, const uint32_t* __res
 }
 // combined addressing: index < 2^31 -> array a (messages), else array b[index & 0x7FFFFFFF] (labels):
 // one gather / scatter per sweep moves cut-edge messages AND boundary labels
-__global__ void gather2_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+// message elements are binary16: moved zero-extended in 4-byte exchange words
+__global__ void gather_msg_kernel(const uint16_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[k] = src[idx[k]];
+}
+__global__ void scatter_msg_kernel(uint16_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = (uint16_t)src[k];
+}
+__global__ void gather2_kernel(const uint16_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = idx[k];
         dst[k] = (i & 0x80000000u) ? b[i & 0x7FFFFFFFu] : a[i];
     }
 }
-__global__ void scatter2_kernel(uint32_t* __restrict__ a, uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+__global__ void scatter2_kernel(uint16_t* __restrict__ a, uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = idx[k];
-        if (i & 0x80000000u) b[i & 0x7FFFFFFFu] = src[k]; else a[i] = src[k];
+        if (i & 0x80000000u) b[i & 0x7FFFFFFFu] = src[k]; else a[i] = (uint16_t)src[k];
     }
 }
 __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, uint32_t* __restrict__ counts) {
@@ -43,9 +50,9 @@ __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, 
 }
 }  // namespace
 
+static uint16_t* mrf_msg(mvs_ctx* ctx) { return ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p; }  // current = what the last sweep wrote
 static uint32_t* mrf_array(mvs_ctx* ctx, int which) {
     switch (which) {
-        case MVS_MRF_MSG: return (uint32_t*)(ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p);  // current = what the last sweep wrote
         case MVS_MRF_LAB: return ctx->m_lab.p;
         case MVS_MRF_GAIN: return (uint32_t*)ctx->m_gain.p;
         case MVS_MRF_BEST_LAB: return ctx->m_best_lab.p;
@@ -128,7 +135,10 @@ mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx, uint
     MVS_API_BEGIN
     if (n && which == MVS_MRF_MSG_LAB) {
         if (ctx->m_total >= 0x80000000ull) throw StatusError(MVS_ERR_UNSUPPORTED, "combined addressing needs < 2^31 message words");
-        hipLaunchKernelGGL(gather2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, MVS_MRF_MSG), ctx->m_lab.p, idx, n, (uint32_t*)dst);
+        hipLaunchKernelGGL(gather2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), ctx->m_lab.p, idx, n, (uint32_t*)dst);
+        MVS_LAUNCH_CHECK();
+    } else if (n && which == MVS_MRF_MSG) {
+        hipLaunchKernelGGL(gather_msg_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), idx, n, (uint32_t*)dst);
         MVS_LAUNCH_CHECK();
     } else if (n) {
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (uint32_t*)dst);
@@ -140,7 +150,10 @@ mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx, uin
     if (!ctx || (n && (!idx || !src))) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
     if (n && which == MVS_MRF_MSG_LAB) {
-        hipLaunchKernelGGL(scatter2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, MVS_MRF_MSG), ctx->m_lab.p, idx, n, (const uint32_t*)src);
+        hipLaunchKernelGGL(scatter2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), ctx->m_lab.p, idx, n, (const uint32_t*)src);
+        MVS_LAUNCH_CHECK();
+    } else if (n && which == MVS_MRF_MSG) {
+        hipLaunchKernelGGL(scatter_msg_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), idx, n, (const uint32_t*)src);
         MVS_LAUNCH_CHECK();
     } else if (n) {
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (const uint32_t*)src);

@@ -746,7 +746,7 @@ void orc_csr_free(orc_csr* c) {
 //        c[t]  = (D[t] + rho * oth[t]) - (1 - rho) * m_e[t];  cmin = min_t c[t]
 //        for t' < K_j:  p = map[moff[rev e] + t']
 //          raw = (p == NONE) ? lam : fminf(c[p] - cmin, lam),   lam = 1 / rho
-//          m'_{rev e}[t'] = raw * (1 - alpha) + m_{rev e}[t'] * alpha
+//          m'_{rev e}[t'] = f16( raw * (1 - alpha) + m_{rev e}[t'] * alpha )   [messages are stored as IEEE binary16, RNE]
 //  * After each sweep the decoded labeling's energy is evaluated exactly in
 //    32.32 fixed point (integer sums are order independent); the best labeling
 //    so far is kept.  Stop like StopWhenReturnsDiminish(5, 0.01)
@@ -763,6 +763,38 @@ uint64_t* g_trace = nullptr; int g_trace_len = 0;
 uint64_t* g_quiet = nullptr;  // optional: per sweep, nodes that a lazy sweep could skip (experiments)  // optional per-sweep energy trace (experiments)
 
 inline uint64_t fix32(float d) { return (uint64_t)((double)d * 4294967296.0); }
+
+// Messages are STORED as IEEE binary16 (round to nearest even), all arithmetic stays fp32.
+// Portable bit-level conversions (no F16C dependency), checked against numpy.float16 in the tests.
+inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t fu; memcpy(&fu, &f, 4);
+    const uint32_t sign = fu & 0x80000000u; fu ^= sign;
+    uint16_t o;
+    if (fu >= ((127u + 16u) << 23)) o = (fu > (255u << 23)) ? 0x7e00 : 0x7c00;            // overflow -> inf, NaN stays NaN
+    else if (fu < (113u << 23)) {                                                         // subnormal half or zero
+        const uint32_t magic = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+        float a, m; memcpy(&a, &fu, 4); memcpy(&m, &magic, 4);
+        const float r = a + m;                                                            // the fp32 add performs the RNE rounding
+        uint32_t ru; memcpy(&ru, &r, 4);
+        o = (uint16_t)(ru - magic);
+    } else {
+        const uint32_t mant_odd = (fu >> 13) & 1u;
+        fu += ((uint32_t)(15 - 127) << 23) + 0xfffu;
+        fu += mant_odd;
+        o = (uint16_t)(fu >> 13);
+    }
+    return (uint16_t)(o | (sign >> 16));
+}
+inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, em = h & 0x7fffu;
+    uint32_t u;
+    if (em >= 0x7c00u) u = sign | 0x7f800000u | ((em & 0x3ffu) << 13);                     // inf / NaN
+    else if (em >= 0x0400u) u = sign | ((em + ((127u - 15u) << 10)) << 13);               // normal
+    else if (em == 0) u = sign;
+    else { float v = (float)em * 5.9604644775390625e-08f; memcpy(&u, &v, 4); u |= sign; } // subnormal: em * 2^-24 (exact)
+    float f; memcpy(&f, &u, 4); return f;
+}
+inline float round_to_f16(float f) { return f16_to_f32(f32_to_f16_rne(f)); }
 
 struct Mrf {
     uint32_t F = 0;
@@ -862,7 +894,7 @@ void mrf_sweep(const Mrf& g, const orc_mrf_params& P, const std::vector<float>& 
                 for (uint32_t t2 = 0; t2 < Kj; ++t2) {
                     const uint16_t p = g.map[o + t2];
                     const float raw = (p == MAP_NONE) ? lam : std::fmin(c[p] - cmin, lam);
-                    mn[o + t2] = raw * oma + mo[o + t2] * alpha;
+                    mn[o + t2] = round_to_f16(raw * oma + mo[o + t2] * alpha);   // stored as binary16
                 }
             }
         }
@@ -914,6 +946,8 @@ uint32_t mrf_icm_iter(const Mrf& g, std::vector<uint32_t>& sel, std::vector<floa
 
 extern "C" {
 
+uint16_t orc_f32_to_f16(float f) { return f32_to_f16_rne(f); }
+float orc_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
 void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = len; }
 void orc_mrf_set_quiet_trace(uint64_t* buf) { g_quiet = buf; }
 

@@ -143,6 +143,21 @@ def test_outlier_detection_matches_numpy_linear_algebra():
             assert q == qn[v]
 
 
+def test_binary16_message_storage_conversions():
+    """the solver stores messages as IEEE binary16 (RNE): its software conversions equal numpy.float16"""
+    L = O.load()
+    L.orc_f32_to_f16.argtypes = [C.c_float]; L.orc_f32_to_f16.restype = C.c_uint16
+    L.orc_f16_to_f32.argtypes = [C.c_uint16]; L.orc_f16_to_f32.restype = C.c_float
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(4000).astype(np.float32) * 1.3, (rng.random(2000) * 1e-4).astype(np.float32),
+                        np.float32([0, 1, 1.25, 6e-8, 3e-8, 2.98e-8, 65504, 1e-10, -0.3, 0.33325195, 0.33337402])])
+    ref = x.astype(np.float16)
+    got = np.array([L.orc_f32_to_f16(C.c_float(float(v))) for v in x], dtype=np.uint16)
+    assert np.array_equal(got, ref.view(np.uint16))
+    back = np.array([L.orc_f16_to_f32(int(h)) for h in got], dtype=np.float32)
+    assert np.array_equal(back.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+
+
 def test_solver_quality_small_instances():
     """the DEFINED-HERE solver: never worse than plain ICM, optimal or near-optimal on tiny instances"""
     worse = 0
