@@ -41,7 +41,7 @@ __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint
         for (uint32_t e = e0; e < e1; ++e) {
             const uint32_t j = adj[e];
             const uint32_t kj = col_ptr[j + 1] - col_ptr[j];
-            size[e] = (k > 0 && kj > 0) ? k : 0u;
+            size[e] = (k > 0 && kj > 0) ? ((k + 1u) & ~1u) : 0u;   // runs padded to an even length: 4-byte aligned pairs
         }
     }
     for (int o = 32; o > 0; o >>= 1) { k = max(k, (uint32_t)__shfl_xor(k, o, 64)); deg = max(deg, (uint32_t)__shfl_xor(deg, o, 64)); }
@@ -124,10 +124,12 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // c[p] is a ds_bpermute (__shfl) inside the node's lane group: no LDS memory, no barrier.
 // Besides sel (label index) the decode also leaves the label itself (view id + 1) and its unary
 // cost, which is all the energy / ICM kernels need of a neighbour.
-// U = nodes per lane group per loop iteration (loads of all U nodes are issued before any is consumed);
-// NT = non-temporal stores for the outgoing messages (they are not re-read before the next sweep).
-// kj's top bit marks an edge whose two label lists are identical: no map load, no re-alignment shuffle.
-template <int G, int R, bool DAMP, int U, bool NT, bool XCD>
+// Blocked layout: lane gl of a node's group owns labels 2*gl and 2*gl + 1, so one 4-byte load brings two
+// binary16 messages (or two u16 map entries); message runs are padded to an even length in HBM.
+// K <= 2 * G.  NT = non-temporal stores; XCD = XCD-aware block remap.  kj's top bit marks an edge whose two
+// label lists are identical: no map load, no re-alignment shuffle.
+struct alignas(4) msg2_t { msg_t a, b; };
+template <int G, bool DAMP, bool NT, bool XCD>
 __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                         const uint16_t* __restrict__ map, const msg_t* __restrict__ mo, msg_t* __restrict__ mn,
                                                         uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
@@ -136,105 +138,102 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
     constexpr uint32_t IDENT = 0x80000000u;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
-    const uint32_t stride = gridDim.x * NPB;           // nodes per "row" of groups
+    const uint32_t stride = gridDim.x * NPB;
     // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed; used for speed only), so give every XCD a
     // CONTIGUOUS eighth of each row: a node and its mesh neighbours (adjacent in Morton order) then share one L2, and
     // a message read twice per sweep (as "in" by the receiver, as "old" by the sender) is fetched once.
     uint32_t vb = blockIdx.x;
     if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    // persistent groups: group g handles nodes g + stride * (U * it + u); next iteration's descriptors are prefetched
-    const uint32_t first = node_begin + vb * NPB + grp;
-    NodeDesc nd[U];
+    // persistent groups: group g handles nodes g, g + stride, ...; the next node's descriptor is prefetched
+    uint32_t i = node_begin + vb * NPB + grp;
+    NodeDesc nd = {};
+    if (i < node_end) nd = desc[i];
+    const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;   // uniform trip count (shuffles need all lanes)
+    const uint32_t t0 = 2u * gl, t1 = 2u * gl + 1u;
+    for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
+        const bool node_ok = i < node_end;
+        const NodeDesc cur = nd;
+        if (i + stride < node_end) nd = desc[i + stride];
+        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
+        const bool ok0 = t0 < K, ok1 = t1 < K;
+        float D[2], in[3][2], old[3][2];
+        uint32_t mp[3][2];
+        D[0] = ok0 ? cost[p0 + t0] : 0.0f;
+        D[1] = ok1 ? cost[p0 + t1] : 0.0f;
+        bool any_shuffle = false;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { nd[u] = NodeDesc{}; const uint32_t i = first + u * stride; if (i < node_end) nd[u] = desc[i]; }
-    const uint32_t n_iter = (node_end - node_begin + stride * U - 1) / (stride * U);   // uniform trip count (shuffles need all lanes)
-    for (uint32_t it = 0; it < n_iter; ++it) {
-        uint32_t ii[U]; bool okn[U]; NodeDesc cur[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ii[u] = first + (it * U + u) * stride; okn[u] = ii[u] < node_end; cur[u] = nd[u];
-            const uint32_t inext = ii[u] + U * stride;
-            if (inext < node_end) nd[u] = desc[inext];
-        }
-        float D[U][R], in[U][3][R], old[U][3][R];
-        uint32_t mp[U][3][R];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t p0 = cur[u].p0, K = okn[u] ? cur[u].k : 0u;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t t = gl + r * G;
-                const bool ok = t < K;
-                D[u][r] = ok ? cost[p0 + t] : 0.0f;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const uint32_t kjf = okn[u] ? cur[u].kj[d] : 0u, kj = kjf & ~IDENT;
-                    in[u][d][r] = (ok && kj) ? msg_load(mo, cur[u].in_off[d] + t) : 0.0f;
-                    const bool ok2 = t < kj;
-                    mp[u][d][r] = (kjf & IDENT) ? t : (ok2 ? (uint32_t)map[cur[u].out_off[d] + t] : 0u);
-                    old[u][d][r] = (DAMP && ok2) ? msg_load(mo, cur[u].out_off[d] + t) : 0.0f;
-                }
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t kjf = node_ok ? cur.kj[d] : 0u, kj = kjf & ~IDENT;
+            msg2_t mi; mi.a = (msg_t)0; mi.b = (msg_t)0;
+            if (ok0 && kj) mi = *reinterpret_cast<const msg2_t*>(mo + cur.in_off[d] + t0);   // even offset: 4-byte aligned
+            in[d][0] = ok0 && kj ? (float)mi.a : 0.0f;
+            in[d][1] = ok1 && kj ? (float)mi.b : 0.0f;
+            const bool o0 = t0 < kj;
+            msg2_t mold; mold.a = (msg_t)0; mold.b = (msg_t)0;
+            if (DAMP && o0) mold = *reinterpret_cast<const msg2_t*>(mo + cur.out_off[d] + t0);
+            old[d][0] = (float)mold.a; old[d][1] = (float)mold.b;
+            if (kjf & IDENT) { mp[d][0] = t0; mp[d][1] = t1; }
+            else {
+                uint32_t m2 = 0;
+                if (o0) m2 = *reinterpret_cast<const uint32_t*>(map + cur.out_off[d] + t0);
+                mp[d][0] = m2 & 0xFFFFu; mp[d][1] = m2 >> 16;
+                any_shuffle = any_shuffle || (kj != 0u);
             }
         }
+        // decode: first argmin_t of b[t] = D[t] + rho * S[t]
+        {
+            float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t i = ii[u], p0 = cur[u].p0, K = okn[u] ? cur[u].k : 0u;
-            // decode: first argmin_t of b[t] = D[t] + rho * S[t]
-            {
-                float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t t = gl + r * G;
-                    const float S = ((0.0f + in[u][0][r]) + in[u][1][r]) + in[u][2][r];
-                    const float b = D[u][r] + rho * S;
-                    if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
-                }
-#pragma unroll
-                for (int o = G / 2; o > 0; o >>= 1) {
-                    const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
-                    if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
-                }
-                if (gl == 0 && okn[u]) {
-                    if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
-                    else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
-                }
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t t = t0 + r;
+                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
+                const float b = D[r] + rho * S;
+                if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
             }
-            // outgoing messages
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
-                float c[R];
-                float cmin = INFINITY;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t t = gl + r * G;
-                    const float oth = (0.0f + in[u][a][r]) + in[u][b2][r];
-                    c[r] = (D[u][r] + rho * oth) - omr * in[u][d][r];
-                    if (t < K) cmin = fminf(cmin, c[r]);
-                }
-#pragma unroll
-                for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
-                const uint32_t kjf = okn[u] ? cur[u].kj[d] : 0u, kj = kjf & ~IDENT, oo = cur[u].out_off[d];
-                // G == 64: one node per wave, so "identical label lists" is wave-uniform and the shuffle can be skipped
-                const bool skip_shuffle = (G == 64) && (kjf & IDENT);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t t2 = gl + r * G;
-                    const uint32_t p = mp[u][d][r];
-                    float cp = c[r];
-                    if (!skip_shuffle) {
-                        const uint32_t pl = p & (uint32_t)(G - 1), ps = (p & 0xFFFFu) / (uint32_t)G;
-#pragma unroll
-                        for (int s2 = 0; s2 < R; ++s2) {   // every lane executes the shuffles (no divergence around ds_bpermute)
-                            const float v = __shfl(c[s2], (int)pl, G);
-                            cp = (ps == (uint32_t)s2) ? v : cp;
-                        }
-                    }
-                    const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
-                    const msg_t outv = msg_pack(DAMP ? (raw * oma + old[u][d][r] * alpha) : raw);
-                    if (t2 < kj) { if (NT) __builtin_nontemporal_store(outv, &mn[oo + t2]); else mn[oo + t2] = outv; }
-                }
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
+                if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
             }
+            if (gl == 0 && node_ok) {
+                if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
+                else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
+            }
+        }
+        const bool wave_shuffle = __ballot(any_shuffle) != 0ull;   // wave-uniform: some group in this wave must re-align
+        // outgoing messages
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
+            float c[2];
+            float cmin = INFINITY;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float oth = (0.0f + in[a][r]) + in[b2][r];
+                c[r] = (D[r] + rho * oth) - omr * in[d][r];
+                if (t0 + r < K) cmin = fminf(cmin, c[r]);
+            }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
+            const uint32_t kjf = node_ok ? cur.kj[d] : 0u, kj = kjf & ~IDENT, oo = cur.out_off[d];
+            float outv[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t p = mp[d][r];
+                float cp = c[r];                       // identical label lists: position p == own label
+                if (wave_shuffle) {                    // every lane executes the shuffles (no divergence around ds_bpermute)
+                    const int src = (int)((p & 0xFFFFu) >> 1) & (G - 1);
+                    const float v0 = __shfl(c[0], src, G), v1 = __shfl(c[1], src, G);
+                    if (!(kjf & IDENT)) cp = (p & 1u) ? v1 : v0;
+                }
+                const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
+                outv[r] = DAMP ? (raw * oma + old[d][r] * alpha) : raw;
+            }
+            if (t1 < kj) {        // both elements: one 4-byte store
+                msg2_t w; w.a = msg_pack(outv[0]); w.b = msg_pack(outv[1]);
+                if (NT) __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&w), reinterpret_cast<uint32_t*>(mn + oo + t0));
+                else *reinterpret_cast<msg2_t*>(mn + oo + t0) = w;
+            } else if (t0 < kj) mn[oo + t0] = msg_pack(outv[0]);
         }
     }
 }
@@ -500,28 +499,23 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_flip = false;
 }
 
-template <int G, int R, int U>
-static void launch_sweep_gru(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
+template <int G>
+static void launch_sweep_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
     constexpr int NPB = 256 / G;
-    const unsigned need = (ne0 - nb0 + NPB * U - 1) / (NPB * U);
+    const unsigned need = (ne0 - nb0 + NPB - 1) / NPB;
     unsigned blocks = std::max(1u, std::min<unsigned>(need, 256u * (unsigned)ctx->mrf_blocks_per_cu));   // persistent lane groups
     if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
     const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
 #define SWEEP_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
     if (alpha != 0.0f) {
-        if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, true, true>), SWEEP_ARGS);
-        else if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, false, true>), SWEEP_ARGS);
-        else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, true, U, false, false>), SWEEP_ARGS);
+        if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, true, true, true>), SWEEP_ARGS);
+        else if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, true, false, true>), SWEEP_ARGS);
+        else hipLaunchKernelGGL((mrf_sweep_kernel<G, true, false, false>), SWEEP_ARGS);
     } else {
-        if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, false, true>), SWEEP_ARGS);
-        else hipLaunchKernelGGL((mrf_sweep_kernel<G, R, false, U, false, false>), SWEEP_ARGS);
+        if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, false, false, true>), SWEEP_ARGS);
+        else hipLaunchKernelGGL((mrf_sweep_kernel<G, false, false, false>), SWEEP_ARGS);
     }
 #undef SWEEP_ARGS
-}
-template <int G, int R>
-static void launch_sweep_gr(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
-    if (ctx->mrf_unroll >= 2 && R <= 2) launch_sweep_gru<G, R, 2>(ctx, mo, mn, nb0, ne0);
-    else launch_sweep_gru<G, R, 1>(ctx, mo, mn, nb0, ne0);
 }
 
 // one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
@@ -530,24 +524,14 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     msg_t* mn = reinterpret_cast<msg_t*>(ctx->m_flip ? ctx->m_msg_a.p : ctx->m_msg_b.p);
     if (ne0 > nb0) {
         const uint32_t K = ctx->m_kmax;
-        if (ctx->m_degmax <= 3 && K <= 256) {
-            // lanes per node (G) x labels per lane (R); several nodes per wave keep more loads in flight
-            const int shape = ctx->mrf_shape;   // 0 = auto
-            if (shape == 0) {
-                if (K <= 8) launch_sweep_gr<8, 1>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 16) launch_sweep_gr<16, 1>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 32) launch_sweep_gr<32, 1>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 128) launch_sweep_gr<64, 2>(ctx, mo, mn, nb0, ne0);
-                else launch_sweep_gr<64, 4>(ctx, mo, mn, nb0, ne0);
-            } else if (shape == 641 && K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
-            else if (shape == 322 && K <= 64) launch_sweep_gr<32, 2>(ctx, mo, mn, nb0, ne0);
-            else if (shape == 164 && K <= 64) launch_sweep_gr<16, 4>(ctx, mo, mn, nb0, ne0);
-            else if (shape == 321 && K <= 32) launch_sweep_gr<32, 1>(ctx, mo, mn, nb0, ne0);
-            else if (shape == 162 && K <= 32) launch_sweep_gr<16, 2>(ctx, mo, mn, nb0, ne0);
-            else if (K <= 64) launch_sweep_gr<64, 1>(ctx, mo, mn, nb0, ne0);
-            else if (K <= 128) launch_sweep_gr<64, 2>(ctx, mo, mn, nb0, ne0);
-            else launch_sweep_gr<64, 4>(ctx, mo, mn, nb0, ne0);
+        if (ctx->m_degmax <= 3 && K <= 128) {
+            // G lanes per node, 2 labels per lane; small columns put several nodes in one wave
+            int g = K <= 16 ? 8 : K <= 32 ? 16 : K <= 64 ? 32 : 64;
+            if (ctx->mrf_shape == 64 || ctx->mrf_shape == 32 || ctx->mrf_shape == 16 || ctx->mrf_shape == 8) { if ((uint32_t)ctx->mrf_shape * 2 >= K) g = ctx->mrf_shape; }
+            if (g == 8) launch_sweep_g<8>(ctx, mo, mn, nb0, ne0);
+            else if (g == 16) launch_sweep_g<16>(ctx, mo, mn, nb0, ne0);
+            else if (g == 32) launch_sweep_g<32>(ctx, mo, mn, nb0, ne0);
+            else launch_sweep_g<64>(ctx, mo, mn, nb0, ne0);
         } else {
             ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
             const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
