@@ -146,39 +146,40 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
     if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // persistent groups: group g handles nodes g, g + stride, ...; the next node's descriptor is prefetched
     uint32_t i = node_begin + vb * NPB + grp;
-    NodeDesc nd = {};
-    if (i < node_end) nd = desc[i];
+    const uint32_t last = node_end - 1;                       // node_end > node_begin (checked by the launcher)
+    // All loads below are UNCONDITIONAL with clamped (always valid) addresses and the results are masked
+    // afterwards: a load under a divergent branch gets its own exec-mask region and s_waitcnt, which
+    // serialises the ~12 loads of a node; unconditional loads are issued back to back.
+    NodeDesc nd = desc[min(i, last)];
     const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;   // uniform trip count (shuffles need all lanes)
     const uint32_t t0 = 2u * gl, t1 = 2u * gl + 1u;
     for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
         const bool node_ok = i < node_end;
         const NodeDesc cur = nd;
-        if (i + stride < node_end) nd = desc[i + stride];
+        nd = desc[min(i + stride, last)];
         const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
         const bool ok0 = t0 < K, ok1 = t1 < K;
         float D[2], in[3][2], old[3][2];
         uint32_t mp[3][2];
-        D[0] = ok0 ? cost[p0 + t0] : 0.0f;
-        D[1] = ok1 ? cost[p0 + t1] : 0.0f;
+        const float d0 = cost[ok0 ? p0 + t0 : 0u], d1 = cost[ok1 ? p0 + t1 : 0u];
+        D[0] = ok0 ? d0 : 0.0f;
+        D[1] = ok1 ? d1 : 0.0f;
         bool any_shuffle = false;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const uint32_t kjf = node_ok ? cur.kj[d] : 0u, kj = kjf & ~IDENT;
-            msg2_t mi; mi.a = (msg_t)0; mi.b = (msg_t)0;
-            if (ok0 && kj) mi = *reinterpret_cast<const msg2_t*>(mo + cur.in_off[d] + t0);   // even offset: 4-byte aligned
-            in[d][0] = ok0 && kj ? (float)mi.a : 0.0f;
-            in[d][1] = ok1 && kj ? (float)mi.b : 0.0f;
-            const bool o0 = t0 < kj;
-            msg2_t mold; mold.a = (msg_t)0; mold.b = (msg_t)0;
-            if (DAMP && o0) mold = *reinterpret_cast<const msg2_t*>(mo + cur.out_off[d] + t0);
-            old[d][0] = (float)mold.a; old[d][1] = (float)mold.b;
-            if (kjf & IDENT) { mp[d][0] = t0; mp[d][1] = t1; }
-            else {
-                uint32_t m2 = 0;
-                if (o0) m2 = *reinterpret_cast<const uint32_t*>(map + cur.out_off[d] + t0);
-                mp[d][0] = m2 & 0xFFFFu; mp[d][1] = m2 >> 16;
-                any_shuffle = any_shuffle || (kj != 0u);
-            }
+            const bool i0 = ok0 && kj != 0u, o0 = t0 < kj, ident = (kjf & IDENT) != 0u;
+            const msg2_t mi = *reinterpret_cast<const msg2_t*>(mo + (i0 ? cur.in_off[d] + t0 : 0u));   // even offsets: 4-byte aligned
+            in[d][0] = i0 ? (float)mi.a : 0.0f;
+            in[d][1] = (ok1 && kj != 0u) ? (float)mi.b : 0.0f;
+            if (DAMP) {
+                const msg2_t mold = *reinterpret_cast<const msg2_t*>(mo + (o0 ? cur.out_off[d] + t0 : 0u));
+                old[d][0] = (float)mold.a; old[d][1] = (float)mold.b;   // only used where t < kj
+            } else { old[d][0] = 0.0f; old[d][1] = 0.0f; }
+            const uint32_t m2 = *reinterpret_cast<const uint32_t*>(map + ((o0 && !ident) ? cur.out_off[d] + t0 : 0u));
+            mp[d][0] = ident ? t0 : (m2 & 0xFFFFu);
+            mp[d][1] = ident ? t1 : (m2 >> 16);
+            any_shuffle = any_shuffle || (!ident && kj != 0u);
         }
         // decode: first argmin_t of b[t] = D[t] + rho * S[t]
         {
@@ -524,7 +525,7 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     msg_t* mn = reinterpret_cast<msg_t*>(ctx->m_flip ? ctx->m_msg_a.p : ctx->m_msg_b.p);
     if (ne0 > nb0) {
         const uint32_t K = ctx->m_kmax;
-        if (ctx->m_degmax <= 3 && K <= 128) {
+        if (ctx->m_degmax <= 3 && K <= 128 && ctx->csr_nnz > 0 && ctx->m_total > 0) {
             // G lanes per node, 2 labels per lane; small columns put several nodes in one wave
             int g = K <= 16 ? 8 : K <= 32 ? 16 : K <= 64 ? 32 : 64;
             if (ctx->mrf_shape == 64 || ctx->mrf_shape == 32 || ctx->mrf_shape == 16 || ctx->mrf_shape == 8) { if ((uint32_t)ctx->mrf_shape * 2 >= K) g = ctx->mrf_shape; }
