@@ -139,7 +139,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_unroll") ctx->mrf_unroll = (int)value;
     else if (n == "mrf_nt") ctx->mrf_nt = (int)value;
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;
-    else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(1, (int)value);
+    else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
 }

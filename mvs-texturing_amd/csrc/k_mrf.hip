@@ -29,6 +29,53 @@ __device__ __forceinline__ msg_t msg_pack(float v) { return (msg_t)v; }
 
 __device__ __forceinline__ unsigned long long fix32(float d) { return (unsigned long long)((double)d * 4294967296.0); }
 
+// Butterfly partner exchange inside a lane group with DPP (VALU latency) instead of ds_bpermute (LDS
+// latency): the pairings xor 1, xor 2 (quad_perm), i <-> 7-i (row_half_mirror) and i <-> 15-i (row_mirror)
+// are involutions that merge groups of 2, 4, 8 and 16 lanes, which is all an all-reduce needs (min and
+// argmin are exact in any order); only the 32- and 64-lane steps go through a shuffle.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+template <int STEP, int G>
+__device__ __forceinline__ float partner_f(float v) {
+    if (STEP == 1) return dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    else if (STEP == 2) return dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    else if (STEP == 4) return dpp_f<0x141>(v);  // row_half_mirror
+    else if (STEP == 8) return dpp_f<0x140>(v);  // row_mirror
+    else return __shfl_xor(v, STEP, G);
+}
+template <int STEP, int G>
+__device__ __forceinline__ uint32_t partner_u(uint32_t v) {
+    if (STEP == 1) return dpp_u<0xB1>(v);
+    else if (STEP == 2) return dpp_u<0x4E>(v);
+    else if (STEP == 4) return dpp_u<0x141>(v);
+    else if (STEP == 8) return dpp_u<0x140>(v);
+    else return __shfl_xor(v, STEP, G);
+}
+template <int G>
+__device__ __forceinline__ float group_min(float v) {
+    v = fminf(v, partner_f<1, G>(v)); v = fminf(v, partner_f<2, G>(v)); v = fminf(v, partner_f<4, G>(v));
+    if (G >= 16) v = fminf(v, partner_f<8, G>(v));
+    if (G >= 32) v = fminf(v, partner_f<16, G>(v));
+    if (G >= 64) v = fminf(v, partner_f<32, G>(v));
+    return v;
+}
+// first argmin: smallest value, ties -> smallest index
+template <int STEP, int G>
+__device__ __forceinline__ void argmin_step(float& bb, uint32_t& bt) {
+    const float ob = partner_f<STEP, G>(bb); const uint32_t ot = partner_u<STEP, G>(bt);
+    const bool take = ob < bb || (ob == bb && ot < bt);
+    bb = take ? ob : bb; bt = take ? ot : bt;
+}
+template <int G>
+__device__ __forceinline__ void group_argmin(float& bb, uint32_t& bt) {
+    argmin_step<1, G>(bb, bt); argmin_step<2, G>(bb, bt); argmin_step<4, G>(bb, bt);
+    if (G >= 16) argmin_step<8, G>(bb, bt);
+    if (G >= 32) argmin_step<16, G>(bb, bt);
+    if (G >= 64) argmin_step<32, G>(bb, bt);
+}
+
 // ---- setup ----
 __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 uint32_t F, uint32_t* __restrict__ size, uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
@@ -191,11 +238,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
                 const float b = D[r] + rho * S;
                 if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
             }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(bb, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
-                if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
-            }
+            group_argmin<G>(bb, bt);
             if (gl == 0 && node_ok) {
                 if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
                 else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
@@ -214,8 +257,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
                 c[r] = (D[r] + rho * oth) - omr * in[d][r];
                 if (t0 + r < K) cmin = fminf(cmin, c[r]);
             }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, G));
+            cmin = group_min<G>(cmin);
             const uint32_t kjf = node_ok ? cur.kj[d] : 0u, kj = kjf & ~IDENT, oo = cur.out_off[d];
             float outv[2];
 #pragma unroll
@@ -504,9 +546,19 @@ template <int G>
 static void launch_sweep_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
     constexpr int NPB = 256 / G;
     const unsigned need = (ne0 - nb0 + NPB - 1) / NPB;
-    unsigned blocks = std::max(1u, std::min<unsigned>(need, 256u * (unsigned)ctx->mrf_blocks_per_cu));   // persistent lane groups
-    if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
     const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+    // persistent lane groups: exactly as many blocks as are resident at once (a partial second wave of
+    // blocks would double the tail); mrf_blocks_per_cu > 0 overrides
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0; hipDeviceProp_t prop;
+        MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep_kernel<G, true, false, true>, 256, 0));
+        MVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        resident = std::max(1, per_cu) * prop.multiProcessorCount;
+    }
+    unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
+    blocks = std::max(1u, std::min(need, blocks));
+    if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
 #define SWEEP_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
     if (alpha != 0.0f) {
         if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, true, true, true>), SWEEP_ARGS);
