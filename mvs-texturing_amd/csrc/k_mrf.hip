@@ -88,7 +88,7 @@ __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint
         for (uint32_t e = e0; e < e1; ++e) {
             const uint32_t j = adj[e];
             const uint32_t kj = col_ptr[j + 1] - col_ptr[j];
-            size[e] = (k > 0 && kj > 0) ? ((k + 1u) & ~1u) : 0u;   // runs padded to an even length: 4-byte aligned pairs
+            size[e] = (k > 0 && kj > 0) ? ((k + 3u) & ~3u) : 0u;   // runs padded to a multiple of 4 elements: 8-byte aligned quads
         }
     }
     for (int o = 32; o > 0; o >>= 1) { k = max(k, (uint32_t)__shfl_xor(k, o, 64)); deg = max(deg, (uint32_t)__shfl_xor(deg, o, 64)); }
@@ -280,6 +280,139 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
         }
     }
 }
+
+// ---- 4 labels per lane: lane gl owns labels 4*gl .. 4*gl+3 (one 8-byte access = four binary16 messages or
+// four u16 map entries), K <= 4 * G, so a 64-lane wave sweeps 64/G nodes per iteration at roughly the
+// instruction count of one.  The kernel is VALU-issue bound, so instructions per node is what counts.
+// The re-alignment gather c[p] goes through a per-wave LDS tile (one 16-byte write, four 4-byte reads per lane
+// and edge; LDS operations of a wave execute in order, so no barrier is needed).
+struct alignas(8) msg4_t { msg_t v[4]; };
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <int G, bool DAMP, bool XCD>
+__global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                         const uint16_t* __restrict__ map, const msg_t* __restrict__ mo, msg_t* __restrict__ mn,
+                                                         uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
+                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha, uint32_t cost_len) {
+    constexpr int NPB = 256 / G;
+    constexpr uint32_t IDENT = 0x80000000u;
+    __shared__ float s_c[256][4];
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int gbase = threadIdx.x - gl;                      // first thread of this lane group (LDS row base)
+    const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
+    const uint32_t stride = gridDim.x * NPB;
+    uint32_t vb = blockIdx.x;
+    if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    uint32_t i = node_begin + vb * NPB + grp;
+    const uint32_t last = node_end - 1;
+    NodeDesc nd = desc[min(i, last)];
+    const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
+    const uint32_t t0 = 4u * gl;
+    for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
+        const bool node_ok = i < node_end;
+        const NodeDesc cur = nd;
+        nd = desc[min(i + stride, last)];
+        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
+        bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ok[r] = t0 + r < K;
+        float D[4], in[3][4], old[3][4];
+        uint32_t mp[3][4];
+        // phase 1: addresses (clamped, always valid); phase 2: ALL loads as raw 8/16-byte words; phase 3: unpack.
+        // Keeping the loads free of conversions lets them issue back to back under one wait.
+        const uint32_t da = ok[0] ? min(p0 + t0, cost_len - 4u) : 0u, dsh = ok[0] ? (p0 + t0 - da) : 0u;   // dsh > 0 only at the very end of the array
+        uint32_t a_in[3], a_out[3], a_map[3], kj3[3]; bool ident3[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t kjf = node_ok ? cur.kj[d] : 0u;
+            kj3[d] = kjf & ~IDENT; ident3[d] = (kjf & IDENT) != 0u;
+            const bool i0 = ok[0] && kj3[d] != 0u, o0 = t0 < kj3[d];
+            a_in[d] = i0 ? cur.in_off[d] + t0 : 0u;                 // multiples of 4 elements: 8-byte aligned
+            a_out[d] = o0 ? cur.out_off[d] + t0 : 0u;
+            a_map[d] = (o0 && !ident3[d]) ? cur.out_off[d] + t0 : 0u;
+        }
+        const f32x4_a4 dv = *reinterpret_cast<const f32x4_a4*>(cost + da);
+        uint2 r_in[3], r_old[3], r_map[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            r_in[d] = *reinterpret_cast<const uint2*>(mo + a_in[d]);
+            if (DAMP) r_old[d] = *reinterpret_cast<const uint2*>(mo + a_out[d]); else r_old[d] = make_uint2(0u, 0u);
+            r_map[d] = *reinterpret_cast<const uint2*>(map + a_map[d]);
+        }
+        {
+            const float dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const uint32_t q = r + dsh; D[r] = (ok[r] && q < 4u) ? (q == 0 ? dd[0] : q == 1 ? dd[1] : q == 2 ? dd[2] : dd[3]) : 0.0f; }
+        }
+        bool any_gather = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t w_in[4] = {r_in[d].x & 0xFFFFu, r_in[d].x >> 16, r_in[d].y & 0xFFFFu, r_in[d].y >> 16};
+            const uint32_t w_old[4] = {r_old[d].x & 0xFFFFu, r_old[d].x >> 16, r_old[d].y & 0xFFFFu, r_old[d].y >> 16};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                in[d][r] = (ok[r] && kj3[d] != 0u) ? (float)__builtin_bit_cast(msg_t, (unsigned short)w_in[r]) : 0.0f;
+                old[d][r] = (float)__builtin_bit_cast(msg_t, (unsigned short)w_old[r]);   // only used where t < kj
+            }
+            mp[d][0] = ident3[d] ? t0 : (r_map[d].x & 0xFFFFu); mp[d][1] = ident3[d] ? t0 + 1 : (r_map[d].x >> 16);
+            mp[d][2] = ident3[d] ? t0 + 2 : (r_map[d].y & 0xFFFFu); mp[d][3] = ident3[d] ? t0 + 3 : (r_map[d].y >> 16);
+            any_gather = any_gather || (!ident3[d] && kj3[d] != 0u);
+        }
+        // decode: first argmin_t of b[t] = D[t] + rho * S[t]
+        {
+            float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
+                const float b = D[r] + rho * S;
+                const bool take = ok[r] && b < bb;            // ascending t within a lane: first minimum kept
+                bb = take ? b : bb; bt = take ? t0 + r : bt;
+            }
+            group_argmin<G>(bb, bt);
+            if (gl == 0 && node_ok) {
+                if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
+                else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
+            }
+        }
+        const bool wave_gather = __ballot(any_gather) != 0ull;   // wave-uniform
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
+            float c[4];
+            float cmin = INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float oth = (0.0f + in[a][r]) + in[b2][r];
+                c[r] = (D[r] + rho * oth) - omr * in[d][r];
+                cmin = ok[r] ? fminf(cmin, c[r]) : cmin;
+            }
+            cmin = group_min<G>(cmin);
+            const uint32_t kj = kj3[d], oo = cur.out_off[d];
+            const bool ident = ident3[d];
+            float cp[4] = {c[0], c[1], c[2], c[3]};          // identical label lists: position p == own label
+            if (wave_gather) {
+                *reinterpret_cast<float4*>(&s_c[threadIdx.x][0]) = make_float4(c[0], c[1], c[2], c[3]);
+                const float* __restrict__ tile = &s_c[gbase][0];   // this group's G x 4 values, label-major
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = tile[mp[d][r] & (uint32_t)(4 * G - 1)];
+                    cp[r] = ident ? cp[r] : v;
+                }
+            }
+            msg4_t w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float raw = (mp[d][r] == (uint32_t)MAP_NONE) ? lam : fminf(cp[r] - cmin, lam);
+                w.v[r] = msg_pack(DAMP ? (raw * oma + old[d][r] * alpha) : raw);
+            }
+            if (t0 + 3u < kj) *reinterpret_cast<msg4_t*>(mn + oo + t0) = w;      // one 8-byte store
+            else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) if (t0 + r < kj) mn[oo + t0 + r] = w.v[r];
+            }
+        }
+    }
+}
+
 
 // generic path: any degree, any K.  One wave per node, cavity vector through a global scratch row.
 template <bool DAMP>
@@ -571,6 +704,28 @@ static void launch_sweep_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb
 #undef SWEEP_ARGS
 }
 
+template <int G>
+static void launch_sweep4_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
+    constexpr int NPB = 256 / G;
+    const unsigned need = (ne0 - nb0 + NPB - 1) / NPB;
+    const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0; hipDeviceProp_t prop;
+        MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep4_kernel<G, true, true>, 256, 0));
+        MVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        resident = std::max(1, per_cu) * prop.multiProcessorCount;
+    }
+    unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
+    blocks = std::max(1u, std::min(need, blocks));
+    if (blocks > 8) blocks &= ~7u;
+    const uint32_t cost_len = (uint32_t)ctx->csr_nnz;
+#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha, cost_len
+    if (alpha != 0.0f) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false>), SWEEP4_ARGS); }
+    else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, false>), SWEEP4_ARGS); }
+#undef SWEEP4_ARGS
+}
+
 // one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     const msg_t* mo = reinterpret_cast<const msg_t*>(ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p);
@@ -578,6 +733,14 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 > nb0) {
         const uint32_t K = ctx->m_kmax;
         if (ctx->m_degmax <= 3 && K <= 128 && ctx->csr_nnz > 0 && ctx->m_total > 0) {
+            if (ctx->mrf_unroll != 2 && ctx->csr_nnz >= 4) {   // default: 4 labels per lane (mrf_unroll == 2 selects the 2-label kernel)
+                if (K <= 32) launch_sweep4_g<8>(ctx, mo, mn, nb0, ne0);
+                else if (K <= 64) launch_sweep4_g<16>(ctx, mo, mn, nb0, ne0);
+                else launch_sweep4_g<32>(ctx, mo, mn, nb0, ne0);
+                MVS_LAUNCH_CHECK();
+                ctx->m_flip = !ctx->m_flip;
+                return;
+            }
             // G lanes per node, 2 labels per lane; small columns put several nodes in one wave
             int g = K <= 16 ? 8 : K <= 32 ? 16 : K <= 64 ? 32 : 64;
             if (ctx->mrf_shape == 64 || ctx->mrf_shape == 32 || ctx->mrf_shape == 16 || ctx->mrf_shape == 8) { if ((uint32_t)ctx->mrf_shape * 2 >= K) g = ctx->mrf_shape; }

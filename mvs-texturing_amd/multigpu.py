@@ -82,7 +82,7 @@ class HaloPlan:
         src = adj                                               # j
         valid = (K[dst] > 0) & (K[src] > 0)
         size = np.where(valid, K[dst], 0)                      # message elements per directed edge
-        padded = (size + 1) & ~1                               # runs are padded to an even length in HBM (k_mrf.hip)
+        padded = (size + 3) & ~3                               # runs are padded to a multiple of 4 elements in HBM (k_mrf.hip)
         in_off = np.zeros(len(size) + 1, dtype=np.int64); in_off[1:] = np.cumsum(padded)
         if in_off[-1] >= 2 ** 32:
             raise ValueError("message array exceeds 2^32 words")

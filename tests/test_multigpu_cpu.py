@@ -67,7 +67,7 @@ class _FakeOps:
         dst = np.repeat(np.arange(F), deg)
         self.valid = (K[dst] > 0) & (K[self.adj] > 0)
         size = np.where(self.valid, K[dst], 0)
-        self.in_off = np.zeros(len(size) + 1, dtype=np.int64); self.in_off[1:] = np.cumsum((size + 1) & ~1)   # padded runs, as the library
+        self.in_off = np.zeros(len(size) + 1, dtype=np.int64); self.in_off[1:] = np.cumsum((size + 3) & ~3)   # padded runs, as the library
         self.size = size
         self.rev = np.zeros(len(size), dtype=np.int64)
         for e in range(len(size)):
