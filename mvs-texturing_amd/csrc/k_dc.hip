@@ -385,7 +385,7 @@ static void upload_views_and_prepare(mvs_ctx* ctx, bool need_gmi) {
 
 // phase 1: everything up to the per-face sorted infos + local max quality
 void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
-    if (!ctx->d_verts || ctx->n_views == 0) throw StatusError(MVS_ERR_STATE, "scene not set (mesh + views)");
+    if (!ctx->d_verts) throw StatusError(MVS_ERR_STATE, "scene not set (mesh + views)");
     /* calculate_data_costs.cpp:315-318 -- F is a uint32 here, so only the view guard can fire */
     if (ctx->n_views > 65535u) throw StatusError(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");
     if (st->data_term != MVS_DATA_TERM_AREA && st->data_term != MVS_DATA_TERM_GMI) throw StatusError(MVS_ERR_INVALID, "bad data_term");
@@ -400,18 +400,21 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     ctx->counters.ensure(64);
     MVS_HIP(hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), s));
 
+    const uint32_t nf_early = ctx->face_end - ctx->face_begin;
+    if (nf_early == 0 || ctx->n_views == 0 || ctx->n_faces == 0) {
+        // nothing to evaluate: every column is empty (the reference's loops simply do not execute)
+        ctx->csr_ptr.ensure((size_t)nf_early + 2); ctx->csr_view.ensure(4); ctx->csr_q.ensure(4); ctx->csr_cost.ensure(4);
+        MVS_HIP(hipMemsetAsync(ctx->csr_ptr.p, 0, ((size_t)nf_early + 2) * sizeof(uint32_t), s));
+        ctx->csr_faces = nf_early; ctx->csr_views = ctx->n_views; ctx->csr_nnz = 0; ctx->dc_phase = 1;
+        ctx->max_q.ensure(4); MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 4 * sizeof(float), s));
+        return;
+    }
     { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }   /* :157-163 */
     if (vis) { Prof pr(ctx, "dc_bvh_build"); build_bvh(ctx); }           /* :144 */
 
     const size_t pw = (size_t)V * fwords;
     ctx->pass_bits.ensure(pw + 1); ctx->surv_bits.ensure(pw + 1); ctx->pass_base.ensure(pw + 2);
     const dim3 fgrid((nf + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
-    if (nf == 0) {
-        ctx->csr_ptr.ensure(2); MVS_HIP(hipMemsetAsync(ctx->csr_ptr.p, 0, 2 * sizeof(uint32_t), s));
-        ctx->csr_faces = 0; ctx->csr_views = V; ctx->csr_nnz = 0; ctx->dc_phase = 1;
-        ctx->max_q.ensure(2); MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
-        return;
-    }
     Prof pr_cull(ctx, "dc_cull");
     if (ctx->stats)
         hipLaunchKernelGGL(cull_kernel<true>, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,

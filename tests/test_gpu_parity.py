@@ -442,3 +442,70 @@ def test_config3_full_size_properties():
     e, cuts = O.energy(O.CsrNp(F, V, dc.col_ptr, dc.view_id, dc.cost), s.adj_ptr, s.adj, labels)   # rejects labels outside the column
     assert e == ms["energy_fixed"] and cuts == ms["cut_edges"]
     c.close()
+
+
+def _degenerate_scene():
+    """bumpy scene + degenerate input: a zero-area face (NaN normal), a sliver, an isolated far-away face that no
+    camera sees, and a camera looking away from the object"""
+    import copy
+    s = copy.copy(get_scene("tiny"))
+    v = s.verts
+    extra_v = np.array([[5.0, 5.0, 5.0], [5.1, 5.0, 5.0], [5.0, 5.1, 5.0]], dtype=np.float32)
+    s.verts = np.ascontiguousarray(np.concatenate([v, extra_v]))
+    nv = len(v)
+    f_deg = np.array([[0, 0, 1]], dtype=np.uint32)                       # zero area: two equal vertices
+    f_sliver = np.array([[0, 1, 1]], dtype=np.uint32)
+    f_far = np.array([[nv, nv + 1, nv + 2]], dtype=np.uint32)
+    s.faces = np.ascontiguousarray(np.concatenate([s.faces, f_deg, f_sliver, f_far]))
+    nan = np.float32(np.nan)
+    n_extra = np.array([[nan, nan, nan], [nan, nan, nan], [0, 0, 1]], dtype=np.float32)
+    s.normals = np.ascontiguousarray(np.concatenate([s.normals, n_extra]))
+    F = len(s.faces)
+    s.adj_ptr = np.ascontiguousarray(np.concatenate([s.adj_ptr, np.full(3, s.adj_ptr[-1], dtype=np.uint32)]))   # the new faces are isolated nodes
+    cams = {k: a.copy() for k, a in s.cams.items()}
+    cams["viewdir"][0] = -cams["viewdir"][0]; cams["w2c"][0][:12] = -cams["w2c"][0][:12]   # camera 0 now looks away (and is mirrored)
+    s.cams = cams
+    assert s.n_faces == F
+    return s
+
+
+def test_degenerate_inputs_match_oracle(ctx):
+    s = _degenerate_scene()
+    _load_scene(ctx, s)
+    for kw in (dict(), dict(data_term="area")):
+        ref, rst = O.data_costs(s, **kw)
+        st = ctx.data_costs(M.Settings(**kw))
+        got = ctx.costs_download()
+        _assert_costs(got, ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        K = np.diff(ref.col_ptr)
+        assert K[-1] == 0 and K[-3] == 0                     # the far face and the zero-area face are unseen
+        lo, so = O.view_selection(ref, s.adj_ptr, s.adj)
+        lg, sg = ctx.view_selection(s.adj_ptr, s.adj)
+        assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and sg["unseen"] == so["unseen"] >= 2
+
+
+def test_empty_and_trivial_inputs():
+    s = get_scene("tiny")
+    c = M.Context(0)
+    # no views at all: every column empty, every label 0 (the reference's loops simply do not run)
+    c.set_mesh(s.verts, s.faces, s.normals); c.set_views({k: v[:0] for k, v in s.cams.items()}, [])
+    st = c.data_costs(M.Settings())
+    dc = c.costs_download()
+    assert dc.nnz == 0 and dc.n_faces == s.n_faces and (dc.col_ptr == 0).all()
+    labels, ms = c.view_selection(s.adj_ptr, s.adj)
+    assert (labels == 0).all() and ms["unseen"] == s.n_faces and ms["energy_fixed"] == s.n_faces << 32
+    # a single face, a single view
+    one = M.synth.make_scene(n=1, n_views=1, width=64, height=64, displacement=0.0, layout=1)
+    c.set_mesh(one.verts, one.faces, one.normals); c.set_views(one.cams, one.images)
+    ref, _ = O.data_costs(one)
+    c.data_costs(M.Settings()); got = c.costs_download()
+    assert np.array_equal(got.col_ptr, ref.col_ptr) and np.array_equal(got.cost.view(np.uint32), ref.cost.view(np.uint32))
+    lo, so = O.view_selection(ref, one.adj_ptr, one.adj)
+    lg, sg = c.view_selection(one.adj_ptr, one.adj)
+    assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"]
+    # a graph without any edge
+    iso_ptr = np.zeros(one.n_faces + 1, dtype=np.uint32); iso = np.zeros(1, dtype=np.uint32)
+    lo, so = O.view_selection(ref, iso_ptr, iso)
+    lg, sg = c.view_selection(iso_ptr, iso)
+    assert np.array_equal(lo, lg) and sg["cut_edges"] == 0
+    c.close()

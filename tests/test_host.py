@@ -156,3 +156,13 @@ def test_kernel_arithmetic_on_host_equals_oracle():
         hits += a
     assert hits > 100
     L.orc_bvh_free(C.c_void_p(bvh))
+
+
+def test_bench_cli_contract():
+    """bench.py exposes the driver's flags (--gpus/--steps/--warmup) and needs no GPU to say so"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in r.stdout
