@@ -370,7 +370,11 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
                                                           const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
     __shared__ float4 s_ray[4][64][2];
     __shared__ uint8_t s_src[4][64];
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // XCD-aware order: hardware block b runs on XCD b % 8 (observed; speed only), so each XCD gets a contiguous
+    // eighth of the (view, vertex patch) sequence and with it a compact part of the BVH in its L2
+    uint32_t vblk = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) vblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint64_t wave = ((uint64_t)vblk * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (wave >= (uint64_t)vwords * n_views) return;
     const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
@@ -530,7 +534,8 @@ void build_bvh(mvs_ctx* ctx) {
 void trace_rays(mvs_ctx* ctx) {
     const uint32_t vwords = (ctx->n_verts + 63) / 64;
     const uint64_t waves = (uint64_t)vwords * ctx->n_views;
-    const uint64_t blocks = (waves + 3) / 4;
+    uint64_t blocks = (waves + 3) / 4;
+    if (ctx->ray_mode == 2) blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
     if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
 #define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
                  vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
