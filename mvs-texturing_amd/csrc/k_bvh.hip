@@ -258,7 +258,9 @@ __global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float*
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= (uint64_t)vwords * n_views) return;
-    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
+    // patch-major order: consecutive waves = the same 64-vertex patch seen from consecutive cameras, so the BVH
+    // neighbourhood of the patch (where its rays spend their time) stays in L2 across the views
+    const uint32_t vw = (uint32_t)(wave / n_views), j = (uint32_t)(wave % n_views);
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t sp = vw * 64 + lane;
@@ -308,7 +310,9 @@ __global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= (uint64_t)vwords * n_views) return;
-    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
+    // patch-major order: consecutive waves = the same 64-vertex patch seen from consecutive cameras, so the BVH
+    // neighbourhood of the patch (where its rays spend their time) stays in L2 across the views
+    const uint32_t vw = (uint32_t)(wave / n_views), j = (uint32_t)(wave % n_views);
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t s = vw * 64 + lane;
@@ -377,7 +381,9 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     const uint64_t wave = ((uint64_t)vblk * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (wave >= (uint64_t)vwords * n_views) return;
-    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
+    // patch-major order: consecutive waves = the same 64-vertex patch seen from consecutive cameras, so the BVH
+    // neighbourhood of the patch (where its rays spend their time) stays in L2 across the views
+    const uint32_t vw = (uint32_t)(wave / n_views), j = (uint32_t)(wave % n_views);
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t s = vw * 64 + lane;
