@@ -128,7 +128,7 @@ def main():
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_option("profile", 1)
-    for env, opt in (("MVS_MRF_SHAPE", "mrf_shape"), ("MVS_MRF_UNROLL", "mrf_unroll"), ("MVS_MRF_NT", "mrf_nt"), ("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd")):
+    for env, opt in (("MVS_MRF_SHAPE", "mrf_shape"), ("MVS_MRF_UNROLL", "mrf_unroll"), ("MVS_MRF_NT", "mrf_nt"), ("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd")):
         if os.environ.get(env):   # tuning knobs for experiments
             ctx.set_option(opt, int(os.environ[env]))
     if os.environ.get("MVS_RAY_MODE"):

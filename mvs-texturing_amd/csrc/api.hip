@@ -135,6 +135,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "verbose") ctx->verbose = value != 0;
     else if (n == "profile") ctx->profile = value != 0;
     else if (n == "ray_mode") ctx->ray_mode = (int)value;
+    else if (n == "ray_xcd") ctx->ray_xcd = (int)value;
     else if (n == "mrf_shape") ctx->mrf_shape = (int)value;
     else if (n == "mrf_unroll") ctx->mrf_unroll = (int)value;
     else if (n == "mrf_nt") ctx->mrf_nt = (int)value;

@@ -258,9 +258,7 @@ __global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float*
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= (uint64_t)vwords * n_views) return;
-    // patch-major order: consecutive waves = the same 64-vertex patch seen from consecutive cameras, so the BVH
-    // neighbourhood of the patch (where its rays spend their time) stays in L2 across the views
-    const uint32_t vw = (uint32_t)(wave / n_views), j = (uint32_t)(wave % n_views);
+    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);   // view-major: needed patches form long runs (measured: patch-major is 40 % slower)
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t sp = vw * 64 + lane;
@@ -310,9 +308,7 @@ __global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= (uint64_t)vwords * n_views) return;
-    // patch-major order: consecutive waves = the same 64-vertex patch seen from consecutive cameras, so the BVH
-    // neighbourhood of the patch (where its rays spend their time) stays in L2 across the views
-    const uint32_t vw = (uint32_t)(wave / n_views), j = (uint32_t)(wave % n_views);
+    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);   // view-major: needed patches form long runs (measured: patch-major is 40 % slower)
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t s = vw * 64 + lane;
@@ -367,7 +363,7 @@ __global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const
 // (5-6 of 64 on average), so instead of 64 lanes x 4 triangles the wave tests (candidate, triangle)
 // PAIRS: lane L takes candidate L/4 and triangle L%4 (16 candidates per round).  Rays are parked in
 // LDS once; the candidate list goes through LDS; results return to the owning lanes through a ballot.
-template <bool COUNT>
+template <bool COUNT, bool XCD>
 __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
                                                           const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
                                                           unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
@@ -377,13 +373,11 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     // XCD-aware order: hardware block b runs on XCD b % 8 (observed; speed only), so each XCD gets a contiguous
     // eighth of the (view, vertex patch) sequence and with it a compact part of the BVH in its L2
     uint32_t vblk = blockIdx.x;
-    if ((gridDim.x & 7u) == 0u) vblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (XCD && (gridDim.x & 7u) == 0u) vblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const uint64_t wave = ((uint64_t)vblk * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (wave >= (uint64_t)vwords * n_views) return;
-    // patch-major order: consecutive waves = the same 64-vertex patch seen from consecutive cameras, so the BVH
-    // neighbourhood of the patch (where its rays spend their time) stays in L2 across the views
-    const uint32_t vw = (uint32_t)(wave / n_views), j = (uint32_t)(wave % n_views);
+    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);   // view-major: needed patches form long runs (measured: patch-major is 40 % slower)
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t s = vw * 64 + lane;
@@ -546,7 +540,9 @@ void trace_rays(mvs_ctx* ctx) {
 #define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
                  vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
     if (ctx->ray_mode == 2) {
-        if (ctx->count_rays) hipLaunchKernelGGL(ray_packet2_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_packet2_kernel<false>, RAY_ARGS);
+        if (ctx->count_rays) hipLaunchKernelGGL((ray_packet2_kernel<true, false>), RAY_ARGS);
+        else if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet2_kernel<false, true>), RAY_ARGS);
+        else hipLaunchKernelGGL((ray_packet2_kernel<false, false>), RAY_ARGS);
     } else if (ctx->ray_mode == 1) {
         if (ctx->count_rays) hipLaunchKernelGGL(ray_packet_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_packet_kernel<false>, RAY_ARGS);
     } else {
