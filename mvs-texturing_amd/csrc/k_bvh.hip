@@ -184,24 +184,27 @@ __global__ void vf_fill_kernel(const uint32_t* __restrict__ faces, uint32_t n_fa
 }
 
 // ---- traversal ----
+// Slab test of one child box.  Box culling only has to be CONSERVATIVE (boxes carry 4*pad of slack and the
+// interval is widened), not bit-reproducible, so it may use FMA: t = bound * inv - o * inv.
+__device__ __forceinline__ bool box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 oi, float t0, float t1) {
+    const float ax = __builtin_fmaf(lox, inv.x, -oi.x), bx = __builtin_fmaf(hix, inv.x, -oi.x);
+    const float ay = __builtin_fmaf(loy, inv.y, -oi.y), by = __builtin_fmaf(hiy, inv.y, -oi.y);
+    const float az = __builtin_fmaf(loz, inv.z, -oi.z), bz = __builtin_fmaf(hiz, inv.z, -oi.z);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t0));   // fmin/fmax drop NaN (0 * inf)
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t1));
+    return tn <= tf;
+}
 __device__ __forceinline__ uint32_t node_hits(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1) {
     // 6 x 16-byte loads of one 128-byte line
     const float4* p = reinterpret_cast<const float4*>(nd);
     const float4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5];
     const uint32_t nchild = nd->nchild;
-    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
-    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+    const V3 oi = {o.x * inv.x, o.y * inv.y, o.z * inv.z};
     uint32_t m = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float ta = (lox[c] - o.x) * inv.x, tb = (hix[c] - o.x) * inv.x;
-        float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-        ta = (loy[c] - o.y) * inv.y; tb = (hiy[c] - o.y) * inv.y;
-        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-        ta = (loz[c] - o.z) * inv.z; tb = (hiz[c] - o.z) * inv.z;
-        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-        if (tn <= tf) m |= 1u << c;
-    }
+    if (box_hit(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, inv, oi, t0, t1)) m |= 1u;
+    if (box_hit(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, inv, oi, t0, t1)) m |= 2u;
+    if (box_hit(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, inv, oi, t0, t1)) m |= 4u;
+    if (box_hit(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, inv, oi, t0, t1)) m |= 8u;
     return m & ((1u << nchild) - 1u);
 }
 
@@ -287,15 +290,11 @@ __global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float*
 __device__ __forceinline__ uint32_t node_hits_uniform(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1, bool active) {
     uint32_t m = 0;
     const uint32_t nchild = nd->nchild;
+    const V3 oi = {o.x * inv.x, o.y * inv.y, o.z * inv.z};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float ta = (nd->lo[0][c] - o.x) * inv.x, tb = (nd->hi[0][c] - o.x) * inv.x;
-        float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-        ta = (nd->lo[1][c] - o.y) * inv.y; tb = (nd->hi[1][c] - o.y) * inv.y;
-        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-        ta = (nd->lo[2][c] - o.z) * inv.z; tb = (nd->hi[2][c] - o.z) * inv.z;
-        tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-        if (__ballot(active && tn <= tf) != 0ull) m |= 1u << c;
+        const bool h = box_hit(nd->lo[0][c], nd->lo[1][c], nd->lo[2][c], nd->hi[0][c], nd->hi[1][c], nd->hi[2][c], inv, oi, t0, t1);
+        if (__ballot(active && h) != 0ull) m |= 1u << c;
     }
     return m & ((1u << nchild) - 1u);
 }
@@ -397,18 +396,13 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     int level = bvh.top;
     uint32_t node = 0, lm0 = 0;   // lm0: this lane's own hit bits for the children (leaves) of the current level-0 node
     // per-lane + wave-level child masks of one node
+    const V3 oi = {r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z};
     auto visit = [&](const Node4* __restrict__ nd, uint32_t& lane_mask) -> uint32_t {
         uint32_t m = 0, lm = 0;
         const uint32_t nchild = nd->nchild;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float ta = (nd->lo[0][c] - r.o.x) * inv.x, tb = (nd->hi[0][c] - r.o.x) * inv.x;
-            float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-            ta = (nd->lo[1][c] - r.o.y) * inv.y; tb = (nd->hi[1][c] - r.o.y) * inv.y;
-            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            ta = (nd->lo[2][c] - r.o.z) * inv.z; tb = (nd->hi[2][c] - r.o.z) * inv.z;
-            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            const bool h = active && tn <= tf;
+            const bool h = active && box_hit(nd->lo[0][c], nd->lo[1][c], nd->lo[2][c], nd->hi[0][c], nd->hi[1][c], nd->hi[2][c], inv, oi, t0, t1);
             if (h) lm |= 1u << c;
             if (__ballot(h) != 0ull) m |= 1u << c;
         }
