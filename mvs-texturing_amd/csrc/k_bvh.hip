@@ -184,12 +184,12 @@ __global__ void vf_fill_kernel(const uint32_t* __restrict__ faces, uint32_t n_fa
 }
 
 // ---- traversal ----
-// Slab test of one child box.  Box culling only has to be CONSERVATIVE (boxes carry 4*pad of slack and the
-// interval is widened), not bit-reproducible, so it may use FMA: t = bound * inv - o * inv.
-__device__ __forceinline__ bool box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 oi, float t0, float t1) {
-    const float ax = __builtin_fmaf(lox, inv.x, -oi.x), bx = __builtin_fmaf(hix, inv.x, -oi.x);
-    const float ay = __builtin_fmaf(loy, inv.y, -oi.y), by = __builtin_fmaf(hiy, inv.y, -oi.y);
-    const float az = __builtin_fmaf(loz, inv.z, -oi.z), bz = __builtin_fmaf(hiz, inv.z, -oi.z);
+// Slab test of one child box: t = (bound - o) * inv per axis (subtract first: bound * inv - o * inv would cancel
+// catastrophically for the nearby boxes that matter), interval [t0, t1] already widened by the caller.
+__device__ __forceinline__ bool box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 o, float t0, float t1) {
+    const float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    const float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    const float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t0));   // fmin/fmax drop NaN (0 * inf)
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t1));
     return tn <= tf;
@@ -199,7 +199,7 @@ __device__ __forceinline__ uint32_t node_hits(const Node4* __restrict__ nd, V3 o
     const float4* p = reinterpret_cast<const float4*>(nd);
     const float4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5];
     const uint32_t nchild = nd->nchild;
-    const V3 oi = {o.x * inv.x, o.y * inv.y, o.z * inv.z};
+    const V3 oi = o;
     uint32_t m = 0;
     if (box_hit(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, inv, oi, t0, t1)) m |= 1u;
     if (box_hit(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, inv, oi, t0, t1)) m |= 2u;
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float*
 __device__ __forceinline__ uint32_t node_hits_uniform(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1, bool active) {
     uint32_t m = 0;
     const uint32_t nchild = nd->nchild;
-    const V3 oi = {o.x * inv.x, o.y * inv.y, o.z * inv.z};
+    const V3 oi = o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const bool h = box_hit(nd->lo[0][c], nd->lo[1][c], nd->lo[2][c], nd->hi[0][c], nd->hi[1][c], nd->hi[2][c], inv, oi, t0, t1);
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     int level = bvh.top;
     uint32_t node = 0, lm0 = 0;   // lm0: this lane's own hit bits for the children (leaves) of the current level-0 node
     // per-lane + wave-level child masks of one node
-    const V3 oi = {r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z};
+    const V3 oi = r.o;
     auto visit = [&](const Node4* __restrict__ nd, uint32_t& lane_mask) -> uint32_t {
         uint32_t m = 0, lm = 0;
         const uint32_t nchild = nd->nchild;
