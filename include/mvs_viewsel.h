@@ -148,6 +148,18 @@ mvs_status mvs_read_spt(const char* path, mvs_csr* out);
 mvs_status mvs_write_labeling_vec(const uint32_t* labels, uint32_t n_faces, const char* path);
 
 /* ------------------------------------------------------------------------
+ * SURVEY.md 8(f) row f1 -- the two stages immediately BEFORE the path (apps/texrecon/texrecon.cpp:78-92)
+ * ------------------------------------------------------------------------ */
+/* replaces tex::prepare_mesh (libs/tex/texturing.h:45-46, prepare_mesh.cpp:57-70): removes redundant faces
+ * (prepare_mesh.cpp:14-55) and computes face normals; faces_out / normals_out hold 3 * n_faces entries */
+mvs_status mvs_prepare_mesh(uint32_t n_verts, const float* verts, uint32_t n_faces, const uint32_t* faces,
+                            uint32_t* faces_out, float* normals_out, uint32_t* n_kept);
+/* replaces tex::build_adjacency_graph (texturing.h:58-60, build_adjacency_graph.cpp:16-53): UniGraph adjacency lists
+ * flattened in list order; adj_ptr_out[n_faces + 1] caller allocated, *adj_out malloc'ed by the library (free()) */
+mvs_status mvs_build_adjacency_graph(uint32_t n_verts, uint32_t n_faces, const uint32_t* faces,
+                                     uint32_t* adj_ptr_out, uint32_t** adj_out, uint64_t* n_entries);
+
+/* ------------------------------------------------------------------------
  * Resident (context) API: inputs live in HBM across calls; used by bench.py,
  * the GPU tests and the multi-GPU driver.  Pointers flagged *_on_device are
  * device pointers owned by the caller (e.g. torch tensors) and must stay
@@ -202,6 +214,9 @@ mvs_status mvs_ctx_costs_device(mvs_ctx* ctx, mvs_csr* device_view);
 mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* host_out, float** quality_out);
 /* replace the resident costs by caller-provided ones (host or device pointers) */
 mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device);
+
+/* tex::build_adjacency_graph on the resident mesh; the result stays on the device (pointers returned) */
+mvs_status mvs_ctx_build_adjacency(mvs_ctx* ctx, uint32_t** adj_ptr_device, uint32_t** adj_device, uint64_t* n_entries);
 
 /* tex::view_selection on the resident costs.  adjacency: host or device pointers.
  * labels_out (n_faces u32) may be a host or a device pointer (labels_on_device). */

@@ -148,6 +148,10 @@ struct mvs_ctx {
     bool have_costs = false;
     mvs_settings dc_settings{}; mvs_dc_stats dc_stats{}; int dc_phase = 0;
 
+    // ---- row f1: mesh preparation + adjacency graph (k_mesh.hip) ----
+    mvs::DBuf<unsigned long long> g_keys, g_keys2; mvs::DBuf<uint32_t> g_vals, g_vals2, g_pos, g_cnt, g_adj_ptr, g_adj, g_faces; mvs::DBuf<float> g_normals;
+    uint64_t g_adj_entries = 0; bool have_adj = false;
+
     // ---- MRF ----
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
     mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_shape = 0, mrf_unroll = 1, mrf_nt = 0, mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1;

@@ -460,6 +460,17 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
 
 }  // namespace
 
+// vertex -> incident faces (CSR vf_ptr / vf); order inside a vertex is arbitrary (atomic cursor): consumers only OR / search
+void build_vertex_faces(mvs_ctx* ctx, const uint32_t* d_faces, uint32_t F, uint32_t NV) {
+    hipStream_t s = ctx->stream;
+    ctx->vf_ptr.ensure((size_t)NV + 1); ctx->vf_cursor.ensure((size_t)NV + 1); ctx->vf.ensure(3 * (size_t)F + 1);
+    MVS_HIP(hipMemsetAsync(ctx->vf_cursor.p, 0, ((size_t)NV + 1) * sizeof(uint32_t), s));
+    if (F) { hipLaunchKernelGGL(vf_count_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, s, d_faces, F, ctx->vf_cursor.p); MVS_LAUNCH_CHECK(); }
+    exclusive_scan_u32(ctx, ctx->vf_cursor.p, ctx->vf_ptr.p, (size_t)NV + 1, nullptr);
+    MVS_HIP(hipMemsetAsync(ctx->vf_cursor.p, 0, ((size_t)NV + 1) * sizeof(uint32_t), s));
+    if (F) { hipLaunchKernelGGL(vf_fill_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, s, d_faces, F, ctx->vf_ptr.p, ctx->vf_cursor.p, ctx->vf.p); MVS_LAUNCH_CHECK(); }
+}
+
 // Builds the BVH and the vertex->face incidence for the resident mesh.
 void build_bvh(mvs_ctx* ctx) {
     const uint32_t F = ctx->n_faces, NV = ctx->n_verts;
@@ -514,15 +525,7 @@ void build_bvh(mvs_ctx* ctx) {
     MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->vperm.p, NV, 0, 30, s));
     hipLaunchKernelGGL(invert_perm_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->vperm.p, NV, ctx->vpos.p);
     MVS_LAUNCH_CHECK();
-    // vertex -> faces
-    ctx->vf_ptr.ensure((size_t)NV + 1); ctx->vf_cursor.ensure((size_t)NV + 1); ctx->vf.ensure(3 * (size_t)F);
-    MVS_HIP(hipMemsetAsync(ctx->vf_cursor.p, 0, ((size_t)NV + 1) * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(vf_count_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, s, ctx->d_faces, F, ctx->vf_cursor.p);
-    MVS_LAUNCH_CHECK();
-    exclusive_scan_u32(ctx, ctx->vf_cursor.p, ctx->vf_ptr.p, (size_t)NV + 1, nullptr);
-    MVS_HIP(hipMemsetAsync(ctx->vf_cursor.p, 0, ((size_t)NV + 1) * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(vf_fill_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, s, ctx->d_faces, F, ctx->vf_ptr.p, ctx->vf_cursor.p, ctx->vf.p);
-    MVS_LAUNCH_CHECK();
+    build_vertex_faces(ctx, ctx->d_faces, F, NV);
 }
 
 void trace_rays(mvs_ctx* ctx) {

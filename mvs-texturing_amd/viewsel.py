@@ -101,6 +101,9 @@ def load_library():
         "mvs_view_selection": [C.POINTER(CCsr), vp, vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
         "mvs_write_spt": [C.POINTER(CCsr), C.c_char_p], "mvs_read_spt": [C.c_char_p, C.POINTER(CCsr)],
         "mvs_write_labeling_vec": [vp, u32, C.c_char_p],
+        "mvs_prepare_mesh": [u32, vp, u32, vp, vp, vp, C.POINTER(u32)],
+        "mvs_build_adjacency_graph": [u32, u32, vp, vp, C.POINTER(vp), C.POINTER(u64)],
+        "mvs_ctx_build_adjacency": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
         "mvs_ctx_create": [i32, C.POINTER(vp)], "mvs_ctx_destroy": [vp], "mvs_ctx_set_stream": [vp, vp],
         "mvs_ctx_synchronize": [vp], "mvs_set_option": [vp, C.c_char_p, C.c_int64],
         "mvs_ctx_get_profile": [vp, C.c_char_p, C.c_size_t],
@@ -138,11 +141,25 @@ def _is_torch(a):
     return type(a).__module__.startswith("torch")
 
 
+class DevArray:
+    """A raw device array owned by the library (pointer + length), accepted wherever a CUDA tensor is."""
+    is_cuda = True
+
+    def __init__(self, ptr, n):
+        self.ptr, self.shape = int(ptr or 0), (int(n),)
+
+    def data_ptr(self):
+        return self.ptr
+
+    def is_contiguous(self):
+        return True
+
+
 def _ptr(a):
     """(pointer, on_device) of a numpy array or torch tensor."""
     if a is None:
         return None, 0
-    if _is_torch(a):
+    if _is_torch(a) or isinstance(a, DevArray):
         assert a.is_contiguous()
         return C.c_void_p(a.data_ptr()), 1 if a.is_cuda else 0
     assert a.flags["C_CONTIGUOUS"]
@@ -256,6 +273,12 @@ class Context:
     def set_face_range(self, begin, end):
         _check(self.L, self.L.mvs_scene_set_face_range(self.h, begin, end))
 
+    def build_adjacency(self):
+        """tex::build_adjacency_graph on the resident mesh; returns device-resident (adj_ptr, adj) usable by view_selection"""
+        pp, pa, n = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        _check(self.L, self.L.mvs_ctx_build_adjacency(self.h, C.byref(pp), C.byref(pa), C.byref(n)))
+        return DevArray(pp.value, self.n_faces + 1), DevArray(pa.value, n.value)
+
     def data_costs(self, settings=None):
         st = settings or Settings()
         ds = DcStats()
@@ -319,3 +342,25 @@ def view_selection(data_costs, adj_ptr, adj, params=None, ctx=None):
     finally:
         if own:
             ctx.close()
+
+
+def prepare_mesh(verts, faces):
+    """tex::prepare_mesh(mesh_info, mesh) (libs/tex/prepare_mesh.cpp:57-70): (faces without redundant ones, face normals)"""
+    L = load_library()
+    verts = np.ascontiguousarray(verts, dtype=np.float32); faces = np.ascontiguousarray(faces, dtype=np.uint32)
+    F = faces.shape[0]
+    fo = np.zeros((max(F, 1), 3), np.uint32); no = np.zeros((max(F, 1), 3), np.float32); kept = C.c_uint32(0)
+    _check(L, L.mvs_prepare_mesh(verts.shape[0], verts.ctypes.data, F, faces.ctypes.data, fo.ctypes.data, no.ctypes.data, C.byref(kept)))
+    return fo[:kept.value].copy(), no[:kept.value].copy()
+
+
+def build_adjacency_graph(n_verts, faces):
+    """tex::build_adjacency_graph(mesh, mesh_info, &graph) (libs/tex/build_adjacency_graph.cpp:16-53): (adj_ptr, adj)"""
+    L = load_library()
+    faces = np.ascontiguousarray(faces, dtype=np.uint32)
+    F = faces.shape[0]
+    adj_ptr = np.zeros(F + 1, np.uint32); pa = C.c_void_p(); n = C.c_uint64(0)
+    _check(L, L.mvs_build_adjacency_graph(int(n_verts), F, faces.ctypes.data, adj_ptr.ctypes.data, C.byref(pa), C.byref(n)))
+    adj = np.ctypeslib.as_array(C.cast(pa, C.POINTER(C.c_uint32)), (max(n.value, 1),))[:n.value].copy()
+    C.CDLL(None).free(pa)
+    return adj_ptr, adj

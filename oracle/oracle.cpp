@@ -1059,3 +1059,83 @@ int orc_icm_baseline(const orc_csr* costs, const uint32_t* adj_ptr, const uint32
 }
 
 }  // extern "C"
+
+// ===========================================================================
+// Row f1: the two stages immediately BEFORE the path.
+// ===========================================================================
+extern "C" {
+
+// tex::build_adjacency_graph (build_adjacency_graph.cpp:16-53) + UniGraph::add_edge (uni_graph.h:86-93).
+// MeshInfo::get_faces_for_edge (MVE, absent) returns the faces containing both vertices; for a manifold edge
+// that is {self, other}.  For an edge shared by more than two faces its order depends on MeshInfo internals:
+// DEFINED HERE as ascending face id.  Output: adjacency lists flattened in list order (malloc'ed).
+int orc_build_adjacency(uint32_t n_faces, const uint32_t* faces, uint32_t** adj_ptr_out, uint32_t** adj_out) {
+    struct EdgeRec { uint64_t key; uint32_t face; };
+    std::vector<EdgeRec> recs; recs.reserve((size_t)n_faces * 3);
+    auto ekey = [](uint32_t a, uint32_t b) { return (uint64_t)std::min(a, b) << 32 | std::max(a, b); };
+    for (uint32_t f = 0; f < n_faces; ++f)
+        for (int k = 0; k < 3; ++k) recs.push_back({ekey(faces[3 * (size_t)f + k], faces[3 * (size_t)f + (k + 1) % 3]), f});
+    std::vector<EdgeRec> sorted(recs);
+    std::stable_sort(sorted.begin(), sorted.end(), [](const EdgeRec& a, const EdgeRec& b) { return a.key < b.key; });
+    auto faces_for_edge = [&](uint64_t key, std::vector<uint32_t>* out) {
+        auto lo = std::lower_bound(sorted.begin(), sorted.end(), key, [](const EdgeRec& r, uint64_t k) { return r.key < k; });
+        for (; lo != sorted.end() && lo->key == key; ++lo) out->push_back(lo->face);
+    };
+    std::vector<std::vector<uint32_t>> lists(n_faces);
+    for (uint32_t f = 0; f < n_faces; ++f) {
+        std::vector<uint32_t> adj_faces;                                   /* build_adjacency_graph.cpp:31-34 */
+        for (int k = 0; k < 3; ++k) faces_for_edge(recs[3 * (size_t)f + k].key, &adj_faces);
+        for (uint32_t g : adj_faces) {
+            if (g == f) continue;                                          /* :41 avoid self referencing */
+            auto& lf = lists[f];
+            if (std::find(lf.begin(), lf.end(), g) != lf.end()) continue;  /* :43 has_edge */
+            lf.push_back(g); lists[g].push_back(f);                        /* uni_graph.h:89-90 */
+        }
+    }
+    uint32_t* ptr = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n_faces + 1));
+    uint64_t total = 0;
+    for (uint32_t f = 0; f < n_faces; ++f) { ptr[f] = (uint32_t)total; total += lists[f].size(); }
+    ptr[n_faces] = (uint32_t)total;
+    uint32_t* adj = (uint32_t*)malloc(sizeof(uint32_t) * std::max<uint64_t>(total, 1));
+    for (uint32_t f = 0; f < n_faces; ++f) std::copy(lists[f].begin(), lists[f].end(), adj + ptr[f]);
+    *adj_ptr_out = ptr; *adj_out = adj;
+    return 0;
+}
+
+// tex::prepare_mesh (prepare_mesh.cpp:14-70): remove_redundant_faces + ensure_normals.
+// A face is redundant iff some face with a LARGER id that touches one of its vertices consists only of vertices
+// of this face (:27-44).  Face normals (MVE TriangleMesh::recalc_normals, absent -- DEFINED HERE): normalised
+// (b - a) x (c - a), the zero vector when its length is 0.  Returns the number of kept faces.
+uint32_t orc_prepare_mesh(uint32_t n_verts, const float* verts, uint32_t n_faces, const uint32_t* faces,
+                          uint32_t* faces_out, float* normals_out) {
+    std::vector<std::vector<uint32_t>> vfaces(n_verts);
+    for (uint32_t f = 0; f < n_faces; ++f) for (int k = 0; k < 3; ++k) vfaces[faces[3 * (size_t)f + k]].push_back(f);
+    uint32_t kept = 0;
+    for (uint32_t f = 0; f < n_faces; ++f) {
+        const uint32_t* fv = faces + 3 * (size_t)f;
+        bool redundant = false;
+        for (int j = 0; !redundant && j < 3; ++j)
+            for (uint32_t g : vfaces[fv[j]]) {
+                if (redundant) break;
+                if (f < g) {
+                    bool identical = true;
+                    for (int l = 0; l < 3; ++l) {
+                        const uint32_t v = faces[3 * (size_t)g + l];
+                        if (std::find(fv, fv + 3, v) == fv + 3) { identical = false; break; }
+                    }
+                    redundant = identical;
+                }
+            }
+        if (redundant) continue;
+        for (int k = 0; k < 3; ++k) faces_out[3 * (size_t)kept + k] = fv[k];
+        const V3 a = load3(verts + 3 * (size_t)fv[0]), b = load3(verts + 3 * (size_t)fv[1]), c = load3(verts + 3 * (size_t)fv[2]);
+        V3 n = cross(b - a, c - a);
+        const float len = norm(n);
+        if (len != 0.0f) n = n / len;
+        normals_out[3 * (size_t)kept] = n.x; normals_out[3 * (size_t)kept + 1] = n.y; normals_out[3 * (size_t)kept + 2] = n.z;
+        ++kept;
+    }
+    return kept;
+}
+
+}  // extern "C"

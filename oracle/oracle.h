@@ -137,6 +137,13 @@ uint64_t orc_energy(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_
 int orc_icm_baseline(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
                      int max_iters, uint32_t* labels);
 
+/* ---- row f1: the stages immediately before the path ---- */
+/* tex::build_adjacency_graph (build_adjacency_graph.cpp:16-53); outputs malloc'ed */
+int orc_build_adjacency(uint32_t n_faces, const uint32_t* faces, uint32_t** adj_ptr_out, uint32_t** adj_out);
+/* tex::prepare_mesh (prepare_mesh.cpp:14-70); faces_out[3*n_faces], normals_out[3*n_faces]; returns kept faces */
+uint32_t orc_prepare_mesh(uint32_t n_verts, const float* verts, uint32_t n_faces, const uint32_t* faces,
+                          uint32_t* faces_out, float* normals_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ def load(timing=False):
         L.orc_bvh_build.restype = C.c_void_p
         L.orc_bvh_free.argtypes = [C.c_void_p]
         L.orc_ray_occluded.argtypes = [C.c_void_p, C.POINTER(Mesh), C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_build_adjacency.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32))]
+        L.orc_prepare_mesh.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_prepare_mesh.restype = C.c_uint32
         _libs[name] = L
     return _libs[name]
 
@@ -197,3 +200,27 @@ def icm_baseline(csr, adj_ptr, adj, max_iters=200):
     L.orc_icm_baseline(C.byref(cs), _ptr(np.ascontiguousarray(adj_ptr, dtype=np.uint32)),
                        _ptr(np.ascontiguousarray(adj, dtype=np.uint32)), max_iters, _ptr(labels))
     return labels
+
+
+def build_adjacency(faces):
+    """tex::build_adjacency_graph: (adj_ptr, adj) in UniGraph list order"""
+    L = load()
+    faces = np.ascontiguousarray(faces, dtype=np.uint32)
+    F = faces.shape[0]
+    pp, pa = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+    L.orc_build_adjacency(F, _ptr(faces), C.byref(pp), C.byref(pa))
+    adj_ptr = np.ctypeslib.as_array(pp, (F + 1,)).copy()
+    n = int(adj_ptr[-1])
+    adj = np.ctypeslib.as_array(pa, (max(n, 1),))[:n].copy()
+    libc = C.CDLL(None); libc.free(pp); libc.free(pa)
+    return adj_ptr, adj
+
+
+def prepare_mesh(verts, faces):
+    """tex::prepare_mesh: (faces_without_redundant, face_normals)"""
+    L = load()
+    verts = np.ascontiguousarray(verts, dtype=np.float32); faces = np.ascontiguousarray(faces, dtype=np.uint32)
+    F = faces.shape[0]
+    fo = np.zeros((F, 3), np.uint32); no = np.zeros((F, 3), np.float32)
+    kept = L.orc_prepare_mesh(verts.shape[0], _ptr(verts), F, _ptr(faces), _ptr(fo), _ptr(no))
+    return fo[:kept].copy(), no[:kept].copy()

@@ -509,3 +509,28 @@ def test_empty_and_trivial_inputs():
     lg, sg = c.view_selection(iso_ptr, iso)
     assert np.array_equal(lo, lg) and sg["cut_edges"] == 0
     c.close()
+
+
+def test_row_f1_prepare_mesh_and_adjacency_graph():
+    """SURVEY.md 8(f) row f1: tex::prepare_mesh and tex::build_adjacency_graph on the GPU == the oracle restatements
+    (integer outputs bit-exact, normals bit-exact), including duplicates, open boundaries, a non-manifold fan and
+    degenerate faces; and the device-resident adjacency feeds view selection directly"""
+    from test_oracle import _f1_meshes
+    for name, (verts, faces) in _f1_meshes().items():
+        ap_o, ad_o = O.build_adjacency(faces)
+        ap_g, ad_g = M.build_adjacency_graph(len(verts), faces)
+        assert np.array_equal(ap_o, ap_g) and np.array_equal(ad_o, ad_g), name
+        f_o, n_o = O.prepare_mesh(verts, faces)
+        f_g, n_g = M.prepare_mesh(verts, faces)
+        assert np.array_equal(f_o, f_g) and np.array_equal(n_o.view(np.uint32), n_g.view(np.uint32)), name
+    s = get_scene("bumpy")
+    ap_g, ad_g = M.build_adjacency_graph(len(s.verts), s.faces)
+    assert np.array_equal(ap_g, s.adj_ptr) and np.array_equal(ad_g, s.adj)
+    c = M.Context(0)
+    _load_scene(c, s)
+    c.data_costs(M.Settings())
+    dev_ptr, dev_adj = c.build_adjacency()
+    l1, s1 = c.view_selection(dev_ptr, dev_adj)
+    l2, s2 = c.view_selection(s.adj_ptr, s.adj)
+    assert np.array_equal(l1, l2) and s1["energy_fixed"] == s2["energy_fixed"]
+    c.close()

@@ -196,3 +196,57 @@ def test_guards():
     out = O.Csr(); stats = O.DcStats()
     rc = L.orc_data_costs(C.byref(m), views, 70000, C.byref(st), 0, 0, 0, 1, C.byref(out), C.byref(stats))
     assert rc == 2
+
+
+def _f1_meshes():
+    """meshes for the row-f1 stages: manifold, open boundary, duplicated faces, a non-manifold fan, degenerate faces"""
+    s = get_scene("tiny")
+    out = {"manifold": (s.verts, s.faces)}
+    out["open"] = (s.verts, s.faces[: len(s.faces) // 2].copy())
+    dup = np.concatenate([s.faces, s.faces[5:9], s.faces[40:41][:, [1, 2, 0]], s.faces[41:42][:, [0, 2, 1]]])
+    out["duplicates"] = (s.verts, np.ascontiguousarray(dup))
+    nv = len(s.verts)
+    extra_v = np.array([[0.0, 0.0, 2.0], [0.0, 0.3, 2.2], [0.2, -0.2, 2.1]], dtype=np.float32)
+    a, b = s.faces[0][0], s.faces[0][1]
+    fan = np.array([[a, b, nv], [b, a, nv + 1], [a, b, nv + 2]], dtype=np.uint32)          # 5 faces on the edge (a, b)
+    out["fan"] = (np.ascontiguousarray(np.concatenate([s.verts, extra_v])), np.ascontiguousarray(np.concatenate([s.faces, fan])))
+    deg = np.array([[a, a, b], [a, b, a], [nv - 1, nv - 1, nv - 1]], dtype=np.uint32)
+    out["degenerate"] = (s.verts, np.ascontiguousarray(np.concatenate([s.faces, deg])))
+    return out
+
+
+def test_adjacency_restatement_properties():
+    """build_adjacency_graph.cpp:16-53 + UniGraph::add_edge: symmetric, no self loops, list order = smaller ids ascending then edge order"""
+    for name, (verts, faces) in _f1_meshes().items():
+        adj_ptr, adj = O.build_adjacency(faces)
+        F = len(faces)
+        pairs = set()
+        for i in range(F):
+            nb = adj[adj_ptr[i]:adj_ptr[i + 1]].tolist()
+            assert len(set(nb)) == len(nb) and i not in nb, name
+            small = [g for g in nb if g < i]
+            assert small == sorted(small) and nb[:len(small)] == small, name
+            for g in nb:
+                pairs.add((i, g))
+                assert len(set(faces[i].tolist()) & set(faces[g].tolist())) >= 2 or name == "degenerate", name
+        assert all((g, i) in pairs for i, g in pairs), name
+    s = get_scene("tiny")
+    ap, ad = O.build_adjacency(s.faces)
+    assert np.array_equal(ap, s.adj_ptr) and np.array_equal(ad, s.adj)      # the scene generator restates the same semantics independently
+
+
+def test_prepare_mesh_restatement():
+    """prepare_mesh.cpp:14-70: the LAST copy of a duplicated face survives, order is kept, normals = normalised (b-a)x(c-a)"""
+    m = _f1_meshes()
+    verts, faces = m["duplicates"]
+    f2, n2 = O.prepare_mesh(verts, faces)
+    F0 = len(get_scene("tiny").faces)
+    assert len(f2) == F0                                                     # 6 duplicates removed, the later copies kept
+    keep = [i for i in range(len(faces)) if not any(set(faces[i].tolist()) == set(faces[g].tolist()) for g in range(i + 1, len(faces)))]
+    assert np.array_equal(f2, faces[keep])
+    a, b, c = verts[f2[:, 0]], verts[f2[:, 1]], verts[f2[:, 2]]
+    ref = np.cross(b - a, c - a); ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+    assert np.allclose(n2, ref, atol=2e-6)
+    verts, faces = m["degenerate"]
+    f3, n3 = O.prepare_mesh(verts, faces)
+    assert (n3[-1] == 0).all()                                               # zero-area face: zero normal, no NaN
