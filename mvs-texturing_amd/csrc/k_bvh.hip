@@ -187,11 +187,12 @@ __global__ void vf_fill_kernel(const uint32_t* __restrict__ faces, uint32_t n_fa
 // Slab test of one child box: t = (bound - o) * inv per axis (subtract first: bound * inv - o * inv would cancel
 // catastrophically for the nearby boxes that matter), interval [t0, t1] already widened by the caller.
 __device__ __forceinline__ bool box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 o, float t0, float t1) {
-    const float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
-    const float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
-    const float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t0));   // fmin/fmax drop NaN (0 * inf)
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t1));
+    float ta = (lox - o.x) * inv.x, tb = (hix - o.x) * inv.x;
+    float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));   // fmin/fmax drop NaN (0 * inf)
+    ta = (loy - o.y) * inv.y; tb = (hiy - o.y) * inv.y;
+    tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+    ta = (loz - o.z) * inv.z; tb = (hiz - o.z) * inv.z;
+    tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
     return tn <= tf;
 }
 __device__ __forceinline__ uint32_t node_hits(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1) {
