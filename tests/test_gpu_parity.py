@@ -534,3 +534,33 @@ def test_row_f1_prepare_mesh_and_adjacency_graph():
     l2, s2 = c.view_selection(s.adj_ptr, s.adj)
     assert np.array_equal(l1, l2) and s1["energy_fixed"] == s2["energy_fixed"]
     c.close()
+
+
+def test_bench_contract_single_and_two_ranks(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys; the N > 1 code path (torch.distributed.run, one process
+    per rank) runs end to end -- here with 2 ranks sharing cuda:0 over gloo, the collectives' call pattern is the RCCL one"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d1 = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d1, k
+    assert d1["n_gpus"] == 1 and d1["steps"] == 2 and d1["config"]["faces"] == 200000 and d1["roofline"]["bound"] == "hbm"
+    env["MVS_BENCH_ONE_GPU"] = "1"
+    port = 29600 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "1", "--warmup", "1",
+                        "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["nnz"] == d1["config"]["nnz"]
+    assert d2["config"]["sweeps"] == d1["config"]["sweeps"] and abs(d2["config"]["energy"] - d1["config"]["energy"]) < 1e-6   # partition invariance
