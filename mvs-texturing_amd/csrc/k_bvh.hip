@@ -397,13 +397,18 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     int level = bvh.top;
     uint32_t node = 0, lm0 = 0;   // lm0: this lane's own hit bits for the children (leaves) of the current level-0 node
     // per-lane + wave-level child masks of one node
-    const V3 oi = r.o;
     auto visit = [&](const Node4* __restrict__ nd, uint32_t& lane_mask) -> uint32_t {
         uint32_t m = 0, lm = 0;
         const uint32_t nchild = nd->nchild;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const bool h = active && box_hit(nd->lo[0][c], nd->lo[1][c], nd->lo[2][c], nd->hi[0][c], nd->hi[1][c], nd->hi[2][c], inv, oi, t0, t1);
+            float ta = (nd->lo[0][c] - r.o.x) * inv.x, tb = (nd->hi[0][c] - r.o.x) * inv.x;
+            float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
+            ta = (nd->lo[1][c] - r.o.y) * inv.y; tb = (nd->hi[1][c] - r.o.y) * inv.y;
+            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+            ta = (nd->lo[2][c] - r.o.z) * inv.z; tb = (nd->hi[2][c] - r.o.z) * inv.z;
+            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+            const bool h = active && tn <= tf;
             if (h) lm |= 1u << c;
             if (__ballot(h) != 0ull) m |= 1u << c;
         }
