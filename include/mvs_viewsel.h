@@ -229,6 +229,16 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
  * driver all-gathers into the global table */
 mvs_status mvs_ctx_costs_export(mvs_ctx* ctx, uint32_t* counts_device, uint16_t* view_id_device, float* cost_device);
 
+/* solver progress as tracked on the device (mvs_ctx_mrf_step) */
+typedef struct mvs_mrf_progress {
+    uint32_t sweep;        /* sweeps accounted so far (stops counting once `stopped`) */
+    uint32_t stopped;      /* the stop rule has fired (or max_sweeps reached) */
+    uint32_t improved;     /* the last accounted sweep lowered the best energy */
+    uint32_t stop_sweep;   /* sweep at which the rule fired = mvs_mrf_stats.sweeps */
+    uint64_t energy;       /* 32.32 fixed point energy of the last accounted sweep */
+    uint64_t best;         /* best energy so far */
+} mvs_mrf_progress;
+
 /* ---- multi-GPU MRF building blocks (one context per rank; DESIGN.md "Multi-GPU") ----
  * Every rank holds the FULL cost table and adjacency (288 GB of HBM make the
  * metadata cheap to replicate) and owns a contiguous node range.  The sweep is
@@ -255,6 +265,16 @@ mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx_devi
 mvs_status mvs_ctx_mrf_energy(mvs_ctx* ctx, int which_sel, uint32_t node_begin, uint32_t node_end, uint64_t* dst_device);
 /* best labeling := current decode (call on every rank when the all-reduced energy improved) */
 mvs_status mvs_ctx_mrf_keep_best(mvs_ctx* ctx);
+/* Device-side bookkeeping of one sweep, so that the host never has to wait for a sweep's energy before it
+ * enqueues the next one: given the (all-reduced) energy pair in energy_device (NULL = the context's own energy of
+ * the last mvs_ctx_mrf_energy), a one-thread kernel advances the sweep counter, tracks the best energy, applies
+ * the stop rule (StopWhenReturnsDiminish-style, view_selection.cpp:84) and, if the energy improved, a second kernel
+ * copies the current decode into the best labeling.  Once the rule has fired every later step is a no-op, so the
+ * host may run `lag` sweeps ahead and poll old reports.  The report of step n (1-based count of mvs_ctx_mrf_step
+ * calls since mvs_ctx_mrf_setup) travels through a pinned ring of 16 slots. */
+mvs_status mvs_ctx_mrf_step(mvs_ctx* ctx, const uint64_t* energy_device);
+/* wait for the report of step `step` (must be within the last 16 issued) */
+mvs_status mvs_ctx_mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 /* ICM on the best labeling: gains of own nodes; then (after the GAIN halo exchange) apply in place */
 mvs_status mvs_ctx_mrf_icm_gain(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
 mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* moved_device);

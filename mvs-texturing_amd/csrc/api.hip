@@ -17,6 +17,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0);
 void mrf_keep_best(mvs_ctx* ctx);
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
+void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
@@ -104,6 +106,7 @@ void mvs_ctx_destroy(mvs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto* b : ctx->own_rgb) delete b;
+    if (ctx->h_ring) { (void)hipHostFree(ctx->h_ring); for (uint32_t k = 0; k < mvs_ctx::RING; ++k) (void)hipEventDestroy(ctx->ring_ev[k]); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -140,6 +143,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_unroll") ctx->mrf_unroll = (int)value;
     else if (n == "mrf_nt") ctx->mrf_nt = (int)value;
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;
+    else if (n == "mrf_lag") ctx->mrf_lag = (int)value;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
@@ -346,26 +350,25 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     { Prof pr(ctx, "mrf_setup"); mrf_setup(ctx, &P); }
     hipStream_t s = ctx->stream;
     mvs_mrf_stats S; memset(&S, 0, sizeof(S));
-    uint64_t best_e = ~0ull;
-    std::vector<uint64_t> hist; hist.push_back(~0ull);
-    int sw = 1;
-    for (; sw <= P.max_sweeps; ++sw) {
+    // The stop rule runs on the device (mrf_step); the host only polls the report of `lag` sweeps ago, so the next
+    // sweep is already queued when a sweep's energy becomes known.  Sweeps issued after the rule fired are no-ops
+    // for the result (the best labeling is frozen on the device).
+    const int lag = std::max(0, std::min(ctx->mrf_lag, (int)mvs_ctx::RING - 2));
+    mvs_mrf_progress pg; memset(&pg, 0, sizeof(pg));
+    auto report = [&](uint32_t n) {
+        mrf_poll(ctx, n, &pg);
+        if (ctx->verbose) fprintf(stderr, "[mvs] sweep %u energy %.3f best %.3f%s\n", n, (double)pg.energy / 4294967296.0, (double)pg.best / 4294967296.0, pg.stopped ? " (stopped)" : "");
+    };
+    int issued = 0, polled = 0;
+    while (issued < P.max_sweeps && !pg.stopped) {
         { Prof pr(ctx, "mrf_sweep"); mrf_sweep(ctx, 0, F); }
-        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, false, 0, F); }
-        uint64_t e[2]; read_energy(ctx, e);
-        if (e[0] < best_e) {
-            best_e = e[0];
-            mrf_keep_best(ctx);
-        }
-        hist.push_back(best_e);
-        if (ctx->verbose) fprintf(stderr, "[mvs] sweep %d energy %.3f best %.3f\n", sw, (double)e[0] / 4294967296.0, (double)best_e / 4294967296.0);
-        if (sw >= P.min_sweeps && sw > P.window) {
-            const uint64_t prev = hist[sw - P.window];
-            if ((double)(prev - best_e) < (double)P.min_improvement * (double)prev) break;
-        }
+        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, false, 0, F); mrf_step(ctx, nullptr); }
+        ++issued;
+        if (issued - lag > polled) report((uint32_t)++polled);
     }
-    S.sweeps = (uint32_t)std::min(sw, P.max_sweeps);
-    if (P.max_sweeps <= 0) S.sweeps = 0;   // best labeling = the argmin-unary start state of mrf_setup
+    while (polled < issued && !pg.stopped) report((uint32_t)++polled);
+    if (issued > 0) mrf_poll(ctx, (uint32_t)issued, &pg);   // final state (drains the stream)
+    S.sweeps = issued > 0 ? pg.stop_sweep : 0u;   // max_sweeps <= 0: best labeling = the argmin-unary start state of mrf_setup
     int it = 0;
     for (; it < P.icm_iters; ++it) {
         Prof pr(ctx, "mrf_icm");

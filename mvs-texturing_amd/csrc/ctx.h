@@ -162,6 +162,10 @@ struct mvs_ctx {
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved;
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0; bool m_flip = false;
     mvs_mrf_params m_params{};
+    // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring
+    static constexpr uint32_t RING = 16;
+    mvs::DBuf<mvs_mrf_progress> m_state; mvs::DBuf<unsigned long long> m_hist;
+    mvs_mrf_progress* h_ring = nullptr; hipEvent_t ring_ev[RING] = {}; uint32_t steps_issued = 0; int mrf_lag = 1;
 };
 
 namespace mvs {

@@ -620,6 +620,41 @@ __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t nod
     labels[i - node_begin] = label;
 }
 
+
+// ---- device-side solver bookkeeping: one thread.  Same decisions, in the same arithmetic, as the host loop it
+// replaces: best = min(best, e); stop iff sweep >= min_sweeps, sweep > window and
+// double(hist[sweep - window] - best) < double(min_improvement) * double(hist[sweep - window]).
+__global__ void mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
+                                const unsigned long long* __restrict__ energy, int max_sweeps, int min_sweeps, int window,
+                                float min_improvement) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->stopped) { st->improved = 0u; return; }
+    const uint32_t sw = st->sweep + 1u;
+    const unsigned long long e0 = energy[0];
+    unsigned long long best = st->best;
+    const bool imp = e0 < best;
+    if (imp) best = e0;
+    st->sweep = sw; st->improved = imp ? 1u : 0u; st->energy = e0; st->best = best;
+    hist[sw] = best;
+    bool stop = false;
+    if ((int)sw >= min_sweeps && (int)sw > window) {
+        const unsigned long long prev = hist[sw - (uint32_t)window];
+        stop = (double)(prev - best) < (double)min_improvement * (double)prev;
+    }
+    if ((int)sw >= max_sweeps) stop = true;
+    if (stop) { st->stopped = 1u; st->stop_sweep = sw; }
+}
+// best labeling := current decode, iff the step above saw an improvement (the flag is wave-uniform)
+__global__ void __launch_bounds__(256) mrf_keep_best_if_kernel(const mvs_mrf_progress* __restrict__ st, const uint32_t* __restrict__ sel,
+                                                               const uint32_t* __restrict__ lab, const float* __restrict__ cost,
+                                                               uint32_t* __restrict__ best_sel, uint32_t* __restrict__ best_lab,
+                                                               float* __restrict__ best_cost, uint32_t n) {
+    if (!st->improved) return;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        best_sel[i] = sel[i]; best_lab[i] = lab[i]; best_cost[i] = cost[i];
+    }
+}
+
 }  // namespace
 
 // Builds the solver's edge tables for the active CSR (ctx->r_ptr / r_view / r_cost) and adjacency.
@@ -673,6 +708,44 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(ctx->m_gain.p, 0, ((size_t)F + 1) * sizeof(float), s));
     ctx->m_energy.ensure(4);
     ctx->m_flip = false;
+    // device-side solver state: sweep 0, best = hist[0] = 2^64 - 1
+    ctx->m_state.ensure(1); ctx->m_hist.ensure((size_t)std::max(params->max_sweeps, 0) + 2);
+    mvs_mrf_progress init; memset(&init, 0, sizeof(init)); init.best = ~0ull; init.energy = ~0ull;
+    if (!ctx->h_ring) {
+        MVS_HIP(hipHostMalloc((void**)&ctx->h_ring, mvs_ctx::RING * sizeof(mvs_mrf_progress), hipHostMallocDefault));
+        for (uint32_t k = 0; k < mvs_ctx::RING; ++k) MVS_HIP(hipEventCreateWithFlags(&ctx->ring_ev[k], hipEventDisableTiming));
+    }
+    ctx->h_ring[0] = init;
+    MVS_HIP(hipMemcpyAsync(ctx->m_state.p, &ctx->h_ring[0], sizeof(init), hipMemcpyHostToDevice, s));
+    MVS_HIP(hipMemsetAsync(ctx->m_hist.p, 0xFF, sizeof(unsigned long long), s));
+    MVS_HIP(hipStreamSynchronize(s));
+    ctx->steps_issued = 0;
+}
+
+// One bookkeeping step (see mrf_step_kernel); energy = device pointer to the (all-reduced) energy pair.
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
+    hipStream_t s = ctx->stream;
+    const mvs_mrf_params& P = ctx->m_params;
+    if (!ctx->h_ring) throw StatusError(MVS_ERR_STATE, "mrf step before mrf setup");
+    hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(64), 0, s, ctx->m_state.p, ctx->m_hist.p, energy ? energy : ctx->m_energy.p,
+                       P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
+    MVS_LAUNCH_CHECK();
+    const uint32_t F = ctx->csr_faces;
+    if (F) {
+        hipLaunchKernelGGL(mrf_keep_best_if_kernel, dim3(std::min<unsigned>((F + 255) / 256, 2048u)), dim3(256), 0, s, ctx->m_state.p,
+                           ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, F);
+        MVS_LAUNCH_CHECK();
+    }
+    const uint32_t n = ++ctx->steps_issued, slot = n % mvs_ctx::RING;
+    MVS_HIP(hipMemcpyAsync(&ctx->h_ring[slot], ctx->m_state.p, sizeof(mvs_mrf_progress), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipEventRecord(ctx->ring_ev[slot], s));
+}
+void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
+    if (step == 0 || step > ctx->steps_issued || step + mvs_ctx::RING <= ctx->steps_issued)
+        throw StatusError(MVS_ERR_INVALID, "mrf poll: step not among the last 16 issued");
+    const uint32_t slot = step % mvs_ctx::RING;
+    MVS_HIP(hipEventSynchronize(ctx->ring_ev[slot]));
+    *out = ctx->h_ring[slot];
 }
 
 template <int G>

@@ -10,6 +10,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0);
 void mrf_keep_best(mvs_ctx* ctx);
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
+void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
@@ -175,6 +177,19 @@ mvs_status mvs_ctx_mrf_keep_best(mvs_ctx* ctx) {
     if (!ctx) return api_fail(MVS_ERR_INVALID, "ctx is null");
     MVS_API_BEGIN
     mrf_keep_best(ctx);
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_step(mvs_ctx* ctx, const uint64_t* energy_device) {
+    if (!ctx) return api_fail(MVS_ERR_INVALID, "ctx is null");
+    MVS_API_BEGIN
+    mrf_step(ctx, (const unsigned long long*)energy_device);
+    MVS_API_END
+}
+mvs_status mvs_ctx_mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
+    if (!ctx || !out) return api_fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    mrf_poll(ctx, step, out);
     MVS_API_END
 }
 

@@ -183,12 +183,13 @@ def stop_rule(hist, sweep, params):
 class ShardedViewSelection:
     """Runs tex::view_selection over `plan.P` parts.  `ops` provides the per-rank compute:
          setup(), sweep(nb, ne), gather(which, idx, dst), scatter(which, idx, src),
-         energy(which_sel, nb, ne) -> int64 tensor[2], keep_best(), icm_gain(nb, ne),
+         energy(which_sel, nb, ne) -> int64 tensor[2], step(e), poll(n) -> report dict, icm_gain(nb, ne),
          icm_apply(nb, ne) -> int tensor[1], labels(nb, ne) -> uint32 labels of own nodes
     (viewsel.Context for the GPU; a numpy stand-in in the CPU tests)."""
 
-    def __init__(self, ops, plan, params, device, dist=None, group=None, hx=None):
+    def __init__(self, ops, plan, params, device, dist=None, group=None, hx=None, lag=None):
         self.ops, self.plan, self.params, self.dist, self.group = ops, plan, params, dist, group
+        self.lag = (2 if plan.P > 1 else 1) if lag is None else int(lag)
         self.hx = hx or HaloExchange(plan, device, dist, group)
 
     def _allreduce(self, t):
@@ -200,24 +201,30 @@ class ShardedViewSelection:
         ops, plan, P = self.ops, self.plan, self.params
         nb, ne = plan.node_begin, plan.node_end
         ops.setup()
-        best = (1 << 64) - 1
-        hist = [best]
-        sweeps = 0
-        for sw in range(1, P.max_sweeps + 1):
+        # The stop rule lives with the ops (on the device for the GPU): step() accounts one sweep's all-reduced
+        # energy, keeps the best labeling and freezes everything once the rule has fired; poll(n) returns the report
+        # of step n.  The host runs `lag` sweeps ahead of the reports it reads, so no rank ever waits for a sweep's
+        # energy before queueing the next sweep; every rank sees the same reports and stops at the same step.
+        lag = self.lag
+        issued = polled = 0
+        rep = None
+        while issued < P.max_sweeps and not (rep and rep["stopped"]):
             ops.sweep(nb, ne)
             if plan.total_words < 2 ** 31:
                 self.hx.exchange([("both", MSG_LAB)], ops.gather, ops.scatter)      # one collective per sweep
             else:
                 self.hx.exchange([("msg", MSG), ("node", LAB)], ops.gather, ops.scatter)
-            e = self._allreduce(ops.energy(LAB, nb, ne))
-            e0 = int(e[0].item()) & ((1 << 64) - 1)
-            if e0 < best:
-                best = e0
-                ops.keep_best()
-            hist.append(best)
-            sweeps = sw
-            if stop_rule(hist, sw, P):
-                break
+            ops.step(self._allreduce(ops.energy(LAB, nb, ne)))
+            issued += 1
+            if issued - lag > polled:
+                polled += 1
+                rep = ops.poll(polled)
+        while polled < issued and not (rep and rep["stopped"]):
+            polled += 1
+            rep = ops.poll(polled)
+        if issued:
+            rep = ops.poll(issued)
+        sweeps = rep["stop_sweep"] if issued else 0
         icm = 0
         for icm in range(P.icm_iters):
             ops.icm_gain(nb, ne)
@@ -281,6 +288,15 @@ class GpuShardOps:
 
     def keep_best(self):
         self._chk(self.L.mvs_ctx_mrf_keep_best(self.h))
+
+    def step(self, e):
+        self._chk(self.L.mvs_ctx_mrf_step(self.h, self.C.c_void_p(e.data_ptr())))
+
+    def poll(self, n):
+        from .viewsel import MrfProgress
+        pg = MrfProgress()
+        self._chk(self.L.mvs_ctx_mrf_poll(self.h, n, self.C.byref(pg)))
+        return {f[0]: getattr(pg, f[0]) for f in pg._fields_}
 
     def icm_gain(self, nb, ne):
         self._chk(self.L.mvs_ctx_mrf_icm_gain(self.h, nb, ne))

@@ -59,6 +59,11 @@ class MrfStats(C.Structure):
                 ("icm_iters", C.c_uint32), ("unseen", C.c_uint32)]
 
 
+class MrfProgress(C.Structure):
+    _fields_ = [("sweep", C.c_uint32), ("stopped", C.c_uint32), ("improved", C.c_uint32), ("stop_sweep", C.c_uint32),
+                ("energy", C.c_uint64), ("best", C.c_uint64)]
+
+
 class DcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("pairs", "cull_backface", "cull_angle", "cull_outside", "cull_occluded",
                                            "cull_zero_quality", "nnz_pre", "nnz", "rays", "ray_nodes", "ray_tris")] + \
@@ -119,6 +124,7 @@ def load_library():
         "mvs_ctx_mrf_setup": [vp, vp, vp, i32, C.POINTER(MrfParams)], "mvs_ctx_mrf_sweep": [vp, u32, u32],
         "mvs_ctx_mrf_gather": [vp, i32, vp, u64, vp], "mvs_ctx_mrf_scatter": [vp, i32, vp, u64, vp],
         "mvs_ctx_mrf_energy": [vp, i32, u32, u32, vp], "mvs_ctx_mrf_keep_best": [vp],
+        "mvs_ctx_mrf_step": [vp, vp], "mvs_ctx_mrf_poll": [vp, u32, C.POINTER(MrfProgress)],
         "mvs_ctx_mrf_icm_gain": [vp, u32, u32], "mvs_ctx_mrf_icm_apply": [vp, u32, u32, vp],
         "mvs_ctx_mrf_labels": [vp, u32, u32, vp, C.POINTER(u32)],
     }

@@ -58,8 +58,9 @@ class _FakeOps:
     """numpy stand-in for the per-rank compute with the SAME data dependencies as the solver:
     a node's outgoing message words are a hash of all its incoming words of the previous sweep."""
 
-    def __init__(self, col_ptr, adj_ptr, adj, torch):
+    def __init__(self, col_ptr, adj_ptr, adj, torch, params=None):
         self.torch = torch
+        self.params = params
         col_ptr = col_ptr.astype(np.int64); adj_ptr = adj_ptr.astype(np.int64)
         self.col_ptr, self.adj_ptr, self.adj = col_ptr, adj_ptr, adj.astype(np.int64)
         F = len(col_ptr) - 1
@@ -79,7 +80,9 @@ class _FakeOps:
         self.prev = self.arr[G.MSG].copy()
 
     def setup(self):
-        pass
+        self.state = {"sweep": 0, "stopped": 0, "improved": 0, "stop_sweep": 0, "energy": 2 ** 64 - 1, "best": 2 ** 64 - 1}
+        self.hist = [2 ** 64 - 1]
+        self.reports = []
 
     def sweep(self, nb, ne):
         old = self.arr[G.MSG].copy(); new = self.arr[G.MSG]
@@ -125,6 +128,27 @@ class _FakeOps:
     def keep_best(self):
         self.arr[G.BEST_LAB][:] = self.arr[G.LAB]
 
+    def step(self, e):
+        """host restatement of the device-side bookkeeping (k_mrf.hip mrf_step_kernel)"""
+        st = self.state
+        if st["stopped"]:
+            st["improved"] = 0
+        else:
+            st["sweep"] += 1
+            e0 = int(e[0].item()) & ((1 << 64) - 1)
+            st["improved"] = int(e0 < st["best"])
+            if st["improved"]:
+                st["best"] = e0
+                self.keep_best()
+            st["energy"] = e0
+            self.hist.append(st["best"])
+            if G.stop_rule(self.hist, st["sweep"], self.params) or st["sweep"] >= self.params.max_sweeps:
+                st["stopped"], st["stop_sweep"] = 1, st["sweep"]
+        self.reports.append(dict(st))
+
+    def poll(self, n):
+        return self.reports[n - 1]
+
     def icm_gain(self, nb, ne):
         self.arr[G.GAIN][nb:ne] = (self.arr[G.BEST_LAB][nb:ne] * 3 + 1) % 5
 
@@ -150,7 +174,7 @@ def _run_rank(rank, world, port, out_dir):
     pb = G.equal_parts(len(faces), world)
     plan = G.HaloPlan(col_ptr, adj_ptr, adj, pb, rank)
     params = M.viewsel.MrfParams(6, 6, 3, 0.0, 0.0, 1.0, 3)
-    solver = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch), plan, params, "cpu", dist)
+    solver = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch, params), plan, params, "cpu", dist)
     labels, stats = solver.run()
     np.save(os.path.join(out_dir, "labels_%d.npy" % rank), labels)
     np.save(os.path.join(out_dir, "stats_%d.npy" % rank), np.array([stats["energy_fixed"], stats["cut_edges"], stats["sweeps"], stats["icm_iters"]], dtype=np.uint64))
@@ -164,7 +188,7 @@ def test_gloo_world2_equals_single_rank(tmp_path):
     s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
     plan1 = G.HaloPlan(col_ptr, adj_ptr, adj, G.equal_parts(len(faces), 1), 0)
     params = M.viewsel.MrfParams(6, 6, 3, 0.0, 0.0, 1.0, 3)
-    ref_labels, ref_stats = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch), plan1, params, "cpu", None).run()
+    ref_labels, ref_stats = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch, params), plan1, params, "cpu", None).run()
     port = 29500 + os.getpid() % 2000
     mp.spawn(_run_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(2)])
