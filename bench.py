@@ -128,7 +128,7 @@ def main():
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_option("profile", 1)
-    for env, opt in (("MVS_MRF_SHAPE", "mrf_shape"), ("MVS_MRF_UNROLL", "mrf_unroll"), ("MVS_MRF_NT", "mrf_nt"), ("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd")):
+    for env, opt in (("MVS_MRF_SHAPE", "mrf_shape"), ("MVS_MRF_UNROLL", "mrf_unroll"), ("MVS_MRF_NT", "mrf_nt"), ("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag")):
         if os.environ.get(env):   # tuning knobs for experiments
             ctx.set_option(opt, int(os.environ[env]))
     if os.environ.get("MVS_RAY_MODE"):
@@ -177,6 +177,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ctx.get_profile()
+    # row f3 (outside the headline window, reported separately): UniGraph::get_subgraphs of the labeling, all labels at once
+    post = {}
+    if world == 1 and args.steps > 0:
+        ctx.get_subgraphs(t_ap, t_ad, t_lab, V + 1, on_device=True); ctx.get_profile()
+        for _ in range(3):
+            sg = ctx.get_subgraphs(t_ap, t_ad, t_lab, V + 1, on_device=True)
+        p = ctx.get_profile()
+        post["get_subgraphs_ms"] = p["get_subgraphs"][0] / p["get_subgraphs"][1]
+        post["patches"] = int(sg[1].shape[0]) - 1
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
     value = F / (ms_per_step / 1000.0)
 
@@ -214,7 +223,7 @@ def main():
                                   "settings gmi/none/visibility-test (reference defaults)" % (args.config, cfg["n"], F, V, cfg["width"], cfg["height"]),
                       "faces": F, "views": V, "nnz": nnz_global, "sweeps": int(mrf["sweeps"]), "icm_iters": int(mrf["icm_iters"]),
                       "energy": float(mrf["energy"]), "partition": "morton-%d" % world},
-           "roofline": roof, "stages": stages, "pre_path": pre}
+           "roofline": roof, "stages": stages, "pre_path": pre, "post_path": post}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(scene, faces, normals, adj_ptr, adj,

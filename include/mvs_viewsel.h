@@ -160,6 +160,25 @@ mvs_status mvs_build_adjacency_graph(uint32_t n_verts, uint32_t n_faces, const u
                                      uint32_t* adj_ptr_out, uint32_t** adj_out, uint64_t* n_entries);
 
 /* ------------------------------------------------------------------------
+ * SURVEY.md 8(f) row f3 -- the step immediately AFTER the path: UniGraph::get_subgraphs
+ * (libs/tex/uni_graph.cpp:21-55), which generate_texture_patches calls once per label
+ * (generate_texture_patches.cpp:469-475).  All labels at once:
+ *   subgraphs of label L = components [label_ptr[L], label_ptr[L + 1]), in the reference's order (ascending
+ *   smallest face); component c = comp_faces[comp_ptr[c] .. comp_ptr[c + 1]) in the reference's BFS queue order.
+ * labels[i] < n_labels (view_selection writes view + 1, 0 = unseen: n_labels = n_views + 1).
+ * ------------------------------------------------------------------------ */
+typedef struct mvs_subgraphs {
+    uint32_t n_faces, n_labels, n_components;
+    uint32_t* label_ptr;    /* [n_labels + 1] */
+    uint32_t* comp_ptr;     /* [n_components + 1] */
+    uint32_t* comp_faces;   /* [n_faces] */
+} mvs_subgraphs;
+/* host arrays in, library-allocated host arrays out (mvs_subgraphs_free) */
+mvs_status mvs_get_subgraphs(uint32_t n_faces, const uint32_t* adj_ptr, const uint32_t* adj, const uint32_t* labels,
+                             uint32_t n_labels, mvs_subgraphs* out);
+void mvs_subgraphs_free(mvs_subgraphs* sg);
+
+/* ------------------------------------------------------------------------
  * Resident (context) API: inputs live in HBM across calls; used by bench.py,
  * the GPU tests and the multi-GPU driver.  Pointers flagged *_on_device are
  * device pointers owned by the caller (e.g. torch tensors) and must stay
@@ -174,7 +193,9 @@ mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
 /* integer options: "stats" (0/1: fill the cull-reason counters of mvs_dc_stats; default 0), "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1),
  * "ray_mode" (0 = one BVH traversal per ray, 1 = one shared traversal per 64-ray wave, 2 = shared traversal with
- * (ray, triangle) work redistribution at the leaves; identical results) */
+ * (ray, triangle) work redistribution at the leaves; identical results), "mrf_lag" (sweeps the host queues ahead of
+ * the energy reports it reads, default 1, 0 = wait for every sweep; identical results), tuning knobs "mrf_shape",
+ * "mrf_xcd", "mrf_blocks_per_cu", "ray_xcd" */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 
 /* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,
@@ -281,6 +302,13 @@ mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t node_begin, uint32_t nod
 /* labels (view_selection.cpp:120-132) of own nodes of the best labeling into labels_device[node_end - node_begin] */
 mvs_status mvs_ctx_mrf_labels(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* labels_device,
                               uint32_t* unseen_out);
+
+
+/* row f3 on a context: inputs host or device (flags); with out_on_device the three arrays of `out` are device
+ * pointers owned by the context (valid until its next get_subgraphs call), otherwise malloc'ed host copies */
+mvs_status mvs_ctx_get_subgraphs(mvs_ctx* ctx, uint32_t n_faces, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
+                                 const uint32_t* labels, int labels_on_device, uint32_t n_labels, mvs_subgraphs* out,
+                                 int out_on_device);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,33 @@ public:
     void set_label(std::size_t n, std::size_t label) { labels[n] = label; }
     std::size_t get_label(std::size_t n) const { return labels[n]; }
     std::vector<std::size_t> const& get_adj_nodes(std::size_t node) const { return adj_lists[node]; }
+
+    /* uni_graph.cpp:21-55: the connected subgraphs of nodes labelled `label`, appended to *subgraphs in ascending
+     * order of their smallest node, each in BFS queue order.  generate_texture_patches.cpp:469-475 asks for every
+     * label in turn; the GPU computes all labels in one pass (mvs_get_subgraphs), so ask through
+     * get_all_subgraphs() once and slice, or call this per label (one pass each). */
+    void get_subgraphs(std::size_t label, std::vector<std::vector<std::size_t> >* subgraphs) const {
+        std::size_t n_labels = label + 1;
+        for (std::size_t l : labels) n_labels = std::max(n_labels, l + 1);
+        mvs_subgraphs sg;
+        get_all_subgraphs(n_labels, &sg);
+        for (std::uint32_t c = sg.label_ptr[label]; c < sg.label_ptr[label + 1]; ++c)
+            subgraphs->push_back(std::vector<std::size_t>(sg.comp_faces + sg.comp_ptr[c], sg.comp_faces + sg.comp_ptr[c + 1]));
+        mvs_subgraphs_free(&sg);
+    }
+    /* all labels 0 .. n_labels - 1 in one GPU pass; free with mvs_subgraphs_free */
+    void get_all_subgraphs(std::size_t n_labels, mvs_subgraphs* out) const {
+        std::vector<std::uint32_t> adj_ptr(adj_lists.size() + 1, 0), adj, lab(labels.size());
+        for (std::size_t i = 0; i < adj_lists.size(); ++i) {
+            for (std::size_t g : adj_lists[i]) adj.push_back(static_cast<std::uint32_t>(g));
+            adj_ptr[i + 1] = static_cast<std::uint32_t>(adj.size());
+            lab[i] = static_cast<std::uint32_t>(labels[i]);
+        }
+        if (adj.empty()) adj.push_back(0);
+        if (mvs_get_subgraphs(static_cast<std::uint32_t>(adj_lists.size()), adj_ptr.data(), adj.data(), lab.data(),
+                              static_cast<std::uint32_t>(n_labels), out) != MVS_OK)
+            throw std::runtime_error(std::string("mvs_viewsel: ") + mvs_last_error());
+    }
 };
 
 namespace tex {

@@ -152,6 +152,9 @@ struct mvs_ctx {
     mvs::DBuf<unsigned long long> g_keys, g_keys2; mvs::DBuf<uint32_t> g_vals, g_vals2, g_pos, g_cnt, g_adj_ptr, g_adj, g_faces; mvs::DBuf<float> g_normals;
     uint64_t g_adj_entries = 0; bool have_adj = false;
 
+    // ---- row f3: patch components (k_patch.hip) ----
+    mvs::DBuf<uint32_t> p_label_ptr, p_comp_ptr, p_comp_faces, p_parent, p_root, p_state, p_flag, p_pos, p_roots, p_roots2, p_rlab, p_rlab2, p_adj_ptr, p_adj, p_labels;
+
     // ---- MRF ----
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
     mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_shape = 0, mrf_unroll = 1, mrf_nt = 0, mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1;

@@ -64,6 +64,11 @@ class MrfProgress(C.Structure):
                 ("energy", C.c_uint64), ("best", C.c_uint64)]
 
 
+class Subgraphs(C.Structure):
+    _fields_ = [("n_faces", C.c_uint32), ("n_labels", C.c_uint32), ("n_components", C.c_uint32),
+                ("label_ptr", C.c_void_p), ("comp_ptr", C.c_void_p), ("comp_faces", C.c_void_p)]
+
+
 class DcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("pairs", "cull_backface", "cull_angle", "cull_outside", "cull_occluded",
                                            "cull_zero_quality", "nnz_pre", "nnz", "rays", "ray_nodes", "ray_tris")] + \
@@ -102,13 +107,15 @@ def load_library():
     sig = {
         "mvs_mrf_default_params": [C.POINTER(MrfParams)], "mvs_default_settings": [C.POINTER(Settings)],
         "mvs_data_costs": [C.POINTER(CMesh), C.POINTER(CView), u32, C.POINTER(Settings), C.POINTER(CCsr), C.POINTER(DcStats)],
-        "mvs_csr_free": [C.POINTER(CCsr)],
+        "mvs_csr_free": [C.POINTER(CCsr)], "mvs_subgraphs_free": [C.POINTER(Subgraphs)],
         "mvs_view_selection": [C.POINTER(CCsr), vp, vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
         "mvs_write_spt": [C.POINTER(CCsr), C.c_char_p], "mvs_read_spt": [C.c_char_p, C.POINTER(CCsr)],
         "mvs_write_labeling_vec": [vp, u32, C.c_char_p],
         "mvs_prepare_mesh": [u32, vp, u32, vp, vp, vp, C.POINTER(u32)],
         "mvs_build_adjacency_graph": [u32, u32, vp, vp, C.POINTER(vp), C.POINTER(u64)],
         "mvs_ctx_build_adjacency": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)],
+        "mvs_get_subgraphs": [u32, vp, vp, vp, u32, C.POINTER(Subgraphs)],
+        "mvs_ctx_get_subgraphs": [vp, u32, vp, vp, i32, vp, i32, u32, C.POINTER(Subgraphs), i32],
         "mvs_ctx_create": [i32, C.POINTER(vp)], "mvs_ctx_destroy": [vp], "mvs_ctx_set_stream": [vp, vp],
         "mvs_ctx_synchronize": [vp], "mvs_set_option": [vp, C.c_char_p, C.c_int64],
         "mvs_ctx_get_profile": [vp, C.c_char_p, C.c_size_t],
@@ -131,7 +138,7 @@ def load_library():
     for name, argtypes in sig.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
-        if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_ctx_destroy"):
+        if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_subgraphs_free", "mvs_ctx_destroy"):
             fn.restype = C.c_int
     L._declared = sorted(list(sig.keys()) + ["mvs_last_error", "mvs_status_string"])
     _lib = L
@@ -321,6 +328,40 @@ class Context:
         self._keep["adj"] = (adj_ptr, adj)
         _check(self.L, self.L.mvs_ctx_view_selection(self.h, pa, pb, d0, C.byref(p), pl, dl, C.byref(ms)))
         return labels_out, _stats_dict(ms)
+
+
+    def get_subgraphs(self, adj_ptr, adj, labels, n_labels, on_device=False):
+        """UniGraph::get_subgraphs for every label at once (row f3).  Host copies (label_ptr, comp_ptr, comp_faces), or
+        with on_device=True DevArrays owned by the context (valid until the next call)."""
+        pa, d0 = _ptr(adj_ptr); pb, d1 = _ptr(adj); pl, dl = _ptr(labels)
+        assert d0 == d1
+        F = int(adj_ptr.shape[0]) - 1
+        sg = Subgraphs()
+        self._keep["sg"] = (adj_ptr, adj, labels)
+        _check(self.L, self.L.mvs_ctx_get_subgraphs(self.h, F, pa, pb, d0, pl, dl, int(n_labels), C.byref(sg), 1 if on_device else 0))
+        if on_device:
+            return DevArray(sg.label_ptr, n_labels + 1), DevArray(sg.comp_ptr, sg.n_components + 1), DevArray(sg.comp_faces, F)
+        return _subgraphs_to_numpy(self.L, sg)
+
+
+def _subgraphs_to_numpy(L, sg):
+    def grab(ptr, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (max(n, 1),))[:n].copy()
+    out = grab(sg.label_ptr, sg.n_labels + 1), grab(sg.comp_ptr, sg.n_components + 1), grab(sg.comp_faces, sg.n_faces)
+    L.mvs_subgraphs_free(C.byref(sg))
+    return out
+
+
+def get_subgraphs(adj_ptr, adj, labels, n_labels):
+    """UniGraph::get_subgraphs(label, &subgraphs) (libs/tex/uni_graph.cpp:21-55) for label = 0 .. n_labels - 1:
+    subgraphs of label L are components label_ptr[L] .. label_ptr[L + 1]; component c is
+    comp_faces[comp_ptr[c]:comp_ptr[c + 1]] in the reference's queue order."""
+    L = load_library()
+    adj_ptr = np.ascontiguousarray(adj_ptr, dtype=np.uint32); adj = np.ascontiguousarray(adj, dtype=np.uint32)
+    labels = np.ascontiguousarray(labels, dtype=np.uint32)
+    sg = Subgraphs()
+    _check(L, L.mvs_get_subgraphs(len(adj_ptr) - 1, adj_ptr.ctypes.data, adj.ctypes.data, labels.ctypes.data, int(n_labels), C.byref(sg)))
+    return _subgraphs_to_numpy(L, sg)
 
 
 def calculate_data_costs(scene, settings=None, ctx=None):

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <utility>
 #include <vector>
@@ -1136,6 +1137,55 @@ uint32_t orc_prepare_mesh(uint32_t n_verts, const float* verts, uint32_t n_faces
         ++kept;
     }
     return kept;
+}
+
+}  // extern "C"
+
+// ---- row f3 ----
+// UniGraph::get_subgraphs (uni_graph.cpp:21-55), statement by statement, on the flattened adjacency lists.
+static void get_subgraphs_of_label(uint32_t n_faces, const uint32_t* adj_ptr, const uint32_t* adj, const uint32_t* labels,
+                                   uint32_t label, std::vector<std::vector<uint32_t>>* subgraphs) {
+    std::vector<bool> used(n_faces, false);                                     /* :25 */
+    for (uint32_t i = 0; i < n_faces; ++i) {                                    /* :27 */
+        if (labels[i] == label && !used[i]) {                                   /* :28 */
+            subgraphs->push_back(std::vector<uint32_t>());                      /* :29 */
+            std::deque<uint32_t> queue;                                         /* :31 (std::list used as a FIFO) */
+            queue.push_back(i); used[i] = true;                                 /* :33-34 */
+            while (!queue.empty()) {                                            /* :36 */
+                const uint32_t node = queue.front(); queue.pop_front();         /* :37-38 */
+                subgraphs->back().push_back(node);                              /* :40 */
+                for (uint32_t e = adj_ptr[node]; e < adj_ptr[node + 1]; ++e) {  /* :43-44 */
+                    const uint32_t adj_node = adj[e];                           /* :45 */
+                    if (labels[adj_node] == label && !used[adj_node]) {         /* :47 */
+                        queue.push_back(adj_node); used[adj_node] = true;       /* :48-49 */
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" {
+// generate_texture_patches.cpp:469-475 calls it for label = i + 1 of every view; label 0 (unseen faces) is
+// included here because the hole filling of the same file walks those components too.
+uint32_t orc_get_subgraphs(uint32_t n_faces, const uint32_t* adj_ptr, const uint32_t* adj, const uint32_t* labels,
+                           uint32_t n_labels, uint32_t* label_ptr, uint32_t** comp_ptr_out, uint32_t* comp_faces) {
+    std::vector<uint32_t> comp_ptr; comp_ptr.push_back(0);
+    uint32_t filled = 0;
+    for (uint32_t label = 0; label < n_labels; ++label) {
+        label_ptr[label] = (uint32_t)comp_ptr.size() - 1;
+        std::vector<std::vector<uint32_t>> subgraphs;
+        get_subgraphs_of_label(n_faces, adj_ptr, adj, labels, label, &subgraphs);
+        for (const auto& sg : subgraphs) {
+            for (uint32_t f : sg) comp_faces[filled++] = f;
+            comp_ptr.push_back(filled);
+        }
+    }
+    label_ptr[n_labels] = (uint32_t)comp_ptr.size() - 1;
+    uint32_t* cp = (uint32_t*)malloc(sizeof(uint32_t) * comp_ptr.size());
+    std::copy(comp_ptr.begin(), comp_ptr.end(), cp);
+    *comp_ptr_out = cp;
+    return (uint32_t)comp_ptr.size() - 1;
 }
 
 }  // extern "C"

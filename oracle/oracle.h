@@ -144,6 +144,14 @@ int orc_build_adjacency(uint32_t n_faces, const uint32_t* faces, uint32_t** adj_
 uint32_t orc_prepare_mesh(uint32_t n_verts, const float* verts, uint32_t n_faces, const uint32_t* faces,
                           uint32_t* faces_out, float* normals_out);
 
+
+/* ---- row f3: the step immediately after the path ---- */
+/* UniGraph::get_subgraphs (uni_graph.cpp:21-55) for label = 0 .. n_labels - 1, flattened:
+ * label_ptr[n_labels + 1] (caller allocated), *comp_ptr_out [C + 1] and comp_faces[n_faces] (caller allocated);
+ * returns the number of components C; *comp_ptr_out is malloc'ed */
+uint32_t orc_get_subgraphs(uint32_t n_faces, const uint32_t* adj_ptr, const uint32_t* adj, const uint32_t* labels,
+                           uint32_t n_labels, uint32_t* label_ptr, uint32_t** comp_ptr_out, uint32_t* comp_faces);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,6 +216,22 @@ def build_adjacency(faces):
     return adj_ptr, adj
 
 
+def get_subgraphs(adj_ptr, adj, labels, n_labels):
+    """UniGraph::get_subgraphs for every label: (label_ptr, comp_ptr, comp_faces)"""
+    L = load()
+    adj_ptr = np.ascontiguousarray(adj_ptr, dtype=np.uint32); adj = np.ascontiguousarray(adj, dtype=np.uint32)
+    labels = np.ascontiguousarray(labels, dtype=np.uint32)
+    F = len(adj_ptr) - 1
+    label_ptr = np.zeros(n_labels + 1, np.uint32); comp_faces = np.zeros(max(F, 1), np.uint32)
+    pc = C.POINTER(C.c_uint32)()
+    L.orc_get_subgraphs.restype = C.c_uint32
+    L.orc_get_subgraphs.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.c_void_p]
+    n = L.orc_get_subgraphs(F, _ptr(adj_ptr), _ptr(adj), _ptr(labels), n_labels, _ptr(label_ptr), C.byref(pc), _ptr(comp_faces))
+    comp_ptr = np.ctypeslib.as_array(pc, (n + 1,)).copy()
+    C.CDLL(None).free(pc)
+    return label_ptr, comp_ptr, comp_faces[:F].copy()
+
+
 def prepare_mesh(verts, faces):
     """tex::prepare_mesh: (faces_without_redundant, face_normals)"""
     L = load()

@@ -58,6 +58,26 @@ int main(int argc, char** argv) {
     tex::DataCosts reload(static_cast<std::uint32_t>(num_faces), static_cast<std::uint16_t>(texture_views.size()));
     tex::DataCosts::load_from_file(prefix + "_data_costs.spt", &reload);          /* texrecon.cpp:110 */
     if (reload.get_nnz() != data_costs.get_nnz()) return 5;
+    /* generate_texture_patches.cpp:469-475: subgraphs of every label == the reference's loop (uni_graph.cpp:21-55) */
+    std::size_t n_patches = 0;
+    for (std::size_t label = 0; label <= texture_views.size(); ++label) {
+        std::vector<std::vector<std::size_t> > got, want;
+        graph.get_subgraphs(label, &got);
+        std::vector<bool> used(graph.num_nodes(), false);
+        for (std::size_t i = 0; i < graph.num_nodes(); ++i) {
+            if (graph.get_label(i) != label || used[i]) continue;
+            want.push_back(std::vector<std::size_t>());
+            std::vector<std::size_t> queue(1, i); used[i] = true;
+            for (std::size_t h = 0; h < queue.size(); ++h) {
+                want.back().push_back(queue[h]);
+                for (std::size_t a : graph.get_adj_nodes(queue[h]))
+                    if (graph.get_label(a) == label && !used[a]) { queue.push_back(a); used[a] = true; }
+            }
+        }
+        if (got != want) return 6;
+        n_patches += got.size();
+    }
+    std::printf("patches=%zu\n", n_patches);
     std::printf("ok faces=%zu views=%zu nnz=%zu\n", num_faces, texture_views.size(), data_costs.get_nnz());
     synth_mesh_free(&sm);
     return 0;

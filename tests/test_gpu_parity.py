@@ -441,6 +441,11 @@ def test_config3_full_size_properties():
     assert ((labels == 0) == (K == 0)).all()
     e, cuts = O.energy(O.CsrNp(F, V, dc.col_ptr, dc.view_id, dc.cost), s.adj_ptr, s.adj, labels)   # rejects labels outside the column
     assert e == ms["energy_fixed"] and cuts == ms["cut_edges"]
+    # row f3 at full size: patches of the solver's labeling == the oracle's per-label BFS (200 scans of 2 M faces)
+    want = O.get_subgraphs(s.adj_ptr, s.adj, labels, V + 1)
+    got = c.get_subgraphs(s.adj_ptr, s.adj, labels, V + 1)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
     c.close()
 
 
@@ -533,6 +538,39 @@ def test_row_f1_prepare_mesh_and_adjacency_graph():
     l1, s1 = c.view_selection(dev_ptr, dev_adj)
     l2, s2 = c.view_selection(s.adj_ptr, s.adj)
     assert np.array_equal(l1, l2) and s1["energy_fixed"] == s2["energy_fixed"]
+    c.close()
+
+
+def test_row_f3_get_subgraphs_equal_the_oracle():
+    """SURVEY.md 8(f) row f3: UniGraph::get_subgraphs for every label on the GPU == the oracle's per-label BFS, element
+    for element (component order and queue order), on mesh graphs, a multigraph with duplicate list entries, isolated
+    nodes, the empty graph; on the labels the solver produced; errors for labels out of range"""
+    from test_oracle import _f3_cases
+    for name, (adj_ptr, adj, labels, n_labels) in _f3_cases().items():
+        want = O.get_subgraphs(adj_ptr, adj, labels, n_labels)
+        got = M.get_subgraphs(adj_ptr, adj, labels, n_labels)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g), name
+    lp, cp, cf = M.get_subgraphs(np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), 4)
+    assert lp.tolist() == [0] * 5 and cp.tolist() == [0] and len(cf) == 0
+    s = get_scene("bumpy")
+    with pytest.raises(M.MvsError):
+        M.get_subgraphs(s.adj_ptr, s.adj, np.full(s.n_faces, 7, np.uint32), 7)
+    c = M.Context(0)
+    _load_scene(c, s)
+    c.data_costs(M.Settings())
+    labels, _ = c.view_selection(s.adj_ptr, s.adj)
+    want = O.get_subgraphs(s.adj_ptr, s.adj, labels, s.n_views + 1)
+    got = c.get_subgraphs(s.adj_ptr, s.adj, labels, s.n_views + 1)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    # one giant component through many queue chunks, and again (state is rebuilt per call)
+    for _ in range(2):
+        one = np.ones(s.n_faces, np.uint32)
+        want = O.get_subgraphs(s.adj_ptr, s.adj, one, 2)
+        got = c.get_subgraphs(s.adj_ptr, s.adj, one, 2)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g)
     c.close()
 
 

@@ -250,3 +250,62 @@ def test_prepare_mesh_restatement():
     verts, faces = m["degenerate"]
     f3, n3 = O.prepare_mesh(verts, faces)
     assert (n3[-1] == 0).all()                                               # zero-area face: zero normal, no NaN
+
+
+def _f3_cases():
+    """(adj_ptr, adj, labels, n_labels) for the row-f3 stage: mesh graphs with few / many labels, one giant
+    component, isolated nodes, and a random multigraph with duplicate list entries and high degrees"""
+    s = get_scene("tiny")
+    F = s.n_faces
+    rng = np.random.default_rng(5)
+    out = {"three_labels": (s.adj_ptr, s.adj, rng.integers(0, 3, F).astype(np.uint32), 3),
+           "noisy": (s.adj_ptr, s.adj, rng.integers(0, 40, F).astype(np.uint32), 41),
+           "giant": (s.adj_ptr, s.adj, np.full(F, 2, np.uint32), 3)}
+    bands = (np.arange(F) * 7 // F).astype(np.uint32)
+    out["bands"] = (s.adj_ptr, s.adj, bands, 9)
+    n = 500
+    src = rng.integers(0, n, 1500); dst = rng.integers(0, n, 1500)
+    lists = [[] for _ in range(n)]
+    for a, b in zip(src.tolist(), dst.tolist()):
+        if a != b:
+            lists[a].append(b); lists[b].append(a)                       # duplicates stay in the lists
+    ap = np.zeros(n + 1, np.uint32); ap[1:] = np.cumsum([len(l) for l in lists])
+    ad = np.array([g for l in lists for g in l], dtype=np.uint32)
+    out["multigraph"] = (ap, ad, rng.integers(0, 2, n).astype(np.uint32), 2)
+    out["isolated"] = (np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.array([1, 0, 1, 1, 0], np.uint32), 2)
+    return out
+
+
+def test_get_subgraphs_restatement():
+    """uni_graph.cpp:21-55: each label's subgraphs in ascending order of their smallest face, members in BFS queue
+    order -- against a pure-Python BFS and scipy's connected components"""
+    import collections
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    for name, (adj_ptr, adj, labels, n_labels) in _f3_cases().items():
+        label_ptr, comp_ptr, comp_faces = O.get_subgraphs(adj_ptr, adj, labels, n_labels)
+        F = len(adj_ptr) - 1
+        assert sorted(comp_faces.tolist()) == list(range(F)), name
+        assert label_ptr[0] == 0 and label_ptr[-1] == len(comp_ptr) - 1 and comp_ptr[-1] == F, name
+        want = []
+        for L in range(n_labels):
+            used = [False] * F
+            for i in range(F):
+                if labels[i] == L and not used[i]:
+                    q = collections.deque([i]); used[i] = True; comp = []
+                    while q:
+                        u = q.popleft(); comp.append(u)
+                        for v in adj[adj_ptr[u]:adj_ptr[u + 1]].tolist():
+                            if labels[v] == L and not used[v]:
+                                used[v] = True; q.append(v)
+                    want.append((L, comp))
+        got = []
+        for L in range(n_labels):
+            for c in range(label_ptr[L], label_ptr[L + 1]):
+                got.append((L, comp_faces[comp_ptr[c]:comp_ptr[c + 1]].tolist()))
+        assert got == want, name
+        rows = np.repeat(np.arange(F), np.diff(adj_ptr.astype(np.int64)))
+        keep = labels[rows] == labels[adj] if len(adj) else np.zeros(0, bool)
+        g = sp.coo_matrix((np.ones(int(keep.sum())), (rows[keep], adj[keep].astype(np.int64))), shape=(F, F))
+        ncc, _ = connected_components(g, directed=False)
+        assert ncc == len(comp_ptr) - 1, name
