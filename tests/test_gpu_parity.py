@@ -574,6 +574,35 @@ def test_row_f3_get_subgraphs_equal_the_oracle():
     c.close()
 
 
+def test_row_f2_scene_folder_to_spt_and_vec(tmp_path):
+    """scene folder (.cam + .png) + PLY -> <prefix>_data_costs.spt / _labeling.vec, the files an
+    unmodified `texrecon -D/-L` reads; equal to the in-memory path on the same scene"""
+    from mvs_texturing_amd import ingest
+    s = get_scene("tiny")
+    d = str(tmp_path / "scene"); ply = str(tmp_path / "mesh.ply"); prefix = str(tmp_path / "out")
+    ingest.save_scene_folder(s, d, ply)
+    ds, ms = ingest.run(d, ply, prefix)
+    r = ingest.load_scene(d, ply)
+    assert np.array_equal(r.faces, s.faces) and np.array_equal(r.adj_ptr, s.adj_ptr) and np.array_equal(r.adj, s.adj)
+    c = M.Context(0)
+    c.set_mesh(r.verts, r.faces, r.normals); c.set_views(r.cams, r.images)
+    c.data_costs(M.Settings()); dc = c.costs_download()
+    labels, ms2 = c.view_selection(r.adj_ptr, r.adj)
+    c.close()
+    assert ms["energy_fixed"] == ms2["energy_fixed"]
+    vec = np.fromfile(prefix + "_labeling.vec", dtype=np.uint64)
+    assert np.array_equal(vec, labels.astype(np.uint64))
+    raw = open(prefix + "_data_costs.spt", "rb").read()
+    header, body = raw.split(b"\n", 1)
+    assert header == b"SPT 0.2 %d %d %d" % (dc.n_faces, dc.n_views, dc.nnz) and len(body) == 10 * dc.nnz
+    rec = np.frombuffer(body, dtype=np.dtype([("col", "<u4"), ("row", "<u2"), ("v", "<f4")]))
+    assert np.array_equal(rec["row"], dc.view_id) and np.array_equal(rec["v"].view(np.uint32), dc.cost.view(np.uint32))
+    # the oracle on the ingested scene agrees (the cameras went through the .cam text round trip)
+    want, _ = O.data_costs(r)
+    assert np.array_equal(want.col_ptr, dc.col_ptr) and np.array_equal(want.view_id, dc.view_id)
+    assert np.array_equal(want.cost.view(np.uint32), dc.cost.view(np.uint32))
+
+
 def test_bench_contract_single_and_two_ranks(tmp_path):
     """bench.py prints ONE JSON line with the contract's keys; the N > 1 code path (torch.distributed.run, one process
     per rank) runs end to end -- here with 2 ranks sharing cuda:0 over gloo, the collectives' call pattern is the RCCL one"""

@@ -166,3 +166,44 @@ def test_bench_cli_contract():
     assert r.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in r.stdout
+
+
+def test_row_f2_scene_folder_round_trip(tmp_path):
+    """a scene written as <name>.cam + <name>.png (+ PLY mesh) reads back to the same camera
+    arrays (TextureView constructor, texture_view.cpp:35-38), pixels and mesh; folder pairing follows
+    generate_texture_views.cpp:71-111; malformed .cam files are rejected like the reference does"""
+    from conftest import get_scene
+    import mvs_texturing_amd as M
+    from mvs_texturing_amd import ingest
+    s = get_scene("tiny")
+    d = str(tmp_path / "scene")
+    ingest.save_scene_folder(s, d, str(tmp_path / "mesh.ply"))
+    open(os.path.join(d, "notes.txt"), "w").write("x")
+    open(os.path.join(d, "orphan.cam"), "w").write("0 0 0 1 0 0 0 1 0 0 0 1\n1\n")   # no image with this prefix: skipped
+    pairs = ingest.list_scene_folder(d)
+    assert len(pairs) == s.n_views and all(c[:-4] == i[:-4] for c, i in pairs)
+    r = ingest.load_scene(d)
+    for j in range(s.n_views):
+        assert np.array_equal(r.images[j], s.images[j])
+    assert np.array_equal(r.cams["width"], s.cams["width"]) and np.array_equal(r.cams["height"], s.cams["height"])
+    assert np.array_equal(r.cams["w2c"], s.cams["w2c"]) and np.array_equal(r.cams["viewdir"], s.cams["viewdir"])
+    assert np.allclose(r.cams["K"], s.cams["K"], rtol=1e-6) and np.allclose(r.cams["pos"], s.cams["pos"], atol=1e-6)
+    v, f = ingest.read_ply(str(tmp_path / "mesh.ply"))
+    assert np.array_equal(v, s.verts) and np.array_equal(f, s.faces)
+    with open(tmp_path / "a.ply", "w") as fh:   # ascii variant
+        fh.write("ply\nformat ascii 1.0\ncomment x\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                 "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    v, f = ingest.read_ply(str(tmp_path / "a.ply"))
+    assert v.shape == (3, 3) and f.tolist() == [[0, 1, 2]]
+    # .cam parsing: optional intrinsics default like mve::CameraInfo; portrait images use the height
+    open(tmp_path / "c.cam", "w").write("1 2 3 1 0 0 0 1 0 0 0 1\n0.8\n")
+    c = ingest.read_cam_file(str(tmp_path / "c.cam"))
+    assert c.flen == np.float32(0.8) and c.paspect == 1 and c.ppoint.tolist() == [0.5, 0.5] and c.dist.tolist() == [0, 0]
+    a = ingest.camera_arrays(c, 100, 200)
+    assert a["K"][0] == np.float32(0.8) * 200 and a["K"][2] == 50 and a["K"][5] == 100 and a["pos"].tolist() == [-1, -2, -3]
+    open(tmp_path / "bad.cam", "w").write("1 2 3\n1\n")
+    with pytest.raises(ValueError, match="Invalid CAM file"):
+        ingest.read_cam_file(str(tmp_path / "bad.cam"))
+    open(os.path.join(d, "view_0000.cam"), "w").write("0 0 0 1 0 0 0 1 0 0 0 1\n1 0.1\n")
+    with pytest.raises(NotImplementedError):
+        ingest.load_scene(d)
