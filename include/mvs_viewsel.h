@@ -271,6 +271,9 @@ typedef struct mvs_mrf_progress {
  * col_ptr + adjacency alone (mvs-texturing_amd/multigpu.py). */
 /* solver arrays addressable by the halo exchange: messages, decoded labels (view + 1) of the current
  * sweep, ICM gains, labels of the best labeling so far */
+/* message element index of the first real run: elements [0, MVS_MRF_MSG_BASE) of the message arrays are a reserved
+ * all-zero run (and of the map array the identity), see k_mrf.hip; halo index lists start from here */
+#define MVS_MRF_MSG_BASE 256u
 enum { MVS_MRF_MSG = 0, MVS_MRF_LAB = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_LAB = 3,
        /* combined addressing for one exchange per sweep: index < 2^31 -> MSG[index], else LAB[index & 0x7FFFFFFF] */
        MVS_MRF_MSG_LAB = 4 };

@@ -293,7 +293,7 @@ mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* out, float** quality_ou
     }
     if (quality_out) {
         *quality_out = (float*)malloc((nnz + 1) * sizeof(float));
-        if (nnz && ctx->r_cost == ctx->csr_cost.p)
+        if (nnz && ctx->csr_q_valid)
             MVS_HIP(hipMemcpyAsync(*quality_out, ctx->csr_q.p, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     MVS_HIP(hipStreamSynchronize(ctx->stream));
@@ -324,7 +324,7 @@ mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device)
         ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p;
     }
     ctx->csr_faces = csr->n_faces; ctx->csr_views = csr->n_views; ctx->csr_nnz = nnz;
-    ctx->have_costs = true;
+    ctx->have_costs = true; ctx->csr_q_valid = false;
     MVS_API_END
 }
 

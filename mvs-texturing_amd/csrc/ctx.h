@@ -145,6 +145,7 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> csr_ptr; mvs::DBuf<uint16_t> csr_view; mvs::DBuf<float> csr_cost; mvs::DBuf<float> csr_q;
     uint32_t csr_faces = 0, csr_views = 0; uint64_t csr_nnz = 0;
     const uint32_t* r_ptr = nullptr; const uint16_t* r_view = nullptr; const float* r_cost = nullptr;  // active CSR
+    bool csr_q_valid = false;   // csr_q holds the qualities of the active CSR (set by the data-cost stage)
     bool have_costs = false;
     mvs_settings dc_settings{}; mvs_dc_stats dc_stats{}; int dc_phase = 0;
 

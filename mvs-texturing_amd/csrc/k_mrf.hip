@@ -20,6 +20,7 @@ namespace mvs {
 namespace {
 
 constexpr uint16_t MAP_NONE = 0xFFFF;
+constexpr uint32_t MSG_BASE = MVS_MRF_MSG_BASE;   // first real message / map element (mvs_viewsel.h)
 
 // Messages live in HBM as IEEE binary16 (round to nearest even on store), arithmetic is fp32:
 // half the bytes per sweep of an fp32 layout at the same solution quality.
@@ -76,6 +77,49 @@ __device__ __forceinline__ void group_argmin(float& bb, uint32_t& bt) {
     if (G >= 64) argmin_step<32, G>(bb, bt);
 }
 
+// Fused forms for the hot sweep: v_min_f32 / v_min_u32 with the DPP modifier on src0, i.e. ONE VALU instruction per
+// butterfly step where the compiler's v_mov_dpp + canonicalise + min takes three (plus the exec-mask branches it
+// builds for a short-circuit argmin).  s_nop 1 = the two wait states a DPP read needs after a VALU write of the
+// same register (the hazard recogniser does not look inside inline asm).  All lanes are active where these run.
+#define MVS_DPP_OP(op, ctrl) asm("s_nop 1\n\t" op " %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v))
+template <int STEP, int G>
+__device__ __forceinline__ float min_step_f(float v) {
+    float r;
+    if (STEP == 1) MVS_DPP_OP("v_min_f32_dpp", "quad_perm:[1,0,3,2]");
+    else if (STEP == 2) MVS_DPP_OP("v_min_f32_dpp", "quad_perm:[2,3,0,1]");
+    else if (STEP == 4) MVS_DPP_OP("v_min_f32_dpp", "row_half_mirror");
+    else if (STEP == 8) MVS_DPP_OP("v_min_f32_dpp", "row_mirror");
+    else r = fminf(v, __shfl_xor(v, STEP, G));
+    return r;
+}
+template <int STEP, int G>
+__device__ __forceinline__ uint32_t min_step_u(uint32_t v) {
+    uint32_t r;
+    if (STEP == 1) MVS_DPP_OP("v_min_u32_dpp", "quad_perm:[1,0,3,2]");
+    else if (STEP == 2) MVS_DPP_OP("v_min_u32_dpp", "quad_perm:[2,3,0,1]");
+    else if (STEP == 4) MVS_DPP_OP("v_min_u32_dpp", "row_half_mirror");
+    else if (STEP == 8) MVS_DPP_OP("v_min_u32_dpp", "row_mirror");
+    else r = min(v, (uint32_t)__shfl_xor(v, STEP, G));
+    return r;
+}
+#undef MVS_DPP_OP
+template <int G>
+__device__ __forceinline__ float group_min_fused(float v) {
+    v = min_step_f<1, G>(v); v = min_step_f<2, G>(v); v = min_step_f<4, G>(v);
+    if (G >= 16) v = min_step_f<8, G>(v);
+    if (G >= 32) v = min_step_f<16, G>(v);
+    if (G >= 64) v = min_step_f<32, G>(v);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_min_fused(uint32_t v) {
+    v = min_step_u<1, G>(v); v = min_step_u<2, G>(v); v = min_step_u<4, G>(v);
+    if (G >= 16) v = min_step_u<8, G>(v);
+    if (G >= 32) v = min_step_u<16, G>(v);
+    if (G >= 64) v = min_step_u<32, G>(v);
+    return v;
+}
+
 // ---- setup ----
 __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 uint32_t F, uint32_t* __restrict__ size, uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
@@ -105,12 +149,14 @@ __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint
         const uint32_t r1 = adj_ptr[j + 1];
         while (r < r1 && adj[r] != i) ++r;
         MrfEdge m;
-        m.in_off = in_off[e];
-        m.out_off = (r < r1) ? in_off[r] : 0u;
+        m.in_off = MSG_BASE + in_off[e];                       // [0, MSG_BASE) is the reserved zero / identity run
+        m.out_off = (r < r1) ? MSG_BASE + in_off[r] : 0u;
         m.kj = (size[e] > 0 && r < r1) ? (col_ptr[j + 1] - col_ptr[j]) : 0u;
         edge[e] = m;
     }
 }
+
+__global__ void mrf_identity_kernel(uint16_t* __restrict__ map) { map[threadIdx.x] = (uint16_t)threadIdx.x; }
 
 // map[in_off(e) + t] = position of L_i[t] in L_j (binary search; lists ascending, calculate_data_costs.cpp:272)
 // ident[e] = 1 iff the two label lists of edge e are identical (map == identity), i.e. the sender's out-edge rev(e) can skip it
@@ -283,21 +329,34 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
 
 // ---- 4 labels per lane: lane gl owns labels 4*gl .. 4*gl+3 (one 8-byte access = four binary16 messages or
 // four u16 map entries), K <= 4 * G, so a 64-lane wave sweeps 64/G nodes per iteration at roughly the
-// instruction count of one.  The kernel is VALU-issue bound, so instructions per node is what counts.
-// The re-alignment gather c[p] goes through a per-wave LDS tile (one 16-byte write, four 4-byte reads per lane
-// and edge; LDS operations of a wave execute in order, so no barrier is needed).
+// instruction count of one.  The kernel is VALU-issue bound (a wave64 VALU op occupies its SIMD for 4 cycles), so
+// instructions per node is what counts, and the layout is arranged so that NO per-label masking is needed:
+//   * elements [0, MSG_BASE) of both message buffers are zero for ever: an absent edge (degree < 3, or an empty
+//     neighbour column) and every lane beyond the node's labels read their "incoming message" there;
+//   * elements [0, MSG_BASE) of the map array are the identity: an edge whose two label lists are identical
+//     (flag in the descriptor) reads its re-alignment map there instead of from its own run (no HBM traffic);
+//   * the re-alignment gather c[p] goes through a per-group LDS tile with one extra slot holding +inf: MAP_NONE is
+//     clamped onto that slot, so "label absent at the sender" needs no compare -- fmin(inf - cmin, 1/rho) = 1/rho;
+//   * message runs are padded to multiples of 4 elements, so a lane stores all four of its values or none;
+//   * the unary array has >= 4 floats of slack behind it (mrf_setup), so the 16-byte unary load needs no clamp.
+// Values a lane computes for label slots beyond the column are garbage that never reaches a valid label: they are
+// excluded from min / argmin by the ok[] mask (the only per-label selects left) and land in run padding.
+// LDS operations of a wave execute in order and a lane group never spans waves, so the tile needs no barrier.
 struct alignas(8) msg4_t { msg_t v[4]; };
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int G, bool DAMP, bool XCD>
 __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                          const uint16_t* __restrict__ map, const msg_t* __restrict__ mo, msg_t* __restrict__ mn,
                                                          uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
-                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha, uint32_t cost_len) {
+                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     constexpr int NPB = 256 / G;
+    constexpr int TS = 4 * G + 4;                            // tile stride: 4G cavity values + the +inf slot (16-byte multiple)
     constexpr uint32_t IDENT = 0x80000000u;
-    __shared__ float s_c[256][4];
+    __shared__ __attribute__((aligned(16))) float s_c[NPB * TS];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const int gbase = threadIdx.x - gl;                      // first thread of this lane group (LDS row base)
+    float* __restrict__ tile = s_c + grp * TS;               // this group's 4G values, label-major
+    if (gl == 0) tile[4 * G] = INFINITY;
+    __syncthreads();
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
     const uint32_t stride = gridDim.x * NPB;
     uint32_t vb = blockIdx.x;
@@ -315,20 +374,18 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ok[r] = t0 + r < K;
-        float D[4], in[3][4], old[3][4];
-        uint32_t mp[3][4];
-        // phase 1: addresses (clamped, always valid); phase 2: ALL loads as raw 8/16-byte words; phase 3: unpack.
-        // Keeping the loads free of conversions lets them issue back to back under one wait.
-        const uint32_t da = ok[0] ? min(p0 + t0, cost_len - 4u) : 0u, dsh = ok[0] ? (p0 + t0 - da) : 0u;   // dsh > 0 only at the very end of the array
-        uint32_t a_in[3], a_out[3], a_map[3], kj3[3]; bool ident3[3];
+        // phase 1: addresses (always valid); phase 2: ALL loads as raw 8/16-byte words, issued back to back under
+        // one wait (a load under a divergent branch would get its own exec region and s_waitcnt); phase 3: unpack.
+        const uint32_t da = ok[0] ? p0 + t0 : 0u;
+        uint32_t a_in[3], a_out[3], a_map[3], kj3[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const uint32_t kjf = node_ok ? cur.kj[d] : 0u;
-            kj3[d] = kjf & ~IDENT; ident3[d] = (kjf & IDENT) != 0u;
-            const bool i0 = ok[0] && kj3[d] != 0u, o0 = t0 < kj3[d];
-            a_in[d] = i0 ? cur.in_off[d] + t0 : 0u;                 // multiples of 4 elements: 8-byte aligned
-            a_out[d] = o0 ? cur.out_off[d] + t0 : 0u;
-            a_map[d] = (o0 && !ident3[d]) ? cur.out_off[d] + t0 : 0u;
+            kj3[d] = kjf & ~IDENT;
+            const bool o0 = t0 < kj3[d];
+            a_in[d] = (ok[0] && kj3[d] != 0u) ? cur.in_off[d] + t0 : t0;       // t0 < MSG_BASE: the zero run
+            a_out[d] = o0 ? cur.out_off[d] + t0 : t0;
+            a_map[d] = (o0 && !(kjf & IDENT)) ? cur.out_off[d] + t0 : t0;      // t0 < MSG_BASE: the identity run
         }
         const f32x4_a4 dv = *reinterpret_cast<const f32x4_a4*>(cost + da);
         uint2 r_in[3], r_old[3], r_map[3];
@@ -338,77 +395,59 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             if (DAMP) r_old[d] = *reinterpret_cast<const uint2*>(mo + a_out[d]); else r_old[d] = make_uint2(0u, 0u);
             r_map[d] = *reinterpret_cast<const uint2*>(map + a_map[d]);
         }
-        {
-            const float dd[4] = {dv.x, dv.y, dv.z, dv.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const uint32_t q = r + dsh; D[r] = (ok[r] && q < 4u) ? (q == 0 ? dd[0] : q == 1 ? dd[1] : q == 2 ? dd[2] : dd[3]) : 0.0f; }
-        }
-        bool any_gather = false;
+        const float D[4] = {dv.x, dv.y, dv.z, dv.w};
+        float in[3][4];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const uint32_t w_in[4] = {r_in[d].x & 0xFFFFu, r_in[d].x >> 16, r_in[d].y & 0xFFFFu, r_in[d].y >> 16};
-            const uint32_t w_old[4] = {r_old[d].x & 0xFFFFu, r_old[d].x >> 16, r_old[d].y & 0xFFFFu, r_old[d].y >> 16};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                in[d][r] = (ok[r] && kj3[d] != 0u) ? (float)__builtin_bit_cast(msg_t, (unsigned short)w_in[r]) : 0.0f;
-                old[d][r] = (float)__builtin_bit_cast(msg_t, (unsigned short)w_old[r]);   // only used where t < kj
-            }
-            mp[d][0] = ident3[d] ? t0 : (r_map[d].x & 0xFFFFu); mp[d][1] = ident3[d] ? t0 + 1 : (r_map[d].x >> 16);
-            mp[d][2] = ident3[d] ? t0 + 2 : (r_map[d].y & 0xFFFFu); mp[d][3] = ident3[d] ? t0 + 3 : (r_map[d].y >> 16);
-            any_gather = any_gather || (!ident3[d] && kj3[d] != 0u);
+            for (int r = 0; r < 4; ++r) in[d][r] = (float)__builtin_bit_cast(msg_t, (unsigned short)w_in[r]);
         }
-        // decode: first argmin_t of b[t] = D[t] + rho * S[t]
-        {
-            float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+        // decode: first argmin_t of b[t] = D[t] + rho * S[t] -- the group minimum, then the smallest label attaining it
+        // (== the sequential "first minimum": comparisons are exact, +0 == -0 in both formulations)
+        float bm[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
-                const float b = D[r] + rho * S;
-                const bool take = ok[r] && b < bb;            // ascending t within a lane: first minimum kept
-                bb = take ? b : bb; bt = take ? t0 + r : bt;
-            }
-            group_argmin<G>(bb, bt);
-            if (gl == 0 && node_ok) {
-                if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
-                else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
-            }
+        for (int r = 0; r < 4; ++r) {
+            const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
+            const float b = D[r] + rho * S;
+            bm[r] = ok[r] ? b : INFINITY;
         }
-        const bool wave_gather = __ballot(any_gather) != 0ull;   // wave-uniform
+        const float gm = group_min_fused<G>(fminf(fminf(bm[0], bm[1]), fminf(bm[2], bm[3])));
+        uint32_t bt = (bm[3] == gm) ? t0 + 3u : 0xFFFFFFFFu;
+        bt = (bm[2] == gm) ? t0 + 2u : bt; bt = (bm[1] == gm) ? t0 + 1u : bt; bt = (bm[0] == gm) ? t0 : bt;
+        bt = group_min_fused<G>(bt);                          // every lane of the group holds the winner
+        // label and unary of the decoded state (all the energy / ICM kernels need of a neighbour): loaded by every
+        // lane (same address inside a group), consumed by the store at the end of the iteration
+        const uint32_t pa = (bt < K) ? p0 + bt : 0u;          // bt < K whenever K > 0
+        const uint32_t dec_view = view_id[pa];
+        const float dec_cost = cost[pa];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
-            float c[4];
-            float cmin = INFINITY;
+            float c[4], cm[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float oth = (0.0f + in[a][r]) + in[b2][r];
                 c[r] = (D[r] + rho * oth) - omr * in[d][r];
-                cmin = ok[r] ? fminf(cmin, c[r]) : cmin;
+                cm[r] = ok[r] ? c[r] : INFINITY;
             }
-            cmin = group_min<G>(cmin);
-            const uint32_t kj = kj3[d], oo = cur.out_off[d];
-            const bool ident = ident3[d];
-            float cp[4] = {c[0], c[1], c[2], c[3]};          // identical label lists: position p == own label
-            if (wave_gather) {
-                *reinterpret_cast<float4*>(&s_c[threadIdx.x][0]) = make_float4(c[0], c[1], c[2], c[3]);
-                const float* __restrict__ tile = &s_c[gbase][0];   // this group's G x 4 values, label-major
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = tile[mp[d][r] & (uint32_t)(4 * G - 1)];
-                    cp[r] = ident ? cp[r] : v;
-                }
-            }
+            const float cmin = group_min_fused<G>(fminf(fminf(cm[0], cm[1]), fminf(cm[2], cm[3])));
+            *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0], c[1], c[2], c[3]);
+            const uint32_t mp[4] = {r_map[d].x & 0xFFFFu, r_map[d].x >> 16, r_map[d].y & 0xFFFFu, r_map[d].y >> 16};
+            const uint32_t w_old[4] = {r_old[d].x & 0xFFFFu, r_old[d].x >> 16, r_old[d].y & 0xFFFFu, r_old[d].y >> 16};
             msg4_t w;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float raw = (mp[d][r] == (uint32_t)MAP_NONE) ? lam : fminf(cp[r] - cmin, lam);
-                w.v[r] = msg_pack(DAMP ? (raw * oma + old[d][r] * alpha) : raw);
+                const float cp = tile[min(mp[r], (uint32_t)(4 * G))];          // MAP_NONE -> the +inf slot
+                const float raw = fminf(cp - cmin, lam);
+                const float old = (float)__builtin_bit_cast(msg_t, (unsigned short)w_old[r]);
+                w.v[r] = msg_pack(DAMP ? (raw * oma + old * alpha) : raw);
             }
-            if (t0 + 3u < kj) *reinterpret_cast<msg4_t*>(mn + oo + t0) = w;      // one 8-byte store
-            else {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) if (t0 + r < kj) mn[oo + t0 + r] = w.v[r];
-            }
+            if (t0 < kj3[d]) *reinterpret_cast<msg4_t*>(mn + cur.out_off[d] + t0) = w;      // one 8-byte store (runs are padded)
+        }
+        if (gl == 0 && node_ok) {
+            /* K == 0: the single label 0 with unary 1 (view_selection.cpp:50-51,70-71) */
+            sel[i] = (K > 0u) ? bt : 0u; lab[i] = (K > 0u) ? dec_view + 1u : 0u; selcost[i] = (K > 0u) ? dec_cost : 1.0f;
         }
     }
 }
@@ -681,16 +720,27 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemcpyAsync(&h[0], in_off.p + E, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipMemcpyAsync(&h[1], maxes, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
-    ctx->m_total = h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
+    ctx->m_total = (uint64_t)MSG_BASE + h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
+    if (ctx->m_total >= 0xFFFFFFF0ull) throw StatusError(MVS_ERR_UNSUPPORTED, "message array exceeds 2^32 elements");
     if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
-    ctx->m_map.ensure(ctx->m_total + 1); ctx->m_ident.ensure((size_t)E + 1);
+    ctx->m_map.ensure(ctx->m_total + 8); ctx->m_ident.ensure((size_t)E + 1);
+    MVS_HIP(hipMemsetAsync(ctx->m_map.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // run padding is read (and ignored): keep it defined
+    hipLaunchKernelGGL(mrf_identity_kernel, dim3(1), dim3(MSG_BASE), 0, s, ctx->m_map.p); MVS_LAUNCH_CHECK();   // map[t] = t for t < MSG_BASE
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
     if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p); MVS_LAUNCH_CHECK(); }
     ctx->m_desc.ensure((size_t)F + 1);
     if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
-    ctx->m_msg_a.ensure(ctx->m_total + 1); ctx->m_msg_b.ensure(ctx->m_total + 1);
-    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1) * sizeof(uint16_t), s));   // binary16 zeros
-    MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 1) * sizeof(uint16_t), s));
+    ctx->m_msg_a.ensure(ctx->m_total + 8); ctx->m_msg_b.ensure(ctx->m_total + 8);
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // binary16 zeros, incl. the reserved zero run
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));
+    // the sweep reads unaries with unclamped 16-byte loads: a caller-owned cost array (mvs_ctx_costs_upload with device
+    // pointers) is copied into the context's own buffer, which always has slack behind the last element
+    if (ctx->r_cost != ctx->csr_cost.p && ctx->csr_nnz) {
+        ctx->csr_cost.ensure(ctx->csr_nnz + 8);
+        MVS_HIP(hipMemcpyAsync(ctx->csr_cost.p, ctx->r_cost, ctx->csr_nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ctx->r_cost = ctx->csr_cost.p;
+    }
+    if (ctx->r_cost == ctx->csr_cost.p && ctx->csr_cost.cap >= ctx->csr_nnz + 8) MVS_HIP(hipMemsetAsync(ctx->csr_cost.p + ctx->csr_nnz, 0, 8 * sizeof(float), s));
     MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
     ctx->m_sel.ensure((size_t)F + 1); ctx->m_best_sel.ensure((size_t)F + 1); ctx->m_sel2.ensure((size_t)F + 1); ctx->m_cand.ensure((size_t)F + 1); ctx->m_gain.ensure((size_t)F + 1);
     ctx->m_lab.ensure((size_t)F + 1); ctx->m_best_lab.ensure((size_t)F + 1); ctx->m_cost.ensure((size_t)F + 1); ctx->m_best_cost.ensure((size_t)F + 1);
@@ -792,8 +842,7 @@ static void launch_sweep4_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t n
     unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
     blocks = std::max(1u, std::min(need, blocks));
     if (blocks > 8) blocks &= ~7u;
-    const uint32_t cost_len = (uint32_t)ctx->csr_nnz;
-#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha, cost_len
+#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
     if (alpha != 0.0f) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false>), SWEEP4_ARGS); }
     else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, false>), SWEEP4_ARGS); }
 #undef SWEEP4_ARGS

@@ -59,6 +59,9 @@ def renumber_faces(faces, normals, adj_ptr, adj, perm):
     return np.ascontiguousarray(faces[perm]), np.ascontiguousarray(normals[perm]), new_ptr, np.ascontiguousarray(new_adj), inv
 
 
+MSG_BASE = 256   # == MVS_MRF_MSG_BASE (include/mvs_viewsel.h): first real element of the message arrays
+
+
 def equal_parts(n, parts):
     return np.array([(n * p) // parts for p in range(parts + 1)], dtype=np.uint32)
 
@@ -84,6 +87,7 @@ class HaloPlan:
         size = np.where(valid, K[dst], 0)                      # message elements per directed edge
         padded = (size + 3) & ~3                               # runs are padded to a multiple of 4 elements in HBM (k_mrf.hip)
         in_off = np.zeros(len(size) + 1, dtype=np.int64); in_off[1:] = np.cumsum(padded)
+        in_off += MSG_BASE                                     # the library reserves [0, MSG_BASE) (zero / identity run)
         if in_off[-1] >= 2 ** 32:
             raise ValueError("message array exceeds 2^32 words")
         pb = np.asarray(part_begin, dtype=np.int64)

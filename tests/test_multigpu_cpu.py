@@ -69,6 +69,7 @@ class _FakeOps:
         self.valid = (K[dst] > 0) & (K[self.adj] > 0)
         size = np.where(self.valid, K[dst], 0)
         self.in_off = np.zeros(len(size) + 1, dtype=np.int64); self.in_off[1:] = np.cumsum((size + 3) & ~3)   # padded runs, as the library
+        self.in_off += G.MSG_BASE                                      # reserved zero / identity run
         self.size = size
         self.rev = np.zeros(len(size), dtype=np.int64)
         for e in range(len(size)):
@@ -204,3 +205,10 @@ def test_stop_rule_is_the_library_rule():
     hist = [2 ** 64 - 1, 1000 << 32, 995 << 32, 994 << 32, 993 << 32]
     assert not G.stop_rule(hist, 2, p)
     assert G.stop_rule(hist, 4, p) == ((995 << 32) - (993 << 32) < float(np.float32(0.01)) * (995 << 32))
+
+
+def test_message_base_matches_the_header():
+    import re
+    from conftest import ROOT
+    h = open(os.path.join(ROOT, "include", "mvs_viewsel.h")).read()
+    assert int(re.search(r"#define MVS_MRF_MSG_BASE (\d+)u", h).group(1)) == G.MSG_BASE
