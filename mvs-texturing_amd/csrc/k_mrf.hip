@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restri
 // LDS operations of a wave execute in order and a lane group never spans waves, so the tile needs no barrier.
 struct alignas(8) msg4_t { msg_t v[4]; };
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-template <int G, bool DAMP, bool XCD>
+template <int G, bool DAMP, bool XCD, bool LATE_OLD>
 __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                          const uint16_t* __restrict__ map, const msg_t* __restrict__ mo, msg_t* __restrict__ mn,
                                                          uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             r_in[d] = *reinterpret_cast<const uint2*>(mo + a_in[d]);
-            if (DAMP) r_old[d] = *reinterpret_cast<const uint2*>(mo + a_out[d]); else r_old[d] = make_uint2(0u, 0u);
             r_map[d] = *reinterpret_cast<const uint2*>(map + a_map[d]);
+            if (!LATE_OLD) { if (DAMP) r_old[d] = *reinterpret_cast<const uint2*>(mo + a_out[d]); else r_old[d] = make_uint2(0u, 0u); }
         }
         const float D[4] = {dv.x, dv.y, dv.z, dv.w};
         float in[3][4];
@@ -416,6 +416,14 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         uint32_t bt = (bm[3] == gm) ? t0 + 3u : 0xFFFFFFFFu;
         bt = (bm[2] == gm) ? t0 + 2u : bt; bt = (bm[1] == gm) ? t0 + 1u : bt; bt = (bm[0] == gm) ? t0 : bt;
         bt = group_min_fused<G>(bt);                          // every lane of the group holds the winner
+        if (LATE_OLD) {
+            // The previous outgoing message of edge (i -> j) is the run node j reads as "in" in this same sweep.  Issued
+            // only now -- after this block's own "in" loads have landed (the decode above consumed them) -- the read hits
+            // the CU's L1 / the XCD's L2 whenever j is swept by this block too, instead of racing the first fetch to HBM.
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { if (DAMP) r_old[d] = *reinterpret_cast<const uint2*>(mo + a_out[d]); else r_old[d] = make_uint2(0u, 0u); }
+        }
         // label and unary of the decoded state (all the energy / ICM kernels need of a neighbour): loaded by every
         // lane (same address inside a group), consumed by the store at the end of the iteration
         const uint32_t pa = (bt < K) ? p0 + bt : 0u;          // bt < K whenever K > 0
@@ -835,7 +843,7 @@ static void launch_sweep4_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t n
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0; hipDeviceProp_t prop;
-        MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep4_kernel<G, true, true>, 256, 0));
+        MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep4_kernel<G, true, true, true>, 256, 0));
         MVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
         resident = std::max(1, per_cu) * prop.multiProcessorCount;
     }
@@ -843,8 +851,10 @@ static void launch_sweep4_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t n
     blocks = std::max(1u, std::min(need, blocks));
     if (blocks > 8) blocks &= ~7u;
 #define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
-    if (alpha != 0.0f) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false>), SWEEP4_ARGS); }
-    else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, false>), SWEEP4_ARGS); }
+    if (alpha != 0.0f) {
+        if (ctx->mrf_late_old) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, true>), SWEEP4_ARGS); }
+        else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, false>), SWEEP4_ARGS); }
+    } else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, false, false>), SWEEP4_ARGS); }
 #undef SWEEP4_ARGS
 }
 
