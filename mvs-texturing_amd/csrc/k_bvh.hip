@@ -34,9 +34,14 @@ __global__ void bbox_kernel(const float* __restrict__ verts, uint32_t n_verts, u
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_verts; v += gridDim.x * blockDim.x)
         for (int a = 0; a < 3; ++a) { const float x = verts[3 * (size_t)v + a]; lo[a] = fminf(lo[a], x); hi[a] = fmaxf(hi[a], x); }
+    // same-address atomics serialise (~12 ns each): skip the ones that cannot move the bound any more
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&box[a], f2ord(lo[a])); atomicMax(&box[3 + a], f2ord(hi[a])); }
+        if ((threadIdx.x & 63) == 0) {
+            const uint32_t l = f2ord(lo[a]), h = f2ord(hi[a]);
+            if (l < __hip_atomic_load(&box[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&box[a], l);
+            if (h > __hip_atomic_load(&box[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&box[3 + a], h);
+        }
     }
 }
 
@@ -487,7 +492,7 @@ void build_bvh(mvs_ctx* ctx) {
     uint32_t* box = (uint32_t*)ctx->scene_box.p;
     const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 2048u)), dim3(256), 0, s, ctx->d_verts, NV, box);
+    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 512u)), dim3(256), 0, s, ctx->d_verts, NV, box);
     MVS_LAUNCH_CHECK();
     ctx->morton_k.ensure(std::max<size_t>(F, NV)); ctx->morton_k2.ensure(std::max<size_t>(F, NV)); ctx->morton_v.ensure(std::max<size_t>(F, NV)); ctx->morton_v2.ensure(F);
     hipLaunchKernelGGL(morton_kernel, dim3((F + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, F, box, ctx->morton_k.p, ctx->morton_v.p);

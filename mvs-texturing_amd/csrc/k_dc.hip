@@ -308,7 +308,8 @@ __global__ void max_kernel(const float* __restrict__ q, size_t n, uint32_t* __re
     float m = 0.0f;  // :278 max_quality = 0.0f
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = smax(m, q[i]);
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));  // qualities are > 0: uint order = float order
+    // qualities are > 0: uint order = float order; same-address atomics serialise, so only a wave that can raise the maximum issues one
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, __float_as_uint(m));
 }
 
 // Histogram::add_value (histogram.cpp:27-35) with LDS-privatised integer bins; hist[HIST_BINS] = num_values
@@ -324,18 +325,41 @@ __global__ void __launch_bounds__(1024) hist_kernel(const float* __restrict__ q,
 }
 
 // Histogram::get_approx_percentile (histogram.cpp:49-63)
-__global__ void percentile_kernel(const uint32_t* __restrict__ hist, const float* __restrict__ max_q, float percentile, float* __restrict__ out) {
-    if (blockIdx.x || threadIdx.x) return;
+// Histogram::get_approx_percentile (histogram.cpp:49-63): the reference walks the bins and returns the previous bin's
+// bound as soon as float(num) / num_values > percentile, where num = counts of the bins before the current one.
+// Parallel form: exclusive prefix sum of the counts, smallest bin index whose test fires, same float expressions.
+__global__ void __launch_bounds__(1024) percentile_kernel(const uint32_t* __restrict__ hist, const float* __restrict__ max_q, float percentile, float* __restrict__ out) {
+    constexpr uint32_t PER = (HIST_BINS + 1023u) / 1024u;
+    __shared__ uint32_t s_sum[1024];
+    __shared__ uint32_t s_first;
+    const uint32_t t = threadIdx.x, b0 = t * PER;
+    uint32_t local = 0;
+    for (uint32_t k = 0; k < PER; ++k) if (b0 + k < HIST_BINS) local += hist[b0 + k];
+    s_sum[t] = local;
+    if (t == 0) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {                     // inclusive Hillis-Steele scan over the thread sums
+        const uint32_t v = (t >= o) ? s_sum[t - o] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
     const float minv = 0.0f, maxv = *max_q;
     const int num_values = (int)hist[HIST_BINS];
-    int num = 0;
-    float upper_bound = minv;
-    for (uint32_t i = 0; i < HIST_BINS; ++i) {
-        if ((float)num / (float)num_values > percentile) { *out = upper_bound; return; }
-        num += (int)hist[i];
-        upper_bound = ((float)i / (float)(HIST_BINS - 1)) * (maxv - minv) + minv;
+    int num = (int)(s_sum[t] - local);                              // counts of all bins before b0
+    uint32_t first = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < PER && b0 + k < HIST_BINS; ++k) {
+        if (first == 0xFFFFFFFFu && (float)num / (float)num_values > percentile) first = b0 + k;
+        num += (int)hist[b0 + k];
     }
-    *out = maxv;
+    if (first != 0xFFFFFFFFu) atomicMin(&s_first, first);
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t i = s_first;
+        if (i == 0xFFFFFFFFu) *out = maxv;
+        else if (i == 0u) *out = minv;
+        else *out = ((float)(i - 1u) / (float)(HIST_BINS - 1)) * (maxv - minv) + minv;
+    }
 }
 
 // cost = 1 - min(1, quality / percentile)  (calculate_data_costs.cpp:295-297)
@@ -540,7 +564,7 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     hipStream_t s = ctx->stream;
     ctx->pctl.ensure(4);
     Prof pr(ctx, "dc_post");
-    hipLaunchKernelGGL(percentile_kernel, dim3(1), dim3(64), 0, s, ctx->hist.p, ctx->max_q.p, 0.995f, ctx->pctl.p);
+    hipLaunchKernelGGL(percentile_kernel, dim3(1), dim3(1024), 0, s, ctx->hist.p, ctx->max_q.p, 0.995f, ctx->pctl.p);
     MVS_LAUNCH_CHECK();
     if (ctx->csr_nnz) {
         hipLaunchKernelGGL(cost_kernel, dim3(2048), dim3(256), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, ctx->pctl.p, ctx->csr_cost.p);

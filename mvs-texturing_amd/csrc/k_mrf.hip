@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t group_min_fused(uint32_t v) {
 
 // ---- setup ----
 __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
-                                uint32_t F, uint32_t* __restrict__ size, uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
+                                uint32_t F, uint32_t pad_mask, uint32_t* __restrict__ size, uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t k = 0, deg = 0;
     if (i < F) {
@@ -132,11 +132,15 @@ __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint
         for (uint32_t e = e0; e < e1; ++e) {
             const uint32_t j = adj[e];
             const uint32_t kj = col_ptr[j + 1] - col_ptr[j];
-            size[e] = (k > 0 && kj > 0) ? ((k + 3u) & ~3u) : 0u;   // runs padded to a multiple of 4 elements: 8-byte aligned quads
+            size[e] = (k > 0 && kj > 0) ? ((k + pad_mask) & ~pad_mask) : 0u;   // runs padded to a multiple of 4 (8-byte quads) or 16 elements (32-byte sectors)
         }
     }
     for (int o = 32; o > 0; o >>= 1) { k = max(k, (uint32_t)__shfl_xor(k, o, 64)); deg = max(deg, (uint32_t)__shfl_xor(deg, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&maxes[0], k); atomicMax(&maxes[1], deg); }
+    // same-address atomics serialise (~12 ns each): only waves that can still raise a maximum issue one
+    if ((threadIdx.x & 63) == 0) {
+        if (k > __hip_atomic_load(&maxes[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxes[0], k);
+        if (deg > __hip_atomic_load(&maxes[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxes[1], deg);
+    }
 }
 
 __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
@@ -527,15 +531,26 @@ __global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restr
             cuts += (lj != 0u && lj != li);
         }
     }
-    // one atomic pair per block (same-address atomics serialise): wave shuffle, then LDS across the 4 waves
+    // no atomics (same-address atomics serialise at ~12 ns each): one partial pair per block, summed by
+    // mrf_energy_reduce_kernel; integer sums, so the result does not depend on the launch geometry
     __shared__ unsigned long long su[4], sc[4];
     for (int o = 32; o > 0; o >>= 1) { unary += __shfl_xor(unary, o, 64); cuts += __shfl_xor(cuts, o, 64); }
     if ((threadIdx.x & 63) == 0) { su[threadIdx.x >> 6] = unary; sc[threadIdx.x >> 6] = cuts; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long u = su[0] + su[1] + su[2] + su[3], c = sc[0] + sc[1] + sc[2] + sc[3];
-        atomicAdd(&out[0], u + (c << 32)); atomicAdd(&out[1], c);
+        out[2 * blockIdx.x] = u + (c << 32); out[2 * blockIdx.x + 1] = c;
     }
+}
+__global__ void __launch_bounds__(256) mrf_energy_reduce_kernel(const unsigned long long* __restrict__ partial, uint32_t n_blocks,
+                                                                unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
+    unsigned long long e = 0, c = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 256u) { e += partial[2 * b]; c += partial[2 * b + 1]; }
+    __shared__ unsigned long long su[4], sc[4];
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { su[threadIdx.x >> 6] = e; sc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = su[0] + su[1] + su[2] + su[3]; out[1] = sc[0] + sc[1] + sc[2] + sc[3]; }
 }
 
 // ---- ICM polish: G lanes per node over its labels ----
@@ -719,7 +734,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 8 * sizeof(uint32_t), s));
     MVS_HIP(hipMemsetAsync(ctx->m_size.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
     const unsigned nb = (F + 255) / 256;
-    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_size.p, maxes); MVS_LAUNCH_CHECK(); }
+    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), ctx->m_size.p, maxes); MVS_LAUNCH_CHECK(); }
     // in_off = exclusive scan of the sizes (E + 1 entries so that in_off[E] = total)
     DBuf<uint32_t>& in_off = ctx->m_sel2;  // temporary home, re-ensured below
     in_off.ensure(std::max<size_t>((size_t)E + 2, (size_t)F + 2));
@@ -764,7 +779,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         MVS_HIP(hipMemcpyAsync(ctx->m_best_cost.p, ctx->m_cost.p, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     MVS_HIP(hipMemsetAsync(ctx->m_gain.p, 0, ((size_t)F + 1) * sizeof(float), s));
-    ctx->m_energy.ensure(4);
+    ctx->m_energy.ensure(4 + 2 * 2048);
     ctx->m_flip = false;
     // device-side solver state: sweep 0, best = hist[0] = 2^64 - 1
     ctx->m_state.ensure(1); ctx->m_hist.ensure((size_t)std::max(params->max_sweeps, 0) + 2);
@@ -896,13 +911,16 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
 // energy of the current decode (best == false) or of the best labeling over nodes [nb0, ne0)
 // -> ctx->m_energy (device, 2 x u64), asynchronous
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0) {
-    MVS_HIP(hipMemsetAsync(ctx->m_energy.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    if (ne0 > nb0) {
-        const unsigned blocks = std::min<unsigned>((ne0 - nb0 + 255) / 256, 1024u);
+    const unsigned blocks = ne0 > nb0 ? std::min<unsigned>((ne0 - nb0 + 255) / 256, 2048u) : 0u;
+    ctx->m_energy.ensure(4 + 2 * 2048);
+    unsigned long long* partial = ctx->m_energy.p + 4;
+    if (blocks) {
         hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj,
-                           best ? ctx->m_best_lab.p : ctx->m_lab.p, best ? ctx->m_best_cost.p : ctx->m_cost.p, nb0, ne0, ctx->m_energy.p);
+                           best ? ctx->m_best_lab.p : ctx->m_lab.p, best ? ctx->m_best_cost.p : ctx->m_cost.p, nb0, ne0, partial);
         MVS_LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, ctx->m_energy.p);
+    MVS_LAUNCH_CHECK();
 }
 
 void mrf_keep_best(mvs_ctx* ctx) {
