@@ -163,7 +163,7 @@ struct mvs_ctx {
     mvs::DBuf<uint16_t> m_msg_a, m_msg_b;   // messages as IEEE binary16 bit patterns, double buffered
     mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
     mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best
-    mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved;
+    mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved; mvs::DBuf<uint8_t> m_dirty; bool icm_dirty_valid = false;
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0; bool m_flip = false;
     mvs_mrf_params m_params{};
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring

@@ -593,7 +593,8 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
 template <int G>
 __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                                 const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
-                                                                uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand) {
+                                                                uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand,
+                                                                uint8_t* __restrict__ dirty /* null = evaluate every node */) {
     constexpr int NPB = 256 / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const uint32_t stride = gridDim.x * NPB;
@@ -602,7 +603,11 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
     if (i < node_end) nd = desc[i];
     const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
-        const bool node_ok = i < node_end;
+        bool node_ok = i < node_end;
+        // a node's gain depends on its column, its own label and its neighbours' labels only: unless one of those
+        // changed in the last apply (dirty flag), the stored gain / candidate are still the values this loop would compute
+        if (dirty && node_ok) { node_ok = dirty[i] != 0; }
+        if (dirty && __ballot(node_ok) == 0ull) { if (i + stride < node_end) nd = desc[i + stride]; continue; }   // wave-uniform skip (the group shuffles below need all lanes)
         const NodeDesc cur = nd;
         if (i + stride < node_end) nd = desc[i + stride];
         const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
@@ -624,7 +629,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
             if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
             cur_e += __shfl_xor(cur_e, o, G);   // exactly one lane holds a non-zero term (or none: 0)
         }
-        if (gl == 0 && node_ok) { gain[i] = (K > 0) ? (cur_e - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; }
+        if (gl == 0 && node_ok) { gain[i] = (K > 0) ? (cur_e - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; if (dirty) dirty[i] = 0; }
     }
 }
 
@@ -632,7 +637,7 @@ __global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                                             const float* __restrict__ gain, const uint32_t* __restrict__ cand,
                                                             uint32_t* sel, uint32_t* lab, float* selcost,
-                                                            uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved) {
+                                                            uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved, uint8_t* __restrict__ dirty) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     bool mv = false;
     if (i < node_end) {
@@ -653,6 +658,7 @@ __global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __re
     if (mv) {
         const uint32_t p0 = col_ptr[i], t = cand[i];
         sel[i] = t; lab[i] = (uint32_t)view_id[p0 + t] + 1u; selcost[i] = cost[p0 + t];
+        if (dirty) { dirty[i] = 1; for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) dirty[adj[e]] = 1; }   // racing stores of the same value
     }
     const unsigned long long b = __ballot(mv);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(moved, (uint32_t)__popcll(b));
@@ -792,7 +798,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemcpyAsync(ctx->m_state.p, &ctx->h_ring[0], sizeof(init), hipMemcpyHostToDevice, s));
     MVS_HIP(hipMemsetAsync(ctx->m_hist.p, 0xFF, sizeof(unsigned long long), s));
     MVS_HIP(hipStreamSynchronize(s));
-    ctx->steps_issued = 0;
+    ctx->steps_issued = 0; ctx->icm_dirty_valid = false;
 }
 
 // One bookkeeping step (see mrf_step_kernel); energy = device pointer to the (all-reduced) energy pair.
@@ -809,6 +815,7 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
                            ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, F);
         MVS_LAUNCH_CHECK();
     }
+    ctx->icm_dirty_valid = false;   // the best labeling may change
     const uint32_t n = ++ctx->steps_issued, slot = n % mvs_ctx::RING;
     MVS_HIP(hipMemcpyAsync(&ctx->h_ring[slot], ctx->m_state.p, sizeof(mvs_mrf_progress), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipEventRecord(ctx->ring_ev[slot], s));
@@ -925,6 +932,7 @@ void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0) {
 
 void mrf_keep_best(mvs_ctx* ctx) {
     const size_t F = ctx->csr_faces;
+    ctx->icm_dirty_valid = false;
     if (!F) return;
     MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, F * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     MVS_HIP(hipMemcpyAsync(ctx->m_best_lab.p, ctx->m_lab.p, F * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -936,8 +944,17 @@ void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 <= nb0) return;
     const uint32_t K = ctx->m_kmax, n = ne0 - nb0;
     if (ctx->m_degmax <= 3) {
+        // active set (unsharded calls only): after the first full evaluation only nodes whose own or neighbouring label
+        // moved are re-evaluated; sharded callers exchange labels behind the library's back, so they evaluate all
+        uint8_t* dirty = nullptr;
+        if (nb0 == 0 && ne0 == ctx->csr_faces) {
+            ctx->m_dirty.ensure((size_t)ctx->csr_faces + 1);
+            if (!ctx->icm_dirty_valid) MVS_HIP(hipMemsetAsync(ctx->m_dirty.p, 1, (size_t)ctx->csr_faces, ctx->stream));
+            ctx->icm_dirty_valid = true;
+            dirty = ctx->m_dirty.p;
+        } else ctx->icm_dirty_valid = false;
 #define ICM_D(GG) hipLaunchKernelGGL(mrf_icm_gain_desc_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((n + (256 / GG) - 1) / (256 / GG), 256u * 8u))), dim3(256), 0, ctx->stream, \
-                                     ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
+                                     ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p, dirty)
         if (K <= 8) ICM_D(8); else if (K <= 16) ICM_D(16); else if (K <= 48) ICM_D(16); else ICM_D(32);
 #undef ICM_D
         MVS_LAUNCH_CHECK();
@@ -945,6 +962,7 @@ void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     }
 #define ICM_G(GG) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3((n + (256 / GG) - 1) / (256 / GG)), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
                                      ctx->r_adj_ptr, ctx->r_adj, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
+    ctx->icm_dirty_valid = false;
     if (K <= 8) ICM_G(8); else if (K <= 16) ICM_G(16); else if (K <= 32) ICM_G(32); else ICM_G(64);
 #undef ICM_G
     MVS_LAUNCH_CHECK();
@@ -953,7 +971,9 @@ void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, sizeof(uint32_t), ctx->stream));
     if (ne0 <= nb0) return;
     hipLaunchKernelGGL(mrf_icm_apply_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                       ctx->m_gain.p, ctx->m_cand.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, nb0, ne0, ctx->m_moved.p);
+                       ctx->m_gain.p, ctx->m_cand.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, nb0, ne0, ctx->m_moved.p,
+                       (ctx->icm_dirty_valid && nb0 == 0 && ne0 == ctx->csr_faces) ? ctx->m_dirty.p : (uint8_t*)nullptr);
+    if (!(nb0 == 0 && ne0 == ctx->csr_faces)) ctx->icm_dirty_valid = false;
     MVS_LAUNCH_CHECK();
 }
 // labels of nodes [nb0, ne0) of the best labeling into d_labels[0 .. ne0 - nb0); out = {bad, unseen}
