@@ -128,7 +128,7 @@ def main():
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_option("profile", 1)
-    for env, opt in (("MVS_MRF_SHAPE", "mrf_shape"), ("MVS_MRF_UNROLL", "mrf_unroll"), ("MVS_MRF_NT", "mrf_nt"), ("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag")):
+    for env, opt in (("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag")):
         if os.environ.get(env):   # tuning knobs for experiments
             ctx.set_option(opt, int(os.environ[env]))
     if os.environ.get("MVS_RAY_MODE"):
@@ -195,24 +195,36 @@ def main():
     stages = {k: {"ms_per_step": v[0] / max(args.steps, 1), "launches_per_step": v[1] / max(args.steps, 1)} for k, v in prof.items()}
     roof = None
     if "mrf_sweep" in prof and prof["mrf_sweep"][1] > 0:
-        sweep_ms = prof["mrf_sweep"][0] / prof["mrf_sweep"][1]
+        import ctypes as C
+        nph = C.c_uint32(0); ctx.L.mvs_ctx_mrf_num_phases(ctx.h, C.byref(nph)); n_phases = max(int(nph.value), 1)
+        # one sweep = n_phases launches of the sweep kernel (one per colour class).  The profile span covers a whole
+        # sweep on one GPU and a single phase in the sharded driver.
+        spans = prof["mrf_sweep"][1]
+        sweeps_run = spans if world == 1 else spans / n_phases
+        sweep_ms = prof["mrf_sweep"][0] / sweeps_run
+        launch_ms = sweep_ms / n_phases
         nf_own = int(part[rank + 1] - part[rank])
         nnz_own = int(dc["nnz"])                             # entries of the nodes this rank sweeps
         if nnz_own:
             # Algorithmic bytes per sweep (labels u16 + unary f32, every message read once and
             # written once, adjacency, label out) with the messages stored as binary16 in this implementation:
             #   6 nnz + 2 B x 3 nnz x 2 + 12 F = 18 nnz + 12 F.   The survey's fp32-message figure is 30 nnz + 12 F.
+            # Per launch: that figure / n_phases (every node is swept by exactly one of the launches).
             b_sweep = 18.0 * nnz_own + 12.0 * nf_own
             b_survey = 30.0 * nnz_own + 12.0 * nf_own
             ach = b_sweep / (sweep_ms * 1e-3) / 1e9
             roof = {"kernel": "mrf_sweep4_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sweep_ms, "algorithmic_bytes_per_launch": b_sweep,
-                    "note": "messages are binary16: algorithmic bytes = 18 nnz + 12 F; with the survey's fp32-message formula "
-                            "(30 nnz + 12 F = %.3e B) the same launch time reads %.0f GB/s" % (b_survey, b_survey / (sweep_ms * 1e-3) / 1e9)}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": b_sweep / n_phases,
+                    "launches_per_sweep": n_phases, "sweep_ms": sweep_ms,
+                    "note": "a sweep is %d launches (one per colour class of the adjacency graph); per-launch figures are the sweep's "
+                            "divided by %d.  Messages are binary16: algorithmic bytes per sweep = 18 nnz + 12 F; with the survey's "
+                            "fp32-message formula (30 nnz + 12 F = %.3e B) the same time reads %.0f GB/s"
+                            % (n_phases, n_phases, b_survey, b_survey / (sweep_ms * 1e-3) / 1e9)}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    roof["traffic"] = json.load(open(pmc)).get("mrf_sweep4_kernel", {}).get("config%d" % args.config)
+                    t = json.load(open(pmc)).get("mrf_sweep4_kernel", {}).get("config%d" % args.config)   # bytes per SWEEP (all colour launches)
+                    roof["traffic"] = t / n_phases if t else None
                 except Exception:
                     pass
 

@@ -79,12 +79,13 @@ typedef struct {
 
 /* Solver controls.  The reference hard-codes its mapMAP configuration
  * (view_selection.cpp:84,103-115); mapMAP is replaced by a GPU-resident
- * tree-reweighted max-product sweep + monotone ICM polish, whose
- * knobs are below.  mvs_mrf_default_params gives the shipped defaults. */
+ * tree-reweighted max-product solver -- colour-phased Gauss-Seidel sweeps + monotone ICM polish --
+ * whose knobs are below.  mvs_mrf_default_params gives the shipped defaults
+ * (200 / 20 / 5 / 0.002 / 0.3 / 0.8 / 50). */
 typedef struct {
     int32_t max_sweeps;
     int32_t min_sweeps;
-    int32_t window;         /* cf. StopWhenReturnsDiminish(5, 0.01)   view_selection.cpp:84 */
+    int32_t window;         /* stop when the best energy gained < min_improvement over `window` sweeps; cf. StopWhenReturnsDiminish(5, 0.01) view_selection.cpp:84 */
     float min_improvement;
     float damping;
     float rho;
@@ -263,11 +264,11 @@ typedef struct mvs_mrf_progress {
 /* ---- multi-GPU MRF building blocks (one context per rank; DESIGN.md "Multi-GPU") ----
  * Every rank holds the FULL cost table and adjacency (288 GB of HBM make the
  * metadata cheap to replicate) and owns a contiguous node range.  The sweep is
- * synchronous (Jacobi), so a node's update depends only on the previous sweep:
- * results are bit-identical for any partition.  One sweep on rank r:
- *   mrf_sweep(own range) -> mrf_gather(MSG | LAB, boundary index lists) ->
- *   RCCL all-to-all by the driver -> mrf_scatter -> mrf_energy(own range) ->
- *   all-reduce of the two u64.  The index lists are planned on the host from
+ * colour-phased: within a phase a node's update depends only on nodes of other colours, which are
+ * exchanged before their next use: results are bit-identical for any partition.  One sweep on rank r:
+ *   for every colour phase: mrf_sweep_phase(own range) -> mrf_gather(MSG | LAB, boundary index lists) ->
+ *   RCCL all-to-all by the driver -> mrf_scatter;  then mrf_energy(own range) ->
+ *   all-reduce of the two u64 -> mrf_step.  The index lists are planned on the host from
  * col_ptr + adjacency alone (mvs-texturing_amd/multigpu.py). */
 /* solver arrays addressable by the halo exchange: messages, decoded labels (view + 1) of the current
  * sweep, ICM gains, labels of the best labeling so far */
@@ -279,8 +280,16 @@ enum { MVS_MRF_MSG = 0, MVS_MRF_LAB = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_LAB = 3,
        MVS_MRF_MSG_LAB = 4 };
 mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
                              const mvs_mrf_params* params);
-/* one sweep over nodes [node_begin, node_end): reads the current messages, writes the next ones, flips */
+/* The sweep is colour-phased Gauss-Seidel: the adjacency graph is coloured at setup (n_phases colours, each an
+ * independent set) and one sweep = for phase in 0 .. n_phases-1: the nodes of that colour recompute their outgoing
+ * messages in place.  A sharded driver runs the phases itself and exchanges the halo after each one. */
+mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases);
+mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t node_begin, uint32_t node_end);
+/* all phases in turn over nodes [node_begin, node_end) (no exchange in between: unsharded use) */
 mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
+/* message layout for the halo planner: in_off_host[e] = first message element of the run of directed edge e
+ * (adjacency-list order, e < adj_ptr[n_faces]); runs are laid out in (colour, face id) node order */
+mvs_status mvs_ctx_mrf_layout(mvs_ctx* ctx, uint32_t* in_off_host, uint64_t n_edges);
 /* dst[k] = array[idx[k]] / array[idx[k]] = src[k] in 4-byte exchange words (message elements are binary16 and travel
  * zero-extended); MSG = the buffer the last sweep wrote */
 mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, void* dst_device);

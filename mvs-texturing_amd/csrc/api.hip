@@ -76,7 +76,7 @@ const char* mvs_status_string(mvs_status s) {
 }
 
 void mvs_mrf_default_params(mvs_mrf_params* p) {
-    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 10; p->min_improvement = 0.002f;
+    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
     p->damping = 0.3f; p->rho = 0.8f; p->icm_iters = 50;
 }
 void mvs_default_settings(mvs_settings* s) {  /* settings.h:85-90 */
@@ -139,9 +139,6 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "profile") ctx->profile = value != 0;
     else if (n == "ray_mode") ctx->ray_mode = (int)value;
     else if (n == "ray_xcd") ctx->ray_xcd = (int)value;
-    else if (n == "mrf_shape") ctx->mrf_shape = (int)value;
-    else if (n == "mrf_unroll") ctx->mrf_unroll = (int)value;
-    else if (n == "mrf_nt") ctx->mrf_nt = (int)value;
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;
     else if (n == "mrf_lag") ctx->mrf_lag = (int)value;
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;

@@ -86,7 +86,8 @@ struct alignas(16) NodeDesc {   // fast-path (degree <= 3) per-node descriptor, 
     uint32_t out_off[3];      // outgoing message offsets (= in_off of the reverse edges)
     uint32_t kj[3];           // neighbour column lengths (0 = edge not in the model); top bit = identical label lists
     uint32_t nbr[3];          // neighbour node ids (0xFFFFFFFF = none)
-    uint32_t pad_[2];
+    uint32_t id;        // the node (face) this descriptor belongs to: descriptors are stored in (colour, id) order
+    uint32_t pad_;
 };
 static_assert(sizeof(NodeDesc) == 64, "NodeDesc must be 64 bytes");
 
@@ -158,13 +159,16 @@ struct mvs_ctx {
 
     // ---- MRF ----
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
-    mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_shape = 0, mrf_unroll = 1, mrf_nt = 0, mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;
+    mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
-    mvs::DBuf<uint16_t> m_msg_a, m_msg_b;   // messages as IEEE binary16 bit patterns, double buffered
+    mvs::DBuf<uint16_t> m_msg_a;   // messages as IEEE binary16 bit patterns, updated in place (one colour class at a time)
     mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
     mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved; mvs::DBuf<uint8_t> m_dirty; bool icm_dirty_valid = false;
-    uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0; bool m_flip = false;
+    uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0;
+    // colour-phased schedule: colours of the adjacency graph, nodes in (colour, id) order, class boundaries (host copy)
+    mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c; uint32_t m_colours = 0; std::vector<uint32_t> m_colour_begin;
+    uint32_t m_range_nb = 0, m_range_ne = 0; std::vector<uint32_t> m_range_q;   // cached own share of every colour class
     mvs_mrf_params m_params{};
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring
     static constexpr uint32_t RING = 16;

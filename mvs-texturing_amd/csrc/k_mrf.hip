@@ -14,6 +14,7 @@
 // lanes of a group stride over the node's labels; per-edge cavity vectors go
 // through LDS for the label re-alignment gather; min / argmin are wave shuffles.
 #include "ctx.h"
+#include <rocprim/rocprim.hpp>
 
 namespace mvs {
 
@@ -143,6 +144,74 @@ __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint
     }
 }
 
+// ---- colour-phased schedule ----
+// Greedy colouring of the adjacency graph in the order of the keys (hash32(i), i) -- the oracle's mrf_colour -- by
+// Jones-Plassmann rounds: a node colours itself (smallest colour no smaller-key neighbour holds) as soon as all its
+// smaller-key neighbours are coloured.  Larger-key neighbours are necessarily still uncoloured at that moment, so the
+// result equals the sequential greedy colouring whatever the interleaving; only the number of rounds varies.
+__device__ __forceinline__ uint32_t mrf_hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+__device__ __forceinline__ bool mrf_key_less(uint32_t a, uint32_t b) { const uint32_t ha = mrf_hash32(a), hb = mrf_hash32(b); return ha != hb ? ha < hb : a < b; }
+constexpr uint32_t NO_COLOUR = 0xFFFFFFFFu;
+__global__ void mrf_colour_init_kernel(uint32_t* __restrict__ colour, uint32_t* __restrict__ iota, uint32_t F) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < F) { colour[i] = NO_COLOUR; iota[i] = i; }
+}
+__global__ void mrf_colour_round_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, uint32_t F,
+                                        uint32_t* colour, uint32_t* __restrict__ pending) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    if (__hip_atomic_load(colour + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NO_COLOUR) return;
+    unsigned long long used = 0ull;
+    bool ready = true;
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+        const uint32_t j = adj[e];
+        if (j == i || !mrf_key_less(j, i)) continue;
+        const uint32_t cj = __hip_atomic_load(colour + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cj == NO_COLOUR) { ready = false; break; }
+        used |= 1ull << cj;
+    }
+    if (ready) __hip_atomic_store(colour + i, (uint32_t)__builtin_ctzll(~used), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *pending = 1u;                                       // racing stores of the same value
+}
+// colour_begin[c] = first position of colour >= c in the sorted colour array, c = 0 .. 64
+__global__ void mrf_colour_begin_kernel(const uint32_t* __restrict__ sorted, uint32_t F, uint32_t* __restrict__ colour_begin) {
+    const uint32_t c = threadIdx.x;
+    if (c > 64u) return;
+    uint32_t lo = 0, hi = F;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted[mid] < c) lo = mid + 1; else hi = mid; }
+    colour_begin[c] = lo;
+}
+// own share of every colour class: positions of the ids in [nb, ne) inside perm[cb[c], cb[c + 1]) (ids ascending)
+__global__ void mrf_phase_range_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ colour_begin, uint32_t C,
+                                       uint32_t nb, uint32_t ne, uint32_t* __restrict__ out) {
+    const uint32_t c = threadIdx.x;
+    if (c >= C) return;
+    const uint32_t cb = colour_begin[c], ce = colour_begin[c + 1];
+    uint32_t lo = cb, hi = ce;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (perm[mid] < nb) lo = mid + 1; else hi = mid; }
+    out[2 * c] = lo;
+    hi = ce;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (perm[mid] < ne) lo = mid + 1; else hi = mid; }
+    out[2 * c + 1] = lo;
+}
+// message layout: runs in (colour, id) node order, a node's in-edges in list order -> the in-runs a phase reads are contiguous
+__global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ size,
+                                    uint32_t F, uint32_t* __restrict__ nsz) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > F) return;
+    uint32_t t = 0;
+    if (q < F) { const uint32_t i = perm[q]; for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) t += size[e]; }
+    nsz[q] = t;
+}
+__global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ size,
+                                 const uint32_t* __restrict__ noff, uint32_t F, uint32_t* __restrict__ in_off) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= F) return;
+    const uint32_t i = perm[q];
+    uint32_t off = noff[q];
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { in_off[e] = off; off += size[e]; }
+}
+
 __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 uint32_t F, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ size, MrfEdge* __restrict__ edge) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,9 +262,11 @@ __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint1
 // One 48-byte descriptor per node (fast path, degree <= 3): everything a sweep needs to know about
 // the node in a single 3 x 16-byte load instead of the col_ptr -> adj_ptr -> edge[] dependent chain.
 __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
-                                const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ ident, uint32_t F, NodeDesc* __restrict__ desc) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= F) return;
+                                const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm,
+                                uint32_t F, NodeDesc* __restrict__ desc) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // position in the (colour, id) order
+    if (q >= F) return;
+    const uint32_t i = perm[q];
     NodeDesc nd;
     nd.p0 = col_ptr[i]; nd.k = col_ptr[i + 1] - nd.p0;
     const uint32_t e0 = adj_ptr[i], deg = adj_ptr[i + 1] - e0;
@@ -211,126 +282,11 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
         }
         nd.in_off[d] = m.in_off; nd.out_off[d] = m.out_off; nd.kj[d] = m.kj | flag; nd.nbr[d] = nb;
     }
-    nd.pad_[0] = nd.pad_[1] = 0;
-    desc[i] = nd;
+    nd.id = i; nd.pad_ = 0;
+    desc[q] = nd;
 }
 
-// ---- one synchronous sweep; fast path: degree <= 3, K <= G * R ----
-// All global loads of a node (unaries, the 3 incoming messages, the 3 re-alignment maps and, with
-// damping, the 3 previous outgoing messages) are issued up front; the label re-alignment gather
-// c[p] is a ds_bpermute (__shfl) inside the node's lane group: no LDS memory, no barrier.
-// Besides sel (label index) the decode also leaves the label itself (view id + 1) and its unary
-// cost, which is all the energy / ICM kernels need of a neighbour.
-// Blocked layout: lane gl of a node's group owns labels 2*gl and 2*gl + 1, so one 4-byte load brings two
-// binary16 messages (or two u16 map entries); message runs are padded to an even length in HBM.
-// K <= 2 * G.  NT = non-temporal stores; XCD = XCD-aware block remap.  kj's top bit marks an edge whose two
-// label lists are identical: no map load, no re-alignment shuffle.
-struct alignas(4) msg2_t { msg_t a, b; };
-template <int G, bool DAMP, bool NT, bool XCD>
-__global__ void __launch_bounds__(256) mrf_sweep_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                        const uint16_t* __restrict__ map, const msg_t* __restrict__ mo, msg_t* __restrict__ mn,
-                                                        uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
-                                                        uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
-    constexpr int NPB = 256 / G;
-    constexpr uint32_t IDENT = 0x80000000u;
-    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
-    const uint32_t stride = gridDim.x * NPB;
-    // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed; used for speed only), so give every XCD a
-    // CONTIGUOUS eighth of each row: a node and its mesh neighbours (adjacent in Morton order) then share one L2, and
-    // a message read twice per sweep (as "in" by the receiver, as "old" by the sender) is fetched once.
-    uint32_t vb = blockIdx.x;
-    if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    // persistent groups: group g handles nodes g, g + stride, ...; the next node's descriptor is prefetched
-    uint32_t i = node_begin + vb * NPB + grp;
-    const uint32_t last = node_end - 1;                       // node_end > node_begin (checked by the launcher)
-    // All loads below are UNCONDITIONAL with clamped (always valid) addresses and the results are masked
-    // afterwards: a load under a divergent branch gets its own exec-mask region and s_waitcnt, which
-    // serialises the ~12 loads of a node; unconditional loads are issued back to back.
-    NodeDesc nd = desc[min(i, last)];
-    const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;   // uniform trip count (shuffles need all lanes)
-    const uint32_t t0 = 2u * gl, t1 = 2u * gl + 1u;
-    for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
-        const bool node_ok = i < node_end;
-        const NodeDesc cur = nd;
-        nd = desc[min(i + stride, last)];
-        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
-        const bool ok0 = t0 < K, ok1 = t1 < K;
-        float D[2], in[3][2], old[3][2];
-        uint32_t mp[3][2];
-        const float d0 = cost[ok0 ? p0 + t0 : 0u], d1 = cost[ok1 ? p0 + t1 : 0u];
-        D[0] = ok0 ? d0 : 0.0f;
-        D[1] = ok1 ? d1 : 0.0f;
-        bool any_shuffle = false;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const uint32_t kjf = node_ok ? cur.kj[d] : 0u, kj = kjf & ~IDENT;
-            const bool i0 = ok0 && kj != 0u, o0 = t0 < kj, ident = (kjf & IDENT) != 0u;
-            const msg2_t mi = *reinterpret_cast<const msg2_t*>(mo + (i0 ? cur.in_off[d] + t0 : 0u));   // even offsets: 4-byte aligned
-            in[d][0] = i0 ? (float)mi.a : 0.0f;
-            in[d][1] = (ok1 && kj != 0u) ? (float)mi.b : 0.0f;
-            if (DAMP) {
-                const msg2_t mold = *reinterpret_cast<const msg2_t*>(mo + (o0 ? cur.out_off[d] + t0 : 0u));
-                old[d][0] = (float)mold.a; old[d][1] = (float)mold.b;   // only used where t < kj
-            } else { old[d][0] = 0.0f; old[d][1] = 0.0f; }
-            const uint32_t m2 = *reinterpret_cast<const uint32_t*>(map + ((o0 && !ident) ? cur.out_off[d] + t0 : 0u));
-            mp[d][0] = ident ? t0 : (m2 & 0xFFFFu);
-            mp[d][1] = ident ? t1 : (m2 >> 16);
-            any_shuffle = any_shuffle || (!ident && kj != 0u);
-        }
-        // decode: first argmin_t of b[t] = D[t] + rho * S[t]
-        {
-            float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t t = t0 + r;
-                const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
-                const float b = D[r] + rho * S;
-                if (t < K && b < bb) { bb = b; bt = t; }  // ascending t within a lane: first minimum kept
-            }
-            group_argmin<G>(bb, bt);
-            if (gl == 0 && node_ok) {
-                if (K > 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
-                else { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; }   /* view_selection.cpp:50-51,70-71 */
-            }
-        }
-        const bool wave_shuffle = __ballot(any_shuffle) != 0ull;   // wave-uniform: some group in this wave must re-align
-        // outgoing messages
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
-            float c[2];
-            float cmin = INFINITY;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float oth = (0.0f + in[a][r]) + in[b2][r];
-                c[r] = (D[r] + rho * oth) - omr * in[d][r];
-                if (t0 + r < K) cmin = fminf(cmin, c[r]);
-            }
-            cmin = group_min<G>(cmin);
-            const uint32_t kjf = node_ok ? cur.kj[d] : 0u, kj = kjf & ~IDENT, oo = cur.out_off[d];
-            float outv[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t p = mp[d][r];
-                float cp = c[r];                       // identical label lists: position p == own label
-                if (wave_shuffle) {                    // every lane executes the shuffles (no divergence around ds_bpermute)
-                    const int src = (int)((p & 0xFFFFu) >> 1) & (G - 1);
-                    const float v0 = __shfl(c[0], src, G), v1 = __shfl(c[1], src, G);
-                    if (!(kjf & IDENT)) cp = (p & 1u) ? v1 : v0;
-                }
-                const float raw = (p == (uint32_t)MAP_NONE) ? lam : fminf(cp - cmin, lam);
-                outv[r] = DAMP ? (raw * oma + old[d][r] * alpha) : raw;
-            }
-            if (t1 < kj) {        // both elements: one 4-byte store
-                msg2_t w; w.a = msg_pack(outv[0]); w.b = msg_pack(outv[1]);
-                if (NT) __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&w), reinterpret_cast<uint32_t*>(mn + oo + t0));
-                else *reinterpret_cast<msg2_t*>(mn + oo + t0) = w;
-            } else if (t0 < kj) mn[oo + t0] = msg_pack(outv[0]);
-        }
-    }
-}
-
+// ---- one colour phase of a sweep; fast path: degree <= 3, K <= 4 * G ----
 // ---- 4 labels per lane: lane gl owns labels 4*gl .. 4*gl+3 (one 8-byte access = four binary16 messages or
 // four u16 map entries), K <= 4 * G, so a 64-lane wave sweeps 64/G nodes per iteration at roughly the
 // instruction count of one.  The kernel is VALU-issue bound (a wave64 VALU op occupies its SIMD for 4 cycles), so
@@ -350,9 +306,12 @@ struct alignas(8) msg4_t { msg_t v[4]; };
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int G, bool DAMP, bool XCD, bool LATE_OLD>
 __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                         const uint16_t* __restrict__ map, const msg_t* __restrict__ mo, msg_t* __restrict__ mn,
+                                                         const uint16_t* __restrict__ map, msg_t* msg,
                                                          uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
-                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
+                                                         uint32_t node_begin /* positions in the (colour, id) order */, uint32_t node_end, float rho, float alpha) {
+    // in place: the nodes of one launch share a colour (an independent set), so no run is read by one node and
+    // written by another; a node reads its old outgoing run before it overwrites it
+    const msg_t* mo = msg; msg_t* mn = msg;
     constexpr int NPB = 256 / G;
     constexpr int TS = 4 * G + 4;                            // tile stride: 4G cavity values + the +inf slot (16-byte multiple)
     constexpr uint32_t IDENT = 0x80000000u;
@@ -459,7 +418,8 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         }
         if (gl == 0 && node_ok) {
             /* K == 0: the single label 0 with unary 1 (view_selection.cpp:50-51,70-71) */
-            sel[i] = (K > 0u) ? bt : 0u; lab[i] = (K > 0u) ? dec_view + 1u : 0u; selcost[i] = (K > 0u) ? dec_cost : 1.0f;
+            const uint32_t id = cur.id;
+            sel[id] = (K > 0u) ? bt : 0u; lab[id] = (K > 0u) ? dec_view + 1u : 0u; selcost[id] = (K > 0u) ? dec_cost : 1.0f;
         }
     }
 }
@@ -469,12 +429,13 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
 template <bool DAMP>
 __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                                const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
-                                                               const msg_t* __restrict__ mo, msg_t* __restrict__ mn, uint32_t* __restrict__ sel,
+                                                               msg_t* msg, const uint32_t* __restrict__ perm, uint32_t* __restrict__ sel,
                                                                uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                                float* __restrict__ scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
-    const uint32_t i = node_begin + blockIdx.x;
+    const msg_t* mo = msg; msg_t* mn = msg;                  // in place (one colour per launch)
     const int lane = threadIdx.x;
-    if (i >= node_end) return;
+    if (node_begin + blockIdx.x >= node_end) return;
+    const uint32_t i = perm[node_begin + blockIdx.x];
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     if (K == 0) { if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; } return; }
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
@@ -595,6 +556,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
                                                                 const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
                                                                 uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand,
                                                                 uint8_t* __restrict__ dirty /* null = evaluate every node */) {
+    // node_begin / node_end are positions in the descriptor array ((colour, id) order); the node itself is cur.id
     constexpr int NPB = 256 / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const uint32_t stride = gridDim.x * NPB;
@@ -606,12 +568,13 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
         bool node_ok = i < node_end;
         // a node's gain depends on its column, its own label and its neighbours' labels only: unless one of those
         // changed in the last apply (dirty flag), the stored gain / candidate are still the values this loop would compute
-        if (dirty && node_ok) { node_ok = dirty[i] != 0; }
+        if (dirty && node_ok) { node_ok = dirty[nd.id] != 0; }
         if (dirty && __ballot(node_ok) == 0ull) { if (i + stride < node_end) nd = desc[i + stride]; continue; }   // wave-uniform skip (the group shuffles below need all lanes)
         const NodeDesc cur = nd;
         if (i + stride < node_end) nd = desc[i + stride];
         const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
-        const uint32_t cur_t = (K > 0) ? sel[i] : 0u;
+        const uint32_t id = cur.id;
+        const uint32_t cur_t = (K > 0) ? sel[id] : 0u;
         uint32_t nl[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && (cur.kj[d] & 0x7FFFFFFFu)) ? lab[cur.nbr[d]] : 0u;
@@ -629,7 +592,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
             if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
             cur_e += __shfl_xor(cur_e, o, G);   // exactly one lane holds a non-zero term (or none: 0)
         }
-        if (gl == 0 && node_ok) { gain[i] = (K > 0) ? (cur_e - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; if (dirty) dirty[i] = 0; }
+        if (gl == 0 && node_ok) { gain[id] = (K > 0) ? (cur_e - best) : 0.0f; cand[id] = (K > 0) ? bt : 0u; if (dirty) dirty[id] = 0; }
     }
 }
 
@@ -735,18 +698,50 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     uint32_t E = 0;
     MVS_HIP(hipMemcpyAsync(&E, ctx->r_adj_ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
-    ctx->m_size.ensure((size_t)E + 2); ctx->m_edge.ensure((size_t)E + 1); ctx->m_moved.ensure(8);
+    ctx->m_size.ensure((size_t)E + 2); ctx->m_edge.ensure((size_t)E + 1); ctx->m_moved.ensure(8 + 2 * 64);
     uint32_t* maxes = ctx->m_moved.p + 4;
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 8 * sizeof(uint32_t), s));
     MVS_HIP(hipMemsetAsync(ctx->m_size.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
     const unsigned nb = (F + 255) / 256;
     if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), ctx->m_size.p, maxes); MVS_LAUNCH_CHECK(); }
-    // in_off = exclusive scan of the sizes (E + 1 entries so that in_off[E] = total)
+    // ---- colour-phased schedule: colouring (Jones-Plassmann rounds), nodes in (colour, id) order ----
+    ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)F + 72); ctx->m_tmp_b.ensure((size_t)F + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
+    ctx->m_colours = 0; ctx->m_colour_begin.assign(66, 0); ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
+    if (F) {
+        uint32_t* pending = ctx->m_moved.p + 1;
+        hipLaunchKernelGGL(mrf_colour_init_kernel, dim3(nb), dim3(256), 0, s, ctx->m_colour.p, ctx->m_tmp_a.p /* iota */, F); MVS_LAUNCH_CHECK();
+        for (int round = 0;; ++round) {
+            if (round >= 4096) throw StatusError(MVS_ERR_HIP, "graph colouring did not terminate");
+            MVS_HIP(hipMemsetAsync(pending, 0, sizeof(uint32_t), s));
+            for (int k = 0; k < 4; ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
+            uint32_t hp = 0;   // set if any of the four rounds left a node waiting
+            MVS_HIP(hipMemcpyAsync(&hp, pending, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            MVS_HIP(hipStreamSynchronize(s));
+            if (!hp) break;
+        }
+        // stable sort of the node ids by colour: perm = nodes in (colour, id) order; a colour class is a contiguous range
+        size_t tmp_bytes = 0;
+        MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->m_colour.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 6, s));
+        ctx->sort_tmp.ensure(tmp_bytes + 16);
+        MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->m_colour.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 6, s));
+        hipLaunchKernelGGL(mrf_colour_begin_kernel, dim3(1), dim3(128), 0, s, ctx->m_tmp_b.p, F, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
+        MVS_HIP(hipMemcpyAsync(ctx->m_colour_begin.data(), ctx->m_tmp_c.p, 65 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        ctx->m_colour_begin[65] = F;
+        uint32_t C = 0; while (C < 64 && ctx->m_colour_begin[C] < F) ++C;   // colours 0 .. C-1 are in use (greedy colours are dense)
+        ctx->m_colours = C;
+        ctx->m_colour_begin.resize(C + 1); ctx->m_colour_begin[C] = F;
+    }
+    // message layout: in-runs in (colour, id) node order.  in_off[e] for every directed edge e (adjacency order)
     DBuf<uint32_t>& in_off = ctx->m_sel2;  // temporary home, re-ensured below
     in_off.ensure(std::max<size_t>((size_t)E + 2, (size_t)F + 2));
-    exclusive_scan_u32(ctx, ctx->m_size.p, in_off.p, (size_t)E + 1, nullptr);
     uint32_t h[3] = {0, 0, 0};
-    MVS_HIP(hipMemcpyAsync(&h[0], in_off.p + E, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (F) {
+        hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->m_size.p, F, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
+        exclusive_scan_u32(ctx, ctx->m_tmp_a.p, ctx->m_tmp_b.p, (size_t)F + 1, nullptr);
+        hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->m_size.p, ctx->m_tmp_b.p, F, in_off.p); MVS_LAUNCH_CHECK();
+        MVS_HIP(hipMemcpyAsync(&h[0], ctx->m_tmp_b.p + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     MVS_HIP(hipMemcpyAsync(&h[1], maxes, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
     ctx->m_total = (uint64_t)MSG_BASE + h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
@@ -758,10 +753,9 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
     if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p); MVS_LAUNCH_CHECK(); }
     ctx->m_desc.ensure((size_t)F + 1);
-    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
-    ctx->m_msg_a.ensure(ctx->m_total + 8); ctx->m_msg_b.ensure(ctx->m_total + 8);
+    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
+    ctx->m_msg_a.ensure(ctx->m_total + 8);
     MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // binary16 zeros, incl. the reserved zero run
-    MVS_HIP(hipMemsetAsync(ctx->m_msg_b.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));
     // the sweep reads unaries with unclamped 16-byte loads: a caller-owned cost array (mvs_ctx_costs_upload with device
     // pointers) is copied into the context's own buffer, which always has slack behind the last element
     if (ctx->r_cost != ctx->csr_cost.p && ctx->csr_nnz) {
@@ -786,7 +780,6 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     }
     MVS_HIP(hipMemsetAsync(ctx->m_gain.p, 0, ((size_t)F + 1) * sizeof(float), s));
     ctx->m_energy.ensure(4 + 2 * 2048);
-    ctx->m_flip = false;
     // device-side solver state: sweep 0, best = hist[0] = 2^64 - 1
     ctx->m_state.ensure(1); ctx->m_hist.ensure((size_t)std::max(params->max_sweeps, 0) + 2);
     mvs_mrf_progress init; memset(&init, 0, sizeof(init)); init.best = ~0ull; init.energy = ~0ull;
@@ -829,39 +822,12 @@ void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
 }
 
 template <int G>
-static void launch_sweep_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
+static void launch_sweep4_g(mvs_ctx* ctx, uint32_t qb, uint32_t qe) {
     constexpr int NPB = 256 / G;
-    const unsigned need = (ne0 - nb0 + NPB - 1) / NPB;
+    const unsigned need = (qe - qb + NPB - 1) / NPB;
     const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
-    // persistent lane groups: exactly as many blocks as are resident at once (a partial second wave of
+    // persistent lane groups: at most as many blocks as are resident at once (a partial second wave of
     // blocks would double the tail); mrf_blocks_per_cu > 0 overrides
-    static int resident = 0;
-    if (resident == 0) {
-        int per_cu = 0; hipDeviceProp_t prop;
-        MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep_kernel<G, true, false, true>, 256, 0));
-        MVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
-        resident = std::max(1, per_cu) * prop.multiProcessorCount;
-    }
-    unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
-    blocks = std::max(1u, std::min(need, blocks));
-    if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
-#define SWEEP_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
-    if (alpha != 0.0f) {
-        if (ctx->mrf_nt) hipLaunchKernelGGL((mrf_sweep_kernel<G, true, true, true>), SWEEP_ARGS);
-        else if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, true, false, true>), SWEEP_ARGS);
-        else hipLaunchKernelGGL((mrf_sweep_kernel<G, true, false, false>), SWEEP_ARGS);
-    } else {
-        if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep_kernel<G, false, false, true>), SWEEP_ARGS);
-        else hipLaunchKernelGGL((mrf_sweep_kernel<G, false, false, false>), SWEEP_ARGS);
-    }
-#undef SWEEP_ARGS
-}
-
-template <int G>
-static void launch_sweep4_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t nb0, uint32_t ne0) {
-    constexpr int NPB = 256 / G;
-    const unsigned need = (ne0 - nb0 + NPB - 1) / NPB;
-    const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0; hipDeviceProp_t prop;
@@ -871,8 +837,9 @@ static void launch_sweep4_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t n
     }
     unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
     blocks = std::max(1u, std::min(need, blocks));
-    if (blocks > 8) blocks &= ~7u;
-#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, nb0, ne0, rho, alpha
+    if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
+    msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
+#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, msg, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, qb, qe, rho, alpha
     if (alpha != 0.0f) {
         if (ctx->mrf_late_old) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, true>), SWEEP4_ARGS); }
         else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, false>), SWEEP4_ARGS); }
@@ -880,39 +847,52 @@ static void launch_sweep4_g(mvs_ctx* ctx, const msg_t* mo, msg_t* mn, uint32_t n
 #undef SWEEP4_ARGS
 }
 
-// one sweep over nodes [nb0, ne0): reads the current message buffer, writes the other one, then flips
-void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
-    const msg_t* mo = reinterpret_cast<const msg_t*>(ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p);
-    msg_t* mn = reinterpret_cast<msg_t*>(ctx->m_flip ? ctx->m_msg_a.p : ctx->m_msg_b.p);
-    if (ne0 > nb0) {
-        const uint32_t K = ctx->m_kmax;
-        if (ctx->m_degmax <= 3 && K <= 128 && ctx->csr_nnz > 0 && ctx->m_total > 0) {
-            if (ctx->mrf_unroll != 2 && ctx->csr_nnz >= 4) {   // default: 4 labels per lane (mrf_unroll == 2 selects the 2-label kernel)
-                if (K <= 32) launch_sweep4_g<8>(ctx, mo, mn, nb0, ne0);
-                else if (K <= 64) launch_sweep4_g<16>(ctx, mo, mn, nb0, ne0);
-                else launch_sweep4_g<32>(ctx, mo, mn, nb0, ne0);
-                MVS_LAUNCH_CHECK();
-                ctx->m_flip = !ctx->m_flip;
-                return;
-            }
-            // G lanes per node, 2 labels per lane; small columns put several nodes in one wave
-            int g = K <= 16 ? 8 : K <= 32 ? 16 : K <= 64 ? 32 : 64;
-            if (ctx->mrf_shape == 64 || ctx->mrf_shape == 32 || ctx->mrf_shape == 16 || ctx->mrf_shape == 8) { if ((uint32_t)ctx->mrf_shape * 2 >= K) g = ctx->mrf_shape; }
-            if (g == 8) launch_sweep_g<8>(ctx, mo, mn, nb0, ne0);
-            else if (g == 16) launch_sweep_g<16>(ctx, mo, mn, nb0, ne0);
-            else if (g == 32) launch_sweep_g<32>(ctx, mo, mn, nb0, ne0);
-            else launch_sweep_g<64>(ctx, mo, mn, nb0, ne0);
-        } else {
-            ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
-            const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
-            if (alpha != 0.0f)
-                hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, nb0, ne0, rho, alpha);
-            else
-                hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, dim3(ne0 - nb0), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, mo, mn, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, nb0, ne0, rho, alpha);
-        }
+// positions [qb, qe) in the (colour, id) order of the nodes of colour `phase` whose id lies in [nb0, ne0)
+static void phase_range(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, uint32_t* qb, uint32_t* qe) {
+    const uint32_t cb = ctx->m_colour_begin[phase], ce = ctx->m_colour_begin[phase + 1];
+    if (nb0 == 0 && ne0 >= ctx->csr_faces) { *qb = cb; *qe = ce; return; }
+    if (ctx->m_range_nb != nb0 || ctx->m_range_ne != ne0 || ctx->m_range_q.size() != 2 * (size_t)ctx->m_colours) {
+        // a rank's own share of every colour class: one small kernel + read-back per (range, setup), then cached
+        const uint32_t C = ctx->m_colours;
+        ctx->m_moved.ensure(8 + 2 * 64);
+        uint32_t* d = ctx->m_moved.p + 8;
+        ctx->m_tmp_a.ensure(72);
+        MVS_HIP(hipMemcpyAsync(ctx->m_tmp_a.p, ctx->m_colour_begin.data(), (C + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(mrf_phase_range_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->m_perm.p, ctx->m_tmp_a.p, C, nb0, ne0, d);
         MVS_LAUNCH_CHECK();
+        ctx->m_range_q.assign(2 * (size_t)C, 0);
+        MVS_HIP(hipMemcpyAsync(ctx->m_range_q.data(), d, 2 * C * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->m_range_nb = nb0; ctx->m_range_ne = ne0;
     }
-    ctx->m_flip = !ctx->m_flip;
+    *qb = ctx->m_range_q[2 * phase]; *qe = ctx->m_range_q[2 * phase + 1];
+}
+
+// one colour phase of a sweep over the nodes of that colour with id in [nb0, ne0): in place
+void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
+    if (phase >= ctx->m_colours || ne0 <= nb0) return;
+    uint32_t qb, qe;
+    phase_range(ctx, phase, nb0, ne0, &qb, &qe);
+    if (qe <= qb) return;
+    const uint32_t K = ctx->m_kmax;
+    if (ctx->m_degmax <= 3 && K <= 128 && ctx->csr_nnz >= 4 && ctx->m_total > MSG_BASE) {
+        if (K <= 32) launch_sweep4_g<8>(ctx, qb, qe);
+        else if (K <= 64) launch_sweep4_g<16>(ctx, qb, qe);
+        else launch_sweep4_g<32>(ctx, qb, qe);
+    } else {
+        ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
+        const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+        msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
+        if (alpha != 0.0f)
+            hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, dim3(qe - qb), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, msg, ctx->m_perm.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, qb, qe, rho, alpha);
+        else
+            hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, dim3(qe - qb), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, msg, ctx->m_perm.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, qb, qe, rho, alpha);
+    }
+    MVS_LAUNCH_CHECK();
+}
+// one sweep = every colour phase in turn (callers that shard the nodes exchange halos between the phases themselves)
+void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
+    for (uint32_t ph = 0; ph < ctx->m_colours; ++ph) mrf_sweep_phase(ctx, ph, nb0, ne0);
 }
 
 // energy of the current decode (best == false) or of the best labeling over nodes [nb0, ne0)
@@ -943,7 +923,7 @@ void mrf_keep_best(mvs_ctx* ctx) {
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 <= nb0) return;
     const uint32_t K = ctx->m_kmax, n = ne0 - nb0;
-    if (ctx->m_degmax <= 3) {
+    if (ctx->m_degmax <= 3 && nb0 == 0 && ne0 == ctx->csr_faces) {   // descriptors are in (colour, id) order: whole-graph calls only
         // active set (unsharded calls only): after the first full evaluation only nodes whose own or neighbouring label
         // moved are re-evaluated; sharded callers exchange labels behind the library's back, so they evaluate all
         uint8_t* dirty = nullptr;

@@ -10,6 +10,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0);
 void mrf_keep_best(mvs_ctx* ctx);
+void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0);
 void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
@@ -52,7 +53,7 @@ __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, 
 }
 }  // namespace
 
-static uint16_t* mrf_msg(mvs_ctx* ctx) { return ctx->m_flip ? ctx->m_msg_b.p : ctx->m_msg_a.p; }  // current = what the last sweep wrote
+static uint16_t* mrf_msg(mvs_ctx* ctx) { return ctx->m_msg_a.p; }  // one buffer, updated in place
 static uint32_t* mrf_array(mvs_ctx* ctx, int which) {
     switch (which) {
         case MVS_MRF_LAB: return ctx->m_lab.p;
@@ -129,6 +130,27 @@ mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     MVS_API_BEGIN
     Prof pr(ctx, "mrf_sweep");
     mrf_sweep(ctx, nb0, ne0);
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases) {
+    if (!ctx || !n_phases) return api_fail(MVS_ERR_INVALID, "null argument");
+    *n_phases = ctx->m_colours;
+    return MVS_OK;
+}
+mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
+    if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces || phase >= ctx->m_colours) return api_fail(MVS_ERR_INVALID, "bad phase or node range");
+    MVS_API_BEGIN
+    Prof pr(ctx, "mrf_sweep");
+    mrf_sweep_phase(ctx, phase, nb0, ne0);
+    MVS_API_END
+}
+mvs_status mvs_ctx_mrf_layout(mvs_ctx* ctx, uint32_t* in_off_host, uint64_t n_edges) {
+    if (!ctx || (n_edges && !in_off_host)) return api_fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    // MrfEdge = {in_off, out_off, kj}: strided copy of the first member
+    if (n_edges) MVS_HIP(hipMemcpy2DAsync(in_off_host, sizeof(uint32_t), ctx->m_edge.p, sizeof(MrfEdge), sizeof(uint32_t), n_edges, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
     MVS_API_END
 }
 

@@ -75,7 +75,7 @@ class HaloPlan:
          node_send[p] / node_recv[p] node ids (selections / gains of boundary nodes)
     ordered identically on both ends of every pair."""
 
-    def __init__(self, col_ptr, adj_ptr, adj, part_begin, me):
+    def __init__(self, col_ptr, adj_ptr, adj, part_begin, me, in_off=None):
         col_ptr = np.asarray(col_ptr, dtype=np.int64); adj_ptr = np.asarray(adj_ptr, dtype=np.int64); adj = np.asarray(adj, dtype=np.int64)
         F = len(col_ptr) - 1
         P = len(part_begin) - 1
@@ -86,15 +86,20 @@ class HaloPlan:
         valid = (K[dst] > 0) & (K[src] > 0)
         size = np.where(valid, K[dst], 0)                      # message elements per directed edge
         padded = (size + 3) & ~3                               # runs are padded to a multiple of 4 elements in HBM (k_mrf.hip)
-        in_off = np.zeros(len(size) + 1, dtype=np.int64); in_off[1:] = np.cumsum(padded)
-        in_off += MSG_BASE                                     # the library reserves [0, MSG_BASE) (zero / identity run)
-        if in_off[-1] >= 2 ** 32:
+        if in_off is None:   # node-major layout (stand-in ops of the CPU tests)
+            in_off = np.zeros(len(size) + 1, dtype=np.int64); in_off[1:] = np.cumsum(padded)
+            in_off += MSG_BASE                                 # the library reserves [0, MSG_BASE) (zero / identity run)
+            total = int(in_off[-1])
+        else:                # the library's layout ((colour, id) node order): mvs_ctx_mrf_layout
+            in_off = np.asarray(in_off, dtype=np.int64)
+            total = int((in_off + padded).max()) if len(in_off) else MSG_BASE
+        if total >= 2 ** 32:
             raise ValueError("message array exceeds 2^32 words")
         pb = np.asarray(part_begin, dtype=np.int64)
         own_dst = np.searchsorted(pb, dst, side="right") - 1
         own_src = np.searchsorted(pb, src, side="right") - 1
         cut = valid & (own_dst != own_src)
-        self.me, self.P, self.total_words = me, P, int(in_off[-1])
+        self.me, self.P, self.total_words = me, P, total
         self.node_begin, self.node_end = int(pb[me]), int(pb[me + 1])
         self.msg_send, self.msg_recv, self.node_send, self.node_recv = [], [], [], []
         empty = np.zeros(0, dtype=np.uint32)
@@ -186,13 +191,14 @@ def stop_rule(hist, sweep, params):
 
 class ShardedViewSelection:
     """Runs tex::view_selection over `plan.P` parts.  `ops` provides the per-rank compute:
-         setup(), sweep(nb, ne), gather(which, idx, dst), scatter(which, idx, src),
+         setup(), n_phases(), sweep_phase(phase, nb, ne), gather(which, idx, dst), scatter(which, idx, src),
          energy(which_sel, nb, ne) -> int64 tensor[2], step(e), poll(n) -> report dict, icm_gain(nb, ne),
          icm_apply(nb, ne) -> int tensor[1], labels(nb, ne) -> uint32 labels of own nodes
     (viewsel.Context for the GPU; a numpy stand-in in the CPU tests)."""
 
-    def __init__(self, ops, plan, params, device, dist=None, group=None, hx=None, lag=None):
+    def __init__(self, ops, plan, params, device, dist=None, group=None, hx=None, lag=None, setup_done=False):
         self.ops, self.plan, self.params, self.dist, self.group = ops, plan, params, dist, group
+        self.setup_done = setup_done
         self.lag = (2 if plan.P > 1 else 1) if lag is None else int(lag)
         self.hx = hx or HaloExchange(plan, device, dist, group)
 
@@ -204,7 +210,9 @@ class ShardedViewSelection:
     def run(self):
         ops, plan, P = self.ops, self.plan, self.params
         nb, ne = plan.node_begin, plan.node_end
-        ops.setup()
+        if not self.setup_done:
+            ops.setup()
+        n_phases = ops.n_phases()
         # The stop rule lives with the ops (on the device for the GPU): step() accounts one sweep's all-reduced
         # energy, keeps the best labeling and freezes everything once the rule has fired; poll(n) returns the report
         # of step n.  The host runs `lag` sweeps ahead of the reports it reads, so no rank ever waits for a sweep's
@@ -213,11 +221,13 @@ class ShardedViewSelection:
         issued = polled = 0
         rep = None
         while issued < P.max_sweeps and not (rep and rep["stopped"]):
-            ops.sweep(nb, ne)
-            if plan.total_words < 2 ** 31:
-                self.hx.exchange([("both", MSG_LAB)], ops.gather, ops.scatter)      # one collective per sweep
-            else:
-                self.hx.exchange([("msg", MSG), ("node", LAB)], ops.gather, ops.scatter)
+            for ph in range(n_phases):                         # colour-phased Gauss-Seidel: halo exchange after every phase
+                ops.sweep_phase(ph, nb, ne)
+                if plan.P > 1:
+                    if plan.total_words < 2 ** 31:
+                        self.hx.exchange([("both", MSG_LAB)], ops.gather, ops.scatter)      # one collective per phase
+                    else:
+                        self.hx.exchange([("msg", MSG), ("node", LAB)], ops.gather, ops.scatter)
             ops.step(self._allreduce(ops.energy(LAB, nb, ne)))
             issued += 1
             if issued - lag > polled:
@@ -272,8 +282,19 @@ class GpuShardOps:
         C = self.C
         self._chk(self.L.mvs_ctx_mrf_setup(self.h, C.c_void_p(self.adj_ptr.data_ptr()), C.c_void_p(self.adj.data_ptr()), 1, C.byref(self.params)))
 
-    def sweep(self, nb, ne):
-        self._chk(self.L.mvs_ctx_mrf_sweep(self.h, nb, ne))
+    def n_phases(self):
+        n = self.C.c_uint32(0)
+        self._chk(self.L.mvs_ctx_mrf_num_phases(self.h, self.C.byref(n)))
+        return int(n.value)
+
+    def sweep_phase(self, phase, nb, ne):
+        self._chk(self.L.mvs_ctx_mrf_sweep_phase(self.h, phase, nb, ne))
+
+    def layout(self, n_edges):
+        """in_off[e] of every directed edge (host array) for the halo planner"""
+        out = np.zeros(max(int(n_edges), 1), dtype=np.uint32)
+        self._chk(self.L.mvs_ctx_mrf_layout(self.h, self.C.c_void_p(out.ctypes.data), int(n_edges)))
+        return out[:int(n_edges)]
 
     def gather(self, which, idx, dst):
         C = self.C
@@ -392,10 +413,12 @@ class ShardedPipeline:
 
     def step(self):
         dc, st = sharded_data_costs(self.ctx, self.settings, self.part, self.rank, self.dist, device=self.device)
-        if self.plan is None:   # the sparsity pattern is the same every step: plan the halo once (host logic)
-            self.plan = HaloPlan(dc.col_ptr.cpu().numpy().view(np.uint32), self.adj_ptr_np, self.adj_np, self.part, self.rank)
+        ops = GpuShardOps(self.ctx, self.adj_ptr_dev, self.adj_dev, self.params)
+        ops.setup()
+        if self.plan is None:   # the sparsity pattern (hence the colouring and the layout) is the same every step: plan the halo once (host logic)
+            self.plan = HaloPlan(dc.col_ptr.cpu().numpy().view(np.uint32), self.adj_ptr_np, self.adj_np, self.part, self.rank,
+                                 in_off=ops.layout(len(self.adj_np)))
             self.hx = HaloExchange(self.plan, self.device, self.dist)
             self.nnz_global = int(dc.col_ptr[-1].item())
-        ops = GpuShardOps(self.ctx, self.adj_ptr_dev, self.adj_dev, self.params)
-        labels, ms = ShardedViewSelection(ops, self.plan, self.params, self.device, self.dist, hx=self.hx).run()
+        labels, ms = ShardedViewSelection(ops, self.plan, self.params, self.device, self.dist, hx=self.hx, setup_done=True).run()
         return labels, st, ms, dc

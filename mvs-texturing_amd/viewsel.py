@@ -129,6 +129,7 @@ def load_library():
         "mvs_ctx_costs_upload": [vp, C.POINTER(CCsr), i32], "mvs_ctx_costs_export": [vp, vp, vp, vp],
         "mvs_ctx_view_selection": [vp, vp, vp, i32, C.POINTER(MrfParams), vp, i32, C.POINTER(MrfStats)],
         "mvs_ctx_mrf_setup": [vp, vp, vp, i32, C.POINTER(MrfParams)], "mvs_ctx_mrf_sweep": [vp, u32, u32],
+        "mvs_ctx_mrf_num_phases": [vp, C.POINTER(u32)], "mvs_ctx_mrf_sweep_phase": [vp, u32, u32, u32], "mvs_ctx_mrf_layout": [vp, vp, u64],
         "mvs_ctx_mrf_gather": [vp, i32, vp, u64, vp], "mvs_ctx_mrf_scatter": [vp, i32, vp, u64, vp],
         "mvs_ctx_mrf_energy": [vp, i32, u32, u32, vp], "mvs_ctx_mrf_keep_best": [vp],
         "mvs_ctx_mrf_step": [vp, vp], "mvs_ctx_mrf_poll": [vp, u32, C.POINTER(MrfProgress)],

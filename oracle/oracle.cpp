@@ -761,7 +761,7 @@ namespace {
 
 const uint16_t MAP_NONE = 0xFFFF;
 uint64_t* g_trace = nullptr; int g_trace_len = 0;
-uint64_t* g_quiet = nullptr;  // optional: per sweep, nodes that a lazy sweep could skip (experiments)  // optional per-sweep energy trace (experiments)
+// optional per-sweep energy trace (experiments)
 
 inline uint64_t fix32(float d) { return (uint64_t)((double)d * 4294967296.0); }
 
@@ -857,8 +857,30 @@ uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t
     return unary + (cuts << 32);
 }
 
-void mrf_sweep(const Mrf& g, const orc_mrf_params& P, const std::vector<float>& mo, std::vector<float>& mn,
-               std::vector<uint32_t>& sel, int n_threads) {
+// Greedy colouring of the adjacency graph in the order of the keys (hash32(i), i): node i takes the smallest
+// colour no earlier neighbour holds.  DEFINED HERE (part of the solver's schedule): the GPU reaches the same
+// colouring with Jones-Plassmann rounds (a node colours itself once all neighbours with a smaller key have).
+inline uint32_t mrf_hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+int mrf_colour(const Mrf& g, std::vector<uint8_t>& colour) {
+    std::vector<uint32_t> order(g.F);
+    for (uint32_t i = 0; i < g.F; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [](uint32_t a, uint32_t b) { const uint32_t ha = mrf_hash32(a), hb = mrf_hash32(b); return ha != hb ? ha < hb : a < b; });
+    colour.assign(g.F, 255);
+    int n_colours = 0;
+    for (uint32_t i : order) {
+        uint64_t used = 0;
+        for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) { const uint8_t cj = colour[g.adj[e]]; if (cj != 255) used |= 1ull << cj; }
+        uint8_t c = 0; while (used & (1ull << c)) ++c;      // degree <= 48 (UniGraph lists are de-duplicated): c <= 48
+        colour[i] = c; n_colours = std::max(n_colours, (int)c + 1);
+    }
+    return n_colours;
+}
+
+// One phase of a sweep: all nodes of colour `phase` (an independent set) recompute their outgoing messages IN PLACE
+// from the current messages -- colour-phased Gauss-Seidel.  Within a phase no node reads what another writes.
+void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<float>& msg,
+               std::vector<uint32_t>& sel, int n_threads, const uint8_t* colour, int phase) {
+    const std::vector<float>& mo = msg; std::vector<float>& mn = msg;
     const float rho = P.rho, omr = 1.0f - P.rho, lam = 1.0f / P.rho;
     const float alpha = P.damping, oma = 1.0f - P.damping;
 #pragma omp parallel num_threads(n_threads)
@@ -867,7 +889,7 @@ void mrf_sweep(const Mrf& g, const orc_mrf_params& P, const std::vector<float>& 
 #pragma omp for schedule(dynamic, 1024)
         for (int64_t ii = 0; ii < (int64_t)g.F; ++ii) {
             const uint32_t i = (uint32_t)ii, Ki = g.K(i);
-            if (Ki == 0) continue;
+            if (Ki == 0 || colour[i] != phase) continue;
             const float* D = g.cost + g.col_ptr[i];
             const uint32_t e0 = g.adj_ptr[i], e1 = g.adj_ptr[i + 1];
             // decode
@@ -950,10 +972,9 @@ extern "C" {
 uint16_t orc_f32_to_f16(float f) { return f32_to_f16_rne(f); }
 float orc_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
 void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = len; }
-void orc_mrf_set_quiet_trace(uint64_t* buf) { g_quiet = buf; }
 
 void orc_mrf_default_params(orc_mrf_params* p) {
-    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 10; p->min_improvement = 0.002f;
+    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
     p->damping = 0.3f; p->rho = 0.8f; p->icm_iters = 50;
 }
 
@@ -972,36 +993,20 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     g.adj_ptr = adj_ptr; g.adj = adj;
     mrf_setup(g);
     const uint64_t M = g.moff[g.adj_ptr[g.F]];
-    std::vector<float> ma(M, 0.0f), mb(M, 0.0f);
+    std::vector<float> msg(M, 0.0f);
+    std::vector<uint8_t> colour;
+    const int n_colours = mrf_colour(g, colour);
     std::vector<uint32_t> sel(g.F, 0), best_sel(g.F, 0);
     S.t_setup = now_s() - t0; t0 = now_s();
     uint64_t best_e = ~0ull, best_cuts = 0;
     std::vector<uint64_t> hist; hist.push_back(~0ull);
     uint32_t s = 0;
     for (s = 1; (int)s <= P.max_sweeps; ++s) {
-        mrf_sweep(g, P, ma, mb, sel, n_threads);
-        ma.swap(mb);
+        for (int phase = 0; phase < n_colours; ++phase) mrf_sweep(g, P, msg, sel, n_threads, colour.data(), phase);
         uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts, n_threads);
         if (e < best_e) { best_e = e; best_cuts = cuts; best_sel = sel; }
         hist.push_back(best_e);
         if (g_trace && (int)s <= g_trace_len) g_trace[s - 1] = e;
-        if (g_quiet && (int)s <= g_trace_len) {
-            // after the swap: ma = messages of this sweep, mb = previous sweep's.  c(i) = any outgoing word of i changed
-            static std::vector<uint8_t> chg_prev; std::vector<uint8_t> chg(g.F, 0);
-            for (uint32_t i = 0; i < g.F; ++i)
-                for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) {
-                    if (!g.valid[e]) continue;
-                    const uint32_t r = g.rev[e]; const uint64_t o = g.moff[r]; const uint32_t kj = g.K(g.adj[e]);
-                    if (memcmp(&ma[o], &mb[o], kj * sizeof(float)) != 0) { chg[i] = 1; break; }
-                }
-            uint64_t quiet = 0;
-            for (uint32_t i = 0; i < g.F; ++i) {
-                bool q = !chg[i];
-                for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1] && q; ++e) if (g.valid[e] && chg[g.adj[e]]) q = false;
-                quiet += q;
-            }
-            g_quiet[s - 1] = quiet;
-        }
         if ((int)s >= P.min_sweeps && (int)s > P.window) {
             const uint64_t prev = hist[s - P.window];
             if ((double)(prev - best_e) < (double)P.min_improvement * (double)prev) break;

@@ -7,7 +7,6 @@ echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail 
 if [ -n "$DO_DIAG" ]; then echo "== diag $DO_DIAG"; timeout 900 python scripts/gpu_diag.py $DO_DIAG > gpurun_out/diag.log 2>&1; grep -v "^   " gpurun_out/diag.log | tail -20; fi
 echo "== bench config ${BENCH_CONFIG:-3}"; ( time timeout 1200 python bench.py --config ${BENCH_CONFIG:-3} --steps 3 --warmup 1 ) > gpurun_out/bench.log 2> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.log
 if [ -n "$DO_MODE0" ]; then echo "== bench ray_mode 0"; MVS_RAY_MODE=0 timeout 1200 python bench.py --config ${BENCH_CONFIG:-3} --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['stages']['dc_rays'])"; fi
-if [ -n "$DO_SHAPES" ]; then for sh in $DO_SHAPES; do echo "== bench mrf_shape $sh"; MVS_MRF_SHAPE=$sh timeout 1200 python bench.py --config ${BENCH_CONFIG:-3} --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['stages']['mrf_sweep'])"; done; fi
 if [ -n "$DO_VARIANTS" ]; then
   IFS=';' read -ra VARS <<< "$DO_VARIANTS"
   for v in "${VARS[@]}"; do echo "== bench variant: $v"; env $v timeout 1200 python bench.py --config ${BENCH_CONFIG:-3} --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); s=d['stages']; print(round(d['ms_per_step'],1), 'sweep', round(s['mrf_sweep']['ms_per_step'],1), 'icm', round(s['mrf_icm']['ms_per_step'],1), 'setup', round(s['mrf_setup']['ms_per_step'],1), 'rays', round(s['dc_rays']['ms_per_step'],1))"; done

@@ -1,4 +1,4 @@
-"""Sweep-kernel probe (GPU box): C3 (or --config N) data costs once, then times N sweeps per variant through the
+"""Sweep probe (GPU box; one sweep = all colour phases): C3 (or --config N) data costs once, then times N sweeps per variant through the
 building-block ABI.  Variants: "name:opt=val,opt=val;..." where opt is a mvs_set_option name or damping / rho.
 Usage: python scripts/sweep_probe.py [--config 3] [--sweeps 30] "base:;nodamp:damping=0;noxcd:mrf_xcd=0" """
 import argparse, ctypes as C, os, sys

@@ -277,11 +277,15 @@ def test_logical_shards_on_one_gpu_equal_single(P):
     # P shards: MRF with planned halo exchange, every shard holding the full table
     params = M.viewsel.default_mrf_params()
     tap, tad = torch.from_numpy(adj_ptr.view(np.int32)).to(dev), torch.from_numpy(adj.view(np.int32)).to(dev)
-    plans = [G.HaloPlan(full.col_ptr, adj_ptr, adj, pb, r) for r in range(P)]
     ops = []
     for r, c in enumerate(ctxs):
         c.costs_upload(M.viewsel.DataCosts(full.n_faces, full.n_views, full.col_ptr, full.view_id, full.cost))
         o = G.GpuShardOps(c, tap, tad, params); o.setup(); ops.append(o)
+    layouts = [o.layout(len(adj)) for o in ops]
+    assert all(np.array_equal(layouts[0], l) for l in layouts)          # every shard derives the same colouring and message layout
+    n_phases = ops[0].n_phases()
+    assert 2 <= n_phases <= 4 and all(o.n_phases() == n_phases for o in ops)
+    plans = [G.HaloPlan(full.col_ptr, adj_ptr, adj, pb, r, in_off=layouts[r]) for r in range(P)]
     def dev_idx(a):
         return torch.from_numpy(np.asarray(a, dtype=np.uint32).astype(np.int64)).to(dev).to(torch.int32)
     hx_idx = [{k: [dev_idx(x) for x in getattr(plans[r], k)] for k in ("msg_send", "msg_recv", "node_send", "node_recv")} for r in range(P)]
@@ -307,8 +311,9 @@ def test_logical_shards_on_one_gpu_equal_single(P):
 
     best = 2 ** 64 - 1; hist_e = [best]; sweeps = 0
     for sw in range(1, params.max_sweeps + 1):
-        for r in range(P): ops[r].sweep(int(pb[r]), int(pb[r + 1]))
-        exchange([("msg", G.MSG), ("node", G.LAB)])
+        for ph in range(n_phases):                                    # colour-phased Gauss-Seidel: exchange after every phase
+            for r in range(P): ops[r].sweep_phase(ph, int(pb[r]), int(pb[r + 1]))
+            exchange([("msg", G.MSG), ("node", G.LAB)])
         e = sum(int(ops[r].energy(G.LAB, int(pb[r]), int(pb[r + 1]))[0].item()) for r in range(P)) & (2 ** 64 - 1)
         if e < best:
             best = e
