@@ -194,22 +194,38 @@ __global__ void mrf_phase_range_kernel(const uint32_t* __restrict__ perm, const 
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (perm[mid] < ne) lo = mid + 1; else hi = mid; }
     out[2 * c + 1] = lo;
 }
-// message layout: runs in (colour, id) node order, a node's in-edges in list order -> the in-runs a phase reads are contiguous
-__global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ size,
-                                    uint32_t F, uint32_t* __restrict__ nsz) {
+// Message layout, SENDER-major: the runs a node WRITES (one per out-edge, in its list order, each as long as the
+// receiver's padded label count) are contiguous, and nodes follow each other in (colour, id) order.  A colour phase
+// therefore streams its previous-outgoing reads and its stores through one contiguous region (2 of the 3 message
+// accesses per label); only the incoming reads gather 1 run out of each neighbour's block.
+// size[e] belongs to the in-edge e = (i <- j) of its receiver i; the out-edge r = (j -> i) of j owns the same run.
+__device__ __forceinline__ uint32_t mrf_reverse_edge(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, uint32_t from, uint32_t to) {
+    uint32_t r = adj_ptr[to];
+    const uint32_t r1 = adj_ptr[to + 1];
+    while (r < r1 && adj[r] != from) ++r;
+    return r < r1 ? r : 0xFFFFFFFFu;                          // position of `from` in the list of `to`
+}
+__global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                    const uint32_t* __restrict__ size, uint32_t F, uint32_t* __restrict__ nsz) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > F) return;
     uint32_t t = 0;
-    if (q < F) { const uint32_t i = perm[q]; for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) t += size[e]; }
+    if (q < F) {
+        const uint32_t j = perm[q];
+        for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) { const uint32_t e = mrf_reverse_edge(adj_ptr, adj, j, adj[r]); if (e != 0xFFFFFFFFu) t += size[e]; }
+    }
     nsz[q] = t;
 }
-__global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ size,
-                                 const uint32_t* __restrict__ noff, uint32_t F, uint32_t* __restrict__ in_off) {
+__global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                 const uint32_t* __restrict__ size, const uint32_t* __restrict__ noff, uint32_t F, uint32_t* __restrict__ in_off) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= F) return;
-    const uint32_t i = perm[q];
+    const uint32_t j = perm[q];
     uint32_t off = noff[q];
-    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { in_off[e] = off; off += size[e]; }
+    for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) {
+        const uint32_t e = mrf_reverse_edge(adj_ptr, adj, j, adj[r]);
+        if (e != 0xFFFFFFFFu) { in_off[e] = off; off += size[e]; }
+    }
 }
 
 __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
@@ -732,14 +748,16 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         ctx->m_colours = C;
         ctx->m_colour_begin.resize(C + 1); ctx->m_colour_begin[C] = F;
     }
-    // message layout: in-runs in (colour, id) node order.  in_off[e] for every directed edge e (adjacency order)
+    // message layout (sender-major, (colour, id) node order): in_off[e] for every directed edge e (adjacency order);
+    // edges whose reverse is missing (asymmetric input) keep offset 0 and are disabled by mrf_edge_kernel
     DBuf<uint32_t>& in_off = ctx->m_sel2;  // temporary home, re-ensured below
     in_off.ensure(std::max<size_t>((size_t)E + 2, (size_t)F + 2));
+    MVS_HIP(hipMemsetAsync(in_off.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
     uint32_t h[3] = {0, 0, 0};
     if (F) {
-        hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->m_size.p, F, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, F, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, ctx->m_tmp_a.p, ctx->m_tmp_b.p, (size_t)F + 1, nullptr);
-        hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->m_size.p, ctx->m_tmp_b.p, F, in_off.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_tmp_b.p, F, in_off.p); MVS_LAUNCH_CHECK();
         MVS_HIP(hipMemcpyAsync(&h[0], ctx->m_tmp_b.p + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     MVS_HIP(hipMemcpyAsync(&h[1], maxes, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -261,12 +261,12 @@ def test_logical_shards_on_one_gpu_equal_single(P):
         c.set_mesh(s.verts, faces, normals); c.set_views(s.cams, s.images); c.set_face_range(int(pb[r]), int(pb[r + 1]))
         assert L.mvs_ctx_dc_phase1(c.h, C.byref(stg)) == 0
         assert L.mvs_ctx_dc_get_max(c.h, C.c_void_p(mx[r:r + 1].data_ptr())) == 0; c.synchronize()
-    gmx = mx.max().reshape(1).contiguous()
+    gmx = mx.max().reshape(1).contiguous(); torch.cuda.synchronize()   # the contexts run on their own streams
     for r, c in enumerate(ctxs):
         assert L.mvs_ctx_dc_set_max(c.h, C.c_void_p(gmx.data_ptr())) == 0
         assert L.mvs_ctx_dc_phase2(c.h) == 0
         assert L.mvs_ctx_dc_get_histogram(c.h, C.c_void_p(hist[r].data_ptr())) == 0; c.synchronize()
-    gh = hist.sum(dim=0).to(torch.int32).contiguous()
+    gh = hist.sum(dim=0).to(torch.int32).contiguous(); torch.cuda.synchronize()
     pieces = []
     for r, c in enumerate(ctxs):
         assert L.mvs_ctx_dc_set_histogram(c.h, C.c_void_p(gh.data_ptr())) == 0
