@@ -3,16 +3,18 @@
 // Model (restated from :27-82): node i = face, label set = {view_id + 1 : view_id
 // in column i} with unaries = column costs, or the single label 0 when the column
 // is empty; Potts edges of weight 1 between adjacent faces whose columns are both
-// non-empty.  mapMAP (:93-118) is replaced by a GPU-resident synchronous
-// tree-reweighted max-product sweep + monotone ICM polish; the algorithm is
-// specified to the float operation in DESIGN.md "MRF solver" and restated for
-// the CPU in oracle/oracle.cpp -- labels are bit-identical by construction:
-// min / argmin reductions are exact in any order, sums follow adjacency order,
+// non-empty.  mapMAP (:93-118) is replaced by a GPU-resident tree-reweighted
+// max-product solver -- colour-phased Gauss-Seidel sweeps (the adjacency graph is
+// coloured, each colour class updates its messages in place in turn) + monotone
+// ICM polish; the algorithm is specified to the float operation in DESIGN.md
+// "MRF solver" and restated for the CPU in oracle/oracle.cpp -- labels are
+// bit-identical by construction: a colour class is an independent set, min /
+// argmin reductions are exact in any order, sums follow adjacency order,
 // energies are 32.32 fixed-point integers.
 //
-// Work mapping: G lanes per node (G = 8..64 chosen from the largest column), the
-// lanes of a group stride over the node's labels; per-edge cavity vectors go
-// through LDS for the label re-alignment gather; min / argmin are wave shuffles.
+// Work mapping: G lanes per node (G = 8 / 16 / 32 from the largest column), 4
+// consecutive labels per lane; per-edge cavity vectors go through an LDS tile for
+// the label re-alignment gather; min / argmin are fused DPP butterflies.
 #include "ctx.h"
 #include <rocprim/rocprim.hpp>
 

@@ -9,13 +9,15 @@ Sharding (DESIGN.md "Multi-GPU"):
     quality and one all-reduce(SUM) of the 10000-bin histogram reproduce the
     global barrier of postprocess_face_infos (calculate_data_costs.cpp:278-288);
     the per-rank CSR pieces are all-gathered so every rank holds the whole table;
-  * MRF: every rank owns the nodes of its part and sweeps only those; after
-    each sweep the messages over cut edges and the decoded selections of
+  * MRF: every rank owns the nodes of its part and sweeps only those, one
+    colour class of the adjacency graph at a time (colour-phased Gauss-Seidel);
+    after each phase the messages over cut edges and the decoded selections of
     boundary nodes are exchanged with an all-to-all whose index lists are
-    planned here, on the host, from col_ptr + adjacency alone; the exact
-    fixed-point energy is all-reduced so that every rank takes the same
-    stop decision.  The schedule is synchronous, so labels are bit-identical
-    for any number of parts.
+    planned here, on the host, from col_ptr + adjacency + the library's message
+    layout; the exact fixed-point energy is all-reduced once per sweep and fed
+    to the device-side stop rule, so every rank takes the same stop decision.
+    A phase only reads nodes of other colours, which were exchanged before, so
+    labels are bit-identical for any number of parts.
 
 Everything in this file is host logic (numpy / torch.distributed); the compute
 is behind the C ABI (viewsel.Context).
