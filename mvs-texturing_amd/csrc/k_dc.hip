@@ -188,6 +188,46 @@ __global__ void __launch_bounds__(256) csr_write_kernel(const unsigned long long
     }
 }
 
+// Default path (no outlier removal): the same scatter, staged through LDS so that HBM sees coalesced rows.  A wave owns
+// 64 consecutive faces, whose CSR columns form ONE contiguous chunk of the output; it fills the chunk segment by segment
+// (SEG entries in LDS, each lane walking its views and depositing the entries that fall into the segment), then streams
+// the segment out with full-width stores.  The direct version above writes one 2-byte and one 4-byte element per lane at
+// addresses ~K entries apart: 32-byte sectors of which 2 or 4 bytes are useful (5.7 GB written for 0.53 GB at C3).
+constexpr int CSR_SEG = 2048;
+__global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned long long* __restrict__ surv, const unsigned long long* __restrict__ pass,
+                                                               const uint32_t* __restrict__ pass_base, const float* __restrict__ pq,
+                                                               uint32_t n_views, uint32_t nf, uint32_t fwords, const uint32_t* __restrict__ col_ptr,
+                                                               uint16_t* __restrict__ view_id, float* __restrict__ quality) {
+    __shared__ float s_q[4][CSR_SEG];
+    __shared__ uint16_t s_v[4][CSR_SEG];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t word = blockIdx.x * 4 + wv;                 // one wave per 64 faces (no block-level barrier is used)
+    if (word >= fwords) return;
+    const uint32_t f0 = word * 64u, lf = f0 + lane;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t c0 = col_ptr[f0], c1 = col_ptr[min(f0 + 64u, nf)];
+    const uint32_t k0 = col_ptr[min(lf, nf)];
+    for (uint32_t segbase = c0; segbase < c1; segbase += CSR_SEG) {
+        const uint32_t segend = min(segbase + (uint32_t)CSR_SEG, c1);
+        uint32_t k = k0;
+        for (uint32_t j = 0; j < n_views; ++j) {
+            const size_t widx = (size_t)j * fwords + word;
+            const unsigned long long sw = surv[widx];
+            if (sw == 0ull) continue;                          // wave-uniform
+            if ((sw >> lane) & 1ull) {
+                if (k >= segbase && k < segend) {
+                    const size_t r = (size_t)pass_base[widx] + __popcll(pass[widx] & lt);
+                    s_v[wv][k - segbase] = (uint16_t)j;
+                    s_q[wv][k - segbase] = pq[r];
+                }
+                ++k;
+            }
+        }
+        // LDS operations of one wave complete in order: the deposits above are visible to the reads below
+        for (uint32_t i = lane; i < segend - segbase; i += 64u) { view_id[segbase + i] = s_v[wv][i]; quality[segbase + i] = s_q[wv][i]; }
+    }
+}
+
 // ---- photometric_outlier_detection (calculate_data_costs.cpp:35-129) ----
 // One thread per face, fp64.  Row order = the reference's single-thread order:
 // descending view id, i.e. the CSR run walked backwards.
@@ -525,8 +565,8 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         ctx->csr_nnz = nnz;
     } else {
         ctx->csr_view.ensure((size_t)nnz_pre + 1); ctx->csr_q.ensure((size_t)nnz_pre + 1); ctx->csr_cost.ensure((size_t)nnz_pre + 1);
-        hipLaunchKernelGGL(csr_write_kernel<false>, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
-                           ctx->pq.p, (const float*)nullptr, V, nf, fwords, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_q.p, (float*)nullptr);
+        hipLaunchKernelGGL(csr_write_staged_kernel, dim3((fwords + 3) / 4), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
+                           ctx->pq.p, V, nf, fwords, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_q.p);
         MVS_LAUNCH_CHECK();
         ctx->csr_nnz = nnz_pre;
     }
