@@ -207,26 +207,52 @@ __device__ __forceinline__ uint32_t mrf_reverse_edge(const uint32_t* __restrict_
     while (r < r1 && adj[r] != from) ++r;
     return r < r1 ? r : 0xFFFFFFFFu;                          // position of `from` in the list of `to`
 }
-__global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
-                                    const uint32_t* __restrict__ size, uint32_t F, uint32_t* __restrict__ nsz) {
+// nsz[b * (F + 1) + q] = message elements node perm[q] sends to receivers of colour b (b < n_col; with n_col == 1 all
+// receivers count as colour 0 = plain sender-major).  One exclusive scan over the n_col * (F + 1) entries then yields the
+// layout  [receiver colour][sender in (colour, id) order][out-edge in list order]:
+//   * what a phase WRITES (and re-reads for damping) is one contiguous stream per receiver colour;
+//   * what a phase READS as incoming messages is the whole super-region of its own colour -- every byte of it is consumed
+//     in that phase, by receivers that follow each other roughly in memory order, so no fetched line is wasted (a plain
+//     sender-major layout gathers one 90-byte run out of each neighbour's 270-byte block: 2x the bytes at C3).
+constexpr int MAX_LAYOUT_COLOURS = 8;
+__global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ colour, const uint32_t* __restrict__ adj_ptr,
+                                    const uint32_t* __restrict__ adj, const uint32_t* __restrict__ size, uint32_t F, uint32_t n_col,
+                                    uint32_t* __restrict__ nsz) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > F) return;
-    uint32_t t = 0;
+    uint32_t acc[MAX_LAYOUT_COLOURS];
+#pragma unroll
+    for (int b = 0; b < MAX_LAYOUT_COLOURS; ++b) acc[b] = 0;
     if (q < F) {
         const uint32_t j = perm[q];
-        for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) { const uint32_t e = mrf_reverse_edge(adj_ptr, adj, j, adj[r]); if (e != 0xFFFFFFFFu) t += size[e]; }
+        for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) {
+            const uint32_t i = adj[r], e = mrf_reverse_edge(adj_ptr, adj, j, i);
+            if (e == 0xFFFFFFFFu) continue;
+            const uint32_t b = (n_col > 1) ? colour[i] : 0u, sz = size[e];
+#pragma unroll
+            for (int c = 0; c < MAX_LAYOUT_COLOURS; ++c) acc[c] += ((uint32_t)c == b) ? sz : 0u;
+        }
     }
-    nsz[q] = t;
+#pragma unroll
+    for (int b = 0; b < MAX_LAYOUT_COLOURS; ++b) if ((uint32_t)b < n_col) nsz[(size_t)b * (F + 1) + q] = acc[b];
 }
-__global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
-                                 const uint32_t* __restrict__ size, const uint32_t* __restrict__ noff, uint32_t F, uint32_t* __restrict__ in_off) {
+__global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ colour, const uint32_t* __restrict__ adj_ptr,
+                                 const uint32_t* __restrict__ adj, const uint32_t* __restrict__ size, const uint32_t* __restrict__ noff,
+                                 uint32_t F, uint32_t n_col, uint32_t* __restrict__ in_off) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= F) return;
     const uint32_t j = perm[q];
-    uint32_t off = noff[q];
+    uint32_t off[MAX_LAYOUT_COLOURS];
+#pragma unroll
+    for (int b = 0; b < MAX_LAYOUT_COLOURS; ++b) off[b] = ((uint32_t)b < n_col) ? noff[(size_t)b * (F + 1) + q] : 0u;
     for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) {
-        const uint32_t e = mrf_reverse_edge(adj_ptr, adj, j, adj[r]);
-        if (e != 0xFFFFFFFFu) { in_off[e] = off; off += size[e]; }
+        const uint32_t i = adj[r], e = mrf_reverse_edge(adj_ptr, adj, j, i);
+        if (e == 0xFFFFFFFFu) continue;
+        const uint32_t b = (n_col > 1) ? colour[i] : 0u, sz = size[e];
+        uint32_t o = 0;
+#pragma unroll
+        for (int c = 0; c < MAX_LAYOUT_COLOURS; ++c) { if ((uint32_t)c == b) { o = off[c]; off[c] += sz; } }
+        in_off[e] = o;
     }
 }
 
@@ -727,7 +753,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     const unsigned nb = (F + 255) / 256;
     if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), ctx->m_size.p, maxes); MVS_LAUNCH_CHECK(); }
     // ---- colour-phased schedule: colouring (Jones-Plassmann rounds), nodes in (colour, id) order ----
-    ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)F + 72); ctx->m_tmp_b.ensure((size_t)F + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
+    ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 72); ctx->m_tmp_b.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
     ctx->m_colours = 0; ctx->m_colour_begin.assign(66, 0); ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
     if (F) {
         uint32_t* pending = ctx->m_moved.p + 1;
@@ -761,10 +787,13 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(in_off.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
     uint32_t h[3] = {0, 0, 0};
     if (F) {
-        hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, F, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
-        exclusive_scan_u32(ctx, ctx->m_tmp_a.p, ctx->m_tmp_b.p, (size_t)F + 1, nullptr);
-        hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_tmp_b.p, F, in_off.p); MVS_LAUNCH_CHECK();
-        MVS_HIP(hipMemcpyAsync(&h[0], ctx->m_tmp_b.p + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        const uint32_t n_col = (ctx->m_colours >= 2 && ctx->m_colours <= (uint32_t)MAX_LAYOUT_COLOURS) ? ctx->m_colours : 1u;
+        const size_t n_ent = (size_t)n_col * ((size_t)F + 1);
+        ctx->m_tmp_a.ensure(n_ent + 72); ctx->m_tmp_b.ensure(n_ent + 2);
+        hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, F, n_col, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
+        exclusive_scan_u32(ctx, ctx->m_tmp_a.p, ctx->m_tmp_b.p, n_ent, nullptr);   // the last entry of every colour segment is 0, so scan[last] = total
+        hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_tmp_b.p, F, n_col, in_off.p); MVS_LAUNCH_CHECK();
+        MVS_HIP(hipMemcpyAsync(&h[0], ctx->m_tmp_b.p + (n_ent - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     MVS_HIP(hipMemcpyAsync(&h[1], maxes, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
