@@ -103,7 +103,7 @@ struct mvs_ctx {
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
-    int ray_mode = 3;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution, 3 = 2 with batched leaf tests
+    int ray_mode = 2;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution
     int lds_bvh_levels = 0;
     float cos_limit = 0.0f;  // see dmath.h cull_pair
 

@@ -469,133 +469,6 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     }
 }
 
-// ---- packet traversal with BATCHED leaf tests (ray_mode 3, default) ----
-// ray_mode 2 tests a leaf as soon as it is reached: 5-6 of the 64 rays enter the leaf box, so a round of
-// "16 rays x 4 triangles" runs at a third of the wave.  Here the (ray, leaf) pairs are queued in LDS and a round is
-// issued only when 16 pairs are waiting (plus a flush at the end): about a third of the rounds per packet at C3.
-// Testing a pair later (or after its ray was already found occluded) cannot change an any-hit result.
-template <bool COUNT, bool XCD>
-__global__ void __launch_bounds__(256) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
-                                                          const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
-                                                          unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
-                                                          const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
-    constexpr int QCAP = 16 + 64;                                // a batch is tested as soon as 16 pairs are queued
-    __shared__ float4 s_ray[4][64][2];
-    __shared__ uint8_t s_src[4][QCAP];
-    __shared__ uint32_t s_leaf[4][QCAP];
-    __shared__ uint8_t s_hit[4][64];
-    // XCD-aware order: hardware block b runs on XCD b % 8 (observed; speed only), so each XCD gets a contiguous
-    // eighth of the (view, vertex patch) sequence and with it a compact part of the BVH in its L2
-    uint32_t vblk = blockIdx.x;
-    if (XCD && (gridDim.x & 7u) == 0u) vblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint64_t wave = ((uint64_t)vblk * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (wave >= (uint64_t)vwords * n_views) return;
-    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);   // view-major: needed patches form long runs (measured: patch-major is 40 % slower)
-    const unsigned long long word = need[(size_t)j * vwords + vw];
-    if (word == 0ull) return;  // occl is pre-zeroed
-    const uint32_t s = vw * 64 + lane;
-    bool active = ((word >> lane) & 1ull) && s < n_verts;
-    const uint32_t v = vperm[s < n_verts ? s : 0];
-    const ViewParams& vp = views[j];
-    const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
-    const float pad = pad_from_box(scene_box);
-    const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad);
-    s_ray[wv][lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmin);
-    s_ray[wv][lane][1] = make_float4(r.d.x, r.d.y, r.d.z, r.tmax);
-    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    s_hit[wv][lane] = 0;
-    int qn = 0;                                                  // queued (ray, leaf) pairs, wave-uniform
-    bool hit = false;
-    uint32_t nn = 0, nt = 0;
-    int level = bvh.top;
-    uint32_t node = 0, lm0 = 0;   // lm0: this lane's own hit bits for the children (leaves) of the current level-0 node
-    // per-lane + wave-level child masks of one node
-    auto visit = [&](const Node4* __restrict__ nd, uint32_t& lane_mask) -> uint32_t {
-        uint32_t m = 0, lm = 0;
-        const uint32_t nchild = nd->nchild;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float ta = (nd->lo[0][c] - r.o.x) * inv.x, tb = (nd->hi[0][c] - r.o.x) * inv.x;
-            float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-            ta = (nd->lo[1][c] - r.o.y) * inv.y; tb = (nd->hi[1][c] - r.o.y) * inv.y;
-            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            ta = (nd->lo[2][c] - r.o.z) * inv.z; tb = (nd->hi[2][c] - r.o.z) * inv.z;
-            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            const bool h = active && tn <= tf;
-            if (h) lm |= 1u << c;
-            if (__ballot(h) != 0ull) m |= 1u << c;
-        }
-        lane_mask = lm;
-        return m & ((1u << nchild) - 1u);
-    };
-    uint32_t lm_tmp;
-    unsigned long long masks = (unsigned long long)visit(bvh.nodes + bvh.level_off[level], lm_tmp) << (4 * level);
-    if (level == 0) lm0 = lm_tmp;
-    if (COUNT) nn++;
-    while (true) {
-        const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
-        if (m == 0) {
-            if (level == bvh.top) break;
-            ++level; node >>= 2;
-            continue;
-        }
-        const int c = __builtin_ctz(m);
-        masks &= ~(1ull << (4 * level + c));
-        const uint32_t child = node * 4 + c;   // wave-uniform
-        if (level == 0) {
-            // queue the (ray, leaf) pairs of this leaf; test in batches of 16 pairs x 4 triangles = one full wave
-            const bool cand = active && ((lm0 >> c) & 1u);
-            const unsigned long long cb = __ballot(cand);
-            if (cand) { const int slot = qn + __popcll(cb & lt); s_src[wv][slot] = (uint8_t)lane; s_leaf[wv][slot] = child; }
-            qn += __popcll(cb);
-            bool tested = false;
-            while (qn >= 16) {
-                qn -= 16;
-                const int q = qn + (lane >> 2);
-                const int sl = (int)s_src[wv][q];
-                const float4* __restrict__ tp = bvh.tris + 3 * ((size_t)s_leaf[wv][q] * 4 + (lane & 3));
-                const float4 A = tp[0], E1 = tp[1], E2 = tp[2];
-                const float4 r0 = s_ray[wv][sl][0], r1 = s_ray[wv][sl][1];
-                Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
-                if (ray_tri(rr, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z})) s_hit[wv][sl] = 1;
-                if (COUNT) nt += 1;
-                tested = true;
-            }
-            if (tested) {                                        // wave-uniform: pick up this ray's verdict (any hit suffices)
-                hit = hit || (s_hit[wv][lane] != 0);
-                active = active && !hit;
-                if (__ballot(active) == 0ull) { qn = 0; break; }
-            }
-        } else {
-            --level; node = child;
-            masks |= (unsigned long long)visit(bvh.nodes + bvh.level_off[level] + node, lm_tmp) << (4 * level);
-            if (level == 0) lm0 = lm_tmp;
-            if (COUNT) nn++;
-        }
-    }
-    // flush: the remaining pairs in rounds of 16
-    for (int base = 0; base < qn; base += 16) {
-        const int q = base + (lane >> 2);
-        const bool valid = q < qn;
-        const int sl = valid ? (int)s_src[wv][q] : lane;
-        const float4* __restrict__ tp = bvh.tris + 3 * ((size_t)(valid ? s_leaf[wv][q] : 0u) * 4 + (lane & 3));
-        const float4 A = tp[0], E1 = tp[1], E2 = tp[2];
-        const float4 r0 = s_ray[wv][sl][0], r1 = s_ray[wv][sl][1];
-        Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
-        if (valid && ray_tri(rr, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z})) s_hit[wv][sl] = 1;
-        if (COUNT) nt += 1;
-    }
-    hit = hit || (s_hit[wv][lane] != 0);
-    const unsigned long long b = __ballot(hit);
-    if (lane == 0) {
-        occl[(size_t)j * vwords + vw] = b;
-        if (COUNT) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
-    }
-}
-
 }  // namespace
 
 // vertex -> incident faces (CSR vf_ptr / vf); order inside a vertex is arbitrary (atomic cursor): consumers only OR / search
@@ -670,15 +543,11 @@ void trace_rays(mvs_ctx* ctx) {
     const uint32_t vwords = (ctx->n_verts + 63) / 64;
     const uint64_t waves = (uint64_t)vwords * ctx->n_views;
     uint64_t blocks = (waves + 3) / 4;
-    if (ctx->ray_mode >= 2) blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
+    if (ctx->ray_mode == 2) blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
     if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
 #define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
                  vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
-    if (ctx->ray_mode == 3) {
-        if (ctx->count_rays) hipLaunchKernelGGL((ray_packet3_kernel<true, false>), RAY_ARGS);
-        else if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet3_kernel<false, true>), RAY_ARGS);
-        else hipLaunchKernelGGL((ray_packet3_kernel<false, false>), RAY_ARGS);
-    } else if (ctx->ray_mode == 2) {
+    if (ctx->ray_mode == 2) {
         if (ctx->count_rays) hipLaunchKernelGGL((ray_packet2_kernel<true, false>), RAY_ARGS);
         else if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet2_kernel<false, true>), RAY_ARGS);
         else hipLaunchKernelGGL((ray_packet2_kernel<false, false>), RAY_ARGS);
