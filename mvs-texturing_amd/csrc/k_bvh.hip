@@ -16,10 +16,18 @@
 // ~6 faces): need bits -> ray kernel -> occluded bits, view-major bit matrices.
 #include "ctx.h"
 #include <rocprim/rocprim.hpp>
+#ifndef MVS_LEAF_T
+#define MVS_LEAF_T 8
+#endif
 
 namespace mvs {
 
 namespace {
+
+// triangles per leaf (consecutive in Morton order).  With the packet traversal a leaf round tests (64 / LEAF_T) candidate
+// rays against LEAF_T triangles: bigger leaves mean fewer node visits and fuller rounds, more triangle tests per ray.
+constexpr uint32_t LEAF_T = MVS_LEAF_T;
+constexpr int LEAF_SLOTS = 64 / (int)LEAF_T;
 
 __device__ __forceinline__ uint32_t f2ord(float f) {  // order-preserving float -> uint
     uint32_t u = __float_as_uint(f);
@@ -110,7 +118,7 @@ __global__ void gather_tris_kernel(const float* __restrict__ verts, const uint32
     tris[3 * (size_t)s] = a; tris[3 * (size_t)s + 1] = e1; tris[3 * (size_t)s + 2] = e2;
 }
 
-// level 0: node n -> child c = leaf 4n + c = triangles 16n + 4c .. +3.  Also emits the node's own box.
+// level 0: node n -> child c = leaf 4n + c = triangles LEAF_T * (4n + c) .. + LEAF_T - 1.  Also emits the node's own box.
 __global__ void build_level0_kernel(const float4* __restrict__ tris, uint32_t n_faces, uint32_t n_leaves, uint32_t n_nodes,
                                     const uint32_t* __restrict__ scene_box, Node4* __restrict__ nodes, float* __restrict__ own_box) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,7 +135,7 @@ __global__ void build_level0_kernel(const float4* __restrict__ tris, uint32_t n_
         if (leaf < n_leaves) {
             nchild = c + 1;
             for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
-            for (uint32_t t = 4 * leaf; t < 4 * leaf + 4 && t < n_faces; ++t) {
+            for (uint32_t t = LEAF_T * leaf; t < LEAF_T * leaf + LEAF_T && t < n_faces; ++t) {
                 const float4 A = tris[3 * (size_t)t], E1 = tris[3 * (size_t)t + 1], E2 = tris[3 * (size_t)t + 2];
                 const float pa[3] = {A.x, A.y, A.z};
                 const float pb[3] = {A.x + E1.x, A.y + E1.y, A.z + E1.z};
@@ -245,9 +253,9 @@ __device__ __forceinline__ bool any_hit(const BvhDev& bvh, const Ray& r, uint32_
         const uint32_t child = node * 4 + c;
         if (level == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (uint32_t k = 0; k < LEAF_T; ++k) {
                 if (COUNT) n_tris++;
-                if (tri_pre_hit(bvh.tris, child * 4 + k, r)) return true;
+                if (tri_pre_hit(bvh.tris, child * LEAF_T + k, r)) return true;
             }
         } else {
             --level; node = child;
@@ -341,13 +349,13 @@ __global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const
         masks &= ~(1ull << (4 * level + c));
         const uint32_t child = node * 4 + c;   // wave-uniform
         if (level == 0) {
-            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * 4);
+            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * LEAF_T);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (uint32_t k = 0; k < LEAF_T; ++k) {
                 const float4 A = tp[3 * k], E1 = tp[3 * k + 1], E2 = tp[3 * k + 2];
                 if (active && ray_tri(r, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z})) hit = true;
             }
-            if (COUNT) nt += 4;
+            if (COUNT) nt += LEAF_T;
             active = active && !hit;
             if (__ballot(active) == 0ull) break;
         } else {
@@ -440,17 +448,17 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
             const int n = __popcll(cb);
             const int rank = __popcll(cb & lt);
             if (cand) s_src[wv][rank] = (uint8_t)lane;
-            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * 4 + (lane & 3));
+            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * LEAF_T + ((uint32_t)lane & (LEAF_T - 1u)));
             const float4 A = tp[0], E1 = tp[1], E2 = tp[2];
-            for (int base = 0; base < n; base += 16) {
-                const int q = base + (lane >> 2);
+            for (int base = 0; base < n; base += LEAF_SLOTS) {
+                const int q = base + lane / (int)LEAF_T;
                 const bool valid = q < n;
                 const int sl = valid ? (int)s_src[wv][q] : lane;
                 const float4 r0 = s_ray[wv][sl][0], r1 = s_ray[wv][sl][1];
                 Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
                 const bool h = valid && ray_tri(rr, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z});
                 const unsigned long long hb = __ballot(h);
-                if (cand && rank >= base && rank < base + 16 && ((hb >> (4 * (rank - base))) & 0xFull)) hit = true;
+                if (cand && rank >= base && rank < base + LEAF_SLOTS && ((hb >> ((int)LEAF_T * (rank - base))) & ((1ull << LEAF_T) - 1ull))) hit = true;
                 if (COUNT) nt += 1;
             }
             active = active && !hit;
@@ -486,8 +494,8 @@ void build_vertex_faces(mvs_ctx* ctx, const uint32_t* d_faces, uint32_t F, uint3
 void build_bvh(mvs_ctx* ctx) {
     const uint32_t F = ctx->n_faces, NV = ctx->n_verts;
     hipStream_t s = ctx->stream;
-    const uint32_t n_leaves = (F + 3) / 4;
-    const uint32_t n_slots = ((n_leaves + 3) / 4) * 16;  // triangles padded to whole level-0 nodes
+    const uint32_t n_leaves = (F + LEAF_T - 1) / LEAF_T;
+    const uint32_t n_slots = ((n_leaves + 3) / 4) * 4 * LEAF_T;  // triangles padded to whole level-0 nodes
     ctx->scene_box.ensure(8);
     uint32_t* box = (uint32_t*)ctx->scene_box.p;
     const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
