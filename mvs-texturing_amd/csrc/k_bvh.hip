@@ -409,44 +409,21 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     uint32_t nn = 0, nt = 0;
     int level = bvh.top;
     uint32_t node = 0, lm0 = 0;   // lm0: this lane's own hit bits for the children (leaves) of the current level-0 node
-    // per-lane + wave-level child masks of one node.
-    // The rays of a packet run from neighbouring vertices to ONE camera, so the signs of their direction components are
-    // almost always the same in every lane: then "near plane = lo or hi" is a wave-uniform choice made on the scalar
-    // side, and the per-lane slab test needs no min / max pair per axis (the values are the same ones -- (bound - o) *
-    // inv -- only selected instead of compared; 17 instead of 25 VALU instructions per child box).
-    const unsigned long long act0 = __ballot(active);
-    const unsigned long long px = __ballot(active && inv.x >= 0.0f), py = __ballot(active && inv.y >= 0.0f), pz = __ballot(active && inv.z >= 0.0f);
-    const bool uniform_signs = (px == 0ull || px == act0) && (py == 0ull || py == act0) && (pz == 0ull || pz == act0) &&
-                               __ballot(active && (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f)) == 0ull;   // 0 * inf = NaN needs the min/max form
-    const bool nx = px != 0ull, ny = py != 0ull, nz = pz != 0ull;   // true: the near plane is lo
+    // per-lane + wave-level child masks of one node
     auto visit = [&](const Node4* __restrict__ nd, uint32_t& lane_mask) -> uint32_t {
         uint32_t m = 0, lm = 0;
         const uint32_t nchild = nd->nchild;
-        if (uniform_signs) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float nxp = nx ? nd->lo[0][c] : nd->hi[0][c], fxp = nx ? nd->hi[0][c] : nd->lo[0][c];   // scalar selects
-                const float nyp = ny ? nd->lo[1][c] : nd->hi[1][c], fyp = ny ? nd->hi[1][c] : nd->lo[1][c];
-                const float nzp = nz ? nd->lo[2][c] : nd->hi[2][c], fzp = nz ? nd->hi[2][c] : nd->lo[2][c];
-                const float tn = fmaxf(fmaxf(t0, (nxp - r.o.x) * inv.x), fmaxf((nyp - r.o.y) * inv.y, (nzp - r.o.z) * inv.z));
-                const float tf = fminf(fminf(t1, (fxp - r.o.x) * inv.x), fminf((fyp - r.o.y) * inv.y, (fzp - r.o.z) * inv.z));
-                const bool h = active && tn <= tf;
-                if (h) lm |= 1u << c;
-                if (__ballot(h) != 0ull) m |= 1u << c;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float ta = (nd->lo[0][c] - r.o.x) * inv.x, tb = (nd->hi[0][c] - r.o.x) * inv.x;
-                float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-                ta = (nd->lo[1][c] - r.o.y) * inv.y; tb = (nd->hi[1][c] - r.o.y) * inv.y;
-                tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-                ta = (nd->lo[2][c] - r.o.z) * inv.z; tb = (nd->hi[2][c] - r.o.z) * inv.z;
-                tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-                const bool h = active && tn <= tf;
-                if (h) lm |= 1u << c;
-                if (__ballot(h) != 0ull) m |= 1u << c;
-            }
+        for (int c = 0; c < 4; ++c) {
+            float ta = (nd->lo[0][c] - r.o.x) * inv.x, tb = (nd->hi[0][c] - r.o.x) * inv.x;
+            float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
+            ta = (nd->lo[1][c] - r.o.y) * inv.y; tb = (nd->hi[1][c] - r.o.y) * inv.y;
+            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+            ta = (nd->lo[2][c] - r.o.z) * inv.z; tb = (nd->hi[2][c] - r.o.z) * inv.z;
+            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
+            const bool h = active && tn <= tf;
+            if (h) lm |= 1u << c;
+            if (__ballot(h) != 0ull) m |= 1u << c;
         }
         lane_mask = lm;
         return m & ((1u << nchild) - 1u);
