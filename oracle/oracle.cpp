@@ -731,8 +731,8 @@ void orc_csr_free(orc_csr* c) {
 // non-empty.  Energy: E(l) = sum_i D_i(l_i) + sum_{(i,j)} [l_i != l_j].
 //
 // The SOLVER is DEFINED HERE (mapMAP fa526e0 is absent -- SURVEY.md 0.2, 7):
-// synchronous (Jacobi) tree-reweighted max-product message passing over the
-// face adjacency graph, followed by a monotone ICM polish.  Every quantity is
+// tree-reweighted max-product message passing over the face adjacency graph with a
+// colour-phased Gauss-Seidel schedule (below), followed by a monotone ICM polish.  Every quantity is
 // specified down to the float operation order so that the HIP implementation
 // can be bit-exact at any number of GPUs / partitions:
 //
@@ -740,7 +740,9 @@ void orc_csr_free(orc_csr* c) {
 //    Message m_e has K_i entries aligned with i's label list; moff[e] is the
 //    exclusive prefix sum of (valid ? K_i : 0) in adjacency-CSR order;
 //    map[moff[e] + t] = position of L_i[t] inside L_j, or 0xFFFF.  m = 0 at start.
-//  * One sweep, for every node i, from the PREVIOUS sweep's messages:
+//  * Schedule: the adjacency graph is coloured greedily in the order of the keys (hash32(i), i) (mrf_colour); one
+//    sweep = for colour 0, 1, ...: every node of that colour (an independent set) updates IN PLACE from the
+//    current messages.  The update of node i:
 //      S[t]  = sum over valid e (CSR order, from 0.0f) of m_e[t]
 //      b[t]  = D[t] + rho * S[t];  sel_i = first argmin_t b[t]
 //      for each valid e (to j):  oth[t] = sum over valid e' != e of m_e'[t]
@@ -751,8 +753,8 @@ void orc_csr_free(orc_csr* c) {
 //  * After each sweep the decoded labeling's energy is evaluated exactly in
 //    32.32 fixed point (integer sums are order independent); the best labeling
 //    so far is kept.  Stop like StopWhenReturnsDiminish(5, 0.01)
-//    (view_selection.cpp:84): when the best energy improved by less than 1 %
-//    over the last 5 sweeps (and at least min_sweeps ran), or at max_sweeps.
+//    (view_selection.cpp:84): when the best energy improved by less than min_improvement (default 0.2 %)
+//    over the last `window` (default 5) sweeps (and at least min_sweeps ran), or at max_sweeps.
 //  * ICM polish: every node computes its best label given the neighbours'
 //    labels and its gain; a node moves iff gain > 0 and (gain, -index) beats
 //    all its neighbours' (an independent set => energy strictly decreases).
