@@ -87,7 +87,7 @@ struct alignas(16) NodeDesc {   // fast-path (degree <= 3) per-node descriptor, 
     uint32_t kj[3];           // neighbour column lengths (0 = edge not in the model); top bit = identical label lists
     uint32_t nbr[3];          // neighbour node ids (0xFFFFFFFF = none)
     uint32_t id;        // the node (face) this descriptor belongs to: descriptors are stored in (colour, id) order
-    uint32_t pc;        // first element of the node's unaries in the phase-ordered copy of the cost array (16-byte aligned)
+    uint32_t pad_;
 };
 static_assert(sizeof(NodeDesc) == 64, "NodeDesc must be 64 bytes");
 
@@ -167,7 +167,7 @@ struct mvs_ctx {
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved; mvs::DBuf<uint8_t> m_dirty; bool icm_dirty_valid = false;
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0;
     // colour-phased schedule: colours of the adjacency graph, nodes in (colour, id) order, class boundaries (host copy)
-    mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c; mvs::DBuf<float> m_cost_perm; uint32_t m_colours = 0; std::vector<uint32_t> m_colour_begin;
+    mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c; uint32_t m_colours = 0; std::vector<uint32_t> m_colour_begin;
     uint32_t m_range_nb = 0, m_range_ne = 0; std::vector<uint32_t> m_range_q;   // cached own share of every colour class
     mvs_mrf_params m_params{};
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring

@@ -256,21 +256,6 @@ __global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32
     }
 }
 
-// unaries in (colour, id) node order, every column padded to 4 floats: a colour phase streams its unaries with
-// aligned 16-byte loads instead of picking every third column out of the CSR
-__global__ void mrf_costsize_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ col_ptr, uint32_t F, uint32_t* __restrict__ kp) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > F) return;
-    kp[q] = (q < F) ? ((col_ptr[perm[q] + 1] - col_ptr[perm[q]] + 3u) & ~3u) : 0u;
-}
-__global__ void mrf_costperm_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost,
-                                    const uint32_t* __restrict__ pc, uint32_t F, float* __restrict__ cost_perm) {
-    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, gl = threadIdx.x & 15;   // 16 lanes per node
-    if (q >= F) return;
-    const uint32_t i = perm[q], p0 = col_ptr[i], K = col_ptr[i + 1] - p0, o = pc[q];
-    for (uint32_t t = gl; t < ((K + 3u) & ~3u); t += 16) cost_perm[o + t] = (t < K) ? cost[p0 + t] : 0.0f;
-}
-
 __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 uint32_t F, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ size, MrfEdge* __restrict__ edge) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,7 +311,7 @@ __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint1
 // the node in a single 3 x 16-byte load instead of the col_ptr -> adj_ptr -> edge[] dependent chain.
 __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm,
-                                const uint32_t* __restrict__ pc, uint32_t F, NodeDesc* __restrict__ desc) {
+                                uint32_t F, NodeDesc* __restrict__ desc) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // position in the (colour, id) order
     if (q >= F) return;
     const uint32_t i = perm[q];
@@ -345,7 +330,7 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
         }
         nd.in_off[d] = m.in_off; nd.out_off[d] = m.out_off; nd.kj[d] = m.kj | flag; nd.nbr[d] = nb;
     }
-    nd.id = i; nd.pc = pc[q];
+    nd.id = i; nd.pad_ = 0;
     desc[q] = nd;
 }
 
@@ -369,7 +354,7 @@ struct alignas(8) msg4_t { msg_t v[4]; };
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int G, bool DAMP, bool XCD, bool LATE_OLD>
 __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                         const float* __restrict__ cost_perm, const uint16_t* __restrict__ map, msg_t* msg,
+                                                         const uint16_t* __restrict__ map, msg_t* msg,
                                                          uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
                                                          uint32_t node_begin /* positions in the (colour, id) order */, uint32_t node_end, float rho, float alpha) {
     // in place: the nodes of one launch share a colour (an independent set), so no run is read by one node and
@@ -402,7 +387,7 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         for (int r = 0; r < 4; ++r) ok[r] = t0 + r < K;
         // phase 1: addresses (always valid); phase 2: ALL loads as raw 8/16-byte words, issued back to back under
         // one wait (a load under a divergent branch would get its own exec region and s_waitcnt); phase 3: unpack.
-        const uint32_t da = ok[0] ? cur.pc + t0 : 0u;        // multiples of 4 floats
+        const uint32_t da = ok[0] ? p0 + t0 : 0u;
         uint32_t a_in[3], a_out[3], a_map[3], kj3[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -413,7 +398,7 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             a_out[d] = o0 ? cur.out_off[d] + t0 : t0;
             a_map[d] = (o0 && !(kjf & IDENT)) ? cur.out_off[d] + t0 : t0;      // t0 < MSG_BASE: the identity run
         }
-        const float4 dv = *reinterpret_cast<const float4*>(cost_perm + da);
+        const f32x4_a4 dv = *reinterpret_cast<const f32x4_a4*>(cost + da);
         uint2 r_in[3], r_old[3], r_map[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -821,17 +806,18 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
     if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p,
                                (ctx->m_degmax <= 3 && ctx->m_kmax <= 128 && ctx->csr_nnz >= 4) ? 1 : 0); MVS_LAUNCH_CHECK(); }
-    // phase-ordered copy of the unaries (m_tmp_c = pc, the first element of every node's padded column)
-    if (F) {
-        hipLaunchKernelGGL(mrf_costsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->r_ptr, F, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
-        exclusive_scan_u32(ctx, ctx->m_tmp_a.p, ctx->m_tmp_c.p, (size_t)F + 1, nullptr);
-        ctx->m_cost_perm.ensure(ctx->csr_nnz + 3 * (size_t)F + 16);   // padding adds at most 3 floats per column
-        hipLaunchKernelGGL(mrf_costperm_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->m_perm.p, ctx->r_ptr, ctx->r_cost, ctx->m_tmp_c.p, F, ctx->m_cost_perm.p); MVS_LAUNCH_CHECK();
-    } else ctx->m_cost_perm.ensure(16);
     ctx->m_desc.ensure((size_t)F + 1);
-    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, ctx->m_tmp_c.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
+    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
     ctx->m_msg_a.ensure(ctx->m_total + 8);
     MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // binary16 zeros, incl. the reserved zero run
+    // the sweep reads unaries with unclamped 16-byte loads: a caller-owned cost array (mvs_ctx_costs_upload with device
+    // pointers) is copied into the context's own buffer, which always has slack behind the last element
+    if (ctx->r_cost != ctx->csr_cost.p && ctx->csr_nnz) {
+        ctx->csr_cost.ensure(ctx->csr_nnz + 8);
+        MVS_HIP(hipMemcpyAsync(ctx->csr_cost.p, ctx->r_cost, ctx->csr_nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ctx->r_cost = ctx->csr_cost.p;
+    }
+    if (ctx->r_cost == ctx->csr_cost.p && ctx->csr_cost.cap >= ctx->csr_nnz + 8) MVS_HIP(hipMemsetAsync(ctx->csr_cost.p + ctx->csr_nnz, 0, 8 * sizeof(float), s));
     MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
     ctx->m_sel.ensure((size_t)F + 1); ctx->m_best_sel.ensure((size_t)F + 1); ctx->m_sel2.ensure((size_t)F + 1); ctx->m_cand.ensure((size_t)F + 1); ctx->m_gain.ensure((size_t)F + 1);
     ctx->m_lab.ensure((size_t)F + 1); ctx->m_best_lab.ensure((size_t)F + 1); ctx->m_cost.ensure((size_t)F + 1); ctx->m_best_cost.ensure((size_t)F + 1);
@@ -907,7 +893,7 @@ static void launch_sweep4_g(mvs_ctx* ctx, uint32_t qb, uint32_t qe) {
     blocks = std::max(1u, std::min(need, blocks));
     if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
     msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
-#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_cost_perm.p, ctx->m_map.p, msg, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, qb, qe, rho, alpha
+#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, msg, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, qb, qe, rho, alpha
     if (alpha != 0.0f) {
         if (ctx->mrf_late_old) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, true>), SWEEP4_ARGS); }
         else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, false>), SWEEP4_ARGS); }
