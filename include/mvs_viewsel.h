@@ -81,7 +81,7 @@ typedef struct {
  * (view_selection.cpp:84,103-115); mapMAP is replaced by a GPU-resident
  * tree-reweighted max-product solver -- colour-phased Gauss-Seidel sweeps + monotone ICM polish --
  * whose knobs are below.  mvs_mrf_default_params gives the shipped defaults
- * (200 / 20 / 5 / 0.002 / 0.3 / 0.8 / 50). */
+ * (200 / 20 / 5 / 0.002 / 0.1 / 0.8 / 50). */
 typedef struct {
     int32_t max_sweeps;
     int32_t min_sweeps;

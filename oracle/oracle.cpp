@@ -977,7 +977,7 @@ void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = le
 
 void orc_mrf_default_params(orc_mrf_params* p) {
     p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
-    p->damping = 0.3f; p->rho = 0.8f; p->icm_iters = 50;
+    p->damping = 0.1f; p->rho = 0.8f; p->icm_iters = 50;
 }
 
 int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
