@@ -63,7 +63,7 @@ static_assert(sizeof(Node4) == 128, "Node4 must be one 128-byte line");
 
 struct BvhDev {
     const Node4* nodes;       // all levels, level L at nodes + level_off[L]
-    const float4* tris;       // 3 float4 per triangle: a, e1 = b - a, e2 = c - a  (Morton order, zero padded)
+    const float4* tris;       // 4 float4 per triangle: {a, lo.x} {e1 = b - a, lo.y} {e2 = c - a, lo.z} {hi, 0}  (curve order, zero padded)
     uint32_t level_off[16];
     uint32_t level_cnt[16];
     int32_t top;              // index of the root level (level_cnt[top] == 1)

@@ -134,30 +134,46 @@ MVS_HD float scene_pad(const float lo[3], const float hi[3]) {
 // rayint (acc::BVHTree, calculate_data_costs.cpp:23,144,209) is not available and
 // the reference only uses the boolean, so the predicate is defined by this
 // library (DESIGN.md "Occlusion rays"): Moeller-Trumbore in fp32 with this exact
-// operation order, no barycentric slack, t in [tmin, tmax], AND the computed hit
+// operation order, in the division-free form -- with s = sign(det) the scaled
+// barycentrics s u det, s v det and the scaled distance s t det are compared with
+// 0, |det|, tmin |det| and tmax |det| (no slack anywhere) -- and, for a ray that
+// passes all of these, t = (t det) / det (correctly rounded) AND the computed hit
 // point o + t d must lie inside the triangle's bounding box grown by `pad`.
 // The last clause makes box culling provably conservative (a grazing ray whose
 // rounded barycentrics are accepted although it misses the triangle's box is
 // rejected by every implementation alike), so the OR over all triangles does not
-// depend on the acceleration structure.
-MVS_HD bool ray_tri(const Ray& r, V3 a, V3 e1, V3 e2) {
+// depend on the acceleration structure.  Only a real crossing pays for the
+// division and the box clause; everything before is branch free.
+// The box clause is evaluated against (lo, hi) = triangle box grown by pad, which the GPU stores with the triangle
+// (tri_pad_box below, evaluated once at build time instead of once per test -- the same fp32 expressions, so the
+// predicate is bit-identical either way).
+MVS_HD void tri_pad_box(V3 a, V3 e1, V3 e2, float pad, V3* lo, V3* hi) {
+    const V3 b = a + e1, c = a + e2;
+    lo->x = fminf(a.x, fminf(b.x, c.x)) - pad; hi->x = fmaxf(a.x, fmaxf(b.x, c.x)) + pad;
+    lo->y = fminf(a.y, fminf(b.y, c.y)) - pad; hi->y = fmaxf(a.y, fmaxf(b.y, c.y)) + pad;
+    lo->z = fminf(a.z, fminf(b.z, c.z)) - pad; hi->z = fmaxf(a.z, fmaxf(b.z, c.z)) + pad;
+}
+MVS_HD bool ray_tri_boxed(const Ray& r, V3 a, V3 e1, V3 e2, V3 lo, V3 hi) {
     const V3 pv = cross(r.d, e2);
     const float det = dot(e1, pv);
-    if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
     const V3 tv = r.o - a;
-    const float u = dot(tv, pv) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const float un = dot(tv, pv);                 // u det
     const V3 qv = cross(tv, e1);
-    const float v = dot(r.d, qv) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    const float t = dot(e2, qv) * inv;
-    if (!(t >= r.tmin && t <= r.tmax)) return false;
-    const V3 b = a + e1, c = a + e2;
+    const float vn = dot(r.d, qv);                // v det
+    const float tn = dot(e2, qv);                 // t det
+    const bool neg = det < 0.0f;
+    const float ad = neg ? -det : det;
+    const float us = neg ? -un : un, vs = neg ? -vn : vn, ts = neg ? -tn : tn;
+    const bool pre = ad > 0.0f && us >= 0.0f && vs >= 0.0f && us + vs <= ad && ts >= r.tmin * ad && ts <= r.tmax * ad;
+    if (!pre) return false;
+    const float t = tn / det;
     const float hx = r.o.x + t * r.d.x, hy = r.o.y + t * r.d.y, hz = r.o.z + t * r.d.z;
-    return hx >= fminf(a.x, fminf(b.x, c.x)) - r.pad && hx <= fmaxf(a.x, fmaxf(b.x, c.x)) + r.pad &&
-           hy >= fminf(a.y, fminf(b.y, c.y)) - r.pad && hy <= fmaxf(a.y, fmaxf(b.y, c.y)) + r.pad &&
-           hz >= fminf(a.z, fminf(b.z, c.z)) - r.pad && hz <= fmaxf(a.z, fmaxf(b.z, c.z)) + r.pad;
+    return hx >= lo.x && hx <= hi.x && hy >= lo.y && hy <= hi.y && hz >= lo.z && hz <= hi.z;
+}
+MVS_HD bool ray_tri(const Ray& r, V3 a, V3 e1, V3 e2) {
+    V3 lo, hi;
+    tri_pad_box(a, e1, e2, r.pad, &lo, &hi);
+    return ray_tri_boxed(r, a, e1, e2, lo, hi);
 }
 
 // mve::Image<uint8_t>::linear_at as used at texture_view.cpp:226-229,240-243

@@ -125,21 +125,36 @@ __global__ void invert_perm_kernel(const uint32_t* __restrict__ perm, uint32_t n
     if (s < n) inv[perm[s]] = s;
 }
 
-// triangles in Morton order as {a, e1 = b - a, e2 = c - a}; slots >= n_faces are degenerate (never hit)
+__device__ __forceinline__ float pad_from_box(const uint32_t* __restrict__ box) {
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = ord2f(box[a]); hi[a] = ord2f(box[3 + a]); }
+    return scene_pad(lo, hi);
+}
+
+// triangles in curve order, 64 bytes each: {a, lo.x}, {e1 = b - a, lo.y}, {e2 = c - a, lo.z}, {hi, 0} with (lo, hi) = the
+// triangle's box grown by pad (dmath.h tri_pad_box: the box clause of the hit predicate, evaluated once here instead of
+// once per test -- 24 VALU instructions of every leaf test); slots >= n_faces are degenerate (never hit)
+constexpr uint32_t TRI_F4 = 4;
 __global__ void gather_tris_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const uint32_t* __restrict__ order,
-                                   uint32_t n_faces, uint32_t n_slots, float4* __restrict__ tris) {
+                                   uint32_t n_faces, uint32_t n_slots, const uint32_t* __restrict__ scene_box, float4* __restrict__ tris) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
-    float4 a = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+    float4 a = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0}, h = {0, 0, 0, 0};
     if (s < n_faces) {
         const uint32_t* fv = faces + 3 * (size_t)order[s];
         const V3 pa = {verts[3 * (size_t)fv[0]], verts[3 * (size_t)fv[0] + 1], verts[3 * (size_t)fv[0] + 2]};
         const V3 pb = {verts[3 * (size_t)fv[1]], verts[3 * (size_t)fv[1] + 1], verts[3 * (size_t)fv[1] + 2]};
         const V3 pc = {verts[3 * (size_t)fv[2]], verts[3 * (size_t)fv[2] + 1], verts[3 * (size_t)fv[2] + 2]};
         const V3 d1 = pb - pa, d2 = pc - pa;
-        a = {pa.x, pa.y, pa.z, 0.0f}; e1 = {d1.x, d1.y, d1.z, 0.0f}; e2 = {d2.x, d2.y, d2.z, 0.0f};
+        V3 lo, hi;
+        tri_pad_box(pa, d1, d2, pad_from_box(scene_box), &lo, &hi);
+        a = {pa.x, pa.y, pa.z, lo.x}; e1 = {d1.x, d1.y, d1.z, lo.y}; e2 = {d2.x, d2.y, d2.z, lo.z}; h = {hi.x, hi.y, hi.z, 0.0f};
     }
-    tris[3 * (size_t)s] = a; tris[3 * (size_t)s + 1] = e1; tris[3 * (size_t)s + 2] = e2;
+    float4* t = tris + TRI_F4 * (size_t)s;
+    t[0] = a; t[1] = e1; t[2] = e2; t[3] = h;
+}
+__device__ __forceinline__ bool tri_hit(const float4 A, const float4 E1, const float4 E2, const float4 H, const Ray& r) {
+    return ray_tri_boxed(r, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z}, V3{A.w, E1.w, E2.w}, V3{H.x, H.y, H.z});
 }
 
 // level 0: node n -> child c = leaf 4n + c = triangles LEAF_T * (4n + c) .. + LEAF_T - 1.  Also emits the node's own box.
@@ -160,7 +175,7 @@ __global__ void build_level0_kernel(const float4* __restrict__ tris, uint32_t n_
             nchild = c + 1;
             for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
             for (uint32_t t = LEAF_T * leaf; t < LEAF_T * leaf + LEAF_T && t < n_faces; ++t) {
-                const float4 A = tris[3 * (size_t)t], E1 = tris[3 * (size_t)t + 1], E2 = tris[3 * (size_t)t + 2];
+                const float4 A = tris[TRI_F4 * (size_t)t], E1 = tris[TRI_F4 * (size_t)t + 1], E2 = tris[TRI_F4 * (size_t)t + 2];
                 const float pa[3] = {A.x, A.y, A.z};
                 const float pb[3] = {A.x + E1.x, A.y + E1.y, A.z + E1.z};
                 const float pc[3] = {A.x + E2.x, A.y + E2.y, A.z + E2.z};
@@ -247,14 +262,8 @@ __device__ __forceinline__ uint32_t node_hits(const Node4* __restrict__ nd, V3 o
 }
 
 __device__ __forceinline__ bool tri_pre_hit(const float4* __restrict__ tris, uint32_t t, const Ray& r) {
-    const float4 A = tris[3 * (size_t)t], E1 = tris[3 * (size_t)t + 1], E2 = tris[3 * (size_t)t + 2];
-    return ray_tri(r, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z});
-}
-
-__device__ __forceinline__ float pad_from_box(const uint32_t* __restrict__ box) {
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) { lo[a] = ord2f(box[a]); hi[a] = ord2f(box[3 + a]); }
-    return scene_pad(lo, hi);
+    const float4* p = tris + TRI_F4 * (size_t)t;
+    return tri_hit(p[0], p[1], p[2], p[3], r);
 }
 
 template <bool COUNT>
@@ -373,11 +382,10 @@ __global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const
         masks &= ~(1ull << (4 * level + c));
         const uint32_t child = node * 4 + c;   // wave-uniform
         if (level == 0) {
-            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * LEAF_T);
+            const float4* __restrict__ tp = bvh.tris + TRI_F4 * (size_t)(child * LEAF_T);
 #pragma unroll
             for (uint32_t k = 0; k < LEAF_T; ++k) {
-                const float4 A = tp[3 * k], E1 = tp[3 * k + 1], E2 = tp[3 * k + 2];
-                if (active && ray_tri(r, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z})) hit = true;
+                if (active && tri_hit(tp[TRI_F4 * k], tp[TRI_F4 * k + 1], tp[TRI_F4 * k + 2], tp[TRI_F4 * k + 3], r)) hit = true;
             }
             if (COUNT) nt += LEAF_T;
             active = active && !hit;
@@ -418,7 +426,7 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     const unsigned long long word = need[(size_t)j * vwords + vw];
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t s = vw * 64 + lane;
-    bool active = ((word >> lane) & 1ull) && s < n_verts;
+    const bool active = ((word >> lane) & 1ull) && s < n_verts;
     const uint32_t v = vperm[s < n_verts ? s : 0];
     const ViewParams& vp = views[j];
     const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
@@ -427,76 +435,93 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     s_ray[wv][lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmin);
     s_ray[wv][lane][1] = make_float4(r.d.x, r.d.y, r.d.z, r.tmax);
     const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+    const V3 oi = {r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z};
     const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    bool hit = false;
     uint32_t nn = 0, nt = 0;
     int level = bvh.top;
-    uint32_t node = 0, lm0 = 0;   // lm0: this lane's own hit bits for the children (leaves) of the current level-0 node
-    // per-lane + wave-level child masks of one node
-    auto visit = [&](const Node4* __restrict__ nd, uint32_t& lane_mask) -> uint32_t {
-        uint32_t m = 0, lm = 0;
+    uint32_t node = 0;
+    // The kernel is VALU bound (SQ_ACTIVE_INST_VALU = 98 % of the SIMD cycles at C3), so everything that is the same for
+    // the whole wave lives in SGPRs: the set of live rays (actm) and of occluded rays (hitm) are 64-bit scalars, the four
+    // per-child hit ballots of a node ARE the per-lane hit bits (bit L = lane L; hm0: those of the current level-0 node,
+    // whose children are the leaves), a scalar mask becomes an execution mask again through inverse_ballot, ranks come
+    // from v_mbcnt on the scalar mask.  A ballot of a bare float compare is the compare itself (it writes an SGPR pair).
+    unsigned long long actm = __builtin_amdgcn_ballot_w64(active), hitm = 0ull;
+    unsigned long long hm0[4] = {0ull, 0ull, 0ull, 0ull};
+    auto visit = [&](const Node4* __restrict__ ndp, unsigned long long (&hm)[4]) -> uint32_t {
+        uint32_t m = 0;
+        const Node4 ndv = *ndp;                // the whole 128-byte line with two wide scalar loads
+        const Node4* nd = &ndv;
         const uint32_t nchild = nd->nchild;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float ta = (nd->lo[0][c] - r.o.x) * inv.x, tb = (nd->hi[0][c] - r.o.x) * inv.x;
+            // t = bound * inv - o * inv as ONE fma (the product is exact inside it; oi is rounded once per ray): 12 instead of
+            // 24 VALU operations per child.  Its absolute error, ulp(o * inv) <= 6e-8 |o| |inv|, is 400 times smaller than
+            // the margin the boxes carry for exactly this purpose (a hit point lies >= 3 pad = 3e-5 max|coord| inside its leaf
+            // box, i.e. 3 pad |inv| inside the slab), so the test stays conservative; inf - inf = NaN drops the axis (fmin/fmax).
+            float ta = __builtin_fmaf(nd->lo[0][c], inv.x, -oi.x), tb = __builtin_fmaf(nd->hi[0][c], inv.x, -oi.x);
             float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-            ta = (nd->lo[1][c] - r.o.y) * inv.y; tb = (nd->hi[1][c] - r.o.y) * inv.y;
+            ta = __builtin_fmaf(nd->lo[1][c], inv.y, -oi.y); tb = __builtin_fmaf(nd->hi[1][c], inv.y, -oi.y);
             tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            ta = (nd->lo[2][c] - r.o.z) * inv.z; tb = (nd->hi[2][c] - r.o.z) * inv.z;
+            ta = __builtin_fmaf(nd->lo[2][c], inv.z, -oi.z); tb = __builtin_fmaf(nd->hi[2][c], inv.z, -oi.z);
             tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            const bool h = active && tn <= tf;
-            if (h) lm |= 1u << c;
-            if (__ballot(h) != 0ull) m |= 1u << c;
+            hm[c] = __builtin_amdgcn_ballot_w64(tn <= tf) & actm;
+            if (hm[c] != 0ull) m |= 1u << c;
         }
-        lane_mask = lm;
         return m & ((1u << nchild) - 1u);
     };
-    uint32_t lm_tmp;
-    unsigned long long masks = (unsigned long long)visit(bvh.nodes + bvh.level_off[level], lm_tmp) << (4 * level);
-    if (level == 0) lm0 = lm_tmp;
+    unsigned long long hm_tmp[4];
+    unsigned long long masks;
+    const uint32_t off0 = bvh.level_off[0];   // heap index of the first level-0 node
+    if (level == 0) masks = (unsigned long long)visit(bvh.nodes, hm0);       // node = heap index (root = 0)
+    else masks = (unsigned long long)visit(bvh.nodes, hm_tmp) << (4 * level);
     if (COUNT) nn++;
     while (true) {
         const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
         if (m == 0) {
             if (level == bvh.top) break;
-            ++level; node >>= 2;
+            ++level; node = (node - 1u) >> 2;
             continue;
         }
         const int c = __builtin_ctz(m);
         masks &= ~(1ull << (4 * level + c));
-        const uint32_t child = node * 4 + c;   // wave-uniform
         if (level == 0) {
-            const bool cand = active && ((lm0 >> c) & 1u);
-            const unsigned long long cb = __ballot(cand);
-            const int n = __popcll(cb);
-            const int rank = __popcll(cb & lt);
-            if (cand) s_src[wv][rank] = (uint8_t)lane;
-            const float4* __restrict__ tp = bvh.tris + 3 * (size_t)(child * LEAF_T + ((uint32_t)lane & (LEAF_T - 1u)));
-            const float4 A = tp[0], E1 = tp[1], E2 = tp[2];
-            for (int base = 0; base < n; base += LEAF_SLOTS) {
-                const int q = base + lane / (int)LEAF_T;
-                const bool valid = q < n;
-                const int sl = valid ? (int)s_src[wv][q] : lane;
-                const float4 r0 = s_ray[wv][sl][0], r1 = s_ray[wv][sl][1];
-                Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
-                const bool h = valid && ray_tri(rr, V3{A.x, A.y, A.z}, V3{E1.x, E1.y, E1.z}, V3{E2.x, E2.y, E2.z});
-                const unsigned long long hb = __ballot(h);
-                if (cand && rank >= base && rank < base + LEAF_SLOTS && ((hb >> ((int)LEAF_T * (rank - base))) & ((1ull << LEAF_T) - 1ull))) hit = true;
-                if (COUNT) nt += 1;
+            const uint32_t child = (node - off0) * 4 + c;   // leaf index, wave-uniform
+            const unsigned long long hsel = (c == 0) ? hm0[0] : (c == 1) ? hm0[1] : (c == 2) ? hm0[2] : hm0[3];
+            const unsigned long long cb = hsel & actm;          // rays that are still live and enter this leaf's box
+            if (cb != 0ull) {
+                const bool cand = __builtin_amdgcn_inverse_ballot_w64(cb);
+                const int n = __builtin_popcountll(cb);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+                if (cand) s_src[wv][rank] = (uint8_t)lane;
+                const float4* __restrict__ tp = bvh.tris + TRI_F4 * (size_t)(child * LEAF_T + ((uint32_t)lane & (LEAF_T - 1u)));
+                const float4 A = tp[0], E1 = tp[1], E2 = tp[2], H = tp[3];
+                for (int base = 0; base < n; base += LEAF_SLOTS) {
+                    const int q = base + lane / (int)LEAF_T;
+                    const bool valid = q < n;
+                    const int sl = valid ? (int)s_src[wv][q] : lane;
+                    const float4 r0 = s_ray[wv][sl][0], r1 = s_ray[wv][sl][1];
+                    Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
+                    const bool h = valid && tri_hit(A, E1, E2, H, rr);
+                    const unsigned long long hb = __builtin_amdgcn_ballot_w64(h);
+                    if (hb != 0ull) {   // wave-uniform and rare (hits are rare): the owner of slot (rank - base) reads its LEAF_T result bits
+                        const bool mine = cand && rank >= base && rank < base + LEAF_SLOTS &&
+                                          ((hb >> ((int)LEAF_T * (rank - base))) & ((1ull << LEAF_T) - 1ull)) != 0ull;
+                        hitm |= __builtin_amdgcn_ballot_w64(mine);
+                    }
+                    if (COUNT) nt += 1;
+                }
+                actm &= ~hitm;
+                if (actm == 0ull) break;
             }
-            active = active && !hit;
-            if (__ballot(active) == 0ull) break;
         } else {
-            --level; node = child;
-            masks |= (unsigned long long)visit(bvh.nodes + bvh.level_off[level] + node, lm_tmp) << (4 * level);
-            if (level == 0) lm0 = lm_tmp;
+            --level; node = node * 4 + 1 + c;
+            if (level == 0) masks |= (unsigned long long)visit(bvh.nodes + node, hm0);
+            else masks |= (unsigned long long)visit(bvh.nodes + node, hm_tmp) << (4 * level);
             if (COUNT) nn++;
         }
     }
-    const unsigned long long b = __ballot(hit);
     if (lane == 0) {
-        occl[(size_t)j * vwords + vw] = b;
+        occl[(size_t)j * vwords + vw] = hitm;
         if (COUNT) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
     }
 }
@@ -533,22 +558,32 @@ void build_bvh(mvs_ctx* ctx) {
     MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->morton_v2.p, F, 0, 30, s));
     ctx->sort_tmp.ensure(tmp_bytes + 16);
     MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->morton_v2.p, F, 0, 30, s));
-    ctx->bvh_tris.ensure(3 * (size_t)n_slots);
-    hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->morton_v2.p, F, n_slots, ctx->bvh_tris.p);
+    ctx->bvh_tris.ensure(TRI_F4 * (size_t)n_slots);
+    hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->morton_v2.p, F, n_slots, box, ctx->bvh_tris.p);
     MVS_LAUNCH_CHECK();
     // level sizes
     BvhDev b{};
-    uint32_t cnt = (n_leaves + 3) / 4, off = 0; int L = 0;
+    uint32_t cnt = (n_leaves + 3) / 4; int L = 0;
     while (true) {
         if (L >= 16) throw HipError("BVH too deep");
-        b.level_off[L] = off; b.level_cnt[L] = cnt; off += cnt;
+        b.level_cnt[L] = cnt;
         if (cnt == 1) break;
         cnt = (cnt + 3) / 4; ++L;
     }
     b.top = L; b.n_leaves = n_leaves;
+    // Levels are stored in 4-ary HEAP order: level L starts at (4^(top-L) - 1) / 3, so node i of a level is heap index
+    // h = level_off + i, its children are 4h + 1 + c and its parent is (h - 1) >> 2 -- the traversal needs no per-level
+    // table (a dynamically indexed kernel argument = one dependent scalar load per node visit).  Slots between the end
+    // of a level and the next level's start are never touched (a node's child count bounds its children).
+    for (int l = 0; l <= L; ++l) {
+        uint64_t p4 = 1; for (int k = 0; k < L - l; ++k) p4 *= 4;
+        if ((p4 - 1) / 3 + b.level_cnt[l] > 0x7FFFFFFFull) throw HipError("BVH too large");
+        b.level_off[l] = (uint32_t)((p4 - 1) / 3);
+    }
+    const uint32_t off = b.level_off[0] + b.level_cnt[0];
     ctx->bvh_nodes.ensure(off);
     ctx->lvl_box_a.ensure(6 * (size_t)b.level_cnt[0]); ctx->lvl_box_b.ensure(6 * (size_t)std::max<uint32_t>(b.level_cnt[L > 0 ? 1 : 0], 1u));
-    hipLaunchKernelGGL(build_level0_kernel, dim3((b.level_cnt[0] + 127) / 128), dim3(128), 0, s, ctx->bvh_tris.p, F, n_leaves, b.level_cnt[0], box, ctx->bvh_nodes.p, ctx->lvl_box_a.p);
+    hipLaunchKernelGGL(build_level0_kernel, dim3((b.level_cnt[0] + 127) / 128), dim3(128), 0, s, ctx->bvh_tris.p, F, n_leaves, b.level_cnt[0], box, ctx->bvh_nodes.p + b.level_off[0], ctx->lvl_box_a.p);
     MVS_LAUNCH_CHECK();
     float* cur = ctx->lvl_box_a.p; float* nxt = ctx->lvl_box_b.p;
     for (int l = 1; l <= L; ++l) {

@@ -194,6 +194,15 @@ __global__ void __launch_bounds__(256) csr_write_kernel(const unsigned long long
 // the segment out with full-width stores.  The direct version above writes one 2-byte and one 4-byte element per lane at
 // addresses ~K entries apart: 32-byte sectors of which 2 or 4 bytes are useful (5.7 GB written for 0.53 GB at C3).
 constexpr int CSR_SEG = 2048;
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int src /* wave-uniform */) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// The walk over the views is latency bound if every view costs a dependent chain of wave-uniform loads (survivor word ->
+// pass word / base -> quality): 31 k waves x 2 segments x 200 serial round trips were 2.05 ms at C3.  Here lane L fetches
+// the three words of view j0 + L (64 views per round trip), the views that have survivors among the wave's faces are
+// then visited through readlane broadcasts four at a time, and the four quality gathers of a group are in flight together.
 __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned long long* __restrict__ surv, const unsigned long long* __restrict__ pass,
                                                                const uint32_t* __restrict__ pass_base, const float* __restrict__ pq,
                                                                uint32_t n_views, uint32_t nf, uint32_t fwords, const uint32_t* __restrict__ col_ptr,
@@ -210,17 +219,39 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
     for (uint32_t segbase = c0; segbase < c1; segbase += CSR_SEG) {
         const uint32_t segend = min(segbase + (uint32_t)CSR_SEG, c1);
         uint32_t k = k0;
-        for (uint32_t j = 0; j < n_views; ++j) {
-            const size_t widx = (size_t)j * fwords + word;
-            const unsigned long long sw = surv[widx];
-            if (sw == 0ull) continue;                          // wave-uniform
-            if ((sw >> lane) & 1ull) {
-                if (k >= segbase && k < segend) {
-                    const size_t r = (size_t)pass_base[widx] + __popcll(pass[widx] & lt);
-                    s_v[wv][k - segbase] = (uint16_t)j;
-                    s_q[wv][k - segbase] = pq[r];
+        for (uint32_t j0 = 0; j0 < n_views; j0 += 64u) {
+            const uint32_t jl = j0 + (uint32_t)lane;
+            const size_t widx = (size_t)min(jl, n_views - 1u) * fwords + word;
+            const unsigned long long sw_l = (jl < n_views) ? surv[widx] : 0ull;
+            const unsigned long long pw_l = pass[widx];
+            const uint32_t pb_l = pass_base[widx];
+            unsigned long long todo = __ballot(sw_l != 0ull);   // views of this round with survivors among the wave's faces
+            while (todo != 0ull) {
+                int b[4]; bool on[4]; uint32_t kk[4]; float q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    b[u] = (todo != 0ull) ? (int)__builtin_ctzll(todo) : -1;
+                    if (todo != 0ull) todo &= todo - 1ull;
                 }
-                ++k;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    on[u] = false; kk[u] = 0u; q[u] = 0.0f;
+                    if (b[u] >= 0) {                           // wave-uniform
+                        const unsigned long long sw = readlane64(sw_l, b[u]);
+                        if ((sw >> lane) & 1ull) {
+                            if (k >= segbase && k < segend) {
+                                const unsigned long long pw = readlane64(pw_l, b[u]);
+                                const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)pb_l, b[u]);
+                                on[u] = true; kk[u] = k - segbase;
+                                q[u] = pq[(size_t)pb + __popcll(pw & lt)];
+                            }
+                            ++k;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (on[u]) { s_v[wv][kk[u]] = (uint16_t)(j0 + (uint32_t)b[u]); s_q[wv][kk[u]] = q[u]; }
             }
         }
         // LDS operations of one wave complete in order: the deposits above are visible to the reads below

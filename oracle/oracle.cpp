@@ -225,26 +225,28 @@ inline void rgb_to_ycbcr(float* v) {
 // Ray / triangle any-hit.  rayint's acc::BVHTree is absent and
 // the reference uses it purely as a boolean (calculate_data_costs.cpp:201-212),
 // so the test is DEFINED HERE: Moeller-Trumbore in fp32 on {a, e1 = b-a, e2 = c-a},
-// fixed operation order, no epsilon on the barycentrics, t in [tmin, tmax], and
-// the computed hit point must lie in the triangle's bounding box grown by `pad`
-// (pad = 1e-5 * max(scene extent, max |coordinate|) + 1e-30).  The last clause
-// makes any conservative box culling exact: the result is the OR over ALL
-// triangles, i.e. independent of the acceleration structure (tests compare the
-// BVH with the brute-force loop).
+// fixed operation order, division free: with s = sign(det) the scaled barycentrics
+// s u det, s v det and the scaled distance s t det are compared with 0, |det|,
+// tmin |det|, tmax |det| (no epsilon anywhere); a ray passing all of these gets
+// t = (t det) / det and its computed hit point must lie in the triangle's bounding
+// box grown by `pad` (pad = 1e-5 * max(scene extent, max |coordinate|) + 1e-30).
+// The last clause makes any conservative box culling exact: the result is the OR
+// over ALL triangles, i.e. independent of the acceleration structure (tests compare
+// the BVH with the brute-force loop).
 inline bool ray_tri(V3 orig, V3 dir, float tmin, float tmax, float pad, V3 a, V3 b, V3 c) {
     const V3 e1 = b - a, e2 = c - a;
     const V3 pv = cross(dir, e2);
     const float det = dot(e1, pv);
-    if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
     const V3 tv = orig - a;
-    const float u = dot(tv, pv) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const float un = dot(tv, pv);
     const V3 qv = cross(tv, e1);
-    const float v = dot(dir, qv) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    const float t = dot(e2, qv) * inv;
-    if (!(t >= tmin && t <= tmax)) return false;
+    const float vn = dot(dir, qv);
+    const float tn = dot(e2, qv);
+    const bool neg = det < 0.0f;
+    const float ad = neg ? -det : det;
+    const float us = neg ? -un : un, vs = neg ? -vn : vn, ts = neg ? -tn : tn;
+    if (!(ad > 0.0f && us >= 0.0f && vs >= 0.0f && us + vs <= ad && ts >= tmin * ad && ts <= tmax * ad)) return false;
+    const float t = tn / det;
     const V3 bb = a + e1, cc = a + e2;
     const float h[3] = {orig.x + t * dir.x, orig.y + t * dir.y, orig.z + t * dir.z};
     const float lo[3] = {std::fmin(a.x, std::fmin(bb.x, cc.x)), std::fmin(a.y, std::fmin(bb.y, cc.y)), std::fmin(a.z, std::fmin(bb.z, cc.z))};

@@ -1,0 +1,38 @@
+"""A/B of library builds on one GPU box: the scene is generated once, every variant runs in a forked child
+(own HIP context), variants are interleaved `--rounds` times; prints per-stage medians of the profile spans.
+Usage: python scripts/ab_libs.py [--config 3] [--rounds 3] [--steps 3] [--mrf] name=path/to/lib.so ..."""
+import argparse, json, multiprocessing as mp, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+import mvs_texturing_amd as M
+
+
+def child(lib, scene, steps, mrf, q):
+    M.viewsel._LIB_PATH = os.path.abspath(lib)
+    c = M.Context(0); c.set_option("profile", 1)
+    c.set_mesh(scene.verts, scene.faces, scene.normals); c.set_views(scene.cams, scene.images)
+    st = c.data_costs(M.Settings()); c.get_profile()
+    for _ in range(steps):
+        st = c.data_costs(M.Settings())
+        if mrf:
+            c.view_selection(scene.adj_ptr, scene.adj, M.viewsel.default_mrf_params())
+    p = c.get_profile()
+    q.put({k: v[0] / steps for k, v in p.items()} | {"nnz": int(st["nnz"]), "occluded": int(st.get("cull_occluded", 0))})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(); ap.add_argument("--config", type=int, default=3); ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3); ap.add_argument("--mrf", action="store_true"); ap.add_argument("libs", nargs="+")
+    a = ap.parse_args()
+    scene = M.synth.make_scene(**M.synth.CONFIGS[a.config])
+    ctx = mp.get_context("fork")
+    res = {}
+    for r in range(a.rounds):
+        for spec in a.libs:
+            name, _, path = spec.partition("=")
+            q = ctx.Queue(); p = ctx.Process(target=child, args=(path, scene, a.steps, a.mrf, q)); p.start(); out = q.get(); p.join()
+            res.setdefault(name, []).append(out)
+    for name, runs in res.items():
+        keys = [k for k in runs[0] if k.startswith("dc_") or k.startswith("mrf_")]
+        print(name, "nnz", runs[0]["nnz"], {k: round(statistics.median(x[k] for x in runs), 3) for k in keys},
+              "rays all:", [round(x["dc_rays"], 2) for x in runs], flush=True)
