@@ -81,13 +81,13 @@ typedef struct {
  * (view_selection.cpp:84,103-115); mapMAP is replaced by a GPU-resident
  * tree-reweighted max-product solver -- colour-phased Gauss-Seidel sweeps + monotone ICM polish --
  * whose knobs are below.  mvs_mrf_default_params gives the shipped defaults
- * (200 / 20 / 5 / 0.002 / 0.1 / 0.8 / 50). */
+ * (200 / 20 / 5 / 0.002 / 0.2 / 0.8 / 50). */
 typedef struct {
     int32_t max_sweeps;
     int32_t min_sweeps;
     int32_t window;         /* stop when the best energy gained < min_improvement over `window` sweeps; cf. StopWhenReturnsDiminish(5, 0.01) view_selection.cpp:84 */
     float min_improvement;
-    float damping;
+    float damping;          /* alpha of m' = (1 - alpha) new + alpha old on ODD sweeps (1st, 3rd, ...); even sweeps are undamped */
     float rho;
     int32_t icm_iters;
 } mvs_mrf_params;

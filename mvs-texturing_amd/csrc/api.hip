@@ -77,7 +77,7 @@ const char* mvs_status_string(mvs_status s) {
 
 void mvs_mrf_default_params(mvs_mrf_params* p) {
     p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
-    p->damping = 0.1f; p->rho = 0.8f; p->icm_iters = 50;
+    p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50;
 }
 void mvs_default_settings(mvs_settings* s) {  /* settings.h:85-90 */
     s->data_term = MVS_DATA_TERM_GMI; s->outlier_removal = MVS_OUTLIER_NONE; s->geometric_visibility_test = 1;

@@ -169,6 +169,7 @@ struct mvs_ctx {
     // colour-phased schedule: colours of the adjacency graph, nodes in (colour, id) order, class boundaries (host copy)
     mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c; uint32_t m_colours = 0; std::vector<uint32_t> m_colour_begin;
     uint32_t m_range_nb = 0, m_range_ne = 0; std::vector<uint32_t> m_range_q;   // cached own share of every colour class
+    uint32_t m_sweep_no = 0;   // sweeps started since mrf_setup (1-based inside a sweep): odd sweeps are damped
     mvs_mrf_params m_params{};
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring
     static constexpr uint32_t RING = 16;

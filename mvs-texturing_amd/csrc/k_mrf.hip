@@ -279,13 +279,18 @@ __global__ void mrf_identity_kernel(uint16_t* __restrict__ map) { map[threadIdx.
 // ident[e] = 1 iff the two label lists of edge e are identical (map == identity), i.e. the sender's out-edge rev(e) can skip it.
 // With skip_ident (fast sweep path: identical-list edges read the reserved identity run instead) the map of such an
 // edge is not even written -- three quarters of the edges on the synthetic scenes.
-__global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
+constexpr uint32_t MAP_TILE = 256;   // neighbour lists up to this length are searched in LDS
+__global__ void __launch_bounds__(256) mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
                                const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint16_t* __restrict__ map,
                                uint8_t* __restrict__ ident, int skip_ident) {
-    // 16 lanes per node
+    // 16 lanes per node.  The binary search is a chain of dependent loads: through global memory it is latency bound
+    // (1.4 ms at C3), so the neighbour's list is first copied (coalesced) into the group's LDS tile.  A group never spans
+    // waves and LDS operations of a wave execute in order, so the tile needs no barrier.
+    __shared__ uint16_t s_l[16][MAP_TILE];
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
     if (i >= F) return;
+    uint16_t* tile = s_l[threadIdx.x >> 4];
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
         const MrfEdge m = edge[e];
@@ -298,11 +303,15 @@ __global__ void mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint1
         }
         if (gl == 0) ident[e] = (uint8_t)same;
         if (same && skip_ident) continue;
+        const bool in_lds = m.kj <= MAP_TILE;                  // group-uniform
+        if (in_lds) for (uint32_t t = gl; t < m.kj; t += 16) tile[t] = view_id[q0 + t];
         for (uint32_t t = gl; t < K; t += 16) {
             const uint16_t key = view_id[p0 + t];
             uint32_t lo = 0, hi = m.kj;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (view_id[q0 + mid] < key) lo = mid + 1; else hi = mid; }
-            map[m.in_off + t] = (lo < m.kj && view_id[q0 + lo] == key) ? (uint16_t)lo : MAP_NONE;
+            if (in_lds) { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tile[mid] < key) lo = mid + 1; else hi = mid; } }
+            else { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (view_id[q0 + mid] < key) lo = mid + 1; else hi = mid; } }
+            const uint16_t found = (lo < m.kj) ? (in_lds ? tile[lo] : view_id[q0 + lo]) : (uint16_t)0;
+            map[m.in_off + t] = (lo < m.kj && found == key) ? (uint16_t)lo : MAP_NONE;
         }
     }
 }
@@ -755,6 +764,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     // ---- colour-phased schedule: colouring (Jones-Plassmann rounds), nodes in (colour, id) order ----
     ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 72); ctx->m_tmp_b.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
     ctx->m_colours = 0; ctx->m_colour_begin.assign(66, 0); ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
+    ctx->m_sweep_no = 0;
     if (F) {
         uint32_t* pending = ctx->m_moved.p + 1;
         hipLaunchKernelGGL(mrf_colour_init_kernel, dim3(nb), dim3(256), 0, s, ctx->m_colour.p, ctx->m_tmp_a.p /* iota */, F); MVS_LAUNCH_CHECK();
@@ -875,11 +885,18 @@ void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
     *out = ctx->h_ring[slot];
 }
 
+// Damping schedule (part of the solver's definition, restated in oracle/oracle.cpp): messages are damped with
+// alpha = params.damping on ODD sweeps (1st, 3rd, ...) and written undamped on even sweeps.  Undamped sweeps oscillate
+// (C3: 0.9 % higher final energy), but damping every second sweep suppresses that just as well as damping every sweep
+// (C3: 44 sweeps to E = 1 111 890 with 0.2 on odd sweeps vs 47 to 1 110 970 with 0.1 on all) -- and an undamped sweep
+// does not re-read its previous outgoing messages (6 nnz bytes of the ~27 nnz a damped sweep moves).
+static float sweep_alpha(const mvs_ctx* ctx) { return (ctx->m_sweep_no & 1u) ? ctx->m_params.damping : 0.0f; }
+
 template <int G>
 static void launch_sweep4_g(mvs_ctx* ctx, uint32_t qb, uint32_t qe) {
     constexpr int NPB = 256 / G;
     const unsigned need = (qe - qb + NPB - 1) / NPB;
-    const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+    const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
     // persistent lane groups: at most as many blocks as are resident at once (a partial second wave of
     // blocks would double the tail); mrf_blocks_per_cu > 0 overrides
     static int resident = 0;
@@ -924,6 +941,7 @@ static void phase_range(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0
 
 // one colour phase of a sweep over the nodes of that colour with id in [nb0, ne0): in place
 void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
+    if (phase == 0) ++ctx->m_sweep_no;      // sweeps are counted by their first phase (every caller runs the phases in order)
     if (phase >= ctx->m_colours || ne0 <= nb0) return;
     uint32_t qb, qe;
     phase_range(ctx, phase, nb0, ne0, &qb, &qe);
@@ -935,7 +953,7 @@ void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
         else launch_sweep4_g<32>(ctx, qb, qe);
     } else {
         ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
-        const float rho = ctx->m_params.rho, alpha = ctx->m_params.damping;
+        const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
         msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
         if (alpha != 0.0f)
             hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, dim3(qe - qb), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, msg, ctx->m_perm.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, qb, qe, rho, alpha);

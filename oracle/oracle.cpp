@@ -882,11 +882,12 @@ int mrf_colour(const Mrf& g, std::vector<uint8_t>& colour) {
 
 // One phase of a sweep: all nodes of colour `phase` (an independent set) recompute their outgoing messages IN PLACE
 // from the current messages -- colour-phased Gauss-Seidel.  Within a phase no node reads what another writes.
+// Damping schedule: alpha = P.damping on ODD sweeps (1st, 3rd, ...), none on even sweeps.
 void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<float>& msg,
-               std::vector<uint32_t>& sel, int n_threads, const uint8_t* colour, int phase) {
+               std::vector<uint32_t>& sel, int n_threads, const uint8_t* colour, int phase, uint32_t sweep_no) {
     const std::vector<float>& mo = msg; std::vector<float>& mn = msg;
     const float rho = P.rho, omr = 1.0f - P.rho, lam = 1.0f / P.rho;
-    const float alpha = P.damping, oma = 1.0f - P.damping;
+    const float alpha = (sweep_no & 1u) ? P.damping : 0.0f, oma = 1.0f - alpha;
 #pragma omp parallel num_threads(n_threads)
     {
         std::vector<float> c;
@@ -979,7 +980,7 @@ void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = le
 
 void orc_mrf_default_params(orc_mrf_params* p) {
     p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
-    p->damping = 0.1f; p->rho = 0.8f; p->icm_iters = 50;
+    p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50;
 }
 
 int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
@@ -1006,7 +1007,7 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     std::vector<uint64_t> hist; hist.push_back(~0ull);
     uint32_t s = 0;
     for (s = 1; (int)s <= P.max_sweeps; ++s) {
-        for (int phase = 0; phase < n_colours; ++phase) mrf_sweep(g, P, msg, sel, n_threads, colour.data(), phase);
+        for (int phase = 0; phase < n_colours; ++phase) mrf_sweep(g, P, msg, sel, n_threads, colour.data(), phase, s);
         uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts, n_threads);
         if (e < best_e) { best_e = e; best_cuts = cuts; best_sel = sel; }
         hist.push_back(best_e);

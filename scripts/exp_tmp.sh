@@ -1,10 +1,4 @@
 mkdir -p gpurun_out
-R=$PWD
-cd /tmp && export TMPDIR=/tmp
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
-  d=$(echo $set | cut -d' ' -f1)
-  timeout 400 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/sq_$d -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/sq_$d.log 2>&1
-  f=$(find $R/gpurun_out/sq_$d -name "*counter_collection.csv" | head -1)
-  echo "== $set"; python $R/scripts/pmc_summary.py $f "ray_packet2"
-  rm -rf $R/gpurun_out/sq_$d
-done
+echo "== pytest"; timeout 900 python -m pytest tests -q -m gpu -x > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+S='import sys,json; d=json.loads(sys.stdin.read()); s=d["stages"]; print(round(d["ms_per_step"],2), "sweeps", d["config"]["sweeps"], "energy", d["config"]["energy"], {k: round(v["ms_per_step"],2) for k,v in s.items()})'
+echo "== base"; timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$S"
