@@ -576,11 +576,13 @@ template <int G>
 __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                            const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                                            const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
-                                                           uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand) {
+                                                           uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand,
+                                                           const uint32_t* __restrict__ list /* null: nodes [node_begin, node_end); else node ids list[node_begin .. node_end) */) {
     constexpr int NPB = 256 / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const uint32_t i = node_begin + blockIdx.x * NPB + grp;
-    const bool node_ok = i < node_end;
+    const uint32_t pos = node_begin + blockIdx.x * NPB + grp;
+    const bool node_ok = pos < node_end;
+    const uint32_t i = (list && node_ok) ? list[pos] : pos;
     const uint32_t p0 = node_ok ? col_ptr[i] : 0u;
     const uint32_t K = node_ok ? col_ptr[i + 1] - p0 : 0u;
     const uint32_t e0 = node_ok ? adj_ptr[i] : 0u, e1 = node_ok ? adj_ptr[i + 1] : 0u;
@@ -611,8 +613,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
 template <int G>
 __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                                 const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
-                                                                uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand,
-                                                                uint8_t* __restrict__ dirty /* null = evaluate every node */) {
+                                                                uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand) {
     // node_begin / node_end are positions in the descriptor array ((colour, id) order); the node itself is cur.id
     constexpr int NPB = 256 / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
@@ -622,11 +623,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
     if (i < node_end) nd = desc[i];
     const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
     for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
-        bool node_ok = i < node_end;
-        // a node's gain depends on its column, its own label and its neighbours' labels only: unless one of those
-        // changed in the last apply (dirty flag), the stored gain / candidate are still the values this loop would compute
-        if (dirty && node_ok) { node_ok = dirty[nd.id] != 0; }
-        if (dirty && __ballot(node_ok) == 0ull) { if (i + stride < node_end) nd = desc[i + stride]; continue; }   // wave-uniform skip (the group shuffles below need all lanes)
+        const bool node_ok = i < node_end;
         const NodeDesc cur = nd;
         if (i + stride < node_end) nd = desc[i + stride];
         const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
@@ -649,7 +646,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
             if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
             cur_e += __shfl_xor(cur_e, o, G);   // exactly one lane holds a non-zero term (or none: 0)
         }
-        if (gl == 0 && node_ok) { gain[id] = (K > 0) ? (cur_e - best) : 0.0f; cand[id] = (K > 0) ? bt : 0u; if (dirty) dirty[id] = 0; }
+        if (gl == 0 && node_ok) { gain[id] = (K > 0) ? (cur_e - best) : 0.0f; cand[id] = (K > 0) ? bt : 0u; }
     }
 }
 
@@ -657,7 +654,8 @@ __global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                                             const float* __restrict__ gain, const uint32_t* __restrict__ cand,
                                                             uint32_t* sel, uint32_t* lab, float* selcost,
-                                                            uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved, uint8_t* __restrict__ dirty) {
+                                                            uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved /* [0] nodes moved, [1] list length */,
+                                                            uint32_t* __restrict__ alist /* null, or: nodes whose gain has to be re-evaluated */) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     bool mv = false;
     if (i < node_end) {
@@ -678,7 +676,12 @@ __global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __re
     if (mv) {
         const uint32_t p0 = col_ptr[i], t = cand[i];
         sel[i] = t; lab[i] = (uint32_t)view_id[p0 + t] + 1u; selcost[i] = cost[p0 + t];
-        if (dirty) { dirty[i] = 1; for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) dirty[adj[e]] = 1; }   // racing stores of the same value
+        if (alist) {   // a node's gain depends on its column, its own label and its neighbours' labels only (duplicates in the list are harmless)
+            const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+            uint32_t w = atomicAdd(&moved[1], 1u + (e1 - e0));
+            alist[w++] = i;
+            for (uint32_t e = e0; e < e1; ++e) alist[w++] = adj[e];
+        }
     }
     const unsigned long long b = __ballot(mv);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(moved, (uint32_t)__popcll(b));
@@ -756,6 +759,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemcpyAsync(&E, ctx->r_adj_ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
     ctx->m_size.ensure((size_t)E + 2); ctx->m_edge.ensure((size_t)E + 1); ctx->m_moved.ensure(8 + 2 * 64);
+    ctx->m_n_adj = E;
     uint32_t* maxes = ctx->m_moved.p + 4;
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 8 * sizeof(uint32_t), s));
     MVS_HIP(hipMemsetAsync(ctx->m_size.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
@@ -995,37 +999,48 @@ void mrf_keep_best(mvs_ctx* ctx) {
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 <= nb0) return;
     const uint32_t K = ctx->m_kmax, n = ne0 - nb0;
-    if (ctx->m_degmax <= 3 && nb0 == 0 && ne0 == ctx->csr_faces) {   // descriptors are in (colour, id) order: whole-graph calls only
-        // active set (unsharded calls only): after the first full evaluation only nodes whose own or neighbouring label
-        // moved are re-evaluated; sharded callers exchange labels behind the library's back, so they evaluate all
-        uint8_t* dirty = nullptr;
-        if (nb0 == 0 && ne0 == ctx->csr_faces) {
-            ctx->m_dirty.ensure((size_t)ctx->csr_faces + 1);
-            if (!ctx->icm_dirty_valid) MVS_HIP(hipMemsetAsync(ctx->m_dirty.p, 1, (size_t)ctx->csr_faces, ctx->stream));
-            ctx->icm_dirty_valid = true;
-            dirty = ctx->m_dirty.p;
-        } else ctx->icm_dirty_valid = false;
-#define ICM_D(GG) hipLaunchKernelGGL(mrf_icm_gain_desc_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((n + (256 / GG) - 1) / (256 / GG), 256u * 8u))), dim3(256), 0, ctx->stream, \
-                                     ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p, dirty)
-        if (K <= 8) ICM_D(8); else if (K <= 16) ICM_D(16); else if (K <= 48) ICM_D(16); else ICM_D(32);
-#undef ICM_D
-        MVS_LAUNCH_CHECK();
+    const bool whole = nb0 == 0 && ne0 == ctx->csr_faces;
+#define ICM_G(GG, B, E, LIST) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3(((E) - (B) + (256 / GG) - 1) / (256 / GG)), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
+                                     ctx->r_adj_ptr, ctx->r_adj, ctx->m_best_sel.p, ctx->m_best_lab.p, (B), (E), ctx->m_gain.p, ctx->m_cand.p, (LIST))
+    // active set (unsharded calls only): after one full evaluation, only the nodes the last apply listed -- the nodes that
+    // moved and their neighbours -- are re-evaluated; everybody else's stored gain / candidate are still the values a
+    // full pass would compute.  Sharded callers exchange labels behind the library's back, so they evaluate all.
+    if (whole && ctx->icm_dirty_valid) {
+        uint32_t cnt = 0;
+        MVS_HIP(hipMemcpyAsync(&cnt, ctx->m_moved.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        if (cnt) {
+            const uint32_t* list = ctx->m_alist.p;
+            if (K <= 8) ICM_G(8, 0u, cnt, list); else if (K <= 16) ICM_G(16, 0u, cnt, list); else if (K <= 32) ICM_G(32, 0u, cnt, list); else ICM_G(64, 0u, cnt, list);
+            MVS_LAUNCH_CHECK();
+        }
         return;
     }
-#define ICM_G(GG) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3((n + (256 / GG) - 1) / (256 / GG)), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
-                                     ctx->r_adj_ptr, ctx->r_adj, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
-    ctx->icm_dirty_valid = false;
-    if (K <= 8) ICM_G(8); else if (K <= 16) ICM_G(16); else if (K <= 32) ICM_G(32); else ICM_G(64);
+    if (ctx->m_degmax <= 3 && whole) {   // descriptors are in (colour, id) order: whole-graph calls only
+#define ICM_D(GG) hipLaunchKernelGGL(mrf_icm_gain_desc_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((n + (256 / GG) - 1) / (256 / GG), 256u * 8u))), dim3(256), 0, ctx->stream, \
+                                     ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
+        if (K <= 8) ICM_D(8); else if (K <= 16) ICM_D(16); else if (K <= 48) ICM_D(16); else ICM_D(32);
+#undef ICM_D
+    } else {
+        const uint32_t* none = nullptr;
+        if (K <= 8) ICM_G(8, nb0, ne0, none); else if (K <= 16) ICM_G(16, nb0, ne0, none); else if (K <= 32) ICM_G(32, nb0, ne0, none); else ICM_G(64, nb0, ne0, none);
+    }
 #undef ICM_G
     MVS_LAUNCH_CHECK();
+    ctx->icm_dirty_valid = whole;   // every gain is current: the next apply starts the list
 }
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
-    MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, sizeof(uint32_t), ctx->stream));
+    MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 2 * sizeof(uint32_t), ctx->stream));
     if (ne0 <= nb0) return;
+    const bool whole = nb0 == 0 && ne0 == ctx->csr_faces;
+    if (!whole) ctx->icm_dirty_valid = false;
+    uint32_t* alist = nullptr;
+    if (ctx->icm_dirty_valid) {   // winners form an independent set: at most (nodes + directed edges) entries
+        ctx->m_alist.ensure((size_t)ctx->csr_faces + (size_t)ctx->m_n_adj + 16);
+        alist = ctx->m_alist.p;
+    }
     hipLaunchKernelGGL(mrf_icm_apply_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                       ctx->m_gain.p, ctx->m_cand.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, nb0, ne0, ctx->m_moved.p,
-                       (ctx->icm_dirty_valid && nb0 == 0 && ne0 == ctx->csr_faces) ? ctx->m_dirty.p : (uint8_t*)nullptr);
-    if (!(nb0 == 0 && ne0 == ctx->csr_faces)) ctx->icm_dirty_valid = false;
+                       ctx->m_gain.p, ctx->m_cand.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, nb0, ne0, ctx->m_moved.p, alist);
     MVS_LAUNCH_CHECK();
 }
 // labels of nodes [nb0, ne0) of the best labeling into d_labels[0 .. ne0 - nb0); out = {bad, unseen}
