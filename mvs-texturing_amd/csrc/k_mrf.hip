@@ -819,7 +819,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     hipLaunchKernelGGL(mrf_identity_kernel, dim3(1), dim3(MSG_BASE), 0, s, ctx->m_map.p); MVS_LAUNCH_CHECK();   // map[t] = t for t < MSG_BASE
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
     if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p,
-                               (ctx->m_degmax <= 3 && ctx->m_kmax <= 128 && ctx->csr_nnz >= 4) ? 1 : 0); MVS_LAUNCH_CHECK(); }
+                               (ctx->m_degmax <= 3 && ctx->m_kmax <= 256 && ctx->csr_nnz >= 4) ? 1 : 0); MVS_LAUNCH_CHECK(); }
     ctx->m_desc.ensure((size_t)F + 1);
     if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
     ctx->m_msg_a.ensure(ctx->m_total + 8);
@@ -951,10 +951,11 @@ void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
     phase_range(ctx, phase, nb0, ne0, &qb, &qe);
     if (qe <= qb) return;
     const uint32_t K = ctx->m_kmax;
-    if (ctx->m_degmax <= 3 && K <= 128 && ctx->csr_nnz >= 4 && ctx->m_total > MSG_BASE) {
+    if (ctx->m_degmax <= 3 && K <= 256 && ctx->csr_nnz >= 4 && ctx->m_total > MSG_BASE) {
         if (K <= 32) launch_sweep4_g<8>(ctx, qb, qe);
         else if (K <= 64) launch_sweep4_g<16>(ctx, qb, qe);
-        else launch_sweep4_g<32>(ctx, qb, qe);
+        else if (K <= 128) launch_sweep4_g<32>(ctx, qb, qe);
+        else launch_sweep4_g<64>(ctx, qb, qe);      // one node per wave: scenes with several hundred views per face
     } else {
         ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
         const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);

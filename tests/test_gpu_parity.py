@@ -155,6 +155,7 @@ def test_labels_bit_exact_vs_oracle(ctx, params):
 @pytest.mark.parametrize("case", [dict(n=3000, views=12, max_k=6, max_deg=3, seed=1),      # G=8 groups
                                   dict(n=2000, views=40, max_k=30, max_deg=3, seed=2),     # G=32
                                   dict(n=1500, views=150, max_k=120, max_deg=3, seed=3),   # G=64, R=2
+                                  dict(n=800, views=300, max_k=250, max_deg=3, seed=7),    # G=64: one node per wave
                                   dict(n=600, views=400, max_k=300, max_deg=3, seed=4),    # K > 256: generic kernel
                                   dict(n=2000, views=20, max_k=9, max_deg=6, seed=5),      # non-manifold degrees: generic kernel
                                   dict(n=500, views=8, max_k=3, max_deg=3, seed=6, p_empty=0.6)])  # mostly unseen faces
