@@ -207,3 +207,54 @@ def test_row_f2_scene_folder_round_trip(tmp_path):
     open(os.path.join(d, "view_0000.cam"), "w").write("0 0 0 1 0 0 0 1 0 0 0 1\n1 0.1\n")
     with pytest.raises(NotImplementedError):
         ingest.load_scene(d)
+
+
+def test_hilbert_index_is_a_hilbert_curve(tmp_path):
+    """The BVH build sorts triangles (and ray origins) by hilbert30() (csrc/k_bvh.hip).  Its numpy twin
+    (multigpu._hilbert30) must be a bijection onto [0, 2^30) whose consecutive indices are lattice neighbours
+    (checked exhaustively on the 3 low bits x 3 axes sub-lattices it is built from), and the device function,
+    compiled for the host from the very source text, must agree with it on random lattice points."""
+    import subprocess
+    from mvs_texturing_amd import multigpu as G
+    # (a) curve property of the construction, exhaustively at 4 bits per axis: the same routine with Q starting at 8
+    def hilbert(q, bits):
+        X = [q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy()]
+        Q = 1 << (bits - 1)
+        while Q > 1:
+            P = Q - 1
+            for i in range(3):
+                hi = (X[i] & Q) != 0
+                X[0] = np.where(hi, X[0] ^ P, X[0])
+                t = np.where(hi, 0, (X[0] ^ X[i]) & P)
+                X[0] = X[0] ^ t; X[i] = X[i] ^ t
+            Q >>= 1
+        X[1] ^= X[0]; X[2] ^= X[1]
+        t = np.zeros_like(X[0]); Q = 1 << (bits - 1)
+        while Q > 1:
+            t = np.where((X[2] & Q) != 0, t ^ (Q - 1), t); Q >>= 1
+        X = [x ^ t for x in X]
+        code = np.zeros(len(q), dtype=np.int64)
+        for b in range(bits):
+            for a in range(3):
+                code |= ((X[a] >> b) & 1) << (3 * b + (2 - a))
+        return code
+    n = 16
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3).astype(np.int64)
+    h = hilbert(g, 4)
+    assert len(np.unique(h)) == n ** 3 and h.max() == n ** 3 - 1
+    assert (np.abs(np.diff(g[np.argsort(h)], axis=0)).sum(axis=1) == 1).all()
+    # (b) the 10-bit numpy twin equals the generic routine, (c) the device source equals the twin
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 1024, (200000, 3)).astype(np.uint32)
+    assert np.array_equal(G._hilbert30(q).astype(np.int64), hilbert(q.astype(np.int64), 10))
+    src = open(os.path.join(ROOT, "mvs-texturing_amd", "csrc", "k_bvh.hip")).read()
+    a = src.index("__device__ __forceinline__ uint32_t expand10"); b = src.index("__global__ void morton_kernel")
+    code = ("#include <cstdint>\n#define __device__\n#define __forceinline__ inline\n" + src[a:b] +
+            '\nextern "C" void hil(const uint32_t* q, uint32_t n, uint32_t* out) { for (uint32_t i = 0; i < n; ++i) out[i] = hilbert30(q[3 * i], q[3 * i + 1], q[3 * i + 2]); }\n')
+    cpp = tmp_path / "h.cpp"; cpp.write_text(code)
+    so = str(tmp_path / "h.so")
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-Wno-unknown-pragmas", str(cpp), "-o", so])
+    L = C.CDLL(so)
+    out = np.zeros(len(q), np.uint32)
+    L.hil(q.ctypes.data_as(C.c_void_p), len(q), out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, G._hilbert30(q))
