@@ -110,8 +110,7 @@ def main():
     cfg = dict(M.synth.CONFIGS[args.config])
     t0 = time.time()
     scene = M.synth.make_scene(**cfg)
-    order = G.hilbert_order if os.environ.get("MVS_FACE_ORDER") == "hilbert" else G.morton_order
-    perm = order(scene.verts, scene.faces)   # contiguous parts = compact patches (METIS stand-in)
+    perm = G.morton_order(scene.verts, scene.faces)   # contiguous parts = compact patches (METIS stand-in; hilbert_order measured the same)
     faces, normals, adj_ptr, adj, _ = G.renumber_faces(scene.faces, scene.normals, scene.adj_ptr, scene.adj, perm)
     F, V = len(faces), scene.n_views
     if rank == 0:

@@ -52,7 +52,7 @@ struct DBuf {
     DBuf& operator=(const DBuf&) = delete;
 };
 
-// ---- implicit 4-ary BVH over Morton-sorted triangles (k_bvh.hip) ----
+// ---- implicit 4-ary BVH over Hilbert-sorted triangles (k_bvh.hip) ----
 struct alignas(128) Node4 {
     float lo[3][4];
     float hi[3][4];
@@ -125,11 +125,11 @@ struct mvs_ctx {
 
     // ---- BVH + incidence ----
     mvs::DBuf<mvs::Node4> bvh_nodes; mvs::DBuf<float4> bvh_tris;
-    mvs::DBuf<uint32_t> morton_k, morton_k2, morton_v, morton_v2; mvs::DBuf<char> sort_tmp;
+    mvs::DBuf<uint32_t> sort_k, sort_k2, sort_v, sort_v2; mvs::DBuf<char> sort_tmp;
     mvs::DBuf<float> lvl_box_a, lvl_box_b; mvs::DBuf<float> scene_box;
     mvs::BvhDev bvh{};
     mvs::DBuf<uint32_t> vf_ptr, vf_cursor, vf;
-    mvs::DBuf<uint32_t> vperm, vpos;   // vertices in Morton order and the inverse map
+    mvs::DBuf<uint32_t> vperm, vpos;   // vertices in Hilbert order and the inverse map
 
     // ---- data costs work buffers ----
     mvs::DBuf<unsigned long long> pass_bits, need_bits, occl_bits, surv_bits;

@@ -3,7 +3,7 @@
 // vertex->camera any-hit rays per (face, view)).
 //
 // rayint's acc::BVHTree is replaced by an implicit 4-ary BVH built ON THE GPU
-// over Morton-sorted triangles (no pointers: node i of level L has children
+// over Hilbert-sorted triangles (no pointers: node i of level L has children
 // 4i..4i+3 of level L-1; a level-0 node's children are leaves of 4 consecutive
 // triangles).  One node = one 128-byte line holding the four child boxes.
 // Traversal is stackless: one 4-bit pending-children mask per level packed in a
@@ -24,7 +24,7 @@ namespace mvs {
 
 namespace {
 
-// triangles per leaf (consecutive in Morton order).  With the packet traversal a leaf round tests (64 / LEAF_T) candidate
+// triangles per leaf (consecutive in Hilbert order).  With the packet traversal a leaf round tests (64 / LEAF_T) candidate
 // rays against LEAF_T triangles: bigger leaves mean fewer node visits and fuller rounds, more triangle tests per ray.
 constexpr uint32_t LEAF_T = MVS_LEAF_T;
 constexpr int LEAF_SLOTS = 64 / (int)LEAF_T;
@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z
     return (expand10(X[0]) << 2) | (expand10(X[1]) << 1) | expand10(X[2]);
 }
 
-__global__ void morton_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t n_faces,
+__global__ void curve_key_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t n_faces,
                               const uint32_t* __restrict__ box, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_faces) return;
@@ -104,9 +104,9 @@ __global__ void morton_kernel(const float* __restrict__ verts, const uint32_t* _
     vals[f] = f;
 }
 
-// Morton code of a vertex (rays are launched in Morton order of their origin: 64 neighbouring
+// Hilbert index of a vertex (rays are launched in Hilbert order of their origin: 64 neighbouring
 // vertices per wave = a compact patch of nearly parallel rays)
-__global__ void vmorton_kernel(const float* __restrict__ verts, uint32_t n_verts, const uint32_t* __restrict__ box,
+__global__ void vertex_key_kernel(const float* __restrict__ verts, uint32_t n_verts, const uint32_t* __restrict__ box,
                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_verts) return;
@@ -551,15 +551,15 @@ void build_bvh(mvs_ctx* ctx) {
     MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 512u)), dim3(256), 0, s, ctx->d_verts, NV, box);
     MVS_LAUNCH_CHECK();
-    ctx->morton_k.ensure(std::max<size_t>(F, NV)); ctx->morton_k2.ensure(std::max<size_t>(F, NV)); ctx->morton_v.ensure(std::max<size_t>(F, NV)); ctx->morton_v2.ensure(F);
-    hipLaunchKernelGGL(morton_kernel, dim3((F + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, F, box, ctx->morton_k.p, ctx->morton_v.p);
+    ctx->sort_k.ensure(std::max<size_t>(F, NV)); ctx->sort_k2.ensure(std::max<size_t>(F, NV)); ctx->sort_v.ensure(std::max<size_t>(F, NV)); ctx->sort_v2.ensure(F);
+    hipLaunchKernelGGL(curve_key_kernel, dim3((F + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, F, box, ctx->sort_k.p, ctx->sort_v.p);
     MVS_LAUNCH_CHECK();
     size_t tmp_bytes = 0;
-    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->morton_v2.p, F, 0, 30, s));
+    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F, 0, 30, s));
     ctx->sort_tmp.ensure(tmp_bytes + 16);
-    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->morton_v2.p, F, 0, 30, s));
+    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F, 0, 30, s));
     ctx->bvh_tris.ensure(TRI_F4 * (size_t)n_slots);
-    hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->morton_v2.p, F, n_slots, box, ctx->bvh_tris.p);
+    hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->sort_v2.p, F, n_slots, box, ctx->bvh_tris.p);
     MVS_LAUNCH_CHECK();
     // level sizes
     BvhDev b{};
@@ -593,14 +593,14 @@ void build_bvh(mvs_ctx* ctx) {
     }
     b.nodes = ctx->bvh_nodes.p; b.tris = ctx->bvh_tris.p;
     ctx->bvh = b;
-    // vertices in Morton order (ray launch order)
+    // vertices in Hilbert order (ray launch order)
     ctx->vperm.ensure((size_t)NV + 1); ctx->vpos.ensure((size_t)NV + 1);
-    ctx->morton_k.ensure(std::max<size_t>(F, NV)); ctx->morton_k2.ensure(std::max<size_t>(F, NV)); ctx->morton_v.ensure(std::max<size_t>(F, NV));
-    hipLaunchKernelGGL(vmorton_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->d_verts, NV, box, ctx->morton_k.p, ctx->morton_v.p);
+    ctx->sort_k.ensure(std::max<size_t>(F, NV)); ctx->sort_k2.ensure(std::max<size_t>(F, NV)); ctx->sort_v.ensure(std::max<size_t>(F, NV));
+    hipLaunchKernelGGL(vertex_key_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->d_verts, NV, box, ctx->sort_k.p, ctx->sort_v.p);
     MVS_LAUNCH_CHECK();
-    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->vperm.p, NV, 0, 30, s));
+    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->vperm.p, NV, 0, 30, s));
     ctx->sort_tmp.ensure(tmp_bytes + 16);
-    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->morton_k.p, ctx->morton_k2.p, ctx->morton_v.p, ctx->vperm.p, NV, 0, 30, s));
+    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->vperm.p, NV, 0, 30, s));
     hipLaunchKernelGGL(invert_perm_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->vperm.p, NV, ctx->vpos.p);
     MVS_LAUNCH_CHECK();
     build_vertex_faces(ctx, ctx->d_faces, F, NV);

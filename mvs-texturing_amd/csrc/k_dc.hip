@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
 }
 
 // ---- which (vertex, view) rays are needed: OR of the pass bits of the incident faces ----
-// (thread s handles the s-th vertex in Morton order: need / occluded bits are indexed by that position)
+// (thread s handles the s-th vertex in Hilbert order: need / occluded bits are indexed by that position)
 template <bool STATS>
 __global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, const uint32_t* __restrict__ vperm, uint32_t n_verts, uint32_t n_views,
                                                    uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,

@@ -248,7 +248,7 @@ def test_hilbert_index_is_a_hilbert_curve(tmp_path):
     q = rng.integers(0, 1024, (200000, 3)).astype(np.uint32)
     assert np.array_equal(G._hilbert30(q).astype(np.int64), hilbert(q.astype(np.int64), 10))
     src = open(os.path.join(ROOT, "mvs-texturing_amd", "csrc", "k_bvh.hip")).read()
-    a = src.index("__device__ __forceinline__ uint32_t expand10"); b = src.index("__global__ void morton_kernel")
+    a = src.index("__device__ __forceinline__ uint32_t expand10"); b = src.index("__global__ void curve_key_kernel")
     code = ("#include <cstdint>\n#define __device__\n#define __forceinline__ inline\n" + src[a:b] +
             '\nextern "C" void hil(const uint32_t* q, uint32_t n, uint32_t* out) { for (uint32_t i = 0; i < n; ++i) out[i] = hilbert30(q[3 * i], q[3 * i + 1], q[3 * i + 2]); }\n')
     cpp = tmp_path / "h.cpp"; cpp.write_text(code)
