@@ -33,6 +33,9 @@ SCENES = {
     # image width not a multiple of 32 / odd sizes: the generic (non-vectorised) image-prep kernels
     "oddw": dict(n=10, n_views=6, width=333, height=251, displacement=0.2, layout=1, zoom_odd=1.3, black_corner=19),
     "tiny": dict(n=6, n_views=8, width=320, height=240, displacement=0.2, layout=1, zoom_odd=1.4),
+    # hundreds of views per face (the shape of BASELINE config 5 at a size the oracle finishes in seconds): columns of
+    # 130-250 labels take the one-node-per-wave sweep path, the CSR transposition walks several 64-view rounds
+    "manyviews": dict(n=16, n_views=700, width=160, height=120, displacement=0.05, layout=1),
 }
 
 _scene_cache = {}

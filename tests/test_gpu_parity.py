@@ -101,6 +101,22 @@ def test_other_image_shapes_against_live_oracle(ctx, name):
         assert st["cull_outside"] == rst["cull_outside"] and st["cull_occluded"] == rst["cull_occluded"]
 
 
+def test_many_views_against_live_oracle(ctx):
+    """700 views (BASELINE config 5's shape, small): label lists of 128 < K <= 256 entries -> sweep fast path with one
+    node per wave (G = 64); data costs and labels bit-exact against the live oracle"""
+    s = get_scene("manyviews")
+    _load_scene(ctx, s)
+    ref, rst = O.data_costs(s)
+    st = ctx.data_costs(M.Settings())
+    _assert_costs(ctx.costs_download(), ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+    K = np.diff(ref.col_ptr.astype(np.int64))
+    assert 128 < K.max() <= 256, K.max()                       # the path this test is for
+    p = dict(max_sweeps=24, min_sweeps=12)
+    lo, so = O.view_selection(ref, s.adj_ptr, s.adj, O.default_mrf_params(**p))
+    lg, sg = ctx.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(**p))
+    assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_ray_traversal_modes_give_the_oracle_booleans(mode):
     """per-ray traversal, shared (packet) traversal and packet + leaf work redistribution: same occlusion decisions"""
