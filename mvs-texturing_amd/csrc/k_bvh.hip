@@ -125,6 +125,84 @@ __global__ void invert_perm_kernel(const uint32_t* __restrict__ perm, uint32_t n
     if (s < n) inv[perm[s]] = s;
 }
 
+// Local refinement of the curve order.  A window of RW = 8 * 4^3 consecutive triangles is exactly the subtree of one
+// level-2 node of the implicit tree.  Inside each window the triangles are re-partitioned top down: a segment is sorted
+// along the longest axis of its centroids and cut in the middle (spatial median), recursively down to the leaves, so two
+// binary levels = one 4-ary level.  The curve decides WHICH 512 triangles share a subtree, the median splits decide how
+// they are grouped inside it: on the C3 mesh 26 % fewer leaf rounds and 34 % fewer (ray, leaf) pairs per packet
+// (simulated; windows of 2048 would give 29 % / 38 %).  Deterministic: ties are broken by the triangle id.
+constexpr int RW = 512;
+__global__ void __launch_bounds__(256) refine_order_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t* __restrict__ order,
+                                                           uint32_t n_faces) {
+    __shared__ float s_c[3][RW];          // centroid of the triangle in slot k (slots never move)
+    __shared__ uint32_t s_id[RW];         // triangle id of slot k (0xFFFFFFFF: padding behind the last triangle)
+    __shared__ float s_key[RW];           // sort key at position i
+    __shared__ uint32_t s_slot[RW];       // slot at position i
+    __shared__ uint32_t s_box[RW / (2 * LEAF_T)][6];   // centroid box per segment (ordered uints)
+    const uint32_t w0 = blockIdx.x * RW;
+    const int t = threadIdx.x;
+    for (int i = t; i < RW; i += 256) {
+        const uint32_t g = w0 + i;
+        uint32_t id = 0xFFFFFFFFu; float c[3] = {INFINITY, INFINITY, INFINITY};
+        if (g < n_faces) {
+            id = order[g];
+            const uint32_t* fv = faces + 3 * (size_t)id;
+            for (int a = 0; a < 3; ++a) c[a] = (verts[3 * (size_t)fv[0] + a] + verts[3 * (size_t)fv[1] + a] + verts[3 * (size_t)fv[2] + a]) * (1.0f / 3.0f);
+        }
+        s_id[i] = id; s_c[0][i] = c[0]; s_c[1][i] = c[1]; s_c[2][i] = c[2]; s_slot[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    for (int seg = RW; seg > (int)LEAF_T; seg >>= 1) {
+        const int nseg = RW / seg;
+        for (int k = t; k < nseg * 6; k += 256) s_box[k / 6][k % 6] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        // centroid box of every segment: a wave holds 64 consecutive positions, i.e. whole segments or a 64-wide piece of
+        // one -- butterfly min / max over min(seg, 64) lanes, then one lane per piece merges into LDS (same-address LDS
+        // atomics from all 512 positions serialise 64-fold)
+        for (int i = t; i < RW; i += 256) {
+            const uint32_t sl = s_slot[i];
+            const bool ok = s_id[sl] != 0xFFFFFFFFu;
+            uint32_t mn[3], mx[3];
+            for (int a = 0; a < 3; ++a) { const uint32_t o = f2ord(s_c[a][sl]); mn[a] = ok ? o : 0xFFFFFFFFu; mx[a] = ok ? o : 0u; }
+            const int w = seg < 64 ? seg : 64;
+            for (int o = 1; o < w; o <<= 1)
+                for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], (uint32_t)__shfl_xor(mn[a], o, 64)); mx[a] = max(mx[a], (uint32_t)__shfl_xor(mx[a], o, 64)); }
+            if ((i & (w - 1)) == 0 && mn[0] != 0xFFFFFFFFu)
+                for (int a = 0; a < 3; ++a) { atomicMin(&s_box[i / seg][a], mn[a]); atomicMax(&s_box[i / seg][3 + a], mx[a]); }
+        }
+        __syncthreads();
+        for (int i = t; i < RW; i += 256) {
+            const uint32_t* b = s_box[i / seg];
+            int ax = 0;
+            if (b[0] != 0xFFFFFFFFu) {   // segment holds at least one triangle
+                const float e0 = ord2f(b[3]) - ord2f(b[0]), e1 = ord2f(b[4]) - ord2f(b[1]), e2 = ord2f(b[5]) - ord2f(b[2]);
+                float best = e0;
+                if (e1 > best) { best = e1; ax = 1; }
+                if (e2 > best) { best = e2; ax = 2; }
+            }
+            s_key[i] = s_c[ax][s_slot[i]];
+        }
+        __syncthreads();
+        // bitonic sort of every aligned segment of `seg` positions by (key, triangle id), ascending
+        for (int k = 2; k <= seg; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int p = t;                                           // RW / 2 = 256 pairs, one per thread
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+                const bool up = (k == seg) || ((i & k) == 0);
+                const float ka = s_key[i], kb = s_key[l];
+                const uint32_t sa = s_slot[i], sb = s_slot[l];
+                const bool gt = ka > kb || (ka == kb && s_id[sa] > s_id[sb]);
+                if (gt == up) { s_key[i] = kb; s_key[l] = ka; s_slot[i] = sb; s_slot[l] = sa; }
+                // partners at distance j <= 64 live in the 128 positions this wave owns for all smaller j (LDS operations of
+                // a wave execute in order): a block barrier is needed only while j > 64 or before the next k starts above 64
+                if (j > 64 || (j == 1 && k >= 128)) __syncthreads();
+            }
+        __syncthreads();   // the next level (and the write-back) read positions other waves sorted
+    }
+    // padding keys are +inf with the largest id: they stay at the tail of every segment, so the triangles are a prefix
+    for (int i = t; i < RW; i += 256) { const uint32_t g = w0 + i; if (g < n_faces) order[g] = s_id[s_slot[i]]; }
+}
+
 __device__ __forceinline__ float pad_from_box(const uint32_t* __restrict__ box) {
     float lo[3], hi[3];
     for (int a = 0; a < 3; ++a) { lo[a] = ord2f(box[a]); hi[a] = ord2f(box[3 + a]); }
@@ -558,6 +636,9 @@ void build_bvh(mvs_ctx* ctx) {
     MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F, 0, 30, s));
     ctx->sort_tmp.ensure(tmp_bytes + 16);
     MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F, 0, 30, s));
+    static_assert(RW == 2 * 256 && RW % (int)LEAF_T == 0, "one pair per thread");
+    hipLaunchKernelGGL(refine_order_kernel, dim3((F + RW - 1) / RW), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->sort_v2.p, F);
+    MVS_LAUNCH_CHECK();
     ctx->bvh_tris.ensure(TRI_F4 * (size_t)n_slots);
     hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->sort_v2.p, F, n_slots, box, ctx->bvh_tris.p);
     MVS_LAUNCH_CHECK();
