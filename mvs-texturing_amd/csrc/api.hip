@@ -15,7 +15,7 @@ void dc_phase2(mvs_ctx* ctx);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
-void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0);
+void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
 void mrf_keep_best(mvs_ctx* ctx);
 void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
@@ -361,7 +361,7 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     int issued = 0, polled = 0;
     while (issued < P.max_sweeps && !pg.stopped) {
         { Prof pr(ctx, "mrf_sweep"); mrf_sweep(ctx, 0, F); }
-        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, false, 0, F); mrf_step(ctx, nullptr); }
+        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, false, 0, F, /*reduce=*/false); mrf_step(ctx, nullptr); }
         ++issued;
         if (issued - lag > polled) report((uint32_t)++polled);
     }

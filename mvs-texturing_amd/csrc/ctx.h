@@ -166,6 +166,7 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved; mvs::DBuf<uint32_t> m_alist; bool icm_dirty_valid = false;   // ICM active set: nodes whose gain the next pass re-evaluates
     uint32_t m_n_adj = 0;      // directed edges of the adjacency given to mrf_setup
+    uint32_t m_energy_blocks = 0;   // per-block partial pairs the last mrf_energy left behind m_energy.p + 4
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0;
     // colour-phased schedule: colours of the adjacency graph, nodes in (colour, id) order, class boundaries (host copy)
     mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c; uint32_t m_colours = 0; std::vector<uint32_t> m_colour_begin;

@@ -715,13 +715,28 @@ __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t nod
 // ---- device-side solver bookkeeping: one thread.  Same decisions, in the same arithmetic, as the host loop it
 // replaces: best = min(best, e); stop iff sweep >= min_sweeps, sweep > window and
 // double(hist[sweep - window] - best) < double(min_improvement) * double(hist[sweep - window]).
-__global__ void mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
-                                const unsigned long long* __restrict__ energy, int max_sweeps, int min_sweeps, int window,
+// With `partial` (single-GPU loop) the block first sums the energy kernel's per-block pairs itself and publishes them in
+// energy_out -- one launch less per sweep than reduce + step; sharded callers pass the all-reduced pair in `energy`.
+__global__ void __launch_bounds__(256) mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
+                                const unsigned long long* __restrict__ energy, const unsigned long long* __restrict__ partial, uint32_t n_partial,
+                                unsigned long long* __restrict__ energy_out, int max_sweeps, int min_sweeps, int window,
                                 float min_improvement) {
+    __shared__ unsigned long long su[4], sc[4];
+    unsigned long long e_sum = 0, c_sum = 0;
+    if (partial) {
+        for (uint32_t b = threadIdx.x; b < n_partial; b += 256u) { e_sum += partial[2 * b]; c_sum += partial[2 * b + 1]; }
+        for (int o = 32; o > 0; o >>= 1) { e_sum += __shfl_xor(e_sum, o, 64); c_sum += __shfl_xor(c_sum, o, 64); }
+        if ((threadIdx.x & 63) == 0) { su[threadIdx.x >> 6] = e_sum; sc[threadIdx.x >> 6] = c_sum; }
+        __syncthreads();
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (partial) {
+        e_sum = su[0] + su[1] + su[2] + su[3]; c_sum = sc[0] + sc[1] + sc[2] + sc[3];
+        energy_out[0] = e_sum; energy_out[1] = c_sum;
+    }
     if (st->stopped) { st->improved = 0u; return; }
     const uint32_t sw = st->sweep + 1u;
-    const unsigned long long e0 = energy[0];
+    const unsigned long long e0 = partial ? e_sum : energy[0];
     unsigned long long best = st->best;
     const bool imp = e0 < best;
     if (imp) best = e0;
@@ -867,7 +882,9 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
     hipStream_t s = ctx->stream;
     const mvs_mrf_params& P = ctx->m_params;
     if (!ctx->h_ring) throw StatusError(MVS_ERR_STATE, "mrf step before mrf setup");
-    hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(64), 0, s, ctx->m_state.p, ctx->m_hist.p, energy ? energy : ctx->m_energy.p,
+    // energy == nullptr: the pair is still in per-block partials (mrf_energy(..., reduce = false)), summed by the step kernel
+    hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(256), 0, s, ctx->m_state.p, ctx->m_hist.p, energy,
+                       energy ? (const unsigned long long*)nullptr : ctx->m_energy.p + 4, energy ? 0u : ctx->m_energy_blocks, ctx->m_energy.p,
                        P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
     MVS_LAUNCH_CHECK();
     const uint32_t F = ctx->csr_faces;
@@ -974,8 +991,9 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
 
 // energy of the current decode (best == false) or of the best labeling over nodes [nb0, ne0)
 // -> ctx->m_energy (device, 2 x u64), asynchronous
-void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0) {
+void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce) {
     const unsigned blocks = ne0 > nb0 ? std::min<unsigned>((ne0 - nb0 + 255) / 256, 2048u) : 0u;
+    ctx->m_energy_blocks = blocks;
     ctx->m_energy.ensure(4 + 2 * 2048);
     unsigned long long* partial = ctx->m_energy.p + 4;
     if (blocks) {
@@ -983,6 +1001,7 @@ void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0) {
                            best ? ctx->m_best_lab.p : ctx->m_lab.p, best ? ctx->m_best_cost.p : ctx->m_cost.p, nb0, ne0, partial);
         MVS_LAUNCH_CHECK();
     }
+    if (!reduce) return;   // the caller's mrf_step sums the partials
     hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, ctx->m_energy.p);
     MVS_LAUNCH_CHECK();
 }
