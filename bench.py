@@ -207,18 +207,19 @@ def main():
         nnz_own = int(dc["nnz"])                             # entries of the nodes this rank sweeps
         if nnz_own:
             # Algorithmic bytes per sweep (labels u16 + unary f32, every message read once and
-            # written once, adjacency, label out) with the messages stored as binary16 in this implementation:
-            #   6 nnz + 2 B x 3 nnz x 2 + 12 F = 18 nnz + 12 F.   The survey's fp32-message figure is 30 nnz + 12 F.
+            # written once, adjacency, label out) with the messages stored as 8-bit codes in this implementation:
+            #   6 nnz + 1 B x 3 nnz x 2 + 12 F = 12 nnz + 12 F.   The survey's fp32-message figure is 30 nnz + 12 F.
             # Per launch: that figure / n_phases (every node is swept by exactly one of the launches).
-            b_sweep = 18.0 * nnz_own + 12.0 * nf_own
+            b_sweep = 12.0 * nnz_own + 12.0 * nf_own
             b_survey = 30.0 * nnz_own + 12.0 * nf_own
             ach = b_sweep / (sweep_ms * 1e-3) / 1e9
             roof = {"kernel": "mrf_sweep4_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": b_sweep / n_phases,
                     "launches_per_sweep": n_phases, "sweep_ms": sweep_ms,
                     "note": "a sweep is %d launches (one per colour class of the adjacency graph); per-launch figures are the sweep's "
-                            "divided by %d.  Messages are binary16: algorithmic bytes per sweep = 18 nnz + 12 F; with the survey's "
-                            "fp32-message formula (30 nnz + 12 F = %.3e B) the same time reads %.0f GB/s"
+                            "divided by %d, averaged over the damped (odd) and undamped (even) sweeps of the solve.  Messages are 8-bit "
+                            "fixed point: algorithmic bytes per sweep = 12 nnz + 12 F; with the survey's fp32-message formula "
+                            "(30 nnz + 12 F = %.3e B) the same time reads %.0f GB/s"
                             % (n_phases, n_phases, b_survey, b_survey / (sweep_ms * 1e-3) / 1e9)}
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):

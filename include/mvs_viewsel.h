@@ -290,7 +290,7 @@ mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_en
 /* message layout for the halo planner: in_off_host[e] = first message element of the run of directed edge e
  * (adjacency-list order, e < adj_ptr[n_faces]); runs are laid out in (colour, face id) node order */
 mvs_status mvs_ctx_mrf_layout(mvs_ctx* ctx, uint32_t* in_off_host, uint64_t n_edges);
-/* dst[k] = array[idx[k]] / array[idx[k]] = src[k] in 4-byte exchange words (message elements are binary16 and travel
+/* dst[k] = array[idx[k]] / array[idx[k]] = src[k] in 4-byte exchange words (message elements are 8-bit codes and travel
  * zero-extended); MSG = the buffer the last sweep wrote */
 mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, void* dst_device);
 mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, const void* src_device);

@@ -161,7 +161,7 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
     mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
-    mvs::DBuf<uint16_t> m_msg_a;   // messages as IEEE binary16 bit patterns, updated in place (one colour class at a time)
+    mvs::DBuf<uint8_t> m_msg_a;    // messages as 8-bit fixed point over [0, 1/rho], updated in place (one colour class at a time)
     mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
     mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved; mvs::DBuf<uint32_t> m_alist; bool icm_dirty_valid = false;   // ICM active set: nodes whose gain the next pass re-evaluates

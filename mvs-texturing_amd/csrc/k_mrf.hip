@@ -25,11 +25,15 @@ namespace {
 constexpr uint16_t MAP_NONE = 0xFFFF;
 constexpr uint32_t MSG_BASE = MVS_MRF_MSG_BASE;   // first real message / map element (mvs_viewsel.h)
 
-// Messages live in HBM as IEEE binary16 (round to nearest even on store), arithmetic is fp32:
-// half the bytes per sweep of an fp32 layout at the same solution quality.
-typedef _Float16 msg_t;
-__device__ __forceinline__ float msg_load(const msg_t* __restrict__ p, size_t i) { return (float)p[i]; }
-__device__ __forceinline__ msg_t msg_pack(float v) { return (msg_t)v; }
+// Messages live in HBM as 8-bit fixed point over their range [0, lam], lam = 1 / rho (a message is a truncated,
+// min-normalised cavity: 0 <= m <= lam by construction); arithmetic is fp32.  code = trunc(m * (255 / lam) + 0.5),
+// value = code * (lam / 255): a quarter of the bytes of an fp32 layout, half of binary16, at the same solution
+// quality (part of the solver's definition, restated in oracle/oracle.cpp).
+typedef uint8_t msg_t;
+struct MsgQ { float scale, step; };      // 255 / lam and lam / 255, fp32, the oracle computes them the same way
+__device__ __forceinline__ MsgQ msg_q(float lam) { return MsgQ{255.0f / lam, lam / 255.0f}; }
+__device__ __forceinline__ float msg_load(const msg_t* __restrict__ p, size_t i, MsgQ q) { return (float)p[i] * q.step; }
+__device__ __forceinline__ uint32_t msg_code(float v, MsgQ q) { return (uint32_t)(v * q.scale + 0.5f); }   // v in [0, lam]: 0 .. 255
 
 __device__ __forceinline__ unsigned long long fix32(float d) { return (unsigned long long)((double)d * 4294967296.0); }
 
@@ -344,7 +348,7 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 }
 
 // ---- one colour phase of a sweep; fast path: degree <= 3, K <= 4 * G ----
-// ---- 4 labels per lane: lane gl owns labels 4*gl .. 4*gl+3 (one 8-byte access = four binary16 messages or
+// ---- 4 labels per lane: lane gl owns labels 4*gl .. 4*gl+3 (one 4-byte access = four 8-bit messages, one 8-byte access =
 // four u16 map entries), K <= 4 * G, so a 64-lane wave sweeps 64/G nodes per iteration at roughly the
 // instruction count of one.  The kernel is VALU-issue bound (a wave64 VALU op occupies its SIMD for 4 cycles), so
 // instructions per node is what counts, and the layout is arranged so that NO per-label masking is needed:
@@ -359,7 +363,6 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // Values a lane computes for label slots beyond the column are garbage that never reaches a valid label: they are
 // excluded from min / argmin by the ok[] mask (the only per-label selects left) and land in run padding.
 // LDS operations of a wave execute in order and a lane group never spans waves, so the tile needs no barrier.
-struct alignas(8) msg4_t { msg_t v[4]; };
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int G, bool DAMP, bool XCD, bool LATE_OLD>
 __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
@@ -378,6 +381,7 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     if (gl == 0) tile[4 * G] = INFINITY;
     __syncthreads();
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
+    const MsgQ mq = msg_q(lam);
     const uint32_t stride = gridDim.x * NPB;
     uint32_t vb = blockIdx.x;
     if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -408,20 +412,19 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             a_map[d] = (o0 && !(kjf & IDENT)) ? cur.out_off[d] + t0 : t0;      // t0 < MSG_BASE: the identity run
         }
         const f32x4_a4 dv = *reinterpret_cast<const f32x4_a4*>(cost + da);
-        uint2 r_in[3], r_old[3], r_map[3];
+        uint32_t r_in[3], r_old[3]; uint2 r_map[3];   // four 8-bit messages per 4-byte word, four u16 map entries per 8-byte word
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            r_in[d] = *reinterpret_cast<const uint2*>(mo + a_in[d]);
+            r_in[d] = *reinterpret_cast<const uint32_t*>(mo + a_in[d]);
             r_map[d] = *reinterpret_cast<const uint2*>(map + a_map[d]);
-            if (!LATE_OLD) { if (DAMP) r_old[d] = *reinterpret_cast<const uint2*>(mo + a_out[d]); else r_old[d] = make_uint2(0u, 0u); }
+            if (!LATE_OLD) { if (DAMP) r_old[d] = *reinterpret_cast<const uint32_t*>(mo + a_out[d]); else r_old[d] = 0u; }
         }
         const float D[4] = {dv.x, dv.y, dv.z, dv.w};
         float in[3][4];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const uint32_t w_in[4] = {r_in[d].x & 0xFFFFu, r_in[d].x >> 16, r_in[d].y & 0xFFFFu, r_in[d].y >> 16};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) in[d][r] = (float)__builtin_bit_cast(msg_t, (unsigned short)w_in[r]);
+            for (int r = 0; r < 4; ++r) in[d][r] = (float)((r_in[d] >> (8 * r)) & 0xFFu) * mq.step;   // v_cvt_f32_ubyte<r>
         }
         // decode: first argmin_t of b[t] = D[t] + rho * S[t] -- the group minimum, then the smallest label attaining it
         // (== the sequential "first minimum": comparisons are exact, +0 == -0 in both formulations)
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             // the CU's L1 / the XCD's L2 whenever j is swept by this block too, instead of racing the first fetch to HBM.
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { if (DAMP) r_old[d] = *reinterpret_cast<const uint2*>(mo + a_out[d]); else r_old[d] = make_uint2(0u, 0u); }
+            for (int d = 0; d < 3; ++d) { if (DAMP) r_old[d] = *reinterpret_cast<const uint32_t*>(mo + a_out[d]); else r_old[d] = 0u; }
         }
         // label and unary of the decoded state (all the energy / ICM kernels need of a neighbour): loaded by every
         // lane (same address inside a group), consumed by the store at the end of the iteration
@@ -462,16 +465,15 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             const float cmin = group_min_fused<G>(fminf(fminf(cm[0], cm[1]), fminf(cm[2], cm[3])));
             *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0], c[1], c[2], c[3]);
             const uint32_t mp[4] = {r_map[d].x & 0xFFFFu, r_map[d].x >> 16, r_map[d].y & 0xFFFFu, r_map[d].y >> 16};
-            const uint32_t w_old[4] = {r_old[d].x & 0xFFFFu, r_old[d].x >> 16, r_old[d].y & 0xFFFFu, r_old[d].y >> 16};
-            msg4_t w;
+            uint32_t w = 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float cp = tile[min(mp[r], (uint32_t)(4 * G))];          // MAP_NONE -> the +inf slot
                 const float raw = fminf(cp - cmin, lam);
-                const float old = (float)__builtin_bit_cast(msg_t, (unsigned short)w_old[r]);
-                w.v[r] = msg_pack(DAMP ? (raw * oma + old * alpha) : raw);
+                const float old = (float)((r_old[d] >> (8 * r)) & 0xFFu) * mq.step;
+                w |= msg_code(DAMP ? (raw * oma + old * alpha) : raw, mq) << (8 * r);
             }
-            if (t0 < kj3[d]) *reinterpret_cast<msg4_t*>(mn + cur.out_off[d] + t0) = w;      // one 8-byte store (runs are padded)
+            if (t0 < kj3[d]) *reinterpret_cast<uint32_t*>(mn + cur.out_off[d] + t0) = w;      // one 4-byte store (runs are padded)
         }
         if (gl == 0 && node_ok) {
             /* K == 0: the single label 0 with unary 1 (view_selection.cpp:50-51,70-71) */
@@ -497,10 +499,11 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
     if (K == 0) { if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; } return; }
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
+    const MsgQ mq = msg_q(lam);
     float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
     for (uint32_t t = lane; t < K; t += 64) {
         float S = 0.0f;
-        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) S = S + msg_load(mo, m.in_off + t); }
+        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) S = S + msg_load(mo, m.in_off + t, mq); }
         const float b = cost[p0 + t] + rho * S;
         if (b < bb) { bb = b; bt = t; }
     }
@@ -515,8 +518,8 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         float cmin = INFINITY;
         for (uint32_t t = lane; t < K; t += 64) {
             float oth = 0.0f;
-            for (uint32_t e2 = e0; e2 < e1; ++e2) { if (e2 == e) continue; const MrfEdge m2 = edge[e2]; if (m2.kj) oth = oth + msg_load(mo, m2.in_off + t); }
-            const float c = (cost[p0 + t] + rho * oth) - omr * msg_load(mo, m.in_off + t);
+            for (uint32_t e2 = e0; e2 < e1; ++e2) { if (e2 == e) continue; const MrfEdge m2 = edge[e2]; if (m2.kj) oth = oth + msg_load(mo, m2.in_off + t, mq); }
+            const float c = (cost[p0 + t] + rho * oth) - omr * msg_load(mo, m.in_off + t, mq);
             scratch[p0 + t] = c;
             cmin = fminf(cmin, c);
         }
@@ -525,7 +528,7 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         for (uint32_t t2 = lane; t2 < m.kj; t2 += 64) {
             const uint16_t p = map[m.out_off + t2];
             const float raw = (p == MAP_NONE) ? lam : fminf(scratch[p0 + p] - cmin, lam);
-            mn[m.out_off + t2] = msg_pack(DAMP ? (raw * oma + msg_load(mo, m.out_off + t2) * alpha) : raw);
+            mn[m.out_off + t2] = (msg_t)msg_code(DAMP ? (raw * oma + msg_load(mo, m.out_off + t2, mq) * alpha) : raw, mq);
         }
         __syncthreads();
     }
@@ -838,7 +841,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_desc.ensure((size_t)F + 1);
     if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
     ctx->m_msg_a.ensure(ctx->m_total + 8);
-    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // binary16 zeros, incl. the reserved zero run
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 8) * sizeof(msg_t), s));   // zero codes, incl. the reserved zero run
     // the sweep reads unaries with unclamped 16-byte loads: a caller-owned cost array (mvs_ctx_costs_upload with device
     // pointers) is copied into the context's own buffer, which always has slack behind the last element
     if (ctx->r_cost != ctx->csr_cost.p && ctx->csr_nnz) {

@@ -28,23 +28,23 @@ __global__ void scatter_kernel(uint32_t* __restrict__ dst, const uint32_t* __res
 }
 // combined addressing: index < 2^31 -> array a (messages), else array b[index & 0x7FFFFFFF] (labels):
 // one gather / scatter per sweep moves cut-edge messages AND boundary labels
-// message elements are binary16: moved zero-extended in 4-byte exchange words
-__global__ void gather_msg_kernel(const uint16_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+// message elements are 8-bit codes: moved zero-extended in 4-byte exchange words
+__global__ void gather_msg_kernel(const uint8_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[k] = src[idx[k]];
 }
-__global__ void scatter_msg_kernel(uint16_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = (uint16_t)src[k];
+__global__ void scatter_msg_kernel(uint8_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = (uint8_t)src[k];
 }
-__global__ void gather2_kernel(const uint16_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+__global__ void gather2_kernel(const uint8_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = idx[k];
         dst[k] = (i & 0x80000000u) ? b[i & 0x7FFFFFFFu] : a[i];
     }
 }
-__global__ void scatter2_kernel(uint16_t* __restrict__ a, uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+__global__ void scatter2_kernel(uint8_t* __restrict__ a, uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = idx[k];
-        if (i & 0x80000000u) b[i & 0x7FFFFFFFu] = src[k]; else a[i] = (uint16_t)src[k];
+        if (i & 0x80000000u) b[i & 0x7FFFFFFFu] = src[k]; else a[i] = (uint8_t)src[k];
     }
 }
 __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, uint32_t* __restrict__ counts) {
@@ -53,7 +53,7 @@ __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, 
 }
 }  // namespace
 
-static uint16_t* mrf_msg(mvs_ctx* ctx) { return ctx->m_msg_a.p; }  // one buffer, updated in place
+static uint8_t* mrf_msg(mvs_ctx* ctx) { return ctx->m_msg_a.p; }  // one buffer, updated in place
 static uint32_t* mrf_array(mvs_ctx* ctx, int which) {
     switch (which) {
         case MVS_MRF_LAB: return ctx->m_lab.p;

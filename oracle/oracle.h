@@ -119,9 +119,10 @@ typedef struct {
 } orc_mrf_stats;
 
 void orc_mrf_default_params(orc_mrf_params* p);
-/* the solver stores messages as IEEE binary16; these are its conversions (tested against numpy.float16) */
-uint16_t orc_f32_to_f16(float f);
-float orc_f16_to_f32(uint16_t h);
+/* the solver stores messages as 8-bit fixed point over [0, 1/rho]: code = trunc(v * (255 rho') + 0.5), value = code / (255 rho')
+ * with rho' = 1 / (1 / rho) evaluated in fp32 exactly as oracle.cpp does (tested against a numpy restatement) */
+uint32_t orc_msg_code(float v, float rho);
+float orc_msg_store(float v, float rho);
 /* experiments: per-sweep energies of the decoded labeling are written to buf[0..len) */
 void orc_mrf_set_trace(uint64_t* buf, int len);
 int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,

@@ -143,19 +143,27 @@ def test_outlier_detection_matches_numpy_linear_algebra():
             assert q == qn[v]
 
 
-def test_binary16_message_storage_conversions():
-    """the solver stores messages as IEEE binary16 (RNE): its software conversions equal numpy.float16"""
+def test_8bit_message_storage():
+    """the solver stores messages as 8-bit fixed point over [0, 1/rho]: the oracle's conversion equals a numpy restatement
+    in fp32 (code = trunc(v * (255 / lam) + 0.5), value = code * (lam / 255)), codes cover 0 .. 255, the stored value is
+    within half a step of the input and storing is idempotent"""
     L = O.load()
-    L.orc_f32_to_f16.argtypes = [C.c_float]; L.orc_f32_to_f16.restype = C.c_uint16
-    L.orc_f16_to_f32.argtypes = [C.c_uint16]; L.orc_f16_to_f32.restype = C.c_float
+    L.orc_msg_code.argtypes = [C.c_float, C.c_float]; L.orc_msg_code.restype = C.c_uint32
+    L.orc_msg_store.argtypes = [C.c_float, C.c_float]; L.orc_msg_store.restype = C.c_float
     rng = np.random.default_rng(0)
-    x = np.concatenate([rng.random(4000).astype(np.float32) * 1.3, (rng.random(2000) * 1e-4).astype(np.float32),
-                        np.float32([0, 1, 1.25, 6e-8, 3e-8, 2.98e-8, 65504, 1e-10, -0.3, 0.33325195, 0.33337402])])
-    ref = x.astype(np.float16)
-    got = np.array([L.orc_f32_to_f16(C.c_float(float(v))) for v in x], dtype=np.uint16)
-    assert np.array_equal(got, ref.view(np.uint16))
-    back = np.array([L.orc_f16_to_f32(int(h)) for h in got], dtype=np.float32)
-    assert np.array_equal(back.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    f32 = np.float32
+    for rho in (f32(0.8), f32(1.0), f32(0.6667), f32(0.5)):
+        lam = f32(1.0) / rho
+        scale, step = f32(255.0) / lam, lam / f32(255.0)
+        x = np.concatenate([rng.random(3000).astype(np.float32) * lam, f32([0, lam, lam / 2, step / 2, step * 0.49, step * 254.5, 1e-9])]).astype(np.float32)
+        code = np.array([L.orc_msg_code(C.c_float(float(v)), C.c_float(float(rho))) for v in x], dtype=np.uint32)
+        ref = (x * scale + f32(0.5)).astype(np.float32).astype(np.uint32)          # fp32 multiply, fp32 add, truncation
+        assert np.array_equal(code, ref) and code.max() == 255 and code.min() == 0
+        val = np.array([L.orc_msg_store(C.c_float(float(v)), C.c_float(float(rho))) for v in x], dtype=np.float32)
+        assert np.array_equal(val.view(np.uint32), (ref.astype(np.float32) * step).view(np.uint32))
+        assert (np.abs(val - x) <= step * 0.5 * (1 + 1e-3) + 1e-7).all()
+        again = np.array([L.orc_msg_store(C.c_float(float(v)), C.c_float(float(rho))) for v in val], dtype=np.float32)
+        assert np.array_equal(again.view(np.uint32), val.view(np.uint32))
 
 
 def test_solver_quality_small_instances():
