@@ -44,4 +44,4 @@ for rep in range(a.repeat):
     ctx.set_option("profile", 0)
 for name, ms in results.items():
     best = min(ms)
-    print("%-24s min %.4f  all %s ms/sweep  (%.0f GB/s algorithmic at min)" % (name, best, " ".join("%.4f" % x for x in ms), (18.0 * st["nnz"] + 12.0 * F) / best / 1e6), flush=True)
+    print("%-24s min %.4f  all %s ms/sweep  (%.0f GB/s algorithmic at min)" % (name, best, " ".join("%.4f" % x for x in ms), (12.0 * st["nnz"] + 12.0 * F) / best / 1e6), flush=True)
