@@ -776,8 +776,8 @@ inline uint64_t fix32(float d) { return (uint64_t)((double)d * 4294967296.0); }
 // reach the same energy as with binary16 or fp32 messages (C3: 1 111 920 vs 1 111 890) at half / a quarter of the bytes.
 struct MsgQ { float scale, step; };
 inline MsgQ msg_q(float lam) { return MsgQ{255.0f / lam, lam / 255.0f}; }
-inline uint32_t msg_code(float v, MsgQ q) { return (uint32_t)(v * q.scale + 0.5f); }
-inline float msg_store(float v, MsgQ q) { return (float)msg_code(v, q) * q.step; }
+inline uint32_t msg_code(float v, MsgQ q) { return (uint32_t)(int32_t)(v * q.scale + 0.5f); }   // 0 .. 255: the signed conversion vectorises
+inline float msg_store(float v, MsgQ q) { return (float)(int32_t)msg_code(v, q) * q.step; }
 
 struct Mrf {
     uint32_t F = 0;
