@@ -751,7 +751,9 @@ void orc_csr_free(orc_csr* c) {
 //        c[t]  = (D[t] + rho * oth[t]) - (1 - rho) * m_e[t];  cmin = min_t c[t]
 //        for t' < K_j:  p = map[moff[rev e] + t']
 //          raw = (p == NONE) ? lam : fminf(c[p] - cmin, lam),   lam = 1 / rho
-//          m'_{rev e}[t'] = f16( raw * (1 - alpha) + m_{rev e}[t'] * alpha )   [messages are stored as IEEE binary16, RNE]
+//          m'_{rev e}[t'] = q8( raw * (1 - alpha) + m_{rev e}[t'] * alpha )
+//        with alpha = damping on ODD sweeps (1st, 3rd, ...) and 0 on even sweeps, and q8 = the 8-bit fixed-point
+//        storage of the messages over [0, lam]: code = trunc(v * (255 / lam) + 0.5), value = code * (lam / 255)
 //  * After each sweep the decoded labeling's energy is evaluated exactly in
 //    32.32 fixed point (integer sums are order independent); the best labeling
 //    so far is kept.  Stop like StopWhenReturnsDiminish(5, 0.01)
