@@ -12,8 +12,9 @@
 // argmin reductions are exact in any order, sums follow adjacency order,
 // energies are 32.32 fixed-point integers.
 //
-// Work mapping: G lanes per node (G = 8 / 16 / 32 from the largest column), 4
-// consecutive labels per lane; per-edge cavity vectors go through an LDS tile for
+// Work mapping: G lanes per node (G = 8 / 16 / 32 / 64 from the largest column), 4
+// consecutive labels per lane; messages are 8-bit fixed point in HBM (four per 4-byte
+// word), damped on odd sweeps only; per-edge cavity vectors go through an LDS tile for
 // the label re-alignment gather; min / argmin are fused DPP butterflies.
 #include "ctx.h"
 #include <rocprim/rocprim.hpp>
