@@ -8,13 +8,18 @@ Sharding (DESIGN.md "Multi-GPU"):
     BVH and images are replicated), then one all-reduce(MAX) of the maximum
     quality and one all-reduce(SUM) of the 10000-bin histogram reproduce the
     global barrier of postprocess_face_infos (calculate_data_costs.cpp:278-288);
-    the per-rank CSR pieces are all-gathered so every rank holds the whole table;
+    the cost table itself stays sharded: a rank's table has a column for every
+    face of the mesh, but only its own columns and those of its halo (faces of
+    other parts adjacent to its own) are filled -- the column lengths of all
+    faces (4 bytes each) and the halo columns are all that travels;
   * MRF: every rank owns the nodes of its part and sweeps only those, one
     colour class of the adjacency graph at a time (colour-phased Gauss-Seidel);
     after each phase the messages over cut edges and the decoded selections of
     boundary nodes are exchanged with an all-to-all whose index lists are
-    planned here, on the host, from col_ptr + adjacency + the library's message
-    layout; the exact fixed-point energy is all-reduced once per sweep and fed
+    planned here, on the host, from the rank's col_ptr + adjacency + the message
+    layout the library derived from ITS table (layouts differ between ranks; both
+    ends enumerate the cut edges in the same order); the exact fixed-point energy
+    is all-reduced once per sweep and fed
     to the device-side stop rule, so every rank takes the same stop decision.
     A phase only reads nodes of other colours, which were exchanged before, so
     labels are bit-identical for any number of parts.
@@ -293,7 +298,8 @@ class ShardedViewSelection:
 
 
 class GpuShardOps:
-    """ShardedViewSelection ops on a viewsel.Context holding the FULL cost table + adjacency."""
+    """ShardedViewSelection ops on a viewsel.Context holding the rank's cost table (own + halo columns, global shape)
+    and the full adjacency."""
 
     def __init__(self, ctx, adj_ptr_dev, adj_dev, params):
         import ctypes as C
@@ -375,9 +381,44 @@ class GpuShardOps:
         return out[:ne - nb]
 
 
-def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, device="cuda"):
-    """tex::calculate_data_costs over P ranks; afterwards every rank's context holds the GLOBAL
-    cost table (device-resident).  Returns (col_ptr, view_id, cost) torch tensors and local stats."""
+def boundary_faces(adj_ptr, adj, part_begin, me):
+    """For every peer p: send[p] = faces of part `me` with a neighbour in part p, recv[p] = faces of part p with a neighbour
+    in part `me` (sorted, unique).  From the adjacency alone, so send[p] here == recv[me] on rank p."""
+    adj_ptr = np.asarray(adj_ptr, dtype=np.int64); adj = np.asarray(adj, dtype=np.int64)
+    F, P = len(adj_ptr) - 1, len(part_begin) - 1
+    pb = np.asarray(part_begin, dtype=np.int64)
+    dst = np.repeat(np.arange(F, dtype=np.int64), np.diff(adj_ptr))
+    own_dst = np.searchsorted(pb, dst, side="right") - 1
+    own_src = np.searchsorted(pb, adj, side="right") - 1
+    empty = np.zeros(0, dtype=np.int64)
+    send, recv = [], []
+    for p in range(P):
+        if p == me:
+            send.append(empty); recv.append(empty)
+            continue
+        send.append(np.unique(adj[(own_src == me) & (own_dst == p)]))
+        recv.append(np.unique(adj[(own_dst == me) & (own_src == p)]))
+    return send, recv
+
+
+def _all_to_all(dist, group, send, recv, sc, rc):
+    if send.is_cuda and dist.get_backend(group) == "gloo":   # test configuration (ranks sharing one GPU): stage through the host
+        import torch
+        hs, hr = send.cpu(), torch.empty(recv.numel(), dtype=recv.dtype)
+        dist.all_to_all_single(hr, hs, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        recv.copy_(hr)
+    else:
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+
+
+def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, device="cuda", boundary=None):
+    """tex::calculate_data_costs over P ranks.  Afterwards the context of rank `me` holds a cost table of the GLOBAL shape
+    (a column per face of the whole mesh) in which its own columns and the columns of its halo -- the faces of other
+    parts adjacent to its own (`boundary` = boundary_faces(...)) -- are filled and every other column is empty: exactly
+    what the solver needs to sweep the own nodes (neighbours' label lists for the re-alignment maps, messages over the
+    cut edges), at a memory and set-up cost that scales with the part, not with the mesh.  Only the column lengths of
+    all faces (4 bytes each) and the halo columns travel.  Returns (DataCosts of the local table, local stats,
+    global nnz)."""
     import ctypes as C
     import torch
     from .viewsel import DcStats, _check, _stats_dict, DataCosts
@@ -400,42 +441,76 @@ def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, dev
     ds = DcStats()
     _check(L, L.mvs_ctx_dc_phase3(h, C.byref(ds)))
     stats = _stats_dict(ds)
-    nf, nnz = int(part_begin[me + 1] - part_begin[me]), int(stats["nnz"])
+    nb, ne = int(part_begin[me]), int(part_begin[me + 1])
+    nf, nnz = ne - nb, int(stats["nnz"])
+    F = int(part_begin[-1])
     counts = torch.zeros(max(nf, 1), dtype=torch.int32, device=device)
     vid = torch.zeros(max(nnz, 1), dtype=torch.int16, device=device)
     cost = torch.zeros(max(nnz, 1), dtype=torch.float32, device=device)
     _check(L, L.mvs_ctx_costs_export(h, C.c_void_p(counts.data_ptr()), C.c_void_p(vid.data_ptr()), C.c_void_p(cost.data_ptr())))
     ctx.synchronize()
+    counts, vid, cost = counts[:nf], vid[:nnz], cost[:nnz]
     if dist is not None and P > 1:
-        sizes = torch.tensor([nf, nnz], dtype=torch.int64, device=device)
-        all_sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(P)]
-        dist.all_gather(all_sizes, sizes, group=group)
-        all_sizes = [[int(x) for x in s.tolist()] for s in all_sizes]
-        mf, mn = max(s[0] for s in all_sizes), max(max(s[1] for s in all_sizes), 1)
+        # (1) column lengths of every face: parts are equal up to one face, so one padded all-gather
+        sizes = [int(part_begin[p + 1] - part_begin[p]) for p in range(P)]
+        pad = torch.zeros(max(sizes), dtype=torch.int32, device=device); pad[:nf] = counts
+        outs = [torch.zeros_like(pad) for _ in range(P)]
+        dist.all_gather(outs, pad, group=group)
+        counts_g = torch.cat([outs[p][:sizes[p]] for p in range(P)]).to(torch.int64)
+        nnz_global = int(counts_g.sum().item())
+        # (2) halo columns: every rank sends the columns of its boundary faces to the parts they touch
+        send_f, recv_f = boundary
+        own_ptr = torch.zeros(nf + 1, dtype=torch.int64, device=device); own_ptr[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        keep = torch.zeros(F, dtype=torch.bool, device=device); keep[nb:ne] = True
 
-        def gather_padded(t, n, m):
-            # as raw bytes: RCCL / gloo have no 16-bit integer type
-            pad = torch.zeros(m, dtype=t.dtype, device=device); pad[:n] = t[:n]
-            pad8 = pad.view(torch.uint8)
-            outs = [torch.zeros(pad8.numel(), dtype=torch.uint8, device=device) for _ in range(P)]
-            dist.all_gather(outs, pad8, group=group)
-            return [o.view(t.dtype) for o in outs]
-        cs = gather_padded(counts, nf, max(mf, 1)); vs = gather_padded(vid, nnz, mn); fs = gather_padded(cost, nnz, mn)
-        counts = torch.cat([cs[p][:all_sizes[p][0]] for p in range(P)])
-        vid = torch.cat([vs[p][:all_sizes[p][1]] for p in range(P)])
-        cost = torch.cat([fs[p][:all_sizes[p][1]] for p in range(P)])
+        def expand(starts, lens):   # element indices of the runs [starts[k], starts[k] + lens[k])
+            total = int(lens.sum().item())
+            if total == 0:
+                return torch.zeros(0, dtype=torch.int64, device=device)
+            rep = torch.repeat_interleave(torch.arange(lens.numel(), device=device), lens)
+            within = torch.arange(total, device=device) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens)
+            return starts[rep] + within
+        s_idx, sc, r_faces, rc = [], [], [], []
+        for p in range(P):
+            fs = torch.from_numpy(np.asarray(send_f[p], dtype=np.int64)).to(device)
+            ln = counts.to(torch.int64)[fs - nb] if fs.numel() else torch.zeros(0, dtype=torch.int64, device=device)
+            s_idx.append(expand(own_ptr[fs - nb] if fs.numel() else ln, ln)); sc.append(int(s_idx[-1].numel()))
+            fr = torch.from_numpy(np.asarray(recv_f[p], dtype=np.int64)).to(device)
+            r_faces.append(fr); rc.append(int(counts_g[fr].sum().item()) if fr.numel() else 0)
+            if fr.numel():
+                keep[fr] = True
+        counts_l = torch.where(keep, counts_g, torch.zeros_like(counts_g))
+        ptr_l = torch.zeros(F + 1, dtype=torch.int64, device=device); ptr_l[1:] = torch.cumsum(counts_l, 0)
+        nnz_l = int(ptr_l[-1].item())
+        if nnz_l >= 2 ** 32:
+            raise ValueError("local cost table exceeds 2^32 entries")
+        vid_l = torch.zeros(max(nnz_l, 1), dtype=torch.int16, device=device)
+        cost_l = torch.zeros(max(nnz_l, 1), dtype=torch.float32, device=device)
+        o0 = int(ptr_l[nb].item())
+        vid_l[o0:o0 + nnz] = vid; cost_l[o0:o0 + nnz] = cost                     # own columns: one contiguous block
+        sidx = torch.cat(s_idx) if sum(sc) else torch.zeros(0, dtype=torch.int64, device=device)
+        send_v = vid[sidx].to(torch.int32) if sum(sc) else torch.zeros(0, dtype=torch.int32, device=device)   # RCCL / gloo have no 16-bit integers
+        send_c = cost[sidx] if sum(sc) else torch.zeros(0, dtype=torch.float32, device=device)
+        recv_v = torch.zeros(sum(rc), dtype=torch.int32, device=device); recv_c = torch.zeros(sum(rc), dtype=torch.float32, device=device)
+        _all_to_all(dist, group, send_v.contiguous(), recv_v, sc, rc)
+        _all_to_all(dist, group, send_c.contiguous(), recv_c, sc, rc)
+        if sum(rc):
+            fr_all = torch.cat(r_faces)
+            didx = expand(ptr_l[fr_all], counts_g[fr_all])       # peers in order, faces ascending: the order the peers packed
+            vid_l[didx] = recv_v.to(torch.int16); cost_l[didx] = recv_c
+        col_ptr = ptr_l.to(torch.int32).contiguous()
+        vid, cost = vid_l, cost_l
     else:
-        counts, vid, cost = counts[:nf], vid[:nnz], cost[:nnz]
-    F = counts.numel()
-    col_ptr = torch.zeros(F + 1, dtype=torch.int64, device=device)
-    col_ptr[1:] = torch.cumsum(counts.to(torch.int64), 0)
-    col_ptr = col_ptr.to(torch.int32).contiguous()
-    vid = vid.contiguous() if vid.numel() else torch.zeros(1, dtype=torch.int16, device=device)
-    cost = cost.contiguous() if cost.numel() else torch.zeros(1, dtype=torch.float32, device=device)
+        nnz_global = nnz
+        col_ptr = torch.zeros(nf + 1, dtype=torch.int64, device=device)
+        col_ptr[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        col_ptr = col_ptr.to(torch.int32).contiguous()
+        vid = vid.contiguous() if vid.numel() else torch.zeros(1, dtype=torch.int16, device=device)
+        cost = cost.contiguous() if cost.numel() else torch.zeros(1, dtype=torch.float32, device=device)
     torch.cuda.current_stream().synchronize()
-    dc = DataCosts(F, ctx.n_views, col_ptr, vid, cost)
+    dc = DataCosts(col_ptr.numel() - 1, ctx.n_views, col_ptr, vid, cost)
     ctx.costs_upload(dc)
-    return dc, stats
+    return dc, stats, nnz_global
 
 
 class ShardedPipeline:
@@ -445,17 +520,19 @@ class ShardedPipeline:
         self.ctx, self.part, self.rank, self.dist, self.device = ctx, part_begin, rank, dist, device
         self.adj_ptr_np, self.adj_np, self.adj_ptr_dev, self.adj_dev = adj_ptr_np, adj_np, adj_ptr_dev, adj_dev
         self.settings, self.params = settings, params
-        self.plan = self.hx = None
+        self.plan = self.hx = self.boundary = None
         self.nnz_global = 0
 
     def step(self):
-        dc, st = sharded_data_costs(self.ctx, self.settings, self.part, self.rank, self.dist, device=self.device)
+        if self.boundary is None:   # from the adjacency and the partition alone (host logic, once)
+            self.boundary = boundary_faces(self.adj_ptr_np, self.adj_np, self.part, self.rank)
+        dc, st, nnz_global = sharded_data_costs(self.ctx, self.settings, self.part, self.rank, self.dist, device=self.device, boundary=self.boundary)
         ops = GpuShardOps(self.ctx, self.adj_ptr_dev, self.adj_dev, self.params)
         ops.setup()
         if self.plan is None:   # the sparsity pattern (hence the colouring and the layout) is the same every step: plan the halo once (host logic)
             self.plan = HaloPlan(dc.col_ptr.cpu().numpy().view(np.uint32), self.adj_ptr_np, self.adj_np, self.part, self.rank,
                                  in_off=ops.layout(len(self.adj_np)))
             self.hx = HaloExchange(self.plan, self.device, self.dist)
-            self.nnz_global = int(dc.col_ptr[-1].item())
+        self.nnz_global = nnz_global
         labels, ms = ShardedViewSelection(ops, self.plan, self.params, self.device, self.dist, hx=self.hx, setup_done=True).run()
         return labels, st, ms, dc

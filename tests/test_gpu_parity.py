@@ -373,9 +373,9 @@ def _two_rank_worker(rank, world, port, out_dir):
     for _ in range(2):   # second step exercises the cached plan
         labels, st, ms, dc = pipe.step()
     np.save(os.path.join(out_dir, "labels_%d.npy" % rank), labels.cpu().numpy().view(np.uint32))
-    if rank == 0:
-        np.savez(os.path.join(out_dir, "global.npz"), col_ptr=dc.col_ptr.cpu().numpy(), cost=dc.cost.cpu().numpy(),
-                 stats=np.array([ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"]], dtype=np.uint64))
+    np.savez(os.path.join(out_dir, "table_%d.npz" % rank), col_ptr=dc.col_ptr.cpu().numpy(), view_id=dc.view_id.cpu().numpy(), cost=dc.cost.cpu().numpy(),
+             part=part, nnz_global=np.array([pipe.nnz_global], dtype=np.uint64),
+             stats=np.array([ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"]], dtype=np.uint64))
     c.close()
     dist.destroy_process_group()
 
@@ -395,11 +395,23 @@ def test_two_ranks_over_torch_distributed_equal_single(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(2)])
-    g = np.load(tmp_path / "global.npz")
-    assert np.array_equal(g["col_ptr"].view(np.uint32), full.col_ptr)
-    assert np.array_equal(g["cost"].view(np.uint32), full.cost.view(np.uint32))
     assert np.array_equal(got, lab0)
-    assert g["stats"].tolist() == [st0["energy_fixed"], st0["cut_edges"], st0["sweeps"], st0["icm_iters"]]
+    Kf = np.diff(full.col_ptr.astype(np.int64))
+    for r in range(2):
+        # the rank's table has the global shape; its own columns and the columns of its halo (faces of the other part
+        # adjacent to its own) equal the single-GPU table's, every other column is empty
+        g = np.load(tmp_path / ("table_%d.npz" % r))
+        part = g["part"].astype(np.int64)
+        send, recv = G.boundary_faces(adj_ptr, adj, part, r)
+        keep = np.zeros(len(Kf), dtype=bool); keep[part[r]:part[r + 1]] = True; keep[recv[1 - r]] = True
+        assert 0 < keep.sum() < len(Kf)
+        cp = g["col_ptr"].view(np.uint32).astype(np.int64)
+        assert np.array_equal(np.diff(cp), np.where(keep, Kf, 0))
+        sel = np.repeat(keep, Kf)                                   # entries of the full table this rank holds, in order
+        assert np.array_equal(g["view_id"].view(np.uint16)[:cp[-1]], full.view_id[sel])
+        assert np.array_equal(g["cost"][:cp[-1]].view(np.uint32), full.cost[sel].view(np.uint32))
+        assert int(g["nnz_global"][0]) == full.nnz
+        assert g["stats"].tolist() == [st0["energy_fixed"], st0["cut_edges"], st0["sweeps"], st0["icm_iters"]]
 
 
 def test_config2_size_properties(ctx):

@@ -177,7 +177,18 @@ class _FakeOps:
         return self.arr[G.BEST_LAB][nb:ne].copy()
 
 
-def _run_rank(rank, world, port, out_dir):
+def _masked_col_ptr(col_ptr, adj_ptr, adj, pb, rank):
+    """the column lengths a rank's sharded cost table has: own faces and their halo keep theirs, all others are empty
+    (multigpu.sharded_data_costs)"""
+    K = np.diff(col_ptr.astype(np.int64))
+    keep = np.zeros(len(K), dtype=bool); keep[int(pb[rank]):int(pb[rank + 1])] = True
+    for fr in G.boundary_faces(adj_ptr, adj, pb, rank)[1]:
+        keep[fr] = True
+    out = np.zeros(len(K) + 1, dtype=np.uint32); out[1:] = np.cumsum(np.where(keep, K, 0))
+    return out
+
+
+def _run_rank(rank, world, port, out_dir, masked=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -185,6 +196,8 @@ def _run_rank(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
     pb = G.equal_parts(len(faces), world)
+    if masked:   # every rank plans and computes on ITS table (own + halo columns, its own message layout)
+        col_ptr = _masked_col_ptr(col_ptr, adj_ptr, adj, pb, rank)
     plan = G.HaloPlan(col_ptr, adj_ptr, adj, pb, rank)
     params = M.viewsel.MrfParams(6, 6, 3, 0.0, 0.0, 1.0, 3)
     solver = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch, params), plan, params, "cpu", dist)
@@ -211,6 +224,28 @@ def test_gloo_world2_equals_single_rank(tmp_path):
         assert st == [ref_stats["energy_fixed"], ref_stats["cut_edges"], ref_stats["sweeps"], ref_stats["icm_iters"]]
 
 
+def test_gloo_world2_with_sharded_tables_equals_single_rank(tmp_path):
+    """as above, but every rank only holds the columns of its own faces and of their halo (the table sharded_data_costs
+    builds): message layouts differ between the ranks, the exchange lists still pair up element for element"""
+    import torch
+    import torch.multiprocessing as mp
+    s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
+    plan1 = G.HaloPlan(col_ptr, adj_ptr, adj, G.equal_parts(len(faces), 1), 0)
+    params = M.viewsel.MrfParams(6, 6, 3, 0.0, 0.0, 1.0, 3)
+    ref_labels, ref_stats = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch, params), plan1, params, "cpu", None).run()
+    pb = G.equal_parts(len(faces), 2)
+    plans = [G.HaloPlan(_masked_col_ptr(col_ptr, adj_ptr, adj, pb, r), adj_ptr, adj, pb, r) for r in range(2)]
+    assert plans[0].total_words != G.HaloPlan(col_ptr, adj_ptr, adj, pb, 0).total_words          # really a smaller, different layout
+    assert len(plans[0].msg_send[1]) == len(plans[1].msg_recv[0]) and len(plans[1].msg_send[0]) == len(plans[0].msg_recv[1])
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_run_rank, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(2)])
+    assert np.array_equal(got, ref_labels)
+    for r in range(2):
+        st = np.load(tmp_path / ("stats_%d.npy" % r)).tolist()
+        assert st == [ref_stats["energy_fixed"], ref_stats["cut_edges"], ref_stats["sweeps"], ref_stats["icm_iters"]]
+
+
 def test_stop_rule_is_the_library_rule():
     """same decision as api.hip: (prev - best) < min_improvement * prev over `window` sweeps"""
     p = M.viewsel.MrfParams(200, 3, 2, 0.01, 0.3, 0.8, 0)
@@ -224,3 +259,23 @@ def test_message_base_matches_the_header():
     from conftest import ROOT
     h = open(os.path.join(ROOT, "include", "mvs_viewsel.h")).read()
     assert int(re.search(r"#define MVS_MRF_MSG_BASE (\d+)u", h).group(1)) == G.MSG_BASE
+
+
+def test_boundary_faces_are_symmetric_and_cover_all_cut_neighbours():
+    """halo columns of the sharded cost table: what rank a sends to rank b is what b expects from a, and the halo of a
+    part is exactly the set of non-own neighbours of its faces"""
+    s = get_scene("bumpy")
+    perm = G.morton_order(s.verts, s.faces)
+    faces, normals, adj_ptr, adj, inv = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)
+    for P in (2, 3, 5):
+        part = G.equal_parts(len(faces), P)
+        b = [G.boundary_faces(adj_ptr, adj, part, r) for r in range(P)]
+        for a in range(P):
+            lo, hi = int(part[a]), int(part[a + 1])
+            nbrs = np.unique(adj[adj_ptr[lo]:adj_ptr[hi]].astype(np.int64))
+            halo = nbrs[(nbrs < lo) | (nbrs >= hi)]
+            assert np.array_equal(np.sort(np.concatenate(b[a][1])), halo)
+            for c in range(P):
+                assert np.array_equal(b[a][0][c], b[c][1][a])
+                if a != c and len(b[a][0][c]):
+                    assert b[a][0][c].min() >= lo and b[a][0][c].max() < hi
