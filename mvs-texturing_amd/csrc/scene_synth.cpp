@@ -326,7 +326,8 @@ void synth_render(const synth_camera* cam, uint32_t view_index, uint32_t seed, i
     const V3 r1 = {cam->w2c[4], cam->w2c[5], cam->w2c[6]};
     const V3 r2 = {cam->w2c[8], cam->w2c[9], cam->w2c[10]};
     const float oo = dot(o, o) - 1.0f;
-#pragma omp parallel for schedule(static)
+    // small images are rendered serially: waking a team of hundreds of threads per call costs far more than the pixels
+#pragma omp parallel for schedule(static) if ((size_t)w * (size_t)h >= 262144)
     for (int y = 0; y < h; ++y) {
         for (int x = 0; x < w; ++x) {
             uint8_t* px = rgb + ((size_t)y * w + x) * 3;
