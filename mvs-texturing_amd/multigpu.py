@@ -451,6 +451,8 @@ def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, dev
     ctx.synchronize()
     counts, vid, cost = counts[:nf], vid[:nnz], cost[:nnz]
     if dist is not None and P > 1:
+        if boundary is None:
+            raise ValueError("sharded_data_costs over several ranks needs boundary = boundary_faces(adj_ptr, adj, part_begin, me)")
         # (1) column lengths of every face: parts are equal up to one face, so one padded all-gather
         sizes = [int(part_begin[p + 1] - part_begin[p]) for p in range(P)]
         pad = torch.zeros(max(sizes), dtype=torch.int32, device=device); pad[:nf] = counts
