@@ -1,7 +1,10 @@
 // CPU ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle.h header comment).
 //
-// PARITY UNPINNED: the reference has no tests/fixtures and cannot be built
-// here.  Every function cites the reference lines it
+// PARITY UNPINNED for the rows whose arithmetic lives in MVE / rayint / Eigen / mapMAP: the reference has no
+// tests/fixtures and its hot path cannot be built here.  PINNED against the reference's own
+// code where its sources are self-contained -- Histogram percentile (row D2), SparseTable / .spt (row E), UniGraph
+// lists and get_subgraphs (rows G, f3), Settings defaults: oracle/_ref (Makefile target `ref`) compiles those sources
+// from /root/reference and tests/test_reference_pins.py compares.  Every function cites the reference lines it
 // restates.  Compile with -O2 -ffp-contract=off -fno-fast-math so that the
 // float operation order written here is the order executed.
 //

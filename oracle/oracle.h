@@ -8,9 +8,11 @@
  * library, and only as the CHECKER.  The product (mvs-texturing_amd/) never
  * links, imports or calls anything in oracle/.
  *
- * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
- *  and its hot path cannot be compiled here because MVE,
- * rayint, Eigen and mapMAP are un-vendored downloads (elibs/CMakeLists.txt:1-42).
+ * PARITY UNPINNED wherever the arithmetic lives in MVE, rayint, Eigen or mapMAP: the reference ships no tests,
+ * fixtures or golden vectors and its hot path cannot be compiled here because those are
+ * un-vendored downloads (elibs/CMakeLists.txt:1-42).  The self-contained reference sources (Histogram, SparseTable,
+ * UniGraph, Settings) ARE compiled from /root/reference into oracle/_ref and pin the corresponding restatements
+ * (tests/test_reference_pins.py).
  * Where the arithmetic lives in those absent dependencies this file DEFINES the
  * semantics (marked "DEFINED HERE" below) -- see DESIGN.md section "Oracle".
  */

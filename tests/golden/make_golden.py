@@ -5,7 +5,8 @@ The reference ships no tests, fixtures or golden vectors and cannot be built
 here, so these files are the pins this repository creates for
 itself: they freeze the oracle's outputs on seeded synthetic scenes so that
 (a) the oracle cannot drift silently and (b) the GPU path can be checked on
-the GPU box without re-deriving anything.  PARITY vs upstream stays UNPINNED.
+the GPU box without re-deriving anything.  PARITY vs upstream stays UNPINNED for everything that depends on the absent
+libraries; the self-contained reference pieces are pinned separately (tests/test_reference_pins.py).
 """
 import hashlib
 import os
