@@ -2,7 +2,7 @@
 //
 // PARITY UNPINNED for the rows whose arithmetic lives in MVE / rayint / Eigen / mapMAP: the reference has no
 // tests/fixtures and its hot path cannot be built here.  PINNED against the reference's own
-// code where its sources are self-contained -- Histogram percentile (row D2), SparseTable / .spt (row E), UniGraph
+// code where its sources are self-contained -- Tri (row C), Histogram percentile (row D2), SparseTable / .spt (row E), UniGraph
 // lists and get_subgraphs (rows G, f3), Settings defaults: oracle/_ref (Makefile target `ref`) compiles those sources
 // from /root/reference and tests/test_reference_pins.py compares.  Every function cites the reference lines it
 // restates.  Compile with -O2 -ffp-contract=off -fno-fast-math so that the
@@ -110,21 +110,41 @@ struct FaceInfo {  // FaceProjectionInfo (texture_view.h:26-34)
     float mean_color[3];
 };
 
+// Tri (tri.cpp:12-24, tri.h:58-84) -- pinned against the reference's own tri.{h,cpp} through oracle/_ref
+// (tests/test_reference_pins.py): constructor (detT, aabb from the unsorted points), get_area, inside.
+struct TriR { float detT, min_x, min_y, max_x, max_y; };
+inline TriR tri_make(V2 t1, V2 t2, V2 t3) {
+    TriR r;
+    const float T0 = t1.x - t3.x, T1 = t2.x - t3.x, T2 = t1.y - t3.y, T3 = t2.y - t3.y;
+    r.detT = T0 * T3 - T2 * T1;
+    r.min_x = std::min(t1.x, std::min(t2.x, t3.x)); r.min_y = std::min(t1.y, std::min(t2.y, t3.y));
+    r.max_x = std::max(t1.x, std::max(t2.x, t3.x)); r.max_y = std::max(t1.y, std::max(t2.y, t3.y));
+    return r;
+}
+inline float tri_area(V2 t1, V2 t2, V2 t3) {
+    const float ux = t2.x - t1.x, uy = t2.y - t1.y, vx = t3.x - t1.x, vy = t3.y - t1.y;
+    return 0.5f * std::abs(ux * vy - uy * vx);
+}
+inline bool tri_inside(V2 t1, V2 t2, V2 t3, float detT, float x, float y) {
+    float const dx = (x - t3.x), dy = (y - t3.y);
+    float const alpha = ((t2.y - t3.y) * dx + (t3.x - t2.x) * dy) / detT;
+    if (alpha < 0.0f || alpha > 1.0f) return false;
+    float const beta = ((t3.y - t1.y) * dx + (t1.x - t3.x) * dy) / detT;
+    if (beta < 0.0f || beta > 1.0f) return false;
+    if (alpha + beta > 1.0f) return false;
+    return true;
+}
+
 // TextureView::get_face_info  (texture_view.cpp:134-251) with Tri (tri.cpp:12-24, tri.h:58-84)
 void get_face_info(const orc_view& view, const uint8_t* gmi_img, V3 v1, V3 v2, V3 v3,
                    const orc_settings& st, FaceInfo* info) {
     V2 p1 = pixel_coords(view, v1), p2 = pixel_coords(view, v2), p3 = pixel_coords(view, v3);
-    // Tri ctor (tri.cpp:12-24): detT and aabb from the UNSORTED points
+    // Tri ctor (tri.cpp:12-24): detT and aabb from the UNSORTED points; Tri::get_area (tri.h:79-84)
     const V2 t1 = p1, t2 = p2, t3 = p3;
-    const float T0 = t1.x - t3.x, T1 = t2.x - t3.x, T2 = t1.y - t3.y, T3 = t2.y - t3.y;
-    const float detT = T0 * T3 - T2 * T1;
-    const float aabb_min_x = std::min(t1.x, std::min(t2.x, t3.x));
-    const float aabb_min_y = std::min(t1.y, std::min(t2.y, t3.y));
-    const float aabb_max_x = std::max(t1.x, std::max(t2.x, t3.x));
-    const float aabb_max_y = std::max(t1.y, std::max(t2.y, t3.y));
-    // Tri::get_area (tri.h:79-84)
-    const float ux = t2.x - t1.x, uy = t2.y - t1.y, vx = t3.x - t1.x, vy = t3.y - t1.y;
-    const float area = 0.5f * std::abs(ux * vy - uy * vx);
+    const TriR tri = tri_make(t1, t2, t3);
+    const float detT = tri.detT;
+    const float aabb_min_x = tri.min_x, aabb_min_y = tri.min_y, aabb_max_x = tri.max_x, aabb_max_y = tri.max_y;
+    const float area = tri_area(t1, t2, t3);
 
     if (area < std::numeric_limits<float>::epsilon()) { info->quality = 0.0f; return; }
 
@@ -166,13 +186,7 @@ void get_face_info(const orc_view& view, const uint8_t* gmi_img, V3 v1, V3 v2, V
                 const float cx = static_cast<float>(x) + 0.5f;
                 const float cy = static_cast<float>(y) + 0.5f;
                 if (!fast_sampling_possible) {
-                    /* Tri::inside (tri.h:58-77) */
-                    float const dx = (cx - t3.x), dy = (cy - t3.y);
-                    float const alpha = ((t2.y - t3.y) * dx + (t3.x - t2.x) * dy) / detT;
-                    if (alpha < 0.0f || alpha > 1.0f) continue;
-                    float const beta = ((t3.y - t1.y) * dx + (t1.x - t3.x) * dy) / detT;
-                    if (beta < 0.0f || beta > 1.0f) continue;
-                    if (alpha + beta > 1.0f) continue;
+                    if (!tri_inside(t1, t2, t3, detT, cx, cy)) continue;   /* Tri::inside (tri.h:58-77) */
                 }
                 if (st.outlier_removal != 0) {
                     for (int i = 0; i < 3; i++)
@@ -958,6 +972,13 @@ uint32_t mrf_icm_iter(const Mrf& g, std::vector<uint32_t>& sel, std::vector<floa
 
 extern "C" {
 
+// Tri as get_face_info uses it: out = {area, aabb min_x, min_y, max_x, max_y}; inside[k] for the n query points
+void orc_tri(const float p[6], float out[5], const float* xy, uint32_t n, uint8_t* inside) {
+    const V2 t1 = {p[0], p[1]}, t2 = {p[2], p[3]}, t3 = {p[4], p[5]};
+    const TriR r = tri_make(t1, t2, t3);
+    out[0] = tri_area(t1, t2, t3); out[1] = r.min_x; out[2] = r.min_y; out[3] = r.max_x; out[4] = r.max_y;
+    for (uint32_t k = 0; k < n; ++k) inside[k] = tri_inside(t1, t2, t3, r.detT, xy[2 * k], xy[2 * k + 1]) ? 1 : 0;
+}
 uint32_t orc_msg_code(float v, float rho) { return msg_code(v, msg_q(1.0f / rho)); }
 float orc_msg_store(float v, float rho) { return msg_store(v, msg_q(1.0f / rho)); }
 void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = len; }

@@ -10,7 +10,7 @@
  *
  * PARITY UNPINNED wherever the arithmetic lives in MVE, rayint, Eigen or mapMAP: the reference ships no tests,
  * fixtures or golden vectors and its hot path cannot be compiled here because those are
- * un-vendored downloads (elibs/CMakeLists.txt:1-42).  The self-contained reference sources (Histogram, SparseTable,
+ * un-vendored downloads (elibs/CMakeLists.txt:1-42).  The self-contained reference sources (Tri, Histogram, SparseTable,
  * UniGraph, Settings) ARE compiled from /root/reference into oracle/_ref and pin the corresponding restatements
  * (tests/test_reference_pins.py).
  * Where the arithmetic lives in those absent dependencies this file DEFINES the
@@ -123,6 +123,8 @@ typedef struct {
 void orc_mrf_default_params(orc_mrf_params* p);
 /* the solver stores messages as 8-bit fixed point over [0, 1/rho]: code = trunc(v * (255 rho') + 0.5), value = code / (255 rho')
  * with rho' = 1 / (1 / rho) evaluated in fp32 exactly as oracle.cpp does (tested against a numpy restatement) */
+/* Tri (tri.cpp:12-24, tri.h:58-84) as get_face_info uses it: out = {area, aabb min_x, min_y, max_x, max_y}; inside[k] = Tri::inside(xy[2k], xy[2k+1]) */
+void orc_tri(const float p[6], float out[5], const float* xy, uint32_t n, uint8_t* inside);
 uint32_t orc_msg_code(float v, float rho);
 float orc_msg_store(float v, float rho);
 /* experiments: per-sweep energies of the decoded labeling are written to buf[0..len) */

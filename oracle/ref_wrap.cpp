@@ -1,8 +1,8 @@
 // oracle/_ref -- the REFERENCE's own code for the pieces of the path that compile without MVE / rayint / Eigen /
 // mapMAP: Histogram (libs/tex/histogram.{h,cpp}), UniGraph (libs/tex/uni_graph.{h,cpp}), SparseTable
-// (libs/tex/sparse_table.h) and the Settings defaults (libs/tex/settings.h).  Their sources are compiled where they lie
+// (libs/tex/sparse_table.h), Tri (libs/tex/tri.{h,cpp}, rect.h) and the Settings defaults (libs/tex/settings.h).  Their sources are compiled where they lie
 // under /root/reference (oracle/Makefile, target `ref`); this file only adds extern "C" entry points so that the tests
-// can pin the oracle's restatements of SURVEY.md rows D2, E, G / f3 and the defaults against the real thing.
+// can pin the oracle's restatements of SURVEY.md rows C (Tri), D2, E, G / f3 and the defaults against the real thing.
 // TEST INFRASTRUCTURE ONLY (never loaded by the product).
 #include <cstdint>
 #include <cstring>
@@ -13,6 +13,7 @@
 #include "histogram.h"
 #include "uni_graph.h"
 #include "sparse_table.h"
+#include "tri.h"
 
 typedef SparseTable<std::uint32_t, std::uint16_t, float> RefDataCosts;   // == tex::DataCosts (libs/tex/texturing.h:36)
 
@@ -68,6 +69,14 @@ std::uint32_t ref_get_subgraphs(std::uint32_t F, const std::uint32_t* adj_ptr, c
     }
     comp_ptr[sub.size()] = n;
     return (std::uint32_t)sub.size();
+}
+
+// Tri (tri.{h,cpp}): out = {get_area, aabb min_x, min_y, max_x, max_y}; inside[k] = Tri::inside(xy[2k], xy[2k+1])
+void ref_tri(const float p[6], float out[5], const float* xy, std::uint32_t n, std::uint8_t* inside) {
+    const Tri tri(math::Vec2f(p[0], p[1]), math::Vec2f(p[2], p[3]), math::Vec2f(p[4], p[5]));
+    const Rect<float> bb = tri.get_aabb();
+    out[0] = tri.get_area(); out[1] = bb.min_x; out[2] = bb.min_y; out[3] = bb.max_x; out[4] = bb.max_y;
+    for (std::uint32_t k = 0; k < n; ++k) inside[k] = tri.inside(xy[2 * k], xy[2 * k + 1]) ? 1 : 0;
 }
 
 // SparseTable::save_to_file / load_from_file (sparse_table.h:112-187) on a table filled by set_value in CSR order

@@ -1,6 +1,6 @@
 """Pins against the REFERENCE'S OWN CODE (oracle/_ref/libtexref.so): the pieces of the path whose sources compile
-without MVE / rayint / Eigen / mapMAP -- Histogram (row D2), SparseTable and its .spt format (row E), UniGraph and
-get_subgraphs (rows G / f3), the Settings defaults -- are compiled from /root/reference where they lie
+without MVE / rayint / Eigen / mapMAP -- Tri (row C), Histogram (row D2), SparseTable and its .spt format (row E),
+UniGraph and get_subgraphs (rows G / f3), the Settings defaults -- are compiled from /root/reference where they lie
 (oracle/Makefile target `ref`, wrappers in oracle/ref_wrap.cpp) and compared with the oracle's restatements and with
 the product's host-side file writers.  The GPU parity tests compare the HIP path with the oracle, so these rows are
 pinned to upstream transitively.  The library is built in the development container (the reference is mounted there)
@@ -32,6 +32,7 @@ def R():
     L.ref_settings_defaults.argtypes = [vp]
     L.ref_unigraph_lists.argtypes = [u32, vp, vp, vp, vp]; L.ref_unigraph_lists.restype = u64
     L.ref_get_subgraphs.argtypes = [u32, vp, vp, vp, u32, vp, vp]; L.ref_get_subgraphs.restype = u32
+    L.ref_tri.argtypes = [vp, vp, vp, u32, vp]
     L.ref_spt_write.argtypes = [C.c_char_p, u32, C.c_uint16, vp, vp, vp]; L.ref_spt_write.restype = C.c_int
     L.ref_spt_read.argtypes = [C.c_char_p, u32, C.c_uint16, vp, vp, vp, u64]; L.ref_spt_read.restype = C.c_int64
     return L
@@ -127,3 +128,37 @@ def test_spt_files_are_the_reference_format(R, tmp_path):
     assert R.ref_spt_read(ours.encode(), 300, 40, _p(cp), _p(vi), _p(co), len(cost)) == len(cost)
     assert np.array_equal(cp, col_ptr) and np.array_equal(vi, view_id) and np.array_equal(co.view(np.uint32), cost.view(np.uint32))
     assert R.ref_spt_read(ours.encode(), 299, 40, _p(cp), _p(vi), _p(co), len(cost)) == -1      # "SparseTable has different dimension!"
+
+
+def test_tri_equals_the_reference_class(R):
+    """row C: Tri's constructor (aabb), get_area and inside (tri.cpp:12-24, tri.h:58-84) as TextureView::get_face_info uses
+    them -- the oracle's restatement against the reference's own class, bit for bit, on projected-footprint-like
+    triangles: sub-pixel, large, needle-shaped, degenerate (zero area: inside() divides by detT = 0), negative coordinates"""
+    OL = O.load()
+    OL.orc_tri.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(3)
+    tris = []
+    for scale in (0.3, 3.0, 40.0, 900.0):
+        base = rng.random((200, 1, 2)).astype(np.float32) * 1500.0
+        tris.append((base + (rng.random((200, 3, 2)).astype(np.float32) - 0.5) * scale).reshape(200, 6))
+    t = rng.random((50, 3, 2)).astype(np.float32) * 100.0
+    t[:, 2] = t[:, 0] + (t[:, 1] - t[:, 0]) * 2.0          # collinear
+    tris.append(t.reshape(50, 6))
+    t = rng.random((20, 3, 2)).astype(np.float32); t[:, 1] = t[:, 0]; tris.append(t.reshape(20, 6))   # repeated vertex
+    tris.append((rng.random((50, 6)).astype(np.float32) - 0.5) * 20.0)                                  # around the origin
+    tris = np.ascontiguousarray(np.concatenate(tris), dtype=np.float32)
+    n_in = 0
+    for p in tris:
+        lo, hi = p.reshape(3, 2).min(0), p.reshape(3, 2).max(0)
+        xy = (lo - 1.0 + rng.random((64, 2)) * (hi - lo + 2.0)).astype(np.float32)
+        xy[:3] = p.reshape(3, 2)                              # the vertices themselves
+        xy[3] = p.reshape(3, 2).mean(0)
+        xy = np.ascontiguousarray(np.floor(xy * 2.0) / 2.0 + np.float32(0.5) * (rng.random((64, 2)) < 0.5), dtype=np.float32)   # pixel-centre like
+        a, b = np.zeros(5, np.float32), np.zeros(5, np.float32)
+        ia, ib = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+        OL.orc_tri(_p(p), _p(a), _p(xy), 64, _p(ia))
+        R.ref_tri(_p(p), _p(b), _p(xy), 64, _p(ib))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (p, a, b)
+        assert np.array_equal(ia, ib), (p, xy[ia != ib])
+        n_in += int(ia.sum())
+    assert n_in > 500                                          # the comparison saw plenty of inside points
