@@ -2,7 +2,8 @@
 //
 // PARITY UNPINNED for the rows whose arithmetic lives in MVE / rayint / Eigen / mapMAP: the reference has no
 // tests/fixtures and its hot path cannot be built here.  PINNED against the reference's own
-// code where its sources are self-contained -- Tri (row C), Histogram percentile (row D2), SparseTable / .spt (row E), UniGraph
+// code where its sources compile without those libraries -- TextureView's masks, valid_pixel and get_face_info (rows B2, B3, C),
+// Tri (row C), Histogram percentile (row D2), SparseTable / .spt (row E), UniGraph
 // lists and get_subgraphs (rows G, f3), Settings defaults: oracle/_ref (Makefile target `ref`) compiles those sources
 // from /root/reference and tests/test_reference_pins.py compares.  Every function cites the reference lines it
 // restates.  Compile with -O2 -ffp-contract=off -fno-fast-math so that the
@@ -972,6 +973,35 @@ uint32_t mrf_icm_iter(const Mrf& g, std::vector<uint32_t>& sel, std::vector<floa
 
 extern "C" {
 
+// For the pins against the reference's own texture_view.cpp (oracle/_ref, tests/test_reference_pins.py): an IDENTITY
+// camera (projection = I, world_to_cam = I) maps the vertex (x + 0.5, y + 0.5, 1) to the pixel coordinates (x, y) exactly
+// in any accumulation order, so the mask / valid_pixel / get_face_info logic can be compared on chosen 2D inputs.
+static orc_view identity_view(const uint8_t* rgb, int w, int h) {
+    orc_view v; memset(&v, 0, sizeof(v));
+    v.K[0] = v.K[4] = v.K[8] = 1.0f; v.w2c[0] = v.w2c[5] = v.w2c[10] = v.w2c[15] = 1.0f; v.viewdir[2] = 1.0f;
+    v.width = w; v.height = h; v.rgb = rgb;
+    return v;
+}
+// out[k] = TextureView::valid_pixel(xy[k]) after generate_validity_mask() (+ erode_validity_mask() if erode)
+void orc_valid_pixel_map(const uint8_t* rgb, int w, int h, int erode, const float* xy, uint32_t n, uint8_t* out) {
+    std::vector<uint8_t> mask((size_t)w * h);
+    orc_validity_mask(rgb, w, h, mask.data());
+    if (erode) orc_erode_validity_mask(mask.data(), w, h);
+    const orc_view v = identity_view(rgb, w, h);
+    for (uint32_t k = 0; k < n; ++k) out[k] = valid_pixel(v, mask.data(), V2{xy[2 * k], xy[2 * k + 1]}) ? 1 : 0;
+}
+// TextureView::get_face_info of n triangles given by 3D vertices (9 floats each) under the identity camera
+void orc_face_info(const uint8_t* rgb, const uint8_t* gmi, int w, int h, int data_term, int outlier, const float* verts, uint32_t n,
+                   float* quality, float* color) {
+    const orc_view v = identity_view(rgb, w, h);
+    orc_settings st; st.data_term = data_term; st.outlier_removal = outlier; st.geometric_visibility_test = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        FaceInfo fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
+        const float* p = verts + 9 * (size_t)k;
+        get_face_info(v, gmi, V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, V3{p[6], p[7], p[8]}, st, &fi);
+        quality[k] = fi.quality; for (int i = 0; i < 3; ++i) color[3 * k + i] = fi.mean_color[i];
+    }
+}
 // Tri as get_face_info uses it: out = {area, aabb min_x, min_y, max_x, max_y}; inside[k] for the n query points
 void orc_tri(const float p[6], float out[5], const float* xy, uint32_t n, uint8_t* inside) {
     const V2 t1 = {p[0], p[1]}, t2 = {p[2], p[3]}, t3 = {p[4], p[5]};

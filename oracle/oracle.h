@@ -10,7 +10,7 @@
  *
  * PARITY UNPINNED wherever the arithmetic lives in MVE, rayint, Eigen or mapMAP: the reference ships no tests,
  * fixtures or golden vectors and its hot path cannot be compiled here because those are
- * un-vendored downloads (elibs/CMakeLists.txt:1-42).  The self-contained reference sources (Tri, Histogram, SparseTable,
+ * un-vendored downloads (elibs/CMakeLists.txt:1-42).  The reference sources that compile without those libraries (TextureView's masks / valid_pixel / get_face_info, Tri, Histogram, SparseTable,
  * UniGraph, Settings) ARE compiled from /root/reference into oracle/_ref and pin the corresponding restatements
  * (tests/test_reference_pins.py).
  * Where the arithmetic lives in those absent dependencies this file DEFINES the
@@ -123,6 +123,12 @@ typedef struct {
 void orc_mrf_default_params(orc_mrf_params* p);
 /* the solver stores messages as 8-bit fixed point over [0, 1/rho]: code = trunc(v * (255 rho') + 0.5), value = code / (255 rho')
  * with rho' = 1 / (1 / rho) evaluated in fp32 exactly as oracle.cpp does (tested against a numpy restatement) */
+/* entry points for the pins against the reference's own texture_view.cpp (identity camera: the vertex (x + 0.5, y + 0.5, 1)
+ * projects to the pixel coordinates (x, y) exactly): valid_pixel after generate_validity_mask (+ erode_validity_mask),
+ * and get_face_info (texture_view.cpp:42-132, 134-251, 253-281) */
+void orc_valid_pixel_map(const uint8_t* rgb, int w, int h, int erode, const float* xy, uint32_t n, uint8_t* out);
+void orc_face_info(const uint8_t* rgb, const uint8_t* gmi, int w, int h, int data_term, int outlier, const float* verts, uint32_t n,
+                   float* quality, float* color);
 /* Tri (tri.cpp:12-24, tri.h:58-84) as get_face_info uses it: out = {area, aabb min_x, min_y, max_x, max_y}; inside[k] = Tri::inside(xy[2k], xy[2k+1]) */
 void orc_tri(const float p[6], float out[5], const float* xy, uint32_t n, uint8_t* inside);
 uint32_t orc_msg_code(float v, float rho);

@@ -1,25 +1,41 @@
-// Stand-in for MVE's math/vector.h, just enough for the reference's tri.{h,cpp} to compile UNCHANGED for oracle/_ref:
-// element storage, element access, construction from components and the component-wise difference.  None of these
-// involves an operation order, so nothing about the reference's arithmetic is decided here (the inner products etc.
-// of the real library are NOT provided: sources that need them stay unbuildable).  Test infrastructure only.
+// Stand-in for MVE's math/vector.h, just enough for the reference's tri.{h,cpp} and texture_view.{h,cpp} to compile
+// UNCHANGED for oracle/_ref: element storage and access, construction, conversion, and COMPONENT-WISE operators.
+// A component-wise operator has no operation order to decide, with one exception that is a convention of the absent
+// library and therefore an assumption here (the same one the oracle makes): `vector / scalar` divides every component
+// (it does not multiply by a reciprocal).  It only reaches FaceProjectionInfo::mean_color (outlier-removal modes);
+// qualities do not pass through it.  Inner products etc. are NOT provided.  Test infrastructure only.
 #ifndef MVS_REF_STUB_MATH_VECTOR_H
 #define MVS_REF_STUB_MATH_VECTOR_H
-#include <algorithm>   // the real header pulls these in; tri.{h,cpp} rely on std::min / std::max / std::abs through it
+#include <algorithm>   // the real header pulls these in; tri.{h,cpp} / texture_view.cpp rely on std::min / std::max / std::abs / std::swap through it
 #include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <limits>
 namespace math {
 template <typename T, int N>
 class Vector {
 public:
     Vector() { for (int i = 0; i < N; ++i) v[i] = T(0); }
-    Vector(T a, T b) { static_assert(N == 2, "2 components"); v[0] = a; v[1] = b; }
-    Vector(T a, T b, T c) { static_assert(N == 3, "3 components"); v[0] = a; v[1] = b; v[2] = c; }
+    explicit Vector(T const& a) { for (int i = 0; i < N; ++i) v[i] = a; }
+    Vector(T const& a, T const& b) { static_assert(N == 2, "2 components"); v[0] = a; v[1] = b; }
+    Vector(T const& a, T const& b, T const& c) { static_assert(N == 3, "3 components"); v[0] = a; v[1] = b; v[2] = c; }
+    template <typename U> Vector(Vector<U, N> const& o) { for (int i = 0; i < N; ++i) v[i] = T(o[i]); }
     T& operator[](int i) { return v[i]; }
     T const& operator[](int i) const { return v[i]; }
+    T* operator*() { return v; }
+    T const* operator*() const { return v; }
     Vector operator-(Vector const& o) const { Vector r; for (int i = 0; i < N; ++i) r.v[i] = v[i] - o.v[i]; return r; }
+    Vector operator+(Vector const& o) const { Vector r; for (int i = 0; i < N; ++i) r.v[i] = v[i] + o.v[i]; return r; }
+    Vector& operator+=(Vector const& o) { for (int i = 0; i < N; ++i) v[i] += o.v[i]; return *this; }
+    Vector operator/(T const& s) const { Vector r; for (int i = 0; i < N; ++i) r.v[i] = v[i] / s; return r; }
+    Vector& operator/=(T const& s) { for (int i = 0; i < N; ++i) v[i] /= s; return *this; }
 private:
     T v[N];
 };
 typedef Vector<float, 2> Vec2f;
 typedef Vector<float, 3> Vec3f;
+typedef Vector<double, 3> Vec3d;
+typedef Vector<int, 2> Vec2i;
+typedef Vector<unsigned char, 3> Vec3uc;
 }  // namespace math
 #endif

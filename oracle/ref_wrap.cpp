@@ -1,6 +1,7 @@
 // oracle/_ref -- the REFERENCE's own code for the pieces of the path that compile without MVE / rayint / Eigen /
 // mapMAP: Histogram (libs/tex/histogram.{h,cpp}), UniGraph (libs/tex/uni_graph.{h,cpp}), SparseTable
-// (libs/tex/sparse_table.h), Tri (libs/tex/tri.{h,cpp}, rect.h) and the Settings defaults (libs/tex/settings.h).  Their sources are compiled where they lie
+// (libs/tex/sparse_table.h), Tri (libs/tex/tri.{h,cpp}, rect.h), TextureView's mask / valid_pixel / get_face_info logic
+// (libs/tex/texture_view.{h,cpp}) and the Settings defaults (libs/tex/settings.h).  Their sources are compiled where they lie
 // under /root/reference (oracle/Makefile, target `ref`); this file only adds extern "C" entry points so that the tests
 // can pin the oracle's restatements of SURVEY.md rows C (Tri), D2, E, G / f3 and the defaults against the real thing.
 // TEST INFRASTRUCTURE ONLY (never loaded by the product).
@@ -14,6 +15,9 @@
 #include "uni_graph.h"
 #include "sparse_table.h"
 #include "tri.h"
+#include "texture_view.h"
+#include <mve/image_tools.h>
+#include <cstdio>
 
 typedef SparseTable<std::uint32_t, std::uint16_t, float> RefDataCosts;   // == tex::DataCosts (libs/tex/texturing.h:36)
 
@@ -77,6 +81,41 @@ void ref_tri(const float p[6], float out[5], const float* xy, std::uint32_t n, s
     const Rect<float> bb = tri.get_aabb();
     out[0] = tri.get_area(); out[1] = bb.min_x; out[2] = bb.min_y; out[3] = bb.max_x; out[4] = bb.max_y;
     for (std::uint32_t k = 0; k < n; ++k) inside[k] = tri.inside(xy[2 * k], xy[2 * k + 1]) ? 1 : 0;
+}
+
+// ---- TextureView (texture_view.{h,cpp}) under an identity camera, image attached with bind_image ----
+static tex::TextureView make_view(const std::uint8_t* rgb, int w, int h) {
+    char name[64]; std::snprintf(name, sizeof(name), "%dx%d", w, h);
+    tex::TextureView tv(0, mve::CameraInfo(), name);
+    mve::ByteImage::Ptr img = mve::ByteImage::create(w, h, 3);
+    std::memcpy(img->get_data_pointer(), rgb, (std::size_t)w * h * 3);
+    tv.bind_image(img);
+    return tv;
+}
+// out[k] = valid_pixel(xy[k]) after generate_validity_mask() (+ erode_validity_mask() if erode)   (texture_view.cpp:42-94,109-132,253-281)
+void ref_valid_pixel_map(const std::uint8_t* rgb, int w, int h, int erode, const float* xy, std::uint32_t n, std::uint8_t* out) {
+    tex::TextureView tv = make_view(rgb, w, h);
+    tv.generate_validity_mask();
+    if (erode) tv.erode_validity_mask();
+    for (std::uint32_t k = 0; k < n; ++k) out[k] = tv.valid_pixel(math::Vec2f(xy[2 * k], xy[2 * k + 1])) ? 1 : 0;
+}
+// get_face_info (texture_view.cpp:134-251) of n triangles given by 3D vertices (9 floats each); gmi = the gradient
+// magnitude image generate_gradient_magnitude() is to install (the Sobel arithmetic itself is MVE's and not pinned)
+void ref_face_info(const std::uint8_t* rgb, const std::uint8_t* gmi, int w, int h, int data_term, int outlier, const float* verts, std::uint32_t n,
+                   float* quality, float* color) {
+    tex::TextureView tv = make_view(rgb, w, h);
+    mve::ByteImage::Ptr g = mve::ByteImage::create(w, h, 1);
+    std::memcpy(g->get_data_pointer(), gmi, (std::size_t)w * h);
+    mve::image::next_gradient_magnitude() = g;
+    tv.generate_gradient_magnitude();
+    tex::Settings st;
+    st.data_term = (tex::DataTerm)data_term; st.outlier_removal = (tex::OutlierRemoval)outlier;
+    for (std::uint32_t k = 0; k < n; ++k) {
+        const float* p = verts + 9 * (std::size_t)k;
+        tex::FaceProjectionInfo info; info.view_id = 0; info.quality = 0.0f; info.mean_color = math::Vec3f(0.0f);
+        tv.get_face_info(math::Vec3f(p[0], p[1], p[2]), math::Vec3f(p[3], p[4], p[5]), math::Vec3f(p[6], p[7], p[8]), &info, st);
+        quality[k] = info.quality; for (int i = 0; i < 3; ++i) color[3 * k + i] = info.mean_color[i];
+    }
 }
 
 // SparseTable::save_to_file / load_from_file (sparse_table.h:112-187) on a table filled by set_value in CSR order

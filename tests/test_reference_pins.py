@@ -1,5 +1,6 @@
 """Pins against the REFERENCE'S OWN CODE (oracle/_ref/libtexref.so): the pieces of the path whose sources compile
-without MVE / rayint / Eigen / mapMAP -- Tri (row C), Histogram (row D2), SparseTable and its .spt format (row E),
+without MVE / rayint / Eigen / mapMAP -- TextureView's validity mask, valid_pixel and get_face_info logic (rows B2, B3,
+C), Tri (row C), Histogram (row D2), SparseTable and its .spt format (row E),
 UniGraph and get_subgraphs (rows G / f3), the Settings defaults -- are compiled from /root/reference where they lie
 (oracle/Makefile target `ref`, wrappers in oracle/ref_wrap.cpp) and compared with the oracle's restatements and with
 the product's host-side file writers.  The GPU parity tests compare the HIP path with the oracle, so these rows are
@@ -33,6 +34,8 @@ def R():
     L.ref_unigraph_lists.argtypes = [u32, vp, vp, vp, vp]; L.ref_unigraph_lists.restype = u64
     L.ref_get_subgraphs.argtypes = [u32, vp, vp, vp, u32, vp, vp]; L.ref_get_subgraphs.restype = u32
     L.ref_tri.argtypes = [vp, vp, vp, u32, vp]
+    L.ref_valid_pixel_map.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u32, vp]
+    L.ref_face_info.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u32, vp, vp]
     L.ref_spt_write.argtypes = [C.c_char_p, u32, C.c_uint16, vp, vp, vp]; L.ref_spt_write.restype = C.c_int
     L.ref_spt_read.argtypes = [C.c_char_p, u32, C.c_uint16, vp, vp, vp, u64]; L.ref_spt_read.restype = C.c_int64
     return L
@@ -162,3 +165,79 @@ def test_tri_equals_the_reference_class(R):
         assert np.array_equal(ia, ib), (p, xy[ia != ib])
         n_in += int(ia.sum())
     assert n_in > 500                                          # the comparison saw plenty of inside points
+
+
+def _test_image(rng, w, h):
+    """noise image with black areas: a blob touching a corner (flood-filled), a border strip, an interior black island
+    (not reachable from a corner: stays valid) and isolated black pixels"""
+    img = (rng.integers(1, 255, (h, w, 3))).astype(np.uint8)
+    img[: h // 3, : w // 4] = 0
+    img[h // 5: h // 5 + 3, : w // 2] = 0                       # a thin arm growing out of the corner blob
+    img[h - 2:, :] = 0                                          # bottom strip (touches two corners)
+    img[h // 2: h // 2 + 6, w // 2: w // 2 + 9] = 0             # island
+    ys, xs = rng.integers(0, h, 40), rng.integers(0, w, 40)
+    img[ys, xs] = 0
+    img[0, w - 1] = (0, 0, 1)                                   # a corner that is NOT black (sum != 0)
+    return np.ascontiguousarray(img)
+
+
+def test_validity_mask_and_valid_pixel_equal_the_reference(R):
+    """rows B2 / B3: generate_validity_mask (corner flood fill, texture_view.cpp:42-94), erode_validity_mask (:109-132)
+    and valid_pixel (:253-281) -- the reference's own code against the oracle on every pixel position and on random
+    sub-pixel positions, with and without erosion"""
+    OL = O.load()
+    OL.orc_valid_pixel_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(21)
+    for (w, h) in ((97, 61), (64, 48), (33, 200)):
+        img = _test_image(rng, w, h)
+        gx, gy = np.meshgrid(np.arange(-1, w + 1), np.arange(-1, h + 1))
+        xy = np.concatenate([np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32),
+                             (rng.random((4000, 2)) * [w + 1, h + 1] - 1).astype(np.float32)])
+        xy = np.ascontiguousarray(xy, dtype=np.float32)
+        for erode in (0, 1):
+            a, b = np.zeros(len(xy), np.uint8), np.zeros(len(xy), np.uint8)
+            OL.orc_valid_pixel_map(_p(img), w, h, erode, _p(xy), len(xy), _p(a))
+            R.ref_valid_pixel_map(_p(img), w, h, erode, _p(xy), len(xy), _p(b))
+            assert np.array_equal(a, b), (w, h, erode, xy[a != b][:5])
+            assert 0 < a.sum() < len(a)
+        # erosion removes valid positions, the flood fill did invalidate the corner blob but not the island
+        assert a.sum() < b.size
+
+
+def test_get_face_info_equals_the_reference(R):
+    """row C: TextureView::get_face_info (texture_view.cpp:134-251) -- the reference's own rasteriser (y-sorted vertices,
+    edge equations, scan-line bounds, Tri::inside fallback, fp64 accumulation of gradient magnitude and colours in
+    scan order, area / gmi quality) against the oracle, bit for bit, on triangles from sub-pixel to hundreds of pixels,
+    needle-shaped, axis-aligned (infinite / zero slopes) and degenerate.  What the comparison canNOT vouch for is said
+    in oracle/ref_stubs: linear_at (used when a footprint has no sample) and vector / scalar (mean_color) are MVE's."""
+    OL = O.load()
+    OL.orc_face_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(33)
+    w, h = 160, 120
+    img = np.ascontiguousarray(rng.integers(1, 255, (h, w, 3)).astype(np.uint8))
+    gmi = np.ascontiguousarray(rng.integers(0, 256, (h, w)).astype(np.uint8))
+    tris = []
+    for scale in (0.4, 1.5, 4.0, 15.0, 60.0):
+        base = rng.random((300, 1, 2)) * [w - 2 - scale, h - 2 - scale] + 0.5
+        tris.append(base + rng.random((300, 3, 2)) * scale)
+    t = rng.random((100, 3, 2)) * 20 + 30; t[:, 1, 1] = t[:, 0, 1]; tris.append(t)          # horizontal edge (slope 0)
+    t = rng.random((100, 3, 2)) * 20 + 30; t[:, 1, 0] = t[:, 0, 0]; tris.append(t)          # vertical edge (infinite slope)
+    t = rng.random((60, 3, 2)) * 30 + 20; t[:, 2] = t[:, 0] + (t[:, 1] - t[:, 0]) * 0.5; tris.append(t)   # collinear
+    t = rng.random((60, 3, 2)) * 40 + 20; t[:, 2] = t[:, 0] + [0.125, 30.0]; t[:, 1] = t[:, 0] + [0.25, 15.0]; tris.append(t)   # needles
+    px = np.floor(np.concatenate(tris) * 8.0) / 8.0                                          # multiples of 1/8: (x + 0.5) - 0.5 is exact
+    px = np.clip(px, 0.0, [w - 1.125, h - 1.125])
+    verts = np.concatenate([px + 0.5, np.ones(px.shape[:2] + (1,))], axis=2).reshape(-1, 9)
+    verts = np.ascontiguousarray(verts, dtype=np.float32)
+    n = len(verts)
+    sampled = 0
+    for data_term, outlier in ((1, 0), (0, 0), (1, 2), (0, 1)):
+        qa, qb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        ca, cb = np.zeros(3 * n, np.float32), np.zeros(3 * n, np.float32)
+        OL.orc_face_info(_p(img), _p(gmi), w, h, data_term, outlier, _p(verts), n, _p(qa), _p(ca))
+        R.ref_face_info(_p(img), _p(gmi), w, h, data_term, outlier, _p(verts), n, _p(qb), _p(cb))
+        bad = np.nonzero(qa.view(np.uint32) != qb.view(np.uint32))[0]
+        assert len(bad) == 0, (data_term, outlier, bad[:5], qa[bad[:5]], qb[bad[:5]], px[bad[:5]])
+        assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32)), (data_term, outlier)
+        if data_term == 1:
+            sampled = int((qa > 0).sum())
+    assert sampled > 800 and (qa == 0).sum() > 50             # plenty of real footprints, and the degenerate ones give quality 0
