@@ -19,6 +19,7 @@ public:
     explicit Vector(T const& a) { for (int i = 0; i < N; ++i) v[i] = a; }
     Vector(T const& a, T const& b) { static_assert(N == 2, "2 components"); v[0] = a; v[1] = b; }
     Vector(T const& a, T const& b, T const& c) { static_assert(N == 3, "3 components"); v[0] = a; v[1] = b; v[2] = c; }
+    Vector(T const& a, T const& b, T const& c, T const& d) { static_assert(N == 4, "4 components"); v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
     template <typename U> Vector(Vector<U, N> const& o) { for (int i = 0; i < N; ++i) v[i] = T(o[i]); }
     T& operator[](int i) { return v[i]; }
     T const& operator[](int i) const { return v[i]; }
@@ -34,6 +35,7 @@ private:
 };
 typedef Vector<float, 2> Vec2f;
 typedef Vector<float, 3> Vec3f;
+typedef Vector<float, 4> Vec4f;
 typedef Vector<double, 3> Vec3d;
 typedef Vector<int, 2> Vec2i;
 typedef Vector<unsigned char, 3> Vec3uc;

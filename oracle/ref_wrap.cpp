@@ -1,7 +1,7 @@
 // oracle/_ref -- the REFERENCE's own code for the pieces of the path that compile without MVE / rayint / Eigen /
 // mapMAP: Histogram (libs/tex/histogram.{h,cpp}), UniGraph (libs/tex/uni_graph.{h,cpp}), SparseTable
 // (libs/tex/sparse_table.h), Tri (libs/tex/tri.{h,cpp}, rect.h), TextureView's mask / valid_pixel / get_face_info logic
-// (libs/tex/texture_view.{h,cpp}) and the Settings defaults (libs/tex/settings.h).  Their sources are compiled where they lie
+// (libs/tex/texture_view.{h,cpp}), the binary vector files of util.h and the Settings defaults (libs/tex/settings.h).  Their sources are compiled where they lie
 // under /root/reference (oracle/Makefile, target `ref`); this file only adds extern "C" entry points so that the tests
 // can pin the oracle's restatements of SURVEY.md rows C (Tri), D2, E, G / f3 and the defaults against the real thing.
 // TEST INFRASTRUCTURE ONLY (never loaded by the product).
@@ -16,6 +16,7 @@
 #include "sparse_table.h"
 #include "tri.h"
 #include "texture_view.h"
+#include "util.h"
 #include <mve/image_tools.h>
 #include <cstdio>
 
@@ -142,6 +143,19 @@ std::int64_t ref_spt_read(const char* path, std::uint32_t cols, std::uint16_t ro
         }
         col_ptr[cols] = (std::uint32_t)n;
         return (std::int64_t)n;
+    } catch (std::exception&) { return -1; }
+}
+
+// vector_to_file<std::size_t> / vector_from_file<std::size_t> (util.h:104-131): the labeling file of texrecon.cpp:130-136
+int ref_vec_write(const char* path, const std::uint32_t* labels, std::uint32_t n) {
+    try { std::vector<std::size_t> v(labels, labels + n); vector_to_file<std::size_t>(path, v); } catch (std::exception&) { return 1; }
+    return 0;
+}
+std::int64_t ref_vec_read(const char* path, std::uint32_t* labels, std::uint32_t cap) {
+    try {
+        std::vector<std::size_t> v = vector_from_file<std::size_t>(path);
+        for (std::size_t i = 0; i < v.size() && i < cap; ++i) labels[i] = (std::uint32_t)v[i];
+        return (std::int64_t)v.size();
     } catch (std::exception&) { return -1; }
 }
 

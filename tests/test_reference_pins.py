@@ -36,6 +36,8 @@ def R():
     L.ref_tri.argtypes = [vp, vp, vp, u32, vp]
     L.ref_valid_pixel_map.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u32, vp]
     L.ref_face_info.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u32, vp, vp]
+    L.ref_vec_write.argtypes = [C.c_char_p, vp, u32]; L.ref_vec_write.restype = C.c_int
+    L.ref_vec_read.argtypes = [C.c_char_p, vp, u32]; L.ref_vec_read.restype = C.c_int64
     L.ref_spt_write.argtypes = [C.c_char_p, u32, C.c_uint16, vp, vp, vp]; L.ref_spt_write.restype = C.c_int
     L.ref_spt_read.argtypes = [C.c_char_p, u32, C.c_uint16, vp, vp, vp, u64]; L.ref_spt_read.restype = C.c_int64
     return L
@@ -241,3 +243,21 @@ def test_get_face_info_equals_the_reference(R):
         if data_term == 1:
             sampled = int((qa > 0).sum())
     assert sampled > 800 and (qa == 0).sum() > 50             # plenty of real footprints, and the degenerate ones give quality 0
+
+
+def test_labeling_vec_files_are_the_reference_format(R, tmp_path):
+    """row H: the product's labeling writer == vector_to_file<std::size_t> (util.h:104-113, texrecon.cpp:130-136) byte for
+    byte, and vector_from_file<std::size_t> (util.h:119-131, texrecon.cpp:141) reads the product's file back"""
+    from mvs_texturing_amd import viewsel
+    try:
+        L = viewsel.load_library()
+    except viewsel.MvsError as e:   # pragma: no cover
+        pytest.skip("HIP library not loadable here: %s" % e)
+    labels = np.array([0, 3, 1, 200, 65535, 7, 0], dtype=np.uint32)
+    ours, theirs = str(tmp_path / "ours_labeling.vec"), str(tmp_path / "theirs_labeling.vec")
+    assert L.mvs_write_labeling_vec(labels.ctypes.data, len(labels), ours.encode()) == 0
+    assert R.ref_vec_write(theirs.encode(), _p(labels), len(labels)) == 0
+    assert open(ours, "rb").read() == open(theirs, "rb").read()
+    back = np.zeros(16, np.uint32)
+    assert R.ref_vec_read(ours.encode(), _p(back), 16) == len(labels)
+    assert np.array_equal(back[:len(labels)], labels)
