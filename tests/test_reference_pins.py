@@ -243,6 +243,24 @@ def test_get_face_info_equals_the_reference(R):
         if data_term == 1:
             sampled = int((qa > 0).sum())
     assert sampled > 800 and (qa == 0).sum() > 50             # plenty of real footprints, and the degenerate ones give quality 0
+    # the arithmetic header the HIP kernels execute (csrc/dmath.h, compiled for the host by dmath_host.cpp) against the
+    # reference DIRECTLY -- qualities of both data terms
+    dpath = os.path.join(ROOT, "mvs-texturing_amd", "csrc", "libmvs_dmath_host.so")
+    if os.path.exists(dpath):
+        class DV(C.Structure):
+            _fields_ = [("pos", C.c_float * 3), ("viewdir", C.c_float * 3), ("K", C.c_float * 9), ("w2c", C.c_float * 16),
+                        ("width", C.c_int32), ("height", C.c_int32), ("rgb", C.c_void_p), ("gmi", C.c_void_p), ("mask", C.c_void_p)]
+        D = C.CDLL(dpath)
+        v = DV(); v.K[0] = v.K[4] = v.K[8] = 1.0; v.w2c[0] = v.w2c[5] = v.w2c[10] = v.w2c[15] = 1.0; v.viewdir[2] = 1.0
+        v.width, v.height, v.rgb, v.gmi, v.mask = w, h, img.ctypes.data, gmi.ctypes.data, None
+        for data_term in (1, 0):
+            qb = np.zeros(n, np.float32); cb = np.zeros(3 * n, np.float32)
+            R.ref_face_info(_p(img), _p(gmi), w, h, data_term, 0, _p(verts), n, _p(qb), _p(cb))
+            q = C.c_float(0.0); col = (C.c_float * 3)()
+            for k in range(n):
+                D.dmh_face_info(C.byref(v), data_term, 0, C.c_void_p(verts[k, 0:3].ctypes.data), C.c_void_p(verts[k, 3:6].ctypes.data),
+                                C.c_void_p(verts[k, 6:9].ctypes.data), C.byref(q), col)
+                assert np.float32(q.value).view(np.uint32) == qb[k].view(np.uint32), (data_term, k, q.value, qb[k])
 
 
 def test_labeling_vec_files_are_the_reference_format(R, tmp_path):
