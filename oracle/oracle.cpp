@@ -347,12 +347,8 @@ float scene_pad(const orc_mesh& m) {
     return 1e-5f * std::fmax(ext, mag) + 1e-30f;
 }
 
-bool any_hit(const orc_bvh* b, const orc_mesh& m, float pad, V3 origin, V3 view_pos, bool brute, RayCounters* rc) {
-    /* calculate_data_costs.cpp:201-206 */
-    V3 dir = view_pos - origin;
-    const float tmax = norm(dir);
-    const float tmin = tmax * 0.0001f;
-    dir = dir / norm(dir);
+// the any-hit query itself (what the reference asks of acc::BVHTree::intersect), for a ray already set up
+bool any_hit_ray(const orc_bvh* b, const orc_mesh& m, float pad, V3 origin, V3 dir, float tmin, float tmax, bool brute, RayCounters* rc) {
     auto tri_hit = [&](uint32_t t) {
         const uint32_t* f = m.faces + 3 * (size_t)t;
         return ray_tri(origin, dir, tmin, tmax, pad, load3(m.verts + 3 * (size_t)f[0]),
@@ -378,6 +374,15 @@ bool any_hit(const orc_bvh* b, const orc_mesh& m, float pad, V3 origin, V3 view_
         } else { stack[sp++] = n.left; stack[sp++] = n.right; }
     }
     return false;
+}
+
+bool any_hit(const orc_bvh* b, const orc_mesh& m, float pad, V3 origin, V3 view_pos, bool brute, RayCounters* rc) {
+    /* calculate_data_costs.cpp:201-206 */
+    V3 dir = view_pos - origin;
+    const float tmax = norm(dir);
+    const float tmin = tmax * 0.0001f;
+    dir = dir / norm(dir);
+    return any_hit_ray(b, m, pad, origin, dir, tmin, tmax, brute, rc);
 }
 
 // ---------------------------------------------------------------------------
@@ -575,6 +580,24 @@ void orc_bvh_free(orc_bvh* b) { delete b; }
 int orc_ray_occluded(const orc_bvh* b, const orc_mesh* mesh, const float origin[3],
                      const float view_pos[3], int brute) {
     return any_hit(b, *mesh, scene_pad(*mesh), load3(origin), load3(view_pos), brute != 0, nullptr) ? 1 : 0;
+}
+// the bare query for a ray the CALLER set up: oracle/_ref's stand-in for acc::BVHTree::intersect forwards the reference's
+// own rays here (tests/test_reference_pins.py)
+int orc_ray_hit(const orc_bvh* b, const orc_mesh* mesh, const float origin[3], const float dir[3], float tmin, float tmax, int brute) {
+    return any_hit_ray(b, *mesh, b ? b->pad : scene_pad(*mesh), load3(origin), load3(dir), tmin, tmax, brute != 0, nullptr) ? 1 : 0;
+}
+// photometric_outlier_detection (calculate_data_costs.cpp:35-129) on one face's infos, in the order given: mean_color[3n]
+// (already YCbCr), quality[n] updated in place; returns the function's bool
+int orc_outlier_detection(uint32_t n, const float* mean_color, float* quality, int outlier_removal) {
+    std::vector<FaceInfo> infos(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        infos[i].view_id = (uint16_t)i; infos[i].quality = quality[i];
+        for (int a = 0; a < 3; ++a) infos[i].mean_color[a] = mean_color[3 * (size_t)i + a];
+    }
+    orc_settings st; st.data_term = 0; st.outlier_removal = outlier_removal; st.geometric_visibility_test = 0;
+    const bool ok = photometric_outlier_detection(&infos, st);
+    for (uint32_t i = 0; i < n; ++i) quality[i] = infos[i].quality;
+    return ok ? 1 : 0;
 }
 
 // Histogram (histogram.cpp:22-63): add_value + get_approx_percentile

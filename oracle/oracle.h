@@ -9,10 +9,12 @@
  * links, imports or calls anything in oracle/.
  *
  * PARITY UNPINNED wherever the arithmetic lives in MVE, rayint, Eigen or mapMAP: the reference ships no tests,
- * fixtures or golden vectors and its hot path cannot be compiled here because those are
- * un-vendored downloads (elibs/CMakeLists.txt:1-42).  The reference sources that compile without those libraries (TextureView's masks / valid_pixel / get_face_info, Tri, Histogram, SparseTable,
- * UniGraph, Settings) ARE compiled from /root/reference into oracle/_ref and pin the corresponding restatements
- * (tests/test_reference_pins.py).
+ * fixtures or golden vectors and those libraries are un-vendored downloads (elibs/CMakeLists.txt:1-42).
+ * PINNED: the reference's own source files for the data-cost half -- calculate_data_costs.cpp, texture_view.cpp, tri.cpp,
+ * histogram.cpp, uni_graph.cpp, sparse_table.h, settings.h, util.h -- ARE compiled from /root/reference into oracle/_ref
+ * against stand-in headers (oracle/ref_stubs) that carry this file's definitions of the library arithmetic, and
+ * tests/test_reference_pins.py shows this file's DataCosts table bit-identical to the one the reference's
+ * tex::calculate_data_costs fills (every cull, order, early exit, the outlier loop, erase / sort / percentile / normalisation).
  * Where the arithmetic lives in those absent dependencies this file DEFINES the
  * semantics (marked "DEFINED HERE" below) -- see DESIGN.md section "Oracle".
  */
@@ -95,6 +97,11 @@ orc_bvh* orc_bvh_build(const orc_mesh* mesh);
 void orc_bvh_free(orc_bvh* b);
 int orc_ray_occluded(const orc_bvh* b, const orc_mesh* mesh, const float origin[3],
                      const float view_pos[3], int brute);
+
+/* the bare any-hit query for a ray the caller set up (what calculate_data_costs.cpp:208 asks of acc::BVHTree::intersect) */
+int orc_ray_hit(const orc_bvh* b, const orc_mesh* mesh, const float origin[3], const float dir[3], float tmin, float tmax, int brute);
+/* photometric_outlier_detection (calculate_data_costs.cpp:35-129) on one face's infos in the order given */
+int orc_outlier_detection(uint32_t n, const float* mean_color, float* quality, int outlier_removal);
 
 /* ---- histogram (histogram.cpp:22-63) ---- */
 float orc_percentile(const float* values, uint64_t n, float max_value, float percentile);

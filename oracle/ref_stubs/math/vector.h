@@ -2,8 +2,12 @@
 // UNCHANGED for oracle/_ref: element storage and access, construction, conversion, and COMPONENT-WISE operators.
 // A component-wise operator has no operation order to decide, with one exception that is a convention of the absent
 // library and therefore an assumption here (the same one the oracle makes): `vector / scalar` divides every component
-// (it does not multiply by a reciprocal).  It only reaches FaceProjectionInfo::mean_color (outlier-removal modes);
-// qualities do not pass through it.  Inner products etc. are NOT provided.  Test infrastructure only.
+// (it does not multiply by a reciprocal).
+// For the reference's calculate_data_costs.cpp (its culls and ray set-up) the inner product, norm and normalisation are
+// provided as well; their operation order IS a convention of the absent library and is an assumption here, the one the
+// oracle states: dot = ((a0 b0 + a1 b1) + a2 b2), norm = sqrt(dot(v, v)), normalize divides every component by norm().
+// What oracle/_ref pins with them is the reference's CONTROL FLOW around this arithmetic, not the arithmetic.
+// Test infrastructure only.
 #ifndef MVS_REF_STUB_MATH_VECTOR_H
 #define MVS_REF_STUB_MATH_VECTOR_H
 #include <algorithm>   // the real header pulls these in; tri.{h,cpp} / texture_view.cpp rely on std::min / std::max / std::abs / std::swap through it
@@ -30,6 +34,14 @@ public:
     Vector& operator+=(Vector const& o) { for (int i = 0; i < N; ++i) v[i] += o.v[i]; return *this; }
     Vector operator/(T const& s) const { Vector r; for (int i = 0; i < N; ++i) r.v[i] = v[i] / s; return r; }
     Vector& operator/=(T const& s) { for (int i = 0; i < N; ++i) v[i] /= s; return *this; }
+    Vector operator*(T const& s) const { Vector r; for (int i = 0; i < N; ++i) r.v[i] = v[i] * s; return r; }
+    T& operator()(int i) { return v[i]; }
+    T const& operator()(int i) const { return v[i]; }
+    T dot(Vector const& o) const { T s = v[0] * o.v[0]; for (int i = 1; i < N; ++i) s = s + v[i] * o.v[i]; return s; }
+    T square_norm() const { return dot(*this); }
+    T norm() const { return std::sqrt(square_norm()); }
+    Vector& normalize() { T const n = norm(); for (int i = 0; i < N; ++i) v[i] /= n; return *this; }
+    Vector normalized() const { return Vector(*this).normalize(); }
 private:
     T v[N];
 };

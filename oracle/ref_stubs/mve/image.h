@@ -39,5 +39,6 @@ private:
     std::vector<T> data;
 };
 typedef Image<std::uint8_t> ByteImage;
+typedef Image<float> FloatImage;
 }  // namespace mve
 #endif

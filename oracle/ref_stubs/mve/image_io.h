@@ -1,9 +1,11 @@
 // Stand-in for MVE's mve/image_io.h.  No files are involved in oracle/_ref: the "file name" a TextureView is constructed
-// with is "<width>x<height>", images are attached with TextureView::bind_image.
+// with starts with "<width>x<height>"; images are attached with TextureView::bind_image, or -- for the reference's own
+// load_image() call in calculate_data_costs.cpp:157 -- looked up by that name in a registry the test fills.
 #ifndef MVS_REF_STUB_MVE_IMAGE_IO_H
 #define MVS_REF_STUB_MVE_IMAGE_IO_H
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <string>
 #include "mve/image.h"
 #include "util/exception.h"
@@ -11,10 +13,15 @@ namespace mve { namespace image {
 struct ImageHeaders { int width, height, channels; };
 inline ImageHeaders load_file_headers(std::string const& name) {
     ImageHeaders h; h.channels = 3;
-    if (std::sscanf(name.c_str(), "%dx%d", &h.width, &h.height) != 2) throw util::Exception("stand-in image name must be <w>x<h>");
+    if (std::sscanf(name.c_str(), "%dx%d", &h.width, &h.height) != 2) throw util::Exception("stand-in image name must start with <w>x<h>");
     return h;
 }
-inline ByteImage::Ptr load_file(std::string const&) { throw util::Exception("oracle/_ref never loads image files"); }
+inline std::map<std::string, ByteImage::Ptr>& file_registry() { static std::map<std::string, ByteImage::Ptr> r; return r; }
+inline ByteImage::Ptr load_file(std::string const& name) {
+    std::map<std::string, ByteImage::Ptr>::const_iterator it = file_registry().find(name);
+    if (it == file_registry().end()) throw util::Exception("oracle/_ref: no image registered as " + name);
+    return it->second;
+}
 inline void save_png_file(ByteImage::Ptr, std::string const&) {}
 } }  // namespace mve::image
 #endif

@@ -1,9 +1,12 @@
-// oracle/_ref -- the REFERENCE's own code for the pieces of the path that compile without MVE / rayint / Eigen /
-// mapMAP: Histogram (libs/tex/histogram.{h,cpp}), UniGraph (libs/tex/uni_graph.{h,cpp}), SparseTable
-// (libs/tex/sparse_table.h), Tri (libs/tex/tri.{h,cpp}, rect.h), TextureView's mask / valid_pixel / get_face_info logic
-// (libs/tex/texture_view.{h,cpp}), the binary vector files of util.h and the Settings defaults (libs/tex/settings.h).  Their sources are compiled where they lie
-// under /root/reference (oracle/Makefile, target `ref`); this file only adds extern "C" entry points so that the tests
-// can pin the oracle's restatements of SURVEY.md rows C (Tri), D2, E, G / f3 and the defaults against the real thing.
+// oracle/_ref -- the REFERENCE's own code for the data-cost half of the path and its neighbours: tex::calculate_data_costs
+// with photometric_outlier_detection, calculate_face_projection_infos and postprocess_face_infos
+// (libs/tex/calculate_data_costs.cpp), TextureView (libs/tex/texture_view.{h,cpp}), Tri (libs/tex/tri.{h,cpp}, rect.h),
+// Histogram (libs/tex/histogram.{h,cpp}), UniGraph (libs/tex/uni_graph.{h,cpp}), SparseTable (libs/tex/sparse_table.h),
+// the binary vector files of util.h and the Settings defaults (libs/tex/settings.h).  The sources are compiled where they
+// lie under /root/reference (oracle/Makefile, target `ref`) against oracle/ref_stubs, which stands in for the headers
+// of the absent libraries (MVE, rayint, Eigen): containers, and the oracle's definitions of their arithmetic.  This file
+// only adds extern "C" entry points so that the tests can pin the oracle's restatements of SURVEY.md rows A, B, C, D, D1,
+// D2, E, G / f3, H and the defaults against the real thing.
 // TEST INFRASTRUCTURE ONLY (never loaded by the product).
 #include <cstdint>
 #include <cstring>
@@ -17,8 +20,14 @@
 #include "tri.h"
 #include "texture_view.h"
 #include "util.h"
+#include "texturing.h"
 #include <mve/image_tools.h>
+#include <mve/image_io.h>
+#include <acc/bvh_tree.h>
 #include <cstdio>
+
+// defined (not static) in libs/tex/calculate_data_costs.cpp:35 but declared in no header
+namespace tex { bool photometric_outlier_detection(std::vector<FaceProjectionInfo>* infos, Settings const& settings); }
 
 typedef SparseTable<std::uint32_t, std::uint16_t, float> RefDataCosts;   // == tex::DataCosts (libs/tex/texturing.h:36)
 
@@ -157,6 +166,84 @@ std::int64_t ref_vec_read(const char* path, std::uint32_t* labels, std::uint32_t
         for (std::size_t i = 0; i < v.size() && i < cap; ++i) labels[i] = (std::uint32_t)v[i];
         return (std::int64_t)v.size();
     } catch (std::exception&) { return -1; }
+}
+
+// ---- the path's data-cost half, whole: tex::calculate_data_costs (calculate_data_costs.cpp:308-323) = the culls and
+// the ray set-up / order / early exit of calculate_face_projection_infos (:131-251), get_face_info, the colour-space change,
+// photometric_outlier_detection, the zero-quality erase, the sort, max / histogram / percentile and the final normalisation
+// of postprocess_face_infos (:253-306) -- the reference's own code, compiled without OpenMP (= its --num_threads 1 order).
+// Supplied by the test rather than computed here, because they are arithmetic of ABSENT libraries: the per-view camera
+// arrays (mve::CameraInfo), the gradient-magnitude images (mve desaturate + sobel_edge) and the boolean answer to each
+// any-hit ray (rayint), which the stand-in acc::BVHTree forwards to `ray_fn` with the ray exactly as the reference set it up.
+struct RefView { float pos[3], viewdir[3], K[9], w2c[16]; std::int32_t width, height; const std::uint8_t* rgb; };   // layout of orc_view
+std::int64_t ref_calculate_data_costs(std::uint32_t n_verts, const float* verts, std::uint32_t n_faces, const std::uint32_t* faces,
+                                      const float* face_normals, const RefView* views, const std::uint8_t* const* gmi, std::uint32_t n_views,
+                                      int data_term, int outlier_removal, int geometric_visibility_test,
+                                      int (*ray_fn)(const void*, const void*, const float*, const float*, float, float, int),
+                                      const void* ray_bvh, const void* ray_mesh, int ray_brute,
+                                      std::uint32_t* col_ptr /* n_faces + 1 */, std::uint16_t* view_id, float* cost, std::uint64_t cap,
+                                      std::uint64_t* rays_cast) {
+    try {
+        mve::TriangleMesh::Ptr mesh = mve::TriangleMesh::create();
+        for (std::uint32_t v = 0; v < n_verts; ++v) mesh->get_vertices().push_back(math::Vec3f(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]));
+        mesh->get_faces().assign(faces, faces + 3 * (std::size_t)n_faces);
+        for (std::uint32_t f = 0; f < n_faces; ++f)
+            mesh->get_face_normals().push_back(math::Vec3f(face_normals[3 * f], face_normals[3 * f + 1], face_normals[3 * f + 2]));
+
+        mve::image::file_registry().clear();
+        mve::image::gradient_registry().clear();
+        std::vector<tex::TextureView> texture_views;
+        for (std::uint32_t j = 0; j < n_views; ++j) {
+            RefView const& rv = views[j];
+            mve::CameraInfo cam;
+            std::memcpy(cam.K, rv.K, sizeof(cam.K)); std::memcpy(cam.w2c, rv.w2c, sizeof(cam.w2c));
+            std::memcpy(cam.pos, rv.pos, sizeof(cam.pos)); std::memcpy(cam.dir, rv.viewdir, sizeof(cam.dir));
+            char name[64]; std::snprintf(name, sizeof(name), "%dx%d#%u", rv.width, rv.height, j);
+            mve::ByteImage::Ptr img = mve::ByteImage::create(rv.width, rv.height, 3);
+            std::memcpy(img->get_data_pointer(), rv.rgb, (std::size_t)rv.width * rv.height * 3);
+            mve::image::file_registry()[name] = img;
+            if (gmi && gmi[j]) {
+                mve::ByteImage::Ptr g = mve::ByteImage::create(rv.width, rv.height, 1);
+                std::memcpy(g->get_data_pointer(), gmi[j], (std::size_t)rv.width * rv.height);
+                mve::image::gradient_registry()[img.get()] = g;
+            }
+            texture_views.push_back(tex::TextureView(j, cam, name));
+        }
+        acc::RayHook& hook = acc::ray_hook();
+        hook.fn = ray_fn; hook.bvh = ray_bvh; hook.mesh = ray_mesh; hook.brute = ray_brute; hook.calls = 0;
+
+        tex::Settings st;
+        st.data_term = (tex::DataTerm)data_term; st.outlier_removal = (tex::OutlierRemoval)outlier_removal;
+        st.geometric_visibility_test = geometric_visibility_test != 0;
+        tex::DataCosts data_costs(n_faces, n_views);
+        tex::calculate_data_costs(mesh, &texture_views, st, &data_costs);
+
+        if (rays_cast) *rays_cast = hook.calls;
+        hook.fn = nullptr;
+        mve::image::file_registry().clear();
+        mve::image::gradient_registry().clear();
+        std::uint64_t n = 0;
+        for (std::uint32_t i = 0; i < n_faces; ++i) {
+            col_ptr[i] = (std::uint32_t)n;
+            tex::DataCosts::Column const& c = data_costs.col(i);
+            for (std::size_t k = 0; k < c.size(); ++k) { if (n < cap) { view_id[n] = c[k].first; cost[n] = c[k].second; } ++n; }
+        }
+        col_ptr[n_faces] = (std::uint32_t)n;
+        return (std::int64_t)n;
+    } catch (std::exception& e) { std::fprintf(stderr, "ref_calculate_data_costs: %s\n", e.what()); return -1; }
+}
+
+// photometric_outlier_detection (calculate_data_costs.cpp:35-129) on one face's infos in the order given
+int ref_outlier_detection(std::uint32_t n, const float* mean_color, float* quality, int outlier_removal) {
+    std::vector<tex::FaceProjectionInfo> infos(n);
+    for (std::uint32_t i = 0; i < n; ++i) {
+        infos[i].view_id = (std::uint16_t)i; infos[i].quality = quality[i];
+        infos[i].mean_color = math::Vec3f(mean_color[3 * i], mean_color[3 * i + 1], mean_color[3 * i + 2]);
+    }
+    tex::Settings st; st.outlier_removal = (tex::OutlierRemoval)outlier_removal;
+    const bool ok = tex::photometric_outlier_detection(&infos, st);
+    for (std::uint32_t i = 0; i < n; ++i) quality[i] = infos[i].quality;
+    return ok ? 1 : 0;
 }
 
 }  // extern "C"

@@ -1,11 +1,11 @@
-"""Pins against the REFERENCE'S OWN CODE (oracle/_ref/libtexref.so): the pieces of the path whose sources compile
-without MVE / rayint / Eigen / mapMAP -- TextureView's validity mask, valid_pixel and get_face_info logic (rows B2, B3,
-C), Tri (row C), Histogram (row D2), SparseTable and its .spt format (row E),
-UniGraph and get_subgraphs (rows G / f3), the Settings defaults -- are compiled from /root/reference where they lie
-(oracle/Makefile target `ref`, wrappers in oracle/ref_wrap.cpp) and compared with the oracle's restatements and with
-the product's host-side file writers.  The GPU parity tests compare the HIP path with the oracle, so these rows are
-pinned to upstream transitively.  The library is built in the development container (the reference is mounted there)
-and travels prebuilt; the tests skip where it does not exist."""
+"""Pins against the REFERENCE'S OWN CODE (oracle/_ref/libtexref.so).  The reference's source files for the data-cost half
+of the path -- calculate_data_costs.cpp (rows A, B, D, D1), texture_view.cpp (rows B2, B3, C), tri.cpp (row C),
+histogram.cpp (row D2) -- and sparse_table.h (row E), uni_graph.cpp (rows G / f3), util.h (row H), settings.h are compiled
+from /root/reference where they lie (oracle/Makefile target `ref`, wrappers in oracle/ref_wrap.cpp) against stand-in
+headers for the absent libraries (oracle/ref_stubs: containers + the oracle's definitions of MVE / rayint / Eigen
+arithmetic), and compared with the oracle's restatements and with the product's host-side file writers.  The GPU parity
+tests compare the HIP path with the oracle, so these rows are pinned to upstream transitively.  The library is built in
+the development container (the reference is mounted there) and travels prebuilt; the tests skip where it does not exist."""
 import ctypes as C
 import os
 
@@ -279,3 +279,107 @@ def test_labeling_vec_files_are_the_reference_format(R, tmp_path):
     back = np.zeros(16, np.uint32)
     assert R.ref_vec_read(ours.encode(), _p(back), 16) == len(labels)
     assert np.array_equal(back[:len(labels)], labels)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rows A, B, D: the reference's OWN calculate_data_costs.cpp, whole
+# ---------------------------------------------------------------------------------------------------------------------
+def _ref_data_costs(R, scene, data_term, outlier, geom, brute=False):
+    """tex::calculate_data_costs (calculate_data_costs.cpp:308-323) compiled from /root/reference, with the arithmetic of
+    the ABSENT libraries supplied from outside: camera arrays, gradient-magnitude images (oracle's), and each any-hit ray
+    answered by the oracle's orc_ray_hit for the ray exactly as the reference's code set it up."""
+    OL = O.load()
+    OL.orc_ray_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int]
+    OL.orc_ray_hit.restype = C.c_int
+    mesh = O.mesh_struct(scene)
+    views = O.view_structs(scene)
+    V, F = scene.n_views, scene.n_faces
+    gmis, gptr = [], (C.c_void_p * V)()
+    for j in range(V):
+        w, h = int(scene.cams["width"][j]), int(scene.cams["height"][j])
+        g = np.zeros(w * h, np.uint8)
+        OL.orc_gradient_magnitude(scene.images[j].ctypes.data, w, h, g.ctypes.data)
+        gmis.append(g); gptr[j] = g.ctypes.data
+    bvh = OL.orc_bvh_build(C.byref(mesh))
+    cap = F * V
+    col_ptr = np.zeros(F + 1, np.uint32); vid = np.zeros(cap, np.uint16); cost = np.zeros(cap, np.float32)
+    rays = C.c_uint64(0)
+    R.ref_calculate_data_costs.restype = C.c_int64
+    R.ref_calculate_data_costs.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    try:
+        n = R.ref_calculate_data_costs(scene.verts.shape[0], _p(scene.verts), F, _p(scene.faces), _p(scene.normals),
+                                       C.cast(views, C.c_void_p), C.cast(gptr, C.c_void_p), V,
+                                       {"area": 0, "gmi": 1}[data_term], {"none": 0, "gauss_damping": 1, "gauss_clamping": 2}[outlier], int(geom),
+                                       C.cast(OL.orc_ray_hit, C.c_void_p), bvh, C.cast(C.pointer(mesh), C.c_void_p), int(brute),
+                                       _p(col_ptr), _p(vid), _p(cost), cap, C.cast(C.pointer(rays), C.c_void_p))
+    finally:
+        OL.orc_bvh_free(bvh)
+    assert 0 <= n <= cap
+    return col_ptr, vid[:n].copy(), cost[:n].copy(), rays.value
+
+
+_DC_CASES = [("tiny", dt, orm, gv) for dt in ("gmi", "area") for orm in ("none", "gauss_damping", "gauss_clamping") for gv in (True, False)] + \
+            [("oddw", "gmi", "none", True), ("oddw", "area", "gauss_clamping", True), ("oddw", "gmi", "gauss_damping", True),
+             ("bumpy", "gmi", "none", True), ("bumpy", "gmi", "gauss_damping", True), ("bumpy", "area", "gauss_clamping", False),
+             ("c1", "gmi", "none", True),
+             # hundreds of infos per face: the outlier loop runs its iterations on real colour sets (clamping erases ~9 % of the entries)
+             ("manyviews", "gmi", "gauss_damping", True), ("manyviews", "area", "gauss_clamping", True)]
+
+
+@pytest.mark.parametrize("name,data_term,outlier,geom", _DC_CASES)
+def test_data_costs_equal_the_reference_calculate_data_costs(R, name, data_term, outlier, geom):
+    """rows A, B1-B4, D, D1, D2 end to end: the oracle's table is BIT-IDENTICAL to the table the reference's own
+    calculate_data_costs.cpp builds (its culls in its order, its ray set-up and early exit, get_face_info, YCbCr at its
+    place, its outlier loop, erase, sort, max, histogram percentile, normalisation, set_value order), and both cast the
+    same number of rays.  The arithmetic of the absent libraries (MVE vectors / cameras / Sobel / YCbCr, rayint, Eigen)
+    is the oracle's definition on both sides (oracle/ref_stubs) -- that part stays an assumption."""
+    s = get_scene(name)
+    col_ptr, vid, cost, rays = _ref_data_costs(R, s, data_term, outlier, geom)
+    want, stats = O.data_costs(s, data_term=data_term, outlier_removal=outlier, geometric_visibility_test=geom)
+    assert np.array_equal(col_ptr, want.col_ptr)
+    assert np.array_equal(vid, want.view_id)
+    assert np.array_equal(cost.view(np.uint32), want.cost.view(np.uint32))
+    assert rays == stats["rays"]
+    assert len(vid) > 0 and (not geom or rays > 0)
+
+
+def test_outlier_detection_equals_the_reference_function(R):
+    """row D1: photometric_outlier_detection (calculate_data_costs.cpp:35-129) itself, on synthetic colour sets that reach
+    every exit: fewer than 4 inliers, covariance below 5e-4 (outliers zeroed), singular covariance (not invertible),
+    10 iterations without convergence, damping and clamping."""
+    OL = O.load()
+    OL.orc_outlier_detection.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]; OL.orc_outlier_detection.restype = C.c_int
+    R.ref_outlier_detection.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]; R.ref_outlier_detection.restype = C.c_int
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (0, 1, 3, 4, 5, 8, 20, 60, 300):
+        for spread in (1e-4, 3e-3, 0.02, 0.1, 0.4):
+            base = rng.random(3).astype(np.float32)
+            col = (base + rng.standard_normal((n, 3)).astype(np.float32) * np.float32(spread)).astype(np.float32)
+            if n >= 5:
+                k = max(1, n // 5)
+                col[:k] = rng.random((k, 3)).astype(np.float32)          # outliers
+            cases.append(col)
+    cases.append(np.tile(np.float32([[0.3, 0.4, 0.5]]), (10, 1)))                                # zero covariance
+    line = np.linspace(0, 1, 12, dtype=np.float32)[:, None] * np.float32([[0.5, 0.25, 0.125]])   # rank 1: singular
+    cases.append(line.astype(np.float32))
+    plane = rng.random((30, 3)).astype(np.float32); plane[:, 2] = plane[:, 0]                    # rank 2
+    cases.append(plane)
+    outcomes = set()
+    for col in cases:
+        col = np.ascontiguousarray(col, np.float32)
+        n = len(col)
+        q0 = (rng.random(n).astype(np.float32) + np.float32(0.1))
+        for mode in (0, 1, 2):
+            qa, qb = q0.copy(), q0.copy()
+            ra = R.ref_outlier_detection(n, _p(col), _p(qa), mode)
+            rb = OL.orc_outlier_detection(n, _p(col), _p(qb), mode)
+            assert ra == rb, (n, mode)
+            assert np.array_equal(qa.view(np.uint32), qb.view(np.uint32)), (n, mode)
+            if mode:
+                outcomes.add((ra, bool((qa == 0).any()), bool(((qa != q0) & (qa != 0)).any())))
+    # the exits were all taken: failure (False), success with zeroed qualities, success with damped qualities, success untouched
+    assert {o[0] for o in outcomes} == {0, 1}
+    assert any(o[1] for o in outcomes) and any(o[2] for o in outcomes)
