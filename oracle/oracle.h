@@ -10,11 +10,13 @@
  *
  * PARITY UNPINNED wherever the arithmetic lives in MVE, rayint, Eigen or mapMAP: the reference ships no tests,
  * fixtures or golden vectors and those libraries are un-vendored downloads (elibs/CMakeLists.txt:1-42).
- * PINNED: the reference's own source files for the data-cost half -- calculate_data_costs.cpp, texture_view.cpp, tri.cpp,
+ * PINNED: the reference's own source files on the path -- calculate_data_costs.cpp, view_selection.cpp, texture_view.cpp, tri.cpp,
  * histogram.cpp, uni_graph.cpp, sparse_table.h, settings.h, util.h -- ARE compiled from /root/reference into oracle/_ref
  * against stand-in headers (oracle/ref_stubs) that carry this file's definitions of the library arithmetic, and
  * tests/test_reference_pins.py shows this file's DataCosts table bit-identical to the one the reference's
  * tex::calculate_data_costs fills (every cull, order, early exit, the outlier loop, erase / sort / percentile / normalisation).
+ * and the MRF model tex::view_selection builds (edges, label sets, costs) and its decode equal to this file's (the solver itself
+ * is DEFINED HERE: mapMAP is absent and parity with its output is unpinned).
  * Where the arithmetic lives in those absent dependencies this file DEFINES the
  * semantics (marked "DEFINED HERE" below) -- see DESIGN.md section "Oracle".
  */

@@ -1,12 +1,13 @@
-// oracle/_ref -- the REFERENCE's own code for the data-cost half of the path and its neighbours: tex::calculate_data_costs
+// oracle/_ref -- the REFERENCE's own code for the path and its neighbours: tex::view_selection's model construction and
+// decode (libs/tex/view_selection.cpp), tex::calculate_data_costs
 // with photometric_outlier_detection, calculate_face_projection_infos and postprocess_face_infos
 // (libs/tex/calculate_data_costs.cpp), TextureView (libs/tex/texture_view.{h,cpp}), Tri (libs/tex/tri.{h,cpp}, rect.h),
 // Histogram (libs/tex/histogram.{h,cpp}), UniGraph (libs/tex/uni_graph.{h,cpp}), SparseTable (libs/tex/sparse_table.h),
 // the binary vector files of util.h and the Settings defaults (libs/tex/settings.h).  The sources are compiled where they
 // lie under /root/reference (oracle/Makefile, target `ref`) against oracle/ref_stubs, which stands in for the headers
-// of the absent libraries (MVE, rayint, Eigen): containers, and the oracle's definitions of their arithmetic.  This file
+// of the absent libraries (MVE, rayint, Eigen, mapMAP): containers, recorders, and the oracle's definitions of their arithmetic.  This file
 // only adds extern "C" entry points so that the tests can pin the oracle's restatements of SURVEY.md rows A, B, C, D, D1,
-// D2, E, G / f3, H and the defaults against the real thing.
+// D2, E, F, G / f3, H and the defaults against the real thing.
 // TEST INFRASTRUCTURE ONLY (never loaded by the product).
 #include <cstdint>
 #include <cstring>
@@ -24,6 +25,7 @@
 #include <mve/image_tools.h>
 #include <mve/image_io.h>
 #include <acc/bvh_tree.h>
+#include "mapmap/full.h"
 #include <cstdio>
 
 // defined (not static) in libs/tex/calculate_data_costs.cpp:35 but declared in no header
@@ -244,6 +246,64 @@ int ref_outlier_detection(std::uint32_t n, const float* mean_color, float* quali
     const bool ok = tex::photometric_outlier_detection(&infos, st);
     for (std::uint32_t i = 0; i < n; ++i) quality[i] = infos[i].quality;
     return ok ? 1 : 0;
+}
+
+// ---- the path's labeling half: tex::view_selection (view_selection.cpp:18-133), the reference's own model construction
+// (edges between faces that both have candidate views, label sets view_id + 1 / {0}, unary tables, Potts weight) and its
+// decode (label_from_offset, the "Incorrect labeling" guard, set_label).  mapMAP is absent: the stand-in mapmap/full.h
+// records the model and asks `solve` for one label offset per node; inside `solve` the caller reads the model with
+// ref_model_sizes / ref_model_get and answers with ref_model_set_offsets.
+void ref_model_sizes(std::uint64_t out[3]) {
+    mapmap::Model const& m = mapmap::model();
+    std::uint64_t total = 0;
+    for (std::size_t i = 0; i < m.labels.size(); ++i) total += m.labels[i].size();
+    out[0] = m.n_nodes; out[1] = m.edge_weights.size(); out[2] = total;
+}
+// edges[2E], weights[E], label_ptr[n + 1], labels[total], costs[total] (-1 entries where a node's cost vector is shorter
+// than its label vector), misc[16] = {potts, window, ratio, components_updated, compress, all set_unary calls consistent,
+// ctrl[0..8], seed}
+void ref_model_get(std::uint32_t* edges, float* weights, std::uint32_t* label_ptr, std::int32_t* labels, float* costs, double* misc) {
+    mapmap::Model const& m = mapmap::model();
+    for (std::size_t e = 0; e < m.edges.size(); ++e) edges[e] = m.edges[e];
+    for (std::size_t e = 0; e < m.edge_weights.size(); ++e) weights[e] = m.edge_weights[e];
+    std::uint32_t n = 0;
+    for (std::size_t i = 0; i < m.labels.size(); ++i) {
+        label_ptr[i] = n;
+        for (std::size_t k = 0; k < m.labels[i].size(); ++k) {
+            labels[n] = m.labels[i][k];
+            costs[n] = (i < m.costs.size() && k < m.costs[i].size() && m.costs[i].size() == m.labels[i].size()) ? m.costs[i][k] : -1.0f;
+            ++n;
+        }
+    }
+    label_ptr[m.labels.size()] = n;
+    bool unaries_ok = m.unary_set.size() == m.n_nodes;
+    for (std::size_t i = 0; i < m.unary_set.size(); ++i) unaries_ok = unaries_ok && m.unary_set[i] == 1;
+    misc[0] = m.potts; misc[1] = m.term_window; misc[2] = m.term_ratio; misc[3] = m.components_updated; misc[4] = m.compress; misc[5] = unaries_ok;
+    for (int i = 0; i < 9; ++i) misc[6 + i] = m.ctrl[i];
+    misc[15] = (double)m.seed;
+}
+void ref_model_set_offsets(const std::int32_t* offsets) {
+    mapmap::SolveHook& h = mapmap::solve_hook();
+    for (std::size_t i = 0; i < h.offsets.size(); ++i) h.offsets[i] = offsets[i];
+}
+// returns 0, or 1 if view_selection threw (what() copied to err); labels_out[i] = graph->get_label(i) afterwards
+int ref_view_selection(std::uint32_t n_faces, std::uint16_t n_views, const std::uint32_t* col_ptr, const std::uint16_t* view_id, const float* cost,
+                       const std::uint32_t* adj_ptr, const std::uint32_t* adj, int (*solve)(void*), std::uint32_t* labels_out, char* err, int err_len) {
+    try {
+        tex::DataCosts data_costs(n_faces, n_views);
+        for (std::uint32_t i = 0; i < n_faces; ++i)
+            for (std::uint32_t k = col_ptr[i]; k < col_ptr[i + 1]; ++k) data_costs.set_value(i, view_id[k], cost[k]);
+        UniGraph graph = make_graph(n_faces, adj_ptr, adj);
+        mapmap::solve_hook().fn = solve; mapmap::solve_hook().user = nullptr;
+        tex::view_selection(data_costs, &graph, tex::Settings());
+        mapmap::solve_hook().fn = nullptr;
+        for (std::uint32_t i = 0; i < n_faces; ++i) labels_out[i] = (std::uint32_t)graph.get_label(i);
+        return 0;
+    } catch (std::exception& e) {
+        mapmap::solve_hook().fn = nullptr;
+        if (err && err_len > 0) std::snprintf(err, (std::size_t)err_len, "%s", e.what());
+        return 1;
+    }
 }
 
 }  // extern "C"

@@ -1,5 +1,5 @@
-"""Pins against the REFERENCE'S OWN CODE (oracle/_ref/libtexref.so).  The reference's source files for the data-cost half
-of the path -- calculate_data_costs.cpp (rows A, B, D, D1), texture_view.cpp (rows B2, B3, C), tri.cpp (row C),
+"""Pins against the REFERENCE'S OWN CODE (oracle/_ref/libtexref.so).  The reference's source files
+on the path -- calculate_data_costs.cpp (rows A, B, D, D1), view_selection.cpp (row F: model + decode), texture_view.cpp (rows B2, B3, C), tri.cpp (row C),
 histogram.cpp (row D2) -- and sparse_table.h (row E), uni_graph.cpp (rows G / f3), util.h (row H), settings.h are compiled
 from /root/reference where they lie (oracle/Makefile target `ref`, wrappers in oracle/ref_wrap.cpp) against stand-in
 headers for the absent libraries (oracle/ref_stubs: containers + the oracle's definitions of MVE / rayint / Eigen
@@ -383,3 +383,108 @@ def test_outlier_detection_equals_the_reference_function(R):
     # the exits were all taken: failure (False), success with zeroed qualities, success with damped qualities, success untouched
     assert {o[0] for o in outcomes} == {0, 1}
     assert any(o[1] for o in outcomes) and any(o[2] for o in outcomes)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# row F: the reference's OWN view_selection.cpp (model construction + decode; mapMAP itself is absent)
+# ---------------------------------------------------------------------------------------------------------------------
+def _ref_view_selection(R, n_views, col_ptr, view_id, cost, adj_ptr, adj):
+    """tex::view_selection compiled from /root/reference.  The recording mapMAP stand-in hands the model the reference
+    built to `solve`, which checks it against an independent numpy statement of view_selection.cpp:26-81, runs the
+    ORACLE's solver on that model and answers with label offsets.  Returns (labels the reference wrote into the UniGraph,
+    model facts)."""
+    F = len(col_ptr) - 1
+    R.ref_model_sizes.argtypes = [C.c_void_p]
+    R.ref_model_get.argtypes = [C.c_void_p] * 6
+    R.ref_model_set_offsets.argtypes = [C.c_void_p]
+    R.ref_view_selection.argtypes = [C.c_uint32, C.c_uint16, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_char_p, C.c_int]
+    R.ref_view_selection.restype = C.c_int
+    seen = {}
+
+    def solve(_user):
+        try:
+            sz = np.zeros(3, np.uint64); R.ref_model_sizes(_p(sz))
+            n, E, T = (int(x) for x in sz)
+            edges = np.zeros(2 * max(E, 1), np.uint32); w = np.zeros(max(E, 1), np.float32)
+            lptr = np.zeros(n + 1, np.uint32); labels = np.zeros(max(T, 1), np.int32); costs = np.zeros(max(T, 1), np.float32)
+            misc = np.zeros(16, np.float64)
+            R.ref_model_get(_p(edges), _p(w), _p(lptr), _p(labels), _p(costs), _p(misc))
+            edges = edges[:2 * E].reshape(-1, 2); w = w[:E]; labels = labels[:T]; costs = costs[:T]
+            seen.update(n=n, edges=edges.copy(), w=w.copy(), lptr=lptr.copy(), labels=labels.copy(), costs=costs.copy(), misc=misc.copy())
+            # the oracle's solver on THE MODEL: columns = label - 1 of the nodes that have views, lists = edge insertion order
+            k = np.diff(lptr.astype(np.int64))
+            has = labels[lptr[:-1]] != 0
+            m_col = np.zeros(n + 1, np.uint32); m_col[1:] = np.cumsum(np.where(has, k, 0))
+            keep = np.repeat(has, k)
+            m_vid = (labels[keep] - 1).astype(np.uint16); m_cost = costs[keep]
+            lists = [[] for _ in range(n)]
+            for a, b in edges.tolist():
+                lists[a].append(b); lists[b].append(a)
+            m_adj_ptr = np.zeros(n + 1, np.uint32); m_adj_ptr[1:] = np.cumsum([len(l) for l in lists])
+            m_adj = np.array([x for l in lists for x in l], dtype=np.uint32)
+            lab, st = O.view_selection(O.CsrNp(n, n_views, m_col, m_vid, m_cost), m_adj_ptr, m_adj)
+            seen.update(model_energy=st["energy_fixed"])
+            off = np.zeros(n, np.int32)
+            for i in np.nonzero(has)[0]:
+                a, b = int(lptr[i]), int(lptr[i + 1])
+                pos = np.nonzero(labels[a:b] == int(lab[i]))[0]
+                assert len(pos) == 1
+                off[i] = pos[0]
+            R.ref_model_set_offsets(_p(off))
+            return 0
+        except Exception as e:          # noqa: BLE001 -- surfaced through the return code
+            seen["error"] = repr(e)
+            return 1
+
+    cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(solve)
+    out = np.zeros(F, np.uint32)
+    err = C.create_string_buffer(256)
+    rc = R.ref_view_selection(F, n_views, _p(col_ptr), _p(view_id), _p(cost), _p(adj_ptr), _p(adj), C.cast(cb, C.c_void_p), _p(out), err, 256)
+    assert rc == 0, (err.value, seen.get("error"))
+    return out, seen
+
+
+def _vs_cases(R):
+    for name in ("tiny", "bumpy"):
+        s = get_scene(name)
+        dc, _ = O.data_costs(s)
+        yield name, s.n_views, dc.col_ptr, dc.view_id, dc.cost, s.adj_ptr, s.adj
+    for seed, (n, v, k, d, pe) in enumerate([(300, 12, 5, 3, 0.15), (1000, 40, 9, 4, 0.05), (64, 6, 3, 3, 0.4), (500, 300, 40, 3, 0.1)]):
+        col_ptr, vid, cost, adj_ptr, adj = random_mrf(n, v, k, d, seed=100 + seed, p_empty=pe)
+        # the lists a UniGraph really holds after the build_adjacency_graph insertion pattern
+        optr = np.zeros(n + 1, np.uint32); oadj = np.zeros(len(adj), np.uint32)
+        R.ref_unigraph_lists(n, _p(adj_ptr), _p(adj), _p(optr), _p(oadj))
+        assert np.array_equal(optr, adj_ptr)
+        yield "random%d" % seed, v, col_ptr, vid, cost, optr, oadj
+
+
+def test_view_selection_equals_the_reference_model_and_decode(R):
+    """row F: upstream's view_selection.cpp builds, through the recording mapMAP stand-in, exactly the model the oracle
+    states (view_selection.cpp:26-81: an edge i < j only between faces that both have candidate views, in UniGraph list
+    order, weight 1; label set {view_id + 1} with the table's costs, or {0} with cost 1 for a face nobody sees; Potts
+    weight 1; StopWhenReturnsDiminish(5, 0.01)); the oracle's solver on THAT model returns the labeling it returns on the
+    raw inputs; and upstream's decode (:120-131) writes those labels into the UniGraph."""
+    for name, n_views, col_ptr, vid, cost, adj_ptr, adj in _vs_cases(R):
+        F = len(col_ptr) - 1
+        got, m = _ref_view_selection(R, n_views, col_ptr, vid, cost, adj_ptr, adj)
+        empty = np.diff(col_ptr.astype(np.int64)) == 0
+        # model == independent statement
+        want_edges = [(i, int(j)) for i in range(F) if not empty[i] for j in adj[adj_ptr[i]:adj_ptr[i + 1]] if i < j and not empty[j]]
+        assert m["n"] == F and m["edges"].tolist() == [list(e) for e in want_edges], name
+        assert (m["w"] == 1.0).all()
+        want_lptr = np.zeros(F + 1, np.int64); want_lptr[1:] = np.cumsum(np.where(empty, 1, np.diff(col_ptr.astype(np.int64))))
+        assert np.array_equal(m["lptr"], want_lptr)
+        want_labels = np.zeros(want_lptr[-1], np.int32); want_costs = np.ones(want_lptr[-1], np.float32)
+        sel = np.repeat(~empty, np.diff(want_lptr))
+        want_labels[sel] = vid.astype(np.int32) + 1; want_costs[sel] = cost
+        assert np.array_equal(m["labels"], want_labels) and np.array_equal(m["costs"].view(np.uint32), want_costs.view(np.uint32)), name
+        misc = m["misc"]
+        assert misc[0] == 1.0 and misc[1] == 5 and misc[2] == 0.01 and misc[3] == 1 and misc[4] == 0 and misc[5] == 1
+        assert misc[6:15].tolist() == [1, 1, 1, 5, 1, 5, 1, 1, 1] and int(misc[15]) == 548923723
+        # decode == the oracle's labeling of the raw inputs
+        want, st = O.view_selection(O.CsrNp(F, n_views, col_ptr, vid, cost), adj_ptr, adj)
+        assert np.array_equal(got, want), name
+        assert (got[empty] == 0).all() and (got[~empty] > 0).all()
+        assert m["model_energy"] == st["energy_fixed"]
+        assert int((got == 0).sum()) == st["unseen"]
