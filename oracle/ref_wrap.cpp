@@ -3,11 +3,12 @@
 // with photometric_outlier_detection, calculate_face_projection_infos and postprocess_face_infos
 // (libs/tex/calculate_data_costs.cpp), TextureView (libs/tex/texture_view.{h,cpp}), Tri (libs/tex/tri.{h,cpp}, rect.h),
 // Histogram (libs/tex/histogram.{h,cpp}), UniGraph (libs/tex/uni_graph.{h,cpp}), SparseTable (libs/tex/sparse_table.h),
+// prepare_mesh / build_adjacency_graph (libs/tex/prepare_mesh.cpp, build_adjacency_graph.cpp),
 // the binary vector files of util.h and the Settings defaults (libs/tex/settings.h).  The sources are compiled where they
 // lie under /root/reference (oracle/Makefile, target `ref`) against oracle/ref_stubs, which stands in for the headers
 // of the absent libraries (MVE, rayint, Eigen, mapMAP): containers, recorders, and the oracle's definitions of their arithmetic.  This file
 // only adds extern "C" entry points so that the tests can pin the oracle's restatements of SURVEY.md rows A, B, C, D, D1,
-// D2, E, F, G / f3, H and the defaults against the real thing.
+// D2, E, F, G / f3, H, f1 and the defaults against the real thing.
 // TEST INFRASTRUCTURE ONLY (never loaded by the product).
 #include <cstdint>
 #include <cstring>
@@ -304,6 +305,40 @@ int ref_view_selection(std::uint32_t n_faces, std::uint16_t n_views, const std::
         if (err && err_len > 0) std::snprintf(err, (std::size_t)err_len, "%s", e.what());
         return 1;
     }
+}
+
+// ---- row f1: tex::prepare_mesh (prepare_mesh.cpp:14-70) and tex::build_adjacency_graph (build_adjacency_graph.cpp:16-53) ----
+static mve::TriangleMesh::Ptr make_mesh(std::uint32_t n_verts, const float* verts, std::uint32_t n_faces, const std::uint32_t* faces) {
+    mve::TriangleMesh::Ptr mesh = mve::TriangleMesh::create();
+    for (std::uint32_t v = 0; v < n_verts; ++v) mesh->get_vertices().push_back(math::Vec3f(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]));
+    mesh->get_faces().assign(faces, faces + 3 * (std::size_t)n_faces);
+    return mesh;
+}
+std::uint32_t ref_prepare_mesh(std::uint32_t n_verts, const float* verts, std::uint32_t n_faces, const std::uint32_t* faces,
+                               std::uint32_t* faces_out, float* normals_out) {
+    mve::TriangleMesh::Ptr mesh = make_mesh(n_verts, verts, n_faces, faces);
+    mve::MeshInfo mesh_info(mesh);
+    tex::prepare_mesh(&mesh_info, mesh);
+    std::uint32_t const kept = (std::uint32_t)(mesh->get_faces().size() / 3);
+    for (std::size_t i = 0; i < mesh->get_faces().size(); ++i) faces_out[i] = mesh->get_faces()[i];
+    for (std::uint32_t f = 0; f < kept; ++f) for (int a = 0; a < 3; ++a) normals_out[3 * f + a] = mesh->get_face_normals()[f][a];
+    return kept;
+}
+std::uint64_t ref_build_adjacency(std::uint32_t n_verts, std::uint32_t n_faces, const std::uint32_t* faces, std::uint32_t* out_ptr, std::uint32_t* out_adj,
+                                  std::uint64_t cap) {
+    std::vector<float> zeros(3 * (std::size_t)n_verts, 0.0f);
+    mve::TriangleMesh::Ptr mesh = make_mesh(n_verts, zeros.data(), n_faces, faces);
+    mve::MeshInfo mesh_info(mesh);
+    UniGraph graph(n_faces);
+    tex::build_adjacency_graph(mesh, mesh_info, &graph);
+    std::uint64_t n = 0;
+    for (std::uint32_t i = 0; i < n_faces; ++i) {
+        out_ptr[i] = (std::uint32_t)n;
+        std::vector<std::size_t> const& l = graph.get_adj_nodes(i);
+        for (std::size_t k = 0; k < l.size(); ++k) { if (n < cap) out_adj[n] = (std::uint32_t)l[k]; ++n; }
+    }
+    out_ptr[n_faces] = (std::uint32_t)n;
+    return graph.num_edges();
 }
 
 }  // extern "C"

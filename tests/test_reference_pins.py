@@ -488,3 +488,48 @@ def test_view_selection_equals_the_reference_model_and_decode(R):
         assert (got[empty] == 0).all() and (got[~empty] > 0).all()
         assert m["model_energy"] == st["energy_fixed"]
         assert int((got == 0).sum()) == st["unseen"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# row f1: the reference's OWN prepare_mesh.cpp and build_adjacency_graph.cpp
+# ---------------------------------------------------------------------------------------------------------------------
+def test_prepare_mesh_and_adjacency_equal_the_reference_functions(R):
+    """row f1: tex::prepare_mesh (redundant-face removal, prepare_mesh.cpp:14-56) and tex::build_adjacency_graph
+    (build_adjacency_graph.cpp:16-53, through the reference's own UniGraph) on closed, open, duplicated and
+    non-manifold meshes and on the test scenes: kept faces, face normals and adjacency lists element for element
+    (faces with a repeated vertex: prepare_mesh equal, adjacency differs around the repeated vertex -- see below).
+    mve::MeshInfo is a stand-in with ascending face lists (only a non-manifold edge can see that order) and face normals
+    follow the oracle's definition (oracle/ref_stubs/mve/mesh{,_info}.h)."""
+    from test_oracle import _f1_meshes
+    R.ref_prepare_mesh.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]; R.ref_prepare_mesh.restype = C.c_uint32
+    R.ref_build_adjacency.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]; R.ref_build_adjacency.restype = C.c_uint64
+    meshes = dict(_f1_meshes())
+    for name in ("tiny", "bumpy"):
+        s = get_scene(name)
+        meshes[name] = (s.verts, s.faces)
+    for name, (verts, faces) in meshes.items():
+        verts = np.ascontiguousarray(verts, np.float32); faces = np.ascontiguousarray(faces, np.uint32)
+        F = len(faces)
+        fo = np.zeros((F, 3), np.uint32); no = np.zeros((F, 3), np.float32)
+        kept = R.ref_prepare_mesh(len(verts), _p(verts), F, _p(faces), _p(fo), _p(no))
+        f_o, n_o = O.prepare_mesh(verts, faces)
+        assert kept == len(f_o) and np.array_equal(fo[:kept], f_o), name
+        assert np.array_equal(no[:kept].view(np.uint32), n_o.view(np.uint32)), name
+        ap_o, ad_o = O.build_adjacency(faces)
+        optr = np.zeros(F + 1, np.uint32); oadj = np.zeros(max(len(ad_o), 1) + 64, np.uint32)
+        edges = R.ref_build_adjacency(len(verts), F, _p(faces), _p(optr), _p(oadj), len(oadj))
+        assert edges * 2 == optr[-1]
+        if name == "degenerate":
+            # KNOWN DIFFERENCE, faces with a repeated vertex only: upstream asks for the faces of the "edge" (a, a), which a
+            # vertex-list intersection answers with EVERY face at a, while the oracle / product match edge keys and connect
+            # such a face only through its proper edge.  Everything away from the repeated vertices is identical.
+            rep = {int(f[k]) for f in faces if len(set(f.tolist())) < 3 for k in range(3) if list(f).count(f[k]) > 1}
+            touched = np.array([bool(rep & set(f.tolist())) for f in faces])
+            for i in np.nonzero(~touched)[0]:
+                assert oadj[optr[i]:optr[i + 1]].tolist() == ad_o[ap_o[i]:ap_o[i + 1]].tolist(), (name, i)
+            assert touched.sum() < 16
+            continue
+        assert np.array_equal(optr, ap_o) and np.array_equal(oadj[:optr[-1]], ad_o), name
+    s = get_scene("bumpy")
+    ap_o, ad_o = O.build_adjacency(s.faces)
+    assert np.array_equal(ap_o, s.adj_ptr) and np.array_equal(ad_o, s.adj)     # what every other test feeds view selection with
