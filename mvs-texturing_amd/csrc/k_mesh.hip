@@ -1,7 +1,8 @@
 // k_mesh.hip -- row f1 of SURVEY.md section 8(f): the two stages immediately before the view-selection path,
 //   tex::prepare_mesh          (libs/tex/prepare_mesh.cpp:14-70)   redundant-face removal + face normals
 //   tex::build_adjacency_graph (libs/tex/build_adjacency_graph.cpp:16-53) face adjacency in UniGraph list order
-// Both are integer / sorting work (HBM bound); results are exact.
+// Both are integer / sorting work (HBM bound); results are exact (pinned to the reference's own two files through oracle/_ref,
+// tests/test_reference_pins.py, including meshes with repeated-vertex faces).
 #include "ctx.h"
 #include <rocprim/rocprim.hpp>
 
@@ -14,13 +15,15 @@ namespace {
 
 constexpr int MAX_NEIGHBOURS = 48;   // distinct neighbours of one face (3 for a manifold mesh)
 
-__global__ void edge_key_kernel(const uint32_t* __restrict__ faces, uint32_t n_faces, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ void edge_key_kernel(const uint32_t* __restrict__ faces, uint32_t n_faces, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                                uint32_t* __restrict__ n_repeated) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n_faces) return;
     const uint32_t f = i / 3, k = i - 3 * f;
     const uint32_t a = faces[3 * (size_t)f + k], b = faces[3 * (size_t)f + (k + 1) % 3];   // edges (v1,v2), (v2,v3), (v3,v1): build_adjacency_graph.cpp:31-34
     keys[i] = (unsigned long long)min(a, b) << 32 | max(a, b);
     vals[i] = i;
+    if (a == b) atomicAdd(n_repeated, 1u);    // a face with a repeated vertex: the mesh takes adjacency_general_kernel
 }
 __global__ void invert_kernel(const uint32_t* __restrict__ vals, uint32_t n, uint32_t* __restrict__ pos) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,6 +75,64 @@ __global__ void adjacency_kernel(const unsigned long long* __restrict__ keys, co
         for (int m = 0; m < ns; ++m) adj[o++] = small[m];
         for (int m = 0; m < nl; ++m) adj[o++] = large[m];
     }
+}
+
+// The same lists for a mesh that has faces with a REPEATED vertex (a, a, b).  The reference asks MeshInfo for the faces of
+// every "edge" of a face (build_adjacency_graph.cpp:31-34); get_faces_for_edge(x, y) is the intersection of the two vertices'
+// face lists, so for the edge (a, a) it returns EVERY face at a.  Queries are then no longer symmetric (the repeated-vertex
+// face finds its neighbours, they do not find it), and add_edge order gives, for face f:
+//   [g < f whose queries find f, ascending] ++ [what f's own queries find, in query order, not yet listed]
+//   ++ [g > f whose queries find f but which f's queries did not find, ascending]
+// One thread per face over the union of the faces at its vertices (vertex -> faces CSR); a rare path, kept simple.
+constexpr int MAX_CANDIDATES = 128;
+template <bool WRITE>
+__global__ void adjacency_general_kernel(const uint32_t* __restrict__ faces, uint32_t n_faces, const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf,
+                                         uint32_t* __restrict__ cnt, const uint32_t* __restrict__ adj_ptr, uint32_t* __restrict__ adj, uint32_t* __restrict__ overflow) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_faces) return;
+    const uint32_t fv[3] = {faces[3 * (size_t)f], faces[3 * (size_t)f + 1], faces[3 * (size_t)f + 2]};
+    uint32_t cand[MAX_CANDIDATES];
+    int nc = 0;
+    bool over = false;
+    for (int j = 0; j < 3; ++j) {
+        if ((j > 0 && fv[j] == fv[0]) || (j > 1 && fv[j] == fv[1])) continue;
+        for (uint32_t p = vf_ptr[fv[j]]; p < vf_ptr[fv[j] + 1]; ++p) {
+            const uint32_t g = vf[p];
+            if (g == f) continue;                                  /* :41 avoid self referencing */
+            int at = 0;
+            while (at < nc && cand[at] < g) ++at;
+            if (at < nc && cand[at] == g) continue;
+            if (nc >= MAX_CANDIDATES) { over = true; continue; }
+            for (int m = nc; m > at; --m) cand[m] = cand[m - 1];
+            cand[at] = g; ++nc;
+        }
+    }
+    auto in_f = [&](uint32_t v) { return v == fv[0] || v == fv[1] || v == fv[2]; };
+    // does one of g's three queries return f?
+    auto finds_f = [&](uint32_t g) {
+        const uint32_t gv[3] = {faces[3 * (size_t)g], faces[3 * (size_t)g + 1], faces[3 * (size_t)g + 2]};
+        bool r = false;
+        for (int k = 0; k < 3; ++k) { const uint32_t x = gv[k], y = gv[(k + 1) % 3]; r = r || (in_f(x) && in_f(y)); }
+        return r;
+    };
+    // does f's query (x, y) return g?
+    auto query_has = [&](uint32_t g, uint32_t x, uint32_t y) {
+        const uint32_t g0 = faces[3 * (size_t)g], g1 = faces[3 * (size_t)g + 1], g2 = faces[3 * (size_t)g + 2];
+        return (g0 == x || g1 == x || g2 == x) && (g0 == y || g1 == y || g2 == y);
+    };
+    uint32_t out[MAX_NEIGHBOURS];
+    int no = 0;
+    auto listed = [&](uint32_t g) { bool r = false; for (int m = 0; m < no; ++m) r = r || out[m] == g; return r; };
+    auto push = [&](uint32_t g) { if (no >= MAX_NEIGHBOURS) over = true; else out[no++] = g; };
+    for (int c = 0; c < nc; ++c) if (cand[c] < f && finds_f(cand[c])) push(cand[c]);
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t x = fv[k], y = fv[(k + 1) % 3];
+        for (int c = 0; c < nc; ++c) if (query_has(cand[c], x, y) && !listed(cand[c])) push(cand[c]);
+    }
+    for (int c = 0; c < nc; ++c) if (cand[c] > f && finds_f(cand[c]) && !listed(cand[c])) push(cand[c]);
+    if (over) atomicAdd(overflow, 1u);
+    if (!WRITE) { cnt[f] = (uint32_t)no; if (f == 0) cnt[n_faces] = 0; }
+    else { uint32_t o = adj_ptr[f]; for (int m = 0; m < no; ++m) adj[o++] = out[m]; }
 }
 
 // remove_redundant_faces (prepare_mesh.cpp:14-55): keep[f] = 0 iff a face g > f touching a vertex of f has all its vertices in f
@@ -128,10 +189,24 @@ uint64_t build_adjacency(mvs_ctx* ctx, const uint32_t* d_faces, uint32_t F, uint
     const uint32_t n = 3 * F;
     ctx->g_keys.ensure(n); ctx->g_keys2.ensure(n); ctx->g_vals.ensure(n); ctx->g_vals2.ensure(n); ctx->g_pos.ensure(n); ctx->g_cnt.ensure((size_t)F + 2);
     ctx->m_moved.ensure(8);
-    uint32_t* overflow = ctx->m_moved.p + 6;
-    MVS_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
-    hipLaunchKernelGGL(edge_key_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_faces, F, ctx->g_keys.p, ctx->g_vals.p);
+    uint32_t* overflow = ctx->m_moved.p + 6;     // [0] overflow, [1] edges (a, a)
+    MVS_HIP(hipMemsetAsync(overflow, 0, 2 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(edge_key_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_faces, F, ctx->g_keys.p, ctx->g_vals.p, overflow + 1);
     MVS_LAUNCH_CHECK();
+    if (read_u32(ctx, overflow + 1)) {           // faces with a repeated vertex: asymmetric edge queries, general kernel
+        build_vertex_faces(ctx, d_faces, F, NV);
+        hipLaunchKernelGGL(adjacency_general_kernel<false>, dim3((F + 127) / 128), dim3(128), 0, s, d_faces, F, (const uint32_t*)ctx->vf_ptr.p,
+                           (const uint32_t*)ctx->vf.p, ctx->g_cnt.p, (const uint32_t*)nullptr, (uint32_t*)nullptr, overflow);
+        MVS_LAUNCH_CHECK();
+        exclusive_scan_u32(ctx, ctx->g_cnt.p, ctx->g_adj_ptr.p, (size_t)F + 1, nullptr);
+        const uint32_t total = read_u32(ctx, ctx->g_adj_ptr.p + F);
+        if (read_u32(ctx, overflow)) throw StatusError(MVS_ERR_UNSUPPORTED, "a face has more than 48 distinct neighbours (or a repeated vertex with more than 128 faces)");
+        ctx->g_adj.ensure((size_t)total + 1);
+        hipLaunchKernelGGL(adjacency_general_kernel<true>, dim3((F + 127) / 128), dim3(128), 0, s, d_faces, F, (const uint32_t*)ctx->vf_ptr.p,
+                           (const uint32_t*)ctx->vf.p, ctx->g_cnt.p, (const uint32_t*)ctx->g_adj_ptr.p, ctx->g_adj.p, overflow);
+        MVS_LAUNCH_CHECK();
+        return total;
+    }
     int vbits = 1; while ((1ull << vbits) < (unsigned long long)NV + 1 && vbits < 32) ++vbits;
     size_t tmp_bytes = 0;
     MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->g_keys.p, ctx->g_keys2.p, ctx->g_vals.p, ctx->g_vals2.p, n, 0, 32 + vbits, s));

@@ -1146,7 +1146,16 @@ int orc_build_adjacency(uint32_t n_faces, const uint32_t* faces, uint32_t** adj_
         for (int k = 0; k < 3; ++k) recs.push_back({ekey(faces[3 * (size_t)f + k], faces[3 * (size_t)f + (k + 1) % 3]), f});
     std::vector<EdgeRec> sorted(recs);
     std::stable_sort(sorted.begin(), sorted.end(), [](const EdgeRec& a, const EdgeRec& b) { return a.key < b.key; });
+    /* mve::MeshInfo::get_faces_for_edge(v1, v2) (MVE, absent; recollection -- DEFINED HERE): the faces in v1's list that are also in
+     * v2's list, ascending.  For v1 != v2 these are the faces owning the edge; for a face with a repeated vertex the reference asks
+     * for the "edge" (a, a) and gets EVERY face at a. */
+    uint32_t n_verts = 0;
+    for (size_t i = 0; i < 3 * (size_t)n_faces; ++i) n_verts = std::max(n_verts, faces[i] + 1);
+    std::vector<std::vector<uint32_t>> vfaces(n_verts);
+    for (uint32_t f = 0; f < n_faces; ++f)
+        for (int k = 0; k < 3; ++k) { auto& l = vfaces[faces[3 * (size_t)f + k]]; if (l.empty() || l.back() != f) l.push_back(f); }
     auto faces_for_edge = [&](uint64_t key, std::vector<uint32_t>* out) {
+        if ((uint32_t)(key >> 32) == (uint32_t)key) { const auto& l = vfaces[(uint32_t)key]; out->insert(out->end(), l.begin(), l.end()); return; }
         auto lo = std::lower_bound(sorted.begin(), sorted.end(), key, [](const EdgeRec& r, uint64_t k) { return r.key < k; });
         for (; lo != sorted.end() && lo->key == key; ++lo) out->push_back(lo->face);
     };

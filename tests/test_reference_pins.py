@@ -495,9 +495,9 @@ def test_view_selection_equals_the_reference_model_and_decode(R):
 # ---------------------------------------------------------------------------------------------------------------------
 def test_prepare_mesh_and_adjacency_equal_the_reference_functions(R):
     """row f1: tex::prepare_mesh (redundant-face removal, prepare_mesh.cpp:14-56) and tex::build_adjacency_graph
-    (build_adjacency_graph.cpp:16-53, through the reference's own UniGraph) on closed, open, duplicated and
+    (build_adjacency_graph.cpp:16-53, through the reference's own UniGraph) on closed, open, duplicated, degenerate and
     non-manifold meshes and on the test scenes: kept faces, face normals and adjacency lists element for element
-    (faces with a repeated vertex: prepare_mesh equal, adjacency differs around the repeated vertex -- see below).
+    (a face with a repeated vertex a is adjacent to EVERY face at a: upstream asks for the faces of the "edge" (a, a)).
     mve::MeshInfo is a stand-in with ascending face lists (only a non-manifold edge can see that order) and face normals
     follow the oracle's definition (oracle/ref_stubs/mve/mesh{,_info}.h)."""
     from test_oracle import _f1_meshes
@@ -519,16 +519,6 @@ def test_prepare_mesh_and_adjacency_equal_the_reference_functions(R):
         optr = np.zeros(F + 1, np.uint32); oadj = np.zeros(max(len(ad_o), 1) + 64, np.uint32)
         edges = R.ref_build_adjacency(len(verts), F, _p(faces), _p(optr), _p(oadj), len(oadj))
         assert edges * 2 == optr[-1]
-        if name == "degenerate":
-            # KNOWN DIFFERENCE, faces with a repeated vertex only: upstream asks for the faces of the "edge" (a, a), which a
-            # vertex-list intersection answers with EVERY face at a, while the oracle / product match edge keys and connect
-            # such a face only through its proper edge.  Everything away from the repeated vertices is identical.
-            rep = {int(f[k]) for f in faces if len(set(f.tolist())) < 3 for k in range(3) if list(f).count(f[k]) > 1}
-            touched = np.array([bool(rep & set(f.tolist())) for f in faces])
-            for i in np.nonzero(~touched)[0]:
-                assert oadj[optr[i]:optr[i + 1]].tolist() == ad_o[ap_o[i]:ap_o[i + 1]].tolist(), (name, i)
-            assert touched.sum() < 16
-            continue
         assert np.array_equal(optr, ap_o) and np.array_equal(oadj[:optr[-1]], ad_o), name
     s = get_scene("bumpy")
     ap_o, ad_o = O.build_adjacency(s.faces)
