@@ -117,6 +117,23 @@ def test_many_views_against_live_oracle(ctx):
     assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
 
 
+@pytest.mark.parametrize("kw", [dict(data_term="gmi", outlier_removal="gauss_damping"), dict(data_term="area", outlier_removal="gauss_clamping")],
+                         ids=["gmi_damp", "area_clamp"])
+def test_many_views_outlier_removal_against_live_oracle(ctx, kw):
+    """photometric_outlier_detection where it really iterates: 100-250 candidate views per face (the other scenes have at
+    most 4, where the loop exits at once).  Ten rounds of mean / covariance / 3x3 LU / Gauss weights per face, clamping
+    erases ~9 % of the entries, damping rescales every quality: sparsity pattern, qualities and costs bit-equal to the
+    oracle, which is itself bit-equal to upstream's calculate_data_costs.cpp on this scene (tests/test_reference_pins.py)."""
+    s = get_scene("manyviews")
+    _load_scene(ctx, s)
+    ref, rst = O.data_costs(s, **kw)
+    plain, _ = O.data_costs(s, data_term=kw["data_term"])
+    assert ref.nnz < plain.nnz or not np.array_equal(ref.cost, plain.cost)          # the mode does something here
+    st = ctx.data_costs(M.Settings(**kw))
+    _assert_costs(ctx.costs_download(), ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+    assert st["nnz_pre"] == rst["nnz_pre"] and np.float32(st["percentile"]) == np.float32(rst["percentile"])
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_ray_traversal_modes_give_the_oracle_booleans(mode):
     """per-ray traversal, shared (packet) traversal and packet + leaf work redistribution: same occlusion decisions"""
