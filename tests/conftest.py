@@ -41,8 +41,25 @@ SCENES = {
 _scene_cache = {}
 
 
+def _mixed_scene():
+    """one mesh seen by views of DIFFERENT image sizes (every TextureView carries its own width / height, texture_view.h:43-48):
+    even views 320x240, odd views 333x251 zoomed, view 1 with a black corner (the flood fill of a non-multiple-of-32 image)"""
+    import mvs_texturing_amd as M
+    kw = dict(n=10, n_views=10, displacement=0.2, layout=1)
+    a = M.synth.make_scene(width=320, height=240, **kw)
+    b = M.synth.make_scene(width=333, height=251, zoom_odd=1.3, **kw)
+    s = a
+    for j in range(1, s.n_views, 2):
+        for k in s.cams:
+            s.cams[k][j] = b.cams[k][j]
+        s.images[j] = b.images[j]
+    # a black corner on one of the odd-sized images (make_scene only puts it on view 0)
+    img = s.images[1].copy(); img[:25, :25] = 0; s.images[1] = img
+    return s
+
+
 def get_scene(name):
     import mvs_texturing_amd as M
     if name not in _scene_cache:
-        _scene_cache[name] = M.synth.make_scene(**SCENES[name])
+        _scene_cache[name] = _mixed_scene() if name == "mixed" else M.synth.make_scene(**SCENES[name])
     return _scene_cache[name]

@@ -117,6 +117,23 @@ def test_many_views_against_live_oracle(ctx):
     assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
 
 
+def test_mixed_image_sizes_against_live_oracle(ctx):
+    """every TextureView carries its own width / height (texture_view.h:43-48): 320x240 and 333x251 views in ONE scene --
+    per-view mask / image offsets, the vectorised and the generic image-prep kernels side by side"""
+    s = get_scene("mixed")
+    assert len(set(s.cams["width"].tolist())) == 2
+    _load_scene(ctx, s)
+    for kw in (dict(), dict(data_term="area", outlier_removal="gauss_clamping"), dict(geometric_visibility_test=False)):
+        ref, rst = O.data_costs(s, **kw)
+        st = ctx.data_costs(M.Settings(**kw))
+        _assert_costs(ctx.costs_download(), ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
+            assert st[k] == rst[k], k
+    lo, so = O.view_selection(ref, s.adj_ptr, s.adj)
+    lg, sg = ctx.view_selection(s.adj_ptr, s.adj)
+    assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"]
+
+
 @pytest.mark.parametrize("kw", [dict(data_term="gmi", outlier_removal="gauss_damping"), dict(data_term="area", outlier_removal="gauss_clamping")],
                          ids=["gmi_damp", "area_clamp"])
 def test_many_views_outlier_removal_against_live_oracle(ctx, kw):

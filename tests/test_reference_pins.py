@@ -324,6 +324,8 @@ _DC_CASES = [("tiny", dt, orm, gv) for dt in ("gmi", "area") for orm in ("none",
             [("oddw", "gmi", "none", True), ("oddw", "area", "gauss_clamping", True), ("oddw", "gmi", "gauss_damping", True),
              ("bumpy", "gmi", "none", True), ("bumpy", "gmi", "gauss_damping", True), ("bumpy", "area", "gauss_clamping", False),
              ("c1", "gmi", "none", True),
+             # views of different image sizes in one scene
+             ("mixed", "gmi", "none", True), ("mixed", "area", "gauss_clamping", True),
              # hundreds of infos per face: the outlier loop runs its iterations on real colour sets (clamping erases ~9 % of the entries)
              ("manyviews", "gmi", "gauss_damping", True), ("manyviews", "area", "gauss_clamping", True)]
 
