@@ -275,7 +275,7 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
         MVS_HIP(hipMemcpyAsync(&changed, d_changed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MVS_HIP(hipStreamSynchronize(s));
         if (!changed) break;
-        if (iter > 100000) throw HipError("validity mask flood fill did not converge");
+        if ((size_t)iter * 16 > (size_t)maxw * (size_t)maxh + 16) throw HipError("validity mask flood fill did not converge");   // a fill gains >= 1 pixel per step
     }
     // ra holds the converged reach set; the final mask must land in mask_all
     uint32_t* reach = ra;

@@ -117,6 +117,34 @@ def test_many_views_against_live_oracle(ctx):
     assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
 
 
+def test_hostile_validity_masks_against_live_oracle(ctx):
+    """generate_validity_mask (texture_view.cpp:42-94) on images built to break a parallel flood fill: everything black, a
+    one-pixel spiral from a corner (thousands of Jacobi steps), a frame with an unreachable island, a serpentine, a
+    diagonal-only contact (4-connectivity), a checkerboard, single corner pixels; with (gmi) and without (area) erosion.
+    The masks decide the "outside" cull, so the tables and cull counters must equal the oracle's, whose masks equal
+    upstream's own code on the same patterns (tests/test_reference_pins.py)."""
+    import copy
+    from util_cases import hostile_images
+    s = copy.copy(get_scene("tiny"))
+    w, h = int(s.cams["width"][0]), int(s.cams["height"][0])
+    pats = hostile_images(np.random.default_rng(5), w, h)
+    s.images = list(s.images)
+    for j, (name, img) in enumerate(pats.items()):
+        s.images[j] = img
+    assert len(pats) < s.n_views                                   # at least one ordinary view remains
+    _load_scene(ctx, s)
+    outside = []
+    for kw in (dict(), dict(data_term="area")):
+        ref, rst = O.data_costs(s, **kw)
+        st = ctx.data_costs(M.Settings(**kw))
+        _assert_costs(ctx.costs_download(), ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
+            assert st[k] == rst[k], k
+        outside.append(st["cull_outside"])
+        assert not (ref.view_id == 0).any()                        # nothing survives in the all-black view
+    assert outside[0] > outside[1] > 0                              # erosion (gmi) invalidates more than the plain mask (area)
+
+
 def test_mixed_image_sizes_against_live_oracle(ctx):
     """every TextureView carries its own width / height (texture_view.h:43-48): 320x240 and 333x251 views in ONE scene --
     per-view mask / image offsets, the vectorised and the generic image-prep kernels side by side"""

@@ -204,6 +204,20 @@ def test_validity_mask_and_valid_pixel_equal_the_reference(R):
             assert 0 < a.sum() < len(a)
         # erosion removes valid positions, the flood fill did invalidate the corner blob but not the island
         assert a.sum() < b.size
+    # hostile patterns: everything black, a one-pixel spiral, a frame with an island, a serpentine, a diagonal contact,
+    # a checkerboard, single corner pixels -- every pixel position, with and without erosion
+    from util_cases import hostile_images
+    for (w, h) in ((96, 72), (45, 38)):
+        gx, gy = np.meshgrid(np.arange(-1, w + 1), np.arange(-1, h + 1))
+        xy = np.ascontiguousarray(np.stack([gx.ravel(), gy.ravel()], 1), dtype=np.float32)
+        for name, img in hostile_images(rng, w, h).items():
+            for erode in (0, 1):
+                a, b = np.zeros(len(xy), np.uint8), np.zeros(len(xy), np.uint8)
+                OL.orc_valid_pixel_map(_p(img), w, h, erode, _p(xy), len(xy), _p(a))
+                R.ref_valid_pixel_map(_p(img), w, h, erode, _p(xy), len(xy), _p(b))
+                assert np.array_equal(a, b), (name, w, h, erode)
+            if name == "all_black":
+                assert a.sum() == 0
 
 
 def test_get_face_info_equals_the_reference(R):

@@ -58,3 +58,38 @@ def brute_force_optimum(col_ptr, view_id, cost, adj_ptr, adj):
         if best is None or e < best:
             best = e
     return best
+
+
+def hostile_images(rng, w, h):
+    """images whose black (channel sum 0) areas stress a corner flood fill (texture_view.cpp:42-94): name -> (h, w, 3) u8.
+    Everything not mentioned is noise >= 1."""
+    def noise():
+        return rng.integers(1, 255, (h, w, 3)).astype(np.uint8)
+    out = {}
+    out["all_black"] = np.zeros((h, w, 3), np.uint8)
+    img = noise()                                                  # a one-pixel spiral from the corner (0, 0), pitch 8: the longest chain
+    x0, y0, x1, y1 = 0, 0, w - 1, h - 1
+    while x1 - x0 > 16 and y1 - y0 > 16:
+        img[y0, x0:x1 + 1] = 0; img[y0:y1 + 1, x1] = 0; img[y1, x0 + 8:x1 + 1] = 0; img[y0 + 8:y1 + 1, x0 + 8] = 0
+        img[y0 + 8, x0 + 8:x0 + 17] = 0
+        x0 += 8; y0 += 8; x1 -= 8; y1 -= 8
+        img[y0, x0:x0 + 9] = 0
+    out["spiral"] = img
+    img = noise(); img[:6] = 0; img[-6:] = 0; img[:, :6] = 0; img[:, -6:] = 0
+    img[h // 2 - 5:h // 2 + 5, w // 2 - 7:w // 2 + 7] = 0          # island: black but unreachable, stays valid
+    out["frame_island"] = img
+    img = noise()                                                  # serpentine: rows every 6 px joined alternately left / right
+    for k, y in enumerate(range(0, h - 1, 6)):
+        img[y, :] = 0
+        if y + 6 < h:
+            img[y:y + 6, (w - 1) if k % 2 == 0 else 0] = 0
+        img[y, 0 if k % 2 == 0 else w - 1] = 0
+    out["serpentine"] = img
+    img = noise(); img[:10, :10] = 0; img[10:20, 10:20] = 0        # second block touches the corner blob only diagonally: NOT filled (4-connected)
+    out["diagonal"] = img
+    img = noise(); img[::2, ::2] = 0; img[1::2, 1::2] = 0          # checkerboard: only the corner pixels themselves
+    out["checker"] = img
+    img = noise(); img[0, 0] = (0, 0, 0); img[0, w - 1] = (0, 0, 1); img[h - 1, 0] = (1, 0, 0)
+    img[h - 1, w - 1] = 0; img[h - 1, w - 40:] = 0                 # one black corner pixel, two almost-black corners, a strip from the fourth
+    out["corners"] = img
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}
