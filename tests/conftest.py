@@ -36,6 +36,10 @@ SCENES = {
     # hundreds of views per face (the shape of BASELINE config 5 at a size the oracle finishes in seconds): columns of
     # 130-250 labels take the one-node-per-wave sweep path, the CSR transposition walks several 64-view rounds
     "manyviews": dict(n=16, n_views=700, width=160, height=120, displacement=0.05, layout=1),
+    # 180 faces in 1024x768 zoomed views: footprints of up to 30 000 pixels (long fp64 scan-order sums, many scan lines)
+    "bigfoot": dict(n=3, n_views=8, width=1024, height=768, displacement=0.1, layout=1, zoom_odd=1.5),
+    # cameras at 1.3 radii from a surface that reaches 1.2: grazing angles, steep perspective inside one footprint
+    "close": dict(n=8, n_views=8, width=320, height=240, displacement=0.2, layout=1, radius=1.3),
 }
 
 _scene_cache = {}

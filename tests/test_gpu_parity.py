@@ -145,6 +145,24 @@ def test_hostile_validity_masks_against_live_oracle(ctx):
     assert outside[0] > outside[1] > 0                              # erosion (gmi) invalidates more than the plain mask (area)
 
 
+@pytest.mark.parametrize("name", ["bigfoot", "close"])
+def test_large_footprints_and_close_cameras_against_live_oracle(ctx, name):
+    """get_face_info (texture_view.cpp:134-251) far from the usual few-pixel footprint: up to 30 000 samples per face
+    accumulated in fp64 in scan order (bigfoot), and cameras 0.1 radii above the surface (close); all three outlier
+    modes and both data terms, bit-equal to the oracle"""
+    s = get_scene(name)
+    _load_scene(ctx, s)
+    for kw in (dict(), dict(data_term="area", outlier_removal="gauss_damping"), dict(data_term="gmi", outlier_removal="gauss_clamping")):
+        ref, rst = O.data_costs(s, **kw)
+        st = ctx.data_costs(M.Settings(**kw))
+        _assert_costs(ctx.costs_download(), ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
+            assert st[k] == rst[k], k
+    if name == "bigfoot":
+        area, _ = O.data_costs(s, data_term="area")
+        assert area.quality.max() > 20000.0
+
+
 def test_mixed_image_sizes_against_live_oracle(ctx):
     """every TextureView carries its own width / height (texture_view.h:43-48): 320x240 and 333x251 views in ONE scene --
     per-view mask / image offsets, the vectorised and the generic image-prep kernels side by side"""

@@ -338,6 +338,8 @@ _DC_CASES = [("tiny", dt, orm, gv) for dt in ("gmi", "area") for orm in ("none",
             [("oddw", "gmi", "none", True), ("oddw", "area", "gauss_clamping", True), ("oddw", "gmi", "gauss_damping", True),
              ("bumpy", "gmi", "none", True), ("bumpy", "gmi", "gauss_damping", True), ("bumpy", "area", "gauss_clamping", False),
              ("c1", "gmi", "none", True),
+             # footprints of tens of thousands of pixels; cameras almost touching the surface
+             ("bigfoot", "gmi", "none", True), ("bigfoot", "area", "gauss_damping", True), ("close", "gmi", "gauss_clamping", True),
              # views of different image sizes in one scene
              ("mixed", "gmi", "none", True), ("mixed", "area", "gauss_clamping", True),
              # hundreds of infos per face: the outlier loop runs its iterations on real colour sets (clamping erases ~9 % of the entries)
