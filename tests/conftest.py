@@ -38,6 +38,9 @@ SCENES = {
     "manyviews": dict(n=16, n_views=700, width=160, height=120, displacement=0.05, layout=1),
     # 180 faces in 1024x768 zoomed views: footprints of up to 30 000 pixels (long fp64 scan-order sums, many scan lines)
     "bigfoot": dict(n=3, n_views=8, width=1024, height=768, displacement=0.1, layout=1, zoom_odd=1.5),
+    # strongly displaced surfaces: 40 % of the front-facing (face, view) pairs are occluded; rays graze silhouettes
+    "spiky": dict(n=16, n_views=14, width=400, height=300, displacement=0.45, layout=1, seed=77),
+    "spiky32": dict(n=32, n_views=10, width=512, height=384, displacement=0.35, layout=1, seed=5, zoom_odd=1.2),
     # cameras at 1.3 radii from a surface that reaches 1.2: grazing angles, steep perspective inside one footprint
     "close": dict(n=8, n_views=8, width=320, height=240, displacement=0.2, layout=1, radius=1.3),
 }

@@ -211,6 +211,24 @@ def test_ray_traversal_modes_give_the_oracle_booleans(mode):
     c.close()
 
 
+@pytest.mark.parametrize("name", ["spiky", "spiky32"])
+def test_heavy_occlusion_against_live_oracle(name):
+    """strongly displaced surfaces (40 % of the candidate pairs occluded, rays grazing silhouettes, 20 480 triangles = 40
+    refinement windows and one more BVH level than the other scenes): the occlusion decisions of the packet traversal and
+    of the per-ray traversal equal the oracle's, whose BVH equals its own brute-force loop (tests/test_oracle.py)"""
+    s = get_scene(name)
+    ref, rst = O.data_costs(s)
+    assert rst["cull_occluded"] * 3 > ref.nnz
+    for mode in (2, 0):
+        c = M.Context(0); c.set_option("stats", 1); c.set_option("ray_mode", mode)
+        _load_scene(c, s)
+        st = c.data_costs(M.Settings())
+        got = c.costs_download()
+        assert st["cull_occluded"] == rst["cull_occluded"]
+        _assert_costs(got, ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        c.close()
+
+
 def test_face_range_sharding_of_data_costs(ctx):
     """faces [a, b) against the full occluder set == the same rows of the full run (qualities; the
     percentile of a shard is local until the driver all-reduces max + histogram)"""

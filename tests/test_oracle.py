@@ -59,7 +59,7 @@ def test_reference_properties_bumpy():
 
 def test_bvh_equals_brute_force():
     """the any-hit boolean does not depend on the acceleration structure"""
-    for name in ("tiny", "bumpy"):
+    for name in ("tiny", "bumpy", "spiky"):
         s = get_scene(name)
         a, sa = O.data_costs(s, brute=False)
         b, sb = O.data_costs(s, brute=True)
