@@ -1120,6 +1120,107 @@ uint64_t orc_energy(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_
     return unary + (cuts << 32);
 }
 
+// A LOWER BOUND on the minimum of E over all labelings (the LP relaxation's dual, by MPLP block coordinate ascent:
+// Globerson & Jaakkola 2007), in fp64.  No labeling -- mapMAP's included -- has a smaller energy, so
+// (E(our labels) - bound) / bound bounds how much better ANY solver could do: the quality statement that stands in for
+// the unavailable label-for-label comparison with mapMAP.  Dual variables lam_{e->i}(x_i) per edge side with
+// lam_{e->i}(x_i) + lam_{e->j}(x_j) <= [x_i != x_j] maintained by every update; bound = sum_i min_x (D_i(x) + sum_e lam_{e->i}(x))
+// + 1 per face without candidates (as orc_energy counts them).  trace[0..iters) receives the bound after each round.
+double orc_mrf_lower_bound(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj, int iters, int n_threads, double* trace) {
+    const uint32_t F = costs->n_faces;
+    auto K = [&](uint32_t i) { return costs->col_ptr[i + 1] - costs->col_ptr[i]; };
+    struct Edge { uint32_t i, j; size_t oi, oj; };   // message offsets of the two sides
+    std::vector<Edge> edges;
+    size_t total = 0;
+    double constant = 0.0;
+    for (uint32_t i = 0; i < F; ++i) {
+        if (K(i) == 0) { constant += 1.0; continue; }
+        for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+            const uint32_t j = adj[e];
+            if (j <= i || K(j) == 0) continue;
+            edges.push_back({i, j, total, total + K(i)});
+            total += (size_t)K(i) + K(j);
+        }
+    }
+    std::vector<double> lam(total, 0.0), b((size_t)costs->col_ptr[F]);
+    for (size_t k = 0; k < b.size(); ++k) b[k] = (double)costs->cost[k];
+    // greedy edge colouring: edges of one colour share no node, so a colour class is updated in parallel (any order ascends)
+    std::vector<std::vector<uint32_t>> classes;
+    {
+        std::vector<std::vector<bool>> used(F);
+        for (uint32_t e = 0; e < edges.size(); ++e) {
+            auto &ui = used[edges[e].i], &uj = used[edges[e].j];
+            size_t c = 0;
+            while ((c < ui.size() && ui[c]) || (c < uj.size() && uj[c])) ++c;
+            if (ui.size() <= c) ui.resize(c + 1, false);
+            if (uj.size() <= c) uj.resize(c + 1, false);
+            ui[c] = uj[c] = true;
+            if (classes.size() <= c) classes.resize(c + 1);
+            classes[c].push_back(e);
+        }
+    }
+    if (n_threads <= 0) n_threads = 1;
+    auto bound = [&]() {
+        double s = constant;
+        for (uint32_t i = 0; i < F; ++i) {
+            if (K(i) == 0) continue;
+            double m = INFINITY;
+            for (uint32_t k = costs->col_ptr[i]; k < costs->col_ptr[i + 1]; ++k) m = std::min(m, b[k]);
+            s += m;
+        }
+        return s;
+    };
+    for (int it = 0; it < iters; ++it) {
+        for (const auto& cls : classes) {
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (cls.size() > 2048)
+        for (int64_t ce = 0; ce < (int64_t)cls.size(); ++ce) {
+            const Edge& ed = edges[cls[ce]];
+            const uint32_t ci = costs->col_ptr[ed.i], cj = costs->col_ptr[ed.j], ki = K(ed.i), kj = K(ed.j);
+            std::vector<double> ai(ki), aj(kj);
+            double mi = INFINITY, mj = INFINITY;
+            for (uint32_t x = 0; x < ki; ++x) { ai[x] = b[ci + x] - lam[ed.oi + x]; mi = std::min(mi, ai[x]); }
+            for (uint32_t x = 0; x < kj; ++x) { aj[x] = b[cj + x] - lam[ed.oj + x]; mj = std::min(mj, aj[x]); }
+            // min over the other side of [x != x'] + a(x'): 1 + its minimum, or its value at the same view (lists ascend by view id)
+            uint32_t y = 0;
+            for (uint32_t x = 0; x < ki; ++x) {
+                const uint16_t v = costs->view_id[ci + x];
+                while (y < kj && costs->view_id[cj + y] < v) ++y;
+                double m = 1.0 + mj;
+                if (y < kj && costs->view_id[cj + y] == v) m = std::min(m, aj[y]);
+                const double l = -0.5 * ai[x] + 0.5 * m;
+                lam[ed.oi + x] = l; b[ci + x] = ai[x] + l;
+            }
+            y = 0;
+            for (uint32_t x = 0; x < kj; ++x) {
+                const uint16_t v = costs->view_id[cj + x];
+                while (y < ki && costs->view_id[ci + y] < v) ++y;
+                double m = 1.0 + mi;
+                if (y < ki && costs->view_id[ci + y] == v) m = std::min(m, ai[y]);
+                const double l = -0.5 * aj[x] + 0.5 * m;
+                lam[ed.oj + x] = l; b[cj + x] = aj[x] + l;
+            }
+        }
+        }
+        if (trace) trace[it] = bound();
+    }
+    // feasibility, checked rather than assumed (rounding): the largest violation of lam_i(x) + lam_j(x') <= [x != x'] is subtracted
+    double slack = 0.0;
+    for (const Edge& ed : edges) {
+        const uint32_t ci = costs->col_ptr[ed.i], cj = costs->col_ptr[ed.j], ki = K(ed.i), kj = K(ed.j);
+        double mxi = -INFINITY, mxj = -INFINITY, same = -INFINITY;
+        for (uint32_t x = 0; x < ki; ++x) mxi = std::max(mxi, lam[ed.oi + x]);
+        for (uint32_t x = 0; x < kj; ++x) mxj = std::max(mxj, lam[ed.oj + x]);
+        uint32_t y = 0;
+        for (uint32_t x = 0; x < ki; ++x) {
+            const uint16_t v = costs->view_id[ci + x];
+            while (y < kj && costs->view_id[cj + y] < v) ++y;
+            if (y < kj && costs->view_id[cj + y] == v) same = std::max(same, lam[ed.oi + x] + lam[ed.oj + y]);
+        }
+        slack += std::max(0.0, std::max(same, mxi + mxj - 1.0));
+    }
+    return bound() - slack;
+}
+
 int orc_icm_baseline(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
                      int max_iters, uint32_t* labels) {
     orc_mrf_params P; orc_mrf_default_params(&P);

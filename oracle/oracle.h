@@ -153,6 +153,9 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
  * generate_texture_patches.cpp:105-109). */
 uint64_t orc_energy(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
                     const uint32_t* labels, uint64_t* cut_edges);
+/* a LOWER BOUND on min E (dual of the LP relaxation, MPLP coordinate ascent, fp64): no labeling has a smaller energy;
+ * trace (may be null) receives the bound after each of the `iters` rounds */
+double orc_mrf_lower_bound(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj, int iters, int n_threads, double* trace);
 /* plain ICM from the per-face argmin-unary labeling (energy sanity baseline) */
 int orc_icm_baseline(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
                      int max_iters, uint32_t* labels);

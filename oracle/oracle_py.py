@@ -194,6 +194,17 @@ def energy(csr, adj_ptr, adj, labels):
     return int(e), int(cuts.value)
 
 
+def lower_bound(csr, adj_ptr, adj, iters=200, timing=False, n_threads=0):
+    """(bound, trace): a lower bound on the minimum energy (LP dual by MPLP), in energy units"""
+    L = load(timing)
+    L.orc_mrf_lower_bound.restype = C.c_double
+    L.orc_mrf_lower_bound.argtypes = [C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    cs = csr.as_struct(); trace = np.zeros(max(iters, 1), np.float64)
+    lb = L.orc_mrf_lower_bound(C.byref(cs), _ptr(np.ascontiguousarray(adj_ptr, dtype=np.uint32)),
+                               _ptr(np.ascontiguousarray(adj, dtype=np.uint32)), iters, _threads(n_threads), _ptr(trace))
+    return float(lb), trace[:iters]
+
+
 def icm_baseline(csr, adj_ptr, adj, max_iters=200):
     L = load()
     cs = csr.as_struct(); labels = np.zeros(csr.n_faces, dtype=np.uint32)
