@@ -229,6 +229,23 @@ def test_heavy_occlusion_against_live_oracle(name):
         c.close()
 
 
+@pytest.mark.parametrize("name,kw", [("spiky32", dict()), ("close", dict(data_term="area")), ("mixed", dict(outlier_removal="gauss_damping")),
+                                     ("manyviews", dict(outlier_removal="gauss_clamping"))], ids=["spiky32", "close_area", "mixed_damp", "manyviews_clamp"])
+def test_labels_on_the_stress_scenes_equal_the_oracle(ctx, name, kw):
+    """view selection on the tables of the stress scenes (heavy occlusion, close cameras with the area term, mixed image
+    sizes with damped qualities, 700 views after clamping erased 9 % of the entries): labels, energy, sweeps and ICM
+    rounds equal the oracle's"""
+    s = get_scene(name)
+    _load_scene(ctx, s)
+    ref, _ = O.data_costs(s, **kw)
+    ctx.data_costs(M.Settings(**kw))
+    p = dict(max_sweeps=40) if name == "manyviews" else dict()
+    lo, so = O.view_selection(ref, s.adj_ptr, s.adj, O.default_mrf_params(**p))
+    lg, sg = ctx.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(**p))
+    assert np.array_equal(lo, lg)
+    assert [so[k] for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters", "unseen")] == [sg[k] for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters", "unseen")]
+
+
 def test_face_range_sharding_of_data_costs(ctx):
     """faces [a, b) against the full occluder set == the same rows of the full run (qualities; the
     percentile of a shard is local until the driver all-reduces max + histogram)"""
