@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 if [ -z "$SKIP_TESTS" ]; then echo "== pytest -m gpu ${PYTEST_K:+-k $PYTEST_K}"; ( time timeout 1200 python -m pytest tests -q -m gpu ${PYTEST_K:+-k "$PYTEST_K"} ) > gpurun_out/pytest_gpu.log 2>&1; tail -5 gpurun_out/pytest_gpu.log; fi
 echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-if [ -n "$DO_DIAG" ]; then echo "== diag $DO_DIAG"; timeout 900 python scripts/gpu_diag.py $DO_DIAG > gpurun_out/diag.log 2>&1; grep -v "^   " gpurun_out/diag.log | tail -20; fi
+if [ -n "$DO_DIAG" ]; then echo "== diag $DO_DIAG"; timeout 900 python tests/tools/gpu_diag.py $DO_DIAG > gpurun_out/diag.log 2>&1; grep -v "^   " gpurun_out/diag.log | tail -20; fi
 echo "== bench config ${BENCH_CONFIG:-3}"; ( time timeout 1200 python bench.py --config ${BENCH_CONFIG:-3} --steps 3 --warmup 1 ) > gpurun_out/bench.log 2> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.log
 if [ -n "$DO_MODE0" ]; then echo "== bench ray_mode 0"; MVS_RAY_MODE=0 timeout 1200 python bench.py --config ${BENCH_CONFIG:-3} --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['stages']['dc_rays'])"; fi
 if [ -n "$DO_VARIANTS" ]; then

@@ -1,7 +1,7 @@
-"""GPU diagnostic: HIP path vs CPU oracle on small / medium scenes, with timings.
-Usage (on the GPU box): python scripts/gpu_diag.py [stage ...]   -> prints to stdout"""
+"""GPU diagnostic (test infrastructure: lives under tests/ because it drives the oracle): HIP path vs CPU oracle on small / medium scenes, with timings.
+Usage (on the GPU box): python tests/tools/gpu_diag.py [stage ...]   -> prints to stdout"""
 import os, sys, time, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import mvs_texturing_amd as M

@@ -1,16 +1,16 @@
 """How far can ANY solver (mapMAP included) be below this one?  Energy of the oracle's labeling (== the GPU's, bit for
 bit) against a lower bound on the minimum energy (dual of the LP relaxation, MPLP coordinate ascent in fp64,
-oracle.cpp orc_mrf_lower_bound).  CPU only; test infrastructure.
+oracle.cpp orc_mrf_lower_bound).  CPU only; TEST INFRASTRUCTURE (lives under tests/ because it drives the oracle).
 
-    python scripts/lower_bound.py --config 2 --rounds 4000          # BASELINE config 2: ~2 min
-    python scripts/lower_bound.py --scene manyviews --rounds 3000
+    python tests/tools/lower_bound.py --config 2 --rounds 4000          # BASELINE config 2: ~2 min
+    python tests/tools/lower_bound.py --scene manyviews --rounds 3000
 """
 import argparse
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 
 import numpy as np  # noqa: E402
