@@ -224,24 +224,28 @@ def test_gloo_world2_equals_single_rank(tmp_path):
         assert st == [ref_stats["energy_fixed"], ref_stats["cut_edges"], ref_stats["sweeps"], ref_stats["icm_iters"]]
 
 
-def test_gloo_world2_with_sharded_tables_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_world2_with_sharded_tables_equals_single_rank(tmp_path, world):
     """as above, but every rank only holds the columns of its own faces and of their halo (the table sharded_data_costs
-    builds): message layouts differ between the ranks, the exchange lists still pair up element for element"""
+    builds): message layouts differ between the ranks, the exchange lists still pair up element for element.  With 4
+    ranks (the driver scales to 8) a rank has several peers, and pairs of parts that do not touch exchange nothing."""
     import torch
     import torch.multiprocessing as mp
     s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
     plan1 = G.HaloPlan(col_ptr, adj_ptr, adj, G.equal_parts(len(faces), 1), 0)
     params = M.viewsel.MrfParams(6, 6, 3, 0.0, 0.0, 1.0, 3)
     ref_labels, ref_stats = G.ShardedViewSelection(_FakeOps(col_ptr, adj_ptr, adj, torch, params), plan1, params, "cpu", None).run()
-    pb = G.equal_parts(len(faces), 2)
-    plans = [G.HaloPlan(_masked_col_ptr(col_ptr, adj_ptr, adj, pb, r), adj_ptr, adj, pb, r) for r in range(2)]
+    pb = G.equal_parts(len(faces), world)
+    plans = [G.HaloPlan(_masked_col_ptr(col_ptr, adj_ptr, adj, pb, r), adj_ptr, adj, pb, r) for r in range(world)]
     assert plans[0].total_words != G.HaloPlan(col_ptr, adj_ptr, adj, pb, 0).total_words          # really a smaller, different layout
-    assert len(plans[0].msg_send[1]) == len(plans[1].msg_recv[0]) and len(plans[1].msg_send[0]) == len(plans[0].msg_recv[1])
-    port = 29500 + (os.getpid() + 7) % 2000
-    mp.spawn(_run_rank, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
-    got = np.concatenate([np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(2)])
+    for a in range(world):
+        for b in range(world):
+            assert len(plans[a].msg_send[b]) == len(plans[b].msg_recv[a]) and len(plans[a].node_send[b]) == len(plans[b].node_recv[a])
+    port = 29500 + (os.getpid() + 7 * world) % 2000
+    mp.spawn(_run_rank, args=(world, port, str(tmp_path), True), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("labels_%d.npy" % r)) for r in range(world)])
     assert np.array_equal(got, ref_labels)
-    for r in range(2):
+    for r in range(world):
         st = np.load(tmp_path / ("stats_%d.npy" % r)).tolist()
         assert st == [ref_stats["energy_fixed"], ref_stats["cut_edges"], ref_stats["sweeps"], ref_stats["icm_iters"]]
 
