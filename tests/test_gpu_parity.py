@@ -780,3 +780,19 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     d2 = json.loads(lines[0])
     assert d2["n_gpus"] == 2 and d2["config"]["nnz"] == d1["config"]["nnz"]
     assert d2["config"]["sweeps"] == d1["config"]["sweeps"] and abs(d2["config"]["energy"] - d1["config"]["energy"]) < 1e-6   # partition invariance
+
+
+@pytest.mark.parametrize("seed,spread", [(0, 0.0), (2, 0.12), (3, 0.05)])
+def test_hostile_soup_against_live_oracle(ctx, seed, spread):
+    """input no sane pipeline produces (tests/util_cases.soup_scene): intersecting random triangles, repeated-vertex faces
+    with NaN normals, flipped normals, duplicates, a camera inside the geometry (negative depths).  The oracle equals
+    upstream's own calculate_data_costs.cpp on exactly these scenes (tests/test_reference_pins.py)."""
+    from util_cases import soup_scene
+    s = soup_scene(seed, spread=spread)
+    _load_scene(ctx, s)
+    for kw in (dict(), dict(data_term="area", outlier_removal="gauss_clamping"), dict(outlier_removal="gauss_damping", geometric_visibility_test=False)):
+        ref, rst = O.data_costs(s, **kw)
+        st = ctx.data_costs(M.Settings(**kw))
+        _assert_costs(ctx.costs_download(), ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
+            assert st[k] == rst[k], k

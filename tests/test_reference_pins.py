@@ -363,6 +363,24 @@ def test_data_costs_equal_the_reference_calculate_data_costs(R, name, data_term,
     assert len(vid) > 0 and (not geom or rays > 0)
 
 
+@pytest.mark.parametrize("seed,spread", [(0, 0.0), (1, 0.0), (2, 0.12), (3, 0.05), (4, 0.08)])
+def test_data_costs_on_a_hostile_soup_equal_the_reference(R, seed, spread):
+    """the same comparison on input no sane pipeline produces: intersecting random triangles, repeated-vertex faces (zero
+    area, NaN normals), flipped normals, duplicates, a camera INSIDE the geometry (faces behind it, negative depths):
+    every comparison with a NaN, every division by a non-positive depth takes the branch upstream's code takes"""
+    from util_cases import soup_scene
+    s = soup_scene(seed, spread=spread)
+    total = 0
+    for data_term, outlier, geom in (("gmi", "none", True), ("area", "gauss_clamping", True), ("gmi", "gauss_damping", False), ("area", "none", True)):
+        col_ptr, vid, cost, rays = _ref_data_costs(R, s, data_term, outlier, geom)
+        want, stats = O.data_costs(s, data_term=data_term, outlier_removal=outlier, geometric_visibility_test=geom)
+        assert np.array_equal(col_ptr, want.col_ptr) and np.array_equal(vid, want.view_id)
+        assert np.array_equal(cost.view(np.uint32), want.cost.view(np.uint32))
+        assert rays == stats["rays"]
+        total += len(vid)
+    assert total > (0 if spread == 0.0 else 300)          # the dense soup occludes almost everything, the loose one does not
+
+
 def test_outlier_detection_equals_the_reference_function(R):
     """row D1: photometric_outlier_detection (calculate_data_costs.cpp:35-129) itself, on synthetic colour sets that reach
     every exit: fewer than 4 inliers, covariance below 5e-4 (outliers zeroed), singular covariance (not invertible),

@@ -93,3 +93,49 @@ def hostile_images(rng, w, h):
     img[h - 1, w - 1] = 0; img[h - 1, w - 40:] = 0                 # one black corner pixel, two almost-black corners, a strip from the fourth
     out["corners"] = img
     return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def soup_scene(seed=0, n_verts=60, n_faces=250, n_views=7, w=200, h=150, spread=0.0):
+    """a HOSTILE data-cost input: random triangle soup (intersecting faces, repeated-vertex faces, duplicates, NaN and
+    flipped normals), cameras on a sphere around it plus one INSIDE it (faces behind the camera, projections with
+    negative depth), noise images with black corner blobs.  Returns a synth.Scene without adjacency."""
+    import mvs_texturing_amd as M
+    rng = np.random.default_rng(seed)
+    s = M.synth.Scene()
+    if spread > 0.0:      # small separate triangles around random centres: most of them are visible from somewhere
+        n_verts = 3 * n_faces
+        centres = np.repeat(rng.uniform(-0.8, 0.8, (n_faces, 3)), 3, axis=0)
+        s.verts = np.ascontiguousarray((centres + spread * rng.standard_normal((n_verts, 3))).astype(np.float32))
+        f = np.arange(n_verts, dtype=np.uint32).reshape(n_faces, 3)
+    else:
+        s.verts = np.ascontiguousarray(rng.uniform(-1, 1, (n_verts, 3)).astype(np.float32))
+        f = rng.integers(0, n_verts, (n_faces, 3)).astype(np.uint32)
+    m = rng.random(n_faces) < 0.05; f[m, 1] = f[m, 0]                      # repeated vertex
+    f[-5:] = f[:5]                                                         # duplicates
+    s.faces = np.ascontiguousarray(f)
+    a, b, c = s.verts[f[:, 0]], s.verts[f[:, 1]], s.verts[f[:, 2]]
+    n = np.cross(b - a, c - a).astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = (n / np.linalg.norm(n, axis=1, keepdims=True).astype(np.float32)).astype(np.float32)   # 0 / 0 = NaN for degenerate faces
+    flip = rng.random(n_faces) < 0.3; n[flip] = -n[flip]
+    s.normals = np.ascontiguousarray(n)
+    pos = rng.standard_normal((n_views, 3)); pos = 2.5 * pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    pos[-1] = [0.2, -0.1, 0.3]                                             # inside the soup
+    cams = {k: [] for k in ("pos", "viewdir", "K", "w2c", "width", "height")}
+    for j in range(n_views):
+        p = pos[j].astype(np.float32)
+        fwd = -p / np.linalg.norm(p) if j < n_views - 1 else np.float32([0.0, 0.6, 0.8])
+        up = np.float32([0.0, 0.0, 1.0]) if abs(fwd[2]) < 0.9 else np.float32([0.0, 1.0, 0.0])
+        right = np.cross(fwd, up); right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        R = np.stack([right, down, fwd]).astype(np.float32)
+        w2c = np.eye(4, dtype=np.float32); w2c[:3, :3] = R; w2c[:3, 3] = -(R @ p)
+        fl = np.float32(0.9 * max(w, h))
+        K = np.float32([[fl, 0, w / 2], [0, fl, h / 2], [0, 0, 1]])
+        cams["pos"].append(p); cams["viewdir"].append(fwd.astype(np.float32)); cams["K"].append(K.ravel()); cams["w2c"].append(w2c.ravel())
+        cams["width"].append(w); cams["height"].append(h)
+        img = rng.integers(1, 255, (h, w, 3)).astype(np.uint8)
+        img[: 10 + 5 * j, : 20 + 3 * j] = 0
+        s.images.append(np.ascontiguousarray(img))
+    s.cams = {k: np.ascontiguousarray(np.array(v, dtype=np.int32 if k in ("width", "height") else np.float32)) for k, v in cams.items()}
+    return s
