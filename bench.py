@@ -70,11 +70,106 @@ def cpu_baseline(scene, faces, normals, adj_ptr, adj, params_kw, budget_s=25.0):
     sadj = np.ascontiguousarray(sub[keep], dtype=np.uint32)
     t = time.time(); labels, ms = O.view_selection(csr, sap, sadj, O.default_mrf_params(timing=True, **params_kw), n_threads=best_nt, timing=True)
     t_mrf = ms["t_setup"] + ms["t_solve"]
-    return {"value": n_sample / (t_dc + t_mrf), "unit": "faces/s", "cores": best_nt, "kind": "port",
-            "sample": "first %d of %d faces (all %d views, full mesh as occluders) + MRF on their induced subgraph; "
+    return {"value": n_sample / (t_dc + t_mrf), "unit": "faces/s", "cores": best_nt, "kind": "port", "sampled": True,
+            "sample_faces": n_sample, "sample": "first %d of %d faces (all %d views, full mesh as occluders) + MRF on their induced subgraph; "
                       "oracle -O3 -march=native OpenMP; BVH build and per-view image prep excluded (favours the CPU); "
                       "t_data_costs=%.2fs t_mrf=%.2fs sweeps=%d" % (n_sample, F, s.n_views, t_dc, t_mrf, ms["sweeps"]),
             "host_cpus": ncpu}
+
+
+def induced_subgraph(adj_ptr, adj, n):
+    """adjacency CSR of the first n faces restricted to neighbours < n (list order kept)"""
+    ap = adj_ptr[:n + 1].astype(np.int64)
+    sub = adj[:ap[-1]]
+    keep = sub < n
+    ck = np.zeros(len(keep) + 1, dtype=np.int64); ck[1:] = np.cumsum(keep)
+    deg = ck[ap[1:]] - ck[ap[:-1]]
+    sap = np.zeros(n + 1, dtype=np.uint32); sap[1:] = np.cumsum(deg)
+    return sap, np.ascontiguousarray(sub[keep], dtype=np.uint32)
+
+
+def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, device):
+    """The checker leg (never timed): the table the LAST TIMED STEP left on the device against the parity build of the
+    oracle (-O2 -ffp-contract=off) on the first n_check faces -- sparsity pattern, view ids and qualities bit for bit --
+    and the GPU solver against the oracle's solver on that sample's own table + induced subgraph (labels, fixed-point
+    energy, sweeps).  Any difference makes bench.py exit non-zero after printing its line."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build_oracle()
+
+    class S:
+        pass
+    s = S(); s.verts, s.faces, s.normals, s.cams, s.images = scene.verts, faces, normals, scene.cams, scene.images
+    s.n_views, s.n_faces = scene.n_views, len(faces)
+    nt = max(1, min(32, len(os.sched_getaffinity(0))))
+    n = int(min(n_check, s.n_faces))
+    got = ctx.costs_download()
+    ref, _ = O.data_costs(s, face_range=(0, n), n_threads=nt)
+    end = int(got.col_ptr[n])
+    res = {"faces": n, "entries": int(ref.nnz)}
+    res["pattern_equal"] = bool(np.array_equal(ref.col_ptr, got.col_ptr[:n + 1]) and np.array_equal(ref.view_id, got.view_id[:end]))
+    res["quality_bits_equal"] = bool(res["pattern_equal"] and np.array_equal(ref.quality.view(np.uint32), got.quality[:end].view(np.uint32)))
+    del got
+    sap, sadj = induced_subgraph(adj_ptr, adj, n)
+    kw = dict(max_sweeps=params.max_sweeps, min_sweeps=params.min_sweeps)
+    lo, so = O.view_selection(ref, sap, sadj, O.default_mrf_params(**kw), n_threads=nt)
+    c2 = M.Context(device)
+    try:
+        c2.costs_upload(M.viewsel.DataCosts(n, s.n_views, ref.col_ptr, ref.view_id, ref.cost))
+        lg, sg = c2.view_selection(sap, sadj, params)
+    finally:
+        c2.close()
+    res["labels_equal"] = bool(np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"])
+    res["sample_sweeps"] = int(sg["sweeps"])
+    res["ok"] = res["pattern_equal"] and res["quality_bits_equal"] and res["labels_equal"]
+    return res
+
+
+def measure_traffic(config, kernel_rx, nnz, timeout_s=420):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, collected NOW, by re-running one step of this
+    script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one pass,
+    MI355X_MICROARCH.md "rocprofv3 PMC slots").  FETCH_SIZE under-reports coalesced streaming reads by 2x on gfx950 (same
+    guide, "HBM"): the factor is calibrated in the same pass on cost_kernel / hist_kernel / max_kernel, which read exactly
+    4 * nnz bytes.  Returns (bytes per launch, details) or (None, reason)."""
+    import csv, glob, re, shutil, subprocess, tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="mvs_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "%s pass failed (rc %d): %s" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-300:])
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                m = re.search(r"([a-z][a-z0-9_]*_kernel)", row["Kernel_Name"])
+                a = acc.setdefault(m.group(1) if m else row["Kernel_Name"][:48], [0, 0.0])
+                a[0] += 1; a[1] += float(row["Counter_Value"])
+            vals[ctr] = acc
+    except Exception as e:  # noqa: BLE001 -- reporting only
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fa, wa = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    # counter unit: KB.  Calibration kernels read exactly 4 * nnz bytes (coalesced dword loads)
+    cal = [(4.0 * nnz) / (fa[k][1] / fa[k][0] * 1024.0) for k in ("cost_kernel", "hist_kernel", "max_kernel") if k in fa and fa[k][1] > 0]
+    factor = sum(cal) / len(cal) if cal else 2.0
+    key = [k for k in fa if re.search(kernel_rx, k)]
+    if not key:
+        return None, "kernel %s not in the counter file" % kernel_rx
+    k = key[0]
+    fetch = fa[k][1] / fa[k][0] * 1024.0 * factor
+    write = wa[k][1] / wa[k][0] * 1024.0 if k in wa and wa[k][0] else 0.0
+    wcal = (4.0 * nnz) / (wa["cost_kernel"][1] / wa["cost_kernel"][0] * 1024.0) if "cost_kernel" in wa and wa["cost_kernel"][1] > 0 else None
+    return fetch + write, {"fetch_bytes": fetch, "write_bytes": write, "fetch_factor": factor, "fetch_factor_calibrated_on": len(cal),
+                           "write_check_cost_kernel": wcal, "launches_counted": fa[k][0]}
 
 
 def main():
@@ -85,6 +180,9 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.md config: 2 = 200k faces / 50 views, 3 = 2M faces / 200 views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed step's table (N = 1 only)")
+    ap.add_argument("--parity-faces", type=int, default=100000)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     args = ap.parse_args()
 
@@ -117,13 +215,16 @@ def main():
         log("scene: %d faces, %d views %dx%d, built in %.1fs" % (F, V, cfg["width"], cfg["height"], time.time() - t0))
     part = G.equal_parts(F, world)
 
-    # ---- inputs resident in HBM ----
+    # ---- inputs resident in HBM (the upload is timed and reported as h2d_ms; it is never part of `value`) ----
+    torch.cuda.synchronize(); t_h2d = time.perf_counter()
     t_v = torch.from_numpy(scene.verts).to(dev)
     t_f = torch.from_numpy(faces.view(np.int32)).to(dev)
     t_n = torch.from_numpy(normals).to(dev)
     t_img = [torch.from_numpy(i).to(dev) for i in scene.images]
     t_ap = torch.from_numpy(adj_ptr.view(np.int32)).to(dev)
     t_ad = torch.from_numpy(adj.view(np.int32)).to(dev)
+    torch.cuda.synchronize(); h2d_ms = 1000.0 * (time.perf_counter() - t_h2d)
+    h2d_bytes = scene.verts.nbytes + faces.nbytes + normals.nbytes + sum(i.nbytes for i in scene.images) + adj_ptr.nbytes + adj.nbytes
     t_lab = torch.zeros(F, dtype=torch.int32, device=dev)
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -221,13 +322,12 @@ def main():
                             "fixed point: algorithmic bytes per sweep = 12 nnz + 12 F; with the survey's fp32-message formula "
                             "(30 nnz + 12 F = %.3e B) the same time reads %.0f GB/s"
                             % (n_phases, n_phases, b_survey, b_survey / (sweep_ms * 1e-3) / 1e9)}
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    t = json.load(open(pmc)).get("mrf_sweep4_kernel", {}).get("config%d" % args.config)   # bytes per SWEEP (all colour launches)
-                    roof["traffic"] = t / n_phases if t else None
-                except Exception:
-                    pass
+            if rank == 0 and world == 1 and not args.no_traffic:
+                t0 = time.time()
+                traffic, detail = measure_traffic(args.config, r"^mrf_sweep4_kernel$", nnz_global)
+                roof["traffic"] = traffic
+                roof["traffic_detail"] = detail if traffic is not None else {"error": detail}
+                roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one step of this command, collected in this run (%.0f s)" % (time.time() - t0)
 
     out = {"metric": "faces/sec through view-selection (data-cost + MRF)", "value": value, "unit": "faces/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
@@ -235,7 +335,10 @@ def main():
            "config": {"workload": "BASELINE config %d: displaced icosphere n=%d (%d faces), %d Fibonacci-sphere views %dx%d RGB8, "
                                   "settings gmi/none/visibility-test (reference defaults)" % (args.config, cfg["n"], F, V, cfg["width"], cfg["height"]),
                       "faces": F, "views": V, "nnz": nnz_global, "sweeps": int(mrf["sweeps"]), "icm_iters": int(mrf["icm_iters"]),
-                      "energy": float(mrf["energy"]), "partition": "morton-%d" % world},
+                      "energy": float(mrf["energy"]), "partition": "morton-%d" % world, "msg_bits": 8,
+                      "arithmetic": "fp32 geometry and messages, fp64 footprint sums, 32.32 fixed-point energies; messages STORED as 8-bit codes"},
+           "h2d_ms": h2d_ms, "h2d_GBps": h2d_bytes / max(h2d_ms, 1e-9) / 1e6,
+           "pcie_inclusive_value": F / ((ms_per_step + h2d_ms) / 1000.0),
            "roofline": roof, "stages": stages, "pre_path": pre, "post_path": post}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -243,11 +346,23 @@ def main():
                                                dict(max_sweeps=params.max_sweeps, min_sweeps=params.min_sweeps), args.cpu_budget)
         except Exception as e:  # the baseline is reporting only; never lose the measurement
             out["cpu_baseline"] = {"error": repr(e)}
+    rc = 0
+    if rank == 0 and world == 1 and not args.no_parity and args.steps > 0:
+        try:
+            out["parity"] = parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, args.parity_faces, local_rank)
+            out["parity_checked"] = bool(out["parity"]["ok"])
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"error": repr(e)}; out["parity_checked"] = False
+        if not out["parity_checked"]:
+            rc = 3
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        log("PARITY CHECK FAILED: %r" % (out.get("parity"),))
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -557,6 +557,67 @@ def test_config2_size_properties(ctx):
     assert ms["energy_fixed"] < ei
 
 
+def _oracle_threads():
+    """the oracle's OpenMP loops stop scaling long before a 256-thread host is full (bench.py calibrates the same way)"""
+    return max(1, min(32, len(os.sched_getaffinity(0))))
+
+
+def test_config2_equals_the_oracle_entry_for_entry(ctx):
+    """BASELINE config 2 (200 000 faces, 50 views) IN FULL against the live oracle: sparsity pattern, view ids, qualities and
+    costs bit for bit (calculate_data_costs.cpp:253-306), cull counters, then labels, fixed-point energy, sweep count and
+    ICM rounds of the solve (view_selection.cpp:120-132)"""
+    s = M.synth.make_scene(**M.synth.CONFIGS[2])
+    assert (s.n_faces, s.n_views) == (200000, 50)
+    _load_scene(ctx, s)
+    nt = _oracle_threads()
+    ref, rst = O.data_costs(s, n_threads=nt)
+    st = ctx.data_costs(M.Settings())
+    got = ctx.costs_download()
+    _assert_costs(got, ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+    for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
+        assert st[k] == rst[k], k
+    assert np.float32(st["max_quality"]) == np.float32(rst["max_quality"]) and np.float32(st["percentile"]) == np.float32(rst["percentile"])
+    lo, so = O.view_selection(ref, s.adj_ptr, s.adj, n_threads=nt)
+    lg, sg = ctx.view_selection(s.adj_ptr, s.adj)
+    assert np.array_equal(lo, lg), "labels differ from the oracle at config 2"
+    for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters", "unseen"):
+        assert so[k] == sg[k], k
+
+
+def test_config3_equals_the_oracle_on_labels_and_sampled_columns():
+    """BASELINE config 3 (1 997 120 faces, 200 views 2048x1536 -- the bench workload itself) against the live oracle:
+    (a) the columns of a 300 000-face sample (three 100 000-face windows: start, middle, end of the face list) -- pattern,
+    view ids and qualities bit for bit (the costs follow from the global percentile, which test_config3_full_size_properties
+    recomputes with the oracle's histogram over ALL qualities); (b) the oracle's solver on the GPU's own table: labels of all
+    1 997 120 faces, fixed-point energy, cut edges, sweeps and ICM rounds identical."""
+    s = M.synth.make_scene(**M.synth.CONFIGS[3])
+    F = s.n_faces
+    assert (F, s.n_views) == (1997120, 200)
+    c = M.Context(0)
+    _load_scene(c, s)
+    c.data_costs(M.Settings())
+    dc = c.costs_download()
+    nt = _oracle_threads()
+    cp = dc.col_ptr.astype(np.int64)
+    checked = 0
+    for fb in (0, F // 2 - 50000, F - 100000):
+        fe = fb + 100000
+        ref, _ = O.data_costs(s, face_range=(fb, fe), n_threads=nt)
+        a, b = cp[fb], cp[fe]
+        assert np.array_equal(ref.col_ptr.astype(np.int64), cp[fb:fe + 1] - a), "sparsity pattern differs in faces [%d, %d)" % (fb, fe)
+        assert np.array_equal(ref.view_id, dc.view_id[a:b])
+        assert np.array_equal(ref.quality.view(np.uint32), dc.quality[a:b].view(np.uint32))
+        checked += fe - fb
+    assert checked == 300000
+    lg, sg = c.view_selection(s.adj_ptr, s.adj)
+    c.close()
+    table = O.CsrNp(F, s.n_views, dc.col_ptr, dc.view_id, dc.cost)
+    lo, so = O.view_selection(table, s.adj_ptr, s.adj, n_threads=nt)
+    assert np.array_equal(lo, lg), "labels differ from the oracle at config 3 (%d faces)" % int((lo != lg).sum())
+    for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters", "unseen"):
+        assert so[k] == sg[k], k
+
+
 def test_config3_full_size_properties():
     """BASELINE config 3 (1 997 120 faces, 200 views 2048x1536 -- the bench workload): size-independent properties.
     The per-entry oracle comparison happens at the small sizes above; here: conservation of pairs, sorted columns,
@@ -760,8 +821,8 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     import sys
     from conftest import ROOT
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                       capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic",
+                        "--parity-faces", "30000"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -769,6 +830,9 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d1, k
     assert d1["n_gpus"] == 1 and d1["steps"] == 2 and d1["config"]["faces"] == 200000 and d1["roofline"]["bound"] == "hbm"
+    # the checker leg: the timed step's table against the oracle (pattern, qualities bit for bit) + solver parity on the sample
+    assert d1["parity_checked"] is True and d1["parity"]["faces"] == 30000 and d1["parity"]["labels_equal"], d1.get("parity")
+    assert d1["config"]["msg_bits"] == 8 and d1["h2d_ms"] > 0
     env["MVS_BENCH_ONE_GPU"] = "1"
     port = 29600 + os.getpid() % 2000
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
