@@ -259,6 +259,8 @@ typedef struct mvs_mrf_progress {
     uint32_t stop_sweep;   /* sweep at which the rule fired = mvs_mrf_stats.sweeps */
     uint64_t energy;       /* 32.32 fixed point energy of the last accounted sweep */
     uint64_t best;         /* best energy so far */
+    uint32_t w;            /* decode buffer (0 / 1) the NEXT sweep writes */
+    uint32_t best_w;       /* decode buffer holding the best labeling so far: "keep the best" flips the two indices, nothing is copied */
 } mvs_mrf_progress;
 
 /* ---- multi-GPU MRF building blocks (one context per rank; DESIGN.md "Multi-GPU") ----

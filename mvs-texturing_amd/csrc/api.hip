@@ -17,6 +17,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
 void mrf_keep_best(mvs_ctx* ctx);
+void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
@@ -361,13 +362,16 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     int issued = 0, polled = 0;
     while (issued < P.max_sweeps && !pg.stopped) {
         { Prof pr(ctx, "mrf_sweep"); mrf_sweep(ctx, 0, F); }
-        { Prof pr(ctx, "mrf_energy"); mrf_energy(ctx, false, 0, F, /*reduce=*/false); mrf_step(ctx, nullptr); }
+        // the fast-path sweep kernels accumulate the sweep's energy themselves; the generic path runs the energy kernel
+        { Prof pr(ctx, "mrf_energy"); if (!ctx->m_energy_from_sweep) mrf_energy(ctx, false, 0, F, /*reduce=*/false); mrf_step(ctx, nullptr); }
         ++issued;
         if (issued - lag > polled) report((uint32_t)++polled);
     }
     while (polled < issued && !pg.stopped) report((uint32_t)++polled);
     if (issued > 0) mrf_poll(ctx, (uint32_t)issued, &pg);   // final state (drains the stream)
     S.sweeps = issued > 0 ? pg.stop_sweep : 0u;   // max_sweeps <= 0: best labeling = the argmin-unary start state of mrf_setup
+    // the sweeps track energies of the 16-bit unaries they stream; from here on (polish, reported energy) the exact costs count
+    mrf_exact_costs(ctx, 0, F);
     int it = 0;
     for (; it < P.icm_iters; ++it) {
         Prof pr(ctx, "mrf_icm");

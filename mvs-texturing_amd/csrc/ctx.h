@@ -80,16 +80,18 @@ struct MrfEdge {      // per directed edge e = (i <- j) in adjacency-CSR order
     uint32_t kj;      // K_j if the edge is valid (both columns non-empty), else 0
 };
 
-struct alignas(16) NodeDesc {   // fast-path (degree <= 3) per-node descriptor, 64 bytes = 4 x 16-byte loads
-    uint32_t p0, k;           // column start / length
-    uint32_t in_off[3];       // incoming message offsets
-    uint32_t out_off[3];      // outgoing message offsets (= in_off of the reverse edges)
-    uint32_t kj[3];           // neighbour column lengths (0 = edge not in the model); top bit = identical label lists
-    uint32_t nbr[3];          // neighbour node ids (0xFFFFFFFF = none)
-    uint32_t id;        // the node (face) this descriptor belongs to: descriptors are stored in (colour, id) order
-    uint32_t pad_;
+// Fast-path (degree <= 3, every column <= 255 labels) per-node descriptor: 48 bytes = 3 x 16-byte loads, stored in
+// (colour, id) order.  Offsets of message runs are multiples of 4 elements, which frees their low bits for flags.
+struct alignas(16) NodeDesc {
+    uint32_t rec;         // first 32-bit word of the node's RECORD in m_rec: ceil4(k) label words {cost code << 16 | view id},
+                          // then, for every out-edge whose two label lists differ, ceil4(kj) one-byte re-alignment map entries
+    uint32_t id;          // the node (face) this descriptor belongs to
+    uint32_t in_off[3];   // incoming message offsets; bit 0: that neighbour has a LOWER colour (its label of this sweep is final when this node is swept)
+    uint32_t out_off[3];  // outgoing message offsets (= in_off of the reverse edges); bit 0: identical label lists (map = identity, not stored)
+    uint32_t kk;          // k | kj[0] << 8 | kj[1] << 16 | kj[2] << 24   (kj = 0: edge not in the model)
+    uint32_t nbr[3];      // neighbour node ids (0xFFFFFFFF = none)
 };
-static_assert(sizeof(NodeDesc) == 64, "NodeDesc must be 64 bytes");
+static_assert(sizeof(NodeDesc) == 48, "NodeDesc must be 48 bytes");
 
 }  // namespace mvs
 
@@ -159,14 +161,20 @@ struct mvs_ctx {
 
     // ---- MRF ----
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
-    mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; int mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;
+    mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; mvs::DBuf<uint32_t> m_rec; uint64_t m_rec_words = 0; bool m_fast = false; int mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
     mvs::DBuf<uint8_t> m_msg_a;    // messages as 8-bit fixed point over [0, 1/rho], updated in place (one colour class at a time)
-    mvs::DBuf<uint32_t> m_sel, m_best_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
-    mvs::DBuf<uint32_t> m_lab, m_best_lab; mvs::DBuf<float> m_cost, m_best_cost;  // decoded label (view + 1) and its unary, current / best
+    // decode of a sweep = position in the column (sel), label (view + 1) and the unary of that label as the sweeps see it.
+    // TWO buffers of F + 1 entries each: the sweeps write buffer m_state->w, the best labeling so far is buffer
+    // m_state->best_w; "keep the best" is a flip of those two indices by the step kernel, never a copy.
+    mvs::DBuf<uint32_t> m_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
+    mvs::DBuf<uint32_t> m_lab; mvs::DBuf<float> m_cost;
+    uint32_t m_stride = 0;      // F + 1: offset of the second buffer
+    uint32_t* b_sel = nullptr; uint32_t* b_lab = nullptr; float* b_cost = nullptr; bool best_resolved = false;   // the best buffer, once the host knows which one it is (resolve_best)
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved; mvs::DBuf<uint32_t> m_alist; bool icm_dirty_valid = false;   // ICM active set: nodes whose gain the next pass re-evaluates
     uint32_t m_n_adj = 0;      // directed edges of the adjacency given to mrf_setup
     uint32_t m_energy_blocks = 0;   // per-block partial pairs the last mrf_energy left behind m_energy.p + 4
+    bool m_energy_from_sweep = false;   // ... or the last sweep's own kernels did (fast path: the energy is accumulated while sweeping)
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0;
     // colour-phased schedule: colours of the adjacency graph, nodes in (colour, id) order, class boundaries (host copy)
     mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c; uint32_t m_colours = 0; std::vector<uint32_t> m_colour_begin;
@@ -176,7 +184,7 @@ struct mvs_ctx {
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring
     static constexpr uint32_t RING = 16;
     mvs::DBuf<mvs_mrf_progress> m_state; mvs::DBuf<unsigned long long> m_hist;
-    mvs_mrf_progress* h_ring = nullptr; hipEvent_t ring_ev[RING] = {}; uint32_t steps_issued = 0; int mrf_lag = 1;
+    mvs_mrf_progress* h_ring = nullptr; mvs_mrf_progress* d_ring = nullptr /* the same pinned slots as the device addresses them */; hipEvent_t ring_ev[RING] = {}; uint32_t steps_issued = 0; int mrf_lag = 1;
 };
 
 namespace mvs {
@@ -195,4 +203,6 @@ struct Prof {
 };
 // generic device exclusive scan (scan.hip): out[i] = sum_{k<i} in[i]; returns total via d_total (device, may be null)
 void exclusive_scan_u32(mvs_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* d_total);
+// exact 64-bit total of a u32 array (blocking): the guard in front of scans whose total may pass 2^32
+uint64_t sum_u32(mvs_ctx* ctx, const uint32_t* in, size_t n);
 }  // namespace mvs

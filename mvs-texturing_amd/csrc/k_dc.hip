@@ -543,6 +543,10 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     MVS_LAUNCH_CHECK();
     ctx->max_q.ensure(4);
     uint32_t* d_total = (uint32_t*)(ctx->max_q.p + 2);
+    // ranks, CSR pointers and nnz are 32 bits wide (the reference uses size_t containers): a scene whose passing pairs could
+    // reach 2^32 gets an exact 64-bit count first and is refused instead of wrapping the scan (shard the faces: face ranges)
+    if ((uint64_t)nf * V >= 0xFFFFFFF0ull && sum_u32(ctx, ctx->pass_base.p, pw) >= 0xFFFFFFF0ull)
+        throw StatusError(MVS_ERR_UNSUPPORTED, "more than 2^32 (face, view) pairs pass the culls in one context: evaluate the faces in ranges (mvs_scene_set_face_range)");
     exclusive_scan_u32(ctx, ctx->pass_base.p, ctx->pass_base.p, pw, d_total);
     pr_rank.end();
     const uint32_t n_pass = read_u32(ctx, d_total);

@@ -177,8 +177,11 @@ __global__ void mrf_colour_round_kernel(const uint32_t* __restrict__ adj_ptr, co
         if (cj == NO_COLOUR) { ready = false; break; }
         used |= 1ull << cj;
     }
-    if (ready) __hip_atomic_store(colour + i, (uint32_t)__builtin_ctzll(~used), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *pending = 1u;                                       // racing stores of the same value
+    if (ready) {
+        // 64 colours in use around one node: the mask (and the 6-bit class sort) cannot hold a 65th -- reported, not wrapped
+        if (used == ~0ull) { pending[1] = 1u; used = 0ull; }
+        __hip_atomic_store(colour + i, (uint32_t)__builtin_ctzll(~used), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else *pending = 1u;                                       // racing stores of the same value
 }
 // colour_begin[c] = first position of colour >= c in the sorted colour array, c = 0 .. 64
 __global__ void mrf_colour_begin_kernel(const uint32_t* __restrict__ sorted, uint32_t F, uint32_t* __restrict__ colour_begin) {
@@ -321,66 +324,161 @@ __global__ void __launch_bounds__(256) mrf_map_kernel(const uint32_t* __restrict
     }
 }
 
-// One 48-byte descriptor per node (fast path, degree <= 3): everything a sweep needs to know about
-// the node in a single 3 x 16-byte load instead of the col_ptr -> adj_ptr -> edge[] dependent chain.
+// ---- fast path (degree <= 3, every column <= 255 labels): per-node RECORDS + 48-byte descriptors ----
+// The sweep streams, per node and in (colour, id) order, ONE read-only record instead of gathering from the CSR:
+//   [ceil4(K) label words: cost code << 16 | view id]  [for every out-edge whose two label lists differ: ceil4(K_j) map bytes]
+// padded to a multiple of four words.  A phase reads a contiguous run of records: no partially used lines (a phase used to
+// read every third column of the CSR), the view id of the decoded label is already in a register (no gather), the unaries
+// are 16-bit fixed point (2 instead of 4 bytes; part of the solver's definition, restated in oracle/oracle.cpp), the
+// re-alignment maps are bytes (K <= 255; 0xFF = label absent at the sender) and exist only where the lists differ.
+constexpr uint32_t REC_BASE = 256;            // words [0, REC_BASE) of the record array are zero: where masked lanes load
+constexpr float COST_SCALE = 65535.0f;
+__device__ __forceinline__ uint32_t cost_code(float c) { return (uint32_t)(c * COST_SCALE + 0.5f); }   // c in [0, 1]
+__device__ __forceinline__ float cost_value(uint32_t code) { return (float)code * (1.0f / 65535.0f); }
+
+// ident[e] = 1 iff the two label lists of the (valid) directed edge e are identical; 16 lanes per node
+__global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
+                                                        const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint8_t* __restrict__ ident) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t gl = threadIdx.x & 15;
+    if (i >= F) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+        const MrfEdge m = edge[e];
+        if (m.kj == 0) continue;
+        uint32_t same = (K == m.kj) ? 1u : 0u;
+        if (same) {
+            const uint32_t q0 = col_ptr[adj[e]];
+            for (uint32_t t = gl; t < K; t += 16) same &= (view_id[p0 + t] == view_id[q0 + t]) ? 1u : 0u;
+            for (int o = 8; o > 0; o >>= 1) same &= __shfl_xor(same, o, 16);
+        }
+        if (gl == 0) ident[e] = (uint8_t)same;
+    }
+}
+// rsz[q] = words of the record of node perm[q] (rsz[F] = 0)
+__global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge,
+                                   const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm, uint32_t F, uint32_t* __restrict__ rsz) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > F) return;
+    uint32_t w = 0;
+    if (q < F) {
+        const uint32_t i = perm[q], K = col_ptr[i + 1] - col_ptr[i];
+        if (K) {
+            w = (K + 3u) & ~3u;
+            for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { const uint32_t kj = edge[e].kj; if (kj && !ident[e]) w += (kj + 3u) >> 2; }
+            w = (w + 3u) & ~3u;
+        }
+    }
+    rsz[q] = w;
+}
+// fills the record of node perm[q]: 16 lanes per node; the node's own list sits in an LDS tile for the binary searches
+// (a group never spans waves and LDS operations of a wave execute in order: no barrier)
+__global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                         const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
+                                                         const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ roff,
+                                                         uint32_t F, uint32_t* __restrict__ rec) {
+    __shared__ uint16_t s_l[16][256];
+    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t gl = threadIdx.x & 15;
+    if (q >= F) return;
+    const uint32_t i = perm[q], p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    if (K == 0) return;
+    uint16_t* tile = s_l[threadIdx.x >> 4];
+    uint32_t* out = rec + REC_BASE + roff[q];
+    const uint32_t K4 = (K + 3u) & ~3u;
+    for (uint32_t t = gl; t < K4; t += 16) {
+        uint32_t w = 0u;
+        if (t < K) { const uint32_t v = view_id[p0 + t]; tile[t] = (uint16_t)v; w = (cost_code(cost[p0 + t]) << 16) | v; }
+        out[t] = w;
+    }
+    uint32_t pos = K4;
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+        const uint32_t kj = edge[e].kj;
+        if (kj == 0 || ident[e]) continue;                     // group-uniform
+        const uint32_t q0 = col_ptr[adj[e]], nw = (kj + 3u) >> 2;
+        for (uint32_t wI = gl; wI < nw; wI += 16) {
+            uint32_t word = 0u;
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint32_t t2 = 4u * wI + r;
+                uint32_t byte = 0xFFu;
+                if (t2 < kj) {                                 // position of the RECEIVER's label t2 in this (the sender's) list
+                    const uint16_t key = view_id[q0 + t2];
+                    uint32_t lo = 0, hi = K;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tile[mid] < key) lo = mid + 1; else hi = mid; }
+                    if (lo < K && tile[lo] == key) byte = lo;
+                }
+                word |= byte << (8 * r);
+            }
+            out[pos + wI] = word;
+        }
+        pos += nw;
+    }
+    for (uint32_t t = pos + gl; t < ((pos + 3u) & ~3u); t += 16) out[t] = 0u;
+}
 __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm,
-                                uint32_t F, NodeDesc* __restrict__ desc) {
+                                const uint32_t* __restrict__ colour, const uint32_t* __restrict__ roff, uint32_t F, NodeDesc* __restrict__ desc) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // position in the (colour, id) order
     if (q >= F) return;
     const uint32_t i = perm[q];
     NodeDesc nd;
-    nd.p0 = col_ptr[i]; nd.k = col_ptr[i + 1] - nd.p0;
-    const uint32_t e0 = adj_ptr[i], deg = adj_ptr[i + 1] - e0;
+    const uint32_t k = col_ptr[i + 1] - col_ptr[i];
+    nd.rec = k ? REC_BASE + roff[q] : 0u; nd.id = i; nd.kk = k;
+    const uint32_t e0 = adj_ptr[i], deg = adj_ptr[i + 1] - e0, ci = colour[i];
     for (int d = 0; d < 3; ++d) {
         MrfEdge m; m.in_off = 0; m.out_off = 0; m.kj = 0;
-        uint32_t flag = 0, nb = 0xFFFFFFFFu;
-        if ((uint32_t)d < deg) nb = adj[e0 + d];
-        if ((uint32_t)d < deg && nd.k > 0) {
+        uint32_t flag_ident = 0, flag_low = 0, nb = 0xFFFFFFFFu;
+        if ((uint32_t)d < deg) { nb = adj[e0 + d]; flag_low = (colour[nb] < ci) ? 1u : 0u; }
+        if ((uint32_t)d < deg && k > 0) {
             m = edge[e0 + d];
             // the message written over out-edge d is aligned with the neighbour's list: identity iff the lists are equal
             // (a symmetric property, so the in-edge's flag serves)
-            if (m.kj && ident[e0 + d]) flag = 0x80000000u;
+            if (m.kj && ident[e0 + d]) flag_ident = 1u;
         }
-        nd.in_off[d] = m.in_off; nd.out_off[d] = m.out_off; nd.kj[d] = m.kj | flag; nd.nbr[d] = nb;
+        nd.in_off[d] = m.in_off | flag_low; nd.out_off[d] = m.out_off | flag_ident; nd.kk |= m.kj << (8 + 8 * d); nd.nbr[d] = nb;
     }
-    nd.id = i; nd.pad_ = 0;
     desc[q] = nd;
 }
 
-// ---- one colour phase of a sweep; fast path: degree <= 3, K <= 4 * G ----
-// ---- 4 labels per lane: lane gl owns labels 4*gl .. 4*gl+3 (one 4-byte access = four 8-bit messages, one 8-byte access =
-// four u16 map entries), K <= 4 * G, so a 64-lane wave sweeps 64/G nodes per iteration at roughly the
-// instruction count of one.  The kernel is VALU-issue bound (a wave64 VALU op occupies its SIMD for 4 cycles), so
-// instructions per node is what counts, and the layout is arranged so that NO per-label masking is needed:
-//   * elements [0, MSG_BASE) of both message buffers are zero for ever: an absent edge (degree < 3, or an empty
-//     neighbour column) and every lane beyond the node's labels read their "incoming message" there;
-//   * elements [0, MSG_BASE) of the map array are the identity: an edge whose two label lists are identical
-//     (flag in the descriptor) reads its re-alignment map there instead of from its own run (no HBM traffic);
-//   * the re-alignment gather c[p] goes through a per-group LDS tile with one extra slot holding +inf: MAP_NONE is
-//     clamped onto that slot, so "label absent at the sender" needs no compare -- fmin(inf - cmin, 1/rho) = 1/rho;
-//   * message runs are padded to multiples of 4 elements, so a lane stores all four of its values or none;
-//   * the unary array has >= 4 floats of slack behind it (mrf_setup), so the 16-byte unary load needs no clamp.
+// ---- one colour phase of a sweep; fast path: degree <= 3, K <= 255 (and K <= 4 * G) ----
+// 4 labels per lane: lane gl owns labels 4*gl .. 4*gl+3 (one 16-byte load = four label words, one 4-byte access = four
+// 8-bit messages or four map bytes), so a 64-lane wave sweeps 64/G nodes per iteration at roughly the instruction count
+// of one.  The layout is arranged so that NO per-label masking of the loads is needed:
+//   * elements [0, MSG_BASE) of the message buffer are zero for ever: an absent edge (degree < 3, or an empty
+//     neighbour column) and every lane beyond the node's labels read their "incoming message" there; words
+//     [0, REC_BASE) of the record array are zero as well (label / map words of masked lanes);
+//   * an edge whose two label lists are identical (flag in the descriptor; 3/4 of the edges on the synthetic scenes)
+//     has no map at all: the identity bytes 4*gl .. 4*gl+3 are a per-lane constant;
+//   * the re-alignment gather c[p] goes through a per-group LDS tile with one extra slot holding +inf: 0xFF ("label
+//     absent at the sender") is steered onto that slot, so it needs no compare -- fmin(inf - cmin, 1/rho) = 1/rho;
+//   * message runs are padded to multiples of 4 elements, so a lane stores all four of its values or none.
 // Values a lane computes for label slots beyond the column are garbage that never reaches a valid label: they are
 // excluded from min / argmin by the ok[] mask (the only per-label selects left) and land in run padding.
 // LDS operations of a wave execute in order and a lane group never spans waves, so the tile needs no barrier.
-typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+//
+// Decode: the lane that owns the winning label writes the node's sel / label / unary into decode buffer st->w.
+// Energy: E = sum_i D_i(l_i) + sum_(i,j) [l_i != l_j] is accumulated HERE, in 32.32 fixed point: the node adds its unary
+// and one cut per model edge to a neighbour of a LOWER colour whose label differs -- that neighbour was swept in an
+// earlier phase of this sweep, so its label is final, and every edge has exactly one higher-coloured end.  Integer sums:
+// the per-block partials (partial[2 * block]) add up to the oracle's energy of the sweep whatever the launch geometry.
 template <int G, bool DAMP, bool XCD, bool LATE_OLD>
-__global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                         const uint16_t* __restrict__ map, msg_t* msg,
-                                                         uint32_t* __restrict__ sel, uint32_t* __restrict__ lab, float* __restrict__ selcost,
-                                                         uint32_t node_begin /* positions in the (colour, id) order */, uint32_t node_end, float rho, float alpha) {
+__global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ rec, msg_t* msg,
+                                                         const mvs_mrf_progress* __restrict__ st, uint32_t* sel2, uint32_t* lab2, float* cost2, uint32_t buf_stride,
+                                                         uint32_t node_begin /* positions in the (colour, id) order */, uint32_t node_end, float rho, float alpha,
+                                                         unsigned long long* __restrict__ partial) {
     // in place: the nodes of one launch share a colour (an independent set), so no run is read by one node and
     // written by another; a node reads its old outgoing run before it overwrites it
     const msg_t* mo = msg; msg_t* mn = msg;
     constexpr int NPB = 256 / G;
     constexpr int TS = 4 * G + 4;                            // tile stride: 4G cavity values + the +inf slot (16-byte multiple)
-    constexpr uint32_t IDENT = 0x80000000u;
     __shared__ __attribute__((aligned(16))) float s_c[NPB * TS];
+    __shared__ unsigned long long s_e[8];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     float* __restrict__ tile = s_c + grp * TS;               // this group's 4G values, label-major
     if (gl == 0) tile[4 * G] = INFINITY;
     __syncthreads();
+    const uint32_t wofs = st->w * buf_stride;                // decode buffer of this sweep (flipped by the step kernel when a sweep improves the best energy)
+    uint32_t* __restrict__ sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* __restrict__ selcost = cost2 + wofs;
     const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
     const MsgQ mq = msg_q(lam);
     const uint32_t stride = gridDim.x * NPB;
@@ -391,36 +489,46 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     NodeDesc nd = desc[min(i, last)];
     const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
     const uint32_t t0 = 4u * gl;
+    const uint32_t ident_word = 0x03020100u + 0x04040404u * (uint32_t)gl;   // map bytes of an identical-list edge: t0 .. t0 + 3
+    unsigned long long acc_e = 0ull; uint32_t acc_c = 0u;
     for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
         const bool node_ok = i < node_end;
         const NodeDesc cur = nd;
         nd = desc[min(i + stride, last)];
-        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
+        const uint32_t K = node_ok ? (cur.kk & 0xFFu) : 0u;
         bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ok[r] = t0 + r < K;
-        // phase 1: addresses (always valid); phase 2: ALL loads as raw 8/16-byte words, issued back to back under
+        // phase 1: addresses (always valid); phase 2: ALL loads as raw 4/16-byte words, issued back to back under
         // one wait (a load under a divergent branch would get its own exec region and s_waitcnt); phase 3: unpack.
-        const uint32_t da = ok[0] ? p0 + t0 : 0u;
-        uint32_t a_in[3], a_out[3], a_map[3], kj3[3];
+        const uint32_t la = ok[0] ? cur.rec + t0 : t0;        // t0 < REC_BASE: the zero words
+        uint32_t a_in[3], a_out[3], a_map[3], a_nb[3], kj3[3], o_out[3]; bool ident[3], low[3];
+        uint32_t mpos = cur.rec + ((K + 3u) & ~3u) + (uint32_t)gl;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const uint32_t kjf = node_ok ? cur.kj[d] : 0u;
-            kj3[d] = kjf & ~IDENT;
+            kj3[d] = node_ok ? ((cur.kk >> (8 + 8 * d)) & 0xFFu) : 0u;
+            ident[d] = (cur.out_off[d] & 1u) != 0u; low[d] = (cur.in_off[d] & 1u) != 0u && kj3[d] != 0u && K != 0u;
+            o_out[d] = cur.out_off[d] & ~3u;
             const bool o0 = t0 < kj3[d];
-            a_in[d] = (ok[0] && kj3[d] != 0u) ? cur.in_off[d] + t0 : t0;       // t0 < MSG_BASE: the zero run
-            a_out[d] = o0 ? cur.out_off[d] + t0 : t0;
-            a_map[d] = (o0 && !(kjf & IDENT)) ? cur.out_off[d] + t0 : t0;      // t0 < MSG_BASE: the identity run
+            a_in[d] = (ok[0] && kj3[d] != 0u) ? (cur.in_off[d] & ~3u) + t0 : t0;   // t0 < MSG_BASE: the zero run
+            a_out[d] = o0 ? o_out[d] + t0 : t0;
+            a_map[d] = (o0 && !ident[d]) ? mpos : (uint32_t)gl;
+            if (kj3[d] != 0u && !ident[d]) mpos += (kj3[d] + 3u) >> 2;
+            a_nb[d] = low[d] ? cur.nbr[d] : 0u;
         }
-        const f32x4_a4 dv = *reinterpret_cast<const f32x4_a4*>(cost + da);
-        uint32_t r_in[3], r_old[3]; uint2 r_map[3];   // four 8-bit messages per 4-byte word, four u16 map entries per 8-byte word
+        const uint4 lw4 = *reinterpret_cast<const uint4*>(rec + la);
+        uint32_t r_in[3], r_old[3], r_map[3], nl[3];   // four 8-bit messages / four map bytes per 4-byte word
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             r_in[d] = *reinterpret_cast<const uint32_t*>(mo + a_in[d]);
-            r_map[d] = *reinterpret_cast<const uint2*>(map + a_map[d]);
+            r_map[d] = rec[a_map[d]];
+            nl[d] = lab[a_nb[d]];
             if (!LATE_OLD) { if (DAMP) r_old[d] = *reinterpret_cast<const uint32_t*>(mo + a_out[d]); else r_old[d] = 0u; }
         }
-        const float D[4] = {dv.x, dv.y, dv.z, dv.w};
+        const uint32_t lw[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+        float D[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[r] = cost_value(lw[r] >> 16);
         float in[3][4];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -448,11 +556,6 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
 #pragma unroll
             for (int d = 0; d < 3; ++d) { if (DAMP) r_old[d] = *reinterpret_cast<const uint32_t*>(mo + a_out[d]); else r_old[d] = 0u; }
         }
-        // label and unary of the decoded state (all the energy / ICM kernels need of a neighbour): loaded by every
-        // lane (same address inside a group), consumed by the store at the end of the iteration
-        const uint32_t pa = (bt < K) ? p0 + bt : 0u;          // bt < K whenever K > 0
-        const uint32_t dec_view = view_id[pa];
-        const float dec_cost = cost[pa];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
@@ -465,22 +568,41 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             }
             const float cmin = group_min_fused<G>(fminf(fminf(cm[0], cm[1]), fminf(cm[2], cm[3])));
             *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0], c[1], c[2], c[3]);
-            const uint32_t mp[4] = {r_map[d].x & 0xFFFFu, r_map[d].x >> 16, r_map[d].y & 0xFFFFu, r_map[d].y >> 16};
+            const uint32_t mw = ident[d] ? ident_word : r_map[d];
             uint32_t w = 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float cp = tile[min(mp[r], (uint32_t)(4 * G))];          // MAP_NONE -> the +inf slot
+                const uint32_t mp = (mw >> (8 * r)) & 0xFFu;
+                const uint32_t slot = (G < 64) ? min(mp, (uint32_t)(4 * G)) : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // 0xFF -> the +inf slot
+                const float cp = tile[slot];
                 const float raw = fminf(cp - cmin, lam);
                 const float old = (float)((r_old[d] >> (8 * r)) & 0xFFu) * mq.step;
                 w |= msg_code(DAMP ? (raw * oma + old * alpha) : raw, mq) << (8 * r);
             }
-            if (t0 < kj3[d]) *reinterpret_cast<uint32_t*>(mn + cur.out_off[d] + t0) = w;      // one 4-byte store (runs are padded)
+            if (t0 < kj3[d]) *reinterpret_cast<uint32_t*>(mn + o_out[d] + t0) = w;      // one 4-byte store (runs are padded)
         }
-        if (gl == 0 && node_ok) {
-            /* K == 0: the single label 0 with unary 1 (view_selection.cpp:50-51,70-71) */
+        // the lane that owns the winning label publishes the decode (K == 0: lane 0 publishes the single label 0 with
+        // unary 1, view_selection.cpp:50-51,70-71) and accounts the node's share of the energy
+        const bool owner = node_ok && ((K > 0u) ? ((bt >> 2) == (uint32_t)gl) : (gl == 0));
+        if (owner) {
+            const uint32_t r = bt & 3u;
+            const uint32_t wsel = (r == 0u) ? lw[0] : (r == 1u) ? lw[1] : (r == 2u) ? lw[2] : lw[3];
+            const uint32_t my_lab = (K > 0u) ? (wsel & 0xFFFFu) + 1u : 0u;
+            const float my_cost = (K > 0u) ? cost_value(wsel >> 16) : 1.0f;
             const uint32_t id = cur.id;
-            sel[id] = (K > 0u) ? bt : 0u; lab[id] = (K > 0u) ? dec_view + 1u : 0u; selcost[id] = (K > 0u) ? dec_cost : 1.0f;
+            sel[id] = (K > 0u) ? bt : 0u; lab[id] = my_lab; selcost[id] = my_cost;
+            acc_e += fix32(my_cost);
+            acc_c += (low[0] && nl[0] != my_lab) + (low[1] && nl[1] != my_lab) + (low[2] && nl[2] != my_lab);
         }
+    }
+    // one partial pair per block (no atomics: same-address atomics serialise at ~12 ns each)
+    unsigned long long e = acc_e, c = acc_c;
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = e; s_e[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; c = s_e[4] + s_e[5] + s_e[6] + s_e[7];
+        partial[2 * blockIdx.x] = e + (c << 32); partial[2 * blockIdx.x + 1] = c;
     }
 }
 
@@ -489,12 +611,14 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
 template <bool DAMP>
 __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                                const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
-                                                               msg_t* msg, const uint32_t* __restrict__ perm, uint32_t* __restrict__ sel,
-                                                               uint32_t* __restrict__ lab, float* __restrict__ selcost,
+                                                               msg_t* msg, const uint32_t* __restrict__ perm, const mvs_mrf_progress* __restrict__ st,
+                                                               uint32_t* __restrict__ sel2, uint32_t* __restrict__ lab2, float* __restrict__ cost2, uint32_t buf_stride,
                                                                float* __restrict__ scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
     const msg_t* mo = msg; msg_t* mn = msg;                  // in place (one colour per launch)
     const int lane = threadIdx.x;
     if (node_begin + blockIdx.x >= node_end) return;
+    const uint32_t wofs = st->w * buf_stride;
+    uint32_t* __restrict__ sel = sel2 + wofs; uint32_t* __restrict__ lab = lab2 + wofs; float* __restrict__ selcost = cost2 + wofs;
     const uint32_t i = perm[node_begin + blockIdx.x];
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     if (K == 0) { if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; } return; }
@@ -505,14 +629,14 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
     for (uint32_t t = lane; t < K; t += 64) {
         float S = 0.0f;
         for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) S = S + msg_load(mo, m.in_off + t, mq); }
-        const float b = cost[p0 + t] + rho * S;
+        const float b = cost_value(cost_code(cost[p0 + t])) + rho * S;   // the unaries as the sweeps see them: 16-bit fixed point
         if (b < bb) { bb = b; bt = t; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(bb, o, 64); const uint32_t ot = __shfl_xor(bt, o, 64);
         if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
     }
-    if (lane == 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost[p0 + bt]; }
+    if (lane == 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost_value(cost_code(cost[p0 + bt])); }
     for (uint32_t e = e0; e < e1; ++e) {
         const MrfEdge m = edge[e];
         if (!m.kj) continue;  // wave-uniform
@@ -520,7 +644,7 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         for (uint32_t t = lane; t < K; t += 64) {
             float oth = 0.0f;
             for (uint32_t e2 = e0; e2 < e1; ++e2) { if (e2 == e) continue; const MrfEdge m2 = edge[e2]; if (m2.kj) oth = oth + msg_load(mo, m2.in_off + t, mq); }
-            const float c = (cost[p0 + t] + rho * oth) - omr * msg_load(mo, m.in_off + t, mq);
+            const float c = (cost_value(cost_code(cost[p0 + t])) + rho * oth) - omr * msg_load(mo, m.in_off + t, mq);
             scratch[p0 + t] = c;
             cmin = fminf(cmin, c);
         }
@@ -540,7 +664,9 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
 // non-zero (both columns non-empty, view_selection.cpp:29-42)
 __global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                                          const uint32_t* __restrict__ lab, const float* __restrict__ selcost,
+                                                         const mvs_mrf_progress* __restrict__ st /* non-null: the decode buffer st->w of lab / selcost */, uint32_t buf_stride,
                                                          uint32_t node_begin, uint32_t node_end, unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
+    if (st) { const uint32_t wofs = st->w * buf_stride; lab += wofs; selcost += wofs; }
     unsigned long long unary = 0, cuts = 0;
     for (uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x; i < node_end; i += gridDim.x * blockDim.x) {
         unary += fix32(selcost[i]);
@@ -615,7 +741,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
 
 // fast path (degree <= 3): persistent lane groups over the node descriptors, next descriptor prefetched
 template <int G>
-__global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* __restrict__ desc, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+__global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                                 const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
                                                                 uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand) {
     // node_begin / node_end are positions in the descriptor array ((colour, id) order); the node itself is cur.id
@@ -630,12 +756,13 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
         const bool node_ok = i < node_end;
         const NodeDesc cur = nd;
         if (i + stride < node_end) nd = desc[i + stride];
-        const uint32_t p0 = cur.p0, K = node_ok ? cur.k : 0u;
+        const uint32_t K = node_ok ? (cur.kk & 0xFFu) : 0u;
         const uint32_t id = cur.id;
+        const uint32_t p0 = (K > 0) ? col_ptr[id] : 0u;
         const uint32_t cur_t = (K > 0) ? sel[id] : 0u;
         uint32_t nl[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && (cur.kj[d] & 0x7FFFFFFFu)) ? lab[cur.nbr[d]] : 0u;
+        for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && ((cur.kk >> (8 + 8 * d)) & 0xFFu)) ? lab[cur.nbr[d]] : 0u;
         float best = INFINITY, cur_e = 0.0f; uint32_t bt = 0xFFFFFFFFu;
         for (uint32_t t = gl; t < K; t += G) {
             const uint32_t l = (uint32_t)view_id[p0 + t] + 1u;
@@ -716,14 +843,17 @@ __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t nod
 }
 
 
-// ---- device-side solver bookkeeping: one thread.  Same decisions, in the same arithmetic, as the host loop it
+// ---- device-side solver bookkeeping: one block.  Same decisions, in the same arithmetic, as the host loop it
 // replaces: best = min(best, e); stop iff sweep >= min_sweeps, sweep > window and
 // double(hist[sweep - window] - best) < double(min_improvement) * double(hist[sweep - window]).
-// With `partial` (single-GPU loop) the block first sums the energy kernel's per-block pairs itself and publishes them in
-// energy_out -- one launch less per sweep than reduce + step; sharded callers pass the all-reduced pair in `energy`.
+// With `partial` (single-GPU loop) the block first sums the per-block energy pairs the sweep kernels (fast path) or the
+// energy kernel left behind and publishes them in energy_out; sharded callers pass the all-reduced pair in `energy`.
+// "Keep the best labeling" is a flip of two indices: the sweep that improved the best energy wrote decode buffer w, which
+// becomes best_w, and the next sweeps write the other buffer -- nothing is copied.  The report goes straight into the
+// pinned ring slot (host memory), so a step is ONE launch.
 __global__ void __launch_bounds__(256) mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
                                 const unsigned long long* __restrict__ energy, const unsigned long long* __restrict__ partial, uint32_t n_partial,
-                                unsigned long long* __restrict__ energy_out, int max_sweeps, int min_sweeps, int window,
+                                unsigned long long* __restrict__ energy_out, mvs_mrf_progress* __restrict__ report, int max_sweeps, int min_sweeps, int window,
                                 float min_improvement) {
     __shared__ unsigned long long su[4], sc[4];
     unsigned long long e_sum = 0, c_sum = 0;
@@ -738,34 +868,35 @@ __global__ void __launch_bounds__(256) mrf_step_kernel(mvs_mrf_progress* __restr
         e_sum = su[0] + su[1] + su[2] + su[3]; c_sum = sc[0] + sc[1] + sc[2] + sc[3];
         energy_out[0] = e_sum; energy_out[1] = c_sum;
     }
-    if (st->stopped) { st->improved = 0u; return; }
-    const uint32_t sw = st->sweep + 1u;
-    const unsigned long long e0 = partial ? e_sum : energy[0];
-    unsigned long long best = st->best;
-    const bool imp = e0 < best;
-    if (imp) best = e0;
-    st->sweep = sw; st->improved = imp ? 1u : 0u; st->energy = e0; st->best = best;
-    hist[sw] = best;
-    bool stop = false;
-    if ((int)sw >= min_sweeps && (int)sw > window) {
-        const unsigned long long prev = hist[sw - (uint32_t)window];
-        stop = (double)(prev - best) < (double)min_improvement * (double)prev;
+    mvs_mrf_progress p = *st;
+    if (p.stopped) { p.improved = 0u; }
+    else {
+        const uint32_t sw = p.sweep + 1u;
+        const unsigned long long e0 = partial ? e_sum : energy[0];
+        const bool imp = e0 < p.best;
+        if (imp) { p.best = e0; p.best_w = p.w; p.w ^= 1u; }
+        p.sweep = sw; p.improved = imp ? 1u : 0u; p.energy = e0;
+        hist[sw] = p.best;
+        bool stop = false;
+        if ((int)sw >= min_sweeps && (int)sw > window) {
+            const unsigned long long prev = hist[sw - (uint32_t)window];
+            stop = (double)(prev - p.best) < (double)min_improvement * (double)prev;
+        }
+        if ((int)sw >= max_sweeps) stop = true;
+        if (stop) { p.stopped = 1u; p.stop_sweep = sw; }
     }
-    if ((int)sw >= max_sweeps) stop = true;
-    if (stop) { st->stopped = 1u; st->stop_sweep = sw; }
+    *st = p;
+    if (report) { *report = p; __threadfence_system(); }
 }
-// best labeling := current decode, iff the step above saw an improvement (the flag is wave-uniform)
-__global__ void __launch_bounds__(256) mrf_keep_best_if_kernel(const mvs_mrf_progress* __restrict__ st, const uint32_t* __restrict__ sel,
-                                                               const uint32_t* __restrict__ lab, const float* __restrict__ cost,
-                                                               uint32_t* __restrict__ best_sel, uint32_t* __restrict__ best_lab,
-                                                               float* __restrict__ best_cost, uint32_t n) {
-    if (!st->improved) return;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        best_sel[i] = sel[i]; best_lab[i] = lab[i]; best_cost[i] = cost[i];
-    }
-}
+// best labeling := the current decode buffer (mvs_ctx_mrf_keep_best): the same index flip, unconditionally
+__global__ void mrf_flip_kernel(mvs_mrf_progress* __restrict__ st) { st->best_w = st->w; st->w ^= 1u; }
 
 }  // namespace
+
+static bool mrf_fast_path(const mvs_ctx* ctx) {
+    return ctx->m_degmax <= 3 && ctx->m_kmax <= 255 && ctx->csr_nnz >= 4 && ctx->m_total > MSG_BASE;
+}
+constexpr uint32_t EPART_BLOCKS = 2048;   // per colour phase: upper bound of the sweep grid (resident blocks)
 
 // Builds the solver's edge tables for the active CSR (ctx->r_ptr / r_view / r_cost) and adjacency.
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
@@ -774,6 +905,9 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_params = *params;
     if (!(params->rho > 0.0f && params->rho <= 1.0f) || !(params->damping >= 0.0f && params->damping < 1.0f))
         throw StatusError(MVS_ERR_INVALID, "mrf params: need 0 < rho <= 1, 0 <= damping < 1");
+    // window < 1 would index the energy history out of bounds (hist[sweep - window]); the others are nonsensical when negative
+    if (params->window < 1 || params->min_sweeps < 0 || !(params->min_improvement >= 0.0f) || params->icm_iters < 0)
+        throw StatusError(MVS_ERR_INVALID, "mrf params: need window >= 1, min_sweeps >= 0, min_improvement >= 0, icm_iters >= 0");
     uint32_t E = 0;
     MVS_HIP(hipMemcpyAsync(&E, ctx->r_adj_ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
@@ -789,17 +923,19 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_colours = 0; ctx->m_colour_begin.assign(66, 0); ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
     ctx->m_sweep_no = 0;
     if (F) {
-        uint32_t* pending = ctx->m_moved.p + 1;
+        uint32_t* pending = ctx->m_moved.p + 1;   // [0] a node is still waiting, [1] a node saw all 64 colours around it
         hipLaunchKernelGGL(mrf_colour_init_kernel, dim3(nb), dim3(256), 0, s, ctx->m_colour.p, ctx->m_tmp_a.p /* iota */, F); MVS_LAUNCH_CHECK();
         for (int round = 0;; ++round) {
             if (round >= 4096) throw StatusError(MVS_ERR_HIP, "graph colouring did not terminate");
             MVS_HIP(hipMemsetAsync(pending, 0, sizeof(uint32_t), s));
             for (int k = 0; k < 4; ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
-            uint32_t hp = 0;   // set if any of the four rounds left a node waiting
-            MVS_HIP(hipMemcpyAsync(&hp, pending, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            uint32_t hp[2] = {0, 0};   // set if any of the four rounds left a node waiting
+            MVS_HIP(hipMemcpyAsync(hp, pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             MVS_HIP(hipStreamSynchronize(s));
-            if (!hp) break;
+            if (hp[1]) throw StatusError(MVS_ERR_UNSUPPORTED, "adjacency graph needs more than 64 colours (a node with >= 64 mutually constrained neighbours)");
+            if (!hp[0]) break;
         }
+        MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 4 * sizeof(uint32_t), s));
         // stable sort of the node ids by colour: perm = nodes in (colour, id) order; a colour class is a contiguous range
         size_t tmp_bytes = 0;
         MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->m_colour.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 6, s));
@@ -820,6 +956,12 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(in_off.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
     uint32_t h[3] = {0, 0, 0};
     if (F) {
+        // the offsets are 32 bits wide: the total is bounded by 3 (degree) x (entries + 3 pad per column) on a manifold; beyond
+        // 2^32 the scan below would wrap silently, so large inputs get an exact 64-bit total first
+        if ((uint64_t)E * 4ull + 4ull * (uint64_t)ctx->csr_nnz >= 0xFFFFFFF0ull) {
+            const uint64_t total = sum_u32(ctx, ctx->m_size.p, (size_t)E + 1);
+            if ((uint64_t)MSG_BASE + total >= 0xFFFFFFF0ull) throw StatusError(MVS_ERR_UNSUPPORTED, "message array exceeds 2^32 elements (shard the graph: DESIGN.md multi-GPU)");
+        }
         const uint32_t n_col = (ctx->m_colours >= 2 && ctx->m_colours <= (uint32_t)MAX_LAYOUT_COLOURS) ? ctx->m_colours : 1u;
         const size_t n_ent = (size_t)n_col * ((size_t)F + 1);
         ctx->m_tmp_a.ensure(n_ent + 72); ctx->m_tmp_b.ensure(n_ent + 2);
@@ -833,73 +975,93 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_total = (uint64_t)MSG_BASE + h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
     if (ctx->m_total >= 0xFFFFFFF0ull) throw StatusError(MVS_ERR_UNSUPPORTED, "message array exceeds 2^32 elements");
     if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
-    ctx->m_map.ensure(ctx->m_total + 8); ctx->m_ident.ensure((size_t)E + 1);
-    MVS_HIP(hipMemsetAsync(ctx->m_map.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // run padding is read (and ignored): keep it defined
-    hipLaunchKernelGGL(mrf_identity_kernel, dim3(1), dim3(MSG_BASE), 0, s, ctx->m_map.p); MVS_LAUNCH_CHECK();   // map[t] = t for t < MSG_BASE
+    ctx->m_ident.ensure((size_t)E + 1);
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
-    if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p,
-                               (ctx->m_degmax <= 3 && ctx->m_kmax <= 256 && ctx->csr_nnz >= 4) ? 1 : 0); MVS_LAUNCH_CHECK(); }
-    ctx->m_desc.ensure((size_t)F + 1);
-    if (F) { hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, ctx->m_desc.p); MVS_LAUNCH_CHECK(); }
+    ctx->m_fast = mrf_fast_path(ctx);
+    if (ctx->m_fast) {
+        // records + descriptors.  Upper bound of the record array (no read-back): labels nnz + 3 F, maps <= one byte per message element
+        const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + 64;
+        ctx->m_rec.ensure(rec_cap);
+        MVS_HIP(hipMemsetAsync(ctx->m_rec.p, 0, REC_BASE * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
+        uint32_t* rsz = ctx->m_tmp_a.p; uint32_t* roff = ctx->m_tmp_b.p;   // F + 1 entries each
+        hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, rsz); MVS_LAUNCH_CHECK();
+        exclusive_scan_u32(ctx, rsz, roff, (size_t)F + 1, nullptr);
+        hipLaunchKernelGGL(mrf_record_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
+                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, roff, F, ctx->m_rec.p); MVS_LAUNCH_CHECK();
+        ctx->m_desc.ensure((size_t)F + 1);
+        hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, ctx->m_colour.p, roff, F, ctx->m_desc.p); MVS_LAUNCH_CHECK();
+    } else {
+        ctx->m_map.ensure(ctx->m_total + 8);
+        MVS_HIP(hipMemsetAsync(ctx->m_map.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // run padding is read (and ignored): keep it defined
+        hipLaunchKernelGGL(mrf_identity_kernel, dim3(1), dim3(MSG_BASE), 0, s, ctx->m_map.p); MVS_LAUNCH_CHECK();   // map[t] = t for t < MSG_BASE
+        if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p, 0); MVS_LAUNCH_CHECK(); }
+    }
     ctx->m_msg_a.ensure(ctx->m_total + 8);
     MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 8) * sizeof(msg_t), s));   // zero codes, incl. the reserved zero run
-    // the sweep reads unaries with unclamped 16-byte loads: a caller-owned cost array (mvs_ctx_costs_upload with device
-    // pointers) is copied into the context's own buffer, which always has slack behind the last element
-    if (ctx->r_cost != ctx->csr_cost.p && ctx->csr_nnz) {
-        ctx->csr_cost.ensure(ctx->csr_nnz + 8);
-        MVS_HIP(hipMemcpyAsync(ctx->csr_cost.p, ctx->r_cost, ctx->csr_nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
-        ctx->r_cost = ctx->csr_cost.p;
-    }
-    if (ctx->r_cost == ctx->csr_cost.p && ctx->csr_cost.cap >= ctx->csr_nnz + 8) MVS_HIP(hipMemsetAsync(ctx->csr_cost.p + ctx->csr_nnz, 0, 8 * sizeof(float), s));
     MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
-    ctx->m_sel.ensure((size_t)F + 1); ctx->m_best_sel.ensure((size_t)F + 1); ctx->m_sel2.ensure((size_t)F + 1); ctx->m_cand.ensure((size_t)F + 1); ctx->m_gain.ensure((size_t)F + 1);
-    ctx->m_lab.ensure((size_t)F + 1); ctx->m_best_lab.ensure((size_t)F + 1); ctx->m_cost.ensure((size_t)F + 1); ctx->m_best_cost.ensure((size_t)F + 1);
+    // decode buffers: two of F + 1 entries each (see ctx.h)
+    const size_t F1 = (size_t)F + 1;
+    ctx->m_stride = (uint32_t)F1;
+    ctx->m_sel.ensure(2 * F1); ctx->m_lab.ensure(2 * F1); ctx->m_cost.ensure(2 * F1);
+    ctx->m_sel2.ensure(F1); ctx->m_cand.ensure(F1); ctx->m_gain.ensure(F1);
+    MVS_HIP(hipMemsetAsync(ctx->m_sel.p, 0, 2 * F1 * sizeof(uint32_t), s));
+    MVS_HIP(hipMemsetAsync(ctx->m_lab.p, 0, 2 * F1 * sizeof(uint32_t), s));
+    MVS_HIP(hipMemsetAsync(ctx->m_cost.p, 0, 2 * F1 * sizeof(float), s));
     // start state = argmin-unary decode everywhere: only needed when no sweep runs (ICM-only); otherwise the first
     // sweep (and, when sharded, the halo exchange that follows it) defines every label that is ever read
-    MVS_HIP(hipMemsetAsync(ctx->m_lab.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
-    MVS_HIP(hipMemsetAsync(ctx->m_best_lab.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
+    mvs_mrf_progress init; memset(&init, 0, sizeof(init)); init.best = ~0ull; init.energy = ~0ull; init.w = 0u; init.best_w = 1u;
     if (F && params->max_sweeps <= 0) {
         hipLaunchKernelGGL(mrf_argmin_unary_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, F, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p);
         MVS_LAUNCH_CHECK();
-        MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        MVS_HIP(hipMemcpyAsync(ctx->m_best_lab.p, ctx->m_lab.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        MVS_HIP(hipMemcpyAsync(ctx->m_best_cost.p, ctx->m_cost.p, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, s));
+        init.w = 1u; init.best_w = 0u;
     }
-    MVS_HIP(hipMemsetAsync(ctx->m_gain.p, 0, ((size_t)F + 1) * sizeof(float), s));
-    ctx->m_energy.ensure(4 + 2 * 2048);
+    ctx->b_sel = ctx->m_sel.p + init.best_w * F1; ctx->b_lab = ctx->m_lab.p + init.best_w * F1; ctx->b_cost = ctx->m_cost.p + init.best_w * F1;
+    ctx->best_resolved = true;
+    MVS_HIP(hipMemsetAsync(ctx->m_gain.p, 0, F1 * sizeof(float), s));
+    // energy partials: [0, 4) the reduced pair; then 2 x EPART_BLOCKS per colour phase (sweep kernels) / 2 x 2048 (energy kernel)
+    const size_t epart = 4 + 2 * (size_t)EPART_BLOCKS * std::max<size_t>(ctx->m_colours, 1);
+    ctx->m_energy.ensure(epart);
+    MVS_HIP(hipMemsetAsync(ctx->m_energy.p, 0, epart * sizeof(unsigned long long), s));   // slots a phase never writes stay zero
     // device-side solver state: sweep 0, best = hist[0] = 2^64 - 1
     ctx->m_state.ensure(1); ctx->m_hist.ensure((size_t)std::max(params->max_sweeps, 0) + 2);
-    mvs_mrf_progress init; memset(&init, 0, sizeof(init)); init.best = ~0ull; init.energy = ~0ull;
     if (!ctx->h_ring) {
-        MVS_HIP(hipHostMalloc((void**)&ctx->h_ring, mvs_ctx::RING * sizeof(mvs_mrf_progress), hipHostMallocDefault));
+        MVS_HIP(hipHostMalloc((void**)&ctx->h_ring, (mvs_ctx::RING + 1) * sizeof(mvs_mrf_progress), hipHostMallocDefault));
+        MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
         for (uint32_t k = 0; k < mvs_ctx::RING; ++k) MVS_HIP(hipEventCreateWithFlags(&ctx->ring_ev[k], hipEventDisableTiming));
     }
-    ctx->h_ring[0] = init;
-    MVS_HIP(hipMemcpyAsync(ctx->m_state.p, &ctx->h_ring[0], sizeof(init), hipMemcpyHostToDevice, s));
+    ctx->h_ring[mvs_ctx::RING] = init;   // staging slot for the upload
+    MVS_HIP(hipMemcpyAsync(ctx->m_state.p, &ctx->h_ring[mvs_ctx::RING], sizeof(init), hipMemcpyHostToDevice, s));
     MVS_HIP(hipMemsetAsync(ctx->m_hist.p, 0xFF, sizeof(unsigned long long), s));
     MVS_HIP(hipStreamSynchronize(s));
     ctx->steps_issued = 0; ctx->icm_dirty_valid = false;
 }
 
-// One bookkeeping step (see mrf_step_kernel); energy = device pointer to the (all-reduced) energy pair.
+// the best labeling's buffer, once the host needs it (ICM, final energy, labels): one read-back of the solver state
+void resolve_best(mvs_ctx* ctx) {
+    if (ctx->best_resolved) return;
+    if (!ctx->m_state.p) throw StatusError(MVS_ERR_STATE, "mrf setup first");
+    mvs_mrf_progress p;
+    MVS_HIP(hipMemcpyAsync(&p, ctx->m_state.p, sizeof(p), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t o = (size_t)(p.best_w & 1u) * ctx->m_stride;
+    ctx->b_sel = ctx->m_sel.p + o; ctx->b_lab = ctx->m_lab.p + o; ctx->b_cost = ctx->m_cost.p + o;
+    ctx->best_resolved = true;
+}
+
+// One bookkeeping step (see mrf_step_kernel); energy = device pointer to the (all-reduced) energy pair, or null: the pair is
+// still in per-block partials -- the sweep kernels' (fast path) or mrf_energy(..., reduce = false)'s -- summed by the step kernel.
 void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
     hipStream_t s = ctx->stream;
     const mvs_mrf_params& P = ctx->m_params;
     if (!ctx->h_ring) throw StatusError(MVS_ERR_STATE, "mrf step before mrf setup");
-    // energy == nullptr: the pair is still in per-block partials (mrf_energy(..., reduce = false)), summed by the step kernel
-    hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(256), 0, s, ctx->m_state.p, ctx->m_hist.p, energy,
-                       energy ? (const unsigned long long*)nullptr : ctx->m_energy.p + 4, energy ? 0u : ctx->m_energy_blocks, ctx->m_energy.p,
-                       P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
-    MVS_LAUNCH_CHECK();
-    const uint32_t F = ctx->csr_faces;
-    if (F) {
-        hipLaunchKernelGGL(mrf_keep_best_if_kernel, dim3(std::min<unsigned>((F + 255) / 256, 2048u)), dim3(256), 0, s, ctx->m_state.p,
-                           ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, F);
-        MVS_LAUNCH_CHECK();
-    }
-    ctx->icm_dirty_valid = false;   // the best labeling may change
     const uint32_t n = ++ctx->steps_issued, slot = n % mvs_ctx::RING;
-    MVS_HIP(hipMemcpyAsync(&ctx->h_ring[slot], ctx->m_state.p, sizeof(mvs_mrf_progress), hipMemcpyDeviceToHost, s));
+    const unsigned long long* partial = nullptr; uint32_t n_partial = 0;
+    if (!energy) { partial = ctx->m_energy.p + 4; n_partial = ctx->m_energy_from_sweep ? EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u) : ctx->m_energy_blocks; }
+    hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(256), 0, s, ctx->m_state.p, ctx->m_hist.p, energy, partial, n_partial, ctx->m_energy.p,
+                       ctx->d_ring + slot, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
+    MVS_LAUNCH_CHECK();
+    ctx->icm_dirty_valid = false; ctx->best_resolved = false;   // the best labeling may change
     MVS_HIP(hipEventRecord(ctx->ring_ev[slot], s));
 }
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
@@ -914,11 +1076,11 @@ void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
 // alpha = params.damping on ODD sweeps (1st, 3rd, ...) and written undamped on even sweeps.  Undamped sweeps oscillate
 // (C3: 0.9 % higher final energy), but damping every second sweep suppresses that just as well as damping every sweep
 // (C3: 44 sweeps to E = 1 111 890 with 0.2 on odd sweeps vs 47 to 1 110 970 with 0.1 on all) -- and an undamped sweep
-// does not re-read its previous outgoing messages (6 nnz bytes of the ~27 nnz a damped sweep moves).
+// does not re-read its previous outgoing messages.
 static float sweep_alpha(const mvs_ctx* ctx) { return (ctx->m_sweep_no & 1u) ? ctx->m_params.damping : 0.0f; }
 
 template <int G>
-static void launch_sweep4_g(mvs_ctx* ctx, uint32_t qb, uint32_t qe) {
+static void launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t qe) {
     constexpr int NPB = 256 / G;
     const unsigned need = (qe - qb + NPB - 1) / NPB;
     const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
@@ -932,10 +1094,11 @@ static void launch_sweep4_g(mvs_ctx* ctx, uint32_t qb, uint32_t qe) {
         resident = std::max(1, per_cu) * prop.multiProcessorCount;
     }
     unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
-    blocks = std::max(1u, std::min(need, blocks));
+    blocks = std::max(1u, std::min(std::min(need, blocks), EPART_BLOCKS));
     if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
     msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
-#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_map.p, msg, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, qb, qe, rho, alpha
+    unsigned long long* partial = ctx->m_energy.p + 4 + 2 * (size_t)EPART_BLOCKS * phase;
+#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->m_rec.p, msg, ctx->m_state.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_stride, qb, qe, rho, alpha, partial
     if (alpha != 0.0f) {
         if (ctx->mrf_late_old) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, true>), SWEEP4_ARGS); }
         else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, false>), SWEEP4_ARGS); }
@@ -972,37 +1135,55 @@ void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
     phase_range(ctx, phase, nb0, ne0, &qb, &qe);
     if (qe <= qb) return;
     const uint32_t K = ctx->m_kmax;
-    if (ctx->m_degmax <= 3 && K <= 256 && ctx->csr_nnz >= 4 && ctx->m_total > MSG_BASE) {
-        if (K <= 32) launch_sweep4_g<8>(ctx, qb, qe);
-        else if (K <= 64) launch_sweep4_g<16>(ctx, qb, qe);
-        else if (K <= 128) launch_sweep4_g<32>(ctx, qb, qe);
-        else launch_sweep4_g<64>(ctx, qb, qe);      // one node per wave: scenes with several hundred views per face
+    if (ctx->m_fast) {
+        if (K <= 32) launch_sweep4_g<8>(ctx, phase, qb, qe);
+        else if (K <= 64) launch_sweep4_g<16>(ctx, phase, qb, qe);
+        else if (K <= 128) launch_sweep4_g<32>(ctx, phase, qb, qe);
+        else launch_sweep4_g<64>(ctx, phase, qb, qe);      // one node per wave: scenes with several hundred views per face
     } else {
         ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
         const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
         msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
-        if (alpha != 0.0f)
-            hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, dim3(qe - qb), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, msg, ctx->m_perm.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, qb, qe, rho, alpha);
-        else
-            hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, dim3(qe - qb), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, msg, ctx->m_perm.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->pq.p, qb, qe, rho, alpha);
+#define GENERIC_ARGS dim3(qe - qb), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, msg, ctx->m_perm.p, ctx->m_state.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_stride, ctx->pq.p, qb, qe, rho, alpha
+        if (alpha != 0.0f) hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, GENERIC_ARGS);
+        else hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, GENERIC_ARGS);
+#undef GENERIC_ARGS
     }
     MVS_LAUNCH_CHECK();
 }
 // one sweep = every colour phase in turn (callers that shard the nodes exchange halos between the phases themselves)
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     for (uint32_t ph = 0; ph < ctx->m_colours; ++ph) mrf_sweep_phase(ctx, ph, nb0, ne0);
+    // the fast-path kernels leave the sweep's energy behind as per-block partials (valid when the range is the whole graph)
+    ctx->m_energy_from_sweep = ctx->m_fast && nb0 == 0 && ne0 >= ctx->csr_faces && ctx->m_colours > 0;
+}
+
+// The solver tracks energies of the 16-bit unaries the sweeps see; the polish and everything reported use the exact costs:
+// best_cost[i] := cost[col_ptr[i] + best_sel[i]] (1.0 for an empty column)
+__global__ void mrf_exact_cost_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, const uint32_t* __restrict__ sel,
+                                      uint32_t node_begin, uint32_t node_end, float* __restrict__ selcost) {
+    const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= node_end) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    selcost[i] = K ? cost[p0 + sel[i]] : 1.0f;
+}
+void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
+    resolve_best(ctx);
+    if (ne0 <= nb0) return;
+    hipLaunchKernelGGL(mrf_exact_cost_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->b_sel, nb0, ne0, ctx->b_cost);
+    MVS_LAUNCH_CHECK();
 }
 
 // energy of the current decode (best == false) or of the best labeling over nodes [nb0, ne0)
 // -> ctx->m_energy (device, 2 x u64), asynchronous
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce) {
     const unsigned blocks = ne0 > nb0 ? std::min<unsigned>((ne0 - nb0 + 255) / 256, 2048u) : 0u;
-    ctx->m_energy_blocks = blocks;
-    ctx->m_energy.ensure(4 + 2 * 2048);
+    ctx->m_energy_blocks = blocks; ctx->m_energy_from_sweep = false;
     unsigned long long* partial = ctx->m_energy.p + 4;
+    if (best) mrf_exact_costs(ctx, nb0, ne0);   // idempotent: whatever is reported about the best labeling uses the exact costs
     if (blocks) {
-        hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj,
-                           best ? ctx->m_best_lab.p : ctx->m_lab.p, best ? ctx->m_best_cost.p : ctx->m_cost.p, nb0, ne0, partial);
+        if (best) hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj, ctx->b_lab, ctx->b_cost, (const mvs_mrf_progress*)nullptr, 0u, nb0, ne0, partial);
+        else hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj, ctx->m_lab.p, ctx->m_cost.p, ctx->m_state.p, ctx->m_stride, nb0, ne0, partial);
         MVS_LAUNCH_CHECK();
     }
     if (!reduce) return;   // the caller's mrf_step sums the partials
@@ -1010,22 +1191,22 @@ void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce
     MVS_LAUNCH_CHECK();
 }
 
+// best labeling := the current decode (an index flip on the device)
 void mrf_keep_best(mvs_ctx* ctx) {
-    const size_t F = ctx->csr_faces;
-    ctx->icm_dirty_valid = false;
-    if (!F) return;
-    MVS_HIP(hipMemcpyAsync(ctx->m_best_sel.p, ctx->m_sel.p, F * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    MVS_HIP(hipMemcpyAsync(ctx->m_best_lab.p, ctx->m_lab.p, F * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    MVS_HIP(hipMemcpyAsync(ctx->m_best_cost.p, ctx->m_cost.p, F * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->icm_dirty_valid = false; ctx->best_resolved = false;
+    if (!ctx->m_state.p) throw StatusError(MVS_ERR_STATE, "mrf setup first");
+    hipLaunchKernelGGL(mrf_flip_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->m_state.p);
+    MVS_LAUNCH_CHECK();
 }
 
 // ICM on the best labeling (in place): gains of nodes [nb0, ne0)
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     if (ne0 <= nb0) return;
+    resolve_best(ctx);
     const uint32_t K = ctx->m_kmax, n = ne0 - nb0;
     const bool whole = nb0 == 0 && ne0 == ctx->csr_faces;
 #define ICM_G(GG, B, E, LIST) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3(((E) - (B) + (256 / GG) - 1) / (256 / GG)), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
-                                     ctx->r_adj_ptr, ctx->r_adj, ctx->m_best_sel.p, ctx->m_best_lab.p, (B), (E), ctx->m_gain.p, ctx->m_cand.p, (LIST))
+                                     ctx->r_adj_ptr, ctx->r_adj, ctx->b_sel, ctx->b_lab, (B), (E), ctx->m_gain.p, ctx->m_cand.p, (LIST))
     // active set (unsharded calls only): after one full evaluation, only the nodes the last apply listed -- the nodes that
     // moved and their neighbours -- are re-evaluated; everybody else's stored gain / candidate are still the values a
     // full pass would compute.  Sharded callers exchange labels behind the library's back, so they evaluate all.
@@ -1040,9 +1221,9 @@ void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
         }
         return;
     }
-    if (ctx->m_degmax <= 3 && whole) {   // descriptors are in (colour, id) order: whole-graph calls only
+    if (ctx->m_fast && whole) {   // descriptors are in (colour, id) order: whole-graph calls only
 #define ICM_D(GG) hipLaunchKernelGGL(mrf_icm_gain_desc_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((n + (256 / GG) - 1) / (256 / GG), 256u * 8u))), dim3(256), 0, ctx->stream, \
-                                     ctx->m_desc.p, ctx->r_view, ctx->r_cost, ctx->m_best_sel.p, ctx->m_best_lab.p, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
+                                     ctx->m_desc.p, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->b_sel, ctx->b_lab, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
         if (K <= 8) ICM_D(8); else if (K <= 16) ICM_D(16); else if (K <= 48) ICM_D(16); else ICM_D(32);
 #undef ICM_D
     } else {
@@ -1056,6 +1237,7 @@ void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 2 * sizeof(uint32_t), ctx->stream));
     if (ne0 <= nb0) return;
+    resolve_best(ctx);
     const bool whole = nb0 == 0 && ne0 == ctx->csr_faces;
     if (!whole) ctx->icm_dirty_valid = false;
     uint32_t* alist = nullptr;
@@ -1064,15 +1246,16 @@ void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
         alist = ctx->m_alist.p;
     }
     hipLaunchKernelGGL(mrf_icm_apply_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                       ctx->m_gain.p, ctx->m_cand.p, ctx->m_best_sel.p, ctx->m_best_lab.p, ctx->m_best_cost.p, nb0, ne0, ctx->m_moved.p, alist);
+                       ctx->m_gain.p, ctx->m_cand.p, ctx->b_sel, ctx->b_lab, ctx->b_cost, nb0, ne0, ctx->m_moved.p, alist);
     MVS_LAUNCH_CHECK();
 }
 // labels of nodes [nb0, ne0) of the best labeling into d_labels[0 .. ne0 - nb0); out = {bad, unseen}
 void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]) {
     uint32_t* bu = ctx->m_moved.p + 2;
+    resolve_best(ctx);
     MVS_HIP(hipMemsetAsync(bu, 0, 2 * sizeof(uint32_t), ctx->stream));
     if (ne0 > nb0) {
-        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->m_best_lab.p, nb0, ne0, ctx->csr_views, d_labels, bu);
+        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->b_lab, nb0, ne0, ctx->csr_views, d_labels, bu);
         MVS_LAUNCH_CHECK();
     }
     MVS_HIP(hipMemcpyAsync(out, bu, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -16,14 +16,18 @@ void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void resolve_best(mvs_ctx* ctx);
 void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device);
 mvs_status api_fail(mvs_status st, const std::string& msg);
 
 namespace {
-__global__ void gather_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+// st != null: the array is the CURRENT decode buffer, i.e. offset st->w * buf_stride (the step kernel flips w on the device)
+__global__ void gather_kernel(const uint32_t* __restrict__ src, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+    if (st) src += (size_t)st->w * buf_stride;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[k] = src[idx[k]];
 }
-__global__ void scatter_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+__global__ void scatter_kernel(uint32_t* __restrict__ dst, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+    if (st) dst += (size_t)st->w * buf_stride;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = src[k];
 }
 // combined addressing: index < 2^31 -> array a (messages), else array b[index & 0x7FFFFFFF] (labels):
@@ -35,13 +39,15 @@ __global__ void gather_msg_kernel(const uint8_t* __restrict__ src, const uint32_
 __global__ void scatter_msg_kernel(uint8_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = (uint8_t)src[k];
 }
-__global__ void gather2_kernel(const uint8_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+__global__ void gather2_kernel(const uint8_t* __restrict__ a, const uint32_t* __restrict__ b, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+    b += (size_t)st->w * buf_stride;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = idx[k];
         dst[k] = (i & 0x80000000u) ? b[i & 0x7FFFFFFFu] : a[i];
     }
 }
-__global__ void scatter2_kernel(uint8_t* __restrict__ a, uint32_t* __restrict__ b, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+__global__ void scatter2_kernel(uint8_t* __restrict__ a, uint32_t* __restrict__ b, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+    b += (size_t)st->w * buf_stride;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = idx[k];
         if (i & 0x80000000u) b[i & 0x7FFFFFFFu] = src[k]; else a[i] = (uint8_t)src[k];
@@ -54,11 +60,13 @@ __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, 
 }  // namespace
 
 static uint8_t* mrf_msg(mvs_ctx* ctx) { return ctx->m_msg_a.p; }  // one buffer, updated in place
-static uint32_t* mrf_array(mvs_ctx* ctx, int which) {
+// LAB = the current decode buffer (resolved on the device through the solver state), BEST_LAB = the best labeling's buffer
+static uint32_t* mrf_array(mvs_ctx* ctx, int which, const mvs_mrf_progress** st) {
+    *st = nullptr;
     switch (which) {
-        case MVS_MRF_LAB: return ctx->m_lab.p;
+        case MVS_MRF_LAB: *st = ctx->m_state.p; return ctx->m_lab.p;
         case MVS_MRF_GAIN: return (uint32_t*)ctx->m_gain.p;
-        case MVS_MRF_BEST_LAB: return ctx->m_best_lab.p;
+        case MVS_MRF_BEST_LAB: resolve_best(ctx); return ctx->b_lab;
     }
     throw StatusError(MVS_ERR_INVALID, "bad array selector");
 }
@@ -159,13 +167,14 @@ mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx, uint
     MVS_API_BEGIN
     if (n && which == MVS_MRF_MSG_LAB) {
         if (ctx->m_total >= 0x80000000ull) throw StatusError(MVS_ERR_UNSUPPORTED, "combined addressing needs < 2^31 message words");
-        hipLaunchKernelGGL(gather2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), ctx->m_lab.p, idx, n, (uint32_t*)dst);
+        hipLaunchKernelGGL(gather2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, idx, n, (uint32_t*)dst);
         MVS_LAUNCH_CHECK();
     } else if (n && which == MVS_MRF_MSG) {
         hipLaunchKernelGGL(gather_msg_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), idx, n, (uint32_t*)dst);
         MVS_LAUNCH_CHECK();
     } else if (n) {
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (uint32_t*)dst);
+        const mvs_mrf_progress* st; const uint32_t* arr = mrf_array(ctx, which, &st);
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, arr, st, ctx->m_stride, idx, n, (uint32_t*)dst);
         MVS_LAUNCH_CHECK();
     }
     MVS_API_END
@@ -175,13 +184,14 @@ mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx, uin
     MVS_API_BEGIN
     if (n) ctx->icm_dirty_valid = false;   // labels changed behind the ICM active set
     if (n && which == MVS_MRF_MSG_LAB) {
-        hipLaunchKernelGGL(scatter2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), ctx->m_lab.p, idx, n, (const uint32_t*)src);
+        hipLaunchKernelGGL(scatter2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, idx, n, (const uint32_t*)src);
         MVS_LAUNCH_CHECK();
     } else if (n && which == MVS_MRF_MSG) {
         hipLaunchKernelGGL(scatter_msg_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), idx, n, (const uint32_t*)src);
         MVS_LAUNCH_CHECK();
     } else if (n) {
-        hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_array(ctx, which), idx, n, (const uint32_t*)src);
+        const mvs_mrf_progress* st; uint32_t* arr = mrf_array(ctx, which, &st);
+        hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, arr, st, ctx->m_stride, idx, n, (const uint32_t*)src);
         MVS_LAUNCH_CHECK();
     }
     MVS_API_END

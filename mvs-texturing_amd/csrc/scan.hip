@@ -80,6 +80,34 @@ static void scan_rec(mvs_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, 
     MVS_LAUNCH_CHECK();
 }
 
+namespace {
+__global__ void __launch_bounds__(256) sum64_kernel(const uint32_t* __restrict__ in, size_t n, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0;
+    for (size_t k = (size_t)blockIdx.x * 256u + threadIdx.x; k < n; k += (size_t)gridDim.x * 256u) s += in[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ unsigned long long ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+}  // namespace
+
+// 64-bit total of a u32 array (blocking).  The scans above are 32 bits wide: callers whose totals can pass 2^32
+// (pairs of a huge scene, message elements) take this exact total first and refuse instead of wrapping.
+uint64_t sum_u32(mvs_ctx* ctx, const uint32_t* in, size_t n) {
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+    ctx->scan_tmp.ensure(2 * 1024 + 8);
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(ctx->scan_tmp.p);
+    hipLaunchKernelGGL(sum64_kernel, dim3(blocks), dim3(256), 0, ctx->stream, in, n, part);
+    MVS_LAUNCH_CHECK();
+    std::vector<unsigned long long> h(blocks);
+    MVS_HIP(hipMemcpyAsync(h.data(), part, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t t = 0; for (auto v : h) t += v;
+    return t;
+}
+
 void exclusive_scan_u32(mvs_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* d_total) {
     if (n == 0) {
         if (d_total) MVS_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));

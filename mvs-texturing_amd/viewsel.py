@@ -61,7 +61,7 @@ class MrfStats(C.Structure):
 
 class MrfProgress(C.Structure):
     _fields_ = [("sweep", C.c_uint32), ("stopped", C.c_uint32), ("improved", C.c_uint32), ("stop_sweep", C.c_uint32),
-                ("energy", C.c_uint64), ("best", C.c_uint64)]
+                ("energy", C.c_uint64), ("best", C.c_uint64), ("w", C.c_uint32), ("best_w", C.c_uint32)]
 
 
 class Subgraphs(C.Structure):

@@ -825,6 +825,7 @@ inline float msg_store(float v, MsgQ q) { return (float)(int32_t)msg_code(v, q) 
 struct Mrf {
     uint32_t F = 0;
     const uint32_t* col_ptr = nullptr; const uint16_t* view_id = nullptr; const float* cost = nullptr;
+    const float* qcost = nullptr;   // the unaries as the sweeps see them (16-bit fixed point, below)
     const uint32_t* adj_ptr = nullptr; const uint32_t* adj = nullptr;
     std::vector<uint8_t> valid;     // per directed edge
     std::vector<uint32_t> rev;      // per directed edge
@@ -864,13 +865,14 @@ void mrf_setup(Mrf& g) {
         }
 }
 
-uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t* cuts_out, int n_threads = 1) {
+uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t* cuts_out, int n_threads = 1, const float* cost = nullptr) {
+    if (!cost) cost = g.cost;
     uint64_t unary = 0, cuts = 0;
 #pragma omp parallel for schedule(static) num_threads(n_threads) reduction(+ : unary, cuts)
     for (int64_t ii = 0; ii < (int64_t)g.F; ++ii) {
         const uint32_t i = (uint32_t)ii;
         if (g.K(i) == 0) { unary += fix32(1.0f); continue; }   /* view_selection.cpp:70-71 */
-        unary += fix32(g.cost[g.col_ptr[i] + sel[i]]);
+        unary += fix32(cost[g.col_ptr[i] + sel[i]]);
         const uint16_t li = g.view_id[g.col_ptr[i] + sel[i]];
         for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) {
             const uint32_t j = g.adj[e];
@@ -917,7 +919,7 @@ void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<float>& msg,
         for (int64_t ii = 0; ii < (int64_t)g.F; ++ii) {
             const uint32_t i = (uint32_t)ii, Ki = g.K(i);
             if (Ki == 0 || colour[i] != phase) continue;
-            const float* D = g.cost + g.col_ptr[i];
+            const float* D = g.qcost + g.col_ptr[i];
             const uint32_t e0 = g.adj_ptr[i], e1 = g.adj_ptr[i + 1];
             // decode
             uint32_t best_t = 0; float best_b = 0.0f;
@@ -1055,6 +1057,14 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     Mrf g; g.F = costs->n_faces; g.col_ptr = costs->col_ptr; g.view_id = costs->view_id; g.cost = costs->cost;
     g.adj_ptr = adj_ptr; g.adj = adj;
     mrf_setup(g);
+    // The sweeps read the unaries as 16-bit fixed point over [0, 1] (costs are 1 - min(1, q / percentile),
+    // calculate_data_costs.cpp:291-296): code = trunc(c * 65535 + 0.5), value = code * (1 / 65535), fp32 on both sides.
+    // Part of the solver's definition: the GPU streams {view id, cost code} as one 32-bit word per label.  The energies
+    // that drive the stop rule and the choice of the best sweep are those of the SAME quantised unaries ("tracking energy");
+    // the ICM polish and the energy that is reported use the exact costs.
+    std::vector<float> qcost(costs->nnz);
+    for (uint64_t k = 0; k < costs->nnz; ++k) qcost[k] = (float)(int32_t)(uint32_t)(costs->cost[k] * 65535.0f + 0.5f) * (1.0f / 65535.0f);
+    g.qcost = qcost.data();
     const uint64_t M = g.moff[g.adj_ptr[g.F]];
     std::vector<float> msg(M, 0.0f);
     std::vector<uint8_t> colour;
@@ -1066,7 +1076,7 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     uint32_t s = 0;
     for (s = 1; (int)s <= P.max_sweeps; ++s) {
         for (int phase = 0; phase < n_colours; ++phase) mrf_sweep(g, P, msg, sel, n_threads, colour.data(), phase, s);
-        uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts, n_threads);
+        uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts, n_threads, g.qcost);
         if (e < best_e) { best_e = e; best_cuts = cuts; best_sel = sel; }
         hist.push_back(best_e);
         if (g_trace && (int)s <= g_trace_len) g_trace[s - 1] = e;
