@@ -33,8 +33,14 @@ constexpr uint32_t MSG_BASE = MVS_MRF_MSG_BASE;   // first real message / map el
 typedef uint8_t msg_t;
 struct MsgQ { float scale, step; };      // 255 / lam and lam / 255, fp32, the oracle computes them the same way
 __device__ __forceinline__ MsgQ msg_q(float lam) { return MsgQ{255.0f / lam, lam / 255.0f}; }
-__device__ __forceinline__ float msg_load(const msg_t* __restrict__ p, size_t i, MsgQ q) { return (float)p[i] * q.step; }
-__device__ __forceinline__ uint32_t msg_code(float v, MsgQ q) { return (uint32_t)(v * q.scale + 0.5f); }   // v in [0, lam]: 0 .. 255
+// the code a message value `raw` in [0, lam] is stored as, damped against the old code (oracle.cpp msg_code):
+// rne(fma(old, alpha, raw * oms)), oms = (1 - alpha) * scale, saturated at 255 -- v_cvt_pk_u8_f32 IS a saturating
+// round-to-nearest-even conversion on gfx950 (scripts/probe/cvt_probe.hip), and it drops the byte into place
+template <bool DAMP>
+__device__ __forceinline__ uint32_t msg_pack(float raw, float oms, float alpha, float old_code, uint32_t byte, uint32_t word) {
+    const float v = DAMP ? __builtin_fmaf(old_code, alpha, raw * oms) : raw * oms;
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, byte, word);
+}
 
 __device__ __forceinline__ unsigned long long fix32(float d) { return (unsigned long long)((double)d * 4294967296.0); }
 
@@ -376,7 +382,8 @@ __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const u
 __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                          const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
                                                          const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ roff,
-                                                         uint32_t F, uint32_t* __restrict__ rec) {
+                                                         uint32_t F, uint32_t none_byte /* what "label absent at the sender" is stored as: the sweep's +inf slot (4 * G), 0xFF for G = 64 */,
+                                                         uint32_t* __restrict__ rec) {
     __shared__ uint16_t s_l[16][256];
     const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
@@ -400,7 +407,7 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
             uint32_t word = 0u;
             for (uint32_t r = 0; r < 4; ++r) {
                 const uint32_t t2 = 4u * wI + r;
-                uint32_t byte = 0xFFu;
+                uint32_t byte = none_byte;
                 if (t2 < kj) {                                 // position of the RECEIVER's label t2 in this (the sender's) list
                     const uint16_t key = view_id[q0 + t2];
                     uint32_t lo = 0, hi = K;
@@ -427,13 +434,14 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
     const uint32_t e0 = adj_ptr[i], deg = adj_ptr[i + 1] - e0, ci = colour[i];
     for (int d = 0; d < 3; ++d) {
         MrfEdge m; m.in_off = 0; m.out_off = 0; m.kj = 0;
-        uint32_t flag_ident = 0, flag_low = 0, nb = 0xFFFFFFFFu;
+        uint32_t flag_ident = 0, flag_low = 0, nb = i;          // absent neighbour: the node itself (a valid index; masked by kj = 0 wherever it is used)
         if ((uint32_t)d < deg) { nb = adj[e0 + d]; flag_low = (colour[nb] < ci) ? 1u : 0u; }
         if ((uint32_t)d < deg && k > 0) {
             m = edge[e0 + d];
             // the message written over out-edge d is aligned with the neighbour's list: identity iff the lists are equal
             // (a symmetric property, so the in-edge's flag serves)
             if (m.kj && ident[e0 + d]) flag_ident = 1u;
+            if (m.kj == 0) { m.in_off = 0; m.out_off = 0; }    // edge not in the model: the sweep reads the reserved zero run
         }
         nd.in_off[d] = m.in_off | flag_low; nd.out_off[d] = m.out_off | flag_ident; nd.kk |= m.kj << (8 + 8 * d); nd.nbr[d] = nb;
     }
@@ -479,8 +487,10 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     __syncthreads();
     const uint32_t wofs = st->w * buf_stride;                // decode buffer of this sweep (flipped by the step kernel when a sweep improves the best energy)
     uint32_t* __restrict__ sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* __restrict__ selcost = cost2 + wofs;
-    const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
+    const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
+    const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale;   // the oracle's constants, fp32
+    constexpr float HUGE_COST = 1e30f;                       // unary of the label slots beyond the column: never a minimum
     const uint32_t stride = gridDim.x * NPB;
     uint32_t vb = blockIdx.x;
     if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -499,22 +509,23 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ok[r] = t0 + r < K;
-        // phase 1: addresses (always valid); phase 2: ALL loads as raw 4/16-byte words, issued back to back under
-        // one wait (a load under a divergent branch would get its own exec region and s_waitcnt); phase 3: unpack.
-        const uint32_t la = ok[0] ? cur.rec + t0 : t0;        // t0 < REC_BASE: the zero words
-        uint32_t a_in[3], a_out[3], a_map[3], a_nb[3], kj3[3], o_out[3]; bool ident[3], low[3];
+        // phase 1: addresses; phase 2: ALL loads as raw 4/16-byte words, issued back to back under one wait (a load
+        // under a divergent branch would get its own exec region and s_waitcnt); phase 3: unpack.  No address needs a
+        // select: a lane beyond the column / the neighbour's column reads whatever follows the run or the record (valid
+        // memory -- both arrays carry slack -- and lines its neighbours fetch anyway) and its values never reach a valid
+        // label; an absent edge has offsets 0 in the descriptor, i.e. the reserved zero run.
+        const uint32_t la = cur.rec + t0;
+        uint32_t a_in[3], a_out[3], a_map[3], kj3[3], o_out[3]; bool ident[3], low[3];
         uint32_t mpos = cur.rec + ((K + 3u) & ~3u) + (uint32_t)gl;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             kj3[d] = node_ok ? ((cur.kk >> (8 + 8 * d)) & 0xFFu) : 0u;
-            ident[d] = (cur.out_off[d] & 1u) != 0u; low[d] = (cur.in_off[d] & 1u) != 0u && kj3[d] != 0u && K != 0u;
+            ident[d] = (cur.out_off[d] & 1u) != 0u; low[d] = (cur.in_off[d] & 1u) != 0u && kj3[d] != 0u;
             o_out[d] = cur.out_off[d] & ~3u;
-            const bool o0 = t0 < kj3[d];
-            a_in[d] = (ok[0] && kj3[d] != 0u) ? (cur.in_off[d] & ~3u) + t0 : t0;   // t0 < MSG_BASE: the zero run
-            a_out[d] = o0 ? o_out[d] + t0 : t0;
-            a_map[d] = (o0 && !ident[d]) ? mpos : (uint32_t)gl;
-            if (kj3[d] != 0u && !ident[d]) mpos += (kj3[d] + 3u) >> 2;
-            a_nb[d] = low[d] ? cur.nbr[d] : 0u;
+            a_in[d] = (cur.in_off[d] & ~3u) + t0;
+            a_out[d] = o_out[d] + t0;
+            a_map[d] = mpos;
+            if (!ident[d]) mpos += (kj3[d] + 3u) >> 2;
         }
         const uint4 lw4 = *reinterpret_cast<const uint4*>(rec + la);
         uint32_t r_in[3], r_old[3], r_map[3], nl[3];   // four 8-bit messages / four map bytes per 4-byte word
@@ -522,31 +533,26 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         for (int d = 0; d < 3; ++d) {
             r_in[d] = *reinterpret_cast<const uint32_t*>(mo + a_in[d]);
             r_map[d] = rec[a_map[d]];
-            nl[d] = lab[a_nb[d]];
+            nl[d] = lab[cur.nbr[d]];                          // an absent neighbour is recorded as the node itself
             if (!LATE_OLD) { if (DAMP) r_old[d] = *reinterpret_cast<const uint32_t*>(mo + a_out[d]); else r_old[d] = 0u; }
         }
         const uint32_t lw[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
-        float D[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) D[r] = cost_value(lw[r] >> 16);
-        float in[3][4];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) in[d][r] = (float)((r_in[d] >> (8 * r)) & 0xFFu) * mq.step;   // v_cvt_f32_ubyte<r>
-        }
-        // decode: first argmin_t of b[t] = D[t] + rho * S[t] -- the group minimum, then the smallest label attaining it
-        // (== the sequential "first minimum": comparisons are exact, +0 == -0 in both formulations)
-        float bm[4];
+        // The update on the 8-bit codes (oracle.cpp mrf_sweep is the definition): Sc = sum of the incoming codes (exact),
+        // b = fma(rho * step, Sc, D), c_e = fma(-step, code_e, b) -- the reweighted cavity D + rho * sum_all - m_e --
+        // code' = rne(fma(old, alpha, min(c[p] - cmin, lam) * ((1 - alpha) * scale))).
+        float cf[3][4], b[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float S = ((0.0f + in[0][r]) + in[1][r]) + in[2][r];
-            const float b = D[r] + rho * S;
-            bm[r] = ok[r] ? b : INFINITY;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) cf[d][r] = (float)((r_in[d] >> (8 * r)) & 0xFFu);   // v_cvt_f32_ubyte<r>
+            const float D = ok[r] ? cost_value(lw[r] >> 16) : HUGE_COST;
+            b[r] = __builtin_fmaf(kappa, (cf[0][r] + cf[1][r]) + cf[2][r], D);
         }
-        const float gm = group_min_fused<G>(fminf(fminf(bm[0], bm[1]), fminf(bm[2], bm[3])));
-        uint32_t bt = (bm[3] == gm) ? t0 + 3u : 0xFFFFFFFFu;
-        bt = (bm[2] == gm) ? t0 + 2u : bt; bt = (bm[1] == gm) ? t0 + 1u : bt; bt = (bm[0] == gm) ? t0 : bt;
+        // decode: first argmin_t b[t] -- the group minimum, then the smallest label attaining it (== the sequential
+        // "first minimum": comparisons are exact)
+        const float gm = group_min_fused<G>(fminf(fminf(b[0], b[1]), fminf(b[2], b[3])));
+        uint32_t bt = (b[3] == gm) ? t0 + 3u : 0xFFFFFFFFu;
+        bt = (b[2] == gm) ? t0 + 2u : bt; bt = (b[1] == gm) ? t0 + 1u : bt; bt = (b[0] == gm) ? t0 : bt;
         bt = group_min_fused<G>(bt);                          // every lane of the group holds the winner
         if (LATE_OLD) {
             // The previous outgoing message of edge (i -> j) is the run node j reads as "in" in this same sweep.  Issued
@@ -558,26 +564,19 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int a = (d == 0) ? 1 : 0, b2 = (d == 2) ? 1 : 2;  // the two other slots, adjacency order
-            float c[4], cm[4];
+            float c[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float oth = (0.0f + in[a][r]) + in[b2][r];
-                c[r] = (D[r] + rho * oth) - omr * in[d][r];
-                cm[r] = ok[r] ? c[r] : INFINITY;
-            }
-            const float cmin = group_min_fused<G>(fminf(fminf(cm[0], cm[1]), fminf(cm[2], cm[3])));
+            for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(nstep, cf[d][r], b[r]);
+            const float cmin = group_min_fused<G>(fminf(fminf(c[0], c[1]), fminf(c[2], c[3])));
             *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0], c[1], c[2], c[3]);
             const uint32_t mw = ident[d] ? ident_word : r_map[d];
             uint32_t w = 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t mp = (mw >> (8 * r)) & 0xFFu;
-                const uint32_t slot = (G < 64) ? min(mp, (uint32_t)(4 * G)) : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // 0xFF -> the +inf slot
-                const float cp = tile[slot];
-                const float raw = fminf(cp - cmin, lam);
-                const float old = (float)((r_old[d] >> (8 * r)) & 0xFFu) * mq.step;
-                w |= msg_code(DAMP ? (raw * oma + old * alpha) : raw, mq) << (8 * r);
+                const uint32_t slot = (G < 64) ? mp : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // "absent at the sender" -> the +inf slot (G < 64: the records hold 4 * G)
+                const float raw = fminf(tile[slot] - cmin, lam);
+                w = msg_pack<DAMP>(raw, oms, alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
             }
             if (t0 < kj3[d]) *reinterpret_cast<uint32_t*>(mn + o_out[d] + t0) = w;      // one 4-byte store (runs are padded)
         }
@@ -623,13 +622,16 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     if (K == 0) { if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; } return; }
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
-    const float omr = 1.0f - rho, lam = 1.0f / rho, oma = 1.0f - alpha;
+    const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
+    const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale;
+    // b[t] goes through the scratch row (K is unbounded here); same arithmetic as the fast path / the oracle
     float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
     for (uint32_t t = lane; t < K; t += 64) {
-        float S = 0.0f;
-        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) S = S + msg_load(mo, m.in_off + t, mq); }
-        const float b = cost_value(cost_code(cost[p0 + t])) + rho * S;   // the unaries as the sweeps see them: 16-bit fixed point
+        float Sc = 0.0f;
+        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) Sc = Sc + (float)mo[m.in_off + t]; }
+        const float b = __builtin_fmaf(kappa, Sc, cost_value(cost_code(cost[p0 + t])));   // the unaries as the sweeps see them: 16-bit fixed point
+        scratch[p0 + t] = b;
         if (b < bb) { bb = b; bt = t; }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -637,25 +639,18 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
     }
     if (lane == 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost_value(cost_code(cost[p0 + bt])); }
+    __syncthreads();
     for (uint32_t e = e0; e < e1; ++e) {
         const MrfEdge m = edge[e];
         if (!m.kj) continue;  // wave-uniform
         float cmin = INFINITY;
-        for (uint32_t t = lane; t < K; t += 64) {
-            float oth = 0.0f;
-            for (uint32_t e2 = e0; e2 < e1; ++e2) { if (e2 == e) continue; const MrfEdge m2 = edge[e2]; if (m2.kj) oth = oth + msg_load(mo, m2.in_off + t, mq); }
-            const float c = (cost_value(cost_code(cost[p0 + t])) + rho * oth) - omr * msg_load(mo, m.in_off + t, mq);
-            scratch[p0 + t] = c;
-            cmin = fminf(cmin, c);
-        }
+        for (uint32_t t = lane; t < K; t += 64) cmin = fminf(cmin, __builtin_fmaf(nstep, (float)mo[m.in_off + t], scratch[p0 + t]));
         for (int o = 32; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, 64));
-        __syncthreads();
         for (uint32_t t2 = lane; t2 < m.kj; t2 += 64) {
             const uint16_t p = map[m.out_off + t2];
-            const float raw = (p == MAP_NONE) ? lam : fminf(scratch[p0 + p] - cmin, lam);
-            mn[m.out_off + t2] = (msg_t)msg_code(DAMP ? (raw * oma + msg_load(mo, m.out_off + t2, mq) * alpha) : raw, mq);
+            const float raw = (p == MAP_NONE) ? lam : fminf(__builtin_fmaf(nstep, (float)mo[m.in_off + p], scratch[p0 + p]) - cmin, lam);
+            mn[m.out_off + t2] = (msg_t)msg_pack<DAMP>(raw, oms, alpha, (float)mo[m.out_off + t2], 0u, 0u);
         }
-        __syncthreads();
     }
 }
 
@@ -896,6 +891,9 @@ __global__ void mrf_flip_kernel(mvs_mrf_progress* __restrict__ st) { st->best_w 
 static bool mrf_fast_path(const mvs_ctx* ctx) {
     return ctx->m_degmax <= 3 && ctx->m_kmax <= 255 && ctx->csr_nnz >= 4 && ctx->m_total > MSG_BASE;
 }
+// lanes per node of the fast sweep for the largest column, and the byte "label absent at the sender" is recorded as
+static int mrf_group(uint32_t kmax) { return kmax <= 32 ? 8 : kmax <= 64 ? 16 : kmax <= 128 ? 32 : 64; }
+static uint32_t mrf_none_byte(uint32_t kmax) { const int g = mrf_group(kmax); return g < 64 ? (uint32_t)(4 * g) : 0xFFu; }
 constexpr uint32_t EPART_BLOCKS = 2048;   // per colour phase: upper bound of the sweep grid (resident blocks)
 
 // Builds the solver's edge tables for the active CSR (ctx->r_ptr / r_view / r_cost) and adjacency.
@@ -980,7 +978,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_fast = mrf_fast_path(ctx);
     if (ctx->m_fast) {
         // records + descriptors.  Upper bound of the record array (no read-back): labels nnz + 3 F, maps <= one byte per message element
-        const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + 64;
+        const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + 1024;   // incl. slack for reads past the last record
         ctx->m_rec.ensure(rec_cap);
         MVS_HIP(hipMemsetAsync(ctx->m_rec.p, 0, REC_BASE * sizeof(uint32_t), s));
         hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
@@ -988,7 +986,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, rsz); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, rsz, roff, (size_t)F + 1, nullptr);
         hipLaunchKernelGGL(mrf_record_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, roff, F, ctx->m_rec.p); MVS_LAUNCH_CHECK();
+                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, roff, F, mrf_none_byte(ctx->m_kmax), ctx->m_rec.p); MVS_LAUNCH_CHECK();
         ctx->m_desc.ensure((size_t)F + 1);
         hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, ctx->m_colour.p, roff, F, ctx->m_desc.p); MVS_LAUNCH_CHECK();
     } else {
@@ -997,8 +995,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         hipLaunchKernelGGL(mrf_identity_kernel, dim3(1), dim3(MSG_BASE), 0, s, ctx->m_map.p); MVS_LAUNCH_CHECK();   // map[t] = t for t < MSG_BASE
         if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p, 0); MVS_LAUNCH_CHECK(); }
     }
-    ctx->m_msg_a.ensure(ctx->m_total + 8);
-    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 8) * sizeof(msg_t), s));   // zero codes, incl. the reserved zero run
+    ctx->m_msg_a.ensure(ctx->m_total + 1024);   // slack: lanes beyond a run read on (up to 4 * 64 elements)
+    MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1024) * sizeof(msg_t), s));   // zero codes, incl. the reserved zero run
     MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
     // decode buffers: two of F + 1 entries each (see ctx.h)
     const size_t F1 = (size_t)F + 1;
@@ -1136,10 +1134,12 @@ void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
     if (qe <= qb) return;
     const uint32_t K = ctx->m_kmax;
     if (ctx->m_fast) {
-        if (K <= 32) launch_sweep4_g<8>(ctx, phase, qb, qe);
-        else if (K <= 64) launch_sweep4_g<16>(ctx, phase, qb, qe);
-        else if (K <= 128) launch_sweep4_g<32>(ctx, phase, qb, qe);
-        else launch_sweep4_g<64>(ctx, phase, qb, qe);      // one node per wave: scenes with several hundred views per face
+        switch (mrf_group(K)) {
+            case 8: launch_sweep4_g<8>(ctx, phase, qb, qe); break;
+            case 16: launch_sweep4_g<16>(ctx, phase, qb, qe); break;
+            case 32: launch_sweep4_g<32>(ctx, phase, qb, qe); break;
+            default: launch_sweep4_g<64>(ctx, phase, qb, qe);      // one node per wave: scenes with several hundred views per face
+        }
     } else {
         ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
         const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);

@@ -785,16 +785,17 @@ void orc_csr_free(orc_csr* c) {
 //    map[moff[e] + t] = position of L_i[t] inside L_j, or 0xFFFF.  m = 0 at start.
 //  * Schedule: the adjacency graph is coloured greedily in the order of the keys (hash32(i), i) (mrf_colour); one
 //    sweep = for colour 0, 1, ...: every node of that colour (an independent set) updates IN PLACE from the
-//    current messages.  The update of node i:
-//      S[t]  = sum over valid e (CSR order, from 0.0f) of m_e[t]
-//      b[t]  = D[t] + rho * S[t];  sel_i = first argmin_t b[t]
-//      for each valid e (to j):  oth[t] = sum over valid e' != e of m_e'[t]
-//        c[t]  = (D[t] + rho * oth[t]) - (1 - rho) * m_e[t];  cmin = min_t c[t]
+//    current messages.  Messages are STORED as 8-bit codes over their range [0, lam], lam = 1 / rho (a message is a
+//    truncated, min-normalised cavity): value = code * step, step = lam / 255, scale = 255 / lam.  The update of node i,
+//    written on the codes (mrf_sweep below is the definition, fma = IEEE fused multiply-add):
+//      Sc[t] = sum over valid e of code_e[t]                 (exact)
+//      b[t]  = fma(rho * step, Sc[t], D[t]);  sel_i = first argmin_t b[t]      D = the 16-bit fixed-point unaries
+//      for each valid e (to j):  c[t] = fma(-step, code_e[t], b[t]);  cmin = min_t c[t]
+//        ( = D + rho * sum_all m - m_e = (D + rho * sum_others m) - (1 - rho) * m_e, the tree-reweighted cavity )
 //        for t' < K_j:  p = map[moff[rev e] + t']
-//          raw = (p == NONE) ? lam : fminf(c[p] - cmin, lam),   lam = 1 / rho
-//          m'_{rev e}[t'] = q8( raw * (1 - alpha) + m_{rev e}[t'] * alpha )
-//        with alpha = damping on ODD sweeps (1st, 3rd, ...) and 0 on even sweeps, and q8 = the 8-bit fixed-point
-//        storage of the messages over [0, lam]: code = trunc(v * (255 / lam) + 0.5), value = code * (lam / 255)
+//          raw   = (p == NONE) ? lam : fminf(c[p] - cmin, lam)
+//          code' = rne( fma(old code, alpha, raw * ((1 - alpha) * scale)) ), saturated at 255
+//        with alpha = damping on ODD sweeps (1st, 3rd, ...) and 0 on even sweeps.
 //  * After each sweep the decoded labeling's energy is evaluated exactly in
 //    32.32 fixed point (integer sums are order independent); the best labeling
 //    so far is kept.  Stop like StopWhenReturnsDiminish(5, 0.01)
@@ -813,14 +814,17 @@ uint64_t* g_trace = nullptr; int g_trace_len = 0;
 inline uint64_t fix32(float d) { return (uint64_t)((double)d * 4294967296.0); }
 
 // Messages are STORED as 8-bit fixed point over their range [0, lam], lam = 1 / rho (a message is a truncated,
-// min-normalised cavity, so 0 <= m <= lam by construction); all arithmetic stays fp32:
-//   code = trunc(m * (255 / lam) + 0.5)  in 0 .. 255,   stored value = code * (lam / 255),
-// with 255 / lam and lam / 255 computed in fp32.  Part of the solver's definition: the labelings
-// reach the same energy as with binary16 or fp32 messages (C3: 1 111 920 vs 1 111 890) at half / a quarter of the bytes.
+// min-normalised cavity, so 0 <= m <= lam by construction): value = code * step, step = lam / 255, scale = 255 / lam
+// (both evaluated in fp32).  Part of the solver's definition: the labelings reach the same energy
+// as with binary16 or fp32 messages at half / a quarter of the bytes.
 struct MsgQ { float scale, step; };
 inline MsgQ msg_q(float lam) { return MsgQ{255.0f / lam, lam / 255.0f}; }
-inline uint32_t msg_code(float v, MsgQ q) { return (uint32_t)(int32_t)(v * q.scale + 0.5f); }   // 0 .. 255: the signed conversion vectorises
-inline float msg_store(float v, MsgQ q) { return (float)(int32_t)msg_code(v, q) * q.step; }
+// the code a message value `raw` in [0, lam] is stored as, damped against the old code (alpha = 0: undamped)
+inline uint32_t msg_code(float raw, float alpha, uint32_t old_code, MsgQ q) {
+    const float oms = (1.0f - alpha) * q.scale;
+    const long code = lrintf(__builtin_fmaf((float)old_code, alpha, raw * oms));   // round to nearest even
+    return (uint32_t)(code > 255 ? 255 : code);
+}
 
 struct Mrf {
     uint32_t F = 0;
@@ -906,15 +910,22 @@ int mrf_colour(const Mrf& g, std::vector<uint8_t>& colour) {
 // One phase of a sweep: all nodes of colour `phase` (an independent set) recompute their outgoing messages IN PLACE
 // from the current messages -- colour-phased Gauss-Seidel.  Within a phase no node reads what another writes.
 // Damping schedule: alpha = P.damping on ODD sweeps (1st, 3rd, ...), none on even sweeps.
-void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<float>& msg,
+// Messages live as their 8-bit codes (value = code * step); the update is written on the codes, with explicit fused
+// multiply-adds (IEEE fma: one rounding, identical on the CPU and the GPU):
+//   Sc[t] = sum of the incoming codes (small integers: exact in fp32 in any order)
+//   b[t]  = fma(rho * step, Sc[t], D[t])                       sel_i = first argmin_t b[t]
+//   c[t]  = fma(-step, code_e[t], b[t])                        ( = D + rho * sum_all - m_e, the reweighted cavity )
+//   raw   = (p == NONE) ? lam : fmin(c[p] - cmin, lam)
+//   code' = rne( fma(old_code, alpha, raw * ((1 - alpha) * scale)) ), saturated to 255
+void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<uint8_t>& msg,
                std::vector<uint32_t>& sel, int n_threads, const uint8_t* colour, int phase, uint32_t sweep_no) {
-    const std::vector<float>& mo = msg; std::vector<float>& mn = msg;
-    const float rho = P.rho, omr = 1.0f - P.rho, lam = 1.0f / P.rho;
-    const float alpha = (sweep_no & 1u) ? P.damping : 0.0f, oma = 1.0f - alpha;
+    const float lam = 1.0f / P.rho;
+    const float alpha = (sweep_no & 1u) ? P.damping : 0.0f;
     const MsgQ mq = msg_q(lam);
+    const float kappa = P.rho * mq.step, nstep = -mq.step;
 #pragma omp parallel num_threads(n_threads)
     {
-        std::vector<float> c;
+        std::vector<float> b, c;
 #pragma omp for schedule(dynamic, 1024)
         for (int64_t ii = 0; ii < (int64_t)g.F; ++ii) {
             const uint32_t i = (uint32_t)ii, Ki = g.K(i);
@@ -922,23 +933,21 @@ void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<float>& msg,
             const float* D = g.qcost + g.col_ptr[i];
             const uint32_t e0 = g.adj_ptr[i], e1 = g.adj_ptr[i + 1];
             // decode
+            b.resize(Ki); c.resize(Ki);
             uint32_t best_t = 0; float best_b = 0.0f;
             for (uint32_t t = 0; t < Ki; ++t) {
-                float S = 0.0f;
-                for (uint32_t e = e0; e < e1; ++e) if (g.valid[e]) S = S + mo[g.moff[e] + t];
-                const float b = D[t] + rho * S;
-                if (t == 0 || b < best_b) { best_b = b; best_t = t; }
+                float Sc = 0.0f;
+                for (uint32_t e = e0; e < e1; ++e) if (g.valid[e]) Sc = Sc + (float)msg[g.moff[e] + t];
+                b[t] = __builtin_fmaf(kappa, Sc, D[t]);
+                if (t == 0 || b[t] < best_b) { best_b = b[t]; best_t = t; }
             }
             sel[i] = best_t;
             // outgoing messages
-            c.resize(Ki);
             for (uint32_t e = e0; e < e1; ++e) {
                 if (!g.valid[e]) continue;
                 float cmin = 0.0f;
                 for (uint32_t t = 0; t < Ki; ++t) {
-                    float oth = 0.0f;
-                    for (uint32_t e2 = e0; e2 < e1; ++e2) if (e2 != e && g.valid[e2]) oth = oth + mo[g.moff[e2] + t];
-                    c[t] = (D[t] + rho * oth) - omr * mo[g.moff[e] + t];
+                    c[t] = __builtin_fmaf(nstep, (float)msg[g.moff[e] + t], b[t]);
                     if (t == 0 || c[t] < cmin) cmin = c[t];
                 }
                 const uint32_t j = g.adj[e], r = g.rev[e], Kj = g.K(j);
@@ -946,7 +955,7 @@ void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<float>& msg,
                 for (uint32_t t2 = 0; t2 < Kj; ++t2) {
                     const uint16_t p = g.map[o + t2];
                     const float raw = (p == MAP_NONE) ? lam : std::fmin(c[p] - cmin, lam);
-                    mn[o + t2] = msg_store(raw * oma + mo[o + t2] * alpha, mq);   // stored as an 8-bit code
+                    msg[o + t2] = (uint8_t)msg_code(raw, alpha, msg[o + t2], mq);
                 }
             }
         }
@@ -1034,8 +1043,7 @@ void orc_tri(const float p[6], float out[5], const float* xy, uint32_t n, uint8_
     out[0] = tri_area(t1, t2, t3); out[1] = r.min_x; out[2] = r.min_y; out[3] = r.max_x; out[4] = r.max_y;
     for (uint32_t k = 0; k < n; ++k) inside[k] = tri_inside(t1, t2, t3, r.detT, xy[2 * k], xy[2 * k + 1]) ? 1 : 0;
 }
-uint32_t orc_msg_code(float v, float rho) { return msg_code(v, msg_q(1.0f / rho)); }
-float orc_msg_store(float v, float rho) { return msg_store(v, msg_q(1.0f / rho)); }
+uint32_t orc_msg_code(float raw, float rho, float alpha, uint32_t old_code) { return msg_code(raw, alpha, old_code, msg_q(1.0f / rho)); }
 void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = len; }
 
 void orc_mrf_default_params(orc_mrf_params* p) {
@@ -1066,7 +1074,7 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     for (uint64_t k = 0; k < costs->nnz; ++k) qcost[k] = (float)(int32_t)(uint32_t)(costs->cost[k] * 65535.0f + 0.5f) * (1.0f / 65535.0f);
     g.qcost = qcost.data();
     const uint64_t M = g.moff[g.adj_ptr[g.F]];
-    std::vector<float> msg(M, 0.0f);
+    std::vector<uint8_t> msg(M, 0);   // 8-bit codes
     std::vector<uint8_t> colour;
     const int n_colours = mrf_colour(g, colour);
     std::vector<uint32_t> sel(g.F, 0), best_sel(g.F, 0);

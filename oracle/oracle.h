@@ -140,8 +140,7 @@ void orc_face_info(const uint8_t* rgb, const uint8_t* gmi, int w, int h, int dat
                    float* quality, float* color);
 /* Tri (tri.cpp:12-24, tri.h:58-84) as get_face_info uses it: out = {area, aabb min_x, min_y, max_x, max_y}; inside[k] = Tri::inside(xy[2k], xy[2k+1]) */
 void orc_tri(const float p[6], float out[5], const float* xy, uint32_t n, uint8_t* inside);
-uint32_t orc_msg_code(float v, float rho);
-float orc_msg_store(float v, float rho);
+uint32_t orc_msg_code(float raw, float rho, float alpha, uint32_t old_code);   /* the 8-bit code a message value is stored as (damped against the old code) */
 /* experiments: per-sweep energies of the decoded labeling are written to buf[0..len) */
 void orc_mrf_set_trace(uint64_t* buf, int len);
 int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,

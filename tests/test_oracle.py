@@ -144,26 +144,32 @@ def test_outlier_detection_matches_numpy_linear_algebra():
 
 
 def test_8bit_message_storage():
-    """the solver stores messages as 8-bit fixed point over [0, 1/rho]: the oracle's conversion equals a numpy restatement
-    in fp32 (code = trunc(v * (255 / lam) + 0.5), value = code * (lam / 255)), codes cover 0 .. 255, the stored value is
-    within half a step of the input and storing is idempotent"""
+    """the solver stores messages as 8-bit codes over [0, 1/rho]: the oracle's conversion equals a numpy restatement --
+    code = rne(fma(old, alpha, raw * ((1 - alpha) * (255 / lam)))) saturated at 255, products in fp32, the fma evaluated
+    exactly in fp64 and rounded once -- codes cover 0 .. 255, the undamped stored value (code * lam / 255) is within half a
+    step of the input, storing a stored value again is the identity, and full damping towards a code reproduces it"""
     L = O.load()
-    L.orc_msg_code.argtypes = [C.c_float, C.c_float]; L.orc_msg_code.restype = C.c_uint32
-    L.orc_msg_store.argtypes = [C.c_float, C.c_float]; L.orc_msg_store.restype = C.c_float
+    L.orc_msg_code.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32]; L.orc_msg_code.restype = C.c_uint32
     rng = np.random.default_rng(0)
     f32 = np.float32
     for rho in (f32(0.8), f32(1.0), f32(0.6667), f32(0.5)):
         lam = f32(1.0) / rho
         scale, step = f32(255.0) / lam, lam / f32(255.0)
-        x = np.concatenate([rng.random(3000).astype(np.float32) * lam, f32([0, lam, lam / 2, step / 2, step * 0.49, step * 254.5, 1e-9])]).astype(np.float32)
-        code = np.array([L.orc_msg_code(C.c_float(float(v)), C.c_float(float(rho))) for v in x], dtype=np.uint32)
-        ref = (x * scale + f32(0.5)).astype(np.float32).astype(np.uint32)          # fp32 multiply, fp32 add, truncation
-        assert np.array_equal(code, ref) and code.max() == 255 and code.min() == 0
-        val = np.array([L.orc_msg_store(C.c_float(float(v)), C.c_float(float(rho))) for v in x], dtype=np.float32)
-        assert np.array_equal(val.view(np.uint32), (ref.astype(np.float32) * step).view(np.uint32))
-        assert (np.abs(val - x) <= step * 0.5 * (1 + 1e-3) + 1e-7).all()
-        again = np.array([L.orc_msg_store(C.c_float(float(v)), C.c_float(float(rho))) for v in val], dtype=np.float32)
-        assert np.array_equal(again.view(np.uint32), val.view(np.uint32))
+        x = np.concatenate([rng.random(3000).astype(np.float32) * lam, f32([0, lam, lam / 2, step / 2, step * 0.49, step * 254.5, step * 1.5, step * 2.5, 1e-9])]).astype(np.float32)
+        for alpha in (f32(0.0), f32(0.2), f32(0.35)):
+            old = rng.integers(0, 256, len(x)).astype(np.uint32)
+            code = np.array([L.orc_msg_code(C.c_float(float(v)), C.c_float(float(rho)), C.c_float(float(alpha)), int(o)) for v, o in zip(x, old)], dtype=np.uint32)
+            oms = (f32(1.0) - alpha) * scale
+            t1 = (x * oms).astype(np.float32)                                           # fp32 product
+            v = (old.astype(np.float64) * np.float64(alpha) + t1.astype(np.float64)).astype(np.float32)   # exact in fp64, one rounding = fma
+            ref = np.minimum(np.rint(v), 255).astype(np.uint32)                         # round to nearest even
+            assert np.array_equal(code, ref)
+            if alpha == 0:
+                assert code.max() == 255 and code.min() == 0
+                val = code.astype(np.float32) * step
+                assert (np.abs(val - x) <= step * 0.5 * (1 + 1e-3) + 1e-7).all()
+                again = np.array([L.orc_msg_code(C.c_float(float(v)), C.c_float(float(rho)), C.c_float(0.0), 0) for v in val], dtype=np.uint32)
+                assert np.array_equal(again, code)
 
 
 def test_solver_quality_small_instances():
