@@ -257,8 +257,10 @@ typedef struct mvs_mrf_progress {
     uint32_t stopped;      /* the stop rule has fired (or max_sweeps reached) */
     uint32_t improved;     /* the last accounted sweep lowered the best energy */
     uint32_t stop_sweep;   /* sweep at which the rule fired = mvs_mrf_stats.sweeps */
-    uint64_t energy;       /* 32.32 fixed point energy of the last accounted sweep */
-    uint64_t best;         /* best energy so far */
+    uint64_t energy;       /* TRACKING energy of the last accounted sweep: the energy under the 16-bit unaries the sweeps see, an
+                              integer in units of 1 / 65535 (sum of cost codes + 65535 per cut edge).  It drives the stop rule and the
+                              choice of the best sweep; mvs_mrf_stats reports the exact 32.32 fixed-point energy of the result */
+    uint64_t best;         /* best tracking energy so far */
     uint32_t w;            /* decode buffer (0 / 1) the NEXT sweep writes */
     uint32_t best_w;       /* decode buffer holding the best labeling so far: "keep the best" flips the two indices, nothing is copied */
 } mvs_mrf_progress;

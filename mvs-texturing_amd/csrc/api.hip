@@ -357,7 +357,7 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     mvs_mrf_progress pg; memset(&pg, 0, sizeof(pg));
     auto report = [&](uint32_t n) {
         mrf_poll(ctx, n, &pg);
-        if (ctx->verbose) fprintf(stderr, "[mvs] sweep %u energy %.3f best %.3f%s\n", n, (double)pg.energy / 4294967296.0, (double)pg.best / 4294967296.0, pg.stopped ? " (stopped)" : "");
+        if (ctx->verbose) fprintf(stderr, "[mvs] sweep %u tracking energy %.3f best %.3f%s\n", n, (double)pg.energy / 65535.0, (double)pg.best / 65535.0, pg.stopped ? " (stopped)" : "");
     };
     int issued = 0, polled = 0;
     while (issued < P.max_sweeps && !pg.stopped) {

@@ -36,6 +36,17 @@ __device__ __forceinline__ MsgQ msg_q(float lam) { return MsgQ{255.0f / lam, lam
 // the code a message value `raw` in [0, lam] is stored as, damped against the old code (oracle.cpp msg_code):
 // rne(fma(old, alpha, raw * oms)), oms = (1 - alpha) * scale, saturated at 255 -- v_cvt_pk_u8_f32 IS a saturating
 // round-to-nearest-even conversion on gfx950 (scripts/probe/cvt_probe.hip), and it drops the byte into place
+// 32-bit byte offsets from a wave-uniform base: the load takes the base from SGPRs and the offset from one VGPR
+// (global_load ... v_off, s[base]) instead of a 64-bit address built with v_lshl_add_u64 per load
+template <class T> __device__ __forceinline__ T ld_off(const void* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
+template <class T> __device__ __forceinline__ void st_off(void* base, uint32_t byte_off, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+// v_min_f32 without the canonicalising v_max_f32 x, x, x the compiler puts in front of fminf() on values it loaded from
+// memory (no NaN can reach these operands: +inf and finite values only)
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <bool DAMP>
+__device__ __forceinline__ uint32_t msg_pack_s(float raw_s, float alpha, float old_code, uint32_t byte, uint32_t word) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(DAMP ? __builtin_fmaf(old_code, alpha, raw_s) : raw_s, byte, word);
+}
 template <bool DAMP>
 __device__ __forceinline__ uint32_t msg_pack(float raw, float oms, float alpha, float old_code, uint32_t byte, uint32_t word) {
     const float v = DAMP ? __builtin_fmaf(old_code, alpha, raw * oms) : raw * oms;
@@ -489,57 +500,64 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     uint32_t* __restrict__ sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* __restrict__ selcost = cost2 + wofs;
     const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
-    const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale;   // the oracle's constants, fp32
+    const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;   // the oracle's constants, fp32
     constexpr float HUGE_COST = 1e30f;                       // unary of the label slots beyond the column: never a minimum
     const uint32_t stride = gridDim.x * NPB;
     uint32_t vb = blockIdx.x;
     if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     uint32_t i = node_begin + vb * NPB + grp;
     const uint32_t last = node_end - 1;
-    NodeDesc nd = desc[min(i, last)];
     const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
     const uint32_t t0 = 4u * gl;
     const uint32_t ident_word = 0x03020100u + 0x04040404u * (uint32_t)gl;   // map bytes of an identical-list edge: t0 .. t0 + 3
-    unsigned long long acc_e = 0ull; uint32_t acc_c = 0u;
+    // Software pipeline, two nodes deep: while a lane group computes node `it`, the loads of node `it + 1` (label words,
+    // three incoming runs, three map words, three neighbour labels and -- damped sweeps -- the three old outgoing runs)
+    // and the descriptor of node `it + 2` are in flight.  The kernel had been latency bound: waves parked on memory 65 %
+    // of their time with the vector unit 60 % busy and HBM at 3.5 TB/s (PMC, profiles/).  Same-colour nodes never touch
+    // each other's runs or labels, so reading a node's inputs one iteration early cannot observe a write of this launch.
+    // No address needs a select: a lane beyond the column / the neighbour's column reads whatever follows the run or
+    // the record (valid memory -- both arrays carry slack -- and lines its neighbours fetch anyway) and its values never
+    // reach a valid label; an absent edge has offsets 0 in the descriptor, i.e. the reserved zero run.
+    struct Raw { uint4 lw; uint32_t in[3], map[3], nl[3], old[3]; };
+    const uint32_t t0b = 4u * t0, glb = 4u * (uint32_t)gl;   // byte offsets of the lane's label words / map word inside a record
+    auto issue = [&](const NodeDesc& d, Raw& r) {
+        const uint32_t K = d.kk & 0xFFu, recb = 4u * d.rec;
+        r.lw = ld_off<uint4>(rec, recb + t0b);
+        uint32_t mposb = recb + 4u * ((K + 3u) & ~3u) + glb;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            r.in[e] = ld_off<uint32_t>(mo, (d.in_off[e] & ~3u) + t0);
+            r.map[e] = ld_off<uint32_t>(rec, mposb);
+            if (!(d.out_off[e] & 1u)) mposb += (((d.kk >> (8 + 8 * e)) & 0xFFu) + 3u) & ~3u;   // 4 bytes per 4 map entries
+            r.nl[e] = ld_off<uint32_t>(lab, 4u * d.nbr[e]);     // an absent neighbour is recorded as the node itself
+            if (DAMP) r.old[e] = ld_off<uint32_t>(mo, (d.out_off[e] & ~3u) + t0); else r.old[e] = 0u;
+        }
+    };
+    NodeDesc cur = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i, last));
+    Raw rw; issue(cur, rw);
+    NodeDesc nxt = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i + stride, last));
+    uint32_t acc_e = 0u, acc_c = 0u;                         // sum of the decoded labels' cost codes (< 2^32 per thread: <= 65535 per node) and cut edges
+#pragma unroll 2
     for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
         const bool node_ok = i < node_end;
-        const NodeDesc cur = nd;
-        nd = desc[min(i + stride, last)];
+        Raw rn; issue(nxt, rn);                                // node it + 1 (clamped to the last descriptor past the end: harmless reads)
+        const NodeDesc nn = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i + 2u * stride, last));  // node it + 2
         const uint32_t K = node_ok ? (cur.kk & 0xFFu) : 0u;
         bool ok[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ok[r] = t0 + r < K;
-        // phase 1: addresses; phase 2: ALL loads as raw 4/16-byte words, issued back to back under one wait (a load
-        // under a divergent branch would get its own exec region and s_waitcnt); phase 3: unpack.  No address needs a
-        // select: a lane beyond the column / the neighbour's column reads whatever follows the run or the record (valid
-        // memory -- both arrays carry slack -- and lines its neighbours fetch anyway) and its values never reach a valid
-        // label; an absent edge has offsets 0 in the descriptor, i.e. the reserved zero run.
-        const uint32_t la = cur.rec + t0;
-        uint32_t a_in[3], a_out[3], a_map[3], kj3[3], o_out[3]; bool ident[3], low[3];
-        uint32_t mpos = cur.rec + ((K + 3u) & ~3u) + (uint32_t)gl;
+        uint32_t kj3[3], o_out[3]; bool ident[3], low[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             kj3[d] = node_ok ? ((cur.kk >> (8 + 8 * d)) & 0xFFu) : 0u;
             ident[d] = (cur.out_off[d] & 1u) != 0u; low[d] = (cur.in_off[d] & 1u) != 0u && kj3[d] != 0u;
             o_out[d] = cur.out_off[d] & ~3u;
-            a_in[d] = (cur.in_off[d] & ~3u) + t0;
-            a_out[d] = o_out[d] + t0;
-            a_map[d] = mpos;
-            if (!ident[d]) mpos += (kj3[d] + 3u) >> 2;
         }
-        const uint4 lw4 = *reinterpret_cast<const uint4*>(rec + la);
-        uint32_t r_in[3], r_old[3], r_map[3], nl[3];   // four 8-bit messages / four map bytes per 4-byte word
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            r_in[d] = *reinterpret_cast<const uint32_t*>(mo + a_in[d]);
-            r_map[d] = rec[a_map[d]];
-            nl[d] = lab[cur.nbr[d]];                          // an absent neighbour is recorded as the node itself
-            if (!LATE_OLD) { if (DAMP) r_old[d] = *reinterpret_cast<const uint32_t*>(mo + a_out[d]); else r_old[d] = 0u; }
-        }
-        const uint32_t lw[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+        const uint32_t lw[4] = {rw.lw.x, rw.lw.y, rw.lw.z, rw.lw.w};
+        const uint32_t* r_in = rw.in; const uint32_t* r_map = rw.map; const uint32_t* nl = rw.nl; const uint32_t* r_old = rw.old;
         // The update on the 8-bit codes (oracle.cpp mrf_sweep is the definition): Sc = sum of the incoming codes (exact),
-        // b = fma(rho * step, Sc, D), c_e = fma(-step, code_e, b) -- the reweighted cavity D + rho * sum_all - m_e --
-        // code' = rne(fma(old, alpha, min(c[p] - cmin, lam) * ((1 - alpha) * scale))).
+        // b = fma(rho * step, Sc, D), cs_e = fma(-step, code_e, b) * oms -- the reweighted cavity D + rho * sum_all - m_e in
+        // damped code units, oms = (1 - alpha) * scale -- code' = rne(fma(old, alpha, min(cs[p] - cmin, lam * oms))).
         float cf[3][4], b[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -554,45 +572,39 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         uint32_t bt = (b[3] == gm) ? t0 + 3u : 0xFFFFFFFFu;
         bt = (b[2] == gm) ? t0 + 2u : bt; bt = (b[1] == gm) ? t0 + 1u : bt; bt = (b[0] == gm) ? t0 : bt;
         bt = group_min_fused<G>(bt);                          // every lane of the group holds the winner
-        if (LATE_OLD) {
-            // The previous outgoing message of edge (i -> j) is the run node j reads as "in" in this same sweep.  Issued
-            // only now -- after this block's own "in" loads have landed (the decode above consumed them) -- the read hits
-            // the CU's L1 / the XCD's L2 whenever j is swept by this block too, instead of racing the first fetch to HBM.
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { if (DAMP) r_old[d] = *reinterpret_cast<const uint32_t*>(mo + a_out[d]); else r_old[d] = 0u; }
-        }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float c[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(nstep, cf[d][r], b[r]);
+            for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(nstep, cf[d][r], b[r]) * oms;
             const float cmin = group_min_fused<G>(fminf(fminf(c[0], c[1]), fminf(c[2], c[3])));
-            *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0], c[1], c[2], c[3]);
+            // the tile holds cs - cmin (the same subtraction the oracle performs after its gather); the extra slot stays +inf
+            *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0] - cmin, c[1] - cmin, c[2] - cmin, c[3] - cmin);
             const uint32_t mw = ident[d] ? ident_word : r_map[d];
             uint32_t w = 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t mp = (mw >> (8 * r)) & 0xFFu;
                 const uint32_t slot = (G < 64) ? mp : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // "absent at the sender" -> the +inf slot (G < 64: the records hold 4 * G)
-                const float raw = fminf(tile[slot] - cmin, lam);
-                w = msg_pack<DAMP>(raw, oms, alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
+                w = msg_pack_s<DAMP>(min_raw(tile[slot], lam_s), alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
             }
-            if (t0 < kj3[d]) *reinterpret_cast<uint32_t*>(mn + o_out[d] + t0) = w;      // one 4-byte store (runs are padded)
+            if (t0 < kj3[d]) st_off<uint32_t>(mn, o_out[d] + t0, w);      // one 4-byte store (runs are padded)
         }
         // the lane that owns the winning label publishes the decode (K == 0: lane 0 publishes the single label 0 with
-        // unary 1, view_selection.cpp:50-51,70-71) and accounts the node's share of the energy
+        // unary 1, view_selection.cpp:50-51,70-71) and accounts the node's share of the tracking energy (integer:
+        // cost codes + 65535 per cut edge, oracle.cpp mrf_energy_sel)
         const bool owner = node_ok && ((K > 0u) ? ((bt >> 2) == (uint32_t)gl) : (gl == 0));
         if (owner) {
             const uint32_t r = bt & 3u;
             const uint32_t wsel = (r == 0u) ? lw[0] : (r == 1u) ? lw[1] : (r == 2u) ? lw[2] : lw[3];
             const uint32_t my_lab = (K > 0u) ? (wsel & 0xFFFFu) + 1u : 0u;
-            const float my_cost = (K > 0u) ? cost_value(wsel >> 16) : 1.0f;
-            const uint32_t id = cur.id;
-            sel[id] = (K > 0u) ? bt : 0u; lab[id] = my_lab; selcost[id] = my_cost;
-            acc_e += fix32(my_cost);
+            const uint32_t my_code = (K > 0u) ? (wsel >> 16) : 65535u;
+            const uint32_t idb = 4u * cur.id;
+            st_off<uint32_t>(sel, idb, (K > 0u) ? bt : 0u); st_off<uint32_t>(lab, idb, my_lab); st_off<float>(selcost, idb, cost_value(my_code));
+            acc_e += my_code;
             acc_c += (low[0] && nl[0] != my_lab) + (low[1] && nl[1] != my_lab) + (low[2] && nl[2] != my_lab);
         }
+        cur = nxt; rw = rn; nxt = nn;
     }
     // one partial pair per block (no atomics: same-address atomics serialise at ~12 ns each)
     unsigned long long e = acc_e, c = acc_c;
@@ -601,7 +613,7 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     __syncthreads();
     if (threadIdx.x == 0) {
         e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; c = s_e[4] + s_e[5] + s_e[6] + s_e[7];
-        partial[2 * blockIdx.x] = e + (c << 32); partial[2 * blockIdx.x + 1] = c;
+        partial[2 * blockIdx.x] = e + 65535ull * c; partial[2 * blockIdx.x + 1] = c;
     }
 }
 
@@ -624,7 +636,7 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
     const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
-    const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale;
+    const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;
     // b[t] goes through the scratch row (K is unbounded here); same arithmetic as the fast path / the oracle
     float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
     for (uint32_t t = lane; t < K; t += 64) {
@@ -644,12 +656,12 @@ __global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* _
         const MrfEdge m = edge[e];
         if (!m.kj) continue;  // wave-uniform
         float cmin = INFINITY;
-        for (uint32_t t = lane; t < K; t += 64) cmin = fminf(cmin, __builtin_fmaf(nstep, (float)mo[m.in_off + t], scratch[p0 + t]));
+        for (uint32_t t = lane; t < K; t += 64) cmin = fminf(cmin, __builtin_fmaf(nstep, (float)mo[m.in_off + t], scratch[p0 + t]) * oms);
         for (int o = 32; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, 64));
         for (uint32_t t2 = lane; t2 < m.kj; t2 += 64) {
             const uint16_t p = map[m.out_off + t2];
-            const float raw = (p == MAP_NONE) ? lam : fminf(__builtin_fmaf(nstep, (float)mo[m.in_off + p], scratch[p0 + p]) - cmin, lam);
-            mn[m.out_off + t2] = (msg_t)msg_pack<DAMP>(raw, oms, alpha, (float)mo[m.out_off + t2], 0u, 0u);
+            const float raw = (p == MAP_NONE) ? lam_s : fminf(__builtin_fmaf(nstep, (float)mo[m.in_off + p], scratch[p0 + p]) * oms - cmin, lam_s);
+            mn[m.out_off + t2] = (msg_t)msg_pack_s<DAMP>(raw, alpha, (float)mo[m.out_off + t2], 0u, 0u);
         }
     }
 }
@@ -661,10 +673,12 @@ __global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ lab, const float* __restrict__ selcost,
                                                          const mvs_mrf_progress* __restrict__ st /* non-null: the decode buffer st->w of lab / selcost */, uint32_t buf_stride,
                                                          uint32_t node_begin, uint32_t node_end, unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
+    // st != null: the TRACKING energy of the current decode (its unaries are dequantised 16-bit codes: integer units of
+    // 1 / 65535, 65535 per cut edge); else the exact 32.32 fixed-point energy of the labeling given
     if (st) { const uint32_t wofs = st->w * buf_stride; lab += wofs; selcost += wofs; }
     unsigned long long unary = 0, cuts = 0;
     for (uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x; i < node_end; i += gridDim.x * blockDim.x) {
-        unary += fix32(selcost[i]);
+        unary += st ? (unsigned long long)cost_code(selcost[i]) : fix32(selcost[i]);
         const uint32_t li = lab[i];
         if (li == 0u) continue;
         for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
@@ -682,7 +696,7 @@ __global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restr
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long u = su[0] + su[1] + su[2] + su[3], c = sc[0] + sc[1] + sc[2] + sc[3];
-        out[2 * blockIdx.x] = u + (c << 32); out[2 * blockIdx.x + 1] = c;
+        out[2 * blockIdx.x] = st ? u + 65535ull * c : u + (c << 32); out[2 * blockIdx.x + 1] = c;
     }
 }
 __global__ void __launch_bounds__(256) mrf_energy_reduce_kernel(const unsigned long long* __restrict__ partial, uint32_t n_blocks,
@@ -846,21 +860,26 @@ __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t nod
 // "Keep the best labeling" is a flip of two indices: the sweep that improved the best energy wrote decode buffer w, which
 // becomes best_w, and the next sweeps write the other buffer -- nothing is copied.  The report goes straight into the
 // pinned ring slot (host memory), so a step is ONE launch.
-__global__ void __launch_bounds__(256) mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
+__global__ void __launch_bounds__(1024) mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
                                 const unsigned long long* __restrict__ energy, const unsigned long long* __restrict__ partial, uint32_t n_partial,
                                 unsigned long long* __restrict__ energy_out, mvs_mrf_progress* __restrict__ report, int max_sweeps, int min_sweeps, int window,
                                 float min_improvement) {
-    __shared__ unsigned long long su[4], sc[4];
+    __shared__ unsigned long long su[16], sc[16];
     unsigned long long e_sum = 0, c_sum = 0;
     if (partial) {
-        for (uint32_t b = threadIdx.x; b < n_partial; b += 256u) { e_sum += partial[2 * b]; c_sum += partial[2 * b + 1]; }
+        // up to 8192 pairs: 1024 threads, the loads of a thread independent of each other (a serial 256-thread loop was
+        // a chain of 32 dependent round trips: 15 us per sweep)
+        const ulonglong2* pp = reinterpret_cast<const ulonglong2*>(partial);
+#pragma unroll 8
+        for (uint32_t b = threadIdx.x; b < n_partial; b += 1024u) { const ulonglong2 v = pp[b]; e_sum += v.x; c_sum += v.y; }
         for (int o = 32; o > 0; o >>= 1) { e_sum += __shfl_xor(e_sum, o, 64); c_sum += __shfl_xor(c_sum, o, 64); }
         if ((threadIdx.x & 63) == 0) { su[threadIdx.x >> 6] = e_sum; sc[threadIdx.x >> 6] = c_sum; }
         __syncthreads();
     }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (partial) {
-        e_sum = su[0] + su[1] + su[2] + su[3]; c_sum = sc[0] + sc[1] + sc[2] + sc[3];
+        e_sum = 0; c_sum = 0;
+        for (int k = 0; k < 16; ++k) { e_sum += su[k]; c_sum += sc[k]; }
         energy_out[0] = e_sum; energy_out[1] = c_sum;
     }
     mvs_mrf_progress p = *st;
@@ -1056,7 +1075,7 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
     const uint32_t n = ++ctx->steps_issued, slot = n % mvs_ctx::RING;
     const unsigned long long* partial = nullptr; uint32_t n_partial = 0;
     if (!energy) { partial = ctx->m_energy.p + 4; n_partial = ctx->m_energy_from_sweep ? EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u) : ctx->m_energy_blocks; }
-    hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(256), 0, s, ctx->m_state.p, ctx->m_hist.p, energy, partial, n_partial, ctx->m_energy.p,
+    hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(1024), 0, s, ctx->m_state.p, ctx->m_hist.p, energy, partial, n_partial, ctx->m_energy.p,
                        ctx->d_ring + slot, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
     MVS_LAUNCH_CHECK();
     ctx->icm_dirty_valid = false; ctx->best_resolved = false;   // the best labeling may change

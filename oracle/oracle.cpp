@@ -793,8 +793,9 @@ void orc_csr_free(orc_csr* c) {
 //      for each valid e (to j):  c[t] = fma(-step, code_e[t], b[t]);  cmin = min_t c[t]
 //        ( = D + rho * sum_all m - m_e = (D + rho * sum_others m) - (1 - rho) * m_e, the tree-reweighted cavity )
 //        for t' < K_j:  p = map[moff[rev e] + t']
-//          raw   = (p == NONE) ? lam : fminf(c[p] - cmin, lam)
-//          code' = rne( fma(old code, alpha, raw * ((1 - alpha) * scale)) ), saturated at 255
+//          ( c and lam taken in damped code units: cs = c * oms, lam_s = lam * oms, oms = (1 - alpha) * scale )
+//          raw   = (p == NONE) ? lam_s : fminf(cs[p] - cmin_s, lam_s)
+//          code' = rne( fma(old code, alpha, raw) ), saturated at 255
 //        with alpha = damping on ODD sweeps (1st, 3rd, ...) and 0 on even sweeps.
 //  * After each sweep the decoded labeling's energy is evaluated exactly in
 //    32.32 fixed point (integer sums are order independent); the best labeling
@@ -819,10 +820,10 @@ inline uint64_t fix32(float d) { return (uint64_t)((double)d * 4294967296.0); }
 // as with binary16 or fp32 messages at half / a quarter of the bytes.
 struct MsgQ { float scale, step; };
 inline MsgQ msg_q(float lam) { return MsgQ{255.0f / lam, lam / 255.0f}; }
-// the code a message value `raw` in [0, lam] is stored as, damped against the old code (alpha = 0: undamped)
-inline uint32_t msg_code(float raw, float alpha, uint32_t old_code, MsgQ q) {
-    const float oms = (1.0f - alpha) * q.scale;
-    const long code = lrintf(__builtin_fmaf((float)old_code, alpha, raw * oms));   // round to nearest even
+// the code a message is stored as: `raw_s` = its value in damped code units, (1 - alpha) * scale * value, in
+// [0, (1 - alpha) * 255]; damped against the old code (alpha = 0: undamped)
+inline uint32_t msg_code(float raw_s, float alpha, uint32_t old_code) {
+    const long code = lrintf(__builtin_fmaf((float)old_code, alpha, raw_s));   // round to nearest even
     return (uint32_t)(code > 255 ? 255 : code);
 }
 
@@ -869,14 +870,16 @@ void mrf_setup(Mrf& g) {
         }
 }
 
-uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t* cuts_out, int n_threads = 1, const float* cost = nullptr) {
-    if (!cost) cost = g.cost;
+// exact energy in 32.32 fixed point (qcode == nullptr), or the solver's TRACKING energy: the same sum over the 16-bit
+// unaries the sweeps see, in units of 1 / 65535 (sum of cost codes + 65535 per cut edge) -- pure integer arithmetic
+uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t* cuts_out, int n_threads = 1, const uint16_t* qcode = nullptr) {
+    const float* cost = g.cost;
     uint64_t unary = 0, cuts = 0;
 #pragma omp parallel for schedule(static) num_threads(n_threads) reduction(+ : unary, cuts)
     for (int64_t ii = 0; ii < (int64_t)g.F; ++ii) {
         const uint32_t i = (uint32_t)ii;
-        if (g.K(i) == 0) { unary += fix32(1.0f); continue; }   /* view_selection.cpp:70-71 */
-        unary += fix32(cost[g.col_ptr[i] + sel[i]]);
+        if (g.K(i) == 0) { unary += qcode ? 65535u : fix32(1.0f); continue; }   /* view_selection.cpp:70-71 */
+        unary += qcode ? (uint64_t)qcode[g.col_ptr[i] + sel[i]] : fix32(cost[g.col_ptr[i] + sel[i]]);
         const uint16_t li = g.view_id[g.col_ptr[i] + sel[i]];
         for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) {
             const uint32_t j = g.adj[e];
@@ -885,7 +888,7 @@ uint64_t mrf_energy_sel(const Mrf& g, const std::vector<uint32_t>& sel, uint64_t
         }
     }
     if (cuts_out) *cuts_out = cuts;
-    return unary + (cuts << 32);
+    return qcode ? unary + 65535ull * cuts : unary + (cuts << 32);
 }
 
 // Greedy colouring of the adjacency graph in the order of the keys (hash32(i), i): node i takes the smallest
@@ -914,15 +917,16 @@ int mrf_colour(const Mrf& g, std::vector<uint8_t>& colour) {
 // multiply-adds (IEEE fma: one rounding, identical on the CPU and the GPU):
 //   Sc[t] = sum of the incoming codes (small integers: exact in fp32 in any order)
 //   b[t]  = fma(rho * step, Sc[t], D[t])                       sel_i = first argmin_t b[t]
-//   c[t]  = fma(-step, code_e[t], b[t])                        ( = D + rho * sum_all - m_e, the reweighted cavity )
-//   raw   = (p == NONE) ? lam : fmin(c[p] - cmin, lam)
-//   code' = rne( fma(old_code, alpha, raw * ((1 - alpha) * scale)) ), saturated to 255
+//   c[t]  = fma(-step, code_e[t], b[t]) * oms                  ( D + rho * sum_all - m_e, the reweighted cavity, in damped
+//                                                                code units: oms = (1 - alpha) * scale, lam_s = lam * oms )
+//   raw   = (p == NONE) ? lam_s : fmin(c[p] - cmin, lam_s)
+//   code' = rne( fma(old_code, alpha, raw) ), saturated to 255
 void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<uint8_t>& msg,
                std::vector<uint32_t>& sel, int n_threads, const uint8_t* colour, int phase, uint32_t sweep_no) {
     const float lam = 1.0f / P.rho;
     const float alpha = (sweep_no & 1u) ? P.damping : 0.0f;
     const MsgQ mq = msg_q(lam);
-    const float kappa = P.rho * mq.step, nstep = -mq.step;
+    const float kappa = P.rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;
 #pragma omp parallel num_threads(n_threads)
     {
         std::vector<float> b, c;
@@ -945,17 +949,17 @@ void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<uint8_t>& msg,
             // outgoing messages
             for (uint32_t e = e0; e < e1; ++e) {
                 if (!g.valid[e]) continue;
-                float cmin = 0.0f;
+                float cmin = 0.0f;                               // of the cavity in (damped) code units: c * oms
                 for (uint32_t t = 0; t < Ki; ++t) {
-                    c[t] = __builtin_fmaf(nstep, (float)msg[g.moff[e] + t], b[t]);
+                    c[t] = __builtin_fmaf(nstep, (float)msg[g.moff[e] + t], b[t]) * oms;
                     if (t == 0 || c[t] < cmin) cmin = c[t];
                 }
                 const uint32_t j = g.adj[e], r = g.rev[e], Kj = g.K(j);
                 const uint64_t o = g.moff[r];
                 for (uint32_t t2 = 0; t2 < Kj; ++t2) {
                     const uint16_t p = g.map[o + t2];
-                    const float raw = (p == MAP_NONE) ? lam : std::fmin(c[p] - cmin, lam);
-                    msg[o + t2] = (uint8_t)msg_code(raw, alpha, msg[o + t2], mq);
+                    const float raw = (p == MAP_NONE) ? lam_s : std::fmin(c[p] - cmin, lam_s);
+                    msg[o + t2] = (uint8_t)msg_code(raw, alpha, msg[o + t2]);
                 }
             }
         }
@@ -1043,7 +1047,10 @@ void orc_tri(const float p[6], float out[5], const float* xy, uint32_t n, uint8_
     out[0] = tri_area(t1, t2, t3); out[1] = r.min_x; out[2] = r.min_y; out[3] = r.max_x; out[4] = r.max_y;
     for (uint32_t k = 0; k < n; ++k) inside[k] = tri_inside(t1, t2, t3, r.detT, xy[2 * k], xy[2 * k + 1]) ? 1 : 0;
 }
-uint32_t orc_msg_code(float raw, float rho, float alpha, uint32_t old_code) { return msg_code(raw, alpha, old_code, msg_q(1.0f / rho)); }
+uint32_t orc_msg_code(float raw, float rho, float alpha, uint32_t old_code) {
+    const MsgQ q = msg_q(1.0f / rho);
+    return msg_code(raw * ((1.0f - alpha) * q.scale), alpha, old_code);
+}
 void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = len; }
 
 void orc_mrf_default_params(orc_mrf_params* p) {
@@ -1070,8 +1077,11 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     // Part of the solver's definition: the GPU streams {view id, cost code} as one 32-bit word per label.  The energies
     // that drive the stop rule and the choice of the best sweep are those of the SAME quantised unaries ("tracking energy");
     // the ICM polish and the energy that is reported use the exact costs.
-    std::vector<float> qcost(costs->nnz);
-    for (uint64_t k = 0; k < costs->nnz; ++k) qcost[k] = (float)(int32_t)(uint32_t)(costs->cost[k] * 65535.0f + 0.5f) * (1.0f / 65535.0f);
+    std::vector<float> qcost(costs->nnz); std::vector<uint16_t> qcode(costs->nnz);
+    for (uint64_t k = 0; k < costs->nnz; ++k) {
+        qcode[k] = (uint16_t)(uint32_t)(costs->cost[k] * 65535.0f + 0.5f);
+        qcost[k] = (float)(int32_t)qcode[k] * (1.0f / 65535.0f);
+    }
     g.qcost = qcost.data();
     const uint64_t M = g.moff[g.adj_ptr[g.F]];
     std::vector<uint8_t> msg(M, 0);   // 8-bit codes
@@ -1084,7 +1094,7 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     uint32_t s = 0;
     for (s = 1; (int)s <= P.max_sweeps; ++s) {
         for (int phase = 0; phase < n_colours; ++phase) mrf_sweep(g, P, msg, sel, n_threads, colour.data(), phase, s);
-        uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts, n_threads, g.qcost);
+        uint64_t cuts; const uint64_t e = mrf_energy_sel(g, sel, &cuts, n_threads, qcode.data());
         if (e < best_e) { best_e = e; best_cuts = cuts; best_sel = sel; }
         hist.push_back(best_e);
         if (g_trace && (int)s <= g_trace_len) g_trace[s - 1] = e;

@@ -145,7 +145,7 @@ def test_outlier_detection_matches_numpy_linear_algebra():
 
 def test_8bit_message_storage():
     """the solver stores messages as 8-bit codes over [0, 1/rho]: the oracle's conversion equals a numpy restatement --
-    code = rne(fma(old, alpha, raw * ((1 - alpha) * (255 / lam)))) saturated at 255, products in fp32, the fma evaluated
+    code = rne(fma(old, alpha, raw_s)), raw_s = raw * ((1 - alpha) * (255 / lam)), saturated at 255, products in fp32, the fma evaluated
     exactly in fp64 and rounded once -- codes cover 0 .. 255, the undamped stored value (code * lam / 255) is within half a
     step of the input, storing a stored value again is the identity, and full damping towards a code reproduces it"""
     L = O.load()
