@@ -326,6 +326,34 @@ mvs_status mvs_ctx_get_subgraphs(mvs_ctx* ctx, uint32_t n_faces, const uint32_t*
                                  const uint32_t* labels, int labels_on_device, uint32_t n_labels, mvs_subgraphs* out,
                                  int out_on_device);
 
+/* ---- sharded view selection: one rank per GPU, host side in C++, RCCL halo exchange (csrc/shard.hip; DESIGN.md "Multi-GPU") ----
+ * Faces are cut into `world` contiguous parts part_begin[0 .. world] (the caller renumbers the faces along a space-filling
+ * curve so that parts are compact).  Every rank holds the replicated scene and the full adjacency; it evaluates the data
+ * costs of its part, keeps a cost table of the GLOBAL shape with only its own and its halo columns filled, sweeps its own
+ * nodes and exchanges -- after every colour phase -- the message runs written in that phase over cut edges (as bytes) and the
+ * labels of that phase's boundary nodes with the ranks that own the neighbours: grouped ncclSend / ncclRecv, neighbours
+ * only.  Results are bit-identical to the single-GPU path for any number of parts.
+ *
+ * Communicators: RCCL (mvs_comm_unique_id on rank 0, the 128 bytes travel by any means, mvs_comm_create_rccl on every
+ * rank) or an in-process one for `world` host threads sharing a device (mvs_comm_create_local: tests on a 1-GPU box). */
+#define MVS_COMM_ID_BYTES 128
+typedef struct mvs_comm mvs_comm;
+typedef struct mvs_shard mvs_shard;
+mvs_status mvs_comm_unique_id(uint8_t id_out[MVS_COMM_ID_BYTES]);
+mvs_status mvs_comm_create_rccl(int device, int rank, int world, const uint8_t id[MVS_COMM_ID_BYTES], mvs_comm** out);
+mvs_status mvs_comm_create_local(int world, mvs_comm** out /* [world] */);
+void mvs_comm_destroy(mvs_comm* comm);
+/* ctx: the rank's context with the FULL mesh and all views set; adjacency: device pointers to the full graph (borrowed) */
+mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_begin /* host, [world + 1] */,
+                            const uint32_t* adj_ptr_device, const uint32_t* adj_device, mvs_shard** out);
+void mvs_shard_destroy(mvs_shard* shard);
+/* tex::calculate_data_costs over all ranks; stats = this rank's pairs / culls, max_quality and percentile global */
+mvs_status mvs_shard_data_costs(mvs_shard* shard, const mvs_settings* settings, mvs_dc_stats* stats, uint64_t* nnz_global);
+/* tex::view_selection over all ranks; labels of the OWN nodes (part_begin[rank] ..) into labels_own_device; stats global */
+mvs_status mvs_shard_view_selection(mvs_shard* shard, const mvs_mrf_params* params, uint32_t* labels_own_device, mvs_mrf_stats* stats);
+/* halo plan of the last view selection: message bytes this rank sends per sweep, its boundary nodes, device time of the planning */
+mvs_status mvs_shard_plan_info(mvs_shard* shard, uint64_t* msg_bytes_per_sweep, uint64_t* boundary_nodes, double* plan_ms);
+
 #ifdef __cplusplus
 }
 #endif

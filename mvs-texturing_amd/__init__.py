@@ -14,5 +14,6 @@ library or a device is missing.
 """
 from . import synth  # noqa: F401
 from . import viewsel  # noqa: F401
+from . import shard  # noqa: F401
 from .viewsel import (Context, Settings, MrfParams, MvsError, calculate_data_costs, view_selection,  # noqa: F401
                       prepare_mesh, build_adjacency_graph, get_subgraphs, lib_path, load_library)

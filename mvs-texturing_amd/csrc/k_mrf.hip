@@ -699,15 +699,17 @@ __global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restr
         out[2 * blockIdx.x] = st ? u + 65535ull * c : u + (c << 32); out[2 * blockIdx.x + 1] = c;
     }
 }
-__global__ void __launch_bounds__(256) mrf_energy_reduce_kernel(const unsigned long long* __restrict__ partial, uint32_t n_blocks,
-                                                                unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
+__global__ void __launch_bounds__(1024) mrf_energy_reduce_kernel(const unsigned long long* __restrict__ partial, uint32_t n_blocks,
+                                                                 unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
     unsigned long long e = 0, c = 0;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += 256u) { e += partial[2 * b]; c += partial[2 * b + 1]; }
-    __shared__ unsigned long long su[4], sc[4];
+    const ulonglong2* pp = reinterpret_cast<const ulonglong2*>(partial);
+#pragma unroll 8
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 1024u) { const ulonglong2 v = pp[b]; e += v.x; c += v.y; }
+    __shared__ unsigned long long su[16], sc[16];
     for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); c += __shfl_xor(c, o, 64); }
     if ((threadIdx.x & 63) == 0) { su[threadIdx.x >> 6] = e; sc[threadIdx.x >> 6] = c; }
     __syncthreads();
-    if (threadIdx.x == 0) { out[0] = su[0] + su[1] + su[2] + su[3]; out[1] = sc[0] + sc[1] + sc[2] + sc[3]; }
+    if (threadIdx.x == 0) { e = 0; c = 0; for (int k = 0; k < 16; ++k) { e += su[k]; c += sc[k]; } out[0] = e; out[1] = c; }
 }
 
 // ---- ICM polish: G lanes per node over its labels ----
@@ -1206,7 +1208,14 @@ void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce
         MVS_LAUNCH_CHECK();
     }
     if (!reduce) return;   // the caller's mrf_step sums the partials
-    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, ctx->m_energy.p);
+    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, partial, blocks, ctx->m_energy.p);
+    MVS_LAUNCH_CHECK();
+}
+// the energy pair the fast-path sweep kernels of the last sweep left behind as per-block partials (own node range of a
+// sharded caller, or the whole graph) -> ctx->m_energy (device), asynchronous
+void mrf_sweep_energy_reduce(mvs_ctx* ctx) {
+    const uint32_t n = EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u);
+    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->m_energy.p + 4, n, ctx->m_energy.p);
     MVS_LAUNCH_CHECK();
 }
 

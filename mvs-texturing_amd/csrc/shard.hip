@@ -1,0 +1,768 @@
+// shard.hip -- the sharded view-selection path in the product's host language (C++): one rank per GPU, RCCL over
+// xGMI for the halo exchange.  tex::calculate_data_costs + tex::view_selection over a face partition:
+//
+//   * faces are cut into `world` contiguous parts (the caller renumbers them along a space-filling curve); rank r evaluates
+//     the (face, view) pairs of its part against the replicated scene, the global barrier of postprocess_face_infos
+//     (calculate_data_costs.cpp:278-288) is one all-reduce MAX of a float and one all-reduce SUM of the 10001 histogram words;
+//   * the cost table stays sharded: global shape, only the own columns and the halo columns (faces of other parts adjacent to
+//     own faces) filled -- column lengths travel by all-gather, halo columns by a neighbour exchange;
+//   * MRF: every rank sweeps its own nodes, colour phase by colour phase; after phase c the runs written in that phase
+//     over cut edges (as BYTES: the messages are 8-bit codes) and the labels of the boundary nodes of colour c go to the
+//     neighbouring ranks -- grouped ncclSend / ncclRecv to actual neighbours only, one group per phase; per sweep one
+//     all-reduce of the energy pair feeds the device-side stop rule, so no rank ever waits on the host for a sweep's energy;
+//   * the halo plan (which runs, which nodes, in which order) is built ON THE DEVICE from the adjacency, the partition, the
+//     colouring and the rank's own message layout: both ends of a pair enumerate a (peer, phase) chunk by ascending global
+//     directed-edge index / node id, so no index ever travels.
+//
+// A phase's nodes read only nodes of other colours, which were exchanged before: labels are bit-identical for any number of parts.
+//
+// Two communicators behind one interface: RCCL (resolved with dlopen at run time, so the library carries no link-time
+// dependency and shares whatever RCCL the process already loaded, e.g. PyTorch's) and an in-process one for `world` host
+// threads sharing a device (tests on a 1-GPU box: the same planner, pack / unpack kernels and loops, copies instead of xGMI).
+#include "ctx.h"
+
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rocprim/rocprim.hpp>
+
+#include <condition_variable>
+#include <mutex>
+
+namespace mvs {
+void dc_phase1(mvs_ctx* ctx, const mvs_settings* st);
+void dc_phase2(mvs_ctx* ctx);
+void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
+void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
+void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0);
+void mrf_sweep_energy_reduce(mvs_ctx* ctx);
+void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
+void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
+void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
+void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void resolve_best(mvs_ctx* ctx);
+void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device);
+mvs_status api_fail(mvs_status st, const std::string& msg);
+}  // namespace mvs
+
+using namespace mvs;
+
+// ---------------------------------------------------------------------------------------------------------------
+// communicators
+// ---------------------------------------------------------------------------------------------------------------
+struct mvs_comm {
+    int rank = 0, world = 1;
+    virtual ~mvs_comm() {}
+    enum Type { U32, U64, F32 };
+    enum Op { SUM, MAX };
+    virtual void allreduce(void* buf, size_t n, Type t, Op op, hipStream_t s) = 0;          // in place, device buffer
+    virtual void allgather(const void* send, void* recv, size_t bytes, hipStream_t s) = 0;  // recv = world x bytes
+    // neighbour exchange of byte ranges: send + soff[q] .. soff[q + 1] goes to rank q, recv + roff[q] .. comes from rank q
+    virtual void exchange(const uint8_t* send, const uint64_t* soff, uint8_t* recv, const uint64_t* roff, hipStream_t s) = 0;
+    // two ranges per peer in ONE group (message bytes + label words of a colour phase)
+    virtual void exchange2(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
+                           const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {
+        exchange(sa, soa, ra, roa, s); exchange(sb, sob, rb, rob, s);
+    }
+};
+
+namespace {
+
+// ---- RCCL, resolved at run time ----
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl& rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the soname first: a process that already loaded an RCCL (PyTorch ships its own next to its HIP runtime) gets that one
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (R.h) break; }
+        if (!R.h) return;
+#define MVS_SYM(f) R.f = reinterpret_cast<decltype(R.f)>(dlsym(R.h, "nccl" #f))
+        MVS_SYM(GetUniqueId); MVS_SYM(CommInitRank); MVS_SYM(CommDestroy); MVS_SYM(AllReduce); MVS_SYM(AllGather); MVS_SYM(Send); MVS_SYM(Recv);
+        MVS_SYM(GroupStart); MVS_SYM(GroupEnd); MVS_SYM(GetErrorString);
+#undef MVS_SYM
+    });
+    if (!R.h || !R.GetUniqueId || !R.CommInitRank || !R.AllReduce || !R.AllGather || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd)
+        throw StatusError(MVS_ERR_UNSUPPORTED, "RCCL (librccl.so) is not available in this process");
+    return R;
+}
+#define MVS_NCCL(expr)                                                                                               \
+    do {                                                                                                             \
+        ncclResult_t _r = (expr);                                                                                    \
+        if (_r != ncclSuccess) throw HipError(std::string(#expr) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(_r) : "RCCL error")); \
+    } while (0)
+
+struct RcclComm : mvs_comm {
+    ncclComm_t comm = nullptr;
+    ~RcclComm() override { if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm); }
+    static ncclDataType_t dt(Type t) { return t == U32 ? ncclUint32 : t == U64 ? ncclUint64 : ncclFloat32; }
+    void allreduce(void* buf, size_t n, Type t, Op op, hipStream_t s) override {
+        MVS_NCCL(rccl().AllReduce(buf, buf, n, dt(t), op == SUM ? ncclSum : ncclMax, comm, s));
+    }
+    void allgather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
+        MVS_NCCL(rccl().AllGather(send, recv, bytes, ncclUint8, comm, s));
+    }
+    void post(const uint8_t* send, const uint64_t* soff, uint8_t* recv, const uint64_t* roff, hipStream_t s) {
+        for (int q = 0; q < world; ++q) {   // actual neighbours only: empty ranges cost nothing
+            if (q == rank) continue;
+            if (soff[q + 1] > soff[q]) MVS_NCCL(rccl().Send(send + soff[q], soff[q + 1] - soff[q], ncclUint8, q, comm, s));
+            if (roff[q + 1] > roff[q]) MVS_NCCL(rccl().Recv(recv + roff[q], roff[q + 1] - roff[q], ncclUint8, q, comm, s));
+        }
+    }
+    void exchange(const uint8_t* send, const uint64_t* soff, uint8_t* recv, const uint64_t* roff, hipStream_t s) override {
+        MVS_NCCL(rccl().GroupStart()); post(send, soff, recv, roff, s); MVS_NCCL(rccl().GroupEnd());
+    }
+    void exchange2(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
+                   const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) override {
+        MVS_NCCL(rccl().GroupStart()); post(sa, soa, ra, roa, s); post(sb, sob, rb, rob, s); MVS_NCCL(rccl().GroupEnd());
+    }
+};
+
+// ---- in-process communicator: `world` host threads, one per rank, sharing a device ----
+// Every operation is a rendezvous: post the pointers, barrier, copy (device to device, on the own stream, after the
+// owner's "data ready" event), barrier, wait for the readers of the own send buffer.  Small reductions go through the host.
+struct LocalHub {
+    int world;
+    std::mutex m; std::condition_variable cv; int waiting = 0; uint64_t generation = 0;
+    std::vector<const uint8_t*> send_a, send_b; std::vector<const uint64_t*> soff_a, soff_b;
+    std::vector<hipEvent_t> ready, done;
+    std::vector<std::vector<uint8_t>> host;
+    explicit LocalHub(int w) : world(w), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w), done(w), host(w) {}
+    void barrier() {
+        std::unique_lock<std::mutex> l(m);
+        const uint64_t g = generation;
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); }
+        else cv.wait(l, [&] { return generation != g; });
+    }
+};
+struct LocalComm : mvs_comm {
+    std::shared_ptr<LocalHub> hub;
+    ~LocalComm() override {}
+    void rendezvous_copy(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
+                         const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {
+        LocalHub& H = *hub;
+        H.send_a[rank] = sa; H.soff_a[rank] = soa; H.send_b[rank] = sb; H.soff_b[rank] = sob;
+        MVS_HIP(hipEventRecord(H.ready[rank], s));
+        H.barrier();
+        for (int q = 0; q < world; ++q) {
+            if (q == rank) continue;
+            MVS_HIP(hipStreamWaitEvent(s, H.ready[q], 0));
+            const uint64_t na = roa[q + 1] - roa[q];
+            if (na) {
+                if (H.soff_a[q][rank + 1] - H.soff_a[q][rank] != na) throw HipError("local exchange: send / receive sizes disagree");
+                MVS_HIP(hipMemcpyAsync(ra + roa[q], H.send_a[q] + H.soff_a[q][rank], na, hipMemcpyDeviceToDevice, s));
+            }
+            if (rb) {
+                const uint64_t nb = rob[q + 1] - rob[q];
+                if (nb) {
+                    if (H.soff_b[q][rank + 1] - H.soff_b[q][rank] != nb) throw HipError("local exchange: send / receive sizes disagree");
+                    MVS_HIP(hipMemcpyAsync(rb + rob[q], H.send_b[q] + H.soff_b[q][rank], nb, hipMemcpyDeviceToDevice, s));
+                }
+            }
+        }
+        MVS_HIP(hipEventRecord(H.done[rank], s));
+        H.barrier();
+        for (int q = 0; q < world; ++q) if (q != rank) MVS_HIP(hipStreamWaitEvent(s, H.done[q], 0));   // my send buffers are free again
+        H.barrier();   // nobody re-posts before everybody has queued its waits on this round's events
+    }
+    void exchange(const uint8_t* send, const uint64_t* soff, uint8_t* recv, const uint64_t* roff, hipStream_t s) override {
+        rendezvous_copy(send, soff, recv, roff, nullptr, nullptr, nullptr, nullptr, s);
+    }
+    void exchange2(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
+                   const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) override {
+        rendezvous_copy(sa, soa, ra, roa, sb, sob, rb, rob, s);
+    }
+    void allgather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
+        LocalHub& H = *hub;
+        H.host[rank].resize(bytes);
+        MVS_HIP(hipMemcpyAsync(H.host[rank].data(), send, bytes, hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        H.barrier();
+        for (int q = 0; q < world; ++q) MVS_HIP(hipMemcpyAsync((uint8_t*)recv + (size_t)q * bytes, H.host[q].data(), bytes, hipMemcpyHostToDevice, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        H.barrier();
+    }
+    void allreduce(void* buf, size_t n, Type t, Op op, hipStream_t s) override {
+        LocalHub& H = *hub;
+        const size_t es = t == U64 ? 8 : 4, bytes = n * es;
+        H.host[rank].resize(bytes);
+        MVS_HIP(hipMemcpyAsync(H.host[rank].data(), buf, bytes, hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        H.barrier();
+        std::vector<uint8_t> out(bytes);
+        for (size_t k = 0; k < n; ++k) {
+            if (t == U32) { uint32_t a = 0; for (int q = 0; q < world; ++q) { const uint32_t v = ((const uint32_t*)H.host[q].data())[k]; a = op == SUM ? a + v : std::max(a, v); } ((uint32_t*)out.data())[k] = a; }
+            else if (t == U64) { uint64_t a = 0; for (int q = 0; q < world; ++q) { const uint64_t v = ((const uint64_t*)H.host[q].data())[k]; a = op == SUM ? a + v : std::max(a, v); } ((uint64_t*)out.data())[k] = a; }
+            else { float a = ((const float*)H.host[0].data())[k]; for (int q = 1; q < world; ++q) { const float v = ((const float*)H.host[q].data())[k]; a = op == SUM ? a + v : std::max(a, v); } ((float*)out.data())[k] = a; }
+        }
+        H.barrier();   // everybody has read every host copy
+        MVS_HIP(hipMemcpyAsync(buf, out.data(), bytes, hipMemcpyHostToDevice, s));
+        MVS_HIP(hipStreamSynchronize(s));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// device side of the plan
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MAX_PARTS = 64;
+struct Parts { uint32_t b[MAX_PARTS + 1]; int n; };
+__device__ __forceinline__ int part_of(const Parts& p, uint32_t i) { int q = 0; while (q + 1 < p.n && i >= p.b[q + 1]) ++q; return q; }
+
+// key = peer << 40 | phase << 32 | index: a (peer, phase) chunk is a contiguous key range, ascending in the global directed-edge
+// index / node id -- the order BOTH ends of a pair derive independently
+__device__ __forceinline__ unsigned long long plan_key(int peer, uint32_t phase, uint32_t index) { return ((unsigned long long)peer << 40) | ((unsigned long long)phase << 32) | index; }
+
+// One thread per own face: the cut edges around it.  For the in-edge e = (i <- j) with j on another rank q:
+//   RECV  the run of e (K_i bytes at in_off[e] of MY layout), written by q in phase colour[j];
+//   SEND  the run of the reverse edge r = (j <- i) (K_j bytes at MY in_off[r] = out_off of e), written here in phase colour[i];
+//   node j is a halo node (its label arrives after phase colour[j]), node i a boundary node (its label leaves after phase colour[i]).
+__global__ void plan_emit_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+                                 const MrfEdge* __restrict__ edge, const uint32_t* __restrict__ colour, Parts parts, int me, uint32_t nb, uint32_t ne,
+                                 unsigned long long* __restrict__ k_msg_send, unsigned long long* __restrict__ v_msg_send,
+                                 unsigned long long* __restrict__ k_msg_recv, unsigned long long* __restrict__ v_msg_recv,
+                                 unsigned long long* __restrict__ k_node_send, unsigned long long* __restrict__ k_node_recv, uint32_t* __restrict__ counters) {
+    const uint32_t i = nb + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ne) return;
+    const uint32_t Ki = col_ptr[i + 1] - col_ptr[i], ci = colour[i];
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+        const uint32_t j = adj[e];
+        const int q = part_of(parts, j);
+        if (q == me) continue;
+        const uint32_t cj = colour[j];
+        k_node_send[atomicAdd(&counters[2], 1u)] = plan_key(q, ci, i);     // duplicates (several neighbours on q) are removed after the sort
+        k_node_recv[atomicAdd(&counters[3], 1u)] = plan_key(q, cj, j);
+        const MrfEdge m = edge[e];
+        if (m.kj == 0) continue;                                           // edge not in the model
+        uint32_t r = adj_ptr[j]; while (adj[r] != i) ++r;                  // global index of the reverse directed edge (j <- i); m.kj != 0 => it exists
+        uint32_t w = atomicAdd(&counters[1], 1u);
+        k_msg_recv[w] = plan_key(q, cj, e); v_msg_recv[w] = ((unsigned long long)m.in_off << 32) | Ki;
+        w = atomicAdd(&counters[0], 1u);
+        k_msg_send[w] = plan_key(q, ci, r); v_msg_send[w] = ((unsigned long long)m.out_off << 32) | m.kj;
+    }
+}
+// flag[k] = 1 iff key[k] differs from key[k - 1] (first of its run)
+__global__ void plan_first_kernel(const unsigned long long* __restrict__ key, uint32_t n, uint32_t* __restrict__ flag) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= n) flag[k] = (k < n && (k == 0 || key[k] != key[k - 1])) ? 1u : 0u;
+}
+__global__ void plan_compact_kernel(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n,
+                                    unsigned long long* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && flag[k]) out[pos[k]] = key[k];
+}
+__global__ void plan_len_kernel(const unsigned long long* __restrict__ val, uint32_t n, uint32_t* __restrict__ len) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= n) len[k] = k < n ? (uint32_t)(val[k] & 0xFFFFFFFFull) : 0u;
+}
+// element offsets of record k: off .. off + len - 1 at idx[pos[k] ..]; one wave per record
+__global__ void plan_expand_kernel(const unsigned long long* __restrict__ val, const uint32_t* __restrict__ pos, uint32_t n, uint32_t* __restrict__ idx) {
+    const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (k >= n) return;
+    const uint32_t off = (uint32_t)(val[k] >> 32), len = (uint32_t)(val[k] & 0xFFFFFFFFull), p = pos[k];
+    for (uint32_t t = lane; t < len; t += 64) idx[p + t] = off + t;
+}
+__global__ void plan_node_kernel(const unsigned long long* __restrict__ key, uint32_t n, uint32_t* __restrict__ node) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) node[k] = (uint32_t)(key[k] & 0xFFFFFFFFull);
+}
+// pack / unpack of one exchange: message bytes by element index, labels (or gains) by node id
+__global__ void pack_bytes_kernel(const uint8_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint8_t* __restrict__ dst) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[k] = src[idx[k]];
+}
+__global__ void unpack_bytes_kernel(uint8_t* __restrict__ dst, const uint32_t* __restrict__ idx, uint64_t n, const uint8_t* __restrict__ src) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = src[k];
+}
+__global__ void pack_words_kernel(const uint32_t* __restrict__ src, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride, const uint32_t* __restrict__ idx, uint64_t n, uint32_t* __restrict__ dst) {
+    if (st) src += (size_t)st->w * buf_stride;      // the current decode buffer
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[k] = src[idx[k]];
+}
+__global__ void unpack_words_kernel(uint32_t* __restrict__ dst, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
+    if (st) dst += (size_t)st->w * buf_stride;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = src[k];
+}
+
+// ---- sharded cost table ----
+__global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) counts[i] = col_ptr[i + 1] - col_ptr[i];
+}
+// all-gathered padded blocks -> one array of F column lengths
+__global__ void unpad_counts_kernel(const uint32_t* __restrict__ padded, uint32_t pad, Parts parts, uint32_t F, uint32_t* __restrict__ counts_g) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const int q = part_of(parts, i);
+    counts_g[i] = padded[(size_t)q * pad + (i - parts.b[q])];
+}
+// keep[i] = 1 for own faces and for halo faces (faces of other parts adjacent to an own face); one thread per own face
+__global__ void keep_own_kernel(uint32_t nb, uint32_t ne, uint32_t* __restrict__ keep) {
+    const uint32_t i = nb + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ne) keep[i] = 1u;
+}
+__global__ void halo_mark_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, Parts parts, int me, uint32_t nb, uint32_t ne,
+                                 uint32_t* __restrict__ keep, unsigned long long* __restrict__ k_send, unsigned long long* __restrict__ k_recv, uint32_t* __restrict__ counters) {
+    const uint32_t i = nb + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ne) return;
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+        const uint32_t j = adj[e];
+        const int q = part_of(parts, j);
+        if (q == me) continue;
+        keep[j] = 1u;                                                     // racing stores of the same value
+        k_send[atomicAdd(&counters[0], 1u)] = plan_key(q, 0u, i);          // my column i goes to q
+        k_recv[atomicAdd(&counters[1], 1u)] = plan_key(q, 0u, j);          // column j comes from q
+    }
+}
+__global__ void masked_counts_kernel(const uint32_t* __restrict__ counts_g, const uint32_t* __restrict__ keep, uint32_t F, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= F) out[i] = (i < F && keep[i]) ? counts_g[i] : 0u;
+}
+// column records of a face list: {view id, cost} pairs, 8 bytes each, at rec[pos[k] ..]
+__global__ void pack_columns_kernel(const uint32_t* __restrict__ faces, const uint32_t* __restrict__ pos, uint32_t n, uint32_t face_base, const uint32_t* __restrict__ col_ptr,
+                                    const uint16_t* __restrict__ view_id, const float* __restrict__ cost, uint2* __restrict__ rec) {
+    const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, lane = threadIdx.x & 15;
+    if (k >= n) return;
+    const uint32_t f = faces[k] - face_base, p0 = col_ptr[f], K = col_ptr[f + 1] - p0, o = pos[k];
+    for (uint32_t t = lane; t < K; t += 16) rec[o + t] = make_uint2((uint32_t)view_id[p0 + t], __float_as_uint(cost[p0 + t]));
+}
+__global__ void unpack_columns_kernel(const uint32_t* __restrict__ faces, const uint32_t* __restrict__ pos, uint32_t n, const uint32_t* __restrict__ col_ptr_l,
+                                      const uint2* __restrict__ rec, uint16_t* __restrict__ view_id, float* __restrict__ cost) {
+    const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, lane = threadIdx.x & 15;
+    if (k >= n) return;
+    const uint32_t f = faces[k], p0 = col_ptr_l[f], K = col_ptr_l[f + 1] - p0, o = pos[k];
+    for (uint32_t t = lane; t < K; t += 16) { const uint2 r = rec[o + t]; view_id[p0 + t] = (uint16_t)r.x; cost[p0 + t] = __uint_as_float(r.y); }
+}
+__global__ void face_len_kernel(const uint32_t* __restrict__ faces, uint32_t n, const uint32_t* __restrict__ counts_g, uint32_t* __restrict__ len) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= n) len[k] = k < n ? counts_g[faces[k]] : 0u;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// the shard object
+// ---------------------------------------------------------------------------------------------------------------
+struct mvs_shard {
+    mvs_ctx* ctx = nullptr; mvs_comm* comm = nullptr;
+    Parts parts{}; int me = 0, P = 1; uint32_t F = 0, nb = 0, ne = 0;
+    const uint32_t* d_adj_ptr = nullptr; const uint32_t* d_adj = nullptr; uint32_t E = 0;
+    // sharded table (global shape)
+    DBuf<uint32_t> t_ptr; DBuf<uint16_t> t_view; DBuf<float> t_cost; DBuf<uint32_t> counts_g, keep, tmp_a, tmp_b, tmp_c;
+    uint64_t nnz_global = 0;
+    // plan scratch + lists
+    DBuf<unsigned long long> k0, k1, k2, k3, v0, v1, ks, vs; DBuf<uint32_t> counters; DBuf<char> sort_tmp;
+    struct Lists {
+        DBuf<uint32_t> idx;                 // message element indices (bytes) / node ids (words)
+        std::vector<uint64_t> off;          // [phase][peer] -> element offset (size phases * P + 1)
+        uint64_t total = 0;
+    } msg_send, msg_recv, node_send, node_recv, all_send, all_recv;   // all_*: every boundary / halo node, by (peer, id): ICM exchanges
+    uint32_t phases = 0;
+    DBuf<uint8_t> sbuf_msg, rbuf_msg; DBuf<uint32_t> sbuf_node, rbuf_node; DBuf<uint2> sbuf_col, rbuf_col;
+    DBuf<unsigned long long> d_energy; DBuf<uint32_t> d_moved;
+    double plan_ms = 0.0;
+};
+
+namespace {
+
+void sort_pairs(mvs_shard* S, DBuf<unsigned long long>& k, DBuf<unsigned long long>* v, uint32_t n, hipStream_t s) {
+    if (n == 0) return;
+    S->ks.ensure(n + 1); if (v) S->vs.ensure(n + 1);
+    size_t tmp = 0;
+    if (v) {
+        MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp, k.p, S->ks.p, v->p, S->vs.p, n, 0, 48, s));
+        S->sort_tmp.ensure(tmp + 16);
+        MVS_HIP(rocprim::radix_sort_pairs(S->sort_tmp.p, tmp, k.p, S->ks.p, v->p, S->vs.p, n, 0, 48, s));
+        MVS_HIP(hipMemcpyAsync(v->p, S->vs.p, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    } else {
+        MVS_HIP(rocprim::radix_sort_keys(nullptr, tmp, k.p, S->ks.p, n, 0, 48, s));
+        S->sort_tmp.ensure(tmp + 16);
+        MVS_HIP(rocprim::radix_sort_keys(S->sort_tmp.p, tmp, k.p, S->ks.p, n, 0, 48, s));
+    }
+    MVS_HIP(hipMemcpyAsync(k.p, S->ks.p, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+}
+// sorted keys with duplicates -> unique keys (in place), returns the new count
+uint32_t unique_keys(mvs_shard* S, DBuf<unsigned long long>& k, uint32_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    S->tmp_a.ensure((size_t)n + 2); S->tmp_b.ensure((size_t)n + 2); S->ks.ensure((size_t)n + 1);
+    hipLaunchKernelGGL(plan_first_kernel, dim3((n + 256) / 256), dim3(256), 0, s, k.p, n, S->tmp_a.p); MVS_LAUNCH_CHECK();
+    exclusive_scan_u32(S->ctx, S->tmp_a.p, S->tmp_b.p, (size_t)n + 1, nullptr);
+    hipLaunchKernelGGL(plan_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, s, k.p, S->tmp_a.p, S->tmp_b.p, n, S->ks.p); MVS_LAUNCH_CHECK();
+    uint32_t m = 0;
+    MVS_HIP(hipMemcpyAsync(&m, S->tmp_b.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    MVS_HIP(hipMemcpyAsync(k.p, S->ks.p, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+    return m;
+}
+// per (phase, peer) offsets of a sorted key list whose records have the given lengths (null: 1 each).  The list is sorted
+// by (peer, phase, index); storage order of the exchange buffers is the same, so a (peer, phase) chunk is contiguous and a
+// peer's chunks over all phases are contiguous as well.
+void segment(const std::vector<unsigned long long>& keys, const std::vector<uint32_t>* lens, int P, uint32_t phases, std::vector<uint64_t>& off, uint64_t& total) {
+    off.assign((size_t)P * phases + 1, 0);
+    std::vector<uint64_t> cnt((size_t)P * phases, 0);
+    for (size_t k = 0; k < keys.size(); ++k) {
+        const int peer = (int)(keys[k] >> 40); const uint32_t ph = (uint32_t)((keys[k] >> 32) & 0xFFu);
+        if (peer >= P || ph >= phases) throw HipError("halo plan: key out of range");
+        cnt[(size_t)peer * phases + ph] += lens ? (*lens)[k] : 1u;
+    }
+    for (size_t c = 0; c < cnt.size(); ++c) off[c + 1] = off[c] + cnt[c];
+    total = off.back();
+}
+
+// builds one message list (records -> expanded element indices) or node list from sorted device keys
+void finish_msg_list(mvs_shard* S, mvs_shard::Lists& L, DBuf<unsigned long long>& k, DBuf<unsigned long long>& v, uint32_t n, hipStream_t s) {
+    std::vector<unsigned long long> hk(n), hv(n);
+    if (n) {
+        MVS_HIP(hipMemcpyAsync(hk.data(), k.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipMemcpyAsync(hv.data(), v.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+    }
+    std::vector<uint32_t> lens(n);
+    for (uint32_t i = 0; i < n; ++i) lens[i] = (uint32_t)(hv[i] & 0xFFFFFFFFull);
+    segment(hk, &lens, S->P, S->phases, L.off, L.total);
+    L.idx.ensure(L.total + 4);
+    if (n) {
+        S->tmp_a.ensure((size_t)n + 2); S->tmp_b.ensure((size_t)n + 2);
+        hipLaunchKernelGGL(plan_len_kernel, dim3((n + 256) / 256), dim3(256), 0, s, v.p, n, S->tmp_a.p); MVS_LAUNCH_CHECK();
+        exclusive_scan_u32(S->ctx, S->tmp_a.p, S->tmp_b.p, (size_t)n + 1, nullptr);
+        hipLaunchKernelGGL(plan_expand_kernel, dim3((unsigned)(((size_t)n * 64 + 255) / 256)), dim3(256), 0, s, v.p, S->tmp_b.p, n, L.idx.p); MVS_LAUNCH_CHECK();
+    }
+}
+void finish_node_list(mvs_shard* S, mvs_shard::Lists& L, DBuf<unsigned long long>& k, uint32_t n, uint32_t phases, hipStream_t s) {
+    std::vector<unsigned long long> hk(n);
+    if (n) { MVS_HIP(hipMemcpyAsync(hk.data(), k.p, (size_t)n * 8, hipMemcpyDeviceToHost, s)); MVS_HIP(hipStreamSynchronize(s)); }
+    segment(hk, nullptr, S->P, phases, L.off, L.total);
+    L.idx.ensure(L.total + 4);
+    if (n) { hipLaunchKernelGGL(plan_node_kernel, dim3((n + 255) / 256), dim3(256), 0, s, k.p, n, L.idx.p); MVS_LAUNCH_CHECK(); }
+}
+
+// per-peer byte offsets of one phase's chunk (elem = bytes per element)
+void phase_offsets(const mvs_shard::Lists& L, int P, uint32_t phases, uint32_t ph, uint32_t elem, std::vector<uint64_t>& out) {
+    // chunk (peer, ph) = [off[peer * phases + ph], off[peer * phases + ph + 1]); the comm takes a [P + 1] offset array of
+    // CONTIGUOUS per-peer ranges, so phase chunks are staged contiguously: out[q] = running sum of this phase's chunk sizes
+    out.assign((size_t)P + 1, 0);
+    for (int q = 0; q < P; ++q) out[q + 1] = out[q] + (L.off[(size_t)q * phases + ph + 1] - L.off[(size_t)q * phases + ph]) * elem;
+}
+
+void build_plan(mvs_shard* S) {
+    mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream;
+    hipEvent_t e0, e1; MVS_HIP(hipEventCreate(&e0)); MVS_HIP(hipEventCreate(&e1)); MVS_HIP(hipEventRecord(e0, s));
+    const uint32_t nf = S->ne - S->nb;
+    uint32_t own_edges = 0;
+    { uint32_t h[2] = {0, 0};
+      MVS_HIP(hipMemcpyAsync(&h[0], S->d_adj_ptr + S->nb, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      MVS_HIP(hipMemcpyAsync(&h[1], S->d_adj_ptr + S->ne, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      MVS_HIP(hipStreamSynchronize(s)); own_edges = h[1] - h[0]; }
+    const size_t cap = (size_t)own_edges + 8;
+    S->k0.ensure(cap); S->k1.ensure(cap); S->k2.ensure(cap); S->k3.ensure(cap); S->v0.ensure(cap); S->v1.ensure(cap); S->counters.ensure(8);
+    MVS_HIP(hipMemsetAsync(S->counters.p, 0, 8 * sizeof(uint32_t), s));
+    S->phases = ctx->m_colours;
+    if (S->phases > 255) throw StatusError(MVS_ERR_UNSUPPORTED, "more than 255 colour phases");
+    if (nf) {
+        hipLaunchKernelGGL(plan_emit_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->r_ptr, S->d_adj_ptr, S->d_adj, ctx->m_edge.p, ctx->m_colour.p, S->parts, S->me, S->nb, S->ne,
+                           S->k0.p, S->v0.p, S->k1.p, S->v1.p, S->k2.p, S->k3.p, S->counters.p);
+        MVS_LAUNCH_CHECK();
+    }
+    uint32_t n[4];
+    MVS_HIP(hipMemcpyAsync(n, S->counters.p, sizeof(n), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    sort_pairs(S, S->k0, &S->v0, n[0], s); sort_pairs(S, S->k1, &S->v1, n[1], s);
+    sort_pairs(S, S->k2, nullptr, n[2], s); sort_pairs(S, S->k3, nullptr, n[3], s);
+    const uint32_t ns = unique_keys(S, S->k2, n[2], s), nr = unique_keys(S, S->k3, n[3], s);
+    finish_msg_list(S, S->msg_send, S->k0, S->v0, n[0], s);
+    finish_msg_list(S, S->msg_recv, S->k1, S->v1, n[1], s);
+    finish_node_list(S, S->node_send, S->k2, ns, S->phases, s);
+    finish_node_list(S, S->node_recv, S->k3, nr, S->phases, s);
+    // the same node lists are contiguous per peer (all phases): the ICM exchanges use them with one range per peer
+    S->sbuf_msg.ensure(S->msg_send.total + 64); S->rbuf_msg.ensure(S->msg_recv.total + 64);
+    S->sbuf_node.ensure(S->node_send.total + 16); S->rbuf_node.ensure(S->node_recv.total + 16);
+    S->d_energy.ensure(4); S->d_moved.ensure(4);
+    MVS_HIP(hipEventRecord(e1, s)); MVS_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f; MVS_HIP(hipEventElapsedTime(&ms, e0, e1)); S->plan_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+}
+
+unsigned grid_for(uint64_t n) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 4096)); }
+
+// after colour phase `ph`: message runs written in this phase over cut edges + labels of this phase's boundary nodes
+void exchange_phase(mvs_shard* S, uint32_t ph) {
+    mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream;
+    const int P = S->P; const uint32_t C = S->phases;
+    std::vector<uint64_t> so_m, ro_m, so_n, ro_n;
+    phase_offsets(S->msg_send, P, C, ph, 1, so_m); phase_offsets(S->msg_recv, P, C, ph, 1, ro_m);
+    phase_offsets(S->node_send, P, C, ph, 4, so_n); phase_offsets(S->node_recv, P, C, ph, 4, ro_n);
+    if (so_m[P] + ro_m[P] + so_n[P] + ro_n[P] == 0) return;
+    // stage this phase's chunks contiguously, peer after peer
+    for (int q = 0; q < P; ++q) {
+        const uint64_t a = S->msg_send.off[(size_t)q * C + ph], nm = S->msg_send.off[(size_t)q * C + ph + 1] - a;
+        if (nm) { hipLaunchKernelGGL(pack_bytes_kernel, dim3(grid_for(nm)), dim3(256), 0, s, ctx->m_msg_a.p, S->msg_send.idx.p + a, nm, S->sbuf_msg.p + so_m[q]); MVS_LAUNCH_CHECK(); }
+        const uint64_t b = S->node_send.off[(size_t)q * C + ph], nn = S->node_send.off[(size_t)q * C + ph + 1] - b;
+        if (nn) { hipLaunchKernelGGL(pack_words_kernel, dim3(grid_for(nn)), dim3(256), 0, s, ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, S->node_send.idx.p + b, nn, S->sbuf_node.p + so_n[q] / 4); MVS_LAUNCH_CHECK(); }
+    }
+    S->comm->exchange2(S->sbuf_msg.p, so_m.data(), S->rbuf_msg.p, ro_m.data(),
+                       (const uint8_t*)S->sbuf_node.p, so_n.data(), (uint8_t*)S->rbuf_node.p, ro_n.data(), s);
+    for (int q = 0; q < P; ++q) {
+        const uint64_t a = S->msg_recv.off[(size_t)q * C + ph], nm = S->msg_recv.off[(size_t)q * C + ph + 1] - a;
+        if (nm) { hipLaunchKernelGGL(unpack_bytes_kernel, dim3(grid_for(nm)), dim3(256), 0, s, ctx->m_msg_a.p, S->msg_recv.idx.p + a, nm, S->rbuf_msg.p + ro_m[q]); MVS_LAUNCH_CHECK(); }
+        const uint64_t b = S->node_recv.off[(size_t)q * C + ph], nn = S->node_recv.off[(size_t)q * C + ph + 1] - b;
+        if (nn) { hipLaunchKernelGGL(unpack_words_kernel, dim3(grid_for(nn)), dim3(256), 0, s, ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, S->node_recv.idx.p + b, nn, S->rbuf_node.p + ro_n[q] / 4); MVS_LAUNCH_CHECK(); }
+    }
+}
+// every boundary node's word of `arr` (gains, labels of the best labeling) to the neighbours, halo words back: ICM
+void exchange_nodes(mvs_shard* S, uint32_t* arr) {
+    mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream;
+    const int P = S->P; const uint32_t C = S->phases;
+    std::vector<uint64_t> so((size_t)P + 1), ro((size_t)P + 1);
+    for (int q = 0; q <= P; ++q) { so[q] = S->node_send.off[(size_t)std::min(q, P) * C] * 4; ro[q] = S->node_recv.off[(size_t)std::min(q, P) * C] * 4; }
+    if (so[P] + ro[P] == 0) return;
+    const uint64_t ns = S->node_send.total, nr = S->node_recv.total;
+    if (ns) { hipLaunchKernelGGL(pack_words_kernel, dim3(grid_for(ns)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->node_send.idx.p, ns, S->sbuf_node.p); MVS_LAUNCH_CHECK(); }
+    S->comm->exchange((const uint8_t*)S->sbuf_node.p, so.data(), (uint8_t*)S->rbuf_node.p, ro.data(), s);
+    if (nr) { hipLaunchKernelGGL(unpack_words_kernel, dim3(grid_for(nr)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->node_recv.idx.p, nr, S->rbuf_node.p); MVS_LAUNCH_CHECK(); }
+}
+
+}  // namespace
+
+#define MVS_API_BEGIN try {
+#define MVS_API_END                                                               \
+    } catch (const StatusError& e) { return api_fail(e.st, e.what()); }           \
+      catch (const HipError& e) { return api_fail(MVS_ERR_HIP, e.what()); }       \
+      catch (const std::exception& e) { return api_fail(MVS_ERR_HIP, e.what()); } \
+    return MVS_OK;
+
+extern "C" {
+
+mvs_status mvs_comm_unique_id(uint8_t id_out[MVS_COMM_ID_BYTES]) {
+    if (!id_out) return api_fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    static_assert(MVS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId id;
+    MVS_NCCL(rccl().GetUniqueId(&id));
+    memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    MVS_API_END
+}
+
+mvs_status mvs_comm_create_rccl(int device, int rank, int world, const uint8_t id[MVS_COMM_ID_BYTES], mvs_comm** out) {
+    if (!id || !out || rank < 0 || rank >= world || world > MAX_PARTS) return api_fail(MVS_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(device));
+    auto* c = new RcclComm; c->rank = rank; c->world = world;
+    ncclUniqueId uid; memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+    try { MVS_NCCL(rccl().CommInitRank(&c->comm, world, uid, rank)); } catch (...) { c->comm = nullptr; delete c; throw; }
+    *out = c;
+    MVS_API_END
+}
+
+mvs_status mvs_comm_create_local(int world, mvs_comm** out) {
+    if (!out || world < 1 || world > MAX_PARTS) return api_fail(MVS_ERR_INVALID, "bad argument");
+    MVS_API_BEGIN
+    auto hub = std::make_shared<LocalHub>(world);
+    for (int r = 0; r < world; ++r) {
+        MVS_HIP(hipEventCreateWithFlags(&hub->ready[r], hipEventDisableTiming));
+        MVS_HIP(hipEventCreateWithFlags(&hub->done[r], hipEventDisableTiming));
+    }
+    for (int r = 0; r < world; ++r) { auto* c = new LocalComm; c->rank = r; c->world = world; c->hub = hub; out[r] = c; }
+    MVS_API_END
+}
+
+void mvs_comm_destroy(mvs_comm* comm) { delete comm; }
+
+mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_begin, const uint32_t* adj_ptr_device, const uint32_t* adj_device, mvs_shard** out) {
+    if (!ctx || !comm || !part_begin || !adj_ptr_device || !adj_device || !out) return api_fail(MVS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    auto* S = new mvs_shard; S->ctx = ctx; S->comm = comm; S->me = comm->rank; S->P = comm->world;
+    S->parts.n = S->P;
+    for (int q = 0; q <= S->P; ++q) { S->parts.b[q] = part_begin[q]; if (q && part_begin[q] < part_begin[q - 1]) { delete S; throw StatusError(MVS_ERR_INVALID, "part_begin must ascend"); } }
+    S->F = part_begin[S->P]; S->nb = part_begin[S->me]; S->ne = part_begin[S->me + 1];
+    if (part_begin[0] != 0 || S->F != ctx->n_faces) { delete S; throw StatusError(MVS_ERR_INVALID, "the partition must cover the mesh of the context"); }
+    S->d_adj_ptr = adj_ptr_device; S->d_adj = adj_device;
+    MVS_HIP(hipMemcpyAsync(&S->E, adj_ptr_device + S->F, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    *out = S;
+    MVS_API_END
+}
+
+void mvs_shard_destroy(mvs_shard* shard) { delete shard; }
+
+/* tex::calculate_data_costs over all ranks (calculate_data_costs.cpp:308-323): afterwards the context holds the cost table
+ * of the GLOBAL shape with the own and the halo columns filled */
+mvs_status mvs_shard_data_costs(mvs_shard* S, const mvs_settings* settings, mvs_dc_stats* stats, uint64_t* nnz_global) {
+    if (!S || !settings) return api_fail(MVS_ERR_INVALID, "null argument");
+    MVS_API_BEGIN
+    mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
+    MVS_HIP(hipSetDevice(ctx->device));
+    const uint32_t F = S->F, nb = S->nb, ne = S->ne, nf = ne - nb; const int P = S->P, me = S->me;
+    ctx->face_begin = nb; ctx->face_end = ne; ctx->have_costs = false; ctx->dc_phase = 0;
+    dc_phase1(ctx, settings);
+    comm->allreduce(ctx->max_q.p, 1, mvs_comm::F32, mvs_comm::MAX, s);                 /* :278-281 */
+    dc_phase2(ctx);
+    comm->allreduce(ctx->hist.p, MVS_HIST_WORDS, mvs_comm::U32, mvs_comm::SUM, s);     /* :283-286 */
+    mvs_dc_stats st; dc_phase3(ctx, &st);
+    if (stats) *stats = st;
+    const uint64_t nnz_own = ctx->csr_nnz;
+    // (1) column lengths of every face: one padded all-gather
+    uint32_t pad = 0; for (int q = 0; q < P; ++q) pad = std::max(pad, S->parts.b[q + 1] - S->parts.b[q]);
+    S->tmp_a.ensure((size_t)pad + 2); S->tmp_b.ensure((size_t)pad * P + 2); S->counts_g.ensure((size_t)F + 2); S->keep.ensure((size_t)F + 2);
+    MVS_HIP(hipMemsetAsync(S->tmp_a.p, 0, ((size_t)pad + 1) * sizeof(uint32_t), s));
+    if (nf) { hipLaunchKernelGGL(counts_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->r_ptr, nf, S->tmp_a.p); MVS_LAUNCH_CHECK(); }
+    comm->allgather(S->tmp_a.p, S->tmp_b.p, (size_t)pad * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(unpad_counts_kernel, dim3((F + 255) / 256), dim3(256), 0, s, S->tmp_b.p, pad, S->parts, F, S->counts_g.p); MVS_LAUNCH_CHECK();
+    S->nnz_global = sum_u32(ctx, S->counts_g.p, F);
+    if (nnz_global) *nnz_global = S->nnz_global;
+    // (2) halo faces and the boundary faces that go to each neighbour, both ascending by (peer, face)
+    uint32_t own_edges = 0;
+    { uint32_t h[2] = {0, 0};
+      MVS_HIP(hipMemcpyAsync(&h[0], S->d_adj_ptr + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      MVS_HIP(hipMemcpyAsync(&h[1], S->d_adj_ptr + ne, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      MVS_HIP(hipStreamSynchronize(s)); own_edges = h[1] - h[0]; }
+    S->k0.ensure((size_t)own_edges + 8); S->k1.ensure((size_t)own_edges + 8); S->counters.ensure(8);
+    MVS_HIP(hipMemsetAsync(S->counters.p, 0, 8 * sizeof(uint32_t), s));
+    MVS_HIP(hipMemsetAsync(S->keep.p, 0, ((size_t)F + 1) * sizeof(uint32_t), s));
+    if (nf) {
+        hipLaunchKernelGGL(keep_own_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, nb, ne, S->keep.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(halo_mark_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, S->d_adj_ptr, S->d_adj, S->parts, me, nb, ne, S->keep.p, S->k0.p, S->k1.p, S->counters.p); MVS_LAUNCH_CHECK();
+    }
+    uint32_t n[2];
+    MVS_HIP(hipMemcpyAsync(n, S->counters.p, sizeof(n), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    sort_pairs(S, S->k0, nullptr, n[0], s); sort_pairs(S, S->k1, nullptr, n[1], s);
+    const uint32_t ns = unique_keys(S, S->k0, n[0], s), nr = unique_keys(S, S->k1, n[1], s);
+    mvs_shard::Lists fs, fr;
+    finish_node_list(S, fs, S->k0, ns, 1, s); finish_node_list(S, fr, S->k1, nr, 1, s);
+    // (3) the local table: own + halo columns at their global positions
+    S->t_ptr.ensure((size_t)F + 2); S->tmp_c.ensure((size_t)F + 2);
+    hipLaunchKernelGGL(masked_counts_kernel, dim3((F + 256) / 256), dim3(256), 0, s, S->counts_g.p, S->keep.p, F, S->tmp_c.p); MVS_LAUNCH_CHECK();
+    exclusive_scan_u32(ctx, S->tmp_c.p, S->t_ptr.p, (size_t)F + 1, nullptr);
+    const uint64_t nnz_bound = sum_u32(ctx, S->tmp_c.p, F);
+    if (nnz_bound >= 0xFFFFFFF0ull) throw StatusError(MVS_ERR_UNSUPPORTED, "local cost table exceeds 2^32 entries: use more parts");
+    const uint32_t nnz_l = (uint32_t)nnz_bound;
+    S->t_view.ensure((size_t)nnz_l + 8); S->t_cost.ensure((size_t)nnz_l + 16);
+    uint32_t own_start = 0;
+    MVS_HIP(hipMemcpyAsync(&own_start, S->t_ptr.p + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    if (nnz_own) {   // the own columns are one contiguous block
+        MVS_HIP(hipMemcpyAsync(S->t_view.p + own_start, ctx->r_view, nnz_own * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+        MVS_HIP(hipMemcpyAsync(S->t_cost.p + own_start, ctx->r_cost, nnz_own * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    // (4) halo columns: {view, cost} records, the boundary columns out, the halo columns in
+    auto positions = [&](mvs_shard::Lists& L, DBuf<uint32_t>& pos, std::vector<uint64_t>& off_bytes) -> uint64_t {
+        const uint32_t m = (uint32_t)L.total;
+        S->tmp_a.ensure((size_t)m + 2); pos.ensure((size_t)m + 2);
+        hipLaunchKernelGGL(face_len_kernel, dim3((m + 256) / 256), dim3(256), 0, s, L.idx.p, m, S->counts_g.p, S->tmp_a.p); MVS_LAUNCH_CHECK();
+        exclusive_scan_u32(ctx, S->tmp_a.p, pos.p, (size_t)m + 1, nullptr);
+        std::vector<uint32_t> hp((size_t)m + 1);
+        MVS_HIP(hipMemcpyAsync(hp.data(), pos.p, ((size_t)m + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        off_bytes.assign((size_t)P + 1, 0);
+        for (int q = 0; q <= P; ++q) off_bytes[q] = (uint64_t)hp[L.off[std::min(q, P)]] * sizeof(uint2);
+        return hp[m];
+    };
+    DBuf<uint32_t> pos_s, pos_r; std::vector<uint64_t> so, ro;
+    const uint64_t rec_s = positions(fs, pos_s, so), rec_r = positions(fr, pos_r, ro);
+    S->sbuf_col.ensure(rec_s + 4); S->rbuf_col.ensure(rec_r + 4);
+    if (fs.total) { hipLaunchKernelGGL(pack_columns_kernel, dim3((unsigned)((fs.total * 16 + 255) / 256)), dim3(256), 0, s, fs.idx.p, pos_s.p, (uint32_t)fs.total, nb, ctx->r_ptr, ctx->r_view, ctx->r_cost, S->sbuf_col.p); MVS_LAUNCH_CHECK(); }
+    comm->exchange((const uint8_t*)S->sbuf_col.p, so.data(), (uint8_t*)S->rbuf_col.p, ro.data(), s);
+    if (fr.total) { hipLaunchKernelGGL(unpack_columns_kernel, dim3((unsigned)((fr.total * 16 + 255) / 256)), dim3(256), 0, s, fr.idx.p, pos_r.p, (uint32_t)fr.total, S->t_ptr.p, S->rbuf_col.p, S->t_view.p, S->t_cost.p); MVS_LAUNCH_CHECK(); }
+    MVS_HIP(hipMemsetAsync(S->t_cost.p + nnz_l, 0, 8 * sizeof(float), s));
+    MVS_HIP(hipStreamSynchronize(s));
+    // the context's active table := the sharded one (its own buffers keep the own columns for the next step's reuse)
+    ctx->r_ptr = S->t_ptr.p; ctx->r_view = S->t_view.p; ctx->r_cost = S->t_cost.p;
+    ctx->csr_faces = F; ctx->csr_views = ctx->n_views; ctx->csr_nnz = nnz_l; ctx->have_costs = true; ctx->csr_q_valid = false;
+    MVS_API_END
+}
+
+/* tex::view_selection over all ranks (view_selection.cpp:18-133): labels of the own nodes into labels_own_device */
+mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, uint32_t* labels_own_device, mvs_mrf_stats* stats) {
+    if (!S || !labels_own_device) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (!S->ctx->have_costs) return api_fail(MVS_ERR_STATE, "view selection needs data costs (mvs_shard_data_costs)");
+    MVS_API_BEGIN
+    mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
+    MVS_HIP(hipSetDevice(ctx->device));
+    mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
+    const uint32_t nb = S->nb, ne = S->ne;
+    set_adjacency(ctx, S->d_adj_ptr, S->d_adj, 1);
+    { Prof pr(ctx, "mrf_setup"); mrf_setup(ctx, &P); }
+    { Prof pr(ctx, "mrf_plan"); build_plan(S); }
+    mvs_mrf_stats R; memset(&R, 0, sizeof(R));
+    const int lag = std::max(0, std::min(std::max(ctx->mrf_lag, 2), (int)mvs_ctx::RING - 2));
+    mvs_mrf_progress pg; memset(&pg, 0, sizeof(pg));
+    int issued = 0, polled = 0;
+    while (issued < P.max_sweeps && !pg.stopped) {
+        for (uint32_t ph = 0; ph < S->phases; ++ph) {
+            { Prof pr(ctx, "mrf_sweep"); mrf_sweep_phase(ctx, ph, nb, ne); }
+            if (S->P > 1) { Prof pr(ctx, "mrf_halo"); exchange_phase(S, ph); }
+        }
+        {   // the sweep's energy: own share (accumulated by the sweep kernels, or the energy kernel on the generic path),
+            // all-reduced, fed to the device-side stop rule -- the host polls the report of `lag` sweeps ago
+            Prof pr(ctx, "mrf_energy");
+            if (ctx->m_fast) mrf_sweep_energy_reduce(ctx); else mrf_energy(ctx, false, nb, ne, true);
+            MVS_HIP(hipMemcpyAsync(S->d_energy.p, ctx->m_energy.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+            if (S->P > 1) comm->allreduce(S->d_energy.p, 2, mvs_comm::U64, mvs_comm::SUM, s);
+            mrf_step(ctx, S->d_energy.p);
+        }
+        ++issued;
+        if (issued - lag > polled) mrf_poll(ctx, (uint32_t)++polled, &pg);
+    }
+    while (polled < issued && !pg.stopped) mrf_poll(ctx, (uint32_t)++polled, &pg);
+    if (issued > 0) mrf_poll(ctx, (uint32_t)issued, &pg);
+    R.sweeps = issued > 0 ? pg.stop_sweep : 0u;
+    resolve_best(ctx);
+    if (S->P > 1 && issued == 0) exchange_nodes(S, ctx->b_lab);   // argmin-unary start: the halo labels
+    mrf_exact_costs(ctx, nb, ne);
+    int it = 0;
+    for (; it < P.icm_iters; ++it) {
+        Prof pr(ctx, "mrf_icm");
+        mrf_icm_gain(ctx, nb, ne);
+        if (S->P > 1) exchange_nodes(S, (uint32_t*)ctx->m_gain.p);
+        mrf_icm_apply(ctx, nb, ne);
+        MVS_HIP(hipMemcpyAsync(S->d_moved.p, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        if (S->P > 1) { comm->allreduce(S->d_moved.p, 1, mvs_comm::U32, mvs_comm::SUM, s); exchange_nodes(S, ctx->b_lab); }
+        pr.end();
+        uint32_t moved = 0;
+        MVS_HIP(hipMemcpyAsync(&moved, S->d_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+        if (moved == 0) break;
+    }
+    R.icm_iters = (uint32_t)it;
+    mrf_energy(ctx, true, nb, ne, true);
+    MVS_HIP(hipMemcpyAsync(S->d_energy.p, ctx->m_energy.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    if (S->P > 1) comm->allreduce(S->d_energy.p, 2, mvs_comm::U64, mvs_comm::SUM, s);
+    unsigned long long e[2];
+    MVS_HIP(hipMemcpyAsync(e, S->d_energy.p, sizeof(e), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    R.energy_fixed = e[0]; R.energy = (double)e[0] / 4294967296.0; R.cut_edges = e[1];
+    uint32_t bu[2];
+    mrf_labels(ctx, nb, ne, labels_own_device, bu);
+    MVS_HIP(hipMemcpyAsync(S->d_moved.p, ctx->m_moved.p + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (S->P > 1) comm->allreduce(S->d_moved.p, 2, mvs_comm::U32, mvs_comm::SUM, s);
+    MVS_HIP(hipMemcpyAsync(bu, S->d_moved.p, sizeof(bu), hipMemcpyDeviceToHost, s));
+    MVS_HIP(hipStreamSynchronize(s));
+    R.unseen = bu[1];
+    if (stats) *stats = R;
+    if (bu[0]) throw StatusError(MVS_ERR_LABELING, "Incorrect labeling");  /* view_selection.cpp:126-128 */
+    MVS_API_END
+}
+
+mvs_status mvs_shard_plan_info(mvs_shard* S, uint64_t* msg_bytes_per_sweep, uint64_t* boundary_nodes, double* plan_ms) {
+    if (!S) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (msg_bytes_per_sweep) *msg_bytes_per_sweep = S->msg_send.total;
+    if (boundary_nodes) *boundary_nodes = S->node_send.total;
+    if (plan_ms) *plan_ms = S->plan_ms;
+    return MVS_OK;
+}
+
+}  // extern "C"

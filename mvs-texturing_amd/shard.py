@@ -1,0 +1,83 @@
+"""ctypes binding of the sharded view-selection path (csrc/shard.hip, include/mvs_viewsel.h "sharded view selection"):
+one rank per GPU, the host side in C++, RCCL halo exchange.  Python only carries the 128-byte communicator id between
+the processes and hands device pointers to the library."""
+import ctypes as C
+
+import numpy as np
+
+from .viewsel import DcStats, MrfStats, _check, _ptr, _stats_dict, default_mrf_params, load_library, Settings
+
+COMM_ID_BYTES = 128
+
+
+def unique_id():
+    """rank 0: the RCCL unique id (bytes) every rank passes to Comm.rccl()"""
+    L = load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(L, L.mvs_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    def __init__(self, handle):
+        self.L, self.h = load_library(), handle
+
+    @classmethod
+    def rccl(cls, device, rank, world, uid):
+        L = load_library()
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(L, L.mvs_comm_create_rccl(int(device), int(rank), int(world), buf, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def local(cls, world):
+        """`world` communicators for as many host threads sharing a device (tests)"""
+        L = load_library()
+        arr = (C.c_void_p * world)()
+        _check(L, L.mvs_comm_create_local(int(world), arr))
+        return [cls(C.c_void_p(arr[r])) for r in range(world)]
+
+    def close(self):
+        if self.h:
+            self.L.mvs_comm_destroy(self.h)
+            self.h = None
+
+
+class Shard:
+    """One rank of the sharded path.  ctx: a viewsel.Context holding the FULL mesh and all views; part_begin: uint32
+    [world + 1]; adj_ptr / adj: device-resident (torch CUDA tensors) full adjacency."""
+
+    def __init__(self, ctx, comm, part_begin, adj_ptr_dev, adj_dev):
+        self.L, self.ctx, self.comm = ctx.L, ctx, comm
+        self.part = np.ascontiguousarray(part_begin, dtype=np.uint32)
+        self._keep = (adj_ptr_dev, adj_dev)
+        pa, d0 = _ptr(adj_ptr_dev); pb, d1 = _ptr(adj_dev)
+        assert d0 == 1 and d1 == 1, "the adjacency must be device resident"
+        h = C.c_void_p()
+        _check(self.L, self.L.mvs_shard_create(ctx.h, comm.h, self.part.ctypes.data_as(C.c_void_p), pa, pb, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mvs_shard_destroy(self.h)
+            self.h = None
+
+    def data_costs(self, settings=None):
+        st = settings or Settings()
+        ds = DcStats(); nnz = C.c_uint64(0)
+        _check(self.L, self.L.mvs_shard_data_costs(self.h, C.byref(st), C.byref(ds), C.byref(nnz)))
+        return _stats_dict(ds), int(nnz.value)
+
+    def view_selection(self, labels_own_dev, params=None):
+        p = params or default_mrf_params()
+        pl, d = _ptr(labels_own_dev)
+        assert d == 1
+        ms = MrfStats()
+        _check(self.L, self.L.mvs_shard_view_selection(self.h, C.byref(p), pl, C.byref(ms)))
+        return _stats_dict(ms)
+
+    def plan_info(self):
+        b, n, t = C.c_uint64(0), C.c_uint64(0), C.c_double(0.0)
+        _check(self.L, self.L.mvs_shard_plan_info(self.h, C.byref(b), C.byref(n), C.byref(t)))
+        return {"msg_bytes_per_sweep": int(b.value), "boundary_nodes": int(n.value), "plan_ms": float(t.value)}

@@ -135,11 +135,16 @@ def load_library():
         "mvs_ctx_mrf_step": [vp, vp], "mvs_ctx_mrf_poll": [vp, u32, C.POINTER(MrfProgress)],
         "mvs_ctx_mrf_icm_gain": [vp, u32, u32], "mvs_ctx_mrf_icm_apply": [vp, u32, u32, vp],
         "mvs_ctx_mrf_labels": [vp, u32, u32, vp, C.POINTER(u32)],
+        "mvs_comm_unique_id": [vp], "mvs_comm_create_rccl": [i32, i32, i32, vp, C.POINTER(vp)], "mvs_comm_create_local": [i32, C.POINTER(vp)],
+        "mvs_comm_destroy": [vp], "mvs_shard_create": [vp, vp, vp, vp, vp, C.POINTER(vp)], "mvs_shard_destroy": [vp],
+        "mvs_shard_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats), C.POINTER(u64)],
+        "mvs_shard_view_selection": [vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
+        "mvs_shard_plan_info": [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)],
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
-        if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_subgraphs_free", "mvs_ctx_destroy"):
+        if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_subgraphs_free", "mvs_ctx_destroy", "mvs_comm_destroy", "mvs_shard_destroy"):
             fn.restype = C.c_int
     L._declared = sorted(list(sig.keys()) + ["mvs_last_error", "mvs_status_string"])
     _lib = L

@@ -466,6 +466,97 @@ def test_logical_shards_on_one_gpu_equal_single(P):
     for c in ctxs + [c0]: c.close()
 
 
+def _renumbered(name):
+    from mvs_texturing_amd import multigpu as G
+    s = get_scene(name)
+    perm = G.morton_order(s.verts, s.faces)
+    faces, normals, adj_ptr, adj, _ = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)
+    return s, faces, normals, adj_ptr, adj
+
+
+@pytest.mark.parametrize("name,P", [("bumpy", 2), ("bumpy", 3), ("spiky32", 4), ("tiny", 5)])
+def test_cpp_sharded_path_equals_single_gpu(name, P):
+    """csrc/shard.hip -- the C++ sharded path (device-side halo plan, per-phase byte exchange, all-reduced energy feeding
+    the device-side stop rule, ICM with gain / label exchange) -- with P ranks as P host threads sharing cuda:0 over the
+    in-process communicator: every rank's table (own + halo columns) and the concatenated labels / energy / sweeps / ICM
+    rounds equal the single-context result, which equals the oracle.  The RCCL communicator differs only in the wire."""
+    import threading
+    import torch
+    from mvs_texturing_amd import multigpu as G
+    s, faces, normals, adj_ptr, adj = _renumbered(name)
+    F = len(faces)
+    dev = torch.device("cuda:0")
+    c0 = M.Context(0); c0.set_mesh(s.verts, faces, normals); c0.set_views(s.cams, s.images)
+    c0.data_costs(M.Settings()); full = c0.costs_download()
+    lab0, st0 = c0.view_selection(adj_ptr, adj)
+    c0.close()
+    pb = G.equal_parts(F, P)
+    comms = M.shard.Comm.local(P)
+    tap, tad = torch.from_numpy(adj_ptr.view(np.int32)).to(dev), torch.from_numpy(adj.view(np.int32)).to(dev)
+    out, err = [None] * P, [None] * P
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            c = M.Context(0); c.set_mesh(s.verts, faces, normals); c.set_views(s.cams, s.images)
+            sh = M.shard.Shard(c, comms[r], pb, tap, tad)
+            for rep in range(2):                                   # twice: steady-state reuse of plan buffers and tables
+                st, nnz_global = sh.data_costs(M.Settings())
+                table = c.costs_download()
+                labels = torch.zeros(max(int(pb[r + 1] - pb[r]), 1), dtype=torch.int32, device=dev)
+                ms = sh.view_selection(labels)
+                c.synchronize()
+            out[r] = (st, nnz_global, table, labels.cpu().numpy().view(np.uint32)[:int(pb[r + 1] - pb[r])], ms, sh.plan_info())
+            sh.close(); c.close()
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+            raise
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=600)
+    assert all(e is None for e in err), err
+    Kf = np.diff(full.col_ptr.astype(np.int64))
+    for r in range(P):
+        st, nnz_global, table, labels, ms, info = out[r]
+        assert nnz_global == full.nnz and np.float32(st["percentile"]) != 0
+        send, recv = G.boundary_faces(adj_ptr, adj, pb, r)
+        keep = np.zeros(F, dtype=bool); keep[pb[r]:pb[r + 1]] = True
+        for q in range(P):
+            keep[recv[q]] = True
+        assert np.array_equal(np.diff(table.col_ptr.astype(np.int64)), np.where(keep, Kf, 0)), "rank %d: column lengths" % r
+        sel = np.repeat(keep, Kf)
+        assert np.array_equal(table.view_id, full.view_id[sel]) and np.array_equal(table.cost.view(np.uint32), full.cost[sel].view(np.uint32))
+        assert (ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"], ms["unseen"]) == \
+               (st0["energy_fixed"], st0["cut_edges"], st0["sweeps"], st0["icm_iters"], st0["unseen"]), "rank %d" % r
+        assert info["boundary_nodes"] > 0 and info["msg_bytes_per_sweep"] > 0
+    assert np.array_equal(np.concatenate([out[r][3] for r in range(P)]), lab0), "labels depend on the partition"
+    for c in comms: c.close()
+
+
+def test_cpp_sharded_path_over_rccl_world_size_one():
+    """the RCCL communicator end to end on the one GPU a test box has: ncclGetUniqueId / ncclCommInitRank, the all-reduces
+    of the data-cost barrier and of the per-sweep energy run through RCCL (world size 1: no peers), result == single context"""
+    import torch
+    s, faces, normals, adj_ptr, adj = _renumbered("bumpy")
+    dev = torch.device("cuda:0")
+    c0 = M.Context(0); c0.set_mesh(s.verts, faces, normals); c0.set_views(s.cams, s.images)
+    c0.data_costs(M.Settings()); full = c0.costs_download()
+    lab0, st0 = c0.view_selection(adj_ptr, adj)
+    uid = M.shard.unique_id()
+    assert len(uid) == 128
+    comm = M.shard.Comm.rccl(0, 0, 1, uid)
+    tap, tad = torch.from_numpy(adj_ptr.view(np.int32)).to(dev), torch.from_numpy(adj.view(np.int32)).to(dev)
+    sh = M.shard.Shard(c0, comm, np.array([0, len(faces)], np.uint32), tap, tad)
+    st, nnz_global = sh.data_costs(M.Settings())
+    got = c0.costs_download()
+    assert nnz_global == full.nnz and np.array_equal(got.col_ptr, full.col_ptr) and np.array_equal(got.cost.view(np.uint32), full.cost.view(np.uint32))
+    labels = torch.zeros(len(faces), dtype=torch.int32, device=dev)
+    ms = sh.view_selection(labels)
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), lab0)
+    assert (ms["energy_fixed"], ms["sweeps"], ms["icm_iters"]) == (st0["energy_fixed"], st0["sweeps"], st0["icm_iters"])
+    sh.close(); comm.close(); c0.close()
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import sys
     import torch
