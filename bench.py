@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--parity-faces", type=int, default=100000)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--shard", action="store_true", help="take the sharded C++ / RCCL path even at world size 1 (test of the N > 1 code path on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,7 +193,7 @@ def main():
     if os.environ.get("MVS_BENCH_ONE_GPU"):   # test mode: every rank on cuda:0 (use with --backend gloo)
         local_rank = 0
     dist = None
-    if world > 1:
+    if world > 1 or (args.shard and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -241,11 +242,26 @@ def main():
     info = {}
 
     def step():
-        if world == 1:
+        if world == 1 and not args.shard:
             st = ctx.data_costs(settings)
             _, ms = ctx.view_selection(t_ap, t_ad, params, labels_out=t_lab)
             info["nnz_global"] = int(st["nnz"])
+        elif args.backend == "nccl":
+            # the product's sharded path: host side in C++ (csrc/shard.hip), halo exchange by RCCL over xGMI; nothing is
+            # cached between steps -- the halo plan is rebuilt on the device inside every step (reported as mrf_plan)
+            if "shard" not in info:
+                uid = [M.shard.unique_id() if rank == 0 else None]
+                if dist is not None:
+                    dist.broadcast_object_list(uid, src=0)
+                info["comm"] = M.shard.Comm.rccl(local_rank, rank, world, uid[0])
+                info["shard"] = M.shard.Shard(ctx, info["comm"], part, t_ap, t_ad)
+                info["labels_own"] = torch.zeros(max(int(part[rank + 1] - part[rank]), 1), dtype=torch.int32, device=dev)
+            st, info["nnz_global"] = info["shard"].data_costs(settings)
+            ms = info["shard"].view_selection(info["labels_own"], params)
+            info["plan"] = info["shard"].plan_info()
         else:
+            # harness path for test boxes with one GPU (several ranks on cuda:0 cannot share an RCCL communicator):
+            # the same building blocks driven from Python over gloo (mvs-texturing_amd/multigpu.py)
             if "pipe" not in info:
                 info["pipe"] = G.ShardedPipeline(ctx, part, rank, dist, dev, adj_ptr, adj, t_ap, t_ad, settings, params)
             labels, st, ms, dc = info["pipe"].step()
@@ -254,7 +270,7 @@ def main():
 
     # row f1 (outside the headline window, reported separately): tex::build_adjacency_graph on the GPU
     pre = {}
-    if world == 1:
+    if world == 1 and not args.shard:
         ctx.build_adjacency(); ctx.get_profile()
         for _ in range(3):
             ctx.build_adjacency()
@@ -280,7 +296,7 @@ def main():
     prof = ctx.get_profile()
     # row f3 (outside the headline window, reported separately): UniGraph::get_subgraphs of the labeling, all labels at once
     post = {}
-    if world == 1 and args.steps > 0:
+    if world == 1 and args.steps > 0 and not args.shard:
         ctx.get_subgraphs(t_ap, t_ad, t_lab, V + 1, on_device=True); ctx.get_profile()
         for _ in range(3):
             sg = ctx.get_subgraphs(t_ap, t_ad, t_lab, V + 1, on_device=True)
@@ -301,7 +317,7 @@ def main():
         # one sweep = n_phases launches of the sweep kernel (one per colour class).  The profile span covers a whole
         # sweep on one GPU and a single phase in the sharded driver.
         spans = prof["mrf_sweep"][1]
-        sweeps_run = spans if world == 1 else spans / n_phases
+        sweeps_run = spans if (world == 1 and not args.shard) else spans / n_phases
         sweep_ms = prof["mrf_sweep"][0] / sweeps_run
         launch_ms = sweep_ms / n_phases
         nf_own = int(part[rank + 1] - part[rank])
@@ -340,6 +356,8 @@ def main():
            "h2d_ms": h2d_ms, "h2d_GBps": h2d_bytes / max(h2d_ms, 1e-9) / 1e6,
            "pcie_inclusive_value": F / ((ms_per_step + h2d_ms) / 1000.0),
            "roofline": roof, "stages": stages, "pre_path": pre, "post_path": post}
+    if "plan" in info:
+        out["halo"] = dict(info["plan"], driver="C++ (csrc/shard.hip), grouped ncclSend/ncclRecv per colour phase, bytes on the wire")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(scene, faces, normals, adj_ptr, adj,
@@ -347,7 +365,7 @@ def main():
         except Exception as e:  # the baseline is reporting only; never lose the measurement
             out["cpu_baseline"] = {"error": repr(e)}
     rc = 0
-    if rank == 0 and world == 1 and not args.no_parity and args.steps > 0:
+    if rank == 0 and world == 1 and not args.no_parity and args.steps > 0 and not args.shard:
         try:
             out["parity"] = parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, args.parity_faces, local_rank)
             out["parity_checked"] = bool(out["parity"]["ok"])

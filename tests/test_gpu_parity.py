@@ -924,6 +924,16 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     # the checker leg: the timed step's table against the oracle (pattern, qualities bit for bit) + solver parity on the sample
     assert d1["parity_checked"] is True and d1["parity"]["faces"] == 30000 and d1["parity"]["labels_equal"], d1.get("parity")
     assert d1["config"]["msg_bits"] == 8 and d1["h2d_ms"] > 0
+    # the N > 1 code path of the product (C++ shard driver + RCCL) launched the way the driver launches it, at the world size a
+    # 1-GPU box allows: same nnz, sweeps and energy as the plain single-GPU path
+    port = 29400 + os.getpid() % 150
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "2", "--steps", "2", "--warmup", "1",
+                        "--shard", "--no-cpu-baseline", "--no-traffic"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ds = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert ds["config"]["nnz"] == d1["config"]["nnz"] and ds["config"]["sweeps"] == d1["config"]["sweeps"] and abs(ds["config"]["energy"] - d1["config"]["energy"]) < 1e-6
+    assert "mrf_plan" in ds["stages"] and ds["halo"]["driver"].startswith("C++")
     env["MVS_BENCH_ONE_GPU"] = "1"
     port = 29600 + os.getpid() % 2000
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
