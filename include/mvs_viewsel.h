@@ -326,6 +326,14 @@ mvs_status mvs_ctx_get_subgraphs(mvs_ctx* ctx, uint32_t n_faces, const uint32_t*
                                  const uint32_t* labels, int labels_on_device, uint32_t n_labels, mvs_subgraphs* out,
                                  int out_on_device);
 
+/* tex::postprocess_face_infos (libs/tex/texturing.h:71-74; calculate_data_costs.cpp:253-306) for callers that hold their own
+ * FaceProjectionInfos: infos of face i are entries info_ptr[i] .. info_ptr[i + 1] of view_id / quality / mean_color
+ * (3 floats, YCbCr, read only when outlier removal is on) IN THE ORDER the caller's vectors hold them -- the outlier
+ * detection sums in that order.  Output as mvs_data_costs (library-allocated, mvs_csr_free). */
+mvs_status mvs_postprocess_face_infos(uint32_t n_faces, uint32_t n_views, const uint32_t* info_ptr, const uint16_t* view_id,
+                                      const float* quality, const float* mean_color, const mvs_settings* settings,
+                                      mvs_csr* out, mvs_dc_stats* stats);
+
 /* ---- sharded view selection: one rank per GPU, host side in C++, RCCL halo exchange (csrc/shard.hip; DESIGN.md "Multi-GPU") ----
  * Faces are cut into `world` contiguous parts part_begin[0 .. world] (the caller renumbers the faces along a space-filling
  * curve so that parts are compact).  Every rank holds the replicated scene and the full adjacency; it evaluates the data

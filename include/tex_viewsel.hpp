@@ -191,6 +191,14 @@ public:
 typedef std::vector<TextureView> TextureViews;
 typedef UniGraph Graph;
 typedef SparseTable<std::uint32_t, std::uint16_t, float> DataCosts;
+/** texture_view.h:26-34 */
+struct FaceProjectionInfo {
+    std::uint16_t view_id;
+    float quality;
+    float mean_color[3];   /* math::Vec3f upstream: YCbCr, filled when outlier removal is on */
+    bool operator<(FaceProjectionInfo const& other) const { return view_id < other.view_id; }
+};
+typedef std::vector<std::vector<FaceProjectionInfo> > FaceProjectionInfos;   /* texturing.h:38 */
 
 /** Stand-in for mve::TriangleMesh::ConstPtr with the three getters of calculate_data_costs.cpp:136-138. */
 struct SimpleMesh {
@@ -258,6 +266,35 @@ void calculate_data_costs(MeshConstPtr mesh, TextureViews* texture_views, Settin
         for (std::uint32_t k = csr.col_ptr[i]; k < csr.col_ptr[i + 1]; ++k) data_costs->set_value(i, csr.view_id[k], csr.cost[k]);
     mvs_csr_free(&csr);
     for (TextureView& tv : *texture_views) tv.release_image();  /* :231 */
+    std::cout << "\tMaximum quality of a face within an image: " << stats.max_quality << std::endl;     /* :304-305 */
+    std::cout << "\tClamping qualities to " << stats.percentile << " within normalization." << std::endl;
+}
+
+/** Postprocessing of the per face projection infos into data costs   (libs/tex/texturing.h:71-74,
+ * calculate_data_costs.cpp:253-306).  As upstream: the infos are consumed (the vector is cleared, :301) and data_costs
+ * must be pre-sized to (faces, views). */
+inline void postprocess_face_infos(Settings const& settings, FaceProjectionInfos* face_projection_infos, DataCosts* data_costs) {
+    std::size_t const F = face_projection_infos->size();
+    std::vector<std::uint32_t> ptr(F + 1, 0);
+    std::vector<std::uint16_t> view_id; std::vector<float> quality, color;
+    for (std::size_t i = 0; i < F; ++i) {
+        for (FaceProjectionInfo const& info : face_projection_infos->at(i)) {
+            view_id.push_back(info.view_id); quality.push_back(info.quality);
+            color.push_back(info.mean_color[0]); color.push_back(info.mean_color[1]); color.push_back(info.mean_color[2]);
+        }
+        ptr[i + 1] = static_cast<std::uint32_t>(view_id.size());
+    }
+    mvs_settings st;
+    st.data_term = settings.data_term; st.outlier_removal = settings.outlier_removal;
+    st.geometric_visibility_test = settings.geometric_visibility_test ? 1 : 0;
+    mvs_csr csr; std::memset(&csr, 0, sizeof(csr));
+    mvs_dc_stats stats;
+    detail::throw_status(mvs_postprocess_face_infos(static_cast<std::uint32_t>(F), data_costs->rows(), ptr.data(), view_id.data(), quality.data(),
+                                                    color.data(), &st, &csr, &stats));
+    for (std::uint32_t i = 0; i < csr.n_faces; ++i)          /* calculate_data_costs.cpp:291-298 */
+        for (std::uint32_t k = csr.col_ptr[i]; k < csr.col_ptr[i + 1]; ++k) data_costs->set_value(i, csr.view_id[k], csr.cost[k]);
+    mvs_csr_free(&csr);
+    face_projection_infos->clear();                           /* :301 */
     std::cout << "\tMaximum quality of a face within an image: " << stats.max_quality << std::endl;     /* :304-305 */
     std::cout << "\tClamping qualities to " << stats.percentile << " within normalization." << std::endl;
 }

@@ -8,11 +8,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace mvs {
 void dc_phase1(mvs_ctx* ctx, const mvs_settings* st);
 void dc_phase2(mvs_ctx* ctx);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
+void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t* h_ptr, const uint16_t* h_view_rev, const float* h_q_rev, const float* h_col_rev, const mvs_settings* st);
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
@@ -417,6 +419,39 @@ mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t 
     return st;
 }
 
+/* tex::postprocess_face_infos (texturing.h:71-74; calculate_data_costs.cpp:253-306) */
+mvs_status mvs_postprocess_face_infos(uint32_t n_faces, uint32_t n_views, const uint32_t* info_ptr, const uint16_t* view_id, const float* quality,
+                                      const float* mean_color, const mvs_settings* settings, mvs_csr* out, mvs_dc_stats* stats) {
+    if (!info_ptr || !settings || !out) return fail(MVS_ERR_INVALID, "null argument");
+    const size_t n = info_ptr[n_faces];
+    if (n && (!view_id || !quality)) return fail(MVS_ERR_INVALID, "null argument");
+    if (settings->outlier_removal != MVS_OUTLIER_NONE && n && !mean_color) return fail(MVS_ERR_INVALID, "outlier removal needs the mean colours");
+    for (uint32_t i = 0; i < n_faces; ++i) if (info_ptr[i + 1] < info_ptr[i]) return fail(MVS_ERR_INVALID, "info_ptr must ascend");
+    for (size_t k = 0; k < n; ++k) if (view_id[k] >= n_views) return fail(MVS_ERR_INVALID, "view id out of range");
+    mvs_ctx* ctx = nullptr;
+    mvs_status st = mvs_ctx_create(0, &ctx);
+    if (st != MVS_OK) return st;
+    try {
+        // every face's list reversed (see dc_postprocess)
+        std::vector<uint16_t> rv(n + 1); std::vector<float> rq(n + 1), rc(mean_color ? 3 * n + 3 : 3);
+        for (uint32_t i = 0; i < n_faces; ++i) {
+            const size_t a = info_ptr[i], b = info_ptr[i + 1];
+            for (size_t k = a; k < b; ++k) {
+                const size_t d = a + (b - 1 - k);
+                rv[d] = view_id[k]; rq[d] = quality[k];
+                if (mean_color) { rc[3 * d] = mean_color[3 * k]; rc[3 * d + 1] = mean_color[3 * k + 1]; rc[3 * d + 2] = mean_color[3 * k + 2]; }
+            }
+        }
+        dc_postprocess(ctx, n_faces, n_views, info_ptr, rv.data(), rq.data(), rc.data(), settings);
+        dc_phase2(ctx);
+        dc_phase3(ctx, stats);
+        st = mvs_ctx_costs_download(ctx, out, nullptr);
+    } catch (const StatusError& e) { st = fail(e.st, e.what()); }
+      catch (const std::exception& e) { st = fail(MVS_ERR_HIP, e.what()); }
+    mvs_ctx_destroy(ctx);
+    return st;
+}
+
 mvs_status mvs_view_selection(const mvs_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj, const mvs_mrf_params* params,
                               uint32_t* labels_out, mvs_mrf_stats* stats) {
     if (!costs || !adj_ptr || !adj || !labels_out) return fail(MVS_ERR_INVALID, "null argument");
@@ -436,18 +471,18 @@ mvs_status mvs_write_spt(const mvs_csr* csr, const char* path) {
     if (!csr || !path) return fail(MVS_ERR_INVALID, "null argument");
     FILE* f = fopen(path, "wb");
     if (!f) return fail(MVS_ERR_INVALID, std::string("cannot open ") + path);
-    fprintf(f, "SPT 0.2 %u %u %llu\n", csr->n_faces, csr->n_views, (unsigned long long)csr->nnz);
-    for (uint32_t col = 0; col < csr->n_faces; ++col)
-        for (uint32_t k = csr->col_ptr[col]; k < csr->col_ptr[col + 1]; ++k) {
-            fwrite(&col, sizeof(uint32_t), 1, f); fwrite(&csr->view_id[k], sizeof(uint16_t), 1, f); fwrite(&csr->cost[k], sizeof(float), 1, f);
-        }
-    fclose(f);
-    return MVS_OK;
+    bool ok = fprintf(f, "SPT 0.2 %u %u %llu\n", csr->n_faces, csr->n_views, (unsigned long long)csr->nnz) > 0;
+    for (uint32_t col = 0; ok && col < csr->n_faces; ++col)
+        for (uint32_t k = csr->col_ptr[col]; ok && k < csr->col_ptr[col + 1]; ++k)
+            ok = fwrite(&col, sizeof(uint32_t), 1, f) == 1 && fwrite(&csr->view_id[k], sizeof(uint16_t), 1, f) == 1 && fwrite(&csr->cost[k], sizeof(float), 1, f) == 1;
+    if (fclose(f) != 0) ok = false;   // a full disk shows up here at the latest
+    return ok ? MVS_OK : fail(MVS_ERR_INVALID, std::string("write error on ") + path);
 }
 
 /* SparseTable::load_from_file (sparse_table.h:138-187) */
 mvs_status mvs_read_spt(const char* path, mvs_csr* out) {
     if (!path || !out) return fail(MVS_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
     FILE* f = fopen(path, "rb");
     if (!f) return fail(MVS_ERR_INVALID, std::string("cannot open ") + path);
     char header[16] = {0}, version[16] = {0};
@@ -455,14 +490,22 @@ mvs_status mvs_read_spt(const char* path, mvs_csr* out) {
     if (fscanf(f, "%15s %15s %u %u %llu", header, version, &cols, &rows, &nnz) != 5 || strcmp(header, "SPT") != 0) { fclose(f); return fail(MVS_ERR_INVALID, "Not a SparseTable file!"); }
     if (strcmp(version, "0.2") != 0) { fclose(f); return fail(MVS_ERR_INVALID, "Incompatible version of SparseTable file!"); }
     int ch; while ((ch = fgetc(f)) != EOF && ch != '\n') {}
+    // the header is untrusted: the records it announces must fit in what is left of the file before anything is allocated
+    const long data_begin = ftell(f);
+    if (data_begin < 0 || fseek(f, 0, SEEK_END) != 0) { fclose(f); return fail(MVS_ERR_INVALID, "corrupt SparseTable file"); }
+    const long file_end = ftell(f);
+    if (file_end < data_begin || nnz > (unsigned long long)(file_end - data_begin) / 10ull || nnz >= 0xFFFFFFF0ull || fseek(f, data_begin, SEEK_SET) != 0) {
+        fclose(f); return fail(MVS_ERR_INVALID, "corrupt SparseTable file (record count exceeds the file)");
+    }
     out->n_faces = cols; out->n_views = rows; out->nnz = nnz;
     out->col_ptr = (uint32_t*)calloc((size_t)cols + 1, sizeof(uint32_t));
     out->view_id = (uint16_t*)malloc((nnz + 1) * sizeof(uint16_t));
     out->cost = (float*)malloc((nnz + 1) * sizeof(float));
+    if (!out->col_ptr || !out->view_id || !out->cost) { fclose(f); mvs_csr_free(out); return fail(MVS_ERR_INVALID, "out of memory reading the SparseTable file"); }
     uint32_t prev = 0;
     for (unsigned long long i = 0; i < nnz; ++i) {
         uint32_t col; uint16_t row; float v;
-        if (fread(&col, 4, 1, f) != 1 || fread(&row, 2, 1, f) != 1 || fread(&v, 4, 1, f) != 1 || col >= cols || col < prev) { fclose(f); mvs_csr_free(out); return fail(MVS_ERR_INVALID, "corrupt SparseTable file"); }
+        if (fread(&col, 4, 1, f) != 1 || fread(&row, 2, 1, f) != 1 || fread(&v, 4, 1, f) != 1 || col >= cols || col < prev || row >= rows) { fclose(f); mvs_csr_free(out); return fail(MVS_ERR_INVALID, "corrupt SparseTable file"); }
         prev = col;
         out->col_ptr[col + 1]++; out->view_id[i] = row; out->cost[i] = v;
     }
@@ -476,9 +519,10 @@ mvs_status mvs_write_labeling_vec(const uint32_t* labels, uint32_t n_faces, cons
     if (!labels || !path) return fail(MVS_ERR_INVALID, "null argument");
     FILE* f = fopen(path, "wb");
     if (!f) return fail(MVS_ERR_INVALID, std::string("cannot open ") + path);
-    for (uint32_t i = 0; i < n_faces; ++i) { const uint64_t v = labels[i]; fwrite(&v, sizeof(uint64_t), 1, f); }
-    fclose(f);
-    return MVS_OK;
+    bool ok = true;
+    for (uint32_t i = 0; ok && i < n_faces; ++i) { const uint64_t v = labels[i]; ok = fwrite(&v, sizeof(uint64_t), 1, f) == 1; }
+    if (fclose(f) != 0) ok = false;
+    return ok ? MVS_OK : fail(MVS_ERR_INVALID, std::string("write error on ") + path);
 }
 
 // ---------------- multi-GPU MRF building blocks: see mgpu.hip ----------------

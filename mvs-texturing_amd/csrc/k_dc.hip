@@ -617,6 +617,76 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     ctx->dc_phase = 1;
 }
 
+// std::sort of a face's infos by view id (calculate_data_costs.cpp:272, operator< of FaceProjectionInfo, texture_view.h:31-33):
+// one thread per face, insertion sort in place (columns are short; equal ids -- which a caller never produces -- keep their order)
+__global__ void sort_columns_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, uint16_t* __restrict__ view_id, float* __restrict__ q) {
+    const uint32_t lf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lf >= nf) return;
+    const uint32_t p0 = col_ptr[lf], p1 = col_ptr[lf + 1];
+    for (uint32_t a = p0 + 1; a < p1; ++a) {
+        const uint16_t v = view_id[a]; const float x = q[a];
+        uint32_t b = a;
+        while (b > p0 && view_id[b - 1] > v) { view_id[b] = view_id[b - 1]; q[b] = q[b - 1]; --b; }
+        view_id[b] = v; q[b] = x;
+    }
+}
+
+// tex::postprocess_face_infos (calculate_data_costs.cpp:253-306, exported at texturing.h:71-74) on caller-provided infos:
+// per face outlier detection in the order the infos are given (:265-267), erase quality == 0 (:268-270), sort by view id
+// (:272); then the global maximum, the histogram and the percentile (:278-288) and the costs (:291-298) -- phases 2 and 3.
+// The arrays arrive with every face's list REVERSED: outlier_kernel walks a list back to front (its other caller holds
+// the lists ascending by view, the order the reference reaches them in is descending).
+void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t* h_ptr, const uint16_t* h_view_rev, const float* h_q_rev,
+                    const float* h_col_rev, const mvs_settings* st) {
+    if (st->outlier_removal < 0 || st->outlier_removal > 2) throw StatusError(MVS_ERR_INVALID, "bad outlier_removal");
+    if (n_views > 65535u) throw StatusError(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");
+    hipStream_t s = ctx->stream;
+    const bool outl = st->outlier_removal != MVS_OUTLIER_NONE;
+    const uint32_t n = h_ptr[nf];
+    ctx->dc_settings = *st; ctx->have_costs = false;
+    memset(&ctx->dc_stats, 0, sizeof(ctx->dc_stats));
+    ctx->dc_stats.nnz_pre = n;
+    ctx->counters.ensure(64);
+    MVS_HIP(hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), s));
+    ctx->pre_ptr.ensure((size_t)nf + 2); ctx->pre_view.ensure((size_t)n + 1); ctx->pre_q.ensure((size_t)n + 1);
+    MVS_HIP(hipMemcpyAsync(ctx->pre_ptr.p, h_ptr, ((size_t)nf + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (n) {
+        MVS_HIP(hipMemcpyAsync(ctx->pre_view.p, h_view_rev, (size_t)n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        MVS_HIP(hipMemcpyAsync(ctx->pre_q.p, h_q_rev, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    if (outl && n) {
+        ctx->pre_col.ensure(3 * ((size_t)n + 1)); ctx->pre_inl.ensure((size_t)n + 1);
+        MVS_HIP(hipMemcpyAsync(ctx->pre_col.p, h_col_rev, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(outlier_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, ctx->pre_ptr.p, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p, st->outlier_removal);
+        MVS_LAUNCH_CHECK();
+    }
+    ctx->face_cnt.ensure((size_t)nf + 2); ctx->csr_ptr.ensure((size_t)nf + 2);
+    uint32_t nnz = n;
+    if (outl) {   // the zero-quality erase belongs to the outlier branch (:265-271): without outlier removal every info stays
+        hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf + 256) / 256), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
+        MVS_LAUNCH_CHECK();
+        exclusive_scan_u32(ctx, ctx->face_cnt.p, ctx->csr_ptr.p, (size_t)nf + 1, nullptr);
+        nnz = read_u32(ctx, ctx->csr_ptr.p + nf);
+    } else MVS_HIP(hipMemcpyAsync(ctx->csr_ptr.p, ctx->pre_ptr.p, ((size_t)nf + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    ctx->csr_view.ensure((size_t)nnz + 1); ctx->csr_q.ensure((size_t)nnz + 1); ctx->csr_cost.ensure((size_t)nnz + 8);
+    if (nf) {
+        if (outl) {
+            hipLaunchKernelGGL(nonzero_copy_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->pre_ptr.p, ctx->csr_ptr.p, nf, ctx->pre_view.p, ctx->pre_q.p, ctx->csr_view.p, ctx->csr_q.p);
+            MVS_LAUNCH_CHECK();
+        } else if (n) {
+            MVS_HIP(hipMemcpyAsync(ctx->csr_view.p, ctx->pre_view.p, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+            MVS_HIP(hipMemcpyAsync(ctx->csr_q.p, ctx->pre_q.p, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL(sort_columns_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->csr_ptr.p, nf, ctx->csr_view.p, ctx->csr_q.p);
+        MVS_LAUNCH_CHECK();
+    }
+    ctx->csr_nnz = nnz; ctx->csr_faces = nf; ctx->csr_views = n_views;
+    ctx->max_q.ensure(4);
+    MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
+    if (nnz) { hipLaunchKernelGGL(max_kernel, dim3(1024), dim3(256), 0, s, ctx->csr_q.p, (size_t)nnz, (uint32_t*)ctx->max_q.p); MVS_LAUNCH_CHECK(); }
+    ctx->dc_phase = 1;
+}
+
 // phase 2: histogram of the local qualities against the (possibly all-reduced) maximum (:283-286)
 void dc_phase2(mvs_ctx* ctx) {
     if (ctx->dc_phase != 1) throw StatusError(MVS_ERR_STATE, "dc_phase2 needs dc_phase1");

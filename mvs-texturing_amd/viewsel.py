@@ -135,6 +135,7 @@ def load_library():
         "mvs_ctx_mrf_step": [vp, vp], "mvs_ctx_mrf_poll": [vp, u32, C.POINTER(MrfProgress)],
         "mvs_ctx_mrf_icm_gain": [vp, u32, u32], "mvs_ctx_mrf_icm_apply": [vp, u32, u32, vp],
         "mvs_ctx_mrf_labels": [vp, u32, u32, vp, C.POINTER(u32)],
+        "mvs_postprocess_face_infos": [u32, u32, vp, vp, vp, vp, C.POINTER(Settings), C.POINTER(CCsr), C.POINTER(DcStats)],
         "mvs_comm_unique_id": [vp], "mvs_comm_create_rccl": [i32, i32, i32, vp, C.POINTER(vp)], "mvs_comm_create_local": [i32, C.POINTER(vp)],
         "mvs_comm_destroy": [vp], "mvs_shard_create": [vp, vp, vp, vp, vp, C.POINTER(vp)], "mvs_shard_destroy": [vp],
         "mvs_shard_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats), C.POINTER(u64)],
@@ -395,6 +396,25 @@ def view_selection(data_costs, adj_ptr, adj, params=None, ctx=None):
     finally:
         if own:
             ctx.close()
+
+
+def postprocess_face_infos(n_views, info_ptr, view_id, quality, mean_color, settings=None):
+    """tex::postprocess_face_infos(settings, &face_projection_infos, &data_costs) (libs/tex/texturing.h:71-74): infos in CSR by
+    face, in the caller's order.  Returns (DataCosts, stats)."""
+    L = load_library()
+    info_ptr = np.ascontiguousarray(info_ptr, dtype=np.uint32); view_id = np.ascontiguousarray(view_id, dtype=np.uint16)
+    quality = np.ascontiguousarray(quality, dtype=np.float32)
+    mean_color = None if mean_color is None else np.ascontiguousarray(mean_color, dtype=np.float32)
+    st = settings or Settings()
+    out = CCsr(); ds = DcStats()
+    _check(L, L.mvs_postprocess_face_infos(len(info_ptr) - 1, int(n_views), info_ptr.ctypes.data, view_id.ctypes.data, quality.ctypes.data,
+                                           None if mean_color is None else mean_color.ctypes.data, C.byref(st), C.byref(out), C.byref(ds)))
+    F, nnz = out.n_faces, out.nnz
+    def grab(ptr, ctype, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (max(n, 1),))[:n].copy()
+    res = DataCosts(F, out.n_views, grab(out.col_ptr, C.c_uint32, F + 1), grab(out.view_id, C.c_uint16, nnz), grab(out.cost, C.c_float, nnz))
+    L.mvs_csr_free(C.byref(out))
+    return res, _stats_dict(ds)
 
 
 def prepare_mesh(verts, faces):

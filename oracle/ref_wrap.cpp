@@ -236,6 +236,34 @@ std::int64_t ref_calculate_data_costs(std::uint32_t n_verts, const float* verts,
     } catch (std::exception& e) { std::fprintf(stderr, "ref_calculate_data_costs: %s\n", e.what()); return -1; }
 }
 
+// tex::postprocess_face_infos (calculate_data_costs.cpp:253-306, exported at texturing.h:71-74) on caller-supplied infos,
+// in the order given: the reference's own outlier detection / erase / sort / max / histogram / percentile / set_value
+std::int64_t ref_postprocess_face_infos(std::uint32_t n_faces, std::uint32_t n_views, const std::uint32_t* info_ptr, const std::uint16_t* view_id,
+                                        const float* quality, const float* mean_color, int outlier_removal,
+                                        std::uint32_t* col_ptr /* n_faces + 1 */, std::uint16_t* view_out, float* cost_out, std::uint64_t cap) {
+    try {
+        tex::FaceProjectionInfos infos(n_faces);
+        for (std::uint32_t i = 0; i < n_faces; ++i)
+            for (std::uint32_t k = info_ptr[i]; k < info_ptr[i + 1]; ++k) {
+                tex::FaceProjectionInfo fi;
+                fi.view_id = view_id[k]; fi.quality = quality[k];
+                fi.mean_color = math::Vec3f(mean_color[3 * k], mean_color[3 * k + 1], mean_color[3 * k + 2]);
+                infos[i].push_back(fi);
+            }
+        tex::Settings st; st.outlier_removal = (tex::OutlierRemoval)outlier_removal;
+        tex::DataCosts data_costs(n_faces, n_views);
+        tex::postprocess_face_infos(st, &infos, &data_costs);
+        std::uint64_t n = 0;
+        for (std::uint32_t i = 0; i < n_faces; ++i) {
+            col_ptr[i] = (std::uint32_t)n;
+            tex::DataCosts::Column const& c = data_costs.col(i);
+            for (std::size_t k = 0; k < c.size(); ++k) { if (n < cap) { view_out[n] = c[k].first; cost_out[n] = c[k].second; } ++n; }
+        }
+        col_ptr[n_faces] = (std::uint32_t)n;
+        return (std::int64_t)n;
+    } catch (std::exception& e) { std::fprintf(stderr, "ref_postprocess_face_infos: %s\n", e.what()); return -1; }
+}
+
 // photometric_outlier_detection (calculate_data_costs.cpp:35-129) on one face's infos in the order given
 int ref_outlier_detection(std::uint32_t n, const float* mean_color, float* quality, int outlier_removal) {
     std::vector<tex::FaceProjectionInfo> infos(n);

@@ -557,6 +557,42 @@ def test_cpp_sharded_path_over_rccl_world_size_one():
     sh.close(); comm.close(); c0.close()
 
 
+def test_postprocess_face_infos_entry_point_equals_upstream_code():
+    """mvs_postprocess_face_infos (tex::postprocess_face_infos, texturing.h:71-74) against the reference's OWN
+    calculate_data_costs.cpp:253-306 compiled into oracle/_ref: infos in arbitrary (shuffled) order, zero qualities, empty
+    faces, faces with < 4 infos, all three outlier modes.  Pattern and view ids identical; costs bit-equal without outlier
+    removal, within 1e-4 relative with it (fp64 exp: glibc vs OCML)."""
+    ref_path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libtexref.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref/libtexref.so not built")
+    R = C.CDLL(ref_path)
+    vp = C.c_void_p
+    R.ref_postprocess_face_infos.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_uint64]
+    R.ref_postprocess_face_infos.restype = C.c_int64
+    rng = np.random.default_rng(7)
+    F, V = 3000, 40
+    cnt = rng.integers(0, 25, F); cnt[rng.random(F) < 0.1] = 0
+    ptr = np.zeros(F + 1, np.uint32); ptr[1:] = np.cumsum(cnt)
+    n = int(ptr[-1])
+    view = np.concatenate([rng.permutation(V)[:c] for c in cnt]).astype(np.uint16)      # distinct per face, shuffled order
+    q = (rng.random(n) ** 3).astype(np.float32) * 5.0; q[rng.random(n) < 0.05] = 0.0
+    base = rng.random((F, 3)).astype(np.float32) * 0.6 + 0.2
+    col = (np.repeat(base, cnt, axis=0) + rng.normal(0, 0.03, (n, 3)).astype(np.float32)).astype(np.float32)
+    out = rng.random(n) < 0.12; col[out] = rng.random((int(out.sum()), 3)).astype(np.float32)   # photometric outliers
+    for mode, name in ((0, "none"), (1, "gauss_damping"), (2, "gauss_clamping")):
+        rp = np.zeros(F + 1, np.uint32); rv = np.zeros(n + 1, np.uint16); rc = np.zeros(n + 1, np.float32)
+        m = R.ref_postprocess_face_infos(F, V, ptr.ctypes.data, view.ctypes.data, q.ctypes.data, col.ctypes.data, mode, rp.ctypes.data, rv.ctypes.data, rc.ctypes.data, n + 1)
+        assert m >= 0
+        got, st = M.viewsel.postprocess_face_infos(V, ptr, view, q, col, M.Settings(outlier_removal=name))
+        assert got.nnz == m and np.array_equal(got.col_ptr, rp), name
+        assert np.array_equal(got.view_id, rv[:m]), name
+        if mode == 0:
+            assert np.array_equal(got.cost.view(np.uint32), rc[:m].view(np.uint32))
+        else:
+            assert np.allclose(got.cost, rc[:m], rtol=REL_TOL, atol=1e-6), name
+        assert (m == n) if mode == 0 else (0 < m < n)      # the zero-quality erase belongs to the outlier branch (:265-271)
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import sys
     import torch
