@@ -1,5 +1,9 @@
-"""Multi-GPU driver for the view-selection path: one process per GPU,
-torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" for the CPU tests).
+"""HARNESS-LEVEL driver of the sharded path: partitioning helpers (Morton / Hilbert order, renumbering) and a reference
+implementation of the per-rank loop over torch.distributed, kept for the CPU tests (gloo, numpy stand-in solver) and for
+1-GPU boxes where several ranks share cuda:0.  The PRODUCT's sharded path is C++: csrc/shard.hip behind
+mvs_shard_* (device-side halo plan, RCCL send / recv to neighbours, bytes on the wire); bench.py uses it for N > 1.
+
+One process per GPU, torch.distributed (backend "gloo" here; "nccl" = RCCL works through the same code).
 
 Sharding (DESIGN.md "Multi-GPU"):
   * faces are renumbered in Morton order of their centroids and cut into P
@@ -249,6 +253,22 @@ class ShardedViewSelection:
             self.dist.all_reduce(t, group=self.group)
         return t
 
+    def _combined(self):
+        """one combined (message + label) exchange per phase needs < 2^31 message elements on EVERY rank: message layouts
+        differ between ranks, so the decision is taken once from the all-reduced maximum -- ranks deciding for themselves
+        could issue mismatching collectives"""
+        if getattr(self, "_comb", None) is None:
+            tw = int(self.plan.total_words)
+            if self.dist is not None and self.plan.P > 1:
+                import torch
+                t = torch.tensor([tw], dtype=torch.int64, device=self.hx.buf["both_send"].device)
+                if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                    t = t.cpu()
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+                tw = int(t.item())
+            self._comb = tw < 2 ** 31
+        return self._comb
+
     def run(self):
         ops, plan, P = self.ops, self.plan, self.params
         nb, ne = plan.node_begin, plan.node_end
@@ -266,7 +286,7 @@ class ShardedViewSelection:
             for ph in range(n_phases):                         # colour-phased Gauss-Seidel: halo exchange after every phase
                 ops.sweep_phase(ph, nb, ne)
                 if plan.P > 1:
-                    if plan.total_words < 2 ** 31:
+                    if self._combined():
                         self.hx.exchange([("both", MSG_LAB)], ops.gather, ops.scatter)      # one collective per phase
                     else:
                         self.hx.exchange([("msg", MSG), ("node", LAB)], ops.gather, ops.scatter)
