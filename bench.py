@@ -88,7 +88,7 @@ def induced_subgraph(adj_ptr, adj, n):
     return sap, np.ascontiguousarray(sub[keep], dtype=np.uint32)
 
 
-def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, device):
+def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, device, max_labels=0, percentile=None):
     """The checker leg (never timed): the table the LAST TIMED STEP left on the device against the parity build of the
     oracle (-O2 -ffp-contract=off) on the first n_check faces -- sparsity pattern, view ids and qualities bit for bit --
     and the GPU solver against the oracle's solver on that sample's own table + induced subgraph (labels, fixed-point
@@ -105,6 +105,12 @@ def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, devi
     n = int(min(n_check, s.n_faces))
     got = ctx.costs_download()
     ref, _ = O.data_costs(s, face_range=(0, n), n_threads=nt)
+    if max_labels:
+        # label-space compression picks by cost, and the costs follow from the GLOBAL percentile: restate them with the
+        # percentile of the timed run (the float expression of calculate_data_costs.cpp:295-296), then prune as the oracle does
+        pct = np.float32(percentile)
+        ref = O.CsrNp(ref.n_faces, ref.n_views, ref.col_ptr, ref.view_id, np.float32(1.0) - np.minimum(np.float32(1.0), ref.quality / pct), ref.quality)
+        ref = O.prune_labels(ref, max_labels)
     end = int(got.col_ptr[n])
     res = {"faces": n, "entries": int(ref.nnz)}
     res["pattern_equal"] = bool(np.array_equal(ref.col_ptr, got.col_ptr[:n + 1]) and np.array_equal(ref.view_id, got.view_id[:end]))
@@ -177,9 +183,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE.md config: 2 = 200k faces / 50 views, 3 = 2M faces / 200 views")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.md config: 2 = 200k faces / 50 views, 3 = 2M faces / 200 views (the headline), 5 = one rank's share of the 10M-face / 1000-view scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--max-labels", type=int, default=-1, help="label-space compression (mvs_set_option max_labels); default: off, 64 for --config 5")
+    ap.add_argument("--config5-n", type=int, default=250, help="icosphere frequency of the reduced config-5 run (250 = one rank's share of 8)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed step's table (N = 1 only)")
     ap.add_argument("--parity-faces", type=int, default=100000)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
@@ -207,6 +215,15 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = dict(M.synth.CONFIGS[args.config])
+    max_labels = args.max_labels
+    if args.config == 5:
+        # BASELINE config 5 (9 996 980 faces x 1000 views on 8 GPUs) at the size ONE of its eight ranks holds: n = 250 ->
+        # 1 250 000 faces against all 1000 views, with label-space compression (64 candidates per face unless --max-labels says
+        # otherwise; DESIGN.md "config 5").  Never the default workload, never compared with the headline.
+        cfg["n"] = args.config5_n
+        if max_labels < 0:
+            max_labels = 64
+    max_labels = max(max_labels, 0)
     t0 = time.time()
     scene = M.synth.make_scene(**cfg)
     perm = G.morton_order(scene.verts, scene.faces)   # contiguous parts = compact patches (METIS stand-in; hilbert_order measured the same)
@@ -230,6 +247,8 @@ def main():
     ctx = M.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_option("profile", 1)
+    if max_labels:
+        ctx.set_option("max_labels", max_labels)
     for env, opt in (("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag")):
         if os.environ.get(env):   # tuning knobs for experiments
             ctx.set_option(opt, int(os.environ[env]))
@@ -351,7 +370,7 @@ def main():
            "config": {"workload": "BASELINE config %d: displaced icosphere n=%d (%d faces), %d Fibonacci-sphere views %dx%d RGB8, "
                                   "settings gmi/none/visibility-test (reference defaults)" % (args.config, cfg["n"], F, V, cfg["width"], cfg["height"]),
                       "faces": F, "views": V, "nnz": nnz_global, "sweeps": int(mrf["sweeps"]), "icm_iters": int(mrf["icm_iters"]),
-                      "energy": float(mrf["energy"]), "partition": "morton-%d" % world, "msg_bits": 8,
+                      "energy": float(mrf["energy"]), "partition": "morton-%d" % world, "msg_bits": 8, "max_labels": max_labels,
                       "arithmetic": "fp32 geometry and messages, fp64 footprint sums, 32.32 fixed-point energies; messages STORED as 8-bit codes"},
            "h2d_ms": h2d_ms, "h2d_GBps": h2d_bytes / max(h2d_ms, 1e-9) / 1e6,
            "pcie_inclusive_value": F / ((ms_per_step + h2d_ms) / 1000.0),
@@ -367,7 +386,7 @@ def main():
     rc = 0
     if rank == 0 and world == 1 and not args.no_parity and args.steps > 0 and not args.shard:
         try:
-            out["parity"] = parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, args.parity_faces, local_rank)
+            out["parity"] = parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, args.parity_faces, local_rank, max_labels, dc.get("percentile"))
             out["parity_checked"] = bool(out["parity"]["ok"])
         except Exception as e:  # noqa: BLE001
             out["parity"] = {"error": repr(e)}; out["parity_checked"] = False

@@ -326,6 +326,13 @@ mvs_status mvs_ctx_get_subgraphs(mvs_ctx* ctx, uint32_t n_faces, const uint32_t*
                                  const uint32_t* labels, int labels_on_device, uint32_t n_labels, mvs_subgraphs* out,
                                  int out_on_device);
 
+/* Label-space compression for scenes with hundreds of candidate views per face (BASELINE config 5): keeps, per face, the
+ * max_labels entries with the smallest (cost, view id) pairs, in ascending view order; shorter columns are untouched.
+ * NOT the reference's model (view_selection.cpp:46-47 keeps every candidate): off unless asked for -- here, or with
+ * mvs_set_option(ctx, "max_labels", K), which applies it at the end of every data-cost pass (also of the sharded path).
+ * With max_labels <= 255 every column takes the solver's fast path.  Works on the context's own table. */
+mvs_status mvs_ctx_prune_labels(mvs_ctx* ctx, uint32_t max_labels);
+
 /* tex::postprocess_face_infos (libs/tex/texturing.h:71-74; calculate_data_costs.cpp:253-306) for callers that hold their own
  * FaceProjectionInfos: infos of face i are entries info_ptr[i] .. info_ptr[i + 1] of view_id / quality / mean_color
  * (3 floats, YCbCr, read only when outlier removal is on) IN THE ORDER the caller's vectors hold them -- the outlier

@@ -14,6 +14,7 @@ namespace mvs {
 void dc_phase1(mvs_ctx* ctx, const mvs_settings* st);
 void dc_phase2(mvs_ctx* ctx);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
+void dc_prune_labels(mvs_ctx* ctx, uint32_t kmax);
 void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t* h_ptr, const uint16_t* h_view_rev, const float* h_q_rev, const float* h_col_rev, const mvs_settings* st);
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
@@ -139,6 +140,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "stats") ctx->stats = value != 0;
     else if (n == "lds_bvh_levels") ctx->lds_bvh_levels = (int)value;
     else if (n == "verbose") ctx->verbose = value != 0;
+    else if (n == "max_labels") { if (value < 0 || value > 65535) return fail(MVS_ERR_INVALID, "max_labels: 0 (off) .. 65535"); ctx->max_labels = (int)value; }
     else if (n == "profile") ctx->profile = value != 0;
     else if (n == "ray_mode") ctx->ray_mode = (int)value;
     else if (n == "ray_xcd") ctx->ray_xcd = (int)value;
@@ -267,6 +269,14 @@ mvs_status mvs_ctx_data_costs(mvs_ctx* ctx, const mvs_settings* settings, mvs_dc
     dc_phase1(ctx, settings);
     dc_phase2(ctx);
     dc_phase3(ctx, stats);
+    MVS_API_END
+}
+
+mvs_status mvs_ctx_prune_labels(mvs_ctx* ctx, uint32_t max_labels) {
+    if (!ctx) return fail(MVS_ERR_INVALID, "ctx is null");
+    MVS_API_BEGIN
+    MVS_HIP(hipSetDevice(ctx->device));
+    dc_prune_labels(ctx, max_labels);
     MVS_API_END
 }
 

@@ -107,6 +107,7 @@ struct mvs_ctx {
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
     int ray_mode = 2;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution
     int lds_bvh_levels = 0;
+    int max_labels = 0;      // > 0: label-space compression after the data costs (k_dc.hip prune_write_kernel); 0 = the reference's model
     float cos_limit = 0.0f;  // see dmath.h cull_pair
 
     // ---- scene ----

@@ -617,6 +617,49 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     ctx->dc_phase = 1;
 }
 
+// ---- label-space compression (BASELINE config 5: hundreds of candidate views per face) ----
+// Keeps, per face, the `kmax` entries with the smallest (cost, view id) pairs -- ties to the smaller view id -- in ascending
+// view order; columns of at most kmax entries are untouched.  NOT part of the reference (its model keeps every candidate,
+// view_selection.cpp:46-47): an explicit option (mvs_set_option "max_labels" / mvs_ctx_prune_labels), off by default,
+// restated identically in the oracle (orc_prune_labels).  With kmax <= 255 every column fits the solver's fast path.
+__global__ void prune_count_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, uint32_t kmax, uint32_t* __restrict__ cnt) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f <= nf) cnt[f] = f < nf ? min(col_ptr[f + 1] - col_ptr[f], kmax) : 0u;
+}
+constexpr uint32_t PRUNE_TILE = 1024;   // columns up to this length rank their costs out of LDS
+__global__ void __launch_bounds__(256) prune_write_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                          const float* __restrict__ q, uint32_t nf, uint32_t kmax, const uint32_t* __restrict__ new_ptr,
+                                                          uint16_t* __restrict__ view2, float* __restrict__ cost2, float* __restrict__ q2) {
+    __shared__ float s_cost[4][PRUNE_TILE];
+    const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (f >= nf) return;                                       // wave-uniform
+    const uint32_t p0 = col_ptr[f], K = col_ptr[f + 1] - p0, o = new_ptr[f];
+    if (K <= kmax) {
+        for (uint32_t t = lane; t < K; t += 64) { view2[o + t] = view_id[p0 + t]; cost2[o + t] = cost[p0 + t]; if (q) q2[o + t] = q[p0 + t]; }
+        return;
+    }
+    float* tile = s_cost[threadIdx.x >> 6];
+    const bool in_lds = K <= PRUNE_TILE;
+    if (in_lds) for (uint32_t t = lane; t < K; t += 64) tile[t] = cost[p0 + t];   // LDS operations of a wave execute in order: no barrier
+    uint32_t base = 0;
+    for (uint32_t t0 = 0; t0 < K; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        bool keep = false;
+        if (t < K) {
+            const float c = in_lds ? tile[t] : cost[p0 + t];
+            uint32_t rank = 0;                                 // entries ordered before t by (cost, position); positions ascend with the view id
+            for (uint32_t u = 0; u < K; ++u) { const float cu = in_lds ? tile[u] : cost[p0 + u]; rank += (cu < c || (cu == c && u < t)) ? 1u : 0u; }
+            keep = rank < kmax;
+        }
+        const unsigned long long b = __ballot(keep);
+        if (keep) {
+            const uint32_t d = o + base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            view2[d] = view_id[p0 + t]; cost2[d] = cost[p0 + t]; if (q) q2[d] = q[p0 + t];
+        }
+        base += (uint32_t)__popcll(b);
+    }
+}
+
 // std::sort of a face's infos by view id (calculate_data_costs.cpp:272, operator< of FaceProjectionInfo, texture_view.h:31-33):
 // one thread per face, insertion sort in place (columns are short; equal ids -- which a caller never produces -- keep their order)
 __global__ void sort_columns_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, uint16_t* __restrict__ view_id, float* __restrict__ q) {
@@ -704,6 +747,7 @@ void dc_phase2(mvs_ctx* ctx) {
 }
 
 // phase 3: percentile from the (possibly all-reduced) histogram, cost write (:288-298)
+void dc_prune_labels(mvs_ctx* ctx, uint32_t kmax);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     if (ctx->dc_phase != 2) throw StatusError(MVS_ERR_STATE, "dc_phase3 needs dc_phase2");
     hipStream_t s = ctx->stream;
@@ -727,7 +771,39 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     S.nnz = ctx->csr_nnz; S.max_quality = mq; S.percentile = pc;
     ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p; ctx->csr_q_valid = true;
     ctx->have_costs = true; ctx->dc_phase = 3;
+    if (ctx->max_labels > 0) { dc_prune_labels(ctx, (uint32_t)ctx->max_labels); S.nnz = ctx->csr_nnz; }   // label-space compression (option, off by default)
     if (stats) *stats = S;
+}
+
+// prunes the active table of the context in place (see prune_write_kernel); the table must be the context's own
+void dc_prune_labels(mvs_ctx* ctx, uint32_t kmax) {
+    if (!ctx->have_costs) throw StatusError(MVS_ERR_STATE, "no data costs on the device");
+    if (kmax == 0) return;
+    if (ctx->r_ptr != ctx->csr_ptr.p) throw StatusError(MVS_ERR_STATE, "label pruning works on the context's own table (not on caller-owned device arrays)");
+    hipStream_t s = ctx->stream;
+    Prof pr(ctx, "dc_prune");
+    const uint32_t nf = ctx->csr_faces;
+    const bool have_q = ctx->csr_q_valid;
+    ctx->face_cnt.ensure((size_t)nf + 2); ctx->pre_ptr.ensure((size_t)nf + 2);
+    hipLaunchKernelGGL(prune_count_kernel, dim3((nf + 256) / 256), dim3(256), 0, s, ctx->csr_ptr.p, nf, kmax, ctx->face_cnt.p); MVS_LAUNCH_CHECK();
+    exclusive_scan_u32(ctx, ctx->face_cnt.p, ctx->pre_ptr.p, (size_t)nf + 1, nullptr);
+    const uint32_t nnz2 = read_u32(ctx, ctx->pre_ptr.p + nf);
+    if (nnz2 == ctx->csr_nnz) return;                          // no column is longer than kmax
+    ctx->pre_view.ensure((size_t)nnz2 + 1); ctx->pre_q.ensure((size_t)nnz2 + 1); ctx->pcol.ensure((size_t)nnz2 + 8);
+    if (nf) {
+        hipLaunchKernelGGL(prune_write_kernel, dim3((unsigned)(((size_t)nf * 64 + 255) / 256)), dim3(256), 0, s, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_cost.p,
+                           have_q ? ctx->csr_q.p : (const float*)nullptr, nf, kmax, ctx->pre_ptr.p, ctx->pre_view.p, ctx->pcol.p, ctx->pre_q.p);
+        MVS_LAUNCH_CHECK();
+    }
+    ctx->csr_view.ensure((size_t)nnz2 + 1); ctx->csr_cost.ensure((size_t)nnz2 + 8); ctx->csr_q.ensure((size_t)nnz2 + 1);
+    MVS_HIP(hipMemcpyAsync(ctx->csr_ptr.p, ctx->pre_ptr.p, ((size_t)nf + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (nnz2) {
+        MVS_HIP(hipMemcpyAsync(ctx->csr_view.p, ctx->pre_view.p, (size_t)nnz2 * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+        MVS_HIP(hipMemcpyAsync(ctx->csr_cost.p, ctx->pcol.p, (size_t)nnz2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (have_q) MVS_HIP(hipMemcpyAsync(ctx->csr_q.p, ctx->pre_q.p, (size_t)nnz2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    ctx->csr_nnz = nnz2; ctx->dc_stats.nnz = nnz2;
+    ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p;
 }
 
 }  // namespace mvs

@@ -135,6 +135,7 @@ def load_library():
         "mvs_ctx_mrf_step": [vp, vp], "mvs_ctx_mrf_poll": [vp, u32, C.POINTER(MrfProgress)],
         "mvs_ctx_mrf_icm_gain": [vp, u32, u32], "mvs_ctx_mrf_icm_apply": [vp, u32, u32, vp],
         "mvs_ctx_mrf_labels": [vp, u32, u32, vp, C.POINTER(u32)],
+        "mvs_ctx_prune_labels": [vp, u32],
         "mvs_postprocess_face_infos": [u32, u32, vp, vp, vp, vp, C.POINTER(Settings), C.POINTER(CCsr), C.POINTER(DcStats)],
         "mvs_comm_unique_id": [vp], "mvs_comm_create_rccl": [i32, i32, i32, vp, C.POINTER(vp)], "mvs_comm_create_local": [i32, C.POINTER(vp)],
         "mvs_comm_destroy": [vp], "mvs_shard_create": [vp, vp, vp, vp, vp, C.POINTER(vp)], "mvs_shard_destroy": [vp],
@@ -316,6 +317,10 @@ class Context:
         self.L.mvs_csr_free(C.byref(out))
         C.CDLL(None).free(q)
         return res
+
+    def prune_labels(self, max_labels):
+        """label-space compression of the resident table (mvs_ctx_prune_labels)"""
+        _check(self.L, self.L.mvs_ctx_prune_labels(self.h, int(max_labels)))
 
     def costs_upload(self, dc):
         s, dev = dc._struct()

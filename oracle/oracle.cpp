@@ -757,6 +757,33 @@ int orc_data_costs(const orc_mesh* mesh, const orc_view* views, uint32_t n_views
     return 0;
 }
 
+// Label-space compression (NOT in the reference; the option of the same name of the product, include/mvs_viewsel.h
+// mvs_ctx_prune_labels): per face the kmax entries with the smallest (cost, view id) pairs, in ascending view order.
+void orc_prune_labels(const orc_csr* in, uint32_t kmax, orc_csr* out) {
+    const uint32_t nf = in->n_faces;
+    out->n_faces = nf; out->n_views = in->n_views;
+    out->col_ptr = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)nf + 1));
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < nf; ++i) { out->col_ptr[i] = (uint32_t)n; n += std::min(in->col_ptr[i + 1] - in->col_ptr[i], kmax); }
+    out->col_ptr[nf] = (uint32_t)n; out->nnz = n;
+    out->view_id = (uint16_t*)malloc(sizeof(uint16_t) * std::max<uint64_t>(n, 1));
+    out->cost = (float*)malloc(sizeof(float) * std::max<uint64_t>(n, 1));
+    out->quality = (float*)malloc(sizeof(float) * std::max<uint64_t>(n, 1));
+    std::vector<uint32_t> order;
+    for (uint32_t i = 0; i < nf; ++i) {
+        const uint32_t p0 = in->col_ptr[i], K = in->col_ptr[i + 1] - p0;
+        order.resize(K);
+        for (uint32_t t = 0; t < K; ++t) order[t] = t;
+        if (K > kmax) {
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return in->cost[p0 + a] != in->cost[p0 + b] ? in->cost[p0 + a] < in->cost[p0 + b] : a < b; });
+            order.resize(kmax);
+            std::sort(order.begin(), order.end());
+        }
+        uint32_t d = out->col_ptr[i];
+        for (uint32_t t : order) { out->view_id[d] = in->view_id[p0 + t]; out->cost[d] = in->cost[p0 + t]; out->quality[d] = in->quality ? in->quality[p0 + t] : 0.0f; ++d; }
+    }
+}
+
 void orc_csr_free(orc_csr* c) {
     free(c->col_ptr); free(c->view_id); free(c->cost); free(c->quality);
     memset(c, 0, sizeof(*c));

@@ -92,6 +92,8 @@ int orc_data_costs(const orc_mesh* mesh, const orc_view* views, uint32_t n_views
                    const orc_settings* settings, uint32_t face_begin, uint32_t face_end,
                    int bvh_mode, int n_threads, orc_csr* out, orc_dc_stats* stats);
 void orc_csr_free(orc_csr* csr);
+/* label-space compression (option of the product, not of the reference): per face the kmax smallest (cost, view id) entries */
+void orc_prune_labels(const orc_csr* in, uint32_t kmax, orc_csr* out);
 
 /* ---- single (vertex, view) any-hit ray: calculate_data_costs.cpp:200-209 ---- */
 typedef struct orc_bvh orc_bvh;

@@ -168,6 +168,24 @@ def data_costs(scene, data_term="gmi", outlier_removal="none", geometric_visibil
     return res, {f[0]: getattr(stats, f[0]) for f in DcStats._fields_}
 
 
+def prune_labels(csr, kmax):
+    """label-space compression (orc_prune_labels): per face the kmax entries with the smallest (cost, view id) pairs"""
+    L = load()
+    L.orc_prune_labels.argtypes = [C.POINTER(Csr), C.c_uint32, C.POINTER(Csr)]
+    cs = csr.as_struct()
+    if csr.quality is not None:
+        cs.quality = csr.quality.ctypes.data_as(C.POINTER(C.c_float))
+    out = Csr()
+    L.orc_prune_labels(C.byref(cs), int(kmax), C.byref(out))
+    nf, nnz = out.n_faces, out.nnz
+    res = CsrNp(nf, out.n_views, np.ctypeslib.as_array(out.col_ptr, (nf + 1,)).copy(),
+                np.ctypeslib.as_array(out.view_id, (max(nnz, 1),))[:nnz].copy(),
+                np.ctypeslib.as_array(out.cost, (max(nnz, 1),))[:nnz].copy(),
+                np.ctypeslib.as_array(out.quality, (max(nnz, 1),))[:nnz].copy())
+    L.orc_csr_free(C.byref(out))
+    return res
+
+
 def default_mrf_params(timing=False, **kw):
     p = MrfParams(); load(timing).orc_mrf_default_params(C.byref(p))
     for k, v in kw.items():

@@ -593,6 +593,41 @@ def test_postprocess_face_infos_entry_point_equals_upstream_code():
         assert (m == n) if mode == 0 else (0 < m < n)      # the zero-quality erase belongs to the outlier branch (:265-271)
 
 
+def test_config5_shape_label_compression_equals_the_oracle():
+    """BASELINE config 5's shape at a size the oracle finishes in seconds: 98 000 faces x 1000 views.  Columns hold ~220
+    candidates (one node per wave in the solver); with label-space compression (max_labels = 64, an explicit
+    option restated identically in the oracle -- orc_prune_labels) the table, the labels and the energy equal the oracle's."""
+    s = M.synth.make_scene(n=70, n_views=1000, width=320, height=240, displacement=0.05, layout=1)
+    assert s.n_faces == 98000
+    nt = _oracle_threads()
+    c = M.Context(0)
+    _load_scene(c, s)
+    c.data_costs(M.Settings())
+    full = c.costs_download()
+    ref_full, _ = O.data_costs(s, n_threads=nt)
+    _assert_costs(full, ref_full.col_ptr, ref_full.view_id, ref_full.cost, ref_full.quality, exact=True)
+    K = np.diff(full.col_ptr.astype(np.int64))
+    assert K.max() > 150, K.max()                              # ~0.22 V candidates per face on this layout
+    c.set_option("max_labels", 64)
+    st = c.data_costs(M.Settings())
+    got = c.costs_download()
+    ref = O.prune_labels(ref_full, 64)
+    assert st["nnz"] == got.nnz == ref.nnz < full.nnz
+    _assert_costs(got, ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+    assert np.diff(got.col_ptr.astype(np.int64)).max() == 64
+    lo, so = O.view_selection(ref, s.adj_ptr, s.adj, n_threads=nt)
+    lg, sg = c.view_selection(s.adj_ptr, s.adj)
+    assert np.array_equal(lo, lg)
+    for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters"):
+        assert so[k] == sg[k], k
+    # the explicit entry point on an uploaded table gives the same columns
+    c.set_option("max_labels", 0)
+    c.data_costs(M.Settings()); c.prune_labels(64)
+    again = c.costs_download()
+    assert np.array_equal(again.col_ptr, got.col_ptr) and np.array_equal(again.view_id, got.view_id) and np.array_equal(again.cost.view(np.uint32), got.cost.view(np.uint32))
+    c.close()
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import sys
     import torch
