@@ -115,6 +115,10 @@ def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, devi
     res = {"faces": n, "entries": int(ref.nnz)}
     res["pattern_equal"] = bool(np.array_equal(ref.col_ptr, got.col_ptr[:n + 1]) and np.array_equal(ref.view_id, got.view_id[:end]))
     res["quality_bits_equal"] = bool(res["pattern_equal"] and np.array_equal(ref.quality.view(np.uint32), got.quality[:end].view(np.uint32)))
+    # footprints above info_wave_area pixels are summed by a wave with integer pixel sums instead of the reference's serial fp64
+    # walk: a few fp64 roundings apart, i.e. bit-equal after the conversion to float except for rare last-bit cases
+    res["quality_max_rel_diff"] = float(np.max(np.abs(got.quality[:end].astype(np.float64) - ref.quality) / np.maximum(ref.quality, 1e-30))) if res["pattern_equal"] and end else 0.0
+    res["quality_bit_mismatches"] = int((ref.quality.view(np.uint32) != got.quality[:end].view(np.uint32)).sum()) if res["pattern_equal"] else -1
     del got
     sap, sadj = induced_subgraph(adj_ptr, adj, n)
     kw = dict(max_sweeps=params.max_sweeps, min_sweeps=params.min_sweeps)
@@ -127,7 +131,7 @@ def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, devi
         c2.close()
     res["labels_equal"] = bool(np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"])
     res["sample_sweeps"] = int(sg["sweeps"])
-    res["ok"] = res["pattern_equal"] and res["quality_bits_equal"] and res["labels_equal"]
+    res["ok"] = bool(res["pattern_equal"] and (res["quality_bits_equal"] or res["quality_max_rel_diff"] <= 1e-6) and res["labels_equal"])
     return res
 
 

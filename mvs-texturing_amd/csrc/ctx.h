@@ -107,6 +107,8 @@ struct mvs_ctx {
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
     int ray_mode = 2;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution
     int lds_bvh_levels = 0;
+    int info_wave_area = 32;   // footprints (sampled ones) above this many pixels go to the wave-per-footprint kernel (k_dc.hip wave_info_kernel); 0 = every footprint serial = bit-exact with the reference's fp64 scan order
+    uint32_t dc_stats_deferred = 0;
     int max_labels = 0;      // > 0: label-space compression after the data costs (k_dc.hip prune_write_kernel); 0 = the reference's model
     float cos_limit = 0.0f;  // see dmath.h cull_pair
 
@@ -137,6 +139,7 @@ struct mvs_ctx {
     // ---- data costs work buffers ----
     mvs::DBuf<unsigned long long> pass_bits, need_bits, occl_bits, surv_bits;
     mvs::DBuf<uint32_t> pass_base;      // exclusive scan of popc(pass words)
+    mvs::DBuf<unsigned long long> defer_bits; mvs::DBuf<uint32_t> defer_base; mvs::DBuf<uint2> defer_list;   // large footprints left to the wave-per-footprint kernel
     mvs::DBuf<float> pq;                // quality per passing pair
     mvs::DBuf<float> pcol;              // 3 floats per passing pair (outlier removal only)
     mvs::DBuf<uint32_t> face_cnt, scan_tmp;

@@ -196,66 +196,128 @@ MVS_HD uint8_t linear_at(const uint8_t* img, int w, int h, int chans, float x, f
 
 struct FaceInfoOut { float quality; float mean_color[3]; };
 
-// TextureView::get_face_info (texture_view.cpp:134-251) with Tri (tri.cpp:12-24,
-// tri.h:58-84).  One sequential scan-line walk per (face, view): the fp64
-// accumulation order is the reference's, which is what makes qualities bit-exact.
-// DATA_TERM: 0 = area, 1 = gmi; OUTLIER: colours are accumulated iff true.
+// TextureView::get_face_info (texture_view.cpp:134-251) with Tri (tri.cpp:12-24, tri.h:58-84), split into the pieces the
+// two footprint walkers share -- every float expression exists once, in the reference's operation order:
+//   foot_setup   projection, Tri (bounding box, area, detT), y-sort of the vertices, edge equations   (:139-180)
+//   foot_row     the pixel span [xb, xe) of scan line y, or false where the reference `continue`s        (:187-200)
+//   foot_inside  Tri::inside for the slow path (an edge slope is 0 / infinite)                          (:205, tri.h:58-77)
+//   foot_finish  quality and mean colour from the sums, incl. the no-sample fallback                    (:222-250)
+struct FootSetup {
+    V2 p1, p2, p3;            // sorted by ascending y
+    V2 t1, t2, t3;            // Tri keeps the unsorted points
+    float detT, aabb_min_x, aabb_min_y, aabb_max_x, aabb_max_y, area;
+    float m1, b1, m2, b2, m3, b3;
+    bool fast;
+};
+MVS_HD void foot_setup(const ViewParams& view, V3 v1, V3 v2, V3 v3, FootSetup& s) {
+    s.p1 = pixel_coords(view, v1); s.p2 = pixel_coords(view, v2); s.p3 = pixel_coords(view, v3);
+    s.t1 = s.p1; s.t2 = s.p2; s.t3 = s.p3;
+    const float T0 = s.t1.x - s.t3.x, T1 = s.t2.x - s.t3.x, T2 = s.t1.y - s.t3.y, T3 = s.t2.y - s.t3.y;
+    s.detT = T0 * T3 - T2 * T1;
+    s.aabb_min_x = smin(s.t1.x, smin(s.t2.x, s.t3.x)); s.aabb_min_y = smin(s.t1.y, smin(s.t2.y, s.t3.y));
+    s.aabb_max_x = smax(s.t1.x, smax(s.t2.x, s.t3.x)); s.aabb_max_y = smax(s.t1.y, smax(s.t2.y, s.t3.y));
+    const float ux = s.t2.x - s.t1.x, uy = s.t2.y - s.t1.y, vx = s.t3.x - s.t1.x, vy = s.t3.y - s.t1.y;
+    s.area = 0.5f * fabsf(ux * vy - uy * vx);
+}
+// the part of the setup only a sampled footprint needs (texture_view.cpp:163-180)
+MVS_HD void foot_edges(FootSetup& s) {
+    while (true) {   // sort by ascending y (:163-167)
+        if (s.p1.y <= s.p2.y) {
+            if (s.p2.y <= s.p3.y) break;
+            V2 t = s.p2; s.p2 = s.p3; s.p3 = t;
+        } else { V2 t = s.p1; s.p1 = s.p2; s.p2 = t; }
+    }
+    s.m1 = (s.p1.y - s.p3.y) / (s.p1.x - s.p3.x); s.b1 = s.p1.y - s.m1 * s.p1.x;
+    s.m2 = (s.p1.y - s.p2.y) / (s.p1.x - s.p2.x); s.b2 = s.p1.y - s.m2 * s.p1.x;
+    s.m3 = (s.p2.y - s.p3.y) / (s.p2.x - s.p3.x); s.b3 = s.p2.y - s.m3 * s.p2.x;
+    s.fast = isfinite(s.m1) && s.m2 != 0.0f && isfinite(s.m2) && s.m3 != 0.0f && isfinite(s.m3);
+}
+MVS_HD bool foot_row(const FootSetup& s, int y, int* xb, int* xe) {
+    float min_x = s.aabb_min_x - 0.5f, max_x = s.aabb_max_x + 0.5f;
+    const float cy = (float)y + 0.5f;
+    if (s.fast) {
+        min_x = (cy - s.b1) / s.m1;
+        if (cy <= s.p2.y) max_x = (cy - s.b2) / s.m2;
+        else max_x = (cy - s.b3) / s.m3;
+        if (min_x >= max_x) { float t = min_x; min_x = max_x; max_x = t; }
+        if (min_x < s.aabb_min_x || min_x > s.aabb_max_x) return false;
+        if (max_x < s.aabb_min_x || max_x > s.aabb_max_x) return false;
+    }
+    *xb = (int)floorf(min_x + 0.5f);
+    *xe = (int)ceilf(max_x - 0.5f);            // the reference loops while (float)x < ceilf(max_x - 0.5f): x < an integer-valued float
+    return true;
+}
+MVS_HD bool foot_inside(const FootSetup& s, int x, int y) {   // Tri::inside (tri.h:58-77)
+    const float cx = (float)x + 0.5f, cy = (float)y + 0.5f;
+    const float dx = cx - s.t3.x, dy = cy - s.t3.y;
+    const float alpha = ((s.t2.y - s.t3.y) * dx + (s.t3.x - s.t2.x) * dy) / s.detT;
+    if (alpha < 0.0f || alpha > 1.0f) return false;
+    const float beta = ((s.t3.y - s.t1.y) * dx + (s.t1.x - s.t3.x) * dy) / s.detT;
+    if (beta < 0.0f || beta > 1.0f) return false;
+    if (alpha + beta > 1.0f) return false;
+    return true;
+}
 template <int DATA_TERM, bool OUTLIER>
-MVS_HD void face_info(const ViewParams& view, V3 v1, V3 v2, V3 v3, FaceInfoOut* out) {
-    V2 p1 = pixel_coords(view, v1), p2 = pixel_coords(view, v2), p3 = pixel_coords(view, v3);
-    const V2 t1 = p1, t2 = p2, t3 = p3;  // Tri keeps the unsorted points
-    const float T0 = t1.x - t3.x, T1 = t2.x - t3.x, T2 = t1.y - t3.y, T3 = t2.y - t3.y;
-    const float detT = T0 * T3 - T2 * T1;
-    const float aabb_min_x = smin(t1.x, smin(t2.x, t3.x)), aabb_min_y = smin(t1.y, smin(t2.y, t3.y));
-    const float aabb_max_x = smax(t1.x, smax(t2.x, t3.x)), aabb_max_y = smax(t1.y, smax(t2.y, t3.y));
-    const float ux = t2.x - t1.x, uy = t2.y - t1.y, vx = t3.x - t1.x, vy = t3.y - t1.y;
-    const float area = 0.5f * fabsf(ux * vy - uy * vx);
+MVS_HD void foot_finish(const ViewParams& view, const FootSetup& s, uint32_t num_samples, double col0, double col1, double col2, double gmi, FaceInfoOut* out) {
+    const int w = view.width, h = view.height;
+    const uint8_t* image = view.rgb;
+    const uint8_t* gimg = view.gmi;
+    if (DATA_TERM == 1) {
+        if (num_samples > 0) {
+            gmi = (gmi / (double)num_samples) * (double)s.area;
+        } else {
+            const double g1 = (double)linear_at(gimg, w, h, 1, s.p1.x, s.p1.y, 0) / 255.0;
+            const double g2 = (double)linear_at(gimg, w, h, 1, s.p2.x, s.p2.y, 0) / 255.0;
+            const double g3 = (double)linear_at(gimg, w, h, 1, s.p3.x, s.p3.y, 0) / 255.0;
+            gmi = (((g1 + g2) + g3) / 3.0) * (double)s.area;
+        }
+    }
+    if (OUTLIER) {
+        if (num_samples > 0) {
+            out->mean_color[0] = (float)(col0 / (double)num_samples);
+            out->mean_color[1] = (float)(col1 / (double)num_samples);
+            out->mean_color[2] = (float)(col2 / (double)num_samples);
+        } else {
+            for (int i = 0; i < 3; ++i) {
+                const double c1 = (double)linear_at(image, w, h, 3, s.p1.x, s.p1.y, i) / 255.0;
+                const double c2 = (double)linear_at(image, w, h, 3, s.p2.x, s.p2.y, i) / 255.0;
+                const double c3 = (double)linear_at(image, w, h, 3, s.p3.x, s.p3.y, i) / 255.0;
+                out->mean_color[i] = (float)(((c1 + c2) + c3) / 3.0);
+            }
+        }
+    }
+    out->quality = (DATA_TERM == 0) ? s.area : (float)gmi;
+}
+
+constexpr float FOOT_DEFERRED = -1.0f;   // quality marker: "sampled by the wave-per-footprint kernel" (qualities are >= 0)
+
+// One sequential scan-line walk per (face, view): the fp64 accumulation order is the reference's, which is what makes
+// qualities bit-exact.  DATA_TERM: 0 = area, 1 = gmi; OUTLIER: colours are accumulated iff true.  A footprint that has to
+// be sampled and whose area exceeds defer_area is NOT walked here: quality = FOOT_DEFERRED.
+template <int DATA_TERM, bool OUTLIER>
+MVS_HD void face_info(const ViewParams& view, V3 v1, V3 v2, V3 v3, FaceInfoOut* out, float defer_area = INFINITY) {
+    FootSetup s;
+    foot_setup(view, v1, v2, v3, s);
     out->quality = 0.0f;
     out->mean_color[0] = out->mean_color[1] = out->mean_color[2] = 0.0f;
-    if (area < FLT_EPSILON) return;
+    if (s.area < FLT_EPSILON) return;
 
     uint32_t num_samples = 0;
     double col0 = 0.0, col1 = 0.0, col2 = 0.0, gmi = 0.0;
-    const int w = view.width, h = view.height;
+    const int w = view.width;
     const uint8_t* image = view.rgb;
     const uint8_t* gimg = view.gmi;
     const bool sampling_necessary = (DATA_TERM != 0) || OUTLIER;
 
-    if (sampling_necessary && area > 0.5f) {
-        // sort by ascending y (texture_view.cpp:163-167)
-        while (true) {
-            if (p1.y <= p2.y) {
-                if (p2.y <= p3.y) break;
-                V2 t = p2; p2 = p3; p3 = t;
-            } else { V2 t = p1; p1 = p2; p2 = t; }
-        }
-        const float m1 = (p1.y - p3.y) / (p1.x - p3.x), b1 = p1.y - m1 * p1.x;
-        const float m2 = (p1.y - p2.y) / (p1.x - p2.x), b2 = p1.y - m2 * p1.x;
-        const float m3 = (p2.y - p3.y) / (p2.x - p3.x), b3 = p2.y - m3 * p2.x;
-        const bool fast = isfinite(m1) && m2 != 0.0f && isfinite(m2) && m3 != 0.0f && isfinite(m3);
-        const float y_end = ceilf(aabb_max_y);
-        for (int y = (int)floorf(aabb_min_y); (float)y < y_end; ++y) {
-            float min_x = aabb_min_x - 0.5f, max_x = aabb_max_x + 0.5f;
-            const float cy = (float)y + 0.5f;
-            if (fast) {
-                min_x = (cy - b1) / m1;
-                if (cy <= p2.y) max_x = (cy - b2) / m2;
-                else max_x = (cy - b3) / m3;
-                if (min_x >= max_x) { float t = min_x; min_x = max_x; max_x = t; }
-                if (min_x < aabb_min_x || min_x > aabb_max_x) continue;
-                if (max_x < aabb_min_x || max_x > aabb_max_x) continue;
-            }
-            const float x_end = ceilf(max_x - 0.5f);
-            for (int x = (int)floorf(min_x + 0.5f); (float)x < x_end; ++x) {
-                if (!fast) {  // Tri::inside (tri.h:58-77)
-                    const float cx = (float)x + 0.5f;
-                    const float dx = cx - t3.x, dy = cy - t3.y;
-                    const float alpha = ((t2.y - t3.y) * dx + (t3.x - t2.x) * dy) / detT;
-                    if (alpha < 0.0f || alpha > 1.0f) continue;
-                    const float beta = ((t3.y - t1.y) * dx + (t1.x - t3.x) * dy) / detT;
-                    if (beta < 0.0f || beta > 1.0f) continue;
-                    if (alpha + beta > 1.0f) continue;
-                }
+    if (sampling_necessary && s.area > 0.5f) {
+        if (s.area > defer_area) { out->quality = FOOT_DEFERRED; return; }
+        foot_edges(s);
+        const float y_end = ceilf(s.aabb_max_y);
+        for (int y = (int)floorf(s.aabb_min_y); (float)y < y_end; ++y) {
+            int xb, xe;
+            if (!foot_row(s, y, &xb, &xe)) continue;
+            for (int x = xb; x < xe; ++x) {
+                if (!s.fast && !foot_inside(s, x, y)) continue;
                 const size_t pix = (size_t)x + (size_t)y * w;
                 if (OUTLIER) {
                     col0 += (double)image[pix * 3 + 0] / 255.0;
@@ -267,31 +329,7 @@ MVS_HD void face_info(const ViewParams& view, V3 v1, V3 v2, V3 v3, FaceInfoOut* 
             }
         }
     }
-    if (DATA_TERM == 1) {
-        if (num_samples > 0) {
-            gmi = (gmi / (double)num_samples) * (double)area;
-        } else {
-            const double g1 = (double)linear_at(gimg, w, h, 1, p1.x, p1.y, 0) / 255.0;
-            const double g2 = (double)linear_at(gimg, w, h, 1, p2.x, p2.y, 0) / 255.0;
-            const double g3 = (double)linear_at(gimg, w, h, 1, p3.x, p3.y, 0) / 255.0;
-            gmi = (((g1 + g2) + g3) / 3.0) * (double)area;
-        }
-    }
-    if (OUTLIER) {
-        if (num_samples > 0) {
-            out->mean_color[0] = (float)(col0 / (double)num_samples);
-            out->mean_color[1] = (float)(col1 / (double)num_samples);
-            out->mean_color[2] = (float)(col2 / (double)num_samples);
-        } else {
-            for (int i = 0; i < 3; ++i) {
-                const double c1 = (double)linear_at(image, w, h, 3, p1.x, p1.y, i) / 255.0;
-                const double c2 = (double)linear_at(image, w, h, 3, p2.x, p2.y, i) / 255.0;
-                const double c3 = (double)linear_at(image, w, h, 3, p3.x, p3.y, i) / 255.0;
-                out->mean_color[i] = (float)(((c1 + c2) + c3) / 3.0);
-            }
-        }
-    }
-    out->quality = (DATA_TERM == 0) ? area : (float)gmi;
+    foot_finish<DATA_TERM, OUTLIER>(view, s, num_samples, col0, col1, col2, gmi, out);
 }
 
 // mve::image::color_rgb_to_ycbcr<float> as applied at calculate_data_costs.cpp:225

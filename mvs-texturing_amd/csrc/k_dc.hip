@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
                                                    const unsigned long long* __restrict__ pass, const unsigned long long* __restrict__ occl,
                                                    const uint32_t* __restrict__ vpos,
                                                    const uint32_t* __restrict__ pass_base, float* __restrict__ pq, float* __restrict__ pcol,
-                                                   unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters) {
+                                                   unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters,
+                                                   float defer_area /* footprints above this area are left to wave_info_kernel (+inf: none) */,
+                                                   unsigned long long* __restrict__ defer_bits) {
     const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
     const bool wave_ok = (lf >> 6) < fwords;  // false: whole wave beyond the face range
     const bool act = lf < nf;
@@ -128,8 +130,8 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
     for (uint32_t j = j0; wave_ok && j < j1; ++j) {
         const size_t widx = (size_t)j * fwords + (lf >> 6);
         const unsigned long long word = pass[widx];  // wave-uniform
-        if (word == 0ull) { if (lane == 0) surv[widx] = 0ull; continue; }
-        bool keep = false;
+        if (word == 0ull) { if (lane == 0) { surv[widx] = 0ull; if (defer_bits) defer_bits[widx] = 0ull; } continue; }
+        bool keep = false, deferred = false;
         if ((word >> lane) & 1ull) {
             bool visible = true;
             if (VISTEST) {
@@ -138,8 +140,9 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
             }
             FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
             if (visible) {
-                face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi);
-                if (fi.quality == 0.0f) ++cnt[1]; else { keep = true; ++cnt[2]; }
+                face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi, defer_area);
+                if (fi.quality == FOOT_DEFERRED) deferred = true;   // quality, survivor bit and counters come from wave_info_kernel
+                else if (fi.quality == 0.0f) ++cnt[1]; else { keep = true; ++cnt[2]; }
             } else ++cnt[0];
             const size_t r = (size_t)pass_base[widx] + __popcll(word & lt);
             pq[r] = fi.quality;
@@ -149,9 +152,80 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
             }
         }
         const unsigned long long b = __ballot(keep);
-        if (lane == 0) surv[widx] = b;
+        const unsigned long long db = defer_bits ? __ballot(deferred) : 0ull;
+        if (lane == 0) { surv[widx] = b; if (defer_bits) defer_bits[widx] = db; }
     }
     if (STATS) { const int slot[3] = {C_OCCL, C_ZEROQ, C_SURV}; block_count_add<3>(cnt, counters, slot); }
+}
+
+// ---- large footprints: a lane GROUP per (face, view) pair ----
+// The reference's rasteriser is a serial scan-line loop (texture_view.cpp:183-219): as one thread per pair a footprint of
+// thousands of pixels keeps one lane busy while its 63 neighbours idle, and real captures are made of such footprints.  Here a
+// footprint is walked by 16 lanes (2 scan lines x 8 pixels at a time; the spans come from the shared foot_row()), its pixels
+// are read along rows and summed as INTEGERS (u8 values: exact, order independent); only the final division by 255 is fp64.  The
+// reference adds the quotients u / 255.0 one by one in fp64, so its sum differs from this one by a few fp64 roundings
+// (~n * 2^-53 relative) -- far inside the 1e-4 bar of the data costs, and after the conversion to float the quality is
+// bit-equal except where that difference straddles a float rounding boundary (probability ~ n * 2^-29 per footprint).
+// Footprints up to `defer_area` pixels keep the bit-exact serial walk (mvs_set_option "info_wave_area"; 0 = all serial).
+__global__ void defer_expand_kernel(const unsigned long long* __restrict__ defer_bits, const uint32_t* __restrict__ base, size_t n_words, uint2* __restrict__ list) {
+    const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    unsigned long long w = defer_bits[wi];
+    uint32_t o = base[wi];
+    while (w) { const int b = __ffsll((long long)w) - 1; w &= w - 1ull; list[o++] = make_uint2((uint32_t)wi, (uint32_t)(wi >> 32) << 8 | (uint32_t)b); }
+}
+template <int DATA_TERM, bool OUTLIER, bool STATS>
+__global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
+                                                        uint32_t fb, uint32_t fwords, const uint2* __restrict__ list, uint32_t n_list,
+                                                        const unsigned long long* __restrict__ pass, const uint32_t* __restrict__ pass_base,
+                                                        float* __restrict__ pq, float* __restrict__ pcol, unsigned long long* __restrict__ surv,
+                                                        unsigned long long* __restrict__ counters) {
+    // 16 lanes per footprint (four footprints per wave), arranged as 2 scan lines x 8 pixels: a lane computes the span of its
+    // own scan line with the shared foot_row() and strides through it by 8 -- no staging, no search, coalesced row reads
+    constexpr int GL = 16, ROWS = 2, COLS = 8;
+    const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) / GL;
+    const bool act = k < n_list;
+    const int sub = threadIdx.x & (GL - 1), dy = sub / COLS, dx = sub % COLS;
+    const uint2 rec = list[act ? k : 0];
+    const size_t widx = (size_t)rec.x | ((size_t)(rec.y >> 8) << 32);
+    const uint32_t bit = rec.y & 63u;
+    const uint32_t j = (uint32_t)(widx / fwords), lf = (uint32_t)(widx % fwords) * 64u + bit;
+    const size_t f = (size_t)fb + lf;
+    const V3 v1 = ld3(verts, faces[3 * f]), v2 = ld3(verts, faces[3 * f + 1]), v3 = ld3(verts, faces[3 * f + 2]);
+    const ViewParams& view = views[j];
+    FootSetup s;
+    foot_setup(view, v1, v2, v3, s);
+    foot_edges(s);
+    const int w = view.width;
+    const uint8_t* image = view.rgb; const uint8_t* gimg = view.gmi;
+    uint32_t n = 0, c0 = 0, c1 = 0, c2 = 0, g = 0;             // per-lane integer sums: <= 255 * (pixels / 16) each
+    const int y_begin = (int)floorf(s.aabb_min_y), y_end = act ? (int)ceilf(s.aabb_max_y) : y_begin;   // (float)y < ceilf(max): y < an integer-valued float
+    for (int y = y_begin + dy; y < y_end; y += ROWS) {
+        int xb, xe;
+        if (!foot_row(s, y, &xb, &xe)) continue;
+        for (int x = xb + dx; x < xe; x += COLS) {
+            if (!s.fast && !foot_inside(s, x, y)) continue;
+            const size_t pix = (size_t)x + (size_t)y * w;
+            if (OUTLIER) { c0 += image[pix * 3 + 0]; c1 += image[pix * 3 + 1]; c2 += image[pix * 3 + 2]; }
+            if (DATA_TERM == 1) g += gimg[pix];
+            ++n;
+        }
+    }
+    for (int o = GL / 2; o > 0; o >>= 1) {
+        n += __shfl_xor(n, o, GL); g += __shfl_xor(g, o, GL);
+        if (OUTLIER) { c0 += __shfl_xor(c0, o, GL); c1 += __shfl_xor(c1, o, GL); c2 += __shfl_xor(c2, o, GL); }
+    }
+    uint32_t cnt[2] = {0, 0};   // zero quality, survivors
+    if (sub == 0 && act) {
+        FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
+        foot_finish<DATA_TERM, OUTLIER>(view, s, n, (double)c0 / 255.0, (double)c1 / 255.0, (double)c2 / 255.0, (double)g / 255.0, &fi);
+        const unsigned long long word = pass[widx];
+        const size_t r = (size_t)pass_base[widx] + __popcll(word & ((1ull << bit) - 1ull));
+        pq[r] = fi.quality;
+        if (OUTLIER) { rgb_to_ycbcr(fi.mean_color); pcol[3 * r] = fi.mean_color[0]; pcol[3 * r + 1] = fi.mean_color[1]; pcol[3 * r + 2] = fi.mean_color[2]; }
+        if (fi.quality != 0.0f) { atomicOr(&surv[widx], 1ull << bit); ++cnt[1]; } else ++cnt[0];
+    }
+    if (STATS) { const int slot[2] = {C_ZEROQ, C_SURV}; block_count_add<2>(cnt, counters, slot); }
 }
 
 // ---- view-major bits -> CSR by face ----
@@ -554,12 +628,18 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     if (outl) ctx->pcol.ensure(3 * ((size_t)n_pass + 1));
 
     Prof pr_info(ctx, "dc_face_info");
+    // footprints above info_wave_area pixels (and only footprints that are sampled at all: gmi or outlier removal) are left to
+    // the wave-per-footprint kernel
+    const bool defer = (gmi || outl) && ctx->info_wave_area > 0;
+    const float defer_area = defer ? (float)ctx->info_wave_area : INFINITY;
+    unsigned long long* defer_bits = nullptr;
+    if (defer) { ctx->defer_bits.ensure(pw + 1); defer_bits = ctx->defer_bits.p; }
 #define LAUNCH_INFO(DT, OL, VT)                                                                                              \
     do { if (ctx->stats) LAUNCH_INFO2(DT, OL, VT, true); else LAUNCH_INFO2(DT, OL, VT, false); } while (0)
 #define LAUNCH_INFO2(DT, OL, VT, ST)                                                                                         \
     hipLaunchKernelGGL((info_kernel<DT, OL, VT, ST>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
                        fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->vpos.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
-                       ctx->surv_bits.p, ctx->counters.p)
+                       ctx->surv_bits.p, ctx->counters.p, defer_area, defer_bits)
     if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true); else LAUNCH_INFO(1, true, false); }
                else      { if (vis) LAUNCH_INFO(1, false, true); else LAUNCH_INFO(1, false, false); } }
     else     { if (outl) { if (vis) LAUNCH_INFO(0, true, true); else LAUNCH_INFO(0, true, false); }
@@ -567,6 +647,25 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
 #undef LAUNCH_INFO
 #undef LAUNCH_INFO2
     MVS_LAUNCH_CHECK();
+    if (defer) {
+        // deferred pairs: bit matrix -> ranks -> list (no atomics), then one wave per pair
+        ctx->defer_base.ensure(pw + 2);
+        hipLaunchKernelGGL(popc_kernel, dim3((unsigned)((pw + 255) / 256)), dim3(256), 0, s, defer_bits, ctx->defer_base.p, pw); MVS_LAUNCH_CHECK();
+        uint32_t* d_total2 = (uint32_t*)(ctx->max_q.p + 3);
+        exclusive_scan_u32(ctx, ctx->defer_base.p, ctx->defer_base.p, pw, d_total2);
+        const uint32_t n_def = read_u32(ctx, d_total2);
+        ctx->dc_stats_deferred = n_def;
+        if (n_def) {
+            ctx->defer_list.ensure((size_t)n_def + 1);
+            hipLaunchKernelGGL(defer_expand_kernel, dim3((unsigned)((pw + 255) / 256)), dim3(256), 0, s, defer_bits, ctx->defer_base.p, pw, ctx->defer_list.p); MVS_LAUNCH_CHECK();
+            const dim3 wgrid((unsigned)(((size_t)n_def * 16 + 255) / 256));
+#define LAUNCH_WAVE(DT, OL) do { if (ctx->stats) hipLaunchKernelGGL((wave_info_kernel<DT, OL, true>), wgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, n_def, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p); \
+                                 else hipLaunchKernelGGL((wave_info_kernel<DT, OL, false>), wgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, n_def, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p); } while (0)
+            if (gmi) { if (outl) LAUNCH_WAVE(1, true); else LAUNCH_WAVE(1, false); } else LAUNCH_WAVE(0, true);
+#undef LAUNCH_WAVE
+            MVS_LAUNCH_CHECK();
+        }
+    }
     pr_info.end();
     Prof pr_csr(ctx, "dc_csr");
 
@@ -621,7 +720,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
 // Keeps, per face, the `kmax` entries with the smallest (cost, view id) pairs -- ties to the smaller view id -- in ascending
 // view order; columns of at most kmax entries are untouched.  NOT part of the reference (its model keeps every candidate,
 // view_selection.cpp:46-47): an explicit option (mvs_set_option "max_labels" / mvs_ctx_prune_labels), off by default,
-// restated identically in the oracle (orc_prune_labels).  With kmax <= 255 every column fits the solver's fast path.
+// restated identically in the oracle (its prune_labels entry point).  With kmax <= 255 every column fits the solver's fast path.
 __global__ void prune_count_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, uint32_t kmax, uint32_t* __restrict__ cnt) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f <= nf) cnt[f] = f < nf ? min(col_ptr[f + 1] - col_ptr[f], kmax) : 0u;

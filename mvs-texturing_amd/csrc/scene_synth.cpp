@@ -289,11 +289,12 @@ static void make_camera(double px, double py, double pz, float focal_px, int w, 
 // layout 0: the 6 axis directions (n_views must be 6); layout 1: Fibonacci sphere.
 // zoom_odd scales the focal length of odd-indexed cameras (> 1 crops the sphere, exercising the
 // valid_pixel cull of calculate_data_costs.cpp:191).
-int synth_cameras(uint32_t n_views, int layout, float radius, int w, int h, float zoom_odd, synth_camera* out) {
-    // sphere of radius ~1.1 spans ~90 % of the short image side
+int synth_cameras2(uint32_t n_views, int layout, float radius, int w, int h, float zoom_odd, float zoom, synth_camera* out) {
+    // sphere of radius ~1.1 spans ~90 % of the short image side at zoom 1; zoom > 1 crops every view to a patch of the
+    // surface (large footprints, few candidate views per face: the shape of a real capture)
     const float rs = 1.1f;
     const float tan_half = rs / std::sqrt(radius * radius - rs * rs);
-    const float focal = 0.45f * (float)std::min(w, h) / tan_half;
+    const float focal = (0.45f * (float)std::min(w, h) / tan_half) * zoom;
     if (layout == 0) {
         if (n_views != 6) return -1;
         const double ax[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
@@ -309,6 +310,10 @@ int synth_cameras(uint32_t n_views, int layout, float radius, int w, int h, floa
         make_camera(radius * rr * std::cos(phi), radius * rr * std::sin(phi), radius * z, (k & 1) ? focal * zoom_odd : focal, w, h, out + k);
     }
     return 0;
+}
+
+int synth_cameras(uint32_t n_views, int layout, float radius, int w, int h, float zoom_odd, synth_camera* out) {
+    return synth_cameras2(n_views, layout, radius, w, h, zoom_odd, 1.0f, out);
 }
 
 // Procedural RGB8 image for one camera: a colour field defined on the unit

@@ -32,6 +32,7 @@ MODES = {
 def ctx():
     c = M.Context(0)
     c.set_option("stats", 1)        # fill the cull-reason counters (diagnostics, off by default)
+    c.set_option("info_wave_area", 0)   # every footprint walked serially in the reference's fp64 order: qualities BIT-exact
     yield c
     c.close()
 
@@ -625,6 +626,36 @@ def test_config5_shape_label_compression_equals_the_oracle():
     c.data_costs(M.Settings()); c.prune_labels(64)
     again = c.costs_download()
     assert np.array_equal(again.col_ptr, got.col_ptr) and np.array_equal(again.view_id, got.view_id) and np.array_equal(again.cost.view(np.uint32), got.cost.view(np.uint32))
+    c.close()
+
+
+@pytest.mark.parametrize("name,kw", [("bigfoot", dict()), ("close", dict(outlier_removal="gauss_clamping")), ("tiny", dict(data_term="area", outlier_removal="gauss_damping")),
+                                     ("bumpy", dict())])
+def test_wave_per_footprint_kernel_against_the_oracle(name, kw):
+    """the default path for large footprints (one wave per (face, view) pair, integer pixel sums; k_dc.hip wave_info_kernel)
+    against the oracle's serial fp64 walk: identical sparsity pattern and view ids, qualities within 1e-6 relative (the
+    sums differ by a few fp64 roundings; after the conversion to float almost every entry is bit-equal), costs within the
+    1e-4 bar of BASELINE.json; and the solver on the GPU's own table equals the oracle's solver on that table."""
+    s = get_scene(name)
+    c = M.Context(0); c.set_option("stats", 1); c.set_option("info_wave_area", 32)
+    _load_scene(c, s)
+    ref, rst = O.data_costs(s, **kw)
+    st = c.data_costs(M.Settings(**kw))
+    got = c.costs_download()
+    assert np.array_equal(got.col_ptr, ref.col_ptr) and np.array_equal(got.view_id, ref.view_id), "sparsity pattern differs"
+    for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
+        assert st[k] == rst[k], k
+    assert np.allclose(got.quality, ref.quality, rtol=1e-6, atol=0) and np.allclose(got.cost, ref.cost, rtol=REL_TOL, atol=1e-6)
+    same = (got.quality.view(np.uint32) == ref.quality.view(np.uint32)).mean()
+    assert same > 0.99, same
+    table = O.CsrNp(got.n_faces, got.n_views, got.col_ptr, got.view_id, got.cost)
+    lo, so = O.view_selection(table, s.adj_ptr, s.adj)
+    lg, sg = c.view_selection(s.adj_ptr, s.adj)
+    assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
+    # and the serial mode on the same context is bit-exact
+    c.set_option("info_wave_area", 0)
+    c.data_costs(M.Settings(**kw)); strict = c.costs_download()
+    assert np.array_equal(strict.quality.view(np.uint32), ref.quality.view(np.uint32))
     c.close()
 
 
