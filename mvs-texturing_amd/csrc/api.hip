@@ -100,6 +100,9 @@ mvs_status mvs_ctx_create(int device, mvs_ctx** out) {
     MVS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     c->cos_limit = compute_cos_limit();
+    // MVS_INFO_WAVE_AREA overrides the default footprint area above which the lane-group sampler takes over (0: every
+    // footprint in the reference's serial fp64 order, i.e. bit-exact qualities); mvs_set_option("info_wave_area") still wins
+    if (const char* e = getenv("MVS_INFO_WAVE_AREA")) c->info_wave_area = std::max(0, atoi(e));
     c->counters.ensure(64);
     *out = c;
     MVS_API_END

@@ -374,61 +374,106 @@ struct Lu3 {
 };
 
 // multi_gauss_unnormalized (util.h:60-66)
-__device__ __forceinline__ double multi_gauss(const double x[3], const double mu[3], const double ci[3][3]) {
+__device__ __forceinline__ double multi_gauss_arg(const double x[3], const double mu[3], const double ci[3][3]) {
     double mr[3], w[3];
     for (int a = 0; a < 3; ++a) mr[a] = x[a] - mu[a];
     for (int b = 0; b < 3; ++b) w[b] = ((-0.5 * mr[0]) * ci[0][b] + (-0.5 * mr[1]) * ci[1][b]) + (-0.5 * mr[2]) * ci[2][b];
-    return exp((w[0] * mr[0] + w[1] * mr[1]) + w[2] * mr[2]);
+    return (w[0] * mr[0] + w[1] * mr[1]) + w[2] * mr[2];
+}
+__device__ __forceinline__ double multi_gauss(const double x[3], const double mu[3], const double ci[3][3]) { return exp(multi_gauss_arg(x, mu, ci)); }
+// exp(arg) >= 6e-3 (the inlier test, :99-103) WITHOUT the exponential wherever the answer cannot depend on its rounding:
+// exp is monotone and accurate to far better than 1e-9 relative, so an argument more than 1e-9 away from ln(6e-3) decides
+// by itself; only arguments inside that band (practically never) evaluate exp().  The fp64 exp was 3/4 of the kernel.
+__device__ __forceinline__ bool gauss_at_least_threshold(double arg) {
+    const double x0 = -5.115995809754082;   // ln(6e-3)
+    if (arg >= x0 + 1e-9) return true;
+    if (arg < x0 - 1e-9) return false;       // also false for NaN, like exp(NaN) >= t
+    return exp(arg) >= 6e-3;
 }
 
-__global__ void outlier_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, const float* __restrict__ color, float* __restrict__ quality,
-                               uint8_t* __restrict__ inl, int mode) {
+// photometric_outlier_detection (calculate_data_costs.cpp:35-129), one thread per face, every fp64 sum in the reference's
+// order (descending view id: SURVEY.md 8a row D) -- the sums decide inlier sets through a threshold, so their order is part
+// of the result.  The loop makes 10 x 12 passes over the face's colours.  LDS = true: the colours and the inlier flags of the
+// block's 64 faces are staged once into LDS, laid out [entry][channel][lane] (conflict free: the lanes of a wave read the same
+// entry of 64 different faces); every later pass is an LDS read.  Straight from HBM (LDS = false; columns longer than the
+// 64 KB of LDS allow) a wave's loads hit 64 different lines per instruction, 120 times over: 97 ms at BASELINE config 3.
+template <bool LDS>
+__global__ void __launch_bounds__(64) outlier_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, const float* __restrict__ color, float* __restrict__ quality,
+                                                     uint8_t* __restrict__ inl_g, int mode, uint32_t kcap) {
+    extern __shared__ float s_dyn[];
     const uint32_t lf = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x;
     if (lf >= nf) return;
     const int64_t p0 = col_ptr[lf], p1 = col_ptr[lf + 1];
     const int64_t n = p1 - p0;
     if (n == 0) return;
-    const double gauss_rejection_threshold = 6e-3, minimal_covariance = 5e-4;
+    float* sc = s_dyn; uint8_t* si = reinterpret_cast<uint8_t*>(s_dyn + (size_t)kcap * 192);
+#define COL(k, a) (LDS ? sc[((k) * 3 + (a)) * 64 + lane] : color[3 * (p0 + (k)) + (a)])
+#define INL(k) (LDS ? si[(k) * 64 + lane] : inl_g[p0 + (k)])
+#define SET_INL(k, v) do { if (LDS) si[(k) * 64 + lane] = (v); else inl_g[p0 + (k)] = (v); } while (0)
+    const double minimal_covariance = 5e-4;
     const float factor = (mode == MVS_OUTLIER_GAUSS_CLAMPING) ? 1.0f : 0.2f;
-    for (int64_t k = p0; k < p1; ++k) inl[k] = 1;
+    for (int64_t k = 0; k < n; ++k) {
+        if (LDS) { sc[(k * 3 + 0) * 64 + lane] = color[3 * (p0 + k)]; sc[(k * 3 + 1) * 64 + lane] = color[3 * (p0 + k) + 1]; sc[(k * 3 + 2) * 64 + lane] = color[3 * (p0 + k) + 2]; }
+        SET_INL(k, 1);
+    }
     int64_t n_in = n;
     double mean[3] = {0, 0, 0}, cov[3][3], ci[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int it = 0; it < 10; ++it) {
         if (n_in < 4) return;
-        for (int a = 0; a < 3; ++a) {
-            double s = 0.0;
-            for (int64_t k = p1 - 1; k >= p0; --k) if (inl[k]) s += (double)color[3 * k + a];
-            mean[a] = s / (double)n_in;
+        // every sum keeps the reference's order (its own sequence of additions); the three means, then the nine covariance
+        // entries, are accumulated side by side in ONE walk each: independent fp64 chains, one read of the colours per walk
+        {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int64_t k = n - 1; k >= 0; --k) {
+                if (!INL(k)) continue;
+                s0 += (double)COL(k, 0); s1 += (double)COL(k, 1); s2 += (double)COL(k, 2);
+            }
+            mean[0] = s0 / (double)n_in; mean[1] = s1 / (double)n_in; mean[2] = s2 / (double)n_in;
         }
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
-            double s = 0.0;
-            for (int64_t k = p1 - 1; k >= p0; --k) if (inl[k]) s += ((double)color[3 * k + a] - mean[a]) * ((double)color[3 * k + b] - mean[b]);
-            cov[a][b] = s / (double)(n_in - 1);
+        {
+            double sc9[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int64_t k = n - 1; k >= 0; --k) {
+                if (!INL(k)) continue;
+                const double d0 = (double)COL(k, 0) - mean[0], d1 = (double)COL(k, 1) - mean[1], d2 = (double)COL(k, 2) - mean[2];
+                sc9[0][0] += d0 * d0; sc9[0][1] += d0 * d1; sc9[0][2] += d0 * d2;
+                sc9[1][0] += d1 * d0; sc9[1][1] += d1 * d1; sc9[1][2] += d1 * d2;
+                sc9[2][0] += d2 * d0; sc9[2][1] += d2 * d1; sc9[2][2] += d2 * d2;
+            }
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] = sc9[a][b] / (double)(n_in - 1);
         }
         double mx = 0.0;
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) mx = (mx < fabs(cov[a][b])) ? fabs(cov[a][b]) : mx;
         if (mx < minimal_covariance) {
-            for (int64_t k = p0; k < p1; ++k) if (!inl[k]) quality[k] = 0.0f;
+            for (int64_t k = 0; k < n; ++k) if (!INL(k)) quality[p0 + k] = 0.0f;
             return;
         }
         Lu3 lu(cov);
         if (!lu.invertible()) return;
         lu.inverse(ci);
         n_in = 0;
-        for (int64_t k = p1 - 1; k >= p0; --k) {
-            const double c[3] = {(double)color[3 * k], (double)color[3 * k + 1], (double)color[3 * k + 2]};
-            const double g = multi_gauss(c, mean, ci);
-            inl[k] = (g >= gauss_rejection_threshold) ? 1 : 0;
-            n_in += inl[k];
+        for (int64_t k = n - 1; k >= 0; --k) {
+            const double c[3] = {(double)COL(k, 0), (double)COL(k, 1), (double)COL(k, 2)};
+            const uint8_t in = gauss_at_least_threshold(multi_gauss_arg(c, mean, ci)) ? 1 : 0;
+            SET_INL(k, in);
+            n_in += in;
         }
     }
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) ci[a][b] *= (double)factor;
-    for (int64_t k = p0; k < p1; ++k) {
-        const double c[3] = {(double)color[3 * k], (double)color[3 * k + 1], (double)color[3 * k + 2]};
-        const double g = multi_gauss(c, mean, ci);
-        if (mode == MVS_OUTLIER_GAUSS_DAMPING) quality[k] = (float)((double)quality[k] * g);
-        else if (g < gauss_rejection_threshold) quality[k] = 0.0f;
+    for (int64_t k = 0; k < n; ++k) {
+        const double c[3] = {(double)COL(k, 0), (double)COL(k, 1), (double)COL(k, 2)};
+        if (mode == MVS_OUTLIER_GAUSS_DAMPING) quality[p0 + k] = (float)((double)quality[p0 + k] * multi_gauss(c, mean, ci));
+        else if (!gauss_at_least_threshold(multi_gauss_arg(c, mean, ci))) quality[p0 + k] = 0.0f;
     }
+#undef COL
+#undef INL
+#undef SET_INL
+}
+__global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, v[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 
 // remove quality == 0 entries (calculate_data_costs.cpp:268-270)
@@ -524,6 +569,10 @@ static uint32_t read_u32(mvs_ctx* ctx, const uint32_t* d) {
     MVS_HIP(hipStreamSynchronize(ctx->stream));
     return h;
 }
+
+// outlier detection over a pre-CSR: LDS-staged when the longest column fits (counts: per-face lengths on the device, or null
+// with the longest column given in kmax_known)
+static void launch_outlier(mvs_ctx* ctx, const uint32_t* ptr, const uint32_t* counts, uint32_t kmax_known, uint32_t nf, const float* col, float* q, uint8_t* inl, int mode);
 
 // (re)compute per-view derived images and upload the view table
 static void upload_views_and_prepare(mvs_ctx* ctx, bool need_gmi) {
@@ -684,9 +733,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         hipLaunchKernelGGL(csr_write_kernel<true>, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
                            ctx->pq.p, ctx->pcol.p, V, nf, fwords, ctx->pre_ptr.p, ctx->pre_view.p, ctx->pre_q.p, ctx->pre_col.p);
         MVS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(outlier_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, ctx->pre_ptr.p, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p,
-                           st->outlier_removal);
-        MVS_LAUNCH_CHECK();
+        launch_outlier(ctx, ctx->pre_ptr.p, ctx->face_cnt.p /* still the per-face counts of csr_count_kernel */, 0u, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p, st->outlier_removal);
         hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf + 256) / 256), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
         MVS_LAUNCH_CHECK();
         ctx->csr_ptr.ensure((size_t)nf + 2);
@@ -799,8 +846,8 @@ void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t*
     if (outl && n) {
         ctx->pre_col.ensure(3 * ((size_t)n + 1)); ctx->pre_inl.ensure((size_t)n + 1);
         MVS_HIP(hipMemcpyAsync(ctx->pre_col.p, h_col_rev, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(outlier_kernel, dim3((nf + 63) / 64), dim3(64), 0, s, ctx->pre_ptr.p, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p, st->outlier_removal);
-        MVS_LAUNCH_CHECK();
+        uint32_t kmax_h = 0; for (uint32_t i = 0; i < nf; ++i) kmax_h = std::max(kmax_h, h_ptr[i + 1] - h_ptr[i]);
+        launch_outlier(ctx, ctx->pre_ptr.p, nullptr, kmax_h, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p, st->outlier_removal);
     }
     ctx->face_cnt.ensure((size_t)nf + 2); ctx->csr_ptr.ensure((size_t)nf + 2);
     uint32_t nnz = n;
@@ -827,6 +874,24 @@ void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t*
     MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
     if (nnz) { hipLaunchKernelGGL(max_kernel, dim3(1024), dim3(256), 0, s, ctx->csr_q.p, (size_t)nnz, (uint32_t*)ctx->max_q.p); MVS_LAUNCH_CHECK(); }
     ctx->dc_phase = 1;
+}
+
+static void launch_outlier(mvs_ctx* ctx, const uint32_t* ptr, const uint32_t* counts, uint32_t kmax_known, uint32_t nf, const float* col, float* q, uint8_t* inl, int mode) {
+    hipStream_t s = ctx->stream;
+    if (!nf) return;
+    constexpr uint32_t LDS_PER_ENTRY = 64 * (3 * sizeof(float) + 1);   // 64 faces x (three floats + the inlier flag)
+    uint32_t kmax = kmax_known;
+    if (counts) {
+        ctx->counters.ensure(64);
+        uint32_t* d = reinterpret_cast<uint32_t*>(ctx->counters.p + 48);
+        MVS_HIP(hipMemsetAsync(d, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(max_u32_kernel, dim3(std::min<unsigned>((nf + 255) / 256, 1024u)), dim3(256), 0, s, counts, nf, d); MVS_LAUNCH_CHECK();
+        kmax = read_u32(ctx, d);
+    }
+    const uint64_t lds = (uint64_t)std::max<uint32_t>(kmax, 1u) * LDS_PER_ENTRY;
+    if (lds <= 64u * 1024u) hipLaunchKernelGGL(outlier_kernel<true>, dim3((nf + 63) / 64), dim3(64), (size_t)lds, s, ptr, nf, col, q, inl, mode, std::max<uint32_t>(kmax, 1u));
+    else hipLaunchKernelGGL(outlier_kernel<false>, dim3((nf + 63) / 64), dim3(64), 0, s, ptr, nf, col, q, inl, mode, 0u);
+    MVS_LAUNCH_CHECK();
 }
 
 // phase 2: histogram of the local qualities against the (possibly all-reduced) maximum (:283-286)

@@ -9,6 +9,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# The parity tests compare qualities BIT for bit with the oracle's serial fp64 scan-line sums: every footprint is walked
+# serially unless a test asks for the lane-group sampler explicitly (set_option("info_wave_area", ...)); the default of the
+# library (32 pixels) is what bench.py and test_wave_per_footprint_kernel_against_the_oracle / the BASELINE-config tests run.
+os.environ.setdefault("MVS_INFO_WAVE_AREA", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -761,6 +761,7 @@ def test_config2_equals_the_oracle_entry_for_entry(ctx):
     ICM rounds of the solve (view_selection.cpp:120-132)"""
     s = M.synth.make_scene(**M.synth.CONFIGS[2])
     assert (s.n_faces, s.n_views) == (200000, 50)
+    ctx.set_option("info_wave_area", 32)                       # the library's default sampler configuration, as bench.py runs it
     _load_scene(ctx, s)
     nt = _oracle_threads()
     ref, rst = O.data_costs(s, n_threads=nt)
@@ -772,6 +773,7 @@ def test_config2_equals_the_oracle_entry_for_entry(ctx):
     assert np.float32(st["max_quality"]) == np.float32(rst["max_quality"]) and np.float32(st["percentile"]) == np.float32(rst["percentile"])
     lo, so = O.view_selection(ref, s.adj_ptr, s.adj, n_threads=nt)
     lg, sg = ctx.view_selection(s.adj_ptr, s.adj)
+    ctx.set_option("info_wave_area", 0)
     assert np.array_equal(lo, lg), "labels differ from the oracle at config 2"
     for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters", "unseen"):
         assert so[k] == sg[k], k
@@ -787,6 +789,7 @@ def test_config3_equals_the_oracle_on_labels_and_sampled_columns():
     F = s.n_faces
     assert (F, s.n_views) == (1997120, 200)
     c = M.Context(0)
+    c.set_option("info_wave_area", 32)                         # the library's default sampler configuration, as bench.py runs it
     _load_scene(c, s)
     c.data_costs(M.Settings())
     dc = c.costs_download()
