@@ -186,7 +186,7 @@ def measure_traffic(config, kernel_rx, nnz, timeout_s=420):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic"]
+                   "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-real-like"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:

@@ -326,6 +326,12 @@ mvs_status mvs_ctx_get_subgraphs(mvs_ctx* ctx, uint32_t n_faces, const uint32_t*
                                  const uint32_t* labels, int labels_on_device, uint32_t n_labels, mvs_subgraphs* out,
                                  int out_on_device);
 
+/* Row f4: the undistortion step of from_images_and_camera_files (generate_texture_views.cpp:153-165): dist0 == 0 copies the
+ * image; dist0 != 0 and dist1 != 0 is mve::image::image_undistort_k2k4(image, flen, dist0, dist1); dist0 != 0 and dist1 == 0 is
+ * image_undistort_vsfm(image, flen, dist0).  rgb / out: host arrays of width * height * 3 bytes.  MVE is absent: the two
+ * models are DEFINED in csrc/k_prep.hip (and restated in the oracle) from recollection of mve/image_tools.h. */
+mvs_status mvs_undistort_image(const uint8_t* rgb, int32_t width, int32_t height, float flen, float dist0, float dist1, uint8_t* out);
+
 /* Label-space compression for scenes with hundreds of candidate views per face (BASELINE config 5): keeps, per face, the
  * max_labels entries with the smallest (cost, view id) pairs, in ascending view order; shorter columns are untouched.
  * NOT the reference's model (view_selection.cpp:46-47 keeps every candidate): off unless asked for -- here, or with

@@ -14,6 +14,7 @@ namespace mvs {
 void dc_phase1(mvs_ctx* ctx, const mvs_settings* st);
 void dc_phase2(mvs_ctx* ctx);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
+void undistort_image(mvs_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, double flen, double d0, double d1);
 void dc_prune_labels(mvs_ctx* ctx, uint32_t kmax);
 void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t* h_ptr, const uint16_t* h_view_rev, const float* h_q_rev, const float* h_col_rev, const mvs_settings* st);
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
@@ -429,6 +430,27 @@ mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t 
     if (st == MVS_OK) st = mvs_scene_set_views(ctx, views, n_views, 0);
     if (st == MVS_OK) st = mvs_ctx_data_costs(ctx, settings, stats);
     if (st == MVS_OK) st = mvs_ctx_costs_download(ctx, out, nullptr);
+    mvs_ctx_destroy(ctx);
+    return st;
+}
+
+/* the undistortion step of from_images_and_camera_files (generate_texture_views.cpp:153-165) */
+mvs_status mvs_undistort_image(const uint8_t* rgb, int32_t width, int32_t height, float flen, float dist0, float dist1, uint8_t* out) {
+    if (!rgb || !out || width < 1 || height < 1) return fail(MVS_ERR_INVALID, "bad argument");
+    const size_t bytes = (size_t)width * height * 3;
+    if (dist0 == 0.0f) { memcpy(out, rgb, bytes); return MVS_OK; }        /* :153 -- only a non-zero first coefficient undistorts */
+    if (!(flen > 0.0f)) return fail(MVS_ERR_INVALID, "undistortion needs a positive focal length");
+    mvs_ctx* ctx = nullptr;
+    mvs_status st = mvs_ctx_create(0, &ctx);
+    if (st != MVS_OK) return st;
+    try {
+        DBuf<uint8_t> a, b; a.ensure(bytes + 16); b.ensure(bytes + 16);
+        MVS_HIP(hipMemcpyAsync(a.p, rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+        undistort_image(ctx, a.p, b.p, width, height, (double)flen, (double)dist0, (double)dist1);
+        MVS_HIP(hipMemcpyAsync(out, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+    } catch (const StatusError& e) { st = fail(e.st, e.what()); }
+      catch (const std::exception& e) { st = fail(MVS_ERR_HIP, e.what()); }
     mvs_ctx_destroy(ctx);
     return st;
 }

@@ -287,4 +287,40 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
         MVS_HIP(hipMemcpyAsync(ctx->mask_all.p, out, ctx->mask_off.back() * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
 }
 
+
+// ---- row f4: lens undistortion of a view's image (generate_texture_views.cpp:153-165: mve::image::image_undistort_k2k4 when
+// both coefficients are set, image_undistort_vsfm when only the first is) ----
+// MVE is absent; DEFINED HERE from recollection of mve/image_tools.h (restated independently in oracle/oracle.cpp): every pixel
+// of the UNDISTORTED output looks up its position in the distorted source -- coordinates centred on (w/2, h/2) and normalised
+// by max(w, h), rsq = (fx^2 + fy^2) / flen^2 -- and samples it with Image::linear_at; positions more than half a pixel outside
+// stay black.  k2k4: factor = 1 + rsq k2 + rsq^2 k4.  vsfm (x_u = x_d (1 + k1 r_d^2), to be inverted): 8 Newton steps on
+// k1 r_d^3 + r_d - r_u = 0 in fp64 from r_d = r_u -- only + - * / and sqrt, so the GPU and the CPU agree bit for bit.
+__global__ void __launch_bounds__(256) undistort_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int w, int h, double flen, double d0, double d1) {
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= w || y >= h) return;
+    const double width_half = (double)w / 2.0, height_half = (double)h / 2.0, norm = (double)(w > h ? w : h);
+    double fx = ((double)x - width_half) / norm, fy = ((double)y - height_half) / norm;
+    double factor;
+    if (d1 != 0.0) {
+        const double rsq = (fx * fx + fy * fy) / (flen * flen);
+        factor = 1.0 + rsq * d0 + (rsq * rsq) * d1;
+    } else {
+        const double ru = sqrt(fx * fx + fy * fy) / flen;
+        double rd = ru;
+        for (int it = 0; it < 8; ++it) rd = rd - (((d0 * rd) * rd) * rd + rd - ru) / ((3.0 * d0) * (rd * rd) + 1.0);
+        factor = ru > 0.0 ? rd / ru : 1.0;
+    }
+    fx = (fx * factor) * norm + width_half;
+    fy = (fy * factor) * norm + height_half;
+    uint8_t* o = dst + ((size_t)y * w + x) * 3;
+    if (!(fx >= -0.5 && fx <= (double)w - 0.5 && fy >= -0.5 && fy <= (double)h - 0.5)) { o[0] = o[1] = o[2] = 0; return; }
+    fx = fx < 0.0 ? 0.0 : (fx > (double)w - 1.0 ? (double)w - 1.0 : fx);
+    fy = fy < 0.0 ? 0.0 : (fy > (double)h - 1.0 ? (double)h - 1.0 : fy);
+    for (int c = 0; c < 3; ++c) o[c] = linear_at(src, w, h, 3, (float)fx, (float)fy, c);
+}
+void undistort_image(mvs_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, double flen, double d0, double d1) {
+    hipLaunchKernelGGL(undistort_kernel, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, ctx->stream, d_src, d_dst, w, h, flen, d0, d1);
+    MVS_LAUNCH_CHECK();
+}
+
 }  // namespace mvs

@@ -9,8 +9,8 @@
     mve::geom::load_ply_mesh the texturing needs (apps/texrecon/texrecon.cpp:52-60).
   * image decode stays on the host (PIL), exactly as in the reference it is outside the timed window.
 
-Lens undistortion (generate_texture_views.cpp:139-152, MVE image_undistort_*) is row f4 and not implemented:
-a `.cam` with a non-zero distortion coefficient raises.
+Lens undistortion (generate_texture_views.cpp:153-165, MVE image_undistort_k2k4 / _vsfm; row f4) runs on the GPU
+(mvs_undistort_image) when a `.cam` carries a non-zero first distortion coefficient.
 
 This is harness code (plumbing around the C ABI); the compute runs in libmvs_viewsel.so.
 
@@ -203,10 +203,10 @@ def load_scene(scene_dir, mesh_path=None):
     cams = {"pos": [], "viewdir": [], "K": [], "w2c": [], "width": [], "height": []}
     for cam_path, img_path in list_scene_folder(scene_dir):
         cam = read_cam_file(cam_path)
-        if cam.dist[0] != 0.0:
-            raise NotImplementedError("%s: lens undistortion (generate_texture_views.cpp:139-152) is row f4, not implemented"
-                                      % os.path.basename(cam_path))
         img = load_image_rgb8(img_path)
+        if cam.dist[0] != 0.0:   # generate_texture_views.cpp:153-165: k2k4 when both coefficients are set, else the VisualSFM model
+            from .viewsel import undistort_image
+            img = undistort_image(img, cam.flen, cam.dist[0], cam.dist[1])
         h, w = img.shape[:2]
         arr = camera_arrays(cam, w, h)
         for k in ("pos", "viewdir", "K", "w2c"):

@@ -135,7 +135,7 @@ def load_library():
         "mvs_ctx_mrf_step": [vp, vp], "mvs_ctx_mrf_poll": [vp, u32, C.POINTER(MrfProgress)],
         "mvs_ctx_mrf_icm_gain": [vp, u32, u32], "mvs_ctx_mrf_icm_apply": [vp, u32, u32, vp],
         "mvs_ctx_mrf_labels": [vp, u32, u32, vp, C.POINTER(u32)],
-        "mvs_ctx_prune_labels": [vp, u32],
+        "mvs_ctx_prune_labels": [vp, u32], "mvs_undistort_image": [vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, vp],
         "mvs_postprocess_face_infos": [u32, u32, vp, vp, vp, vp, C.POINTER(Settings), C.POINTER(CCsr), C.POINTER(DcStats)],
         "mvs_comm_unique_id": [vp], "mvs_comm_create_rccl": [i32, i32, i32, vp, C.POINTER(vp)], "mvs_comm_create_local": [i32, C.POINTER(vp)],
         "mvs_comm_destroy": [vp], "mvs_shard_create": [vp, vp, vp, vp, vp, C.POINTER(vp)], "mvs_shard_destroy": [vp],
@@ -420,6 +420,16 @@ def postprocess_face_infos(n_views, info_ptr, view_id, quality, mean_color, sett
     res = DataCosts(F, out.n_views, grab(out.col_ptr, C.c_uint32, F + 1), grab(out.view_id, C.c_uint16, nnz), grab(out.cost, C.c_float, nnz))
     L.mvs_csr_free(C.byref(out))
     return res, _stats_dict(ds)
+
+
+def undistort_image(rgb, flen, dist0, dist1):
+    """the undistortion step of from_images_and_camera_files (generate_texture_views.cpp:153-165) on an (H, W, 3) uint8 image"""
+    L = load_library()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    assert rgb.ndim == 3 and rgb.shape[2] == 3
+    out = np.empty_like(rgb)
+    _check(L, L.mvs_undistort_image(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], float(flen), float(dist0), float(dist1), out.ctypes.data))
+    return out
 
 
 def prepare_mesh(verts, faces):

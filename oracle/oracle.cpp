@@ -784,6 +784,39 @@ void orc_prune_labels(const orc_csr* in, uint32_t kmax, orc_csr* out) {
     }
 }
 
+// Row f4: mve::image::image_undistort_k2k4 / image_undistort_vsfm as generate_texture_views.cpp:153-165 applies them
+// (dist0 != 0: k2k4 if dist1 != 0, else vsfm).  MVE is absent -- DEFINED HERE from recollection of mve/image_tools.h:
+// output pixel (x, y) -> centred, divided by max(w, h); rsq over flen^2; k2k4 factor 1 + rsq k2 + rsq^2 k4; vsfm inverts
+// r_u = r_d (1 + k1 r_d^2) with 8 Newton steps in fp64 from r_d = r_u; source positions beyond half a pixel outside stay
+// black, others are clamped and sampled with linear_at.
+void orc_undistort(const uint8_t* rgb, int w, int h, float flen_f, float dist0, float dist1, uint8_t* out) {
+    const size_t bytes = (size_t)w * h * 3;
+    if (dist0 == 0.0f) { memcpy(out, rgb, bytes); return; }
+    const double flen = flen_f, d0 = dist0, d1 = dist1;
+    const double width_half = (double)w / 2.0, height_half = (double)h / 2.0, norm = (double)std::max(w, h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            double fx = ((double)x - width_half) / norm, fy = ((double)y - height_half) / norm;
+            double factor;
+            if (d1 != 0.0) {
+                const double rsq = (fx * fx + fy * fy) / (flen * flen);
+                factor = 1.0 + rsq * d0 + (rsq * rsq) * d1;
+            } else {
+                const double ru = std::sqrt(fx * fx + fy * fy) / flen;
+                double rd = ru;
+                for (int it = 0; it < 8; ++it) rd = rd - (((d0 * rd) * rd) * rd + rd - ru) / ((3.0 * d0) * (rd * rd) + 1.0);
+                factor = ru > 0.0 ? rd / ru : 1.0;
+            }
+            fx = (fx * factor) * norm + width_half;
+            fy = (fy * factor) * norm + height_half;
+            uint8_t* o = out + ((size_t)y * w + x) * 3;
+            if (!(fx >= -0.5 && fx <= (double)w - 0.5 && fy >= -0.5 && fy <= (double)h - 0.5)) { o[0] = o[1] = o[2] = 0; continue; }
+            fx = std::max(0.0, std::min((double)w - 1.0, fx));
+            fy = std::max(0.0, std::min((double)h - 1.0, fy));
+            for (int c = 0; c < 3; ++c) o[c] = linear_at(rgb, w, h, 3, (float)fx, (float)fy, c);
+        }
+}
+
 void orc_csr_free(orc_csr* c) {
     free(c->col_ptr); free(c->view_id); free(c->cost); free(c->quality);
     memset(c, 0, sizeof(*c));

@@ -92,6 +92,8 @@ int orc_data_costs(const orc_mesh* mesh, const orc_view* views, uint32_t n_views
                    const orc_settings* settings, uint32_t face_begin, uint32_t face_end,
                    int bvh_mode, int n_threads, orc_csr* out, orc_dc_stats* stats);
 void orc_csr_free(orc_csr* csr);
+/* row f4: image_undistort_k2k4 / _vsfm as generate_texture_views.cpp:153-165 picks them (MVE absent: defined in oracle.cpp) */
+void orc_undistort(const uint8_t* rgb, int w, int h, float flen, float dist0, float dist1, uint8_t* out);
 /* label-space compression (option of the product, not of the reference): per face the kmax smallest (cost, view id) entries */
 void orc_prune_labels(const orc_csr* in, uint32_t kmax, orc_csr* out);
 

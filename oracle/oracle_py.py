@@ -168,6 +168,14 @@ def data_costs(scene, data_term="gmi", outlier_removal="none", geometric_visibil
     return res, {f[0]: getattr(stats, f[0]) for f in DcStats._fields_}
 
 
+def undistort(rgb, flen, dist0, dist1):
+    L = load()
+    L.orc_undistort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8); out = np.empty_like(rgb)
+    L.orc_undistort(_ptr(rgb), rgb.shape[1], rgb.shape[0], float(flen), float(dist0), float(dist1), _ptr(out))
+    return out
+
+
 def prune_labels(csr, kmax):
     """label-space compression (orc_prune_labels): per face the kmax entries with the smallest (cost, view id) pairs"""
     L = load()

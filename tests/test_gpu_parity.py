@@ -659,6 +659,31 @@ def test_wave_per_footprint_kernel_against_the_oracle(name, kw):
     c.close()
 
 
+def test_row_f4_undistortion_equals_the_oracle(tmp_path):
+    """row f4: mvs_undistort_image (generate_texture_views.cpp:153-165) bit for bit against the oracle on random images (odd
+    sizes), both lens models, both signs; and through the scene ingest: a .cam with distortion coefficients yields the
+    undistorted image"""
+    from mvs_texturing_amd import ingest
+    rng = np.random.default_rng(3)
+    for (h, w) in ((97, 131), (240, 320)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        for flen, d0, d1 in ((0.9, -0.2, 0.05), (1.3, 0.15, -0.03), (0.8, 0.1, 0.0), (1.1, -0.12, 0.0), (1.0, 0.0, 0.3)):
+            got = M.viewsel.undistort_image(img, flen, d0, d1)
+            assert np.array_equal(got, O.undistort(img, flen, d0, d1)), (h, w, flen, d0, d1)
+    s = get_scene("tiny")
+    d = str(tmp_path / "scene")
+    ingest.save_scene_folder(s, d)
+    cams = sorted(f for f in os.listdir(d) if f.endswith(".cam"))
+    lines = open(os.path.join(d, cams[0])).read().splitlines()
+    vals = lines[1].split()
+    vals[1], vals[2] = "-0.11", "0.02"                               # dist[0], dist[1] (generate_texture_views.cpp:141-146)
+    open(os.path.join(d, cams[0]), "w").write(lines[0] + "\n" + " ".join(vals) + "\n")
+    s2 = ingest.load_scene(d)
+    cam0 = ingest.read_cam_file(os.path.join(d, cams[0]))
+    assert np.array_equal(s2.images[0], O.undistort(s.images[0], cam0.flen, -0.11, 0.02)) and not np.array_equal(s2.images[0], s.images[0])
+    assert np.array_equal(s2.images[1], s.images[1])
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import sys
     import torch

@@ -355,3 +355,33 @@ def test_energy_is_within_a_fraction_of_a_percent_of_the_lp_lower_bound():
         e_icm = O.energy(dc, s.adj_ptr, s.adj, O.icm_baseline(dc, s.adj_ptr, s.adj))[0] / 2.0 ** 32
         assert e_icm - lb > 10 * (st["energy"] - lb) or st["energy"] - lb < 1e-6 * lb, name   # the bound separates a good labeling from a greedy one
 
+
+
+def test_undistortion_models_row_f4():
+    """row f4 (generate_texture_views.cpp:153-165; MVE's image_undistort_k2k4 / _vsfm are absent: DEFINED in oracle.cpp): zero
+    first coefficient = copy; otherwise every output pixel samples the source at the distorted position of an independent fp64
+    restatement (numpy) -- k2k4 factor 1 + rsq k2 + rsq^2 k4; vsfm: the root of k1 r^3 + r - r_u -- checked on an image whose
+    red / green channels ARE the pixel coordinates, so the sampled value reveals the position"""
+    h, w, flen = 96, 128, 0.8
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([xx, yy, (xx + yy) // 2], -1).astype(np.uint8)
+    assert np.array_equal(O.undistort(img, flen, 0.0, 0.5), img)
+    for d0, d1 in ((-0.15, 0.04), (0.1, 0.02), (0.12, 0.0), (-0.1, 0.0)):
+        out = O.undistort(img, flen, d0, d1)
+        fx = (xx - w / 2.0) / max(w, h); fy = (yy - h / 2.0) / max(w, h)
+        if d1 != 0.0:
+            rsq = (fx * fx + fy * fy) / flen ** 2
+            factor = 1.0 + rsq * d0 + rsq * rsq * d1
+        else:
+            ru = np.sqrt(fx * fx + fy * fy) / flen
+            rd = ru.copy()
+            for _ in range(60):
+                rd = rd - (d0 * rd ** 3 + rd - ru) / (3 * d0 * rd ** 2 + 1)
+            assert np.abs(d0 * rd ** 3 + rd - ru).max() < 1e-12
+            factor = np.where(ru > 0, rd / np.maximum(ru, 1e-300), 1.0)
+        sx = fx * factor * max(w, h) + w / 2.0; sy = fy * factor * max(w, h) + h / 2.0
+        inside = (sx >= -0.5) & (sx <= w - 0.5) & (sy >= -0.5) & (sy <= h - 0.5)
+        assert np.array_equal((out == 0).all(axis=2) & ~inside, ~inside)               # outside stays black
+        m = inside & (sx > 1) & (sx < w - 2) & (sy > 1) & (sy < h - 2)
+        assert np.abs(out[..., 0][m] - sx[m]).max() <= 0.51 and np.abs(out[..., 1][m] - sy[m]).max() <= 0.51   # bilinear of a ramp = the position, rounded
+        assert m.mean() > 0.7
