@@ -288,7 +288,7 @@ def main():
     ctx.set_option("profile", 1)
     if max_labels:
         ctx.set_option("max_labels", max_labels)
-    for env, opt in (("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag")):
+    for env, opt in (("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag"), ("MVS_LDS_BVH", "lds_bvh_levels")):
         if os.environ.get(env):   # tuning knobs for experiments
             ctx.set_option(opt, int(os.environ[env]))
     if os.environ.get("MVS_RAY_MODE"):

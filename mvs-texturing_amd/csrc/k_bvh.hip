@@ -488,13 +488,24 @@ __global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const
 // (5-6 of 64 on average), so instead of 64 lanes x 4 triangles the wave tests (candidate, triangle)
 // PAIRS: lane L takes candidate L/4 and triangle L%4 (16 candidates per round).  Rays are parked in
 // LDS once; the candidate list goes through LDS; results return to the owning lanes through a ballot.
-template <bool COUNT, bool XCD>
+// LDSN (mvs_set_option "lds_bvh_levels" > 0): the top levels of the tree (heap order: the first n_lds nodes) are staged in LDS by
+// every block and read from there.  Measured A/B at BASELINE config 3 (profiles/r02_lds_bvh_ab.txt): NOT faster -- a node read
+// from LDS lands in 32 VGPRs of every lane and is consumed as vector operands, whereas the default reads the node with two
+// wide scalar loads into SGPRs (served by the scalar cache, which the top levels never leave) and feeds the fma's scalar
+// operands.  Kept as an option for the record; the default is 0.
+template <bool COUNT, bool XCD, bool LDSN>
 __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
                                                           const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
                                                           unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
-                                                          const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
+                                                          const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters, uint32_t n_lds) {
     __shared__ float4 s_ray[4][64][2];
     __shared__ uint8_t s_src[4][64];
+    extern __shared__ float4 s_top4[];
+    if (LDSN) {
+        for (uint32_t k = threadIdx.x; k < n_lds * 8u; k += 256u) s_top4[k] = reinterpret_cast<const float4*>(bvh.nodes)[k];
+        __syncthreads();
+    }
+    const Node4* s_top = reinterpret_cast<const Node4*>(s_top4);
     // XCD-aware order: hardware block b runs on XCD b % 8 (observed; speed only), so each XCD gets a contiguous
     // eighth of the (view, vertex patch) sequence and with it a compact part of the BVH in its L2
     uint32_t vblk = blockIdx.x;
@@ -527,9 +538,11 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     // from v_mbcnt on the scalar mask.  A ballot of a bare float compare is the compare itself (it writes an SGPR pair).
     unsigned long long actm = __builtin_amdgcn_ballot_w64(active), hitm = 0ull;
     unsigned long long hm0[4] = {0ull, 0ull, 0ull, 0ull};
-    auto visit = [&](const Node4* __restrict__ ndp, unsigned long long (&hm)[4]) -> uint32_t {
+    auto visit = [&](uint32_t nidx, unsigned long long (&hm)[4]) -> uint32_t {
         uint32_t m = 0;
-        const Node4 ndv = *ndp;                // the whole 128-byte line with two wide scalar loads
+        Node4 ndv;
+        if (LDSN && nidx < n_lds) ndv = s_top[nidx];   // wave-uniform branch
+        else ndv = bvh.nodes[nidx];                    // the whole 128-byte line with two wide scalar loads
         const Node4* nd = &ndv;
         const uint32_t nchild = nd->nchild;
 #pragma unroll
@@ -552,8 +565,8 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     unsigned long long hm_tmp[4];
     unsigned long long masks;
     const uint32_t off0 = bvh.level_off[0];   // heap index of the first level-0 node
-    if (level == 0) masks = (unsigned long long)visit(bvh.nodes, hm0);       // node = heap index (root = 0)
-    else masks = (unsigned long long)visit(bvh.nodes, hm_tmp) << (4 * level);
+    if (level == 0) masks = (unsigned long long)visit(0u, hm0);       // node = heap index (root = 0)
+    else masks = (unsigned long long)visit(0u, hm_tmp) << (4 * level);
     if (COUNT) nn++;
     while (true) {
         const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
@@ -595,8 +608,8 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
             }
         } else {
             --level; node = node * 4 + 1 + c;
-            if (level == 0) masks |= (unsigned long long)visit(bvh.nodes + node, hm0);
-            else masks |= (unsigned long long)visit(bvh.nodes + node, hm_tmp) << (4 * level);
+            if (level == 0) masks |= (unsigned long long)visit(node, hm0);
+            else masks |= (unsigned long long)visit(node, hm_tmp) << (4 * level);
             if (COUNT) nn++;
         }
     }
@@ -698,9 +711,19 @@ void trace_rays(mvs_ctx* ctx) {
 #define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
                  vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
     if (ctx->ray_mode == 2) {
-        if (ctx->count_rays) hipLaunchKernelGGL((ray_packet2_kernel<true, false>), RAY_ARGS);
-        else if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet2_kernel<false, true>), RAY_ARGS);
-        else hipLaunchKernelGGL((ray_packet2_kernel<false, false>), RAY_ARGS);
+        // top levels in LDS (option, default off): levels counted from the root; at most what 48 KB hold, never the leaves' parents' level and below
+        uint32_t n_lds = 0;
+        if (ctx->lds_bvh_levels > 0) {
+            const int lv = std::min(std::min(ctx->lds_bvh_levels, 5), (int)ctx->bvh.top);
+            uint32_t cnt = 0, w = 1; for (int l = 0; l < lv; ++l) { cnt += w; w *= 4; }
+            n_lds = cnt;
+        }
+        const size_t lds = (size_t)n_lds * sizeof(Node4);
+        if (ctx->count_rays) hipLaunchKernelGGL((ray_packet2_kernel<true, false, false>), RAY_ARGS, 0u);
+        else if (n_lds) hipLaunchKernelGGL((ray_packet2_kernel<false, true, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p,
+                                           ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p, n_lds);
+        else if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet2_kernel<false, true, false>), RAY_ARGS, 0u);
+        else hipLaunchKernelGGL((ray_packet2_kernel<false, false, false>), RAY_ARGS, 0u);
     } else if (ctx->ray_mode == 1) {
         if (ctx->count_rays) hipLaunchKernelGGL(ray_packet_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_packet_kernel<false>, RAY_ARGS);
     } else {
