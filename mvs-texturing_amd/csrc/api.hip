@@ -214,9 +214,14 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
     for (auto* b : ctx->own_rgb) delete b;
     ctx->own_rgb.clear();
     ctx->h_views.assign(n_views, ViewParams{});
+    // Host images: the caller's buffers are pageable, and a pageable hipMemcpyAsync is staged through the driver's bounce
+    // buffer at ~13 GB/s (1.9 GB of BASELINE config 3: 146 ms).  Pinning the caller's pages in place for the duration of the
+    // call (hipHostRegister) lets the copy engine read them directly; all copies are queued back to back, one wait at the
+    // end.  A buffer that cannot be registered (read-only mapping, limit reached) goes the pageable way.
+    std::vector<void*> registered;
     for (uint32_t j = 0; j < n_views; ++j) {
         const mvs_view& v = views[j];
-        if (v.width < 2 || v.height < 2 || !v.rgb) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image");
+        if (v.width < 2 || v.height < 2 || !v.rgb) { for (void* p : registered) (void)hipHostUnregister(p); throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image"); }
         ViewParams& p = ctx->h_views[j];
         memcpy(p.pos, v.pos, sizeof(p.pos)); memcpy(p.viewdir, v.viewdir, sizeof(p.viewdir));
         memcpy(p.K, v.K, sizeof(p.K)); memcpy(p.w2c, v.w2c, sizeof(p.w2c));
@@ -227,11 +232,15 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
             ctx->own_rgb.push_back(b);
             const size_t bytes = (size_t)v.width * v.height * 3;
             b->ensure(bytes + 16);
+            if (bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(const_cast<uint8_t*>(v.rgb));
+            else (void)hipGetLastError();   // not registered: clear the sticky error, copy from pageable memory
             MVS_HIP(hipMemcpyAsync(b->p, v.rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
             p.rgb = b->p;
         }
     }
-    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    const hipError_t sync_err = hipStreamSynchronize(ctx->stream);
+    for (void* p : registered) (void)hipHostUnregister(p);
+    MVS_HIP(sync_err);
     ctx->n_views = n_views;
     ctx->have_costs = false; ctx->dc_phase = 0;
     MVS_API_END
