@@ -222,9 +222,10 @@ constexpr int MAX_PARTS = 64;
 struct Parts { uint32_t b[MAX_PARTS + 1]; int n; };
 __device__ __forceinline__ int part_of(const Parts& p, uint32_t i) { int q = 0; while (q + 1 < p.n && i >= p.b[q + 1]) ++q; return q; }
 
-// key = peer << 40 | phase << 32 | index: a (peer, phase) chunk is a contiguous key range, ascending in the global directed-edge
-// index / node id -- the order BOTH ends of a pair derive independently
-__device__ __forceinline__ unsigned long long plan_key(int peer, uint32_t phase, uint32_t index) { return ((unsigned long long)peer << 40) | ((unsigned long long)phase << 32) | index; }
+// key = phase << 40 | peer << 32 | index: PHASE-major, so everything a colour phase puts on the wire is one contiguous range
+// of a list (one pack and one unpack launch per phase, whatever the number of neighbours), inside it one contiguous chunk per
+// peer, ascending in the global directed-edge index / node id -- the order BOTH ends of a pair derive independently
+__device__ __forceinline__ unsigned long long plan_key(int peer, uint32_t phase, uint32_t index) { return ((unsigned long long)phase << 40) | ((unsigned long long)peer << 32) | index; }
 
 // One thread per own face: the cut edges around it.  For the in-edge e = (i <- j) with j on another rank q:
 //   RECV  the run of e (K_i bytes at in_off[e] of MY layout), written by q in phase colour[j];
@@ -275,6 +276,11 @@ __global__ void plan_expand_kernel(const unsigned long long* __restrict__ val, c
     const uint32_t off = (uint32_t)(val[k] >> 32), len = (uint32_t)(val[k] & 0xFFFFFFFFull), p = pos[k];
     for (uint32_t t = lane; t < len; t += 64) idx[p + t] = off + t;
 }
+// (phase, peer, id) -> (0, peer, id)
+__global__ void plan_rekey_kernel(unsigned long long* __restrict__ key, uint32_t n) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) key[k] &= 0xFFFFFFFFFFull;
+}
 __global__ void plan_node_kernel(const unsigned long long* __restrict__ key, uint32_t n, uint32_t* __restrict__ node) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) node[k] = (uint32_t)(key[k] & 0xFFFFFFFFull);
@@ -293,6 +299,26 @@ __global__ void pack_words_kernel(const uint32_t* __restrict__ src, const mvs_mr
 __global__ void unpack_words_kernel(uint32_t* __restrict__ dst, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ src) {
     if (st) dst += (size_t)st->w * buf_stride;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[idx[k]] = src[k];
+}
+
+// one launch per phase: the message bytes and the labels of everything this phase sends (all peers) / received
+__global__ void pack_phase_kernel(const uint8_t* __restrict__ msg, const uint32_t* __restrict__ midx, uint64_t nm, uint8_t* __restrict__ mdst,
+                                  const uint32_t* __restrict__ lab, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride,
+                                  const uint32_t* __restrict__ nidx, uint64_t nn, uint32_t* __restrict__ ndst) {
+    lab += (size_t)st->w * buf_stride;              // the current decode buffer
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nm || k < nn; k += (uint64_t)gridDim.x * blockDim.x) {
+        if (k < nm) mdst[k] = msg[midx[k]];
+        if (k < nn) ndst[k] = lab[nidx[k]];
+    }
+}
+__global__ void unpack_phase_kernel(uint8_t* __restrict__ msg, const uint32_t* __restrict__ midx, uint64_t nm, const uint8_t* __restrict__ msrc,
+                                    uint32_t* __restrict__ lab, const mvs_mrf_progress* __restrict__ st, uint32_t buf_stride,
+                                    const uint32_t* __restrict__ nidx, uint64_t nn, const uint32_t* __restrict__ nsrc) {
+    lab += (size_t)st->w * buf_stride;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nm || k < nn; k += (uint64_t)gridDim.x * blockDim.x) {
+        if (k < nm) msg[midx[k]] = msrc[k];
+        if (k < nn) lab[nidx[k]] = nsrc[k];
+    }
 }
 
 // ---- sharded cost table ----
@@ -406,15 +432,14 @@ uint32_t unique_keys(mvs_shard* S, DBuf<unsigned long long>& k, uint32_t n, hipS
     return m;
 }
 // per (phase, peer) offsets of a sorted key list whose records have the given lengths (null: 1 each).  The list is sorted
-// by (peer, phase, index); storage order of the exchange buffers is the same, so a (peer, phase) chunk is contiguous and a
-// peer's chunks over all phases are contiguous as well.
+// by (phase, peer, index) and the exchange buffers use the same order: off[phase * P + peer].
 void segment(const std::vector<unsigned long long>& keys, const std::vector<uint32_t>* lens, int P, uint32_t phases, std::vector<uint64_t>& off, uint64_t& total) {
     off.assign((size_t)P * phases + 1, 0);
     std::vector<uint64_t> cnt((size_t)P * phases, 0);
     for (size_t k = 0; k < keys.size(); ++k) {
-        const int peer = (int)(keys[k] >> 40); const uint32_t ph = (uint32_t)((keys[k] >> 32) & 0xFFu);
+        const uint32_t ph = (uint32_t)(keys[k] >> 40); const int peer = (int)((keys[k] >> 32) & 0xFFu);
         if (peer >= P || ph >= phases) throw HipError("halo plan: key out of range");
-        cnt[(size_t)peer * phases + ph] += lens ? (*lens)[k] : 1u;
+        cnt[(size_t)ph * P + peer] += lens ? (*lens)[k] : 1u;
     }
     for (size_t c = 0; c < cnt.size(); ++c) off[c + 1] = off[c] + cnt[c];
     total = off.back();
@@ -449,10 +474,10 @@ void finish_node_list(mvs_shard* S, mvs_shard::Lists& L, DBuf<unsigned long long
 
 // per-peer byte offsets of one phase's chunk (elem = bytes per element)
 void phase_offsets(const mvs_shard::Lists& L, int P, uint32_t phases, uint32_t ph, uint32_t elem, std::vector<uint64_t>& out) {
-    // chunk (peer, ph) = [off[peer * phases + ph], off[peer * phases + ph + 1]); the comm takes a [P + 1] offset array of
-    // CONTIGUOUS per-peer ranges, so phase chunks are staged contiguously: out[q] = running sum of this phase's chunk sizes
+    // a phase's chunk of a list is contiguous, peer after peer: offsets relative to the start of the phase
     out.assign((size_t)P + 1, 0);
-    for (int q = 0; q < P; ++q) out[q + 1] = out[q] + (L.off[(size_t)q * phases + ph + 1] - L.off[(size_t)q * phases + ph]) * elem;
+    (void)phases;
+    for (int q = 0; q <= P; ++q) out[q] = (L.off[(size_t)ph * P + q] - L.off[(size_t)ph * P]) * elem;
 }
 
 void build_plan(mvs_shard* S) {
@@ -484,6 +509,12 @@ void build_plan(mvs_shard* S) {
     finish_msg_list(S, S->msg_recv, S->k1, S->v1, n[1], s);
     finish_node_list(S, S->node_send, S->k2, ns, S->phases, s);
     finish_node_list(S, S->node_recv, S->k3, nr, S->phases, s);
+    // the same nodes peer-major over all phases (key = peer << 32 | id): the ICM exchanges send one range per peer
+    if (ns) { hipLaunchKernelGGL(plan_rekey_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, S->k2.p, ns); MVS_LAUNCH_CHECK(); }
+    if (nr) { hipLaunchKernelGGL(plan_rekey_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, S->k3.p, nr); MVS_LAUNCH_CHECK(); }
+    sort_pairs(S, S->k2, nullptr, ns, s); sort_pairs(S, S->k3, nullptr, nr, s);
+    finish_node_list(S, S->all_send, S->k2, ns, 1, s);
+    finish_node_list(S, S->all_recv, S->k3, nr, 1, s);
     // the same node lists are contiguous per peer (all phases): the ICM exchanges use them with one range per peer
     S->sbuf_msg.ensure(S->msg_send.total + 64); S->rbuf_msg.ensure(S->msg_recv.total + 64);
     S->sbuf_node.ensure(S->node_send.total + 16); S->rbuf_node.ensure(S->node_recv.total + 16);
@@ -503,33 +534,35 @@ void exchange_phase(mvs_shard* S, uint32_t ph) {
     phase_offsets(S->msg_send, P, C, ph, 1, so_m); phase_offsets(S->msg_recv, P, C, ph, 1, ro_m);
     phase_offsets(S->node_send, P, C, ph, 4, so_n); phase_offsets(S->node_recv, P, C, ph, 4, ro_n);
     if (so_m[P] + ro_m[P] + so_n[P] + ro_n[P] == 0) return;
-    // stage this phase's chunks contiguously, peer after peer
-    for (int q = 0; q < P; ++q) {
-        const uint64_t a = S->msg_send.off[(size_t)q * C + ph], nm = S->msg_send.off[(size_t)q * C + ph + 1] - a;
-        if (nm) { hipLaunchKernelGGL(pack_bytes_kernel, dim3(grid_for(nm)), dim3(256), 0, s, ctx->m_msg_a.p, S->msg_send.idx.p + a, nm, S->sbuf_msg.p + so_m[q]); MVS_LAUNCH_CHECK(); }
-        const uint64_t b = S->node_send.off[(size_t)q * C + ph], nn = S->node_send.off[(size_t)q * C + ph + 1] - b;
-        if (nn) { hipLaunchKernelGGL(pack_words_kernel, dim3(grid_for(nn)), dim3(256), 0, s, ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, S->node_send.idx.p + b, nn, S->sbuf_node.p + so_n[q] / 4); MVS_LAUNCH_CHECK(); }
+    // ONE pack launch (message bytes and labels of the whole phase, all peers), one grouped exchange, ONE unpack launch
+    const uint64_t ms0 = S->msg_send.off[(size_t)ph * P], nms = S->msg_send.off[(size_t)(ph + 1) * P] - ms0;
+    const uint64_t ns0 = S->node_send.off[(size_t)ph * P], nns = S->node_send.off[(size_t)(ph + 1) * P] - ns0;
+    const uint64_t mr0 = S->msg_recv.off[(size_t)ph * P], nmr = S->msg_recv.off[(size_t)(ph + 1) * P] - mr0;
+    const uint64_t nr0 = S->node_recv.off[(size_t)ph * P], nnr = S->node_recv.off[(size_t)(ph + 1) * P] - nr0;
+    if (nms + nns) {
+        hipLaunchKernelGGL(pack_phase_kernel, dim3(grid_for(std::max(nms, nns))), dim3(256), 0, s, ctx->m_msg_a.p, S->msg_send.idx.p + ms0, nms, S->sbuf_msg.p,
+                           ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, S->node_send.idx.p + ns0, nns, S->sbuf_node.p);
+        MVS_LAUNCH_CHECK();
     }
     S->comm->exchange2(S->sbuf_msg.p, so_m.data(), S->rbuf_msg.p, ro_m.data(),
                        (const uint8_t*)S->sbuf_node.p, so_n.data(), (uint8_t*)S->rbuf_node.p, ro_n.data(), s);
-    for (int q = 0; q < P; ++q) {
-        const uint64_t a = S->msg_recv.off[(size_t)q * C + ph], nm = S->msg_recv.off[(size_t)q * C + ph + 1] - a;
-        if (nm) { hipLaunchKernelGGL(unpack_bytes_kernel, dim3(grid_for(nm)), dim3(256), 0, s, ctx->m_msg_a.p, S->msg_recv.idx.p + a, nm, S->rbuf_msg.p + ro_m[q]); MVS_LAUNCH_CHECK(); }
-        const uint64_t b = S->node_recv.off[(size_t)q * C + ph], nn = S->node_recv.off[(size_t)q * C + ph + 1] - b;
-        if (nn) { hipLaunchKernelGGL(unpack_words_kernel, dim3(grid_for(nn)), dim3(256), 0, s, ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, S->node_recv.idx.p + b, nn, S->rbuf_node.p + ro_n[q] / 4); MVS_LAUNCH_CHECK(); }
+    if (nmr + nnr) {
+        hipLaunchKernelGGL(unpack_phase_kernel, dim3(grid_for(std::max(nmr, nnr))), dim3(256), 0, s, ctx->m_msg_a.p, S->msg_recv.idx.p + mr0, nmr, S->rbuf_msg.p,
+                           ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, S->node_recv.idx.p + nr0, nnr, S->rbuf_node.p);
+        MVS_LAUNCH_CHECK();
     }
 }
 // every boundary node's word of `arr` (gains, labels of the best labeling) to the neighbours, halo words back: ICM
 void exchange_nodes(mvs_shard* S, uint32_t* arr) {
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream;
-    const int P = S->P; const uint32_t C = S->phases;
+    const int P = S->P;
     std::vector<uint64_t> so((size_t)P + 1), ro((size_t)P + 1);
-    for (int q = 0; q <= P; ++q) { so[q] = S->node_send.off[(size_t)std::min(q, P) * C] * 4; ro[q] = S->node_recv.off[(size_t)std::min(q, P) * C] * 4; }
+    for (int q = 0; q <= P; ++q) { so[q] = S->all_send.off[q] * 4; ro[q] = S->all_recv.off[q] * 4; }   // peer-major lists over all phases
     if (so[P] + ro[P] == 0) return;
-    const uint64_t ns = S->node_send.total, nr = S->node_recv.total;
-    if (ns) { hipLaunchKernelGGL(pack_words_kernel, dim3(grid_for(ns)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->node_send.idx.p, ns, S->sbuf_node.p); MVS_LAUNCH_CHECK(); }
+    const uint64_t ns = S->all_send.total, nr = S->all_recv.total;
+    if (ns) { hipLaunchKernelGGL(pack_words_kernel, dim3(grid_for(ns)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->all_send.idx.p, ns, S->sbuf_node.p); MVS_LAUNCH_CHECK(); }
     S->comm->exchange((const uint8_t*)S->sbuf_node.p, so.data(), (uint8_t*)S->rbuf_node.p, ro.data(), s);
-    if (nr) { hipLaunchKernelGGL(unpack_words_kernel, dim3(grid_for(nr)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->node_recv.idx.p, nr, S->rbuf_node.p); MVS_LAUNCH_CHECK(); }
+    if (nr) { hipLaunchKernelGGL(unpack_words_kernel, dim3(grid_for(nr)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->all_recv.idx.p, nr, S->rbuf_node.p); MVS_LAUNCH_CHECK(); }
 }
 
 }  // namespace
