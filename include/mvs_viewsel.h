@@ -81,7 +81,7 @@ typedef struct {
  * (view_selection.cpp:84,103-115); mapMAP is replaced by a GPU-resident
  * tree-reweighted max-product solver -- colour-phased Gauss-Seidel sweeps + monotone ICM polish --
  * whose knobs are below.  mvs_mrf_default_params gives the shipped defaults
- * (200 / 20 / 5 / 0.002 / 0.2 / 0.8 / 50). */
+ * (200 / 20 / 5 / 0.002 / 0.2 / 0.8 / 50 / 0). */
 typedef struct {
     int32_t max_sweeps;
     int32_t min_sweeps;
@@ -90,6 +90,9 @@ typedef struct {
     float damping;          /* alpha of m' = (1 - alpha) new + alpha old on ODD sweeps (1st, 3rd, ...); even sweeps are undamped */
     float rho;
     int32_t icm_iters;
+    int32_t region_rounds;  /* > 0: after the ICM polish, up to this many rounds of REGION MOVES (a connected same-label patch takes a
+                               neighbouring patch's label when that lowers the energy; csrc/k_region.hip), each followed by a fresh
+                               polish.  0 = off (default).  Single-context solves only: the sharded path refuses it. */
 } mvs_mrf_params;
 
 typedef struct {
@@ -99,6 +102,8 @@ typedef struct {
     uint32_t sweeps;
     uint32_t icm_iters;
     uint32_t unseen;        /* "faces have not been seen"  view_selection.cpp:129,132 */
+    uint32_t region_rounds; /* rounds of region moves that moved something */
+    uint32_t region_moves;  /* regions relabelled in total */
 } mvs_mrf_stats;
 
 typedef struct {

@@ -22,6 +22,7 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
 void mrf_keep_best(mvs_ctx* ctx);
 void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
+uint32_t mrf_region_round(mvs_ctx* ctx);
 void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
@@ -82,7 +83,7 @@ const char* mvs_status_string(mvs_status s) {
 
 void mvs_mrf_default_params(mvs_mrf_params* p) {
     p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
-    p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50;
+    p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50; p->region_rounds = 0;
 }
 void mvs_default_settings(mvs_settings* s) {  /* settings.h:85-90 */
     s->data_term = MVS_DATA_TERM_GMI; s->outlier_removal = MVS_OUTLIER_NONE; s->geometric_visibility_test = 1;
@@ -410,6 +411,23 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
         if (moved == 0) break;
     }
     S.icm_iters = (uint32_t)it;
+    /* region moves (off by default), each round followed by a fresh polish -- the control flow the oracle defines */
+    for (int r = 0; r < P.region_rounds; ++r) {
+        const uint32_t m = mrf_region_round(ctx);
+        if (m == 0) break;
+        S.region_rounds++; S.region_moves += m;
+        for (it = 0; it < P.icm_iters; ++it) {
+            S.icm_iters++;
+            Prof pr(ctx, "mrf_icm");
+            mrf_icm_gain(ctx, 0, F);
+            mrf_icm_apply(ctx, 0, F);
+            pr.end();
+            uint32_t moved = 0;
+            MVS_HIP(hipMemcpyAsync(&moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            MVS_HIP(hipStreamSynchronize(s));
+            if (moved == 0) break;
+        }
+    }
     mrf_energy(ctx, true, 0, F);
     uint64_t e[2]; read_energy(ctx, e);
     S.energy_fixed = e[0]; S.energy = (double)e[0] / 4294967296.0; S.cut_edges = e[1];

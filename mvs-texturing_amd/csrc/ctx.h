@@ -163,6 +163,10 @@ struct mvs_ctx {
     // ---- row f3: patch components (k_patch.hip) ----
     mvs::DBuf<uint32_t> p_label_ptr, p_comp_ptr, p_comp_faces, p_parent, p_root, p_state, p_flag, p_pos, p_roots, p_roots2, p_rlab, p_rlab2, p_adj_ptr, p_adj, p_labels;
 
+    // ---- region moves (k_region.hip) ----
+    mvs::DBuf<uint32_t> rg_parent, rg_root, rg_size, rg_bestl, rg_lose, rg_flag, rg_pos, rg_cstart, rg_have;
+    mvs::DBuf<unsigned long long> rg_gain, rg_cur, rg_key, rg_key2, rg_ck, rg_sum; mvs::DBuf<long long> rg_cgain; mvs::DBuf<uint2> rg_cut;
+
     // ---- MRF ----
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
     mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; mvs::DBuf<uint32_t> m_rec; uint64_t m_rec_words = 0; bool m_fast = false; int mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;

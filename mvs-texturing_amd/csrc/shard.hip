@@ -726,6 +726,7 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
     MVS_HIP(hipSetDevice(ctx->device));
     mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
+    if (P.region_rounds > 0) throw StatusError(MVS_ERR_UNSUPPORTED, "region moves (region_rounds > 0) are a single-context option");
     const uint32_t nb = S->nb, ne = S->ne;
     set_adjacency(ctx, S->d_adj_ptr, S->d_adj, 1);
     { Prof pr(ctx, "mrf_setup"); mrf_setup(ctx, &P); }

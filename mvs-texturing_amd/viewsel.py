@@ -51,12 +51,13 @@ class CCsr(C.Structure):
 
 class MrfParams(C.Structure):
     _fields_ = [("max_sweeps", C.c_int32), ("min_sweeps", C.c_int32), ("window", C.c_int32),
-                ("min_improvement", C.c_float), ("damping", C.c_float), ("rho", C.c_float), ("icm_iters", C.c_int32)]
+                ("min_improvement", C.c_float), ("damping", C.c_float), ("rho", C.c_float), ("icm_iters", C.c_int32),
+                ("region_rounds", C.c_int32)]
 
 
 class MrfStats(C.Structure):
     _fields_ = [("energy_fixed", C.c_uint64), ("energy", C.c_double), ("cut_edges", C.c_uint64), ("sweeps", C.c_uint32),
-                ("icm_iters", C.c_uint32), ("unseen", C.c_uint32)]
+                ("icm_iters", C.c_uint32), ("unseen", C.c_uint32), ("region_rounds", C.c_uint32), ("region_moves", C.c_uint32)]
 
 
 class MrfProgress(C.Structure):

@@ -1067,6 +1067,76 @@ uint32_t mrf_icm_iter(const Mrf& g, std::vector<uint32_t>& sel, std::vector<floa
     return moved;
 }
 
+// Region moves (option region_rounds; a two-level step in the spirit of mapMAP's multilevel contraction of same-label regions,
+// view_selection.cpp:103-115 use_multilevel -- DEFINED HERE): a REGION = connected component of equally labelled faces over
+// the model's edges, named by its smallest face.  A region may take the label l of a neighbouring region if every one of its
+// faces has l among its candidates; the energy changes by  sum_i (D_i(l) - D_i(l_i))  -  #edges to neighbours labelled l
+// (those edges stop being cut; every other boundary edge stays cut).  All in 32.32 fixed point: exact, order independent.
+// Per region the best candidate (largest gain, ties to the smaller label); a region moves iff its gain is positive and
+// beats the gains of all neighbouring regions (ties to the smaller region id) -- an independent set, so the energy drops by
+// exactly the sum of the gains.  Returns the number of regions that moved.
+uint32_t mrf_region_round(const Mrf& g, std::vector<uint32_t>& sel) {
+    const uint32_t F = g.F;
+    std::vector<uint32_t> lab(F), root(F);
+    for (uint32_t i = 0; i < F; ++i) { lab[i] = g.K(i) ? (uint32_t)g.view_id[g.col_ptr[i] + sel[i]] + 1u : 0u; root[i] = i; }
+    auto find = [&](uint32_t x) { while (root[x] != x) { root[x] = root[root[x]]; x = root[x]; } return x; };
+    for (uint32_t i = 0; i < F; ++i)
+        for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) {
+            const uint32_t j = g.adj[e];
+            if (!g.valid[e] || lab[j] != lab[i]) continue;
+            uint32_t a = find(i), b = find(j);
+            if (a != b) { if (a < b) root[b] = a; else root[a] = b; }      // the smaller id stays the root
+        }
+    for (uint32_t i = 0; i < F; ++i) root[i] = find(i);
+    std::vector<uint64_t> keys;                                            // (region << 16 | label) per directed cut edge
+    for (uint32_t i = 0; i < F; ++i)
+        for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) {
+            const uint32_t j = g.adj[e];
+            if (g.valid[e] && lab[j] != lab[i]) keys.push_back(((uint64_t)root[i] << 16) | lab[j]);
+        }
+    std::sort(keys.begin(), keys.end());
+    std::vector<uint64_t> ck; std::vector<uint32_t> cnt;
+    for (size_t k = 0; k < keys.size(); ++k) { if (k == 0 || keys[k] != keys[k - 1]) { ck.push_back(keys[k]); cnt.push_back(0); } cnt.back()++; }
+    std::vector<uint64_t> cur(F, 0), sum(ck.size(), 0); std::vector<uint32_t> size(F, 0), have(ck.size(), 0);
+    for (uint32_t i = 0; i < F; ++i) {
+        const uint32_t R = root[i], p0 = g.col_ptr[i], K = g.K(i);
+        size[R]++; cur[R] += K ? fix32(g.cost[p0 + sel[i]]) : fix32(1.0f);
+        const size_t c0 = std::lower_bound(ck.begin(), ck.end(), (uint64_t)R << 16) - ck.begin();
+        for (size_t c = c0; c < ck.size() && (ck[c] >> 16) == R; ++c) {
+            const uint16_t v = (uint16_t)((ck[c] & 0xFFFFu) - 1u);
+            const uint16_t* L = g.view_id + p0;
+            const uint16_t* it = std::lower_bound(L, L + K, v);
+            if (it != L + K && *it == v) { have[c]++; sum[c] += fix32(g.cost[p0 + (it - L)]); }
+        }
+    }
+    std::vector<int64_t> gain(F, 0); std::vector<uint32_t> bestl(F, 0);
+    for (size_t c = 0; c < ck.size(); ++c) {
+        const uint32_t R = (uint32_t)(ck[c] >> 16), l = (uint32_t)(ck[c] & 0xFFFFu);
+        if (have[c] != size[R]) continue;
+        const int64_t gn = (int64_t)(cur[R] - sum[c]) + ((int64_t)cnt[c] << 32);
+        if (gn > gain[R] || (gn == gain[R] && gn > 0 && l < bestl[R])) { gain[R] = gn; bestl[R] = l; }   // candidates ascend in l: ties keep the first
+    }
+    std::vector<uint8_t> lose(F, 0);
+    for (uint32_t i = 0; i < F; ++i)
+        for (uint32_t e = g.adj_ptr[i]; e < g.adj_ptr[i + 1]; ++e) {
+            const uint32_t j = g.adj[e];
+            if (!g.valid[e] || lab[j] == lab[i]) continue;
+            const uint32_t R = root[i], S = root[j];
+            if (gain[S] > gain[R] || (gain[S] == gain[R] && S < R)) lose[R] = 1;
+        }
+    uint32_t moved = 0;
+    for (uint32_t i = 0; i < F; ++i) {
+        const uint32_t R = root[i];
+        if (gain[R] <= 0 || lose[R]) continue;
+        const uint32_t p0 = g.col_ptr[i], K = g.K(i);
+        const uint16_t v = (uint16_t)(bestl[R] - 1u);
+        const uint16_t* L = g.view_id + p0;
+        sel[i] = (uint32_t)(std::lower_bound(L, L + K, v) - L);
+        if (i == R) ++moved;
+    }
+    return moved;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1115,7 +1185,7 @@ void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = le
 
 void orc_mrf_default_params(orc_mrf_params* p) {
     p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
-    p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50;
+    p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50; p->region_rounds = 0;
 }
 
 int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint32_t* adj,
@@ -1175,6 +1245,13 @@ int orc_view_selection(const orc_csr* costs, const uint32_t* adj_ptr, const uint
     int it = 0;
     for (; it < P.icm_iters; ++it) if (mrf_icm_iter(g, best_sel, gain, cand, n_threads) == 0) break;
     S.icm_iters = (uint32_t)it;
+    /* region moves (off by default: region_rounds = 0), each round followed by a fresh ICM polish */
+    for (int r = 0; r < P.region_rounds; ++r) {
+        const uint32_t m = mrf_region_round(g, best_sel);
+        if (m == 0) break;
+        S.region_rounds++; S.region_moves += m;
+        for (it = 0; it < P.icm_iters; ++it) { S.icm_iters++; if (mrf_icm_iter(g, best_sel, gain, cand, n_threads) == 0) break; }
+    }
     best_e = mrf_energy_sel(g, best_sel, &best_cuts);
     /* label extraction (view_selection.cpp:120-132) */
     for (uint32_t i = 0; i < g.F; ++i) {

@@ -121,6 +121,7 @@ typedef struct {
     float damping;           /* message damping alpha in [0,1), applied on odd sweeps (1st, 3rd, ...); even sweeps are undamped */
     float rho;               /* edge appearance probability (1 = max-product BP, <1 = tree-reweighted) */
     int32_t icm_iters;       /* monotone ICM polish iterations after decoding */
+    int32_t region_rounds;   /* > 0: up to this many rounds of region moves (+ ICM) after the polish; 0 = off (default) */
 } orc_mrf_params;
 
 typedef struct {
@@ -130,6 +131,7 @@ typedef struct {
     uint32_t sweeps;
     uint32_t icm_iters;
     uint32_t unseen;         /* faces with label 0 (view_selection.cpp:129,132) */
+    uint32_t region_rounds, region_moves;   /* rounds of region moves that moved something, regions moved in total */
     double t_setup, t_solve;
 } orc_mrf_stats;
 

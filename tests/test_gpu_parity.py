@@ -684,6 +684,47 @@ def test_row_f4_undistortion_equals_the_oracle(tmp_path):
     assert np.array_equal(s2.images[1], s.images[1])
 
 
+@pytest.mark.parametrize("name", ["bumpy", "spiky32", "close", "manyviews"])
+def test_region_moves_equal_the_oracle(ctx, name):
+    """option region_rounds (csrc/k_region.hip): after the polish, connected same-label patches take a neighbouring patch's
+    label where that lowers the energy -- components, candidate sums, gains, the independent-set rule and the follow-up ICM
+    are integer work restated from oracle.cpp mrf_region_round: labels, energy, rounds and moves identical, energy never above
+    the plain solve's"""
+    s = get_scene(name)
+    ref, _ = O.data_costs(s)
+    ctx.costs_upload(M.viewsel.DataCosts(ref.n_faces, ref.n_views, ref.col_ptr, ref.view_id, ref.cost))
+    kw = dict(max_sweeps=24, min_sweeps=12) if name == "manyviews" else {}
+    l0, s0 = ctx.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(**kw))
+    lo, so = O.view_selection(ref, s.adj_ptr, s.adj, O.default_mrf_params(region_rounds=6, **kw))
+    lg, sg = ctx.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(region_rounds=6, **kw))
+    assert np.array_equal(lo, lg)
+    for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters", "region_rounds", "region_moves"):
+        assert so[k] == sg[k], k
+    assert sg["energy_fixed"] <= s0["energy_fixed"]
+    e, cuts = O.energy(ref, s.adj_ptr, s.adj, lg)
+    assert e == sg["energy_fixed"] and cuts == sg["cut_edges"]
+
+
+def test_region_moves_at_config2_and_refused_when_sharded():
+    s = M.synth.make_scene(**M.synth.CONFIGS[2])
+    c = M.Context(0); _load_scene(c, s)
+    c.data_costs(M.Settings()); dc = c.costs_download()
+    nt = _oracle_threads()
+    table = O.CsrNp(dc.n_faces, dc.n_views, dc.col_ptr, dc.view_id, dc.cost)
+    lo, so = O.view_selection(table, s.adj_ptr, s.adj, O.default_mrf_params(region_rounds=4), n_threads=nt)
+    lg, sg = c.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(region_rounds=4))
+    assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["region_moves"] == sg["region_moves"] > 0
+    import torch
+    dev = torch.device("cuda:0")
+    comm = M.shard.Comm.local(1)[0]
+    tap, tad = torch.from_numpy(s.adj_ptr.view(np.int32)).to(dev), torch.from_numpy(s.adj.view(np.int32)).to(dev)
+    sh = M.shard.Shard(c, comm, np.array([0, s.n_faces], np.uint32), tap, tad)
+    sh.data_costs(M.Settings())
+    with pytest.raises(M.MvsError, match="single-context"):
+        sh.view_selection(torch.zeros(s.n_faces, dtype=torch.int32, device=dev), M.viewsel.default_mrf_params(region_rounds=2))
+    sh.close(); comm.close(); c.close()
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     import sys
     import torch
