@@ -164,7 +164,7 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> p_label_ptr, p_comp_ptr, p_comp_faces, p_parent, p_root, p_state, p_flag, p_pos, p_roots, p_roots2, p_rlab, p_rlab2, p_adj_ptr, p_adj, p_labels;
 
     // ---- region moves (k_region.hip) ----
-    mvs::DBuf<uint32_t> rg_parent, rg_root, rg_size, rg_bestl, rg_lose, rg_flag, rg_pos, rg_cstart, rg_have;
+    mvs::DBuf<uint32_t> rg_parent, rg_root, rg_size, rg_bestl, rg_lose, rg_flag, rg_pos, rg_cstart, rg_have, rg_cfirst;
     mvs::DBuf<unsigned long long> rg_gain, rg_cur, rg_key, rg_key2, rg_ck, rg_sum; mvs::DBuf<long long> rg_cgain; mvs::DBuf<uint2> rg_cut;
 
     // ---- MRF ----

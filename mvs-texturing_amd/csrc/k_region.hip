@@ -33,9 +33,9 @@ __device__ inline uint32_t uf_find(uint32_t* parent, uint32_t x) {
 __device__ __forceinline__ unsigned long long fix32(float d) { return (unsigned long long)((double)d * 4294967296.0); }
 
 __global__ void rg_init_kernel(uint32_t* __restrict__ parent, unsigned long long* __restrict__ gain, unsigned long long* __restrict__ cur,
-                               uint32_t* __restrict__ size, uint32_t* __restrict__ bestl, uint32_t* __restrict__ lose, uint32_t n) {
+                               uint32_t* __restrict__ size, uint32_t* __restrict__ bestl, uint32_t* __restrict__ lose, uint32_t* __restrict__ cfirst, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { parent[i] = i; gain[i] = 0ull; cur[i] = 0ull; size[i] = 0u; bestl[i] = 0xFFFFFFFFu; lose[i] = 0u; }
+    if (i < n) { parent[i] = i; gain[i] = 0ull; cur[i] = 0ull; size[i] = 0u; bestl[i] = 0xFFFFFFFFu; lose[i] = 0u; cfirst[i] = 0xFFFFFFFFu; }
 }
 // link i with every equally labelled neighbour j < i over a model edge (both labels non-zero)
 __global__ void rg_hook_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const uint32_t* __restrict__ lab, uint32_t* __restrict__ parent, uint32_t n) {
@@ -88,16 +88,20 @@ __global__ void rg_first_kernel(const unsigned long long* __restrict__ key, uint
 }
 // unique candidates: ck[c] = key, cstart[c] = first position of its run (cstart[nC] = n): count = cstart[c + 1] - cstart[c]
 __global__ void rg_unique_kernel(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n, uint32_t nC,
-                                 unsigned long long* __restrict__ ck, uint32_t* __restrict__ cstart) {
+                                 unsigned long long* __restrict__ ck, uint32_t* __restrict__ cstart, uint32_t* __restrict__ cfirst) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n && flag[k]) { ck[pos[k]] = key[k]; cstart[pos[k]] = k; }
+    if (k < n && flag[k]) {
+        ck[pos[k]] = key[k]; cstart[pos[k]] = k;
+        // first candidate of its region (keys are sorted by region, then label): where the region's faces start reading
+        if (k == 0 || (key[k - 1] >> 16) != (key[k] >> 16)) cfirst[(uint32_t)(key[k] >> 16)] = pos[k];
+    }
     if (k == 0) cstart[nC] = n;
 }
 // per face: its region's size and current unary sum, and for every candidate label of its region whether the face has it and
 // at what cost -- aggregated over the lanes of a wave that share the region before anything touches memory
 __global__ void __launch_bounds__(256) rg_accumulate_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                             const uint32_t* __restrict__ sel, const uint32_t* __restrict__ root, uint32_t n,
-                                                            const unsigned long long* __restrict__ ck, uint32_t nC,
+                                                            const unsigned long long* __restrict__ ck, const uint32_t* __restrict__ cfirst, uint32_t nC,
                                                             uint32_t* __restrict__ size, unsigned long long* __restrict__ cur,
                                                             uint32_t* __restrict__ have, unsigned long long* __restrict__ sum) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,20 +121,28 @@ __global__ void __launch_bounds__(256) rg_accumulate_kernel(const uint32_t* __re
         unsigned long long v = in ? mine : 0ull;
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == leader) { atomicAdd(&size[R0], (uint32_t)__popcll(grp)); atomicAdd(&cur[R0], v); }
-        // candidates of the region: the run of keys with region field R0 (wave-uniform loop)
-        uint32_t lo = 0, hi = nC;
-        const unsigned long long kmin = (unsigned long long)R0 << 16;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ck[mid] < kmin) lo = mid + 1; else hi = mid; }
-        for (uint32_t c = lo; c < nC && (uint32_t)(ck[c] >> 16) == R0; ++c) {
-            const uint32_t want = (uint32_t)(ck[c] & 0xFFFFull) - 1u;          // view id of the candidate label
-            unsigned long long f = 0ull; uint32_t h = 0u;
-            if (in) {
-                uint32_t a = 0, b = K;
-                while (a < b) { const uint32_t m = (a + b) >> 1; if ((uint32_t)view_id[p0 + m] < want) a = m + 1; else b = m; }
-                if (a < K && (uint32_t)view_id[p0 + a] == want) { h = 1u; f = fix32(cost[p0 + a]); }
+        // candidates of the region: the run of keys with region field R0, from cfirst[R0]; 64 keys per round trip (lane k
+        // holds key k of the chunk, broadcast with a shuffle), wave-uniform loop
+        const uint32_t lo = cfirst[R0];
+        if (lo == 0xFFFFFFFFu) continue;
+        for (uint32_t base = lo; base < nC; base += 64) {
+            const unsigned long long mykey = (base + lane < nC) ? ck[base + lane] : ~0ull;
+            bool more = true;
+            for (int k = 0; k < 64; ++k) {
+                const unsigned long long key = __shfl(mykey, k, 64);
+                if ((uint32_t)(key >> 16) != R0) { more = false; break; }     // wave-uniform (~0 never matches: regions are < 2^32 - 1)
+                const uint32_t c = base + (uint32_t)k;
+                const uint32_t want = (uint32_t)(key & 0xFFFFull) - 1u;       // view id of the candidate label
+                unsigned long long f = 0ull; uint32_t h = 0u;
+                if (in) {
+                    uint32_t a = 0, b = K;
+                    while (a < b) { const uint32_t m = (a + b) >> 1; if ((uint32_t)view_id[p0 + m] < want) a = m + 1; else b = m; }
+                    if (a < K && (uint32_t)view_id[p0 + a] == want) { h = 1u; f = fix32(cost[p0 + a]); }
+                }
+                for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); h += __shfl_xor(h, o, 64); }
+                if (lane == leader && h) { atomicAdd(&have[c], h); atomicAdd(&sum[c], f); }
             }
-            for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); h += __shfl_xor(h, o, 64); }
-            if (lane == leader && h) { atomicAdd(&have[c], h); atomicAdd(&sum[c], f); }
+            if (!more) break;
         }
     }
 }
@@ -193,9 +205,9 @@ uint32_t mrf_region_round(mvs_ctx* ctx) {
     Prof pr(ctx, "mrf_region");
     const unsigned nb = (F + 255) / 256;
     ctx->rg_parent.ensure((size_t)F + 2); ctx->rg_root.ensure((size_t)F + 2); ctx->rg_gain.ensure((size_t)F + 2); ctx->rg_cur.ensure((size_t)F + 2);
-    ctx->rg_size.ensure((size_t)F + 2); ctx->rg_bestl.ensure((size_t)F + 2); ctx->rg_lose.ensure((size_t)F + 2);
+    ctx->rg_size.ensure((size_t)F + 2); ctx->rg_bestl.ensure((size_t)F + 2); ctx->rg_lose.ensure((size_t)F + 2); ctx->rg_cfirst.ensure((size_t)F + 2);
     ctx->rg_flag.ensure((size_t)E + 2); ctx->rg_pos.ensure((size_t)E + 2);
-    hipLaunchKernelGGL(rg_init_kernel, dim3(nb), dim3(256), 0, s, ctx->rg_parent.p, ctx->rg_gain.p, ctx->rg_cur.p, ctx->rg_size.p, ctx->rg_bestl.p, ctx->rg_lose.p, F); MVS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rg_init_kernel, dim3(nb), dim3(256), 0, s, ctx->rg_parent.p, ctx->rg_gain.p, ctx->rg_cur.p, ctx->rg_size.p, ctx->rg_bestl.p, ctx->rg_lose.p, ctx->rg_cfirst.p, F); MVS_LAUNCH_CHECK();
     hipLaunchKernelGGL(rg_hook_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, ctx->b_lab, ctx->rg_parent.p, F); MVS_LAUNCH_CHECK();
     hipLaunchKernelGGL(rg_flatten_kernel, dim3(nb), dim3(256), 0, s, ctx->rg_parent.p, ctx->rg_root.p, F); MVS_LAUNCH_CHECK();
     hipLaunchKernelGGL(rg_cut_flag_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, ctx->b_lab, F, E, ctx->rg_flag.p); MVS_LAUNCH_CHECK();
@@ -214,10 +226,10 @@ uint32_t mrf_region_round(mvs_ctx* ctx) {
     exclusive_scan_u32(ctx, ctx->rg_flag.p, ctx->rg_pos.p, (size_t)n_cut + 1, nullptr);
     const uint32_t nC = read_u32(ctx, ctx->rg_pos.p + n_cut);
     ctx->rg_ck.ensure((size_t)nC + 2); ctx->rg_cstart.ensure((size_t)nC + 2); ctx->rg_have.ensure((size_t)nC + 2); ctx->rg_sum.ensure((size_t)nC + 2); ctx->rg_cgain.ensure((size_t)nC + 2);
-    hipLaunchKernelGGL(rg_unique_kernel, dim3((n_cut + 255) / 256), dim3(256), 0, s, ctx->rg_key2.p, ctx->rg_flag.p, ctx->rg_pos.p, n_cut, nC, ctx->rg_ck.p, ctx->rg_cstart.p); MVS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rg_unique_kernel, dim3((n_cut + 255) / 256), dim3(256), 0, s, ctx->rg_key2.p, ctx->rg_flag.p, ctx->rg_pos.p, n_cut, nC, ctx->rg_ck.p, ctx->rg_cstart.p, ctx->rg_cfirst.p); MVS_LAUNCH_CHECK();
     MVS_HIP(hipMemsetAsync(ctx->rg_have.p, 0, ((size_t)nC + 1) * sizeof(uint32_t), s));
     MVS_HIP(hipMemsetAsync(ctx->rg_sum.p, 0, ((size_t)nC + 1) * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(rg_accumulate_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->b_sel, ctx->rg_root.p, F, ctx->rg_ck.p, nC,
+    hipLaunchKernelGGL(rg_accumulate_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->b_sel, ctx->rg_root.p, F, ctx->rg_ck.p, ctx->rg_cfirst.p, nC,
                        ctx->rg_size.p, ctx->rg_cur.p, ctx->rg_have.p, ctx->rg_sum.p); MVS_LAUNCH_CHECK();
     const unsigned cb = (nC + 255) / 256;
     hipLaunchKernelGGL(rg_gain_kernel, dim3(cb), dim3(256), 0, s, ctx->rg_ck.p, ctx->rg_cstart.p, nC, ctx->rg_size.p, ctx->rg_cur.p, ctx->rg_have.p, ctx->rg_sum.p, ctx->rg_cgain.p, ctx->rg_gain.p); MVS_LAUNCH_CHECK();
