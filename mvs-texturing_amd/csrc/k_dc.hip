@@ -61,9 +61,21 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     uint32_t cnt[4] = {0, 0, 0, 0};
+    // Clear cases of the first cull (calculate_data_costs.cpp:183-185: the face looks away from the view, or lies behind it)
+    // are decided without the two normalisations (2 sqrt + 6 correctly rounded divisions per pair, half of all pairs): with
+    // d = view_pos - centre exactly as cull_pair forms it, the reference's viewing_angle = dot(d / |d|, n) evaluated in
+    // fp32 differs from dot(d, n) / |d| by at most 6 * 2^-24 * A / |d|, A = sum |d_k n_k|, and the unnormalised fp32 dot from
+    // its exact value by 3 * 2^-24 * A: dot(d, n) < -4e-6 * A therefore implies viewing_angle < 0 -- with an eightfold margin.
+    // Likewise for dot(viewdir, -d).  Everything else takes cull_pair unchanged; the reason code (1) is the same.
+    const V3 centre = ((v1 + v2) + v3) / 3.0f;
     if (wave_ok) {
         for (uint32_t j = j0; j < j1; ++j) {
-            const int reason = act ? cull_pair(views[j], v1, v2, v3, nrm, cos_limit) : -1;
+            const ViewParams& vw = views[j];
+            const V3 d = V3{vw.pos[0], vw.pos[1], vw.pos[2]} - centre;
+            const float un = (d.x * nrm.x + d.y * nrm.y) + d.z * nrm.z, an = (fabsf(d.x * nrm.x) + fabsf(d.y * nrm.y)) + fabsf(d.z * nrm.z);
+            const float uv = (d.x * vw.viewdir[0] + d.y * vw.viewdir[1]) + d.z * vw.viewdir[2], av = (fabsf(d.x * vw.viewdir[0]) + fabsf(d.y * vw.viewdir[1])) + fabsf(d.z * vw.viewdir[2]);
+            const bool clear_back = (un < -4e-6f * an) || (uv > 4e-6f * av);      // dot(viewdir, centre - pos) = -uv < 0
+            const int reason = act ? (clear_back ? 1 : cull_pair(vw, v1, v2, v3, nrm, cos_limit)) : -1;
             if (STATS) { cnt[0] += reason == 1; cnt[1] += reason == 2; cnt[2] += reason == 3; cnt[3] += reason == 0; }
             const unsigned long long b = __ballot(reason == 0);
             if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
