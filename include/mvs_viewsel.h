@@ -119,6 +119,8 @@ typedef struct {
     uint64_t rays;              /* (vertex, view) rays traced -- each distinct ray once */
     uint64_t ray_nodes;         /* BVH nodes fetched  (only with mvs_set_option("count_rays", 1)) */
     uint64_t ray_tris;          /* triangles tested   (idem) */
+    uint64_t ray_packets;         /* 64-ray packets traced (ray_mode 3 with "stats") */
+    uint64_t ray_packets_generic; /* ... of which with mixed / degenerate direction signs: the unspecialised slab test */
     float max_quality;          /* :278-281 */
     float percentile;           /* :288 */
 } mvs_dc_stats;
@@ -199,7 +201,8 @@ mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
 /* integer options: "stats" (0/1: fill the cull-reason counters of mvs_dc_stats; default 0), "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1),
  * "ray_mode" (0 = one BVH traversal per ray, 1 = one shared traversal per 64-ray wave, 2 = shared traversal with
- * (ray, triangle) work redistribution at the leaves; identical results), "mrf_lag" (sweeps the host queues ahead of
+ * (ray, triangle) work redistribution at the leaves, 3 = 2 with the packed, direction-sign-specialised slab test -- the default;
+ * identical results), "mrf_lag" (sweeps the host queues ahead of
  * the energy reports it reads, default 1, 0 = wait for every sweep; identical results), tuning knobs "mrf_xcd",
  * "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd" */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);

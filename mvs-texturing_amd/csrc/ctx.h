@@ -54,10 +54,12 @@ struct DBuf {
 
 // ---- implicit 4-ary BVH over Hilbert-sorted triangles (k_bvh.hip) ----
 struct alignas(128) Node4 {
-    float lo[3][4];
-    float hi[3][4];
+    float b[4][6];            // child c: lo.x lo.y lo.z hi.x hi.y hi.z -- child-major, so that (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z) are
+                              // the aligned SGPR pairs of three v_pk_fma_f32 per child; absent children are far-away points
     uint32_t nchild;
     uint32_t pad_[7];
+    __host__ __device__ float lo(int a, int c) const { return b[c][a]; }
+    __host__ __device__ float hi(int a, int c) const { return b[c][3 + a]; }
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be one 128-byte line");
 
@@ -105,7 +107,7 @@ struct mvs_ctx {
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
-    int ray_mode = 2;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution
+    int ray_mode = 3;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution, 3 = 2 with the packed, sign-specialised slab test
     int lds_bvh_levels = 0;
     int info_wave_area = 32;   // footprints (sampled ones) above this many pixels go to the wave-per-footprint kernel (k_dc.hip wave_info_kernel); 0 = every footprint serial = bit-exact with the reference's fp64 scan order
     uint32_t dc_stats_deferred = 0;

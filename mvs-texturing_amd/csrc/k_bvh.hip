@@ -267,7 +267,7 @@ __global__ void build_level0_kernel(const float4* __restrict__ tris, uint32_t n_
             // ray_tri accepts only hit points inside (triangle box + pad): 4*pad keeps the slab test conservative
             for (int a = 0; a < 3; ++a) { lo[a] -= 4.0f * pad; hi[a] += 4.0f * pad; nlo[a] = fminf(nlo[a], lo[a]); nhi[a] = fmaxf(nhi[a], hi[a]); }
         }
-        for (int a = 0; a < 3; ++a) { nd.lo[a][c] = lo[a]; nd.hi[a][c] = hi[a]; }
+        for (int a = 0; a < 3; ++a) { nd.b[c][a] = lo[a]; nd.b[c][3 + a] = hi[a]; }
     }
     nd.nchild = nchild;
     for (int k = 0; k < 7; ++k) nd.pad_[k] = 0;
@@ -292,7 +292,7 @@ __global__ void build_level_kernel(const float* __restrict__ child_box, uint32_t
                 nlo[a] = fminf(nlo[a], lo[a]); nhi[a] = fmaxf(nhi[a], hi[a]);
             }
         }
-        for (int a = 0; a < 3; ++a) { nd.lo[a][c] = lo[a]; nd.hi[a][c] = hi[a]; }
+        for (int a = 0; a < 3; ++a) { nd.b[c][a] = lo[a]; nd.b[c][3 + a] = hi[a]; }
     }
     nd.nchild = nchild;
     for (int k = 0; k < 7; ++k) nd.pad_[k] = 0;
@@ -330,14 +330,14 @@ __device__ __forceinline__ bool box_hit(float lox, float loy, float loz, float h
 __device__ __forceinline__ uint32_t node_hits(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1) {
     // 6 x 16-byte loads of one 128-byte line
     const float4* p = reinterpret_cast<const float4*>(nd);
-    const float4 lx = p[0], ly = p[1], lz = p[2], hx = p[3], hy = p[4], hz = p[5];
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
     const uint32_t nchild = nd->nchild;
     const V3 oi = o;
     uint32_t m = 0;
-    if (box_hit(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, inv, oi, t0, t1)) m |= 1u;
-    if (box_hit(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, inv, oi, t0, t1)) m |= 2u;
-    if (box_hit(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, inv, oi, t0, t1)) m |= 4u;
-    if (box_hit(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, inv, oi, t0, t1)) m |= 8u;
+    if (box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oi, t0, t1)) m |= 1u;
+    if (box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oi, t0, t1)) m |= 2u;
+    if (box_hit(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, inv, oi, t0, t1)) m |= 4u;
+    if (box_hit(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, inv, oi, t0, t1)) m |= 8u;
     return m & ((1u << nchild) - 1u);
 }
 
@@ -420,7 +420,7 @@ __device__ __forceinline__ uint32_t node_hits_uniform(const Node4* __restrict__ 
     const V3 oi = o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const bool h = box_hit(nd->lo[0][c], nd->lo[1][c], nd->lo[2][c], nd->hi[0][c], nd->hi[1][c], nd->hi[2][c], inv, oi, t0, t1);
+        const bool h = box_hit(nd->lo(0, c), nd->lo(1, c), nd->lo(2, c), nd->hi(0, c), nd->hi(1, c), nd->hi(2, c), inv, oi, t0, t1);
         if (__ballot(active && h) != 0ull) m |= 1u << c;
     }
     return m & ((1u << nchild) - 1u);
@@ -530,7 +530,6 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
     uint32_t nn = 0, nt = 0;
     int level = bvh.top;
-    uint32_t node = 0;
     // The kernel is VALU bound (SQ_ACTIVE_INST_VALU = 98 % of the SIMD cycles at C3), so everything that is the same for
     // the whole wave lives in SGPRs: the set of live rays (actm) and of occluded rays (hitm) are 64-bit scalars, the four
     // per-child hit ballots of a node ARE the per-lane hit bits (bit L = lane L; hm0: those of the current level-0 node,
@@ -551,11 +550,11 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
             // 24 VALU operations per child.  Its absolute error, ulp(o * inv) <= 6e-8 |o| |inv|, is 400 times smaller than
             // the margin the boxes carry for exactly this purpose (a hit point lies >= 3 pad = 3e-5 max|coord| inside its leaf
             // box, i.e. 3 pad |inv| inside the slab), so the test stays conservative; inf - inf = NaN drops the axis (fmin/fmax).
-            float ta = __builtin_fmaf(nd->lo[0][c], inv.x, -oi.x), tb = __builtin_fmaf(nd->hi[0][c], inv.x, -oi.x);
+            float ta = __builtin_fmaf(nd->lo(0, c), inv.x, -oi.x), tb = __builtin_fmaf(nd->hi(0, c), inv.x, -oi.x);
             float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-            ta = __builtin_fmaf(nd->lo[1][c], inv.y, -oi.y); tb = __builtin_fmaf(nd->hi[1][c], inv.y, -oi.y);
+            ta = __builtin_fmaf(nd->lo(1, c), inv.y, -oi.y); tb = __builtin_fmaf(nd->hi(1, c), inv.y, -oi.y);
             tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            ta = __builtin_fmaf(nd->lo[2][c], inv.z, -oi.z); tb = __builtin_fmaf(nd->hi[2][c], inv.z, -oi.z);
+            ta = __builtin_fmaf(nd->lo(2, c), inv.z, -oi.z); tb = __builtin_fmaf(nd->hi(2, c), inv.z, -oi.z);
             tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
             hm[c] = __builtin_amdgcn_ballot_w64(tn <= tf) & actm;
             if (hm[c] != 0ull) m |= 1u << c;
@@ -565,14 +564,15 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
     unsigned long long hm_tmp[4];
     unsigned long long masks;
     const uint32_t off0 = bvh.level_off[0];   // heap index of the first level-0 node
-    if (level == 0) masks = (unsigned long long)visit(0u, hm0);       // node = heap index (root = 0)
-    else masks = (unsigned long long)visit(0u, hm_tmp) << (4 * level);
+    uint32_t node = 1;   // heap index, root = 1 (see build_bvh)
+    if (level == 0) masks = (unsigned long long)visit(1u, hm0);
+    else masks = (unsigned long long)visit(1u, hm_tmp) << (4 * level);
     if (COUNT) nn++;
     while (true) {
         const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
         if (m == 0) {
             if (level == bvh.top) break;
-            ++level; node = (node - 1u) >> 2;
+            ++level; node >>= 2;
             continue;
         }
         const int c = __builtin_ctz(m);
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
                 if (actm == 0ull) break;
             }
         } else {
-            --level; node = node * 4 + 1 + c;
+            --level; node = node * 4 + c;
             if (level == 0) masks |= (unsigned long long)visit(node, hm0);
             else masks |= (unsigned long long)visit(node, hm_tmp) << (4 * level);
             if (COUNT) nn++;
@@ -617,6 +617,184 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
         occl[(size_t)j * vwords + vw] = hitm;
         if (COUNT) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
     }
+}
+
+
+// ---- packet traversal, round 3 (ray_mode 3, the default) ----
+// The same shared traversal, leaf redistribution and predicate as ray_packet2_kernel -- identical booleans -- with the
+// instruction count of a node visit cut by more than half (the kernel is issue bound on BOTH the vector and the scalar port):
+//  * slab test with packed math: a child's six bounds are three aligned SGPR pairs, so the six t = bound * inv - o * inv
+//    are three v_pk_fma_f32 (full rate with a scalar-pair operand on gfx950: scripts/probe/pk_probe.hip);
+//  * direction-sign specialisation: all rays of a packet go from one surface patch to one camera, so nearly always every
+//    live lane has the same sign of d on each axis.  Then near / far planes are known statically -- near_x is lo.x if
+//    d.x > 0 else hi.x -- and min / max per axis disappear: tn = max(max3(near), t0), tf = min(min3(far), t1), 5 instead of
+//    13 instructions per child after the fma's.  fma is monotone in the bound for a fixed finite multiplier, so
+//    min(t_lo, t_hi) IS t_near bit for bit: the hit masks equal the generic test's.  Packets with mixed signs, zero or
+//    tiny direction components (|1/d| >= 1e30 or non-finite) take the generic variant OCT = 8, which is the round-2 test;
+//  * no per-level climbing: the pending-children nibbles of all levels sit in one 64-bit mask, s_ff1 finds the deepest
+//    pending child, the ancestor's position in its level is a shift (heap order: node = (4^depth - 1) / 3 + position);
+//  * a level-0 node's leaves are processed right after its visit, from the hit ballots still in registers -- nothing
+//    per-node is carried around the loop (round 2 copied four 64-bit masks through every iteration);
+//  * absent children are far-away points (build kernels), so the child-count mask is not needed.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// m = 2 m + (mask != 0): shifts the "some live ray enters child c" bit into the child mask with two scalar instructions
+__device__ __forceinline__ uint32_t shift_in_nonzero(uint32_t m, unsigned long long mask) {
+    asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(m) : "s"(mask) : "scc");
+    return m;
+}
+__device__ __forceinline__ unsigned long long clear_bit(unsigned long long x, uint32_t bit) {
+    asm("s_bitset0_b64 %0, %1" : "+s"(x) : "s"(bit));
+    return x;
+}
+
+template <int OCT>
+__device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4 (*s_ray)[2], uint8_t* s_src, const int lane, const float pad,
+                                                 const V3 inv, const V3 oi, const float t0, float t1,
+                                                 unsigned long long& actm) {   // in: live rays; out: live rays never occluded
+    constexpr bool SX = (OCT & 1) != 0, SY = (OCT & 2) != 0, SZ = (OCT & 4) != 0, GEN = OCT >= 8;
+    const f2 I0 = {inv.x, inv.y}, I1 = {inv.z, inv.x}, I2 = {inv.y, inv.z};
+    const f2 O0 = {-oi.x, -oi.y}, O1 = {-oi.z, -oi.x}, O2 = {-oi.y, -oi.z};
+    const Node4* __restrict__ nodes = bvh.nodes;
+    // A lane that is not live (never needed, or already occluded) gets the empty interval t1 = -1 < 0 <= t0: it enters no
+    // box, so the hit ballots need no masking.
+    t1 = __builtin_amdgcn_inverse_ballot_w64(actm) ? t1 : -1.0f;
+    unsigned long long hm0 = 0ull, hm1 = 0ull, hm2 = 0ull, hm3 = 0ull;   // separate scalars, never an indexed array (that would live in scratch)
+    auto visit = [&](uint32_t h) -> uint32_t {   // h wave-uniform: the 96 bytes of bounds arrive with two wide scalar loads
+        const Node4 nd = *reinterpret_cast<const Node4*>(reinterpret_cast<const char*>(nodes) + (h << 7));   // 32-bit byte offset (build_bvh bounds h): base + offset addressing
+        uint32_t m = 0;
+#pragma unroll
+        for (int c = 3; c >= 0; --c) {
+            const f2 P0 = {nd.b[c][0], nd.b[c][1]}, P1 = {nd.b[c][2], nd.b[c][3]}, P2 = {nd.b[c][4], nd.b[c][5]};
+            const f2 R0 = __builtin_elementwise_fma(P0, I0, O0);   // t(lo.x), t(lo.y)
+            const f2 R1 = __builtin_elementwise_fma(P1, I1, O1);   // t(lo.z), t(hi.x)
+            const f2 R2 = __builtin_elementwise_fma(P2, I2, O2);   // t(hi.y), t(hi.z)
+            float tn, tf;
+            if (GEN) {   // the round-2 sequence (fmin / fmax drop the NaN of inf - inf)
+                tn = fmaxf(t0, fminf(R0.x, R1.y)); tf = fminf(t1, fmaxf(R0.x, R1.y));
+                tn = fmaxf(tn, fminf(R0.y, R2.x)); tf = fminf(tf, fmaxf(R0.y, R2.x));
+                tn = fmaxf(tn, fminf(R1.x, R2.y)); tf = fminf(tf, fmaxf(R1.x, R2.y));
+            } else {
+                const float nx = SX ? R1.y : R0.x, fx = SX ? R0.x : R1.y;
+                const float ny = SY ? R2.x : R0.y, fy = SY ? R0.y : R2.x;
+                const float nz = SZ ? R2.y : R1.x, fz = SZ ? R1.x : R2.y;
+                tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), t0);
+                tf = fminf(fminf(fminf(fx, fy), fz), t1);
+            }
+            const unsigned long long hb = __builtin_amdgcn_ballot_w64(tn <= tf);
+            if (c == 0) hm0 = hb; else if (c == 1) hm1 = hb; else if (c == 2) hm2 = hb; else hm3 = hb;
+            m = shift_in_nonzero(m, hb);
+        }
+        return m;
+    };
+    // the leaves (children c of the level-0 node h0, c in m) whose boxes some live ray enters; stops when no ray is left (actm == 0)
+    auto leaves = [&](uint32_t h0, uint32_t m) {
+        const uint32_t leaf0 = (h0 - bvh.level_off[0]) * 4u;
+        while (m != 0u) {
+            const uint32_t c = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            // three scalar selects; the empty asm keeps the compiler from turning the chain into an indexed table in scratch
+            unsigned long long hsel = (c == 1u) ? hm1 : hm0;
+            asm("" : "+s"(hsel));
+            hsel = (c == 2u) ? hm2 : hsel;
+            asm("" : "+s"(hsel));
+            hsel = (c == 3u) ? hm3 : hsel;
+            const unsigned long long cb = hsel & actm;          // rays that are still live and enter this leaf's box
+            if (cb != 0ull) {
+                const bool cand = __builtin_amdgcn_inverse_ballot_w64(cb);
+                const int n = __builtin_popcountll(cb);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+                if (cand) s_src[rank] = (uint8_t)lane;
+                const float4* __restrict__ tp = bvh.tris + TRI_F4 * (size_t)((leaf0 + c) * LEAF_T + ((uint32_t)lane & (LEAF_T - 1u)));
+                const float4 A = tp[0], E1 = tp[1], E2 = tp[2], H = tp[3];
+                unsigned long long hitm = 0ull;
+                for (int base = 0; base < n; base += LEAF_SLOTS) {
+                    const int q = base + lane / (int)LEAF_T;     // slots >= n hold lane numbers of earlier lists (or the initial ones): harmless work, masked below
+                    const int sl = (int)s_src[q];
+                    const float4 r0 = s_ray[sl][0], r1 = s_ray[sl][1];
+                    Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
+                    const bool h = tri_hit(A, E1, E2, H, rr) && q < n;
+                    const unsigned long long hb = __builtin_amdgcn_ballot_w64(h);
+                    if (hb != 0ull) {   // wave-uniform and rare: the owner of slot (rank - base) reads its LEAF_T result bits
+                        const bool mine = cand && rank >= base && rank < base + LEAF_SLOTS &&
+                                          ((hb >> ((int)LEAF_T * (rank - base))) & ((1ull << LEAF_T) - 1ull)) != 0ull;
+                        hitm |= __builtin_amdgcn_ballot_w64(mine);
+                    }
+                }
+                if (hitm != 0ull) {
+                    actm &= ~hitm;
+                    t1 = __builtin_amdgcn_inverse_ballot_w64(actm) ? t1 : -1.0f;
+                    if (actm == 0ull) m = 0u;
+                }
+            }
+        }
+    };
+    const uint32_t top = (uint32_t)bvh.top;
+    uint32_t m = visit(1u);
+    if (top == 0u) { leaves(1u, m); return; }
+    unsigned long long masks = (unsigned long long)m << (4u * top);   // nibble L: hit children not yet visited of the current ancestor on level L
+    uint32_t level = top, h = 1u;                                     // current node: heap index h on `level`
+    if (masks == 0ull) return;
+    const char* __restrict__ nbase = reinterpret_cast<const char*>(nodes);
+    (void)nbase;
+    do {
+        const uint32_t idx = (uint32_t)__builtin_ctzll(masks);        // deepest level first = depth first
+        masks = clear_bit(masks, idx);
+        const uint32_t lv = idx >> 2;
+        const uint32_t ch = ((h >> (2u * (lv - level))) << 2) | (idx & 3u);   // the ancestor on level lv, then its child
+        m = visit(ch);
+        if (lv != 1u) { masks |= (unsigned long long)m << (4u * (lv - 1u)); h = ch; level = lv - 1u; }
+        else { h = ch >> 2; level = 1u; leaves(ch, m); masks = (actm == 0ull) ? 0ull : masks; }
+    } while (masks != 0ull);
+}
+
+template <bool XCD>
+__global__ void __launch_bounds__(256) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
+                                                          const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
+                                                          unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
+                                                          const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
+    __shared__ float4 s_ray[4][64][2];
+    __shared__ uint8_t s_src[4][80];   // candidate lists; a round reads up to LEAF_SLOTS - 1 slots past the list
+    uint32_t vblk = blockIdx.x;   // XCD-aware order, see ray_packet2_kernel
+    if (XCD && (gridDim.x & 7u) == 0u) vblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint64_t wave = ((uint64_t)vblk * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wave >= (uint64_t)vwords * n_views) return;
+    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);
+    const unsigned long long word = need[(size_t)j * vwords + vw];
+    if (word == 0ull) return;  // occl is pre-zeroed
+    const uint32_t s = vw * 64 + lane;
+    const bool active = ((word >> lane) & 1ull) && s < n_verts;
+    const uint32_t v = vperm[s < n_verts ? s : 0];
+    const ViewParams& vp = views[j];
+    const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
+    const float pad = pad_from_box(scene_box);
+    const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad);
+    s_ray[wv][lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmin);
+    s_ray[wv][lane][1] = make_float4(r.d.x, r.d.y, r.d.z, r.tmax);
+    s_src[wv][lane] = (uint8_t)lane; if (lane < 16) s_src[wv][64 + lane] = (uint8_t)lane;
+    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+    const V3 oi = {r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z};
+    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
+    const unsigned long long actm = __builtin_amdgcn_ballot_w64(active);
+    unsigned long long live = actm;
+    // direction-sign octant of the packet over its live lanes; 8 = mixed / degenerate
+    const float big = 1e30f;
+    const unsigned long long okm = __builtin_amdgcn_ballot_w64(fabsf(inv.x) < big && fabsf(inv.y) < big && fabsf(inv.z) < big) & actm;
+    const unsigned long long nxm = __builtin_amdgcn_ballot_w64(inv.x < 0.0f) & actm, nym = __builtin_amdgcn_ballot_w64(inv.y < 0.0f) & actm,
+                             nzm = __builtin_amdgcn_ballot_w64(inv.z < 0.0f) & actm;
+    int oct = 8;
+    if (okm == actm && (nxm == 0ull || nxm == actm) && (nym == 0ull || nym == actm) && (nzm == 0ull || nzm == actm))
+        oct = (nxm ? 1 : 0) | (nym ? 2 : 0) | (nzm ? 4 : 0);
+    if (counters && lane == 0) { atomicAdd(&counters[10], 1ull); if (oct == 8) atomicAdd(&counters[11], 1ull); }   // diagnostics ("stats" option)
+#define MVS_P3(O) packet3_traverse<O>(bvh, s_ray[wv], s_src[wv], lane, pad, inv, oi, t0, t1, live)
+    switch (oct) {
+        case 0: MVS_P3(0); break; case 1: MVS_P3(1); break; case 2: MVS_P3(2); break; case 3: MVS_P3(3); break;
+        case 4: MVS_P3(4); break; case 5: MVS_P3(5); break; case 6: MVS_P3(6); break; case 7: MVS_P3(7); break;
+        default: MVS_P3(8); break;
+    }
+#undef MVS_P3
+    if (lane == 0) occl[(size_t)j * vwords + vw] = actm & ~live;
 }
 
 }  // namespace
@@ -667,17 +845,17 @@ void build_bvh(mvs_ctx* ctx) {
         cnt = (cnt + 3) / 4; ++L;
     }
     b.top = L; b.n_leaves = n_leaves;
-    // Levels are stored in 4-ary HEAP order: level L starts at (4^(top-L) - 1) / 3, so node i of a level is heap index
-    // h = level_off + i, its children are 4h + 1 + c and its parent is (h - 1) >> 2 -- the traversal needs no per-level
-    // table (a dynamically indexed kernel argument = one dependent scalar load per node visit).  Slots between the end
-    // of a level and the next level's start are never touched (a node's child count bounds its children).
+    // Levels are stored in 4-ary heap order with the root at index 1: level L (depth d = top - L) starts at 4^d, the node at
+    // position p of its level is h = 4^d + p, its children are 4h + c, its ancestor k levels up is h >> 2k -- the traversal
+    // needs no per-level table and climbs any number of levels with one shift.  Slots between the end of a level and the
+    // next level's start are never touched (absent children are far-away points no ray reaches).
     for (int l = 0; l <= L; ++l) {
         uint64_t p4 = 1; for (int k = 0; k < L - l; ++k) p4 *= 4;
-        if ((p4 - 1) / 3 + b.level_cnt[l] > 0x7FFFFFFFull) throw HipError("BVH too large");
-        b.level_off[l] = (uint32_t)((p4 - 1) / 3);
+        if (p4 + b.level_cnt[l] > 0x01FFFFFFull) throw HipError("BVH too large");   // node byte offsets stay below 2^32
+        b.level_off[l] = (uint32_t)p4;
     }
     const uint32_t off = b.level_off[0] + b.level_cnt[0];
-    ctx->bvh_nodes.ensure(off);
+    ctx->bvh_nodes.ensure(std::max<uint32_t>(off, 256u));   // 256: the LDS option stages a fixed prefix
     ctx->lvl_box_a.ensure(6 * (size_t)b.level_cnt[0]); ctx->lvl_box_b.ensure(6 * (size_t)std::max<uint32_t>(b.level_cnt[L > 0 ? 1 : 0], 1u));
     hipLaunchKernelGGL(build_level0_kernel, dim3((b.level_cnt[0] + 127) / 128), dim3(128), 0, s, ctx->bvh_tris.p, F, n_leaves, b.level_cnt[0], box, ctx->bvh_nodes.p + b.level_off[0], ctx->lvl_box_a.p);
     MVS_LAUNCH_CHECK();
@@ -706,17 +884,23 @@ void trace_rays(mvs_ctx* ctx) {
     const uint32_t vwords = (ctx->n_verts + 63) / 64;
     const uint64_t waves = (uint64_t)vwords * ctx->n_views;
     uint64_t blocks = (waves + 3) / 4;
-    if (ctx->ray_mode == 2) blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
+    if (ctx->ray_mode >= 2) blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
     if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
 #define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
                  vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
-    if (ctx->ray_mode == 2) {
+    if (ctx->ray_mode == 3 && !ctx->count_rays && ctx->lds_bvh_levels <= 0) {
+        blocks = (blocks + 7) & ~7ull;
+        if (ctx->ray_xcd) hipLaunchKernelGGL(ray_packet3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p,
+                                             ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->stats ? ctx->counters.p : nullptr);
+        else hipLaunchKernelGGL(ray_packet3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p,
+                                ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->stats ? ctx->counters.p : nullptr);
+    } else if (ctx->ray_mode >= 2) {
         // top levels in LDS (option, default off): levels counted from the root; at most what 48 KB hold, never the leaves' parents' level and below
         uint32_t n_lds = 0;
         if (ctx->lds_bvh_levels > 0) {
-            const int lv = std::min(std::min(ctx->lds_bvh_levels, 5), (int)ctx->bvh.top);
-            uint32_t cnt = 0, w = 1; for (int l = 0; l < lv; ++l) { cnt += w; w *= 4; }
-            n_lds = cnt;
+            const int lv = std::min(std::min(ctx->lds_bvh_levels, 4), (int)ctx->bvh.top);
+            uint32_t w = 1; for (int l = 1; l < lv; ++l) w *= 4;
+            n_lds = 2 * w;   // heap indices below 2 * 4^(lv - 1) hold the lv levels from the root (root = index 1)
         }
         const size_t lds = (size_t)n_lds * sizeof(Node4);
         if (ctx->count_rays) hipLaunchKernelGGL((ray_packet2_kernel<true, false, false>), RAY_ARGS, 0u);

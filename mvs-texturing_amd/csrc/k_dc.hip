@@ -944,6 +944,7 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     mvs_dc_stats& S = ctx->dc_stats;
     S.cull_backface = hc[C_BACK]; S.cull_angle = hc[C_ANGLE]; S.cull_outside = hc[C_OUTSIDE]; S.cull_occluded = hc[C_OCCL];
     S.cull_zero_quality = hc[C_ZEROQ]; S.rays = hc[C_RAYS]; S.ray_nodes = hc[C_RNODES]; S.ray_tris = hc[C_RTRIS];
+    S.ray_packets = hc[10]; S.ray_packets_generic = hc[11];
     S.nnz = ctx->csr_nnz; S.max_quality = mq; S.percentile = pc;
     ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p; ctx->csr_q_valid = true;
     ctx->have_costs = true; ctx->dc_phase = 3;

@@ -198,9 +198,10 @@ def test_many_views_outlier_removal_against_live_oracle(ctx, kw):
     assert st["nnz_pre"] == rst["nnz_pre"] and np.float32(st["percentile"]) == np.float32(rst["percentile"])
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_ray_traversal_modes_give_the_oracle_booleans(mode):
-    """per-ray traversal, shared (packet) traversal and packet + leaf work redistribution: same occlusion decisions"""
+    """per-ray traversal, shared (packet) traversal, packet + leaf work redistribution, and the latter with the packed,
+    direction-sign-specialised slab test (the default): same occlusion decisions"""
     s = get_scene("bumpy")
     ref, rst = O.data_costs(s)
     c = M.Context(0); c.set_option("stats", 1); c.set_option("ray_mode", mode)
@@ -209,6 +210,8 @@ def test_ray_traversal_modes_give_the_oracle_booleans(mode):
     got = c.costs_download()
     assert st["cull_occluded"] == rst["cull_occluded"] > 0
     assert np.array_equal(got.col_ptr, ref.col_ptr) and np.array_equal(got.cost.view(np.uint32), ref.cost.view(np.uint32))
+    if mode == 3:   # both slab tests ran: sign-specialised packets and packets with mixed direction signs
+        assert 0 < st["ray_packets_generic"] < st["ray_packets"]
     c.close()
 
 
@@ -220,7 +223,7 @@ def test_heavy_occlusion_against_live_oracle(name):
     s = get_scene(name)
     ref, rst = O.data_costs(s)
     assert rst["cull_occluded"] * 3 > ref.nnz
-    for mode in (2, 0):
+    for mode in (3, 2, 0):
         c = M.Context(0); c.set_option("stats", 1); c.set_option("ray_mode", mode)
         _load_scene(c, s)
         st = c.data_costs(M.Settings())
