@@ -63,7 +63,7 @@ def build_host(force=False):
     for src, lib in (("scene_synth.cpp", "libmvs_synth.so"), ("dmath_host.cpp", "libmvs_dmath_host.so")):
         s = os.path.join(CSRC, src); l = os.path.join(CSRC, lib)
         if force or _newer(l, [s, os.path.join(CSRC, "dmath.h")]):
-            subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-std=c++17",
+            subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-std=c++17",
                                    "-shared", "-o", l, s])
         out.append(l)
     return out

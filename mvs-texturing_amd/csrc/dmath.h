@@ -133,10 +133,11 @@ MVS_HD float scene_pad(const float lo[3], const float hi[3]) {
 // Ray / triangle any-hit test on a triangle given as {a, e1 = b - a, e2 = c - a}.
 // rayint (acc::BVHTree, calculate_data_costs.cpp:23,144,209) is not available and
 // the reference only uses the boolean, so the predicate is defined by this
-// library (DESIGN.md "Occlusion rays"): Moeller-Trumbore in fp32 with this exact
-// operation order, in the division-free form -- with s = sign(det) the scaled
-// barycentrics s u det, s v det and the scaled distance s t det are compared with
-// 0, |det|, tmin |det| and tmax |det| (no slack anywhere) -- and, for a ray that
+// library (DESIGN.md "Occlusion rays"): Moeller-Trumbore in fp32 with an exact
+// operation order (fused multiply-adds, listed at ray_tri_boxed), in the division-free
+// form -- with s = sign(det) the scaled barycentrics s u det, s v det and the scaled
+// distance s t det are compared with 0, |det|, tmin |det| and tmax |det| (no slack
+// anywhere) -- and, for a ray that
 // passes all of these, t = (t det) / det (correctly rounded) AND the computed hit
 // point o + t d must lie inside the triangle's bounding box grown by `pad`.
 // The last clause makes box culling provably conservative (a grazing ray whose
@@ -153,22 +154,39 @@ MVS_HD void tri_pad_box(V3 a, V3 e1, V3 e2, float pad, V3* lo, V3* hi) {
     lo->y = fminf(a.y, fminf(b.y, c.y)) - pad; hi->y = fmaxf(a.y, fmaxf(b.y, c.y)) + pad;
     lo->z = fminf(a.z, fminf(b.z, c.z)) - pad; hi->z = fmaxf(a.z, fmaxf(b.z, c.z)) + pad;
 }
-MVS_HD bool ray_tri_boxed(const Ray& r, V3 a, V3 e1, V3 e2, V3 lo, V3 hi) {
-    const V3 pv = cross(r.d, e2);
-    const float det = dot(e1, pv);
-    const V3 tv = r.o - a;
-    const float un = dot(tv, pv);                 // u det
-    const V3 qv = cross(tv, e1);
-    const float vn = dot(r.d, qv);                // v det
-    const float tn = dot(e2, qv);                 // t det
-    const bool neg = det < 0.0f;
-    const float ad = neg ? -det : det;
-    const float us = neg ? -un : un, vs = neg ? -vn : vn, ts = neg ? -tn : tn;
-    const bool pre = ad > 0.0f && us >= 0.0f && vs >= 0.0f && us + vs <= ad && ts >= r.tmin * ad && ts <= r.tmax * ad;
-    if (!pre) return false;
+// The arithmetic of the predicate, fixed to the operation (IEEE fma = one rounding; the lane-pair kernel evaluates two
+// triangles per lane with the packed forms of exactly these operations):
+//   cross(a, b) = { fma(a.y, b.z, -(a.z b.y)), fma(a.z, b.x, -(a.x b.z)), fma(a.x, b.y, -(a.y b.x)) }
+//   dot(a, b)   = fma(a.z, b.z, fma(a.y, b.y, a.x b.x))
+//   pv = cross(d, e2), det = dot(e1, pv), tv = o - a, un = dot(tv, pv), qv = cross(tv, e1), vn = dot(d, qv), tn = dot(e2, qv)
+//   sg = det < 0 ? -1 : 1; ad = det sg, us = un sg, vs = vn sg, ts = tn sg           (exact)
+//   w = ad - (us + vs), g1 = fma(-tmin, ad, ts), g2 = fma(tmax, ad, -ts)
+//   pre = ad > 0 && min(min(min(min(us, vs), w), g1), g2) >= 0                         (min = fminf)
+//   hit = pre && the point o + (tn / det) d lies in [lo, hi]                           (division correctly rounded)
+MVS_HD float dot_fma(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+MVS_HD V3 cross_fma(V3 a, V3 b) {
+    return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
+}
+MVS_HD bool ray_tri_point_in_box(const Ray& r, float tn, float det, V3 lo, V3 hi) {
     const float t = tn / det;
     const float hx = r.o.x + t * r.d.x, hy = r.o.y + t * r.d.y, hz = r.o.z + t * r.d.z;
     return hx >= lo.x && hx <= hi.x && hy >= lo.y && hy <= hi.y && hz >= lo.z && hz <= hi.z;
+}
+MVS_HD bool ray_tri_boxed(const Ray& r, V3 a, V3 e1, V3 e2, V3 lo, V3 hi) {
+    const V3 pv = cross_fma(r.d, e2);
+    const float det = dot_fma(e1, pv);
+    const V3 tv = r.o - a;
+    const float un = dot_fma(tv, pv);             // u det
+    const V3 qv = cross_fma(tv, e1);
+    const float vn = dot_fma(r.d, qv);            // v det
+    const float tn = dot_fma(e2, qv);             // t det
+    const float sg = det < 0.0f ? -1.0f : 1.0f;
+    const float ad = det * sg, us = un * sg, vs = vn * sg, ts = tn * sg;
+    const float w = ad - (us + vs);
+    const float g1 = __builtin_fmaf(-r.tmin, ad, ts), g2 = __builtin_fmaf(r.tmax, ad, -ts);
+    const bool pre = (ad > 0.0f) & (fminf(fminf(fminf(fminf(us, vs), w), g1), g2) >= 0.0f);   // & not &&: branch free
+    if (!pre) return false;
+    return ray_tri_point_in_box(r, tn, det, lo, hi);
 }
 MVS_HD bool ray_tri(const Ray& r, V3 a, V3 e1, V3 e2) {
     V3 lo, hi;

@@ -243,27 +243,38 @@ inline void rgb_to_ycbcr(float* v) {
 // Ray / triangle any-hit.  rayint's acc::BVHTree is absent and
 // the reference uses it purely as a boolean (calculate_data_costs.cpp:201-212),
 // so the test is DEFINED HERE: Moeller-Trumbore in fp32 on {a, e1 = b-a, e2 = c-a},
-// fixed operation order, division free: with s = sign(det) the scaled barycentrics
-// s u det, s v det and the scaled distance s t det are compared with 0, |det|,
-// tmin |det|, tmax |det| (no epsilon anywhere); a ray passing all of these gets
+// fixed operation order with fused multiply-adds (cross = fma(a.y, b.z, -(a.z b.y)) ...,
+// dot = fma(a.z, b.z, fma(a.y, b.y, a.x b.x))), division free: with s = sign(det) the
+// scaled barycentrics s u det, s v det and the scaled distance s t det are compared with
+// 0, |det|, tmin |det|, tmax |det| (as ad - (us + vs) >= 0, fma(-tmin, ad, ts) >= 0,
+// fma(tmax, ad, -ts) >= 0 -- no epsilon anywhere); a ray passing all of these gets
 // t = (t det) / det and its computed hit point must lie in the triangle's bounding
 // box grown by `pad` (pad = 1e-5 * max(scene extent, max |coordinate|) + 1e-30).
 // The last clause makes any conservative box culling exact: the result is the OR
 // over ALL triangles, i.e. independent of the acceleration structure (tests compare
 // the BVH with the brute-force loop).
+inline float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+inline V3 fcross(V3 a, V3 b) {
+    V3 r;
+    r.x = __builtin_fmaf(a.y, b.z, -(a.z * b.y));
+    r.y = __builtin_fmaf(a.z, b.x, -(a.x * b.z));
+    r.z = __builtin_fmaf(a.x, b.y, -(a.y * b.x));
+    return r;
+}
 inline bool ray_tri(V3 orig, V3 dir, float tmin, float tmax, float pad, V3 a, V3 b, V3 c) {
     const V3 e1 = b - a, e2 = c - a;
-    const V3 pv = cross(dir, e2);
-    const float det = dot(e1, pv);
+    const V3 pv = fcross(dir, e2);
+    const float det = fdot(e1, pv);
     const V3 tv = orig - a;
-    const float un = dot(tv, pv);
-    const V3 qv = cross(tv, e1);
-    const float vn = dot(dir, qv);
-    const float tn = dot(e2, qv);
-    const bool neg = det < 0.0f;
-    const float ad = neg ? -det : det;
-    const float us = neg ? -un : un, vs = neg ? -vn : vn, ts = neg ? -tn : tn;
-    if (!(ad > 0.0f && us >= 0.0f && vs >= 0.0f && us + vs <= ad && ts >= tmin * ad && ts <= tmax * ad)) return false;
+    const float un = fdot(tv, pv);
+    const V3 qv = fcross(tv, e1);
+    const float vn = fdot(dir, qv);
+    const float tn = fdot(e2, qv);
+    const float sg = det < 0.0f ? -1.0f : 1.0f;
+    const float ad = det * sg, us = un * sg, vs = vn * sg, ts = tn * sg;
+    const float w = ad - (us + vs);
+    const float g1 = __builtin_fmaf(-tmin, ad, ts), g2 = __builtin_fmaf(tmax, ad, -ts);
+    if (!(ad > 0.0f && std::fmin(std::fmin(std::fmin(std::fmin(us, vs), w), g1), g2) >= 0.0f)) return false;
     const float t = tn / det;
     const V3 bb = a + e1, cc = a + e2;
     const float h[3] = {orig.x + t * dir.x, orig.y + t * dir.y, orig.z + t * dir.z};

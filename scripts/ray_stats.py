@@ -10,5 +10,8 @@ for mode in (2, 1):
     c.set_option("ray_mode", mode)
     st = c.data_costs(M.Settings())
     print("mode", mode, {k: st[k] for k in ("pairs", "cull_backface", "cull_angle", "cull_outside", "cull_occluded", "nnz", "rays", "ray_nodes", "ray_tris")})
+c.set_option("count_rays", 0); c.set_option("ray_mode", 3)
+st = c.data_costs(M.Settings())
+print("mode 3 packets", st["ray_packets"], "generic", st["ray_packets_generic"])
 nv = len(s.verts); words = (nv + 63) // 64 * s.n_views
 print("verts", nv, "vertex words x views", words, "rays per word if all needed", 64)
