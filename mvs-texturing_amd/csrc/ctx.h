@@ -141,6 +141,7 @@ struct mvs_ctx {
     // ---- data costs work buffers ----
     mvs::DBuf<unsigned long long> pass_bits, need_bits, occl_bits, surv_bits;
     mvs::DBuf<uint32_t> pass_base;      // exclusive scan of popc(pass words)
+    mvs::DBuf<uint32_t> pass_face;      // [view chunk][face] the chunk's pass bits of a face (face-major copy read by need_kernel)
     mvs::DBuf<unsigned long long> defer_bits; mvs::DBuf<uint32_t> defer_base; mvs::DBuf<uint2> defer_list;   // large footprints left to the wave-per-footprint kernel
     mvs::DBuf<float> pq;                // quality per passing pair
     mvs::DBuf<float> pcol;              // 3 floats per passing pair (outlier removal only)

@@ -51,13 +51,15 @@ __device__ __forceinline__ void block_count_add(const uint32_t (&c)[N], unsigned
 template <bool STATS>
 __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const float* __restrict__ normals,
                                                    const ViewParams* __restrict__ views, uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords,
-                                                   float cos_limit, unsigned long long* __restrict__ pass, unsigned long long* __restrict__ counters) {
+                                                   float cos_limit, unsigned long long* __restrict__ pass, uint32_t* __restrict__ pass_face /* may be null */,
+                                                   unsigned long long* __restrict__ counters) {
     const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
     const bool wave_ok = (lf >> 6) < fwords;  // false: whole wave beyond the face range
     const bool act = lf < nf;
     const size_t f = (size_t)fb + (act ? lf : 0);
     const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const V3 v1 = ld3(verts, i0), v2 = ld3(verts, i1), v3 = ld3(verts, i2), nrm = ld3(normals, f);
+    uint32_t mine = 0;   // this face's pass bits for the views of the chunk (face-major copy for need_kernel: one load instead of 32)
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     uint32_t cnt[4] = {0, 0, 0, 0};
@@ -79,7 +81,9 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
             if (STATS) { cnt[0] += reason == 1; cnt[1] += reason == 2; cnt[2] += reason == 3; cnt[3] += reason == 0; }
             const unsigned long long b = __ballot(reason == 0);
             if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
+            mine |= (reason == 0 ? 1u : 0u) << (j - j0);
         }
+        if (pass_face) pass_face[(size_t)blockIdx.y * ((size_t)fwords * 64u) + lf] = mine;
     }
     if (STATS) { const int slot[4] = {C_BACK, C_ANGLE, C_OUTSIDE, C_PASS}; block_count_add<4>(cnt, counters, slot); }
 }
@@ -89,8 +93,8 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
 template <bool STATS>
 __global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, const uint32_t* __restrict__ vperm, uint32_t n_verts, uint32_t n_views,
                                                    uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
-                                                   const unsigned long long* __restrict__ pass, unsigned long long* __restrict__ need,
-                                                   unsigned long long* __restrict__ counters) {
+                                                   const uint32_t* __restrict__ pass_face /* [view chunk][face]: the chunk's pass bits of a face (cull_kernel) */,
+                                                   unsigned long long* __restrict__ need, unsigned long long* __restrict__ counters) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if ((v >> 6) >= vwords) return;  // whole wave beyond the vertex range
     const bool act = v < n_verts;
@@ -102,8 +106,7 @@ __global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ 
     for (uint32_t p = p0; p < p1; ++p) {
         const uint32_t lf = vf[p] - fb;  // wraps for faces below the range
         if (lf >= nf) continue;
-        for (uint32_t j = j0; j < j1; ++j)
-            acc |= (uint32_t)((pass[(size_t)j * fwords + (lf >> 6)] >> (lf & 63)) & 1ull) << (j - j0);
+        acc |= pass_face[(size_t)blockIdx.y * ((size_t)fwords * 64u) + lf];
     }
     uint32_t n_rays = 0;
     for (uint32_t j = j0; j < j1; ++j) {
@@ -645,13 +648,15 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     const size_t pw = (size_t)V * fwords;
     ctx->pass_bits.ensure(pw + 1); ctx->surv_bits.ensure(pw + 1); ctx->pass_base.ensure(pw + 2);
     const dim3 fgrid((nf + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
+    uint32_t* pass_face = nullptr;
+    if (vis) { ctx->pass_face.ensure((size_t)fgrid.y * fwords * 64u + 1); pass_face = ctx->pass_face.p; }
     Prof pr_cull(ctx, "dc_cull");
     if (ctx->stats)
         hipLaunchKernelGGL(cull_kernel<true>, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
-                           ctx->cos_limit, ctx->pass_bits.p, ctx->counters.p);
+                           ctx->cos_limit, ctx->pass_bits.p, pass_face, ctx->counters.p);
     else
         hipLaunchKernelGGL(cull_kernel<false>, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
-                           ctx->cos_limit, ctx->pass_bits.p, ctx->counters.p);
+                           ctx->cos_limit, ctx->pass_bits.p, pass_face, ctx->counters.p);
     MVS_LAUNCH_CHECK();
     pr_cull.end();
     if (vis) {
@@ -662,10 +667,10 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         Prof pr_need(ctx, "dc_need");
         if (ctx->stats)
             hipLaunchKernelGGL(need_kernel<true>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
-                               ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
+                               pass_face, ctx->need_bits.p, ctx->counters.p);
         else
             hipLaunchKernelGGL(need_kernel<false>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
-                               ctx->pass_bits.p, ctx->need_bits.p, ctx->counters.p);
+                               pass_face, ctx->need_bits.p, ctx->counters.p);
         MVS_LAUNCH_CHECK();
         pr_need.end();
         Prof pr_rays(ctx, "dc_rays");
