@@ -353,33 +353,48 @@ constexpr float COST_SCALE = 65535.0f;
 __device__ __forceinline__ uint32_t cost_code(float c) { return (uint32_t)(c * COST_SCALE + 0.5f); }   // c in [0, 1]
 __device__ __forceinline__ float cost_value(uint32_t code) { return (float)code * (1.0f / 65535.0f); }
 
-// ident[e] = 1 iff the two label lists of the (valid) directed edge e are identical; 16 lanes per node
+// ident[e] = 1 iff the two label lists of the (valid) directed edge e are identical; 16 lanes per node.  The kernel is a chain
+// of dependent gathers (edge -> neighbour -> its column -> its view ids), so three edges are in flight at a time.
 __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
                                                         const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint8_t* __restrict__ ident) {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
     if (i >= F) return;
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
-        const MrfEdge m = edge[e];
-        if (m.kj == 0) continue;
-        uint32_t same = (K == m.kj) ? 1u : 0u;
-        if (same) {
-            const uint32_t q0 = col_ptr[adj[e]];
-            for (uint32_t t = gl; t < K; t += 16) same &= (view_id[p0 + t] == view_id[q0 + t]) ? 1u : 0u;
+    const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+    for (uint32_t e = e0; e < e1; e += 3) {
+        uint32_t kj[3], q0[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool on = e + k < e1;
+            kj[k] = on ? edge[e + k].kj : 0u;
+            q0[k] = col_ptr[on ? adj[e + k] : i];
+        }
+        uint32_t same = 0;   // bit k: edge e + k still looks identical
+#pragma unroll
+        for (int k = 0; k < 3; ++k) same |= (kj[k] != 0u && kj[k] == K) ? (1u << k) : 0u;
+        if (same) {          // group-uniform
+            for (uint32_t t = gl; t < K; t += 16) {
+                const uint32_t v = view_id[p0 + t];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if ((same >> k) & 1u) { if (view_id[q0[k] + t] != v) same &= ~(1u << k); }
+            }
             for (int o = 8; o > 0; o >>= 1) same &= __shfl_xor(same, o, 16);
         }
-        if (gl == 0) ident[e] = (uint8_t)same;
+        if (gl < 3 && e + gl < e1 && kj[gl] != 0u) ident[e + gl] = (uint8_t)((same >> gl) & 1u);
     }
 }
 // rsz[q] = words of the record of node perm[q] (rsz[F] = 0)
+// qpos[i] = position of node i in the (colour, id) order (the inverse of perm)
 __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge,
-                                   const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm, uint32_t F, uint32_t* __restrict__ rsz) {
+                                   const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm, uint32_t F, uint32_t* __restrict__ rsz, uint32_t* __restrict__ qpos) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > F) return;
     uint32_t w = 0;
     if (q < F) {
         const uint32_t i = perm[q], K = col_ptr[i + 1] - col_ptr[i];
+        qpos[i] = q;
         if (K) {
             w = (K + 3u) & ~3u;
             for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { const uint32_t kj = edge[e].kj; if (kj && !ident[e]) w += (kj + 3u) >> 2; }
@@ -388,19 +403,22 @@ __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const u
     }
     rsz[q] = w;
 }
-// fills the record of node perm[q]: 16 lanes per node; the node's own list sits in an LDS tile for the binary searches
-// (a group never spans waves and LDS operations of a wave execute in order: no barrier)
+// fills the record of node i: 16 lanes per node, nodes in FACE order -- the columns are read as one sequential stream (in the
+// (colour, id) order of the records a pass would touch every fourth column), the records are written where they belong;
+// the node's own list sits in an LDS tile for the searches (a group never spans waves and LDS operations of a wave
+// execute in order: no barrier)
 __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                          const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
-                                                         const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ roff,
+                                                         const uint8_t* __restrict__ ident, const uint32_t* __restrict__ qpos, const uint32_t* __restrict__ roff,
                                                          uint32_t F, uint32_t none_byte /* what "label absent at the sender" is stored as: the sweep's +inf slot (4 * G), 0xFF for G = 64 */,
                                                          uint32_t* __restrict__ rec) {
     __shared__ uint16_t s_l[16][256];
-    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
-    if (q >= F) return;
-    const uint32_t i = perm[q], p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+    if (i >= F) return;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     if (K == 0) return;
+    const uint32_t q = qpos[i];
     uint16_t* tile = s_l[threadIdx.x >> 4];
     uint32_t* out = rec + REC_BASE + roff[q];
     const uint32_t K4 = (K + 3u) & ~3u;
@@ -415,16 +433,23 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
         if (kj == 0 || ident[e]) continue;                     // group-uniform
         const uint32_t q0 = col_ptr[adj[e]], nw = (kj + 3u) >> 2;
         for (uint32_t wI = gl; wI < nw; wI += 16) {
+            // positions of the RECEIVER's labels 4 wI .. 4 wI + 3 in this (the sender's) list: four lower-bound searches in
+            // lockstep (the step count depends on K only), so their LDS reads are independent
+            uint32_t key[4], lo[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) { const uint32_t t2 = 4u * wI + r; key[r] = (t2 < kj) ? (uint32_t)view_id[q0 + t2] : 0xFFFFFFFFu; }
+            for (uint32_t n = K; n > 1u;) {
+                const uint32_t half = n >> 1;
+#pragma unroll
+                for (uint32_t r = 0; r < 4; ++r) lo[r] += ((uint32_t)tile[lo[r] + half - 1u] < key[r]) ? half : 0u;
+                n -= half;
+            }
             uint32_t word = 0u;
+#pragma unroll
             for (uint32_t r = 0; r < 4; ++r) {
-                const uint32_t t2 = 4u * wI + r;
-                uint32_t byte = none_byte;
-                if (t2 < kj) {                                 // position of the RECEIVER's label t2 in this (the sender's) list
-                    const uint16_t key = view_id[q0 + t2];
-                    uint32_t lo = 0, hi = K;
-                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tile[mid] < key) lo = mid + 1; else hi = mid; }
-                    if (lo < K && tile[lo] == key) byte = lo;
-                }
+                // lo = the last candidate position: the key sits there, or one further (beyond the list), or nowhere
+                uint32_t at = lo[r] + (((uint32_t)tile[lo[r]] < key[r]) ? 1u : 0u);
+                const uint32_t byte = (at < K && (uint32_t)tile[at < K ? at : 0u] == key[r]) ? at : none_byte;
                 word |= byte << (8 * r);
             }
             out[pos + wI] = word;
@@ -1004,10 +1029,10 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         MVS_HIP(hipMemsetAsync(ctx->m_rec.p, 0, REC_BASE * sizeof(uint32_t), s));
         hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
         uint32_t* rsz = ctx->m_tmp_a.p; uint32_t* roff = ctx->m_tmp_b.p;   // F + 1 entries each
-        hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, rsz); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, rsz, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, rsz, roff, (size_t)F + 1, nullptr);
         hipLaunchKernelGGL(mrf_record_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, roff, F, mrf_none_byte(ctx->m_kmax), ctx->m_rec.p); MVS_LAUNCH_CHECK();
+                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_tmp_c.p /* qpos */, roff, F, mrf_none_byte(ctx->m_kmax), ctx->m_rec.p); MVS_LAUNCH_CHECK();
         ctx->m_desc.ensure((size_t)F + 1);
         hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, ctx->m_colour.p, roff, F, ctx->m_desc.p); MVS_LAUNCH_CHECK();
     } else {
