@@ -115,6 +115,7 @@ void mvs_ctx_destroy(mvs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto* b : ctx->own_rgb) delete b;
+    if (ctx->h_icm) { (void)hipHostFree(ctx->h_icm); for (uint32_t k = 0; k < mvs_ctx::ICM_RING; ++k) (void)hipEventDestroy(ctx->icm_ev[k]); }
     if (ctx->h_ring) { (void)hipHostFree(ctx->h_ring); for (uint32_t k = 0; k < mvs_ctx::RING; ++k) (void)hipEventDestroy(ctx->ring_ev[k]); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -365,6 +366,35 @@ static void read_energy(mvs_ctx* ctx, uint64_t out[2]) {
 
 // The solver's host loop (single GPU): sweeps with exact-energy tracking, the
 // stop rule mirroring StopWhenReturnsDiminish (view_selection.cpp:84), ICM polish.
+// ICM polish of the best labeling (whole graph): rounds of gain + apply until a round moves nothing or max_iters rounds ran.
+// Returns the index of the round that moved nothing (max_iters if none did) -- the oracle's loop counter.  The "moved" counts
+// come back through a pinned ring, `lag` rounds late: the host queues round k + lag before it reads round k's count, so the
+// GPU never idles on a round trip; a round queued after the one that moved nothing finds an empty active list and no winner,
+// i.e. changes nothing.
+static int icm_polish(mvs_ctx* ctx, uint32_t F, int max_iters) {
+    hipStream_t s = ctx->stream;
+    constexpr int R = (int)mvs_ctx::ICM_RING, LAG = 2;
+    if (!ctx->h_icm) {
+        MVS_HIP(hipHostMalloc((void**)&ctx->h_icm, R * sizeof(uint32_t), hipHostMallocDefault));
+        for (int k = 0; k < R; ++k) MVS_HIP(hipEventCreateWithFlags(&ctx->icm_ev[k], hipEventDisableTiming));
+    }
+    int issued = 0, polled = 0, stop = -1;
+    auto poll = [&]() { const int k = polled++; MVS_HIP(hipEventSynchronize(ctx->icm_ev[k % R])); if (stop < 0 && ctx->h_icm[k % R] == 0u) stop = k; };
+    while (issued < max_iters && stop < 0) {
+        {
+            Prof pr(ctx, "mrf_icm");
+            mrf_icm_gain(ctx, 0, F);
+            mrf_icm_apply(ctx, 0, F);   // in place: winners form an independent set
+        }
+        MVS_HIP(hipMemcpyAsync(&ctx->h_icm[issued % R], ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipEventRecord(ctx->icm_ev[issued % R], s));
+        ++issued;
+        if (issued - polled > LAG) poll();
+    }
+    while (polled < issued) poll();
+    return stop >= 0 ? stop : max_iters;
+}
+
 mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
                                   const mvs_mrf_params* params, uint32_t* labels_out, int labels_on_device, mvs_mrf_stats* stats) {
     if (!ctx || !adj_ptr || !adj || !labels_out) return fail(MVS_ERR_INVALID, "null argument");
@@ -399,34 +429,15 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     S.sweeps = issued > 0 ? pg.stop_sweep : 0u;   // max_sweeps <= 0: best labeling = the argmin-unary start state of mrf_setup
     // the sweeps track energies of the 16-bit unaries they stream; from here on (polish, reported energy) the exact costs count
     mrf_exact_costs(ctx, 0, F);
-    int it = 0;
-    for (; it < P.icm_iters; ++it) {
-        Prof pr(ctx, "mrf_icm");
-        mrf_icm_gain(ctx, 0, F);
-        mrf_icm_apply(ctx, 0, F);   // in place: winners form an independent set
-        pr.end();
-        uint32_t moved = 0;
-        MVS_HIP(hipMemcpyAsync(&moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        MVS_HIP(hipStreamSynchronize(s));
-        if (moved == 0) break;
-    }
+    int it = icm_polish(ctx, F, P.icm_iters);
     S.icm_iters = (uint32_t)it;
     /* region moves (off by default), each round followed by a fresh polish -- the control flow the oracle defines */
     for (int r = 0; r < P.region_rounds; ++r) {
         const uint32_t m = mrf_region_round(ctx);
         if (m == 0) break;
         S.region_rounds++; S.region_moves += m;
-        for (it = 0; it < P.icm_iters; ++it) {
-            S.icm_iters++;
-            Prof pr(ctx, "mrf_icm");
-            mrf_icm_gain(ctx, 0, F);
-            mrf_icm_apply(ctx, 0, F);
-            pr.end();
-            uint32_t moved = 0;
-            MVS_HIP(hipMemcpyAsync(&moved, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            MVS_HIP(hipStreamSynchronize(s));
-            if (moved == 0) break;
-        }
+        it = icm_polish(ctx, F, P.icm_iters);
+        S.icm_iters += (uint32_t)std::min(it + 1, P.icm_iters);   // rounds run, including the one that found nothing to move
     }
     mrf_energy(ctx, true, 0, F);
     uint64_t e[2]; read_energy(ctx, e);

@@ -194,6 +194,8 @@ struct mvs_ctx {
     mvs_mrf_params m_params{};
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring
     static constexpr uint32_t RING = 16;
+    static constexpr uint32_t ICM_RING = 8;
+    uint32_t* h_icm = nullptr; hipEvent_t icm_ev[ICM_RING] = {};   // pinned "moved" counts of the ICM rounds, read a few rounds late
     mvs::DBuf<mvs_mrf_progress> m_state; mvs::DBuf<unsigned long long> m_hist;
     mvs_mrf_progress* h_ring = nullptr; mvs_mrf_progress* d_ring = nullptr /* the same pinned slots as the device addresses them */; hipEvent_t ring_ev[RING] = {}; uint32_t steps_issued = 0; int mrf_lag = 1;
 };

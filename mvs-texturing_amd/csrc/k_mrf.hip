@@ -743,36 +743,38 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                                            const uint32_t* __restrict__ sel, const uint32_t* __restrict__ lab,
                                                            uint32_t node_begin, uint32_t node_end, float* __restrict__ gain, uint32_t* __restrict__ cand,
-                                                           const uint32_t* __restrict__ list /* null: nodes [node_begin, node_end); else node ids list[node_begin .. node_end) */) {
+                                                           const uint32_t* __restrict__ list /* null: nodes [node_begin, node_end); else node ids list[node_begin .. node_end) */,
+                                                           const uint32_t* __restrict__ list_count /* non-null: node_end = node_begin + *list_count */) {
     constexpr int NPB = 256 / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const uint32_t pos = node_begin + blockIdx.x * NPB + grp;
-    const bool node_ok = pos < node_end;
-    const uint32_t i = (list && node_ok) ? list[pos] : pos;
-    const uint32_t p0 = node_ok ? col_ptr[i] : 0u;
-    const uint32_t K = node_ok ? col_ptr[i + 1] - p0 : 0u;
-    const uint32_t e0 = node_ok ? adj_ptr[i] : 0u, e1 = node_ok ? adj_ptr[i + 1] : 0u;
-    const uint32_t cur_t = (K > 0) ? sel[i] : 0u;
-    float best = INFINITY, cur = 0.0f; uint32_t bt = 0xFFFFFFFFu;
-    // neighbour labels: the first three once (the manifold case), any further ones inside the loop
-    uint32_t nl[3];
+    if (list_count) node_end = node_begin + *list_count;   // the active list's length stays on the device: no read-back between the ICM rounds
+    for (uint32_t pos = node_begin + blockIdx.x * NPB + grp; pos < node_end; pos += gridDim.x * NPB) {   // trip counts are uniform within a lane group
+        const uint32_t i = list ? list[pos] : pos;
+        const uint32_t p0 = col_ptr[i];
+        const uint32_t K = col_ptr[i + 1] - p0;
+        const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+        const uint32_t cur_t = (K > 0) ? sel[i] : 0u;
+        float best = INFINITY, cur = 0.0f; uint32_t bt = 0xFFFFFFFFu;
+        // neighbour labels: the first three once (the manifold case), any further ones inside the loop
+        uint32_t nl[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && e0 + d < e1) ? lab[adj[e0 + d]] : 0u;
-    for (uint32_t t = gl; t < K; t += G) {
-        const uint32_t l = (uint32_t)view_id[p0 + t] + 1u;
-        uint32_t diff = (nl[0] != 0u && nl[0] != l) + (nl[1] != 0u && nl[1] != l) + (nl[2] != 0u && nl[2] != l);
-        for (uint32_t e = e0 + 3; e < e1; ++e) { const uint32_t lj = lab[adj[e]]; diff += (lj != 0u && lj != l); }
-        const float en = cost[p0 + t] + (float)diff;
-        if (en < best) { best = en; bt = t; }
-        if (t == cur_t) cur = en;
-    }
+        for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && e0 + d < e1) ? lab[adj[e0 + d]] : 0u;
+        for (uint32_t t = gl; t < K; t += G) {
+            const uint32_t l = (uint32_t)view_id[p0 + t] + 1u;
+            uint32_t diff = (nl[0] != 0u && nl[0] != l) + (nl[1] != 0u && nl[1] != l) + (nl[2] != 0u && nl[2] != l);
+            for (uint32_t e = e0 + 3; e < e1; ++e) { const uint32_t lj = lab[adj[e]]; diff += (lj != 0u && lj != l); }
+            const float en = cost[p0 + t] + (float)diff;
+            if (en < best) { best = en; bt = t; }
+            if (t == cur_t) cur = en;
+        }
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
-        if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
-        cur += __shfl_xor(cur, o, G);   // exactly one lane holds a non-zero term (or none: 0)
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, G); const uint32_t ot = __shfl_xor(bt, o, G);
+            if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+            cur += __shfl_xor(cur, o, G);   // exactly one lane holds a non-zero term (or none: 0)
+        }
+        if (gl == 0) { gain[i] = (K > 0) ? (cur - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; }
     }
-    if (gl == 0 && node_ok) { gain[i] = (K > 0) ? (cur - best) : 0.0f; cand[i] = (K > 0) ? bt : 0u; }
 }
 
 // fast path (degree <= 3): persistent lane groups over the node descriptors, next descriptor prefetched
@@ -1259,19 +1261,18 @@ void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     const uint32_t K = ctx->m_kmax, n = ne0 - nb0;
     const bool whole = nb0 == 0 && ne0 == ctx->csr_faces;
 #define ICM_G(GG, B, E, LIST) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3(((E) - (B) + (256 / GG) - 1) / (256 / GG)), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
-                                     ctx->r_adj_ptr, ctx->r_adj, ctx->b_sel, ctx->b_lab, (B), (E), ctx->m_gain.p, ctx->m_cand.p, (LIST))
+                                     ctx->r_adj_ptr, ctx->r_adj, ctx->b_sel, ctx->b_lab, (B), (E), ctx->m_gain.p, ctx->m_cand.p, (LIST), (const uint32_t*)nullptr)
     // active set (unsharded calls only): after one full evaluation, only the nodes the last apply listed -- the nodes that
     // moved and their neighbours -- are re-evaluated; everybody else's stored gain / candidate are still the values a
     // full pass would compute.  Sharded callers exchange labels behind the library's back, so they evaluate all.
+    // The list's length is read on the device (fixed grid, grid-stride loop): no host round trip between the rounds.
     if (whole && ctx->icm_dirty_valid) {
-        uint32_t cnt = 0;
-        MVS_HIP(hipMemcpyAsync(&cnt, ctx->m_moved.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        MVS_HIP(hipStreamSynchronize(ctx->stream));
-        if (cnt) {
-            const uint32_t* list = ctx->m_alist.p;
-            if (K <= 8) ICM_G(8, 0u, cnt, list); else if (K <= 16) ICM_G(16, 0u, cnt, list); else if (K <= 32) ICM_G(32, 0u, cnt, list); else ICM_G(64, 0u, cnt, list);
-            MVS_LAUNCH_CHECK();
-        }
+        const uint32_t* list = ctx->m_alist.p; const uint32_t* cnt = ctx->m_moved.p + 1;
+#define ICM_L(GG) hipLaunchKernelGGL(mrf_icm_gain_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((n + (256 / GG) - 1) / (256 / GG), 1024u))), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, \
+                                     ctx->r_adj_ptr, ctx->r_adj, ctx->b_sel, ctx->b_lab, 0u, 0u, ctx->m_gain.p, ctx->m_cand.p, list, cnt)
+        if (K <= 8) ICM_L(8); else if (K <= 16) ICM_L(16); else if (K <= 32) ICM_L(32); else ICM_L(64);
+#undef ICM_L
+        MVS_LAUNCH_CHECK();
         return;
     }
     if (ctx->m_fast && whole) {   // descriptors are in (colour, id) order: whole-graph calls only
