@@ -150,6 +150,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "max_labels") { if (value < 0 || value > 65535) return fail(MVS_ERR_INVALID, "max_labels: 0 (off) .. 65535"); ctx->max_labels = (int)value; }
     else if (n == "profile") ctx->profile = value != 0;
     else if (n == "ray_mode") ctx->ray_mode = (int)value;
+    else if (n == "prep_fused") ctx->prep_fused = value != 0;
     else if (n == "ray_xcd") ctx->ray_xcd = (int)value;
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;
     else if (n == "mrf_lag") ctx->mrf_lag = (int)value;

@@ -104,6 +104,7 @@ struct mvs_ctx {
     bool verbose = false;
     bool profile = false;
     std::vector<mvs::ProfSpan> prof_spans; std::vector<hipEvent_t> prof_pool;
+    bool prep_fused = true;  // image prep: luminance + Sobel in one pass through LDS (false: the two-pass kernels; identical output)
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel

@@ -227,6 +227,91 @@ __global__ void __launch_bounds__(256) sobel4_kernel(const ViewParams* __restric
     *reinterpret_cast<uint32_t*>(gmi_all + gmi_off[blockIdx.z] + (size_t)y * w + x4) = out;
 }
 
+// ---- fused fast path: luminance + zero map + Sobel magnitude in ONE pass over the RGB image ----
+// A block owns a strip of 1024 x FUSE_ROWS pixels: it converts rows y0 - 1 .. y0 + FUSE_ROWS (one halo row above and below,
+// one halo pixel left and right) to luminance in LDS, then takes the Sobel magnitude from LDS.  The luminance plane never
+// goes to HBM (the two-pass version wrote and re-read it: 2 x 629 MB at C3); the halo rows cost 2 / FUSE_ROWS extra reads.
+// Same integer arithmetic as lum_zero_kernel + sobel4_kernel (and gmi_kernel): bit-identical output.
+constexpr int FUSE_ROWS = 16;
+__global__ void __launch_bounds__(256) lum_sobel_kernel(const ViewParams* __restrict__ views, uint8_t* __restrict__ gmi_all, const size_t* __restrict__ gmi_off,
+                                                        uint32_t* __restrict__ zero_all, uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off) {
+    __shared__ uint32_t s_lum[FUSE_ROWS + 2][258];   // [row][1 + thread]: four luminances per word; words 0 and 257 hold the halo pixels (byte 3 / byte 0)
+    const ViewParams& vp = views[blockIdx.z];
+    const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
+    const int tx0 = blockIdx.x * 1024, x4 = tx0 + threadIdx.x * 4, y0 = blockIdx.y * FUSE_ROWS;
+    if (tx0 >= w || y0 >= h) return;
+    const bool ok = x4 < w;   // w % 32 == 0: a group of 8 lanes (32 pixels) is entirely in or out
+    for (int r = 0; r < FUSE_ROWS + 2; ++r) {
+        const int y = y0 - 1 + r;
+        const bool row_ok = y >= 0 && y < h;
+        uint32_t zbits = 0, lum4 = 0;
+        if (ok && row_ok) {
+            const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(vp.rgb + ((size_t)y * w + x4) * 3);
+            const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+            const uint8_t px[4][3] = {{(uint8_t)d0, (uint8_t)(d0 >> 8), (uint8_t)(d0 >> 16)}, {(uint8_t)(d0 >> 24), (uint8_t)d1, (uint8_t)(d1 >> 8)},
+                                      {(uint8_t)(d1 >> 16), (uint8_t)(d1 >> 24), (uint8_t)d2}, {(uint8_t)(d2 >> 8), (uint8_t)(d2 >> 16), (uint8_t)(d2 >> 24)}};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((int)px[k][0] + (int)px[k][1] + (int)px[k][2] == 0) zbits |= 1u << k;
+                lum4 |= (uint32_t)luminance_u8(px[k][0], px[k][1], px[k][2]) << (8 * k);
+            }
+        }
+        s_lum[r][1 + threadIdx.x] = lum4;
+        if (threadIdx.x == 0) {         // halo pixel left of the strip -> byte 3 of word 0
+            uint32_t v = 0;
+            if (row_ok && tx0 > 0) { const uint8_t* q = vp.rgb + ((size_t)y * w + tx0 - 1) * 3; v = (uint32_t)luminance_u8(q[0], q[1], q[2]) << 24; }
+            s_lum[r][0] = v;
+        }
+        if (threadIdx.x == 255) {       // halo pixel right of the strip -> byte 0 of word 257
+            uint32_t v = 0;
+            if (row_ok && tx0 + 1024 < w) { const uint8_t* q = vp.rgb + ((size_t)y * w + tx0 + 1024) * 3; v = (uint32_t)luminance_u8(q[0], q[1], q[2]); }
+            s_lum[r][257] = v;
+        }
+        if (r >= 1 && r <= FUSE_ROWS) {   // the strip's own rows: zero map + corner seeds of the validity flood fill
+            uint32_t word = zbits << (4 * (threadIdx.x & 7));
+            word |= __shfl_xor(word, 1, 8); word |= __shfl_xor(word, 2, 8); word |= __shfl_xor(word, 4, 8);
+            if (ok && row_ok && (threadIdx.x & 7) == 0) {
+                const int wx = x4 >> 5;
+                uint32_t seed = 0;
+                if (y == 0 || y == h - 1) {
+                    if (wx == 0) seed |= 1u;
+                    if (wx == (w - 1) / 32) seed |= 1u << ((w - 1) & 31);
+                }
+                const size_t idx = mask_off[blockIdx.z] + (size_t)y * wpr + wx;
+                zero_all[idx] = word;
+                reach_all[idx] = seed & word;
+            }
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    uint8_t* __restrict__ gmi = gmi_all + gmi_off[blockIdx.z];
+    for (int r = 1; r <= FUSE_ROWS; ++r) {
+        const int y = y0 - 1 + r;
+        if (y >= h) break;
+        uint32_t out = 0;
+        if (y > 0 && y < h - 1) {
+            int l[3][6];   // rows y-1..y+1, columns x4-1..x4+4
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const uint32_t a = s_lum[r - 1 + q][threadIdx.x], d = s_lum[r - 1 + q][1 + threadIdx.x], b = s_lum[r - 1 + q][2 + threadIdx.x];
+                l[q][0] = x4 > 0 ? (int)(a >> 24) : 0;
+                l[q][1] = d & 0xFF; l[q][2] = (d >> 8) & 0xFF; l[q][3] = (d >> 16) & 0xFF; l[q][4] = d >> 24;
+                l[q][5] = x4 + 4 < w ? (int)(b & 0xFF) : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x4 + k;
+                if (x == 0 || x == w - 1) continue;
+                const int sx = (l[0][k + 2] - l[0][k]) + 2 * (l[1][k + 2] - l[1][k]) + (l[2][k + 2] - l[2][k]);
+                const int sy = (l[2][k] - l[0][k]) + 2 * (l[2][k + 1] - l[0][k + 1]) + (l[2][k + 2] - l[0][k + 2]);
+                out |= (uint32_t)isqrt_clamp255(sx * sx + sy * sy) << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(gmi + (size_t)y * w + x4) = out;
+    }
+}
+
 }  // namespace
 
 // Runs the image preparation for all views; needs ctx->d_views uploaded with
@@ -245,12 +330,18 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
     uint32_t* rb = ctx->mask_tmp.p;   // pong
     if (fast) {
         dim3 g4((maxw / 4 + 255) / 256, maxh, V);
-        if (need_gmi) ctx->lum_all.ensure(ctx->gmi_off.back() + 16);
-        hipLaunchKernelGGL(lum_zero_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, d_gmi_off, zero, ra, d_mask_off, need_gmi ? 1 : 0);
-        MVS_LAUNCH_CHECK();
-        if (need_gmi) {
-            hipLaunchKernelGGL(sobel4_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, ctx->gmi_all.p, d_gmi_off);
+        if (need_gmi && ctx->prep_fused) {
+            dim3 gf((maxw + 1023) / 1024, (maxh + FUSE_ROWS - 1) / FUSE_ROWS, V);
+            hipLaunchKernelGGL(lum_sobel_kernel, gf, dim3(256), 0, s, ctx->d_views.p, ctx->gmi_all.p, d_gmi_off, zero, ra, d_mask_off);
             MVS_LAUNCH_CHECK();
+        } else {
+            if (need_gmi) ctx->lum_all.ensure(ctx->gmi_off.back() + 16);
+            hipLaunchKernelGGL(lum_zero_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, d_gmi_off, zero, ra, d_mask_off, need_gmi ? 1 : 0);
+            MVS_LAUNCH_CHECK();
+            if (need_gmi) {
+                hipLaunchKernelGGL(sobel4_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, ctx->gmi_all.p, d_gmi_off);
+                MVS_LAUNCH_CHECK();
+            }
         }
     } else {
         if (need_gmi) {

@@ -1,4 +1,5 @@
-# quick GPU check: a few parity tests + one bench line summary
+# quick GPU check: a few parity tests + one bench line summary.  Environment does not travel through gpurun: pass the knobs inside
+# the command string, e.g. gpurun -- 'QB_K="ray or golden" QB_ARGS="--no-real-like" bash scripts/quick_bench.sh'
 mkdir -p gpurun_out
 (timeout 900 python -m pytest tests -q -m gpu -x -k "${QB_K:-labels_bit_exact or stress or golden or config2_equals or random_instances}") > gpurun_out/t1.log 2>&1; tail -4 gpurun_out/t1.log
 (timeout 900 python bench.py --no-traffic --no-cpu-baseline ${QB_ARGS}) > gpurun_out/bench.log 2> gpurun_out/bench.err; tail -2 gpurun_out/bench.err

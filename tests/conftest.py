@@ -49,6 +49,9 @@ SCENES = {
     "spiky32": dict(n=32, n_views=10, width=512, height=384, displacement=0.35, layout=1, seed=5, zoom_odd=1.2),
     # cameras at 1.3 radii from a surface that reaches 1.2: grazing angles, steep perspective inside one footprint
     "close": dict(n=8, n_views=8, width=320, height=240, displacement=0.2, layout=1, radius=1.3),
+    # images wider than one 1024-pixel strip of the fused luminance + Sobel kernel (two full strips + a 32-pixel one) and a
+    # height that is not a multiple of its 16-row tiles; a black corner seeds the validity flood fill across strips
+    "wide": dict(n=8, n_views=5, width=2080, height=70, displacement=0.2, layout=1, black_corner=40),
 }
 
 _scene_cache = {}

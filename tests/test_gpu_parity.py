@@ -198,6 +198,24 @@ def test_many_views_outlier_removal_against_live_oracle(ctx, kw):
     assert st["nnz_pre"] == rst["nnz_pre"] and np.float32(st["percentile"]) == np.float32(rst["percentile"])
 
 
+def test_fused_image_prep_equals_the_two_pass_kernels_and_the_oracle():
+    """luminance + Sobel in one pass through LDS (strips of 1024 x 16 pixels with halos) against the two-pass kernels and the
+    oracle, on images of 2080 x 70 pixels: strip seams, a partial last strip, a partial last row tile"""
+    s = get_scene("wide")
+    ref, rst = O.data_costs(s)
+    assert ref.nnz > 100
+    tables = []
+    for fused in (1, 0):
+        c = M.Context(0); c.set_option("prep_fused", fused)
+        _load_scene(c, s)
+        c.data_costs(M.Settings())
+        got = c.costs_download()
+        _assert_costs(got, ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        tables.append(got)
+        c.close()
+    assert np.array_equal(tables[0].cost.view(np.uint32), tables[1].cost.view(np.uint32))
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_ray_traversal_modes_give_the_oracle_booleans(mode):
     """per-ray traversal, shared (packet) traversal, packet + leaf work redistribution, and the latter with the packed,
