@@ -92,6 +92,12 @@ MVS_HD bool valid_pixel(const ViewParams& v, V2 px) {
 // cos_limit replaces `std::acos(viewing_angle) > MATH_DEG2RAD(75.0f)`: it is the
 // smallest float c with !(acosf(c) > 75 deg), found on the host with the host's
 // acosf, so `viewing_angle < cos_limit` decides identically (acosf is monotone).
+// the last cull (calculate_data_costs.cpp:191): all three vertices project onto valid pixels
+MVS_HD int cull_pixels(const ViewParams& v, V3 v1, V3 v2, V3 v3) {
+    if (!(valid_pixel(v, pixel_coords(v, v1)) && valid_pixel(v, pixel_coords(v, v2)) &&
+          valid_pixel(v, pixel_coords(v, v3)))) return 3;
+    return 0;
+}
 MVS_HD int cull_pair(const ViewParams& v, V3 v1, V3 v2, V3 v3, V3 face_normal, float cos_limit) {
     const V3 view_pos = {v.pos[0], v.pos[1], v.pos[2]};
     const V3 viewing_direction = {v.viewdir[0], v.viewdir[1], v.viewdir[2]};
@@ -101,9 +107,7 @@ MVS_HD int cull_pair(const ViewParams& v, V3 v1, V3 v2, V3 v3, V3 face_normal, f
     const float viewing_angle = dot(face_to_view_vec, face_normal);
     if (viewing_angle < 0.0f || dot(viewing_direction, view_to_face_vec) < 0.0f) return 1;
     if (viewing_angle < cos_limit) return 2;
-    if (!(valid_pixel(v, pixel_coords(v, v1)) && valid_pixel(v, pixel_coords(v, v2)) &&
-          valid_pixel(v, pixel_coords(v, v3)))) return 3;
-    return 0;
+    return cull_pixels(v, v1, v2, v3);
 }
 
 // Visibility ray of calculate_data_costs.cpp:200-206: origin = vertex,

@@ -77,7 +77,23 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
             const float un = (d.x * nrm.x + d.y * nrm.y) + d.z * nrm.z, an = (fabsf(d.x * nrm.x) + fabsf(d.y * nrm.y)) + fabsf(d.z * nrm.z);
             const float uv = (d.x * vw.viewdir[0] + d.y * vw.viewdir[1]) + d.z * vw.viewdir[2], av = (fabsf(d.x * vw.viewdir[0]) + fabsf(d.y * vw.viewdir[1])) + fabsf(d.z * vw.viewdir[2]);
             const bool clear_back = (un < -4e-6f * an) || (uv > 4e-6f * av);      // dot(viewdir, centre - pos) = -uv < 0
-            const int reason = act ? (clear_back ? 1 : cull_pair(vw, v1, v2, v3, nrm, cos_limit)) : -1;
+            int reason = -1;
+            if (act) {
+                if (clear_back) reason = 1;
+                else {
+                    // Clear cases of the angle cull (:187-188) without the normalisations as well.  With both dot products
+                    // clearly on the front side (same margins as above) reason 1 is excluded; the reference's
+                    // viewing_angle (fp32) differs from dot(d, n) / |d| by less than 4e-7 A / |d|, this kernel's un from
+                    // dot(d, n) by less than 2e-7 A, and s = v_sqrt(dd) from |d| by less than 4e-7 |d|: comparing
+                    // un -+ 4e-6 A with cos_limit s (1 +- 4e-6) decides `viewing_angle < cos_limit` with a tenfold margin.
+                    // Everything in between takes cull_pair unchanged.
+                    const bool clear_front = (un > 4e-6f * an) && (uv < -4e-6f * av);
+                    const float ls = cos_limit * __builtin_amdgcn_sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
+                    if (clear_front && un + 4e-6f * an <= ls * (1.0f - 4e-6f)) reason = 2;
+                    else if (clear_front && un - 4e-6f * an >= ls * (1.0f + 4e-6f)) reason = cull_pixels(vw, v1, v2, v3);
+                    else reason = cull_pair(vw, v1, v2, v3, nrm, cos_limit);
+                }
+            }
             if (STATS) { cnt[0] += reason == 1; cnt[1] += reason == 2; cnt[2] += reason == 3; cnt[3] += reason == 0; }
             const unsigned long long b = __ballot(reason == 0);
             if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
@@ -533,7 +549,8 @@ __global__ void __launch_bounds__(1024) hist_kernel(const float* __restrict__ q,
 // Histogram::get_approx_percentile (histogram.cpp:49-63): the reference walks the bins and returns the previous bin's
 // bound as soon as float(num) / num_values > percentile, where num = counts of the bins before the current one.
 // Parallel form: exclusive prefix sum of the counts, smallest bin index whose test fires, same float expressions.
-__global__ void __launch_bounds__(1024) percentile_kernel(const uint32_t* __restrict__ hist, const float* __restrict__ max_q, float percentile, float* __restrict__ out) {
+__global__ void __launch_bounds__(1024) percentile_kernel(const uint32_t* __restrict__ hist, const float* __restrict__ max_q, float percentile, float* __restrict__ out,
+                                                          unsigned long long* __restrict__ report /* [0] bits of max_q, [1] bits of the percentile: read back with the counters */) {
     constexpr uint32_t PER = (HIST_BINS + 1023u) / 1024u;
     __shared__ uint32_t s_sum[1024];
     __shared__ uint32_t s_first;
@@ -564,6 +581,7 @@ __global__ void __launch_bounds__(1024) percentile_kernel(const uint32_t* __rest
         if (i == 0xFFFFFFFFu) *out = maxv;
         else if (i == 0u) *out = minv;
         else *out = ((float)(i - 1u) / (float)(HIST_BINS - 1)) * (maxv - minv) + minv;
+        if (report) { report[0] = __float_as_uint(maxv); report[1] = __float_as_uint(*out); }
     }
 }
 
@@ -934,18 +952,17 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     hipStream_t s = ctx->stream;
     ctx->pctl.ensure(4);
     Prof pr(ctx, "dc_post");
-    hipLaunchKernelGGL(percentile_kernel, dim3(1), dim3(1024), 0, s, ctx->hist.p, ctx->max_q.p, 0.995f, ctx->pctl.p);
+    hipLaunchKernelGGL(percentile_kernel, dim3(1), dim3(1024), 0, s, ctx->hist.p, ctx->max_q.p, 0.995f, ctx->pctl.p, ctx->counters.p + 14);
     MVS_LAUNCH_CHECK();
     if (ctx->csr_nnz) {
         hipLaunchKernelGGL(cost_kernel, dim3(2048), dim3(256), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, ctx->pctl.p, ctx->csr_cost.p);
         MVS_LAUNCH_CHECK();
     }
     pr.end();
-    unsigned long long hc[16]; float mq = 0.0f, pc = 0.0f;
+    unsigned long long hc[16];   // counters + (percentile_kernel's report) max quality and percentile: one read-back
     MVS_HIP(hipMemcpyAsync(hc, ctx->counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-    MVS_HIP(hipMemcpyAsync(&mq, ctx->max_q.p, sizeof(float), hipMemcpyDeviceToHost, s));
-    MVS_HIP(hipMemcpyAsync(&pc, ctx->pctl.p, sizeof(float), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
+    float mq, pc; { const uint32_t a = (uint32_t)hc[14], b = (uint32_t)hc[15]; memcpy(&mq, &a, 4); memcpy(&pc, &b, 4); }
     mvs_dc_stats& S = ctx->dc_stats;
     S.cull_backface = hc[C_BACK]; S.cull_angle = hc[C_ANGLE]; S.cull_outside = hc[C_OUTSIDE]; S.cull_occluded = hc[C_OCCL];
     S.cull_zero_quality = hc[C_ZEROQ]; S.rays = hc[C_RAYS]; S.ray_nodes = hc[C_RNODES]; S.ray_tris = hc[C_RTRIS];

@@ -974,8 +974,9 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         for (int round = 0;; ++round) {
             if (round >= 4096) throw StatusError(MVS_ERR_HIP, "graph colouring did not terminate");
             MVS_HIP(hipMemsetAsync(pending, 0, sizeof(uint32_t), s));
-            for (int k = 0; k < 4; ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
-            uint32_t hp[2] = {0, 0};   // set if any of the four rounds left a node waiting
+            // a batch of rounds per read-back: 8 first (large meshes need ~12 rounds, a round costs 10 us, a read-back 25), then 4
+            for (int k = 0; k < (round == 0 ? 8 : 4); ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
+            uint32_t hp[2] = {0, 0};   // set if any round of the batch left a node waiting
             MVS_HIP(hipMemcpyAsync(hp, pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             MVS_HIP(hipStreamSynchronize(s));
             if (hp[1]) throw StatusError(MVS_ERR_UNSUPPORTED, "adjacency graph needs more than 64 colours (a node with >= 64 mutually constrained neighbours)");
