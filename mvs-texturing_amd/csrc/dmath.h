@@ -317,7 +317,9 @@ constexpr float FOOT_DEFERRED = -1.0f;   // quality marker: "sampled by the wave
 // qualities bit-exact.  DATA_TERM: 0 = area, 1 = gmi; OUTLIER: colours are accumulated iff true.  A footprint that has to
 // be sampled and whose area exceeds defer_area is NOT walked here: quality = FOOT_DEFERRED.
 template <int DATA_TERM, bool OUTLIER>
-MVS_HD void face_info(const ViewParams& view, V3 v1, V3 v2, V3 v3, FaceInfoOut* out, float defer_area = INFINITY) {
+MVS_HD void face_info(const ViewParams& view, V3 v1, V3 v2, V3 v3, FaceInfoOut* out, float defer_area = INFINITY,
+                      const double* u8_over_255 = nullptr /* optional table of (double)v / 255.0, v = 0..255: the same correctly rounded
+                                                             quotients the walk would compute, looked up instead of divided */) {
     FootSetup s;
     foot_setup(view, v1, v2, v3, s);
     out->quality = 0.0f;
@@ -342,11 +344,12 @@ MVS_HD void face_info(const ViewParams& view, V3 v1, V3 v2, V3 v3, FaceInfoOut* 
                 if (!s.fast && !foot_inside(s, x, y)) continue;
                 const size_t pix = (size_t)x + (size_t)y * w;
                 if (OUTLIER) {
-                    col0 += (double)image[pix * 3 + 0] / 255.0;
-                    col1 += (double)image[pix * 3 + 1] / 255.0;
-                    col2 += (double)image[pix * 3 + 2] / 255.0;
+                    const uint8_t c0 = image[pix * 3 + 0], c1 = image[pix * 3 + 1], c2 = image[pix * 3 + 2];
+                    col0 += u8_over_255 ? u8_over_255[c0] : (double)c0 / 255.0;
+                    col1 += u8_over_255 ? u8_over_255[c1] : (double)c1 / 255.0;
+                    col2 += u8_over_255 ? u8_over_255[c2] : (double)c2 / 255.0;
                 }
-                if (DATA_TERM == 1) gmi += (double)gimg[pix] / 255.0;
+                if (DATA_TERM == 1) { const uint8_t g = gimg[pix]; gmi += u8_over_255 ? u8_over_255[g] : (double)g / 255.0; }
                 ++num_samples;
             }
         }

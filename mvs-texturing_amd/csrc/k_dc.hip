@@ -147,6 +147,11 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
                                                    unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters,
                                                    float defer_area /* footprints above this area are left to wave_info_kernel (+inf: none) */,
                                                    unsigned long long* __restrict__ defer_bits) {
+    // the walk adds (double)u8 / 255.0 per pixel and channel: the 256 possible quotients, correctly rounded by the same
+    // division, are looked up in LDS instead of divided (an fp64 division is ~15 double-precision instructions)
+    __shared__ double s_q255[256];
+    s_q255[threadIdx.x] = (double)threadIdx.x / 255.0;
+    __syncthreads();
     const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
     const bool wave_ok = (lf >> 6) < fwords;  // false: whole wave beyond the face range
     const bool act = lf < nf;
@@ -171,7 +176,7 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
             }
             FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
             if (visible) {
-                face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi, defer_area);
+                face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi, defer_area, s_q255);
                 if (fi.quality == FOOT_DEFERRED) deferred = true;   // quality, survivor bit and counters come from wave_info_kernel
                 else if (fi.quality == 0.0f) ++cnt[1]; else { keep = true; ++cnt[2]; }
             } else ++cnt[0];
