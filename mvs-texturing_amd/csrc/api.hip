@@ -115,8 +115,9 @@ void mvs_ctx_destroy(mvs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto* b : ctx->own_rgb) delete b;
-    if (ctx->h_icm) { (void)hipHostFree(ctx->h_icm); for (uint32_t k = 0; k < mvs_ctx::ICM_RING; ++k) (void)hipEventDestroy(ctx->icm_ev[k]); }
-    if (ctx->h_ring) { (void)hipHostFree(ctx->h_ring); for (uint32_t k = 0; k < mvs_ctx::RING; ++k) (void)hipEventDestroy(ctx->ring_ev[k]); }
+    if (ctx->h_icm) (void)hipHostFree(ctx->h_icm);
+    if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -174,7 +175,8 @@ mvs_status mvs_ctx_get_profile(mvs_ctx* ctx, char* buf, size_t buf_size) {
         for (; k < names.size(); ++k) if (names[k] == sp.name) break;
         if (k == names.size()) { names.push_back(sp.name); ms.push_back(0.0); cnt.push_back(0); }
         ms[k] += t; cnt[k] += 1;
-        ctx->prof_pool.push_back(sp.a); ctx->prof_pool.push_back(sp.b);
+        if (sp.owns_a) ctx->prof_pool.push_back(sp.a);
+        ctx->prof_pool.push_back(sp.b);
     }
     ctx->prof_spans.clear();
     std::string out = "{";
@@ -373,26 +375,23 @@ static void read_energy(mvs_ctx* ctx, uint64_t out[2]) {
 // GPU never idles on a round trip; a round queued after the one that moved nothing finds an empty active list and no winner,
 // i.e. changes nothing.
 static int icm_polish(mvs_ctx* ctx, uint32_t F, int max_iters) {
-    hipStream_t s = ctx->stream;
     constexpr int R = (int)mvs_ctx::ICM_RING, LAG = 2;
-    if (!ctx->h_icm) {
-        MVS_HIP(hipHostMalloc((void**)&ctx->h_icm, R * sizeof(uint32_t), hipHostMallocDefault));
-        for (int k = 0; k < R; ++k) MVS_HIP(hipEventCreateWithFlags(&ctx->icm_ev[k], hipEventDisableTiming));
-    }
+    ensure_report_ring(ctx);
     int issued = 0, polled = 0, stop = -1;
-    auto poll = [&]() { const int k = polled++; MVS_HIP(hipEventSynchronize(ctx->icm_ev[k % R])); if (stop < 0 && ctx->h_icm[k % R] == 0u) stop = k; };
+    uint32_t seq0 = ctx->icm_seq;
+    auto poll = [&]() { const int k = polled++; wait_report(ctx, mvs_ctx::RING + (uint32_t)(k % R), seq0 + (uint32_t)k + 1u); if (stop < 0 && ctx->h_icm[k % R] == 0u) stop = k; };
+    ProfChain pc(ctx);
     while (issued < max_iters && stop < 0) {
-        {
-            Prof pr(ctx, "mrf_icm");
-            mrf_icm_gain(ctx, 0, F);
-            mrf_icm_apply(ctx, 0, F);   // in place: winners form an independent set
-        }
-        MVS_HIP(hipMemcpyAsync(&ctx->h_icm[issued % R], ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        MVS_HIP(hipEventRecord(ctx->icm_ev[issued % R], s));
+        pc.begin();
+        mrf_icm_gain(ctx, 0, F);
+        mrf_icm_apply(ctx, 0, F);   // in place: winners form an independent set
+        report_u32(ctx, ctx->m_moved.p, ctx->d_icm + issued % R, mvs_ctx::RING + (uint32_t)(issued % R), seq0 + (uint32_t)issued + 1u);
+        pc.mark("mrf_icm");
         ++issued;
         if (issued - polled > LAG) poll();
     }
     while (polled < issued) poll();
+    ctx->icm_seq = seq0 + (uint32_t)issued;
     return stop >= 0 ? stop : max_iters;
 }
 
@@ -418,10 +417,15 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
         if (ctx->verbose) fprintf(stderr, "[mvs] sweep %u tracking energy %.3f best %.3f%s\n", n, (double)pg.energy / 65535.0, (double)pg.best / 65535.0, pg.stopped ? " (stopped)" : "");
     };
     int issued = 0, polled = 0;
+    ProfChain pc(ctx);
     while (issued < P.max_sweeps && !pg.stopped) {
-        { Prof pr(ctx, "mrf_sweep"); mrf_sweep(ctx, 0, F); }
+        pc.begin();
+        mrf_sweep(ctx, 0, F);
+        pc.mark("mrf_sweep");
         // the fast-path sweep kernels accumulate the sweep's energy themselves; the generic path runs the energy kernel
-        { Prof pr(ctx, "mrf_energy"); if (!ctx->m_energy_from_sweep) mrf_energy(ctx, false, 0, F, /*reduce=*/false); mrf_step(ctx, nullptr); }
+        if (!ctx->m_energy_from_sweep) mrf_energy(ctx, false, 0, F, /*reduce=*/false);
+        mrf_step(ctx, nullptr);
+        pc.mark("mrf_energy");
         ++issued;
         if (issued - lag > polled) report((uint32_t)++polled);
     }

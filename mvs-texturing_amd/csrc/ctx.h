@@ -74,7 +74,7 @@ struct BvhDev {
 
 // Stage profiler: hipEvent pairs recorded on the context's stream (enabled by
 // mvs_set_option("profile", 1)); read back with mvs_ctx_get_profile.
-struct ProfSpan { std::string name; hipEvent_t a, b; };
+struct ProfSpan { std::string name; hipEvent_t a, b; bool owns_a; };   // owns_a = false: `a` is the previous span's `b` (ProfChain)
 
 struct MrfEdge {      // per directed edge e = (i <- j) in adjacency-CSR order
     uint32_t in_off;  // offset of the message INTO i over e (K_i floats, aligned with i's labels)
@@ -196,9 +196,12 @@ struct mvs_ctx {
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring
     static constexpr uint32_t RING = 16;
     static constexpr uint32_t ICM_RING = 8;
-    uint32_t* h_icm = nullptr; hipEvent_t icm_ev[ICM_RING] = {};   // pinned "moved" counts of the ICM rounds, read a few rounds late
+    uint32_t* h_icm = nullptr; uint32_t* d_icm = nullptr; uint32_t icm_seq = 0;   // pinned "moved" counts of the ICM rounds, read a few rounds late
     mvs::DBuf<mvs_mrf_progress> m_state; mvs::DBuf<unsigned long long> m_hist;
-    mvs_mrf_progress* h_ring = nullptr; mvs_mrf_progress* d_ring = nullptr /* the same pinned slots as the device addresses them */; hipEvent_t ring_ev[RING] = {}; uint32_t steps_issued = 0; int mrf_lag = 1;
+    mvs_mrf_progress* h_ring = nullptr; mvs_mrf_progress* d_ring = nullptr /* the same pinned slots as the device addresses them */; uint32_t steps_issued = 0; int mrf_lag = 1;
+    // arrival of a report = its sequence number in the pinned word next to it (written after a system-scope fence): the host polls
+    // memory, no event is recorded in the stream.  Sequence numbers never repeat within a context.
+    uint32_t* h_seq = nullptr; uint32_t* d_seq = nullptr; uint32_t seq_base = 0;   // [0, RING): solver steps; [RING, RING + ICM_RING): ICM rounds
 };
 
 namespace mvs {
@@ -208,13 +211,34 @@ struct Prof {
     Prof(mvs_ctx* ctx, const char* name) : c(ctx), idx(0), on(ctx->profile) {
         if (!on) return;
         auto get = [&]() { hipEvent_t e; if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); } else { MVS_HIP(hipEventCreate(&e)); } return e; };
-        ProfSpan sp{name, get(), get()};
+        ProfSpan sp{name, get(), get(), true};
         MVS_HIP(hipEventRecord(sp.a, c->stream));
         idx = c->prof_spans.size(); c->prof_spans.push_back(sp);
     }
     void end() { if (on) { MVS_HIP(hipEventRecord(c->prof_spans[idx].b, c->stream)); on = false; } }
     ~Prof() { if (on) (void)hipEventRecord(c->prof_spans[idx].b, c->stream); }
 };
+// Adjacent spans that share their boundary events: one hipEventRecord per mark instead of two per span (an event record costs
+// ~5 us of stream time; the solver loop alternates two short stages 42 times).
+struct ProfChain {
+    mvs_ctx* c; hipEvent_t prev; bool on;
+    static hipEvent_t get(mvs_ctx* c) { hipEvent_t e; if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); } else { MVS_HIP(hipEventCreate(&e)); } return e; }
+    explicit ProfChain(mvs_ctx* ctx) : c(ctx), prev(nullptr), on(ctx->profile) {}
+    void begin() { if (on && !prev) { prev = get(c); MVS_HIP(hipEventRecord(prev, c->stream)); first = true; } }
+    void mark(const char* name) {       // closes the span [previous mark, now)
+        if (!on) return;
+        begin();
+        hipEvent_t e = get(c);
+        MVS_HIP(hipEventRecord(e, c->stream));
+        c->prof_spans.push_back(ProfSpan{name, prev, e, first});
+        first = false; prev = e;
+    }
+    bool first = false;
+};
+// reports through pinned host memory (k_mrf.hip)
+void ensure_report_ring(mvs_ctx* ctx);
+void report_u32(mvs_ctx* ctx, const uint32_t* d_src, uint32_t* d_dst, uint32_t seq_slot, uint32_t seq);
+void wait_report(mvs_ctx* ctx, uint32_t seq_slot, uint32_t seq);
 // generic device exclusive scan (scan.hip): out[i] = sum_{k<i} in[i]; returns total via d_total (device, may be null)
 void exclusive_scan_u32(mvs_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* d_total);
 // exact 64-bit total of a u32 array (blocking): the guard in front of scans whose total may pass 2^32

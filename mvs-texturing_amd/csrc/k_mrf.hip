@@ -18,6 +18,7 @@
 // the label re-alignment gather; min / argmin are fused DPP butterflies.
 #include "ctx.h"
 #include <rocprim/rocprim.hpp>
+#include <atomic>
 
 namespace mvs {
 
@@ -891,8 +892,8 @@ __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t nod
 // pinned ring slot (host memory), so a step is ONE launch.
 __global__ void __launch_bounds__(1024) mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
                                 const unsigned long long* __restrict__ energy, const unsigned long long* __restrict__ partial, uint32_t n_partial,
-                                unsigned long long* __restrict__ energy_out, mvs_mrf_progress* __restrict__ report, int max_sweeps, int min_sweeps, int window,
-                                float min_improvement) {
+                                unsigned long long* __restrict__ energy_out, mvs_mrf_progress* __restrict__ report, uint32_t* __restrict__ report_seq, uint32_t seq,
+                                int max_sweeps, int min_sweeps, int window, float min_improvement) {
     __shared__ unsigned long long su[16], sc[16];
     unsigned long long e_sum = 0, c_sum = 0;
     if (partial) {
@@ -929,7 +930,17 @@ __global__ void __launch_bounds__(1024) mrf_step_kernel(mvs_mrf_progress* __rest
         if (stop) { p.stopped = 1u; p.stop_sweep = sw; }
     }
     *st = p;
-    if (report) { *report = p; __threadfence_system(); }
+    if (report) {   // pinned host memory: the report, a system-scope fence, then its sequence number -- the host polls the number
+        *report = p;
+        __threadfence_system();
+        __hip_atomic_store(report_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// one value from device memory into a pinned slot, announced the same way (ICM "moved" counts)
+__global__ void report_u32_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t* __restrict__ dst_seq, uint32_t seq) {
+    *dst = *src;
+    __threadfence_system();
+    __hip_atomic_store(dst_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // best labeling := the current decode buffer (mvs_ctx_mrf_keep_best): the same index flip, unconditionally
 __global__ void mrf_flip_kernel(mvs_mrf_progress* __restrict__ st) { st->best_w = st->w; st->w ^= 1u; }
@@ -1072,11 +1083,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(ctx->m_energy.p, 0, epart * sizeof(unsigned long long), s));   // slots a phase never writes stay zero
     // device-side solver state: sweep 0, best = hist[0] = 2^64 - 1
     ctx->m_state.ensure(1); ctx->m_hist.ensure((size_t)std::max(params->max_sweeps, 0) + 2);
-    if (!ctx->h_ring) {
-        MVS_HIP(hipHostMalloc((void**)&ctx->h_ring, (mvs_ctx::RING + 1) * sizeof(mvs_mrf_progress), hipHostMallocDefault));
-        MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
-        for (uint32_t k = 0; k < mvs_ctx::RING; ++k) MVS_HIP(hipEventCreateWithFlags(&ctx->ring_ev[k], hipEventDisableTiming));
-    }
+    ensure_report_ring(ctx);
+    ctx->seq_base += ctx->steps_issued;   // sequence numbers of this solve: seq_base + step (never reused within the context)
     ctx->h_ring[mvs_ctx::RING] = init;   // staging slot for the upload
     MVS_HIP(hipMemcpyAsync(ctx->m_state.p, &ctx->h_ring[mvs_ctx::RING], sizeof(init), hipMemcpyHostToDevice, s));
     MVS_HIP(hipMemsetAsync(ctx->m_hist.p, 0xFF, sizeof(unsigned long long), s));
@@ -1106,17 +1114,48 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
     const unsigned long long* partial = nullptr; uint32_t n_partial = 0;
     if (!energy) { partial = ctx->m_energy.p + 4; n_partial = ctx->m_energy_from_sweep ? EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u) : ctx->m_energy_blocks; }
     hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(1024), 0, s, ctx->m_state.p, ctx->m_hist.p, energy, partial, n_partial, ctx->m_energy.p,
-                       ctx->d_ring + slot, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
+                       ctx->d_ring + slot, ctx->d_seq + slot, ctx->seq_base + n, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
     MVS_LAUNCH_CHECK();
     ctx->icm_dirty_valid = false; ctx->best_resolved = false;   // the best labeling may change
-    MVS_HIP(hipEventRecord(ctx->ring_ev[slot], s));
 }
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
     if (step == 0 || step > ctx->steps_issued || step + mvs_ctx::RING <= ctx->steps_issued)
         throw StatusError(MVS_ERR_INVALID, "mrf poll: step not among the last 16 issued");
     const uint32_t slot = step % mvs_ctx::RING;
-    MVS_HIP(hipEventSynchronize(ctx->ring_ev[slot]));
+    wait_report(ctx, slot, ctx->seq_base + step);
     *out = ctx->h_ring[slot];
+}
+
+// ---- reports through pinned host memory ----
+// Coherent (fine-grained) host memory: a value, a system-scope fence, then the slot's sequence number.  The host spins on the
+// number -- no event in the stream (an event record costs the stream ~5 us, and the solver would record one per sweep).
+void ensure_report_ring(mvs_ctx* ctx) {
+    if (ctx->h_ring) return;
+    constexpr uint32_t NS = mvs_ctx::RING + mvs_ctx::ICM_RING;
+    MVS_HIP(hipHostMalloc((void**)&ctx->h_ring, (mvs_ctx::RING + 1) * sizeof(mvs_mrf_progress), hipHostMallocCoherent));
+    MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
+    MVS_HIP(hipHostMalloc((void**)&ctx->h_seq, NS * sizeof(uint32_t), hipHostMallocCoherent));
+    MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_seq, ctx->h_seq, 0));
+    MVS_HIP(hipHostMalloc((void**)&ctx->h_icm, mvs_ctx::ICM_RING * sizeof(uint32_t), hipHostMallocCoherent));
+    MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_icm, ctx->h_icm, 0));
+    for (uint32_t k = 0; k < NS; ++k) ctx->h_seq[k] = 0u;
+    ctx->seq_base = 1u; ctx->icm_seq = 0x40000000u;   // no report carries the initial 0
+}
+void report_u32(mvs_ctx* ctx, const uint32_t* d_src, uint32_t* d_dst, uint32_t seq_slot, uint32_t seq) {
+    hipLaunchKernelGGL(report_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, d_src, d_dst, ctx->d_seq + seq_slot, seq);
+    MVS_LAUNCH_CHECK();
+}
+void wait_report(mvs_ctx* ctx, uint32_t seq_slot, uint32_t seq) {
+    const volatile uint32_t* p = ctx->h_seq + seq_slot;
+    for (uint64_t spins = 1; *p != seq; ++spins) {
+        if ((spins & 0x3FFFu) == 0u) {   // now and then: is the stream still working on it?
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) { if (*p == seq) break; throw HipError("a device report did not arrive although the stream is idle"); }
+            if (q != hipErrorNotReady) MVS_HIP(q);
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
 }
 
 // Damping schedule (part of the solver's definition, restated in oracle/oracle.cpp): messages are damped with
