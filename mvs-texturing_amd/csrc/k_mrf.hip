@@ -1057,7 +1057,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     }
     ctx->m_msg_a.ensure(ctx->m_total + 1024);   // slack: lanes beyond a run read on (up to 4 * 64 elements)
     MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1024) * sizeof(msg_t), s));   // zero codes, incl. the reserved zero run
-    MVS_HIP(hipStreamSynchronize(s));  // in_off (m_sel2) is consumed; safe to reuse
+    // in_off lived in m_sel2: everything that reads it is queued on this stream ahead of the memsets below (and a re-allocation frees
+    // through hipFree, which waits for the device), so no host synchronisation is needed before the buffer is reused
     // decode buffers: two of F + 1 entries each (see ctx.h)
     const size_t F1 = (size_t)F + 1;
     ctx->m_stride = (uint32_t)F1;
@@ -1088,8 +1089,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->h_ring[mvs_ctx::RING] = init;   // staging slot for the upload
     MVS_HIP(hipMemcpyAsync(ctx->m_state.p, &ctx->h_ring[mvs_ctx::RING], sizeof(init), hipMemcpyHostToDevice, s));
     MVS_HIP(hipMemsetAsync(ctx->m_hist.p, 0xFF, sizeof(unsigned long long), s));
-    MVS_HIP(hipStreamSynchronize(s));
-    ctx->steps_issued = 0; ctx->icm_dirty_valid = false;
+    ctx->steps_issued = 0; ctx->icm_dirty_valid = false;   // no synchronisation: the solver's launches queue behind the set-up on the same stream
 }
 
 // the best labeling's buffer, once the host needs it (ICM, final energy, labels): one read-back of the solver state
