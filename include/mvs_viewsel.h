@@ -204,7 +204,8 @@ mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
  * (ray, triangle) work redistribution at the leaves, 3 = 2 with the packed, direction-sign-specialised slab test -- the default;
  * identical results), "mrf_lag" (sweeps the host queues ahead of
  * the energy reports it reads, default 1, 0 = wait for every sweep; identical results), tuning knobs "mrf_xcd",
- * "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd" */
+ * "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd", "prep_fused" (1 = luminance + Sobel in one pass through LDS,
+ * the default; 0 = the two-pass kernels; identical output) */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 
 /* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,
