@@ -137,6 +137,23 @@ __device__ __forceinline__ float group_min_fused(float v) {
     if (G >= 64) v = min_step_f<32, G>(v);
     return v;
 }
+// Four group minima at once: the DPP steps of the four chains are interleaved, so a step's operand was written three
+// instructions earlier and only the first block needs the DPP read-after-write wait states (one chain at a time costs
+// `s_nop 1` plus the compiler's own padding in front of each of its 4 steps).
+#define MVS_DPP4(nop, ctrl) asm(nop "v_min_f32_dpp %0, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf\n\tv_min_f32_dpp %1, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+                                    "v_min_f32_dpp %2, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf\n\tv_min_f32_dpp %3, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf"          \
+                                : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd) : "v"(a), "v"(b), "v"(c), "v"(d)); a = ra; b = rb; c = rc; d = rd
+template <int G>
+__device__ __forceinline__ void group_min_fused4(float& a, float& b, float& c, float& d) {
+    if (G == 8 || G == 16) {
+        float ra, rb, rc, rd;
+        MVS_DPP4("s_nop 1\n\t", "quad_perm:[1,0,3,2]");
+        MVS_DPP4("", "quad_perm:[2,3,0,1]");
+        MVS_DPP4("", "row_half_mirror");
+        if (G == 16) { MVS_DPP4("", "row_mirror"); }
+    } else { a = group_min_fused<G>(a); b = group_min_fused<G>(b); c = group_min_fused<G>(c); d = group_min_fused<G>(d); }
+}
+#undef MVS_DPP4
 template <int G>
 __device__ __forceinline__ uint32_t group_min_fused(uint32_t v) {
     v = min_step_u<1, G>(v); v = min_step_u<2, G>(v); v = min_step_u<4, G>(v);
@@ -592,18 +609,26 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             const float D = ok[r] ? cost_value(lw[r] >> 16) : HUGE_COST;
             b[r] = __builtin_fmaf(kappa, (cf[0][r] + cf[1][r]) + cf[2][r], D);
         }
+        // the three cavities and the four group minima (of b and of each cavity) in one interleaved reduction
+        float cv[3][4];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[d][r] = __builtin_fmaf(nstep, cf[d][r], b[r]) * oms;
+        float gm = fminf(fminf(b[0], b[1]), fminf(b[2], b[3]));
+        float cm0 = fminf(fminf(cv[0][0], cv[0][1]), fminf(cv[0][2], cv[0][3])), cm1 = fminf(fminf(cv[1][0], cv[1][1]), fminf(cv[1][2], cv[1][3])),
+              cm2 = fminf(fminf(cv[2][0], cv[2][1]), fminf(cv[2][2], cv[2][3]));
+        group_min_fused4<G>(gm, cm0, cm1, cm2);
+        const float cmin3[3] = {cm0, cm1, cm2};
         // decode: first argmin_t b[t] -- the group minimum, then the smallest label attaining it (== the sequential
         // "first minimum": comparisons are exact)
-        const float gm = group_min_fused<G>(fminf(fminf(b[0], b[1]), fminf(b[2], b[3])));
         uint32_t bt = (b[3] == gm) ? t0 + 3u : 0xFFFFFFFFu;
         bt = (b[2] == gm) ? t0 + 2u : bt; bt = (b[1] == gm) ? t0 + 1u : bt; bt = (b[0] == gm) ? t0 : bt;
         bt = group_min_fused<G>(bt);                          // every lane of the group holds the winner
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float c[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = __builtin_fmaf(nstep, cf[d][r], b[r]) * oms;
-            const float cmin = group_min_fused<G>(fminf(fminf(c[0], c[1]), fminf(c[2], c[3])));
+            const float* c = cv[d];
+            const float cmin = cmin3[d];
             // the tile holds cs - cmin (the same subtraction the oracle performs after its gather); the extra slot stays +inf
             *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0] - cmin, c[1] - cmin, c[2] - cmin, c[3] - cmin);
             const uint32_t mw = ident[d] ? ident_word : r_map[d];

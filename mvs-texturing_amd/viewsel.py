@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "csrc", "libmvs_viewsel.so")
+# MVS_VIEWSEL_LIB: another build of the same library (A/B experiments on one GPU box: scripts/variants.sh)
+_LIB_PATH = os.environ.get("MVS_VIEWSEL_LIB") or os.path.join(_HERE, "csrc", "libmvs_viewsel.so")
 
 
 class MvsError(RuntimeError):
