@@ -812,11 +812,10 @@ __global__ void prune_count_kernel(const uint32_t* __restrict__ col_ptr, uint32_
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f <= nf) cnt[f] = f < nf ? min(col_ptr[f + 1] - col_ptr[f], kmax) : 0u;
 }
-constexpr uint32_t PRUNE_TILE = 1024;   // columns up to this length rank their costs out of LDS
+constexpr uint32_t PRUNE_TILE = 1024;   // columns up to this length are selected from registers (16 keys per lane)
 __global__ void __launch_bounds__(256) prune_write_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                           const float* __restrict__ q, uint32_t nf, uint32_t kmax, const uint32_t* __restrict__ new_ptr,
                                                           uint16_t* __restrict__ view2, float* __restrict__ cost2, float* __restrict__ q2) {
-    __shared__ float s_cost[4][PRUNE_TILE];
     const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (f >= nf) return;                                       // wave-uniform
     const uint32_t p0 = col_ptr[f], K = col_ptr[f + 1] - p0, o = new_ptr[f];
@@ -824,17 +823,57 @@ __global__ void __launch_bounds__(256) prune_write_kernel(const uint32_t* __rest
         for (uint32_t t = lane; t < K; t += 64) { view2[o + t] = view_id[p0 + t]; cost2[o + t] = cost[p0 + t]; if (q) q2[o + t] = q[p0 + t]; }
         return;
     }
-    float* tile = s_cost[threadIdx.x >> 6];
-    const bool in_lds = K <= PRUNE_TILE;
-    if (in_lds) for (uint32_t t = lane; t < K; t += 64) tile[t] = cost[p0 + t];   // LDS operations of a wave execute in order: no barrier
+    if (K <= PRUNE_TILE) {
+        // Selection instead of ranking: the kmax smallest (cost, position) pairs are those below the kmax-th smallest cost T, plus
+        // the first (kmax - #below) entries equal to T in position order.  T is built bit by bit (32 steps of "how many keys lie
+        // below this candidate", a ballot and a popcount per register) on order-preserving integer keys held in registers:
+        // ~400 instructions per column where ranking every entry against every other took K^2 / 64 LDS reads (K = 220: ~4400).
+        constexpr int R = (int)(PRUNE_TILE / 64);
+        uint32_t key[R];
+        const uint32_t nreg = (K + 63u) / 64u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t t = (uint32_t)r * 64u + lane;
+            uint32_t k = 0xFFFFFFFFu;
+            if ((uint32_t)r < nreg && t < K) { const uint32_t u = __float_as_uint(cost[p0 + t] + 0.0f); k = (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+            key[r] = k;   // entries beyond the column: the largest key (a real cost is never the NaN pattern that maps there)
+        }
+        auto below = [&](uint32_t T) {
+            uint32_t n = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if ((uint32_t)r < nreg) n += (uint32_t)__popcll(__ballot(key[r] < T));
+            return n;
+        };
+        uint32_t T = 0;
+        for (int bit = 31; bit >= 0; --bit) { const uint32_t Tc = T | (1u << bit); if (below(Tc) <= kmax - 1u) T = Tc; }
+        const uint32_t need_eq = kmax - below(T);   // >= 1: the entry of rank kmax - 1 has key T
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        uint32_t base = 0, eq_seen = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((uint32_t)r >= nreg) break;
+            const uint32_t t = (uint32_t)r * 64u + lane;
+            const bool in = t < K, eq = in && key[r] == T;
+            const unsigned long long eqb = __ballot(eq);
+            const bool keep = in && (key[r] < T || (eq && eq_seen + (uint32_t)__popcll(eqb & lt) < need_eq));
+            const unsigned long long b = __ballot(keep);
+            if (keep) {
+                const uint32_t d = o + base + (uint32_t)__popcll(b & lt);
+                view2[d] = view_id[p0 + t]; cost2[d] = cost[p0 + t]; if (q) q2[d] = q[p0 + t];
+            }
+            base += (uint32_t)__popcll(b); eq_seen += (uint32_t)__popcll(eqb);
+        }
+        return;
+    }
+    // longer columns: rank every entry against the column in global memory
     uint32_t base = 0;
     for (uint32_t t0 = 0; t0 < K; t0 += 64) {
         const uint32_t t = t0 + lane;
         bool keep = false;
         if (t < K) {
-            const float c = in_lds ? tile[t] : cost[p0 + t];
+            const float c = cost[p0 + t];
             uint32_t rank = 0;                                 // entries ordered before t by (cost, position); positions ascend with the view id
-            for (uint32_t u = 0; u < K; ++u) { const float cu = in_lds ? tile[u] : cost[p0 + u]; rank += (cu < c || (cu == c && u < t)) ? 1u : 0u; }
+            for (uint32_t u = 0; u < K; ++u) { const float cu = cost[p0 + u]; rank += (cu < c || (cu == c && u < t)) ? 1u : 0u; }
             keep = rank < kmax;
         }
         const unsigned long long b = __ballot(keep);

@@ -650,6 +650,33 @@ def test_config5_shape_label_compression_equals_the_oracle():
     c.close()
 
 
+@pytest.mark.parametrize("kmax", [1, 7, 64, 255])
+def test_label_compression_with_ties_and_long_columns(kmax):
+    """the selection kernel of the label-space compression on an uploaded table built to hurt: costs drawn from a handful of
+    values (ties everywhere, also exactly at the selection threshold, decided by the view id), columns shorter than kmax,
+    columns around the 64-lane register tiles (63, 64, 65, 1023, 1024) and longer than the 1024 entries the register path
+    holds (the ranking fallback) -- against the oracle's prune_labels"""
+    rng = np.random.default_rng(1000 + kmax)
+    V = 1300
+    lens = np.concatenate([np.array([0, 1, kmax, kmax + 1, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 1200], dtype=np.int64),
+                           rng.integers(0, 400, size=200)])
+    col_ptr = np.zeros(len(lens) + 1, dtype=np.uint32); col_ptr[1:] = np.cumsum(lens)
+    view_id = np.concatenate([np.sort(rng.choice(V, size=int(n), replace=False)) for n in lens]).astype(np.uint16)
+    levels = np.array([0.0, 0.125, 0.25, 0.25000003, 0.5, 0.75, 1.0], dtype=np.float32)
+    cost = levels[rng.integers(0, len(levels), size=int(col_ptr[-1]))].astype(np.float32)
+    smooth = rng.random(int(col_ptr[-1]), dtype=np.float32)
+    cost = np.where(rng.random(int(col_ptr[-1])) < 0.3, smooth, cost).astype(np.float32)   # a third of the entries without ties
+    ref = O.prune_labels(O.CsrNp(len(lens), V, col_ptr, view_id, cost), kmax)
+    c = M.Context(0)
+    c.costs_upload(M.viewsel.DataCosts(len(lens), V, col_ptr, view_id, cost))
+    c.prune_labels(kmax)
+    got = c.costs_download()
+    assert got.nnz == ref.nnz == int(np.minimum(lens, kmax).sum())
+    assert np.array_equal(got.col_ptr, ref.col_ptr) and np.array_equal(got.view_id, ref.view_id)
+    assert np.array_equal(got.cost.view(np.uint32), ref.cost.view(np.uint32))
+    c.close()
+
+
 @pytest.mark.parametrize("name,kw", [("bigfoot", dict()), ("close", dict(outlier_removal="gauss_clamping")), ("tiny", dict(data_term="area", outlier_removal="gauss_damping")),
                                      ("bumpy", dict())])
 def test_wave_per_footprint_kernel_against_the_oracle(name, kw):
