@@ -303,7 +303,6 @@ __global__ void __launch_bounds__(256) csr_write_kernel(const unsigned long long
 // (SEG entries in LDS, each lane walking its views and depositing the entries that fall into the segment), then streams
 // the segment out with full-width stores.  The direct version above writes one 2-byte and one 4-byte element per lane at
 // addresses ~K entries apart: 32-byte sectors of which 2 or 4 bytes are useful (5.7 GB written for 0.53 GB at C3).
-constexpr int CSR_SEG = 2048;
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int src /* wave-uniform */) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
@@ -313,12 +312,16 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 // pass word / base -> quality): 31 k waves x 2 segments x 200 serial round trips were 2.05 ms at C3.  Here lane L fetches
 // the three words of view j0 + L (64 views per round trip), the views that have survivors among the wave's faces are
 // then visited through readlane broadcasts four at a time, and the four quality gathers of a group are in flight together.
+// OUTLIER: the mean colours (three floats per entry) travel with the qualities, in segments of a quarter of the size.
+template <bool OUTLIER>
 __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned long long* __restrict__ surv, const unsigned long long* __restrict__ pass,
-                                                               const uint32_t* __restrict__ pass_base, const float* __restrict__ pq,
+                                                               const uint32_t* __restrict__ pass_base, const float* __restrict__ pq, const float* __restrict__ pcol,
                                                                uint32_t n_views, uint32_t nf, uint32_t fwords, const uint32_t* __restrict__ col_ptr,
-                                                               uint16_t* __restrict__ view_id, float* __restrict__ quality) {
+                                                               uint16_t* __restrict__ view_id, float* __restrict__ quality, float* __restrict__ color) {
+    constexpr int CSR_SEG = OUTLIER ? 512 : 2048;   // shadows the namespace constant: 4 x (2 + 4 [+ 12]) x SEG bytes of LDS per block
     __shared__ float s_q[4][CSR_SEG];
     __shared__ uint16_t s_v[4][CSR_SEG];
+    __shared__ float s_c[4][OUTLIER ? 3 * CSR_SEG : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t word = blockIdx.x * 4 + wv;                 // one wave per 64 faces (no block-level barrier is used)
     if (word >= fwords) return;
@@ -337,7 +340,7 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
             const uint32_t pb_l = pass_base[widx];
             unsigned long long todo = __ballot(sw_l != 0ull);   // views of this round with survivors among the wave's faces
             while (todo != 0ull) {
-                int b[4]; bool on[4]; uint32_t kk[4]; float q[4];
+                int b[4]; bool on[4]; uint32_t kk[4]; float q[4]; float cr[4], cg[4], cb[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     b[u] = (todo != 0ull) ? (int)__builtin_ctzll(todo) : -1;
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    on[u] = false; kk[u] = 0u; q[u] = 0.0f;
+                    on[u] = false; kk[u] = 0u; q[u] = 0.0f; cr[u] = cg[u] = cb[u] = 0.0f;
                     if (b[u] >= 0) {                           // wave-uniform
                         const unsigned long long sw = readlane64(sw_l, b[u]);
                         if ((sw >> lane) & 1ull) {
@@ -353,7 +356,9 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
                                 const unsigned long long pw = readlane64(pw_l, b[u]);
                                 const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)pb_l, b[u]);
                                 on[u] = true; kk[u] = k - segbase;
-                                q[u] = pq[(size_t)pb + __popcll(pw & lt)];
+                                const size_t r = (size_t)pb + __popcll(pw & lt);
+                                q[u] = pq[r];
+                                if (OUTLIER) { cr[u] = pcol[3 * r]; cg[u] = pcol[3 * r + 1]; cb[u] = pcol[3 * r + 2]; }
                             }
                             ++k;
                         }
@@ -361,11 +366,15 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (on[u]) { s_v[wv][kk[u]] = (uint16_t)(j0 + (uint32_t)b[u]); s_q[wv][kk[u]] = q[u]; }
+                    if (on[u]) {
+                        s_v[wv][kk[u]] = (uint16_t)(j0 + (uint32_t)b[u]); s_q[wv][kk[u]] = q[u];
+                        if (OUTLIER) { s_c[wv][3 * kk[u]] = cr[u]; s_c[wv][3 * kk[u] + 1] = cg[u]; s_c[wv][3 * kk[u] + 2] = cb[u]; }
+                    }
             }
         }
         // LDS operations of one wave complete in order: the deposits above are visible to the reads below
         for (uint32_t i = lane; i < segend - segbase; i += 64u) { view_id[segbase + i] = s_v[wv][i]; quality[segbase + i] = s_q[wv][i]; }
+        if (OUTLIER) for (uint32_t i = lane; i < 3u * (segend - segbase); i += 64u) color[3 * (size_t)segbase + i] = s_c[wv][i];
     }
 }
 
@@ -512,21 +521,47 @@ __global__ void max_u32_kernel(const uint32_t* __restrict__ v, uint32_t n, uint3
     if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 
-// remove quality == 0 entries (calculate_data_costs.cpp:268-270)
-__global__ void nonzero_count_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, const float* __restrict__ quality, uint32_t* __restrict__ cnt) {
-    const uint32_t lf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lf > nf) return;
+// remove quality == 0 entries (calculate_data_costs.cpp:268-270).  One wave per 64 consecutive faces, whose columns are one
+// contiguous chunk: the chunk is STREAMED 64 entries at a time (coalesced), never walked column by column.
+//   count: the ballot of "quality != 0" of a tile is handed to every lane, and lane f adds the bits that lie inside its own
+//          column [k0, k1) -- no search for the face an entry belongs to;
+//   copy:  the survivors of the chunk are a contiguous run of the output starting at dst_ptr[first face] (dst_ptr is the scan of
+//          the counts), so the copy is a plain order-preserving compaction: ballot, prefix popcount, store.
+__global__ void __launch_bounds__(256) nonzero_count_kernel(const uint32_t* __restrict__ col_ptr, uint32_t nf, const float* __restrict__ quality, uint32_t* __restrict__ cnt) {
+    const uint32_t word = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t f0 = word * 64u, lf = f0 + lane;
+    if (f0 > nf) return;                                          // wave-uniform (f0 == nf: only the sentinel entry cnt[nf] = 0)
+    const uint32_t c0 = col_ptr[min(f0, nf)], c1 = col_ptr[min(f0 + 64u, nf)];
+    const uint32_t k0 = col_ptr[min(lf, nf)], k1 = col_ptr[min(lf + 1u, nf)];
     uint32_t c = 0;
-    if (lf < nf) for (uint32_t k = col_ptr[lf]; k < col_ptr[lf + 1]; ++k) c += quality[k] != 0.0f;
-    cnt[lf] = c;
+    for (uint32_t t0 = c0; t0 < c1; t0 += 64u) {
+        const uint32_t i = t0 + lane;
+        const unsigned long long nz = __ballot(i < c1 && quality[i] != 0.0f);
+        // bits [lo, hi) of the tile belong to this lane's column
+        const uint32_t lo = max(k0, t0) - t0, hi = min(max(k1, t0), t0 + 64u) - t0;
+        if (hi > lo) {
+            const unsigned long long m = ((hi >= 64u) ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            c += (uint32_t)__popcll(nz & m);
+        }
+    }
+    if (lf <= nf) cnt[lf] = (lf < nf) ? c : 0u;
 }
-__global__ void nonzero_copy_kernel(const uint32_t* __restrict__ src_ptr, const uint32_t* __restrict__ dst_ptr, uint32_t nf,
-                                    const uint16_t* __restrict__ sv, const float* __restrict__ sq, uint16_t* __restrict__ dv, float* __restrict__ dq) {
-    const uint32_t lf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lf >= nf) return;
-    uint32_t d = dst_ptr[lf];
-    for (uint32_t k = src_ptr[lf]; k < src_ptr[lf + 1]; ++k)
-        if (sq[k] != 0.0f) { dv[d] = sv[k]; dq[d] = sq[k]; ++d; }
+__global__ void __launch_bounds__(256) nonzero_copy_kernel(const uint32_t* __restrict__ src_ptr, const uint32_t* __restrict__ dst_ptr, uint32_t nf,
+                                                           const uint16_t* __restrict__ sv, const float* __restrict__ sq, uint16_t* __restrict__ dv, float* __restrict__ dq) {
+    const uint32_t word = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t f0 = word * 64u;
+    if (f0 >= nf) return;                                         // wave-uniform
+    const uint32_t c0 = src_ptr[f0], c1 = src_ptr[min(f0 + 64u, nf)];
+    uint32_t d = dst_ptr[f0];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t t0 = c0; t0 < c1; t0 += 64u) {
+        const uint32_t i = t0 + lane;
+        const float q = (i < c1) ? sq[i] : 0.0f;
+        const bool keep = i < c1 && q != 0.0f;
+        const unsigned long long b = __ballot(keep);
+        if (keep) { const uint32_t o = d + (uint32_t)__popcll(b & lt); dv[o] = sv[i]; dq[o] = q; }
+        d += (uint32_t)__popcll(b);
+    }
 }
 
 // ---- postprocess_face_infos (calculate_data_costs.cpp:278-302) ----
@@ -770,24 +805,24 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     if (outl) {
         ctx->pre_view.ensure((size_t)nnz_pre + 1); ctx->pre_q.ensure((size_t)nnz_pre + 1); ctx->pre_col.ensure(3 * ((size_t)nnz_pre + 1));
         ctx->pre_inl.ensure((size_t)nnz_pre + 1);
-        hipLaunchKernelGGL(csr_write_kernel<true>, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
+        hipLaunchKernelGGL(csr_write_staged_kernel<true>, dim3((fwords + 3) / 4), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
                            ctx->pq.p, ctx->pcol.p, V, nf, fwords, ctx->pre_ptr.p, ctx->pre_view.p, ctx->pre_q.p, ctx->pre_col.p);
         MVS_LAUNCH_CHECK();
         launch_outlier(ctx, ctx->pre_ptr.p, ctx->face_cnt.p /* still the per-face counts of csr_count_kernel */, 0u, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p, st->outlier_removal);
-        hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf + 256) / 256), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
+        hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf / 64u + 1u + 3u) / 4u), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
         MVS_LAUNCH_CHECK();
         ctx->csr_ptr.ensure((size_t)nf + 2);
         exclusive_scan_u32(ctx, ctx->face_cnt.p, ctx->csr_ptr.p, (size_t)nf + 1, nullptr);
         const uint32_t nnz = read_u32(ctx, ctx->csr_ptr.p + nf);
         ctx->csr_view.ensure((size_t)nnz + 1); ctx->csr_q.ensure((size_t)nnz + 1); ctx->csr_cost.ensure((size_t)nnz + 1);
-        hipLaunchKernelGGL(nonzero_copy_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->pre_ptr.p, ctx->csr_ptr.p, nf, ctx->pre_view.p, ctx->pre_q.p,
+        hipLaunchKernelGGL(nonzero_copy_kernel, dim3(((nf + 63u) / 64u + 3u) / 4u), dim3(256), 0, s, ctx->pre_ptr.p, ctx->csr_ptr.p, nf, ctx->pre_view.p, ctx->pre_q.p,
                            ctx->csr_view.p, ctx->csr_q.p);
         MVS_LAUNCH_CHECK();
         ctx->csr_nnz = nnz;
     } else {
         ctx->csr_view.ensure((size_t)nnz_pre + 1); ctx->csr_q.ensure((size_t)nnz_pre + 1); ctx->csr_cost.ensure((size_t)nnz_pre + 1);
-        hipLaunchKernelGGL(csr_write_staged_kernel, dim3((fwords + 3) / 4), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
-                           ctx->pq.p, V, nf, fwords, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_q.p);
+        hipLaunchKernelGGL(csr_write_staged_kernel<false>, dim3((fwords + 3) / 4), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
+                           ctx->pq.p, (const float*)nullptr, V, nf, fwords, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_q.p, (float*)nullptr);
         MVS_LAUNCH_CHECK();
         ctx->csr_nnz = nnz_pre;
     }
@@ -931,7 +966,7 @@ void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t*
     ctx->face_cnt.ensure((size_t)nf + 2); ctx->csr_ptr.ensure((size_t)nf + 2);
     uint32_t nnz = n;
     if (outl) {   // the zero-quality erase belongs to the outlier branch (:265-271): without outlier removal every info stays
-        hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf + 256) / 256), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
+        hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf / 64u + 1u + 3u) / 4u), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
         MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, ctx->face_cnt.p, ctx->csr_ptr.p, (size_t)nf + 1, nullptr);
         nnz = read_u32(ctx, ctx->csr_ptr.p + nf);
@@ -939,7 +974,7 @@ void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t*
     ctx->csr_view.ensure((size_t)nnz + 1); ctx->csr_q.ensure((size_t)nnz + 1); ctx->csr_cost.ensure((size_t)nnz + 8);
     if (nf) {
         if (outl) {
-            hipLaunchKernelGGL(nonzero_copy_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, ctx->pre_ptr.p, ctx->csr_ptr.p, nf, ctx->pre_view.p, ctx->pre_q.p, ctx->csr_view.p, ctx->csr_q.p);
+            hipLaunchKernelGGL(nonzero_copy_kernel, dim3(((nf + 63u) / 64u + 3u) / 4u), dim3(256), 0, s, ctx->pre_ptr.p, ctx->csr_ptr.p, nf, ctx->pre_view.p, ctx->pre_q.p, ctx->csr_view.p, ctx->csr_q.p);
             MVS_LAUNCH_CHECK();
         } else if (n) {
             MVS_HIP(hipMemcpyAsync(ctx->csr_view.p, ctx->pre_view.p, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
