@@ -468,9 +468,20 @@ __global__ void __launch_bounds__(64) outlier_kernel(const uint32_t* __restrict_
         if (n_in < 4) return;
         // every sum keeps the reference's order (its own sequence of additions); the three means, then the nine covariance
         // entries, are accumulated side by side in ONE walk each: independent fp64 chains, one read of the colours per walk
+        // The walks are unrolled by four with the skipped entries turned into additions of +0.0 (exact: an accumulator that
+        // starts at +0.0 never becomes -0.0, and x + 0.0 == x): straight-line code whose twelve colour reads are in flight
+        // together -- with one wave per SIMD (the LDS footprint of the colours) nothing else hides their latency.
         {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-            for (int64_t k = n - 1; k >= 0; --k) {
+            int64_t k = n - 1;
+            for (; k >= 3; k -= 4) {
+                float c[4][3]; bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { in[u] = INL(k - u) != 0; c[u][0] = COL(k - u, 0); c[u][1] = COL(k - u, 1); c[u][2] = COL(k - u, 2); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s0 += (double)(in[u] ? c[u][0] : 0.0f); s1 += (double)(in[u] ? c[u][1] : 0.0f); s2 += (double)(in[u] ? c[u][2] : 0.0f); }
+            }
+            for (; k >= 0; --k) {
                 if (!INL(k)) continue;
                 s0 += (double)COL(k, 0); s1 += (double)COL(k, 1); s2 += (double)COL(k, 2);
             }
@@ -478,12 +489,25 @@ __global__ void __launch_bounds__(64) outlier_kernel(const uint32_t* __restrict_
         }
         {
             double sc9[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-            for (int64_t k = n - 1; k >= 0; --k) {
-                if (!INL(k)) continue;
-                const double d0 = (double)COL(k, 0) - mean[0], d1 = (double)COL(k, 1) - mean[1], d2 = (double)COL(k, 2) - mean[2];
+            auto acc = [&](double d0, double d1, double d2) {
                 sc9[0][0] += d0 * d0; sc9[0][1] += d0 * d1; sc9[0][2] += d0 * d2;
                 sc9[1][0] += d1 * d0; sc9[1][1] += d1 * d1; sc9[1][2] += d1 * d2;
                 sc9[2][0] += d2 * d0; sc9[2][1] += d2 * d1; sc9[2][2] += d2 * d2;
+            };
+            int64_t k = n - 1;
+            for (; k >= 3; k -= 4) {
+                float c[4][3]; bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { in[u] = INL(k - u) != 0; c[u][0] = COL(k - u, 0); c[u][1] = COL(k - u, 1); c[u][2] = COL(k - u, 2); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {   // a skipped entry contributes products of +0.0
+                    const double d0 = in[u] ? (double)c[u][0] - mean[0] : 0.0, d1 = in[u] ? (double)c[u][1] - mean[1] : 0.0, d2 = in[u] ? (double)c[u][2] - mean[2] : 0.0;
+                    acc(d0, d1, d2);
+                }
+            }
+            for (; k >= 0; --k) {
+                if (!INL(k)) continue;
+                acc((double)COL(k, 0) - mean[0], (double)COL(k, 1) - mean[1], (double)COL(k, 2) - mean[2]);
             }
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[a][b] = sc9[a][b] / (double)(n_in - 1);
         }
