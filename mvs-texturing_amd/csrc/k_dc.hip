@@ -521,11 +521,21 @@ __global__ void __launch_bounds__(64) outlier_kernel(const uint32_t* __restrict_
         if (!lu.invertible()) return;
         lu.inverse(ci);
         n_in = 0;
-        for (int64_t k = n - 1; k >= 0; --k) {
-            const double c[3] = {(double)COL(k, 0), (double)COL(k, 1), (double)COL(k, 2)};
-            const uint8_t in = gauss_at_least_threshold(multi_gauss_arg(c, mean, ci)) ? 1 : 0;
-            SET_INL(k, in);
-            n_in += in;
+        {
+            int64_t k = n - 1;
+            for (; k >= 3; k -= 4) {   // four independent entries at a time: their reads and fp64 chains overlap
+                double a4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const double c[3] = {(double)COL(k - u, 0), (double)COL(k - u, 1), (double)COL(k - u, 2)}; a4[u] = multi_gauss_arg(c, mean, ci); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint8_t in = gauss_at_least_threshold(a4[u]) ? 1 : 0; SET_INL(k - u, in); n_in += in; }
+            }
+            for (; k >= 0; --k) {
+                const double c[3] = {(double)COL(k, 0), (double)COL(k, 1), (double)COL(k, 2)};
+                const uint8_t in = gauss_at_least_threshold(multi_gauss_arg(c, mean, ci)) ? 1 : 0;
+                SET_INL(k, in);
+                n_in += in;
+            }
         }
     }
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) ci[a][b] *= (double)factor;
