@@ -276,33 +276,11 @@ __global__ void __launch_bounds__(256) csr_count_kernel(const unsigned long long
     if (lf == 0) cnt[nf] = 0;  // sentinel so that the scan of nf + 1 entries yields col_ptr[nf] = nnz
 }
 
-template <bool OUTLIER>
-__global__ void __launch_bounds__(256) csr_write_kernel(const unsigned long long* __restrict__ surv, const unsigned long long* __restrict__ pass,
-                                                        const uint32_t* __restrict__ pass_base, const float* __restrict__ pq, const float* __restrict__ pcol,
-                                                        uint32_t n_views, uint32_t nf, uint32_t fwords, const uint32_t* __restrict__ col_ptr,
-                                                        uint16_t* __restrict__ view_id, float* __restrict__ quality, float* __restrict__ color) {
-    const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
-    if ((lf >> 6) >= fwords) return;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    size_t k = (lf < nf) ? col_ptr[lf] : 0;
-    for (uint32_t j = 0; j < n_views; ++j) {
-        const size_t widx = (size_t)j * fwords + (lf >> 6);
-        const unsigned long long s = surv[widx];
-        if (!((s >> lane) & 1ull)) continue;
-        const size_t r = (size_t)pass_base[widx] + __popcll(pass[widx] & lt);
-        view_id[k] = (uint16_t)j;
-        quality[k] = pq[r];
-        if (OUTLIER) { color[3 * k] = pcol[3 * r]; color[3 * k + 1] = pcol[3 * r + 1]; color[3 * k + 2] = pcol[3 * r + 2]; }
-        ++k;
-    }
-}
-
-// Default path (no outlier removal): the same scatter, staged through LDS so that HBM sees coalesced rows.  A wave owns
+// The per-face scatter of the surviving pairs into CSR columns, staged through LDS so that HBM sees coalesced rows.  A wave owns
 // 64 consecutive faces, whose CSR columns form ONE contiguous chunk of the output; it fills the chunk segment by segment
 // (SEG entries in LDS, each lane walking its views and depositing the entries that fall into the segment), then streams
-// the segment out with full-width stores.  The direct version above writes one 2-byte and one 4-byte element per lane at
-// addresses ~K entries apart: 32-byte sectors of which 2 or 4 bytes are useful (5.7 GB written for 0.53 GB at C3).
+// the segment out with full-width stores.  A direct scatter (one thread per face walking its views) writes one 2-byte and one
+// 4-byte element per lane at addresses ~K entries apart: 32-byte sectors of which 2 or 4 bytes are useful (5.7 GB written for 0.53 GB at C3).
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int src /* wave-uniform */) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
