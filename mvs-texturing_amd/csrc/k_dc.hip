@@ -295,7 +295,8 @@ template <bool OUTLIER>
 __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned long long* __restrict__ surv, const unsigned long long* __restrict__ pass,
                                                                const uint32_t* __restrict__ pass_base, const float* __restrict__ pq, const float* __restrict__ pcol,
                                                                uint32_t n_views, uint32_t nf, uint32_t fwords, const uint32_t* __restrict__ col_ptr,
-                                                               uint16_t* __restrict__ view_id, float* __restrict__ quality, float* __restrict__ color) {
+                                                               uint16_t* __restrict__ view_id, float* __restrict__ quality, float* __restrict__ color,
+                                                               uint32_t* __restrict__ max_bits /* non-null: also the maximum quality (:278-281), saving a pass over the table */) {
     constexpr int CSR_SEG = OUTLIER ? 512 : 2048;   // shadows the namespace constant: 4 x (2 + 4 [+ 12]) x SEG bytes of LDS per block
     __shared__ float s_q[4][CSR_SEG];
     __shared__ uint16_t s_v[4][CSR_SEG];
@@ -307,6 +308,7 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t c0 = col_ptr[f0], c1 = col_ptr[min(f0 + 64u, nf)];
     const uint32_t k0 = col_ptr[min(lf, nf)];
+    float qmax = 0.0f;   // :278 max_quality = 0.0f
     for (uint32_t segbase = c0; segbase < c1; segbase += CSR_SEG) {
         const uint32_t segend = min(segbase + (uint32_t)CSR_SEG, c1);
         uint32_t k = k0;
@@ -351,8 +353,12 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
             }
         }
         // LDS operations of one wave complete in order: the deposits above are visible to the reads below
-        for (uint32_t i = lane; i < segend - segbase; i += 64u) { view_id[segbase + i] = s_v[wv][i]; quality[segbase + i] = s_q[wv][i]; }
+        for (uint32_t i = lane; i < segend - segbase; i += 64u) { const float qv = s_q[wv][i]; view_id[segbase + i] = s_v[wv][i]; quality[segbase + i] = qv; qmax = fmaxf(qmax, qv); }
         if (OUTLIER) for (uint32_t i = lane; i < 3u * (segend - segbase); i += 64u) color[3 * (size_t)segbase + i] = s_c[wv][i];
+    }
+    if (max_bits) {   // qualities are > 0: uint order = float order; only a wave that can raise the maximum issues the atomic
+        for (int o = 32; o > 0; o >>= 1) qmax = fmaxf(qmax, __shfl_xor(qmax, o, 64));
+        if (lane == 0 && __float_as_uint(qmax) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, __float_as_uint(qmax));
     }
 }
 
@@ -818,7 +824,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         ctx->pre_view.ensure((size_t)nnz_pre + 1); ctx->pre_q.ensure((size_t)nnz_pre + 1); ctx->pre_col.ensure(3 * ((size_t)nnz_pre + 1));
         ctx->pre_inl.ensure((size_t)nnz_pre + 1);
         hipLaunchKernelGGL(csr_write_staged_kernel<true>, dim3((fwords + 3) / 4), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
-                           ctx->pq.p, ctx->pcol.p, V, nf, fwords, ctx->pre_ptr.p, ctx->pre_view.p, ctx->pre_q.p, ctx->pre_col.p);
+                           ctx->pq.p, ctx->pcol.p, V, nf, fwords, ctx->pre_ptr.p, ctx->pre_view.p, ctx->pre_q.p, ctx->pre_col.p, (uint32_t*)nullptr);
         MVS_LAUNCH_CHECK();
         launch_outlier(ctx, ctx->pre_ptr.p, ctx->face_cnt.p /* still the per-face counts of csr_count_kernel */, 0u, nf, ctx->pre_col.p, ctx->pre_q.p, ctx->pre_inl.p, st->outlier_removal);
         hipLaunchKernelGGL(nonzero_count_kernel, dim3((nf / 64u + 1u + 3u) / 4u), dim3(256), 0, s, ctx->pre_ptr.p, nf, ctx->pre_q.p, ctx->face_cnt.p);
@@ -833,19 +839,22 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         ctx->csr_nnz = nnz;
     } else {
         ctx->csr_view.ensure((size_t)nnz_pre + 1); ctx->csr_q.ensure((size_t)nnz_pre + 1); ctx->csr_cost.ensure((size_t)nnz_pre + 1);
+        MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));   // the kernel also leaves the maximum quality behind
         hipLaunchKernelGGL(csr_write_staged_kernel<false>, dim3((fwords + 3) / 4), dim3(256), 0, s, ctx->surv_bits.p, ctx->pass_bits.p, ctx->pass_base.p,
-                           ctx->pq.p, (const float*)nullptr, V, nf, fwords, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_q.p, (float*)nullptr);
+                           ctx->pq.p, (const float*)nullptr, V, nf, fwords, ctx->csr_ptr.p, ctx->csr_view.p, ctx->csr_q.p, (float*)nullptr, (uint32_t*)ctx->max_q.p);
         MVS_LAUNCH_CHECK();
         ctx->csr_nnz = nnz_pre;
     }
     pr_csr.end();
     Prof pr_post(ctx, "dc_post");
     ctx->csr_faces = nf; ctx->csr_views = V;
-    // local max quality (:278-281)
-    MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
-    if (ctx->csr_nnz) {
-        hipLaunchKernelGGL(max_kernel, dim3(1024), dim3(256), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, (uint32_t*)ctx->max_q.p);
-        MVS_LAUNCH_CHECK();
+    // local max quality (:278-281): after outlier removal a pass of its own, otherwise left behind by the CSR kernel
+    if (outl) {
+        MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 2 * sizeof(float), s));
+        if (ctx->csr_nnz) {
+            hipLaunchKernelGGL(max_kernel, dim3(1024), dim3(256), 0, s, ctx->csr_q.p, (size_t)ctx->csr_nnz, (uint32_t*)ctx->max_q.p);
+            MVS_LAUNCH_CHECK();
+        }
     }
     ctx->dc_phase = 1;
 }
