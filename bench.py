@@ -310,6 +310,8 @@ def main():
             if "shard" not in info:
                 err = None
                 try:
+                    if os.environ.get("MVS_BENCH_FORCE_PY_SHARD"):   # test hook: exercise the fallback below
+                        raise RuntimeError("forced by MVS_BENCH_FORCE_PY_SHARD")
                     uid = [M.shard.unique_id() if rank == 0 else None]
                     if dist is not None:
                         dist.broadcast_object_list(uid, src=0)
