@@ -239,6 +239,22 @@ __global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict_
     for (int y = y_begin + dy; y < y_end; y += ROWS) {
         int xb, xe;
         if (!foot_row(s, y, &xb, &xe)) continue;
+        if (DATA_TERM == 1 && !OUTLIER && s.fast && xe > xb) {
+            // gradient magnitudes only, whole spans: four pixels per load.  The groups are aligned in ADDRESS space (the first one
+            // starts at or up to three bytes before the span), bytes outside [xb, xe) are masked, v_sad_u8 adds the four bytes
+            // of a word in one instruction.  Integer sums of the same pixels: identical result.  (gmi points into the context's
+            // own padded buffer: an aligned word around a valid pixel is always inside it.)
+            const uint8_t* rowp = gimg + (size_t)y * w;
+            const int x_al = xb - (int)(reinterpret_cast<uintptr_t>(rowp + xb) & 3u);
+            for (int x0 = x_al + 4 * dx; x0 < xe; x0 += 4 * COLS) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + x0);
+                const int lo = max(xb - x0, 0), hi = min(xe - x0, 4);          // bytes [lo, hi) of the word are pixels of the span
+                const uint32_t m = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+                g = __builtin_amdgcn_sad_u8(v & m, 0u, g);
+                n += (uint32_t)(hi - lo);
+            }
+            continue;
+        }
         for (int x = xb + dx; x < xe; x += COLS) {
             if (!s.fast && !foot_inside(s, x, y)) continue;
             const size_t pix = (size_t)x + (size_t)y * w;
