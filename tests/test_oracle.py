@@ -385,3 +385,24 @@ def test_undistortion_models_row_f4():
         m = inside & (sx > 1) & (sx < w - 2) & (sy > 1) & (sy < h - 2)
         assert np.abs(out[..., 0][m] - sx[m]).max() <= 0.51 and np.abs(out[..., 1][m] - sy[m]).max() <= 0.51   # bilinear of a ramp = the position, rounded
         assert m.mean() > 0.7
+
+
+@pytest.mark.parametrize("kmax", [1, 5, 64])
+def test_label_compression_restatement_against_numpy(kmax):
+    """orc_prune_labels (the definition of the `max_labels` option): per face the kmax entries with the smallest (cost, view id)
+    pairs, kept in ascending view order -- against a plain numpy lexsort, on a table full of cost ties"""
+    rng = np.random.default_rng(7 + kmax)
+    V = 300
+    lens = np.concatenate([np.array([0, 1, kmax, kmax + 1, 130], dtype=np.int64), rng.integers(0, 120, size=60)])
+    col_ptr = np.zeros(len(lens) + 1, dtype=np.uint32); col_ptr[1:] = np.cumsum(lens)
+    view_id = np.concatenate([np.sort(rng.choice(V, size=int(n), replace=False)) for n in lens]).astype(np.uint16)
+    cost = rng.choice(np.array([0.0, 0.25, 0.5, 0.50000006, 1.0], dtype=np.float32), size=int(col_ptr[-1])).astype(np.float32)
+    got = O.prune_labels(O.CsrNp(len(lens), V, col_ptr, view_id, cost), kmax)
+    exp_v, exp_c, exp_ptr = [], [], [0]
+    for f in range(len(lens)):
+        a, b = int(col_ptr[f]), int(col_ptr[f + 1])
+        v, c = view_id[a:b], cost[a:b]
+        keep = np.sort(np.lexsort((v, c))[:kmax])          # smallest (cost, view id) pairs, back in view order
+        exp_v.append(v[keep]); exp_c.append(c[keep]); exp_ptr.append(exp_ptr[-1] + len(keep))
+    assert np.array_equal(got.col_ptr, np.array(exp_ptr, dtype=np.uint32))
+    assert np.array_equal(got.view_id, np.concatenate(exp_v)) and np.array_equal(got.cost.view(np.uint32), np.concatenate(exp_c).view(np.uint32))
