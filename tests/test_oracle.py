@@ -406,3 +406,43 @@ def test_label_compression_restatement_against_numpy(kmax):
         exp_v.append(v[keep]); exp_c.append(c[keep]); exp_ptr.append(exp_ptr[-1] + len(keep))
     assert np.array_equal(got.col_ptr, np.array(exp_ptr, dtype=np.uint32))
     assert np.array_equal(got.view_id, np.concatenate(exp_v)) and np.array_equal(got.cost.view(np.uint32), np.concatenate(exp_c).view(np.uint32))
+
+
+def test_ray_predicate_agrees_with_exact_geometry_away_from_boundaries():
+    """the occlusion predicate DEFINED by this repository (Moeller-Trumbore in fp32 with fused multiply-adds, oracle.cpp ray_tri)
+    against an fp64 segment / triangle intersection: whenever the exact barycentrics and the exact distance are clear of
+    their limits by 1e-4, the boolean is the geometric truth -- also for rays that start ON the triangle's plane neighbours
+    (the reference's rays start at mesh vertices) and for both orientations of the triangle"""
+    rng = np.random.default_rng(42)
+    L = O.load()
+    checked = hits = 0
+    for _ in range(4000):
+        tri = rng.uniform(-1, 1, size=(3, 3)).astype(np.float32)
+        if rng.random() < 0.5:
+            tri = tri[::-1].copy()                                   # flipped winding: det changes sign
+        o = rng.uniform(-2, 2, size=3).astype(np.float32)
+        p = rng.uniform(-2, 2, size=3).astype(np.float32)
+        a, b, c = (tri[k].astype(np.float64) for k in range(3))
+        e1, e2 = b - a, c - a
+        d = p.astype(np.float64) - o.astype(np.float64)
+        n = np.cross(e1, e2)
+        den = float(np.dot(n, d))
+        if abs(den) < 1e-3 or np.linalg.norm(n) < 1e-2:
+            continue                                                 # nearly parallel or degenerate: not "away from boundaries"
+        s = float(np.dot(n, a - o.astype(np.float64))) / den         # hit at o + s d, s in [0, 1] along the segment
+        q = o.astype(np.float64) + s * d
+        m = np.array([e1, e2]).T
+        uv, *_ = np.linalg.lstsq(m, q - a, rcond=None)
+        u, v = float(uv[0]), float(uv[1])
+        margins = [u, v, 1.0 - u - v, s - 1e-4, 1.0 - s]
+        if min(abs(x) for x in margins) < 1e-4:
+            continue                                                 # too close to an edge of the triangle or an end of the segment
+        truth = all(x > 0 for x in margins)
+        verts = np.ascontiguousarray(tri, dtype=np.float32)
+        faces = np.array([[0, 1, 2]], dtype=np.uint32)
+        normals = np.zeros((1, 3), dtype=np.float32)
+        mesh = O.Mesh(3, 1, verts.ctypes.data, faces.ctypes.data, normals.ctypes.data)
+        got = L.orc_ray_occluded(None, C.byref(mesh), o.ctypes.data, p.ctypes.data, 1)
+        assert bool(got) == truth, (tri, o, p, margins)
+        checked += 1; hits += truth
+    assert checked > 2500 and 100 < hits < checked - 100
