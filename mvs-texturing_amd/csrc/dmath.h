@@ -110,6 +110,35 @@ MVS_HD int cull_pair(const ViewParams& v, V3 v1, V3 v2, V3 v3, V3 face_normal, f
     return cull_pixels(v, v1, v2, v3);
 }
 
+// cull_pair with its clear cases decided WITHOUT the two normalisations (2 sqrt + 6 correctly rounded divisions per pair): the
+// culls kernel's entry point; identical reason codes (tests/test_host.py compares it with cull_pair on adversarial pairs).
+//  * first cull (:183-185: the face looks away from the view, or lies behind it).  With d = view_pos - centre exactly as
+//    cull_pair forms it, the reference's viewing_angle = dot(d / |d|, n) evaluated in fp32 differs from dot(d, n) / |d| by less
+//    than 4e-7 A / |d|, A = sum |d_k n_k|, and the unnormalised fp32 dot from its exact value by less than 2e-7 A: dot(d, n) <
+//    -4e-6 A therefore implies viewing_angle < 0 with a tenfold margin; likewise for dot(viewdir, -d);
+//  * angle cull (:187-188), only when both dot products are as clearly on the FRONT side (reason 1 excluded): s = sqrt(dd)
+//    differs from |d| by less than 4e-7 |d| (correctly rounded on the host, 1 ulp on the device: both inside the margin), so
+//    comparing un -+ 4e-6 A with cos_limit s (1 +- 4e-6) decides `viewing_angle < cos_limit`;
+//  * everything in between takes cull_pair unchanged.  (A NaN cos_limit -- host_cos_limit's failure value -- fails both
+//    comparisons and falls through to cull_pair.)
+MVS_HD int cull_pair_prefiltered(const ViewParams& vw, V3 v1, V3 v2, V3 v3, V3 nrm, V3 centre /* ((v1 + v2) + v3) / 3 */, float cos_limit) {
+    const V3 d = V3{vw.pos[0], vw.pos[1], vw.pos[2]} - centre;
+    const float un = (d.x * nrm.x + d.y * nrm.y) + d.z * nrm.z, an = (fabsf(d.x * nrm.x) + fabsf(d.y * nrm.y)) + fabsf(d.z * nrm.z);
+    const float uv = (d.x * vw.viewdir[0] + d.y * vw.viewdir[1]) + d.z * vw.viewdir[2],
+                av = (fabsf(d.x * vw.viewdir[0]) + fabsf(d.y * vw.viewdir[1])) + fabsf(d.z * vw.viewdir[2]);
+    if ((un < -4e-6f * an) || (uv > 4e-6f * av)) return 1;      // dot(viewdir, centre - pos) = -uv < 0
+    const bool clear_front = (un > 4e-6f * an) && (uv < -4e-6f * av);
+    const float dd = (d.x * d.x + d.y * d.y) + d.z * d.z;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float ls = cos_limit * __builtin_amdgcn_sqrtf(dd);
+#else
+    const float ls = cos_limit * sqrtf(dd);
+#endif
+    if (clear_front && un + 4e-6f * an <= ls * (1.0f - 4e-6f)) return 2;
+    if (clear_front && un - 4e-6f * an >= ls * (1.0f + 4e-6f)) return cull_pixels(vw, v1, v2, v3);
+    return cull_pair(vw, v1, v2, v3, nrm, cos_limit);
+}
+
 // Visibility ray of calculate_data_costs.cpp:200-206: origin = vertex,
 // dir = normalised (view_pos - origin), tmax = |view_pos - origin|, tmin = 1e-4 tmax.
 // `pad` is the scene-scale slack of the hit predicate (see ray_tri).

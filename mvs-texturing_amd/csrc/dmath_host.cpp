@@ -43,6 +43,21 @@ void dmh_cull_all(const dmh_view* views, uint32_t n_views, const float* verts, c
     }
 }
 
+// the culls kernel's entry point (clear cases without normalisations) next to plain cull_pair, for n independent pairs:
+// view pose, triangle, normal given per pair; out[2 * i] = cull_pair, out[2 * i + 1] = cull_pair_prefiltered
+void dmh_cull_pairs(const dmh_view* base, uint32_t n, const float* pos, const float* viewdir, const float* tri9, const float* normal,
+                    float cos_limit, int8_t* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        ViewParams vp = to_vp(base);
+        for (int a = 0; a < 3; ++a) { vp.pos[a] = pos[3 * i + a]; vp.viewdir[a] = viewdir[3 * i + a]; }
+        const float* t = tri9 + 9 * (size_t)i;
+        const V3 v1 = {t[0], t[1], t[2]}, v2 = {t[3], t[4], t[5]}, v3 = {t[6], t[7], t[8]}, nr = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+        const V3 centre = ((v1 + v2) + v3) / 3.0f;
+        out[2 * i] = (int8_t)cull_pair(vp, v1, v2, v3, nr, cos_limit);
+        out[2 * i + 1] = (int8_t)cull_pair_prefiltered(vp, v1, v2, v3, nr, centre, cos_limit);
+    }
+}
+
 // quality / YCbCr mean colour of one (face, view) pair
 void dmh_face_info(const dmh_view* view, int data_term, int outlier, const float* v1, const float* v2, const float* v3,
                    float* quality, float* ycbcr) {

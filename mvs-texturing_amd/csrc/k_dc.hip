@@ -63,37 +63,12 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     uint32_t cnt[4] = {0, 0, 0, 0};
-    // Clear cases of the first cull (calculate_data_costs.cpp:183-185: the face looks away from the view, or lies behind it)
-    // are decided without the two normalisations (2 sqrt + 6 correctly rounded divisions per pair, half of all pairs): with
-    // d = view_pos - centre exactly as cull_pair forms it, the reference's viewing_angle = dot(d / |d|, n) evaluated in
-    // fp32 differs from dot(d, n) / |d| by at most 6 * 2^-24 * A / |d|, A = sum |d_k n_k|, and the unnormalised fp32 dot from
-    // its exact value by 3 * 2^-24 * A: dot(d, n) < -4e-6 * A therefore implies viewing_angle < 0 -- with an eightfold margin.
-    // Likewise for dot(viewdir, -d).  Everything else takes cull_pair unchanged; the reason code (1) is the same.
+    // the clear cases of the first two culls are decided without normalisations: dmath.h cull_pair_prefiltered
     const V3 centre = ((v1 + v2) + v3) / 3.0f;
     if (wave_ok) {
         for (uint32_t j = j0; j < j1; ++j) {
             const ViewParams& vw = views[j];
-            const V3 d = V3{vw.pos[0], vw.pos[1], vw.pos[2]} - centre;
-            const float un = (d.x * nrm.x + d.y * nrm.y) + d.z * nrm.z, an = (fabsf(d.x * nrm.x) + fabsf(d.y * nrm.y)) + fabsf(d.z * nrm.z);
-            const float uv = (d.x * vw.viewdir[0] + d.y * vw.viewdir[1]) + d.z * vw.viewdir[2], av = (fabsf(d.x * vw.viewdir[0]) + fabsf(d.y * vw.viewdir[1])) + fabsf(d.z * vw.viewdir[2]);
-            const bool clear_back = (un < -4e-6f * an) || (uv > 4e-6f * av);      // dot(viewdir, centre - pos) = -uv < 0
-            int reason = -1;
-            if (act) {
-                if (clear_back) reason = 1;
-                else {
-                    // Clear cases of the angle cull (:187-188) without the normalisations as well.  With both dot products
-                    // clearly on the front side (same margins as above) reason 1 is excluded; the reference's
-                    // viewing_angle (fp32) differs from dot(d, n) / |d| by less than 4e-7 A / |d|, this kernel's un from
-                    // dot(d, n) by less than 2e-7 A, and s = v_sqrt(dd) from |d| by less than 4e-7 |d|: comparing
-                    // un -+ 4e-6 A with cos_limit s (1 +- 4e-6) decides `viewing_angle < cos_limit` with a tenfold margin.
-                    // Everything in between takes cull_pair unchanged.
-                    const bool clear_front = (un > 4e-6f * an) && (uv < -4e-6f * av);
-                    const float ls = cos_limit * __builtin_amdgcn_sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
-                    if (clear_front && un + 4e-6f * an <= ls * (1.0f - 4e-6f)) reason = 2;
-                    else if (clear_front && un - 4e-6f * an >= ls * (1.0f + 4e-6f)) reason = cull_pixels(vw, v1, v2, v3);
-                    else reason = cull_pair(vw, v1, v2, v3, nrm, cos_limit);
-                }
-            }
+            const int reason = act ? cull_pair_prefiltered(vw, v1, v2, v3, nrm, centre, cos_limit) : -1;
             if (STATS) { cnt[0] += reason == 1; cnt[1] += reason == 2; cnt[2] += reason == 3; cnt[3] += reason == 0; }
             const unsigned long long b = __ballot(reason == 0);
             if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;

@@ -262,3 +262,48 @@ def test_hilbert_index_is_a_hilbert_curve(tmp_path):
     out = np.zeros(len(q), np.uint32)
     L.hil(q.ctypes.data_as(C.c_void_p), len(q), out.ctypes.data_as(C.c_void_p))
     assert np.array_equal(out, G._hilbert30(q))
+
+
+def test_cull_prefilter_equals_cull_pair_on_adversarial_pairs():
+    """the culls kernel decides clear cases without normalisations (dmath.h cull_pair_prefiltered): against plain cull_pair on
+    random pairs AND on pairs constructed to sit on the thresholds -- viewing angle within a few ulps of 0 and of cos 75 deg,
+    the face centre within ulps of the camera's image plane -- over six orders of magnitude of scene scale"""
+    from mvs_texturing_amd import build as B
+    B.build_host()
+    D = C.CDLL(os.path.join(ROOT, "mvs-texturing_amd", "csrc", "libmvs_dmath_host.so"))
+    D.dmh_cos_limit.restype = C.c_float
+    cl = D.dmh_cos_limit()
+    rng = np.random.default_rng(123)
+    n = 400000
+    base = _DV()   # a camera without images: the pixel cull needs only K, w2c, size (mask = null: bounds only)
+    base.K[:] = [500.0, 0.0, 320.0, 0.0, 500.0, 240.0, 0.0, 0.0, 1.0]
+    base.w2c[:] = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0][:len(base.w2c)] + [0.0] * max(0, len(base.w2c) - 12)
+    base.width, base.height, base.rgb, base.gmi, base.mask = 640, 480, None, None, None
+    scale = (10.0 ** rng.uniform(-3, 3, size=n)).astype(np.float32)
+    centre = rng.normal(size=(n, 3)).astype(np.float32) * scale[:, None]
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    dist = (rng.uniform(0.5, 5.0, size=n) * scale).astype(np.float64)
+    # direction from the centre to the camera at a chosen angle to the normal: a third random, a third at 90 deg +- ulps,
+    # a third at 75 deg +- ulps
+    t = rng.normal(size=(n, 3)); t -= (t * nrm).sum(1, keepdims=True) * nrm; t /= np.linalg.norm(t, axis=1, keepdims=True)
+    kind = rng.integers(0, 3, size=n)
+    ang = np.where(kind == 0, rng.uniform(0, np.pi, size=n),
+                   np.where(kind == 1, np.pi / 2, np.deg2rad(75.0)) + rng.normal(size=n) * 10.0 ** rng.uniform(-9, -3, size=n))
+    dirv = np.cos(ang)[:, None] * nrm + np.sin(ang)[:, None] * t
+    pos = (centre.astype(np.float64) + dirv * dist[:, None]).astype(np.float32)
+    # viewing direction: mostly towards the face, sometimes perpendicular to the line of sight +- ulps (second half of the first cull)
+    vd = -dirv + rng.normal(size=(n, 3)) * 0.3
+    perp = rng.random(n) < 0.25
+    vp = rng.normal(size=(n, 3)); vp -= (vp * dirv).sum(1, keepdims=True) * dirv; vp /= np.linalg.norm(vp, axis=1, keepdims=True)
+    vd = np.where(perp[:, None], vp + dirv * (rng.normal(size=n) * 10.0 ** rng.uniform(-9, -3, size=n))[:, None], vd)
+    vd = (vd / np.linalg.norm(vd, axis=1, keepdims=True)).astype(np.float32)
+    # a small triangle around the centre (its exact shape only matters for the pixel cull)
+    off = rng.normal(size=(n, 3, 3)).astype(np.float32) * (0.01 * scale)[:, None, None]
+    off -= off.mean(axis=1, keepdims=True)
+    tri = (centre[:, None, :] + off).astype(np.float32).reshape(n, 9)
+    out = np.zeros((n, 2), np.int8)
+    D.dmh_cull_pairs(C.byref(base), n, C.c_void_p(pos.ctypes.data), C.c_void_p(vd.ctypes.data), C.c_void_p(tri.ctypes.data),
+                     C.c_void_p(np.ascontiguousarray(nrm, dtype=np.float32).ctypes.data), C.c_float(cl), C.c_void_p(out.ctypes.data))
+    assert np.array_equal(out[:, 0], out[:, 1]), np.flatnonzero(out[:, 0] != out[:, 1])[:10]
+    counts = [(out[:, 0] == r).sum() for r in (1, 2, 3, 0)]
+    assert min(counts[:3]) > 1000, counts            # every reason occurs often (reason 0 needs the triangle inside the image)
