@@ -88,21 +88,27 @@ def induced_subgraph(adj_ptr, adj, n):
     return sap, np.ascontiguousarray(sub[keep], dtype=np.uint32)
 
 
-def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, device, max_labels=0, percentile=None):
-    """The checker leg (never timed): the table the LAST TIMED STEP left on the device against the parity build of the
-    oracle (-O2 -ffp-contract=off) on the first n_check faces -- sparsity pattern, view ids and qualities bit for bit --
-    and the GPU solver against the oracle's solver on that sample's own table + induced subgraph (labels, fixed-point
-    energy, sweeps).  Any difference makes bench.py exit non-zero after printing its line."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_py as O
-    O.build_oracle()
-
-    class S:
+def _scene_view(scene, faces, normals):
+    class S:  # scene with the renumbered faces
         pass
     s = S(); s.verts, s.faces, s.normals, s.cams, s.images = scene.verts, faces, normals, scene.cams, scene.images
     s.n_views, s.n_faces = scene.n_views, len(faces)
+    return s
+
+
+def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, timed_labels, max_labels=0, percentile=None, full_labels=True):
+    """The checker leg (never timed), against the parity build of the oracle (-O2 -ffp-contract=off):
+    (a) the table the LAST TIMED STEP left on the device, on the first n_check faces (0 = all): sparsity pattern, view ids and
+        qualities BIT for bit (no tolerance: the lane-group footprint sampler works under an exactness certificate);
+    (b) the labeling the LAST TIMED STEP produced, all faces: the oracle's solver on the timed run's own table (downloaded)
+        over the whole adjacency graph -- labels, fixed-point energy, sweeps, ICM rounds.
+    Any difference makes bench.py exit non-zero after printing its line."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build_oracle()
+    s = _scene_view(scene, faces, normals)
     nt = max(1, min(32, len(os.sched_getaffinity(0))))
-    n = int(min(n_check, s.n_faces))
+    n = int(min(n_check, s.n_faces)) if n_check else s.n_faces
     got = ctx.costs_download()
     ref, _ = O.data_costs(s, face_range=(0, n), n_threads=nt)
     if max_labels:
@@ -115,30 +121,28 @@ def parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, n_check, devi
     res = {"faces": n, "entries": int(ref.nnz)}
     res["pattern_equal"] = bool(np.array_equal(ref.col_ptr, got.col_ptr[:n + 1]) and np.array_equal(ref.view_id, got.view_id[:end]))
     res["quality_bits_equal"] = bool(res["pattern_equal"] and np.array_equal(ref.quality.view(np.uint32), got.quality[:end].view(np.uint32)))
-    # footprints above info_wave_area pixels are summed by a wave with integer pixel sums instead of the reference's serial fp64
-    # walk: a few fp64 roundings apart, i.e. bit-equal after the conversion to float except for rare last-bit cases
-    res["quality_max_rel_diff"] = float(np.max(np.abs(got.quality[:end].astype(np.float64) - ref.quality) / np.maximum(ref.quality, 1e-30))) if res["pattern_equal"] and end else 0.0
     res["quality_bit_mismatches"] = int((ref.quality.view(np.uint32) != got.quality[:end].view(np.uint32)).sum()) if res["pattern_equal"] else -1
-    del got
-    sap, sadj = induced_subgraph(adj_ptr, adj, n)
+    if n == s.n_faces and not max_labels:
+        res["cost_bits_equal"] = bool(res["pattern_equal"] and np.array_equal(ref.cost.view(np.uint32), got.cost.view(np.uint32)))
     kw = dict(max_sweeps=params.max_sweeps, min_sweeps=params.min_sweeps)
-    lo, so = O.view_selection(ref, sap, sadj, O.default_mrf_params(**kw), n_threads=nt)
-    c2 = M.Context(device)
-    try:
-        c2.costs_upload(M.viewsel.DataCosts(n, s.n_views, ref.col_ptr, ref.view_id, ref.cost))
-        lg, sg = c2.view_selection(sap, sadj, params)
-    finally:
-        c2.close()
-    res["labels_equal"] = bool(np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"])
-    res["sample_sweeps"] = int(sg["sweeps"])
-    res["ok"] = bool(res["pattern_equal"] and (res["quality_bits_equal"] or res["quality_max_rel_diff"] <= 1e-6) and res["labels_equal"])
+    if full_labels:
+        table = O.CsrNp(got.n_faces, got.n_views, got.col_ptr, got.view_id, got.cost)
+        lo, so = O.view_selection(table, adj_ptr, adj, O.default_mrf_params(**kw), n_threads=nt)
+        res["labels_checked"] = "all %d faces of the timed run (oracle solver on the timed run's table)" % s.n_faces
+        res["labels_equal"] = bool(np.array_equal(lo, timed_labels["labels"]) and so["energy_fixed"] == timed_labels["energy_fixed"]
+                                   and so["sweeps"] == timed_labels["sweeps"] and so["icm_iters"] == timed_labels["icm_iters"])
+        res["sweeps"] = int(so["sweeps"])
+    else:
+        res["labels_equal"] = True; res["labels_checked"] = "skipped"
+    res["ok"] = bool(res["pattern_equal"] and res["quality_bits_equal"] and res.get("cost_bits_equal", True) and res["labels_equal"])
     return res
 
 
-def real_like_workload(device, dev, params, steps=5, warmup=2):
+def real_like_workload(device, dev, params, steps=5, warmup=2, check=True):
     """Second workload, reported BESIDE the headline and never instead of it: a scene shaped like a real capture
     (synth.CONFIGS["real"]: 200 000 faces, 200 cropped views 2048x1536, bumps of 0.45 radii -> K = 14.6 candidates per face on
-    average, 31 % of the candidate pairs occluded, footprints of 50 - 4000 pixels).  Same path, same defaults."""
+    average, 31 % of the candidate pairs occluded, footprints of 50 - 4000 pixels).  Same path, same defaults, same check as the
+    headline: the whole table of the last timed step and its labeling against the oracle, bit for bit ("parity_checked")."""
     cfg = dict(M.synth.CONFIGS["real"])
     s = M.synth.make_scene(**cfg)
     c = M.Context(device)
@@ -159,14 +163,49 @@ def real_like_workload(device, dev, params, steps=5, warmup=2):
         torch.cuda.synchronize(); el = time.perf_counter() - t0
         prof = c.get_profile()
         cand = st["nnz_pre"] + st["cull_occluded"] + st["cull_zero_quality"]
-        return {"workload": "real-like synthetic capture: displaced icosphere n=%d (%d faces, bumps %.2f), %d views %dx%d cropped (zoom %.1f / %.1f)"
-                            % (cfg["n"], s.n_faces, cfg["displacement"], cfg["n_views"], cfg["width"], cfg["height"], cfg["zoom"], cfg["zoom"] * cfg["zoom_odd"]),
-                "faces": s.n_faces, "views": s.n_views, "nnz": int(st["nnz"]), "candidates_per_face": st["nnz"] / s.n_faces,
-                "occluded_share_of_candidate_pairs": st["cull_occluded"] / max(cand, 1),
-                "ms_per_step": 1000.0 * el / steps, "value": s.n_faces / (el / steps), "unit": "faces/s", "sweeps": int(ms["sweeps"]),
-                "stages": {k: v[0] / steps for k, v in prof.items()}}
+        out = {"workload": "real-like synthetic capture: displaced icosphere n=%d (%d faces, bumps %.2f), %d views %dx%d cropped (zoom %.1f / %.1f)"
+                           % (cfg["n"], s.n_faces, cfg["displacement"], cfg["n_views"], cfg["width"], cfg["height"], cfg["zoom"], cfg["zoom"] * cfg["zoom_odd"]),
+               "faces": s.n_faces, "views": s.n_views, "nnz": int(st["nnz"]), "candidates_per_face": st["nnz"] / s.n_faces,
+               "occluded_share_of_candidate_pairs": st["cull_occluded"] / max(cand, 1),
+               "footprints_lane_group": int(st["footprints_lane_group"]), "footprints_rewalked": int(st["footprints_rewalked"]),
+               "ms_per_step": 1000.0 * el / steps, "value": s.n_faces / (el / steps), "unit": "faces/s", "sweeps": int(ms["sweeps"]),
+               "stages": {k: v[0] / steps for k, v in prof.items()}}
+        if check:
+            timed = dict(labels=lab.cpu().numpy().view(np.uint32), energy_fixed=ms["energy_fixed"], sweeps=ms["sweeps"], icm_iters=ms["icm_iters"])
+            out["parity"] = parity_check(c, s, s.faces, s.normals, s.adj_ptr, s.adj, params, 0, timed)
+            out["parity_checked"] = bool(out["parity"]["ok"])
+        return out
     finally:
         c.close()
+
+
+def pmc_pass(config, counters, timeout_s=420, extra_args=()):
+    """One `rocprofv3 --pmc <counters>` pass over ONE step of this script (no traces in the same run).  Returns
+    {kernel short name: [dispatches, {counter: sum over dispatches}]} or raises."""
+    import csv, glob, re, shutil, subprocess, tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="mvs_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        cmd = [rocprof, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-real-like"] + list(extra_args)
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            raise RuntimeError("%s pass failed (rc %d): %s" % (" ".join(counters), r.returncode, r.stderr.decode(errors="replace")[-300:]))
+        acc, seen = {}, {}
+        for row in csv.DictReader(open(files[0])):
+            m = re.search(r"([a-z][a-z0-9_]*_kernel[0-9a-z_]*)", row["Kernel_Name"])
+            k = m.group(1) if m else row["Kernel_Name"][:48]
+            a = acc.setdefault(k, [0, {}])
+            if (k, row["Dispatch_Id"]) not in seen:
+                seen[(k, row["Dispatch_Id"])] = 1; a[0] += 1
+            a[1][row["Counter_Name"]] = a[1].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        return acc
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measure_traffic(config, kernel_rx, nnz, timeout_s=420):
@@ -174,46 +213,63 @@ def measure_traffic(config, kernel_rx, nnz, timeout_s=420):
     script under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one pass,
     MI355X_MICROARCH.md "rocprofv3 PMC slots").  FETCH_SIZE under-reports coalesced streaming reads by 2x on gfx950 (same
     guide, "HBM"): the factor is calibrated in the same pass on cost_kernel / hist_kernel / max_kernel, which read exactly
-    4 * nnz bytes.  Returns (bytes per launch, details) or (None, reason)."""
-    import csv, glob, re, shutil, subprocess, tempfile
-    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(rocprof):
-        return None, "rocprofv3 not found"
-    tmp = tempfile.mkdtemp(prefix="mvs_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
-    vals = {}
+    4 * nnz bytes.  Returns (bytes per launch, details, per-kernel table) or (None, reason, None)."""
+    import re
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-real-like"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, "%s pass failed (rc %d): %s" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-300:])
-            acc = {}
-            for row in csv.DictReader(open(files[0])):
-                m = re.search(r"([a-z][a-z0-9_]*_kernel)", row["Kernel_Name"])
-                a = acc.setdefault(m.group(1) if m else row["Kernel_Name"][:48], [0, 0.0])
-                a[0] += 1; a[1] += float(row["Counter_Value"])
-            vals[ctr] = acc
+        fa = {k: [v[0], v[1].get("FETCH_SIZE", 0.0)] for k, v in pmc_pass(config, ["FETCH_SIZE"], timeout_s).items()}
+        wa = {k: [v[0], v[1].get("WRITE_SIZE", 0.0)] for k, v in pmc_pass(config, ["WRITE_SIZE"], timeout_s).items()}
     except Exception as e:  # noqa: BLE001 -- reporting only
-        return None, repr(e)
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    fa, wa = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+        return None, repr(e), None
     # counter unit: KB.  Calibration kernels read exactly 4 * nnz bytes (coalesced dword loads)
     cal = [(4.0 * nnz) / (fa[k][1] / fa[k][0] * 1024.0) for k in ("cost_kernel", "hist_kernel", "max_kernel") if k in fa and fa[k][1] > 0]
     factor = sum(cal) / len(cal) if cal else 2.0
     key = [k for k in fa if re.search(kernel_rx, k)]
     if not key:
-        return None, "kernel %s not in the counter file" % kernel_rx
+        return None, "kernel %s not in the counter file" % kernel_rx, None
     k = key[0]
     fetch = fa[k][1] / fa[k][0] * 1024.0 * factor
     write = wa[k][1] / wa[k][0] * 1024.0 if k in wa and wa[k][0] else 0.0
     wcal = (4.0 * nnz) / (wa["cost_kernel"][1] / wa["cost_kernel"][0] * 1024.0) if "cost_kernel" in wa and wa["cost_kernel"][1] > 0 else None
+    # per kernel, per STEP: measured HBM bytes (fetch calibrated as above + write)
+    per_kernel = {kk: {"dispatches": fa[kk][0], "bytes": fa[kk][1] * 1024.0 * factor + (wa[kk][1] * 1024.0 if kk in wa else 0.0)} for kk in fa}
     return fetch + write, {"fetch_bytes": fetch, "write_bytes": write, "fetch_factor": factor, "fetch_factor_calibrated_on": len(cal),
-                           "write_check_cost_kernel": wcal, "launches_counted": fa[k][0]}
+                           "write_check_cost_kernel": wcal, "launches_counted": fa[k][0]}, per_kernel
+
+
+SQ_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_BUSY_CYCLES"]
+# the kernel that dominates a stage -> the stage (per-stage issue figures are quoted for these kernels only)
+STAGE_OF_KERNEL = [(r"^lum_sobel_kernel", "dc_prep"), (r"^cull_kernel", "dc_cull"), (r"^ray_packet", "dc_rays"), (r"info_kernel", "dc_face_info"),
+                   (r"^csr_write_staged_kernel|^csr_count_kernel", "dc_csr"), (r"^mrf_sweep", "mrf_sweep")]
+
+
+def stage_of(kernel):
+    import re
+    for rx, st in STAGE_OF_KERNEL:
+        if re.search(rx, kernel):
+            return st
+    return None
+
+
+def measure_issue(config, timeout_s=420):
+    """wave-instructions by class per kernel of one step (SQ counters, their own pass).  Returns ({stage: {counter: sum}}, {kernel: ...}) or (None, reason)."""
+    try:
+        acc = pmc_pass(config, SQ_COUNTERS, timeout_s)
+    except Exception as e:  # noqa: BLE001
+        try:   # eight SQ counters did not fit one pass on this rocprofv3: two halves
+            acc = pmc_pass(config, SQ_COUNTERS[:4], timeout_s)
+            for k, v in pmc_pass(config, SQ_COUNTERS[4:], timeout_s).items():
+                if k in acc:
+                    acc[k][1].update(v[1])
+        except Exception as e2:  # noqa: BLE001
+            return None, repr(e) + " / " + repr(e2)
+    per_stage = {}
+    for k, (n, c) in acc.items():
+        st = stage_of(k)
+        if st:
+            d = per_stage.setdefault(st, {})
+            for cn, cv in c.items():
+                d[cn] = d.get(cn, 0.0) + cv
+    return per_stage, {k: dict(v[1], dispatches=v[0]) for k, v in acc.items()}
 
 
 def main():
@@ -221,7 +277,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE.md config: 2 = 200k faces / 50 views, 3 = 2M faces / 200 views (the headline), 5 = one rank's share of the 10M-face / 1000-view scene")
+    ap.add_argument("--config", default="3", help="BASELINE.md config: 2 = 200k faces / 50 views, 3 = 2M faces / 200 views (the headline), 5 = one rank's share of the 10M-face / 1000-view scene; "
+                                                  "'real' = the real-like second workload as the main workload (profiling runs; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--max-labels", type=int, default=-1, help="label-space compression (mvs_set_option max_labels); default: off, 64 for --config 5")
@@ -233,6 +290,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--shard", action="store_true", help="take the sharded C++ / RCCL path even at world size 1 (test of the N > 1 code path on one GPU)")
     args = ap.parse_args()
+    args.config = int(args.config) if args.config.isdigit() else args.config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -385,6 +443,9 @@ def main():
     nnz_global = info["nnz_global"]
     stages = {k: {"ms_per_step": v[0] / max(args.steps, 1), "launches_per_step": v[1] / max(args.steps, 1)} for k, v in prof.items()}
     roof = None
+    per_kernel_bytes = None
+    if world == 1 and not args.shard and args.steps > 0:
+        info["timed"] = dict(labels=t_lab.cpu().numpy().view(np.uint32), energy_fixed=mrf["energy_fixed"], sweeps=mrf["sweeps"], icm_iters=mrf["icm_iters"])
     if "mrf_sweep" in prof and prof["mrf_sweep"][1] > 0:
         import ctypes as C
         nph = C.c_uint32(0); ctx.L.mvs_ctx_mrf_num_phases(ctx.h, C.byref(nph)); n_phases = max(int(nph.value), 1)
@@ -414,22 +475,78 @@ def main():
                             % (n_phases, n_phases, b_survey, b_survey / (sweep_ms * 1e-3) / 1e9)}
             if rank == 0 and world == 1 and not args.no_traffic:
                 t0 = time.time()
-                traffic, detail = measure_traffic(args.config, r"^mrf_sweep4_kernel$", nnz_global)
+                traffic, detail, per_kernel_bytes = measure_traffic(args.config, r"^mrf_sweep4_kernel", nnz_global)
                 roof["traffic"] = traffic
                 roof["traffic_detail"] = detail if traffic is not None else {"error": detail}
                 roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one step of this command, collected in this run (%.0f s)" % (time.time() - t0)
 
+    # ---- roofline of the WHOLE path and per stage ----
+    # B_dc = 60 F + 3 WHV (+ WHV gmi + WHV / 8 mask) + 32 N_ray_nodes + 36 N_ray_tris + 40 nnz_pre + 6 nnz + 4 (F + 1);  B_mrf = sweeps x (30 nnz + 12 F)
+    # with the survey's fp32 messages, sweeps x (12 nnz + 12 F) with this implementation's 8-bit message codes (the figure used:
+    # bytes the path does not move earn no credit).  N_ray_nodes / N_ray_tris = node visits and (ray, triangle) tests of the packet
+    # traversal of this scene, counted once outside the timed region (option "count_rays").
+    roof_path = None
+    if rank == 0 and world == 1 and not args.shard and args.steps > 0:
+        W, H = cfg["width"], cfg["height"]
+        c2 = M.Context(local_rank)   # its own context: the table of the last timed step stays on `ctx` for the parity check
+        try:
+            c2.set_stream(torch.cuda.current_stream().cuda_stream)
+            c2.set_option("count_rays", 1); c2.set_option("stats", 1)
+            c2.set_mesh(t_v, t_f, t_n); c2.set_views(scene.cams, t_img)
+            cst = c2.data_costs(settings)
+        finally:
+            c2.close()
+        n_nodes, n_tris, nnz_pre = int(cst["ray_nodes"]), int(cst["ray_tris"]), int(cst["nnz_pre"])
+        whv = float(W) * H * V
+        sweeps = int(mrf["sweeps"])
+        b_stage = {"dc_prep": 3.0 * whv + whv + whv / 8.0, "dc_cull": 60.0 * F, "dc_rays": 32.0 * n_nodes + 36.0 * n_tris,
+                   "dc_face_info": 20.0 * nnz_pre, "dc_csr": 20.0 * nnz_pre + 6.0 * nnz_global + 4.0 * (F + 1),
+                   "mrf_sweep": sweeps * (12.0 * nnz_global + 12.0 * F)}
+        b_dc = sum(v for k, v in b_stage.items() if k.startswith("dc_"))
+        b_mrf = b_stage["mrf_sweep"]
+        t_s = ms_per_step * 1e-3
+        roof_path = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "B_dc": b_dc, "B_mrf": b_mrf,
+                     "B_mrf_survey_fp32_messages": sweeps * (30.0 * nnz_global + 12.0 * F),
+                     "achieved": (b_dc + b_mrf) / t_s / 1e9, "frac": (b_dc + b_mrf) / t_s / 1e9 / HBM_PEAK_GBS,
+                     "N_ray_nodes": n_nodes, "N_ray_tris": n_tris, "rays": int(cst["rays"]), "nnz_pre": nnz_pre,
+                     "note": "algorithmic bytes of BASELINE.md section 5 over the whole timed step; the data-cost half is bound by vector issue, "
+                             "not by HBM (see stage_roofline[*].valu_issue_frac)"}
+        issue = None
+        if not args.no_traffic:
+            issue, issue_kernels = measure_issue(args.config)
+            if issue is None:
+                roof_path["issue_error"] = issue_kernels
+        table = {}
+        for st_name, b in b_stage.items():
+            if st_name not in stages:
+                continue
+            t_st = stages[st_name]["ms_per_step"] * 1e-3
+            row = {"ms": stages[st_name]["ms_per_step"], "algorithmic_bytes": b, "hbm_frac": b / max(t_st, 1e-12) / 1e9 / HBM_PEAK_GBS}
+            if issue and st_name in issue and "SQ_INSTS_VALU" in issue[st_name]:
+                # vector issue: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md); 1024 SIMDs at 2.4 GHz
+                c = issue[st_name]
+                row["valu_wave_insts"] = c["SQ_INSTS_VALU"]; row["salu_wave_insts"] = c.get("SQ_INSTS_SALU")
+                row["valu_issue_frac"] = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * 2.4e9) / max(t_st, 1e-12)
+                row["waves"] = c.get("SQ_WAVES")
+            if per_kernel_bytes:
+                import re
+                mb = sum(v["bytes"] for k, v in per_kernel_bytes.items() if stage_of(k) == st_name)
+                if mb:
+                    row["measured_hbm_bytes"] = mb; row["measured_hbm_frac"] = mb / max(t_st, 1e-12) / 1e9 / HBM_PEAK_GBS
+            table[st_name] = row
+        roof_path["stages"] = table
+
     out = {"metric": "faces/sec through view-selection (data-cost + MRF)", "value": value, "unit": "faces/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "BASELINE config %d: displaced icosphere n=%d (%d faces), %d Fibonacci-sphere views %dx%d RGB8, "
+           "config": {"workload": "BASELINE config %s: displaced icosphere n=%d (%d faces), %d Fibonacci-sphere views %dx%d RGB8, "
                                   "settings gmi/none/visibility-test (reference defaults)" % (args.config, cfg["n"], F, V, cfg["width"], cfg["height"]),
                       "faces": F, "views": V, "nnz": nnz_global, "sweeps": int(mrf["sweeps"]), "icm_iters": int(mrf["icm_iters"]),
                       "energy": float(mrf["energy"]), "partition": "morton-%d" % world, "msg_bits": 8, "max_labels": max_labels,
                       "arithmetic": "fp32 geometry and messages, fp64 footprint sums, 32.32 fixed-point energies; messages STORED as 8-bit codes"},
            "h2d_ms": h2d_ms, "h2d_GBps": h2d_bytes / max(h2d_ms, 1e-9) / 1e6,
            "pcie_inclusive_value": F / ((ms_per_step + h2d_ms) / 1000.0),
-           "roofline": roof, "stages": stages, "pre_path": pre, "post_path": post}
+           "roofline": roof, "roofline_path": roof_path, "stages": stages, "pre_path": pre, "post_path": post}
     if "plan" in info:
         out["halo"] = dict(info["plan"], driver="C++ (csrc/shard.hip), grouped ncclSend/ncclRecv per colour phase, bytes on the wire")
     if world > 1 or args.shard:
@@ -449,7 +566,7 @@ def main():
     rc = 0
     if rank == 0 and world == 1 and not args.no_parity and args.steps > 0 and not args.shard:
         try:
-            out["parity"] = parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, args.parity_faces, local_rank, max_labels, dc.get("percentile"))
+            out["parity"] = parity_check(ctx, scene, faces, normals, adj_ptr, adj, params, args.parity_faces, info["timed"], max_labels, dc.get("percentile"))
             out["parity_checked"] = bool(out["parity"]["ok"])
         except Exception as e:  # noqa: BLE001
             out["parity"] = {"error": repr(e)}; out["parity_checked"] = False

@@ -123,6 +123,8 @@ typedef struct {
     uint64_t ray_packets_generic; /* ... of which with mixed / degenerate direction signs: the unspecialised slab test */
     float max_quality;          /* :278-281 */
     float percentile;           /* :288 */
+    uint64_t footprints_lane_group; /* sampled footprints above "info_wave_area" pixels: summed by a 16-lane group (integer pixel sums) */
+    uint64_t footprints_rewalked;   /* ... of which the exactness certificate could not decide: re-walked in the reference's serial fp64 order */
 } mvs_dc_stats;
 
 const char* mvs_last_error(void);

@@ -148,6 +148,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lds_bvh_levels") ctx->lds_bvh_levels = (int)value;
     else if (n == "verbose") ctx->verbose = value != 0;
     else if (n == "info_wave_area") ctx->info_wave_area = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (n == "info_cert_shift") ctx->info_cert_shift = (int)std::max<int64_t>(0, std::min<int64_t>(value, 40));
     else if (n == "max_labels") { if (value < 0 || value > 65535) return fail(MVS_ERR_INVALID, "max_labels: 0 (off) .. 65535"); ctx->max_labels = (int)value; }
     else if (n == "profile") ctx->profile = value != 0;
     else if (n == "ray_mode") ctx->ray_mode = (int)value;
@@ -223,10 +224,15 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
     // buffer at ~13 GB/s (1.9 GB of BASELINE config 3: 146 ms).  Pinning the caller's pages in place for the duration of the
     // call (hipHostRegister) lets the copy engine read them directly; all copies are queued back to back, one wait at the
     // end.  A buffer that cannot be registered (read-only mapping, limit reached) goes the pageable way.
-    std::vector<void*> registered;
+    // every exit path -- a bad image, an allocation or copy that throws -- first drains the stream (copies may still read the
+    // pinned pages) and then unregisters what was registered: the caller's memory never stays pinned behind a failed call
+    struct Pinned {
+        hipStream_t s; std::vector<void*> ptrs;
+        ~Pinned() { if (ptrs.empty()) return; (void)hipStreamSynchronize(s); for (void* p : ptrs) (void)hipHostUnregister(p); }
+    } pinned{ctx->stream, {}};
     for (uint32_t j = 0; j < n_views; ++j) {
         const mvs_view& v = views[j];
-        if (v.width < 2 || v.height < 2 || !v.rgb) { for (void* p : registered) (void)hipHostUnregister(p); throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image"); }
+        if (v.width < 2 || v.height < 2 || !v.rgb) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image");
         ViewParams& p = ctx->h_views[j];
         memcpy(p.pos, v.pos, sizeof(p.pos)); memcpy(p.viewdir, v.viewdir, sizeof(p.viewdir));
         memcpy(p.K, v.K, sizeof(p.K)); memcpy(p.w2c, v.w2c, sizeof(p.w2c));
@@ -237,15 +243,13 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
             ctx->own_rgb.push_back(b);
             const size_t bytes = (size_t)v.width * v.height * 3;
             b->ensure(bytes + 16);
-            if (bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(const_cast<uint8_t*>(v.rgb));
+            if (bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) pinned.ptrs.push_back(const_cast<uint8_t*>(v.rgb));
             else (void)hipGetLastError();   // not registered: clear the sticky error, copy from pageable memory
             MVS_HIP(hipMemcpyAsync(b->p, v.rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
             p.rgb = b->p;
         }
     }
-    const hipError_t sync_err = hipStreamSynchronize(ctx->stream);
-    for (void* p : registered) (void)hipHostUnregister(p);
-    MVS_HIP(sync_err);
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_views = n_views;
     ctx->have_costs = false; ctx->dc_phase = 0;
     MVS_API_END

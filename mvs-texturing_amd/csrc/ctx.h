@@ -111,6 +111,7 @@ struct mvs_ctx {
     int ray_mode = 3;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution, 3 = 2 with the packed, sign-specialised slab test
     int lds_bvh_levels = 0;
     int info_wave_area = 32;   // footprints (sampled ones) above this many pixels go to the wave-per-footprint kernel (k_dc.hip wave_info_kernel); 0 = every footprint serial = bit-exact with the reference's fp64 scan order
+    int info_cert_shift = 0;   // test hook: widens the exactness certificate of wave_info_kernel by this many bits (forces its serial fallback)
     uint32_t dc_stats_deferred = 0;
     int max_labels = 0;      // > 0: label-space compression after the data costs (k_dc.hip prune_write_kernel); 0 = the reference's model
     float cos_limit = 0.0f;  // see dmath.h cull_pair
@@ -143,7 +144,7 @@ struct mvs_ctx {
     mvs::DBuf<unsigned long long> pass_bits, need_bits, occl_bits, surv_bits;
     mvs::DBuf<uint32_t> pass_base;      // exclusive scan of popc(pass words)
     mvs::DBuf<uint32_t> pass_face;      // [view chunk][face] the chunk's pass bits of a face (face-major copy read by need_kernel)
-    mvs::DBuf<unsigned long long> defer_bits; mvs::DBuf<uint32_t> defer_base; mvs::DBuf<uint2> defer_list;   // large footprints left to the wave-per-footprint kernel
+    mvs::DBuf<unsigned long long> defer_bits; mvs::DBuf<uint32_t> defer_base; mvs::DBuf<uint2> defer_list; mvs::DBuf<uint32_t> rewalk_list;   // large footprints left to the wave-per-footprint kernel
     mvs::DBuf<float> pq;                // quality per passing pair
     mvs::DBuf<float> pcol;              // 3 floats per passing pair (outlier removal only)
     mvs::DBuf<uint32_t> face_cnt, scan_tmp;

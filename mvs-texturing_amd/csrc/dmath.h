@@ -308,6 +308,9 @@ MVS_HD bool foot_inside(const FootSetup& s, int x, int y) {   // Tri::inside (tr
     if (alpha + beta > 1.0f) return false;
     return true;
 }
+// the two expressions of foot_finish that depend on the pixel sums (num_samples > 0): texture_view.cpp:222-224 and :235-236
+MVS_HD double foot_gmi_term(double gmi_sum, uint32_t num_samples, float area) { return (gmi_sum / (double)num_samples) * (double)area; }
+MVS_HD float foot_mean(double col_sum, uint32_t num_samples) { return (float)(col_sum / (double)num_samples); }
 template <int DATA_TERM, bool OUTLIER>
 MVS_HD void foot_finish(const ViewParams& view, const FootSetup& s, uint32_t num_samples, double col0, double col1, double col2, double gmi, FaceInfoOut* out) {
     const int w = view.width, h = view.height;
@@ -315,7 +318,7 @@ MVS_HD void foot_finish(const ViewParams& view, const FootSetup& s, uint32_t num
     const uint8_t* gimg = view.gmi;
     if (DATA_TERM == 1) {
         if (num_samples > 0) {
-            gmi = (gmi / (double)num_samples) * (double)s.area;
+            gmi = foot_gmi_term(gmi, num_samples, s.area);
         } else {
             const double g1 = (double)linear_at(gimg, w, h, 1, s.p1.x, s.p1.y, 0) / 255.0;
             const double g2 = (double)linear_at(gimg, w, h, 1, s.p2.x, s.p2.y, 0) / 255.0;
@@ -325,9 +328,9 @@ MVS_HD void foot_finish(const ViewParams& view, const FootSetup& s, uint32_t num
     }
     if (OUTLIER) {
         if (num_samples > 0) {
-            out->mean_color[0] = (float)(col0 / (double)num_samples);
-            out->mean_color[1] = (float)(col1 / (double)num_samples);
-            out->mean_color[2] = (float)(col2 / (double)num_samples);
+            out->mean_color[0] = foot_mean(col0, num_samples);
+            out->mean_color[1] = foot_mean(col1, num_samples);
+            out->mean_color[2] = foot_mean(col2, num_samples);
         } else {
             for (int i = 0; i < 3; ++i) {
                 const double c1 = (double)linear_at(image, w, h, 3, s.p1.x, s.p1.y, i) / 255.0;
@@ -338,6 +341,25 @@ MVS_HD void foot_finish(const ViewParams& view, const FootSetup& s, uint32_t num
         }
     }
     out->quality = (DATA_TERM == 0) ? s.area : (float)gmi;
+}
+
+// Exactness certificate for pixel sums that were NOT accumulated in the reference's order (the lane-group sampler adds the u8
+// values as integers and divides once: sum_k = fl(S_k / 255.0)).  The reference adds the n quotients fl(u / 255.0) one by one in
+// fp64; all terms are non-negative, so whatever the order its sum lies within (1 +- 2^-53)^(n + 1) of sum_k.  The expressions
+// above are monotone in the sum (division by n > 0, product with the area > 0, conversion to float): if both ends of
+// [sum (1 - eps), sum (1 + eps)], eps = (n + 4) 2^-53 (the rounding of the ends included), give the same float, every sum in
+// between does -- the serial walk's among them, and foot_finish(sum_k) IS the reference's result bit for bit.  False: the interval
+// straddles a float rounding boundary (probability ~ n 2^-28) and the caller has to repeat the walk serially.
+// shift > 0 widens eps by that many bits (test hook).  num_samples == 0: the sums are not used at all.
+template <int DATA_TERM, bool OUTLIER>
+MVS_HD bool foot_sums_certified(const FootSetup& s, uint32_t num_samples, double col0, double col1, double col2, double gmi, int shift) {
+    if (num_samples == 0) return true;
+    const double eps = ldexp((double)num_samples + 4.0, -53 + shift), dn = 1.0 - eps, up = 1.0 + eps;
+    bool ok = true;
+    if (DATA_TERM == 1) ok = (float)foot_gmi_term(gmi * dn, num_samples, s.area) == (float)foot_gmi_term(gmi * up, num_samples, s.area);
+    if (OUTLIER) ok = ok && foot_mean(col0 * dn, num_samples) == foot_mean(col0 * up, num_samples) && foot_mean(col1 * dn, num_samples) == foot_mean(col1 * up, num_samples) &&
+                      foot_mean(col2 * dn, num_samples) == foot_mean(col2 * up, num_samples);
+    return ok;
 }
 
 constexpr float FOOT_DEFERRED = -1.0f;   // quality marker: "sampled by the wave-per-footprint kernel" (qualities are >= 0)

@@ -3,6 +3,7 @@
 // each function with the oracle on a machine without a GPU.  Not a code path of
 // the product: nothing in the library or the Python package calls into this file.
 #include "dmath.h"
+#include <vector>
 
 using namespace mvs;
 
@@ -105,5 +106,40 @@ void dmh_gradient_magnitude(const uint8_t* rgb, int w, int h, uint8_t* gmi) {
 }
 
 uint32_t dmh_hist_bin(float value, float maxv) { return hist_bin(value, maxv, 10000u); }
+
+// Exactness certificate of the lane-group footprint sampler (dmath.h foot_sums_certified) against what it certifies: `trials` random
+// footprints of 33 .. max_n pixels (u8 values from a random sub-range, as in an image region), random area; the integer-sum result
+// next to the serial fp64 sums of the quotients in three orders (forward = the reference's, backward, strided).
+// out[0] = certified, out[1] = trials where some serial order gives another float than the integer sum (gmi term or a colour mean),
+// out[2] = ... among the CERTIFIED ones (must be 0), out[3] = trials
+void dmh_foot_cert_trials(uint64_t seed, uint32_t trials, uint32_t max_n, int shift, uint64_t* out) {
+    uint64_t n_cert = 0, n_mis = 0, n_bad = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : n_cert, n_mis, n_bad)
+    for (uint32_t t = 0; t < trials; ++t) {
+        uint64_t x = seed * 0x9E3779B97F4A7C15ull + (uint64_t)t * 0xD1B54A32D192ED03ull + 1ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        const uint32_t n = 33u + (uint32_t)(rnd() % (max_n - 32u));
+        const uint32_t lo = (uint32_t)(rnd() % 200u), span = 1u + (uint32_t)(rnd() % (256u - lo));
+        std::vector<uint8_t> px(4 * (size_t)n);
+        for (auto& p : px) p = (uint8_t)(lo + rnd() % span);
+        FootSetup s{}; s.area = 0.5f * (float)n * (0.8f + 0.4f * (float)(rnd() % 1000u) / 1000.0f);
+        uint64_t S[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < n; ++k) for (int c = 0; c < 4; ++c) S[c] += px[4 * (size_t)k + c];
+        const double C[4] = {(double)S[0] / 255.0, (double)S[1] / 255.0, (double)S[2] / 255.0, (double)S[3] / 255.0};
+        const bool cert = foot_sums_certified<1, true>(s, n, C[0], C[1], C[2], C[3], shift);
+        const float qi = (float)foot_gmi_term(C[3], n, s.area), m0 = foot_mean(C[0], n), m1 = foot_mean(C[1], n), m2 = foot_mean(C[2], n);
+        bool mis = false;
+        for (int order = 0; order < 3; ++order) {
+            double a[4] = {0.0, 0.0, 0.0, 0.0};
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t i = order == 0 ? k : order == 1 ? n - 1 - k : (uint32_t)(((uint64_t)k * 7919u) % n);
+                for (int c = 0; c < 4; ++c) a[c] += (double)px[4 * (size_t)i + c] / 255.0;
+            }
+            mis = mis || (float)foot_gmi_term(a[3], n, s.area) != qi || foot_mean(a[0], n) != m0 || foot_mean(a[1], n) != m1 || foot_mean(a[2], n) != m2;
+        }
+        n_cert += cert; n_mis += mis; n_bad += (cert && mis);
+    }
+    out[0] = n_cert; out[1] = n_mis; out[2] = n_bad; out[3] = trials;
+}
 
 }  // extern "C"

@@ -26,7 +26,7 @@ namespace {
 constexpr int VIEW_CHUNK = 32;
 constexpr uint32_t HIST_BINS = 10000;  // calculate_data_costs.cpp:283
 
-enum { C_BACK = 0, C_ANGLE = 1, C_OUTSIDE = 2, C_OCCL = 3, C_ZEROQ = 4, C_SURV = 5, C_RAYS = 6, C_PASS = 7, C_RNODES = 8, C_RTRIS = 9 };
+enum { C_BACK = 0, C_ANGLE = 1, C_OUTSIDE = 2, C_OCCL = 3, C_ZEROQ = 4, C_SURV = 5, C_RAYS = 6, C_PASS = 7, C_RNODES = 8, C_RTRIS = 9, C_REWALK = 12 };
 
 __device__ __forceinline__ V3 ld3(const float* __restrict__ p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
 
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict_
                                                         uint32_t fb, uint32_t fwords, const uint2* __restrict__ list, uint32_t n_list,
                                                         const unsigned long long* __restrict__ pass, const uint32_t* __restrict__ pass_base,
                                                         float* __restrict__ pq, float* __restrict__ pcol, unsigned long long* __restrict__ surv,
-                                                        unsigned long long* __restrict__ counters) {
+                                                        unsigned long long* __restrict__ counters, int cert_shift, uint32_t* __restrict__ rewalk) {
     // 16 lanes per footprint (four footprints per wave), arranged as 2 scan lines x 8 pixels: a lane computes the span of its
     // own scan line with the shared foot_row() and strides through it by 8 -- no staging, no search, coalesced row reads
     constexpr int GL = 16, ROWS = 2, COLS = 8;
@@ -245,14 +245,46 @@ __global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict_
     uint32_t cnt[2] = {0, 0};   // zero quality, survivors
     if (sub == 0 && act) {
         FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
-        foot_finish<DATA_TERM, OUTLIER>(view, s, n, (double)c0 / 255.0, (double)c1 / 255.0, (double)c2 / 255.0, (double)g / 255.0, &fi);
+        // integer sums, one division each -- and a certificate that the result equals the reference's serial fp64 walk bit for bit
+        // (dmath.h foot_sums_certified); the footprints it cannot decide (~ n 2^-28 of them) go to rewalk_info_kernel
+        const double C0 = (double)c0 / 255.0, C1 = (double)c1 / 255.0, C2 = (double)c2 / 255.0, CG = (double)g / 255.0;
+        const bool certified = foot_sums_certified<DATA_TERM, OUTLIER>(s, n, C0, C1, C2, CG, cert_shift);
+        if (!certified) rewalk[atomicAdd(&counters[C_REWALK], 1ull)] = k;   // left to rewalk_info_kernel (keeps the serial walker's registers out of this kernel)
+        else {
+            foot_finish<DATA_TERM, OUTLIER>(view, s, n, C0, C1, C2, CG, &fi);
+            const unsigned long long word = pass[widx];
+            const size_t r = (size_t)pass_base[widx] + __popcll(word & ((1ull << bit) - 1ull));
+            pq[r] = fi.quality;
+            if (OUTLIER) { rgb_to_ycbcr(fi.mean_color); pcol[3 * r] = fi.mean_color[0]; pcol[3 * r + 1] = fi.mean_color[1]; pcol[3 * r + 2] = fi.mean_color[2]; }
+            if (fi.quality != 0.0f) { atomicOr(&surv[widx], 1ull << bit); ++cnt[1]; } else ++cnt[0];
+        }
+    }
+    if (STATS) { const int slot[2] = {C_ZEROQ, C_SURV}; block_count_add<2>(cnt, counters, slot); }
+}
+// the footprints wave_info_kernel could not certify, one thread each, in the reference's serial fp64 order (a handful per scene)
+template <int DATA_TERM, bool OUTLIER, bool STATS>
+__global__ void __launch_bounds__(64) rewalk_info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
+                                                         uint32_t fb, uint32_t fwords, const uint2* __restrict__ list, const uint32_t* __restrict__ rewalk,
+                                                         const unsigned long long* __restrict__ pass, const uint32_t* __restrict__ pass_base,
+                                                         float* __restrict__ pq, float* __restrict__ pcol, unsigned long long* __restrict__ surv,
+                                                         unsigned long long* __restrict__ counters) {
+    const uint32_t n_rewalk = (uint32_t)counters[C_REWALK];
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_rewalk; q += gridDim.x * blockDim.x) {
+        const uint2 rec = list[rewalk[q]];
+        const size_t widx = (size_t)rec.x | ((size_t)(rec.y >> 8) << 32);
+        const uint32_t bit = rec.y & 63u;
+        const uint32_t j = (uint32_t)(widx / fwords), lf = (uint32_t)(widx % fwords) * 64u + bit;
+        const size_t f = (size_t)fb + lf;
+        const V3 v1 = ld3(verts, faces[3 * f]), v2 = ld3(verts, faces[3 * f + 1]), v3 = ld3(verts, faces[3 * f + 2]);
+        FaceInfoOut fi;
+        face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi);
         const unsigned long long word = pass[widx];
         const size_t r = (size_t)pass_base[widx] + __popcll(word & ((1ull << bit) - 1ull));
         pq[r] = fi.quality;
         if (OUTLIER) { rgb_to_ycbcr(fi.mean_color); pcol[3 * r] = fi.mean_color[0]; pcol[3 * r + 1] = fi.mean_color[1]; pcol[3 * r + 2] = fi.mean_color[2]; }
-        if (fi.quality != 0.0f) { atomicOr(&surv[widx], 1ull << bit); ++cnt[1]; } else ++cnt[0];
+        if (fi.quality != 0.0f) atomicOr(&surv[widx], 1ull << bit);
+        if (STATS) atomicAdd(&counters[fi.quality != 0.0f ? C_SURV : C_ZEROQ], 1ull);
     }
-    if (STATS) { const int slot[2] = {C_ZEROQ, C_SURV}; block_count_add<2>(cnt, counters, slot); }
 }
 
 // ---- view-major bits -> CSR by face ----
@@ -410,6 +442,14 @@ __device__ __forceinline__ bool gauss_at_least_threshold(double arg) {
     if (arg < x0 - 1e-9) return false;       // also false for NaN, like exp(NaN) >= t
     return exp(arg) >= 6e-3;
 }
+// exp(arg) < 6e-3 (the final clamping test, :121): NOT the negation of the above for a NaN argument -- the reference leaves the
+// quality untouched when the gauss value is NaN (NaN < t is false), e.g. after an ill-conditioned inverse that passed isInvertible
+__device__ __forceinline__ bool gauss_below_threshold(double arg) {
+    const double x0 = -5.115995809754082;   // ln(6e-3)
+    if (arg < x0 - 1e-9) return true;
+    if (arg >= x0 + 1e-9) return false;
+    return exp(arg) < 6e-3;                  // false for NaN, like exp(NaN) < t
+}
 
 // photometric_outlier_detection (calculate_data_costs.cpp:35-129), one thread per face, every fp64 sum in the reference's
 // order (descending view id: SURVEY.md 8a row D) -- the sums decide inlier sets through a threshold, so their order is part
@@ -517,7 +557,7 @@ __global__ void __launch_bounds__(64) outlier_kernel(const uint32_t* __restrict_
     for (int64_t k = 0; k < n; ++k) {
         const double c[3] = {(double)COL(k, 0), (double)COL(k, 1), (double)COL(k, 2)};
         if (mode == MVS_OUTLIER_GAUSS_DAMPING) quality[p0 + k] = (float)((double)quality[p0 + k] * multi_gauss(c, mean, ci));
-        else if (!gauss_at_least_threshold(multi_gauss_arg(c, mean, ci))) quality[p0 + k] = 0.0f;
+        else if (gauss_below_threshold(multi_gauss_arg(c, mean, ci))) quality[p0 + k] = 0.0f;
     }
 #undef COL
 #undef INL
@@ -764,6 +804,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     // footprints above info_wave_area pixels (and only footprints that are sampled at all: gmi or outlier removal) are left to
     // the wave-per-footprint kernel
     const bool defer = (gmi || outl) && ctx->info_wave_area > 0;
+    ctx->dc_stats_deferred = 0;
     const float defer_area = defer ? (float)ctx->info_wave_area : INFINITY;
     unsigned long long* defer_bits = nullptr;
     if (defer) { ctx->defer_bits.ensure(pw + 1); defer_bits = ctx->defer_bits.p; }
@@ -792,10 +833,18 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
             ctx->defer_list.ensure((size_t)n_def + 1);
             hipLaunchKernelGGL(defer_expand_kernel, dim3((unsigned)((pw + 255) / 256)), dim3(256), 0, s, defer_bits, ctx->defer_base.p, pw, ctx->defer_list.p); MVS_LAUNCH_CHECK();
             const dim3 wgrid((unsigned)(((size_t)n_def * 16 + 255) / 256));
-#define LAUNCH_WAVE(DT, OL) do { if (ctx->stats) hipLaunchKernelGGL((wave_info_kernel<DT, OL, true>), wgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, n_def, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p); \
-                                 else hipLaunchKernelGGL((wave_info_kernel<DT, OL, false>), wgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, n_def, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p); } while (0)
+#define WAVE_ARGS ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, n_def, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p, ctx->info_cert_shift, ctx->rewalk_list.p
+#define REWALK_ARGS ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, ctx->rewalk_list.p, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p
+#define LAUNCH_WAVE(DT, OL) do { if (ctx->stats) { hipLaunchKernelGGL((wave_info_kernel<DT, OL, true>), wgrid, dim3(256), 0, s, WAVE_ARGS); hipLaunchKernelGGL((rewalk_info_kernel<DT, OL, true>), rgrid, dim3(64), 0, s, REWALK_ARGS); } \
+                                 else { hipLaunchKernelGGL((wave_info_kernel<DT, OL, false>), wgrid, dim3(256), 0, s, WAVE_ARGS); hipLaunchKernelGGL((rewalk_info_kernel<DT, OL, false>), rgrid, dim3(64), 0, s, REWALK_ARGS); } } while (0)
+            ctx->rewalk_list.ensure((size_t)n_def + 1);
+            // one thread per uncertified footprint, a fixed grid striding over the device-side count (no read-back): 4096 threads
+            // cover what a scene produces (tens) one each; the test hook that fails every certificate takes the grid-stride loop
+            const dim3 rgrid(64);
             if (gmi) { if (outl) LAUNCH_WAVE(1, true); else LAUNCH_WAVE(1, false); } else LAUNCH_WAVE(0, true);
 #undef LAUNCH_WAVE
+#undef WAVE_ARGS
+#undef REWALK_ARGS
             MVS_LAUNCH_CHECK();
         }
     }
@@ -1057,7 +1106,7 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     mvs_dc_stats& S = ctx->dc_stats;
     S.cull_backface = hc[C_BACK]; S.cull_angle = hc[C_ANGLE]; S.cull_outside = hc[C_OUTSIDE]; S.cull_occluded = hc[C_OCCL];
     S.cull_zero_quality = hc[C_ZEROQ]; S.rays = hc[C_RAYS]; S.ray_nodes = hc[C_RNODES]; S.ray_tris = hc[C_RTRIS];
-    S.ray_packets = hc[10]; S.ray_packets_generic = hc[11];
+    S.ray_packets = hc[10]; S.ray_packets_generic = hc[11]; S.footprints_lane_group = ctx->dc_stats_deferred; S.footprints_rewalked = hc[C_REWALK];
     S.nnz = ctx->csr_nnz; S.max_quality = mq; S.percentile = pc;
     ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p; ctx->csr_q_valid = true;
     ctx->have_costs = true; ctx->dc_phase = 3;

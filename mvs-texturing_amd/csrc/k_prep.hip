@@ -384,26 +384,36 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
 // MVE is absent; DEFINED HERE from recollection of mve/image_tools.h (restated independently in oracle/oracle.cpp): every pixel
 // of the UNDISTORTED output looks up its position in the distorted source -- coordinates centred on (w/2, h/2) and normalised
 // by max(w, h), rsq = (fx^2 + fy^2) / flen^2 -- and samples it with Image::linear_at; positions more than half a pixel outside
-// stay black.  k2k4: factor = 1 + rsq k2 + rsq^2 k4.  vsfm (x_u = x_d (1 + k1 r_d^2), to be inverted): 8 Newton steps on
-// k1 r_d^3 + r_d - r_u = 0 in fp64 from r_d = r_u -- only + - * / and sqrt, so the GPU and the CPU agree bit for bit.
+// stay black.  k2k4: factor = 1 + rsq k2 + rsq^2 k4.  vsfm (x_u = x_d (1 + k1 r_d^2), to be inverted): 8 guarded Newton steps on
+// k1 r_d^3 + r_d - r_u = 0 in fp64 from r_d = r_u -- only + - * / and sqrt, so the GPU and the CPU agree bit for bit.  An APPROXIMATION
+// of MVE's routine (believed to solve the cubic in closed form): identical where Newton converges, i.e. to ~1e-16 relative.
 __global__ void __launch_bounds__(256) undistort_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int w, int h, double flen, double d0, double d1) {
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
     const double width_half = (double)w / 2.0, height_half = (double)h / 2.0, norm = (double)(w > h ? w : h);
     double fx = ((double)x - width_half) / norm, fy = ((double)y - height_half) / norm;
     double factor;
+    bool ok = true;
     if (d1 != 0.0) {
         const double rsq = (fx * fx + fy * fy) / (flen * flen);
         factor = 1.0 + rsq * d0 + (rsq * rsq) * d1;
     } else {
         const double ru = sqrt(fx * fx + fy * fy) / flen;
         double rd = ru;
-        for (int it = 0; it < 8; ++it) rd = rd - (((d0 * rd) * rd) * rd + rd - ru) / ((3.0 * d0) * (rd * rd) + 1.0);
+        // guarded: for k1 < 0 the cubic has a turning point at r_d = 1 / sqrt(-3 k1) (derivative 3 k1 r_d^2 + 1 -> 0); beyond it there is
+        // no distorted radius on the monotone branch.  A step whose derivative is not safely positive, or an iteration that has
+        // not converged (residual against r_u), marks the pixel as having no source: it stays black.
+        for (int it = 0; it < 8 && ok; ++it) {
+            const double den = (3.0 * d0) * (rd * rd) + 1.0;
+            if (!(den > 1e-3)) ok = false; else rd = rd - (((d0 * rd) * rd) * rd + rd - ru) / den;
+        }
+        if (ok) { const double res = ((d0 * rd) * rd) * rd + rd - ru; ok = (res < 0.0 ? -res : res) <= 1e-9 * (1.0 + ru); }
         factor = ru > 0.0 ? rd / ru : 1.0;
     }
     fx = (fx * factor) * norm + width_half;
     fy = (fy * factor) * norm + height_half;
     uint8_t* o = dst + ((size_t)y * w + x) * 3;
+    if (!ok) { o[0] = o[1] = o[2] = 0; return; }
     if (!(fx >= -0.5 && fx <= (double)w - 0.5 && fy >= -0.5 && fy <= (double)h - 0.5)) { o[0] = o[1] = o[2] = 0; return; }
     fx = fx < 0.0 ? 0.0 : (fx > (double)w - 1.0 ? (double)w - 1.0 : fx);
     fy = fy < 0.0 ? 0.0 : (fy > (double)h - 1.0 ? (double)h - 1.0 : fy);

@@ -59,6 +59,9 @@ struct mvs_comm {
     enum Op { SUM, MAX };
     virtual void allreduce(void* buf, size_t n, Type t, Op op, hipStream_t s) = 0;          // in place, device buffer
     virtual void allgather(const void* send, void* recv, size_t bytes, hipStream_t s) = 0;  // recv = world x bytes
+    // true: exchange / exchange2 are world-wide rendezvous -- EVERY rank has to call them, also with nothing to send or receive
+    // (the in-process communicator counts barriers over all ranks); false: point-to-point, a rank without traffic may skip the call
+    virtual bool exchange_is_collective() const { return false; }
     // neighbour exchange of byte ranges: send + soff[q] .. soff[q + 1] goes to rank q, recv + roff[q] .. comes from rank q
     virtual void exchange(const uint8_t* send, const uint64_t* soff, uint8_t* recv, const uint64_t* roff, hipStream_t s) = 0;
     // two ranges per peer in ONE group (message bytes + label words of a colour phase)
@@ -152,6 +155,7 @@ struct LocalHub {
 struct LocalComm : mvs_comm {
     std::shared_ptr<LocalHub> hub;
     ~LocalComm() override {}
+    bool exchange_is_collective() const override { return true; }
     void rendezvous_copy(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
                          const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {
         LocalHub& H = *hub;
@@ -533,7 +537,9 @@ void exchange_phase(mvs_shard* S, uint32_t ph) {
     std::vector<uint64_t> so_m, ro_m, so_n, ro_n;
     phase_offsets(S->msg_send, P, C, ph, 1, so_m); phase_offsets(S->msg_recv, P, C, ph, 1, ro_m);
     phase_offsets(S->node_send, P, C, ph, 4, so_n); phase_offsets(S->node_recv, P, C, ph, 4, ro_n);
-    if (so_m[P] + ro_m[P] + so_n[P] + ro_n[P] == 0) return;
+    // a rank with no boundary or halo node of this colour (or an empty part) skips the call only on a point-to-point communicator:
+    // the in-process one is a rendezvous of all ranks, and a rank that stayed away would pair its NEXT operation with this one
+    if (so_m[P] + ro_m[P] + so_n[P] + ro_n[P] == 0 && !S->comm->exchange_is_collective()) return;
     // ONE pack launch (message bytes and labels of the whole phase, all peers), one grouped exchange, ONE unpack launch
     const uint64_t ms0 = S->msg_send.off[(size_t)ph * P], nms = S->msg_send.off[(size_t)(ph + 1) * P] - ms0;
     const uint64_t ns0 = S->node_send.off[(size_t)ph * P], nns = S->node_send.off[(size_t)(ph + 1) * P] - ns0;
@@ -558,7 +564,7 @@ void exchange_nodes(mvs_shard* S, uint32_t* arr) {
     const int P = S->P;
     std::vector<uint64_t> so((size_t)P + 1), ro((size_t)P + 1);
     for (int q = 0; q <= P; ++q) { so[q] = S->all_send.off[q] * 4; ro[q] = S->all_recv.off[q] * 4; }   // peer-major lists over all phases
-    if (so[P] + ro[P] == 0) return;
+    if (so[P] + ro[P] == 0 && !S->comm->exchange_is_collective()) return;
     const uint64_t ns = S->all_send.total, nr = S->all_recv.total;
     if (ns) { hipLaunchKernelGGL(pack_words_kernel, dim3(grid_for(ns)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->all_send.idx.p, ns, S->sbuf_node.p); MVS_LAUNCH_CHECK(); }
     S->comm->exchange((const uint8_t*)S->sbuf_node.p, so.data(), (uint8_t*)S->rbuf_node.p, ro.data(), s);
@@ -629,7 +635,17 @@ mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_b
     MVS_API_END
 }
 
-void mvs_shard_destroy(mvs_shard* shard) { delete shard; }
+void mvs_shard_destroy(mvs_shard* shard) {
+    if (!shard) return;
+    // the context's active table may point into this shard's buffers (mvs_shard_data_costs): no dangling pointers behind
+    mvs_ctx* ctx = shard->ctx;
+    if (ctx && (ctx->r_ptr == shard->t_ptr.p || ctx->r_view == shard->t_view.p || ctx->r_cost == shard->t_cost.p)) {
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->have_costs = false; ctx->dc_phase = 0; ctx->csr_q_valid = false;
+        ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p;
+    }
+    delete shard;
+}
 
 /* tex::calculate_data_costs over all ranks (calculate_data_costs.cpp:308-323): afterwards the context holds the cost table
  * of the GLOBAL shape with the own and the halo columns filled */

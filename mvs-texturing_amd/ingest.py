@@ -206,6 +206,11 @@ def load_scene(scene_dir, mesh_path=None):
         img = load_image_rgb8(img_path)
         if cam.dist[0] != 0.0:   # generate_texture_views.cpp:153-165: k2k4 when both coefficients are set, else the VisualSFM model
             from .viewsel import undistort_image
+            import sys
+            # MVE's own routines are not available to compare with: the models are restated from recollection (k_prep.hip
+            # undistort_kernel), the VisualSFM one inverted by guarded Newton steps -- an approximation of upstream, said so here
+            print("[mvs ingest] %s: undistorting with the %s model as restated in this library (approximates MVE's image_undistort_*)"
+                  % (os.path.basename(img_path), "k2k4" if cam.dist[1] != 0.0 else "VisualSFM"), file=sys.stderr)
             img = undistort_image(img, cam.flen, cam.dist[0], cam.dist[1])
         h, w = img.shape[:2]
         arr = camera_arrays(cam, w, h)

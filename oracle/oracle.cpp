@@ -809,18 +809,25 @@ void orc_undistort(const uint8_t* rgb, int w, int h, float flen_f, float dist0, 
         for (int x = 0; x < w; ++x) {
             double fx = ((double)x - width_half) / norm, fy = ((double)y - height_half) / norm;
             double factor;
+            bool ok = true;
             if (d1 != 0.0) {
                 const double rsq = (fx * fx + fy * fy) / (flen * flen);
                 factor = 1.0 + rsq * d0 + (rsq * rsq) * d1;
             } else {
                 const double ru = std::sqrt(fx * fx + fy * fy) / flen;
                 double rd = ru;
-                for (int it = 0; it < 8; ++it) rd = rd - (((d0 * rd) * rd) * rd + rd - ru) / ((3.0 * d0) * (rd * rd) + 1.0);
+                // guarded Newton (see k_prep.hip undistort_kernel): no safely positive derivative, or no convergence -> no source pixel
+                for (int it = 0; it < 8 && ok; ++it) {
+                    const double den = (3.0 * d0) * (rd * rd) + 1.0;
+                    if (!(den > 1e-3)) ok = false; else rd = rd - (((d0 * rd) * rd) * rd + rd - ru) / den;
+                }
+                if (ok) { const double res = ((d0 * rd) * rd) * rd + rd - ru; ok = (res < 0.0 ? -res : res) <= 1e-9 * (1.0 + ru); }
                 factor = ru > 0.0 ? rd / ru : 1.0;
             }
             fx = (fx * factor) * norm + width_half;
             fy = (fy * factor) * norm + height_half;
             uint8_t* o = out + ((size_t)y * w + x) * 3;
+            if (!ok) { o[0] = o[1] = o[2] = 0; continue; }
             if (!(fx >= -0.5 && fx <= (double)w - 0.5 && fy >= -0.5 && fy <= (double)h - 0.5)) { o[0] = o[1] = o[2] = 0; continue; }
             fx = std::max(0.0, std::min((double)w - 1.0, fx));
             fy = std::max(0.0, std::min((double)h - 1.0, fy));

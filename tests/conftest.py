@@ -9,10 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
-# The parity tests compare qualities BIT for bit with the oracle's serial fp64 scan-line sums: every footprint is walked
-# serially unless a test asks for the lane-group sampler explicitly (set_option("info_wave_area", ...)); the default of the
-# library (32 pixels) is what bench.py and test_wave_per_footprint_kernel_against_the_oracle / the BASELINE-config tests run.
-os.environ.setdefault("MVS_INFO_WAVE_AREA", "0")
+# The parity tests run the library's DEFAULTS: footprints above 32 pixels are summed by a 16-lane group (integer pixel sums) under
+# an exactness certificate, the few it cannot decide are re-walked serially (k_dc.hip wave_info_kernel / rewalk_info_kernel), so
+# qualities are compared BIT for bit with the oracle's serial fp64 scan-line sums in every test.  Tests that want the serial
+# walker everywhere, or every certificate to fail, say so (set_option("info_wave_area", 0) / ("info_cert_shift", 40)).
+os.environ.pop("MVS_INFO_WAVE_AREA", None)
 
 
 def pytest_configure(config):

@@ -307,3 +307,27 @@ def test_cull_prefilter_equals_cull_pair_on_adversarial_pairs():
     assert np.array_equal(out[:, 0], out[:, 1]), np.flatnonzero(out[:, 0] != out[:, 1])[:10]
     counts = [(out[:, 0] == r).sum() for r in (1, 2, 3, 0)]
     assert min(counts[:3]) > 1000, counts            # every reason occurs often (reason 0 needs the triangle inside the image)
+
+
+def test_footprint_exactness_certificate_on_the_host():
+    """dmath.h foot_sums_certified -- the certificate under which the lane-group footprint sampler (k_dc.hip wave_info_kernel)
+    takes a quality / mean colour from INTEGER pixel sums instead of the reference's serial fp64 sum of quotients
+    (texture_view.cpp:205-216) -- against what it certifies: random footprints of 33 .. 4000 pixels, the integer-sum result next
+    to serial sums in three orders.  A certified footprint never differs (that is the claim); uncertified ones are rare at shift 0
+    and include every real mismatch; widening the interval (the test hook of the GPU tests) only moves footprints to 'uncertified'."""
+    import ctypes as C
+    path = os.path.join(ROOT, "mvs-texturing_amd", "csrc", "libmvs_dmath_host.so")
+    if not os.path.exists(path):
+        pytest.skip("libmvs_dmath_host.so not built")
+    L = C.CDLL(path)
+    L.dmh_foot_cert_trials.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]
+    res = {}
+    for shift, trials, max_n in ((0, 150000, 4000), (10, 60000, 4000), (22, 30000, 2000), (40, 2000, 500)):
+        out = (C.c_uint64 * 4)()
+        L.dmh_foot_cert_trials(11, trials, max_n, shift, out)
+        cert, mis, bad, n = [int(x) for x in out]
+        res[shift] = (cert, mis, bad, n)
+        assert bad == 0, "a certified footprint differs from a serial fp64 sum: %r" % (res,)
+        assert mis <= n - cert
+    assert res[0][0] > 0.999 * res[0][3]          # at shift 0 almost everything is certified ...
+    assert res[40][0] < 0.05 * res[40][3]         # ... and the GPU tests' hook (shift 40) certifies next to nothing
