@@ -486,7 +486,7 @@ def main():
     # bytes the path does not move earn no credit).  N_ray_nodes / N_ray_tris = node visits and (ray, triangle) tests of the packet
     # traversal of this scene, counted once outside the timed region (option "count_rays").
     roof_path = None
-    if rank == 0 and world == 1 and not args.shard and args.steps > 0:
+    if rank == 0 and world == 1 and not args.shard and args.steps > 0 and not args.no_traffic:   # (--no-traffic = the counter passes' own child runs)
         W, H = cfg["width"], cfg["height"]
         c2 = M.Context(local_rank)   # its own context: the table of the last timed step stays on `ctx` for the parity check
         try:
@@ -511,11 +511,9 @@ def main():
                      "N_ray_nodes": n_nodes, "N_ray_tris": n_tris, "rays": int(cst["rays"]), "nnz_pre": nnz_pre,
                      "note": "algorithmic bytes of BASELINE.md section 5 over the whole timed step; the data-cost half is bound by vector issue, "
                              "not by HBM (see stage_roofline[*].valu_issue_frac)"}
-        issue = None
-        if not args.no_traffic:
-            issue, issue_kernels = measure_issue(args.config)
-            if issue is None:
-                roof_path["issue_error"] = issue_kernels
+        issue, issue_kernels = measure_issue(args.config)
+        if issue is None:
+            roof_path["issue_error"] = issue_kernels
         table = {}
         for st_name, b in b_stage.items():
             if st_name not in stages:

@@ -156,6 +156,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ray_xcd") ctx->ray_xcd = (int)value;
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;
     else if (n == "mrf_lag") ctx->mrf_lag = (int)value;
+    else if (n == "mrf_force_generic") ctx->mrf_force_generic = value != 0;
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);

@@ -189,9 +189,12 @@ struct mvs_ctx {
     uint32_t m_energy_blocks = 0;   // per-block partial pairs the last mrf_energy left behind m_energy.p + 4
     bool m_energy_from_sweep = false;   // ... or the last sweep's own kernels did (fast path: the energy is accumulated while sweeping)
     uint64_t m_total = 0; uint32_t m_kmax = 0, m_degmax = 0;
-    // colour-phased schedule: colours of the adjacency graph, nodes in (colour, id) order, class boundaries (host copy)
-    mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c; uint32_t m_colours = 0; std::vector<uint32_t> m_colour_begin;
-    uint32_t m_range_nb = 0, m_range_ne = 0; std::vector<uint32_t> m_range_q;   // cached own share of every colour class
+    // colour-phased schedule: colours of the adjacency graph and per-node classes (k_mrf.hip mrf_node_class); nodes in SCHEDULE order =
+    // sorted by sub-class key (fast nodes by (colour, class, id), then generic nodes by (colour, id)); m_sub_begin[key] = first position
+    // of a key >= `key` (host copy of m_sub); positions [0, m_n_fast) are the fast nodes
+    mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c, m_sub; mvs::DBuf<uint8_t> m_cls; uint32_t m_colours = 0, m_n_fast = 0; std::vector<uint32_t> m_sub_begin;
+    int mrf_force_generic = 0;   // test hook: every node takes the generic sweep kernel
+    uint32_t m_range_nb = 0, m_range_ne = 0; std::vector<uint32_t> m_range_q;   // cached own share of every sub-class
     uint32_t m_sweep_no = 0;   // sweeps started since mrf_setup (1-based inside a sweep): odd sweeps are damped
     mvs_mrf_params m_params{};
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring

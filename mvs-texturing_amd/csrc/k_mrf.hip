@@ -164,19 +164,36 @@ __device__ __forceinline__ uint32_t group_min_fused(uint32_t v) {
 }
 
 // ---- setup ----
+// Node classes: the sweep is routed PER NODE, not per solve.  A node of degree <= 3 whose own column and whose in-model
+// neighbours' columns hold at most 255 labels is a FAST node, swept by mrf_sweep4_kernel<G> with the lane-group width of its
+// neighbourhood: G = 8 / 16 / 32 / 64 for kmx = max(K_i, K_j) <= 32 / 64 / 128 / 255 (classes 0 .. 3; the node's three outgoing runs are
+// as long as the NEIGHBOURS' label lists, so they count).  Everything else -- a non-manifold edge (degree > 3), a column of more
+// than 255 labels at the node or next to it -- is a GENERIC node (class 4): one wave per node, any degree, any K.  One
+// non-manifold edge or one long column therefore costs a handful of generic nodes, not the whole solve, and the lane-group
+// width follows the local column sizes instead of the largest column of the mesh.  A colour class is an independent set, so
+// the order in which its nodes are swept -- hence the split into launches -- cannot change the result.
+constexpr uint32_t CLS_GENERIC = 4;
+__device__ __forceinline__ uint32_t mrf_node_class(uint32_t kmx, uint32_t deg, uint32_t force_generic) {
+    if (force_generic || deg > 3u || kmx > 255u) return CLS_GENERIC;
+    return kmx <= 32u ? 0u : kmx <= 64u ? 1u : kmx <= 128u ? 2u : 3u;
+}
 __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
-                                uint32_t F, uint32_t pad_mask, uint32_t* __restrict__ size, uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
+                                uint32_t F, uint32_t pad_mask, uint32_t force_generic, uint32_t* __restrict__ size, uint8_t* __restrict__ cls,
+                                uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t k = 0, deg = 0;
     if (i < F) {
         k = col_ptr[i + 1] - col_ptr[i];
         const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
         deg = e1 - e0;
+        uint32_t kmx = k;
         for (uint32_t e = e0; e < e1; ++e) {
             const uint32_t j = adj[e];
             const uint32_t kj = col_ptr[j + 1] - col_ptr[j];
             size[e] = (k > 0 && kj > 0) ? ((k + pad_mask) & ~pad_mask) : 0u;   // runs padded to a multiple of 4 (8-byte quads) or 16 elements (32-byte sectors)
+            if (k > 0) kmx = max(kmx, kj);
         }
+        cls[i] = (uint8_t)mrf_node_class(kmx, deg, force_generic);
     }
     for (int o = 32; o > 0; o >>= 1) { k = max(k, (uint32_t)__shfl_xor(k, o, 64)); deg = max(deg, (uint32_t)__shfl_xor(deg, o, 64)); }
     // same-address atomics serialise (~12 ns each): only waves that can still raise a maximum issue one
@@ -218,20 +235,29 @@ __global__ void mrf_colour_round_kernel(const uint32_t* __restrict__ adj_ptr, co
         __hip_atomic_store(colour + i, (uint32_t)__builtin_ctzll(~used), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else *pending = 1u;                                       // racing stores of the same value
 }
-// colour_begin[c] = first position of colour >= c in the sorted colour array, c = 0 .. 64
-__global__ void mrf_colour_begin_kernel(const uint32_t* __restrict__ sorted, uint32_t F, uint32_t* __restrict__ colour_begin) {
-    const uint32_t c = threadIdx.x;
-    if (c > 64u) return;
+// Schedule order = nodes sorted by SUB-CLASS key: fast nodes first, by (colour, class, id) -- key = 4 * colour + class < 256 --
+// then the generic nodes by (colour, id) -- key = 256 + colour.  Every (colour, class) pair is one contiguous range of the
+// order = one launch; the fast nodes (their records and descriptors) are positions [0, n_fast).
+constexpr uint32_t N_SUB = 320;            // keys 0 .. 319 (64 colours x 4 fast classes, 64 generic colour classes)
+constexpr uint32_t SUB_GENERIC = 256;
+__global__ void mrf_sortkey_kernel(const uint32_t* __restrict__ colour, const uint8_t* __restrict__ cls, uint32_t F, uint32_t* __restrict__ key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < F) { const uint32_t c = colour[i], k = cls[i]; key[i] = (k == CLS_GENERIC) ? SUB_GENERIC + c : 4u * c + k; }
+}
+// sub_begin[k] = first position of a key >= k in the sorted key array, k = 0 .. N_SUB
+__global__ void mrf_sub_begin_kernel(const uint32_t* __restrict__ sorted, uint32_t F, uint32_t* __restrict__ sub_begin) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > N_SUB) return;
     uint32_t lo = 0, hi = F;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted[mid] < c) lo = mid + 1; else hi = mid; }
-    colour_begin[c] = lo;
+    sub_begin[c] = lo;
 }
-// own share of every colour class: positions of the ids in [nb, ne) inside perm[cb[c], cb[c + 1]) (ids ascending)
-__global__ void mrf_phase_range_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ colour_begin, uint32_t C,
-                                       uint32_t nb, uint32_t ne, uint32_t* __restrict__ out) {
-    const uint32_t c = threadIdx.x;
-    if (c >= C) return;
-    const uint32_t cb = colour_begin[c], ce = colour_begin[c + 1];
+// own share of every sub-class: positions of the ids in [nb, ne) inside perm[sb[k], sb[k + 1]) (ids ascending inside a sub-class)
+__global__ void mrf_sub_range_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sub_begin,
+                                     uint32_t nb, uint32_t ne, uint32_t* __restrict__ out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N_SUB) return;
+    const uint32_t cb = sub_begin[c], ce = sub_begin[c + 1];
     uint32_t lo = cb, hi = ce;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (perm[mid] < nb) lo = mid + 1; else hi = mid; }
     out[2 * c] = lo;
@@ -316,18 +342,14 @@ __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint
     }
 }
 
-__global__ void mrf_identity_kernel(uint16_t* __restrict__ map) { map[threadIdx.x] = (uint16_t)threadIdx.x; }
-
-// map[in_off(e) + t] = position of L_i[t] in L_j (binary search; lists ascending, calculate_data_costs.cpp:272)
-// ident[e] = 1 iff the two label lists of edge e are identical (map == identity), i.e. the sender's out-edge rev(e) can skip it.
-// With skip_ident (fast sweep path: identical-list edges read the reserved identity run instead) the map of such an
-// edge is not even written -- three quarters of the edges on the synthetic scenes.
+// map[in_off(e) + t] = position of L_i[t] in L_j (binary search; lists ascending, calculate_data_costs.cpp:272), for the in-edges
+// e = (i <- j) whose SENDER j is a generic node: the generic sweep kernel re-aligns its outgoing runs through these 16-bit maps
+// (fast senders carry byte maps in their records).
 constexpr uint32_t MAP_TILE = 256;   // neighbour lists up to this length are searched in LDS
 __global__ void __launch_bounds__(256) mrf_map_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
-                               const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint16_t* __restrict__ map,
-                               uint8_t* __restrict__ ident, int skip_ident) {
-    // 16 lanes per node.  The binary search is a chain of dependent loads: through global memory it is latency bound
-    // (1.4 ms at C3), so the neighbour's list is first copied (coalesced) into the group's LDS tile.  A group never spans
+                               const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ cls, uint16_t* __restrict__ map) {
+    // 16 lanes per node.  The binary search is a chain of dependent loads: through global memory it is latency bound,
+    // so the neighbour's list is first copied (coalesced) into the group's LDS tile.  A group never spans
     // waves and LDS operations of a wave execute in order, so the tile needs no barrier.
     __shared__ uint16_t s_l[16][MAP_TILE];
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -337,15 +359,8 @@ __global__ void __launch_bounds__(256) mrf_map_kernel(const uint32_t* __restrict
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
         const MrfEdge m = edge[e];
-        if (m.kj == 0) continue;
+        if (m.kj == 0 || cls[adj[e]] != CLS_GENERIC) continue;  // group-uniform
         const uint32_t q0 = col_ptr[adj[e]];
-        uint32_t same = (K == m.kj) ? 1u : 0u;
-        if (same) {                                            // group-uniform: compare the two lists element by element (coalesced)
-            for (uint32_t t = gl; t < K; t += 16) same &= (view_id[p0 + t] == view_id[q0 + t]) ? 1u : 0u;
-            for (int o = 8; o > 0; o >>= 1) same &= __shfl_xor(same, o, 16);
-        }
-        if (gl == 0) ident[e] = (uint8_t)same;
-        if (same && skip_ident) continue;
         const bool in_lds = m.kj <= MAP_TILE;                  // group-uniform
         if (in_lds) for (uint32_t t = gl; t < m.kj; t += 16) tile[t] = view_id[q0 + t];
         for (uint32_t t = gl; t < K; t += 16) {
@@ -359,7 +374,7 @@ __global__ void __launch_bounds__(256) mrf_map_kernel(const uint32_t* __restrict
     }
 }
 
-// ---- fast path (degree <= 3, every column <= 255 labels): per-node RECORDS + 48-byte descriptors ----
+// ---- fast nodes (degree <= 3, columns of the neighbourhood <= 255 labels): per-node RECORDS + 48-byte descriptors ----
 // The sweep streams, per node and in (colour, id) order, ONE read-only record instead of gathering from the CSR:
 //   [ceil4(K) label words: cost code << 16 | view id]  [for every out-edge whose two label lists differ: ceil4(K_j) map bytes]
 // padded to a multiple of four words.  A phase reads a contiguous run of records: no partially used lines (a phase used to
@@ -374,10 +389,11 @@ __device__ __forceinline__ float cost_value(uint32_t code) { return (float)code 
 // ident[e] = 1 iff the two label lists of the (valid) directed edge e are identical; 16 lanes per node.  The kernel is a chain
 // of dependent gathers (edge -> neighbour -> its column -> its view ids), so three edges are in flight at a time.
 __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
-                                                        const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, uint8_t* __restrict__ ident) {
+                                                        const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ cls,
+                                                        uint8_t* __restrict__ ident) {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
-    if (i >= F) return;
+    if (i >= F || cls[i] == CLS_GENERIC) return;               // only fast nodes have records
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
     for (uint32_t e = e0; e < e1; e += 3) {
@@ -406,14 +422,14 @@ __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restri
 // rsz[q] = words of the record of node perm[q] (rsz[F] = 0)
 // qpos[i] = position of node i in the (colour, id) order (the inverse of perm)
 __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge,
-                                   const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm, uint32_t F, uint32_t* __restrict__ rsz, uint32_t* __restrict__ qpos) {
+                                   const uint8_t* __restrict__ ident, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ perm, uint32_t F, uint32_t* __restrict__ rsz, uint32_t* __restrict__ qpos) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > F) return;
     uint32_t w = 0;
     if (q < F) {
         const uint32_t i = perm[q], K = col_ptr[i + 1] - col_ptr[i];
         qpos[i] = q;
-        if (K) {
+        if (K && cls[i] != CLS_GENERIC) {
             w = (K + 3u) & ~3u;
             for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { const uint32_t kj = edge[e].kj; if (kj && !ident[e]) w += (kj + 3u) >> 2; }
             w = (w + 3u) & ~3u;
@@ -427,15 +443,17 @@ __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const u
 // execute in order: no barrier)
 __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                          const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
-                                                         const uint8_t* __restrict__ ident, const uint32_t* __restrict__ qpos, const uint32_t* __restrict__ roff,
-                                                         uint32_t F, uint32_t none_byte /* what "label absent at the sender" is stored as: the sweep's +inf slot (4 * G), 0xFF for G = 64 */,
-                                                         uint32_t* __restrict__ rec) {
+                                                         const uint8_t* __restrict__ ident, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ qpos, const uint32_t* __restrict__ roff,
+                                                         uint32_t F, uint32_t* __restrict__ rec) {
     __shared__ uint16_t s_l[16][256];
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
     if (i >= F) return;
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-    if (K == 0) return;
+    const uint32_t ci = cls[i];
+    if (K == 0 || ci == CLS_GENERIC) return;
+    // what "label absent at the sender" is stored as: the +inf slot of the node's sweep kernel (4 * G, G = 8 << class), 0xFF for G = 64
+    const uint32_t none_byte = ci < 3u ? (32u << ci) : 0xFFu;
     const uint32_t q = qpos[i];
     uint16_t* tile = s_l[threadIdx.x >> 4];
     uint32_t* out = rec + REC_BASE + roff[q];
@@ -478,9 +496,9 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
 }
 __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ ident, const uint32_t* __restrict__ perm,
-                                const uint32_t* __restrict__ colour, const uint32_t* __restrict__ roff, uint32_t F, NodeDesc* __restrict__ desc) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // position in the (colour, id) order
-    if (q >= F) return;
+                                const uint32_t* __restrict__ colour, const uint32_t* __restrict__ roff, uint32_t n_fast, NodeDesc* __restrict__ desc) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // position in the schedule order; the fast nodes come first
+    if (q >= n_fast) return;
     const uint32_t i = perm[q];
     NodeDesc nd;
     const uint32_t k = col_ptr[i + 1] - col_ptr[i];
@@ -669,51 +687,83 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
 }
 
 
-// generic path: any degree, any K.  One wave per node, cavity vector through a global scratch row.
+// generic nodes: any degree, any K.  One wave per node (persistent waves striding over the range), cavity vector through a global
+// scratch row (a wave's own stores and loads of that row are ordered by workgroup-scope fences; rows of different nodes are
+// disjoint).  Same arithmetic as the fast kernel / the oracle; the node's share of the sweep's tracking energy (cost code of
+// the decoded label + one cut per model edge to a lower-coloured neighbour whose label differs) goes into per-block partials
+// like the fast kernel's.
 template <bool DAMP>
-__global__ void __launch_bounds__(64) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                                               const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge, const uint16_t* __restrict__ map,
-                                                               msg_t* msg, const uint32_t* __restrict__ perm, const mvs_mrf_progress* __restrict__ st,
-                                                               uint32_t* __restrict__ sel2, uint32_t* __restrict__ lab2, float* __restrict__ cost2, uint32_t buf_stride,
-                                                               float* __restrict__ scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha) {
+__global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                                const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
+                                                                const uint16_t* __restrict__ map, const uint32_t* __restrict__ colour,
+                                                                msg_t* msg, const uint32_t* __restrict__ perm, const mvs_mrf_progress* __restrict__ st,
+                                                                uint32_t* sel2, uint32_t* lab2, float* cost2, uint32_t buf_stride,
+                                                                float* scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha,
+                                                                unsigned long long* __restrict__ partial) {
     const msg_t* mo = msg; msg_t* mn = msg;                  // in place (one colour per launch)
-    const int lane = threadIdx.x;
-    if (node_begin + blockIdx.x >= node_end) return;
+    __shared__ unsigned long long s_e[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wofs = st->w * buf_stride;
-    uint32_t* __restrict__ sel = sel2 + wofs; uint32_t* __restrict__ lab = lab2 + wofs; float* __restrict__ selcost = cost2 + wofs;
-    const uint32_t i = perm[node_begin + blockIdx.x];
-    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-    if (K == 0) { if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; } return; }
-    const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+    uint32_t* sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* selcost = cost2 + wofs;
     const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
     const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;
-    // b[t] goes through the scratch row (K is unbounded here); same arithmetic as the fast path / the oracle
-    float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
-    for (uint32_t t = lane; t < K; t += 64) {
-        float Sc = 0.0f;
-        for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) Sc = Sc + (float)mo[m.in_off + t]; }
-        const float b = __builtin_fmaf(kappa, Sc, cost_value(cost_code(cost[p0 + t])));   // the unaries as the sweeps see them: 16-bit fixed point
-        scratch[p0 + t] = b;
-        if (b < bb) { bb = b; bt = t; }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(bb, o, 64); const uint32_t ot = __shfl_xor(bt, o, 64);
-        if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
-    }
-    if (lane == 0) { sel[i] = bt; lab[i] = (uint32_t)view_id[p0 + bt] + 1u; selcost[i] = cost_value(cost_code(cost[p0 + bt])); }
-    __syncthreads();
-    for (uint32_t e = e0; e < e1; ++e) {
-        const MrfEdge m = edge[e];
-        if (!m.kj) continue;  // wave-uniform
-        float cmin = INFINITY;
-        for (uint32_t t = lane; t < K; t += 64) cmin = fminf(cmin, __builtin_fmaf(nstep, (float)mo[m.in_off + t], scratch[p0 + t]) * oms);
-        for (int o = 32; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, 64));
-        for (uint32_t t2 = lane; t2 < m.kj; t2 += 64) {
-            const uint16_t p = map[m.out_off + t2];
-            const float raw = (p == MAP_NONE) ? lam_s : fminf(__builtin_fmaf(nstep, (float)mo[m.in_off + p], scratch[p0 + p]) * oms - cmin, lam_s);
-            mn[m.out_off + t2] = (msg_t)msg_pack_s<DAMP>(raw, alpha, (float)mo[m.out_off + t2], 0u, 0u);
+    unsigned long long acc_e = 0ull, acc_c = 0ull;           // lane 0 of the wave accumulates
+    for (uint32_t q = node_begin + blockIdx.x * 4u + (uint32_t)wave; q < node_end; q += gridDim.x * 4u) {   // wave-uniform
+        const uint32_t i = perm[q];
+        const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
+        if (K == 0) {   // the single label 0 with unary 1 (view_selection.cpp:50-51,70-71): cost code 65535, no model edge
+            if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; acc_e += 65535ull; }
+            continue;
         }
+        const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+        // b[t] goes through the scratch row (K is unbounded here)
+        float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
+        for (uint32_t t = lane; t < K; t += 64) {
+            float Sc = 0.0f;
+            for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) Sc = Sc + (float)mo[m.in_off + t]; }
+            const float b = __builtin_fmaf(kappa, Sc, cost_value(cost_code(cost[p0 + t])));   // the unaries as the sweeps see them: 16-bit fixed point
+            scratch[p0 + t] = b;
+            if (b < bb) { bb = b; bt = t; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(bb, o, 64); const uint32_t ot = __shfl_xor(bt, o, 64);
+            if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
+        }
+        const uint32_t my_lab = (uint32_t)view_id[p0 + bt] + 1u, my_code = cost_code(cost[p0 + bt]);
+        if (lane == 0) { sel[i] = bt; lab[i] = my_lab; selcost[i] = cost_value(my_code); acc_e += my_code; }
+        // cut edges to lower-coloured neighbours (their labels of this sweep are final): one edge per lane
+        {
+            const uint32_t ci = colour[i];
+            uint32_t cuts = 0;
+            for (uint32_t e = e0 + lane; e < e1; e += 64) {
+                const uint32_t j = adj[e];
+                if (edge[e].kj != 0u && colour[j] < ci && lab[j] != my_lab) ++cuts;
+            }
+            for (int o = 32; o > 0; o >>= 1) cuts += __shfl_xor(cuts, o, 64);
+            if (lane == 0) acc_c += cuts;
+        }
+        // the scratch row written above is read below by other lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t e = e0; e < e1; ++e) {
+            const MrfEdge m = edge[e];
+            if (!m.kj) continue;  // wave-uniform
+            float cmin = INFINITY;
+            for (uint32_t t = lane; t < K; t += 64) cmin = fminf(cmin, __builtin_fmaf(nstep, (float)mo[m.in_off + t], scratch[p0 + t]) * oms);
+            for (int o = 32; o > 0; o >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, o, 64));
+            for (uint32_t t2 = lane; t2 < m.kj; t2 += 64) {
+                const uint16_t p = map[m.out_off + t2];
+                const float raw = (p == MAP_NONE) ? lam_s : fminf(__builtin_fmaf(nstep, (float)mo[m.in_off + p], scratch[p0 + p]) * oms - cmin, lam_s);
+                mn[m.out_off + t2] = (msg_t)msg_pack_s<DAMP>(raw, alpha, (float)mo[m.out_off + t2], 0u, 0u);
+            }
+        }
+    }
+    if (lane == 0) { s_e[wave] = acc_e; s_e[4 + wave] = acc_c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long e = s_e[0] + s_e[1] + s_e[2] + s_e[3], c = s_e[4] + s_e[5] + s_e[6] + s_e[7];
+        partial[2 * blockIdx.x] = e + 65535ull * c; partial[2 * blockIdx.x + 1] = c;
     }
 }
 
@@ -972,13 +1022,7 @@ __global__ void mrf_flip_kernel(mvs_mrf_progress* __restrict__ st) { st->best_w 
 
 }  // namespace
 
-static bool mrf_fast_path(const mvs_ctx* ctx) {
-    return ctx->m_degmax <= 3 && ctx->m_kmax <= 255 && ctx->csr_nnz >= 4 && ctx->m_total > MSG_BASE;
-}
-// lanes per node of the fast sweep for the largest column, and the byte "label absent at the sender" is recorded as
-static int mrf_group(uint32_t kmax) { return kmax <= 32 ? 8 : kmax <= 64 ? 16 : kmax <= 128 ? 32 : 64; }
-static uint32_t mrf_none_byte(uint32_t kmax) { const int g = mrf_group(kmax); return g < 64 ? (uint32_t)(4 * g) : 0xFFu; }
-constexpr uint32_t EPART_BLOCKS = 2048;   // per colour phase: upper bound of the sweep grid (resident blocks)
+constexpr uint32_t EPART_BLOCKS = 2048;   // per colour phase: upper bound of the blocks of all its launches together (resident blocks)
 
 // Builds the solver's edge tables for the active CSR (ctx->r_ptr / r_view / r_cost) and adjacency.
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
@@ -999,10 +1043,13 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 8 * sizeof(uint32_t), s));
     MVS_HIP(hipMemsetAsync(ctx->m_size.p, 0, ((size_t)E + 2) * sizeof(uint32_t), s));
     const unsigned nb = (F + 255) / 256;
-    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), ctx->m_size.p, maxes); MVS_LAUNCH_CHECK(); }
+    // degenerate inputs (fewer than four table entries, no edge at all) take the generic kernel throughout; "mrf_force_generic" is a test hook
+    const uint32_t force_generic = (ctx->csr_nnz < 4 || E == 0 || ctx->mrf_force_generic) ? 1u : 0u;
+    ctx->m_cls.ensure((size_t)F + 4);
+    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), force_generic, ctx->m_size.p, ctx->m_cls.p, maxes); MVS_LAUNCH_CHECK(); }
     // ---- colour-phased schedule: colouring (Jones-Plassmann rounds), nodes in (colour, id) order ----
     ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 72); ctx->m_tmp_b.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
-    ctx->m_colours = 0; ctx->m_colour_begin.assign(66, 0); ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
+    ctx->m_colours = 0; ctx->m_sub_begin.assign(N_SUB + 1, 0); ctx->m_n_fast = 0; ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
     ctx->m_sweep_no = 0;
     if (F) {
         uint32_t* pending = ctx->m_moved.p + 1;   // [0] a node is still waiting, [1] a node saw all 64 colours around it
@@ -1019,18 +1066,21 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
             if (!hp[0]) break;
         }
         MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 4 * sizeof(uint32_t), s));
-        // stable sort of the node ids by colour: perm = nodes in (colour, id) order; a colour class is a contiguous range
+        // stable sort of the node ids by sub-class key: perm = the schedule order; every (colour, class) pair is a contiguous range
+        hipLaunchKernelGGL(mrf_sortkey_kernel, dim3(nb), dim3(256), 0, s, ctx->m_colour.p, ctx->m_cls.p, F, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
         size_t tmp_bytes = 0;
-        MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->m_colour.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 6, s));
+        MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 9, s));
         ctx->sort_tmp.ensure(tmp_bytes + 16);
-        MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->m_colour.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 6, s));
-        hipLaunchKernelGGL(mrf_colour_begin_kernel, dim3(1), dim3(128), 0, s, ctx->m_tmp_b.p, F, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
-        MVS_HIP(hipMemcpyAsync(ctx->m_colour_begin.data(), ctx->m_tmp_c.p, 65 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 9, s));
+        ctx->m_sub.ensure(N_SUB + 2);
+        hipLaunchKernelGGL(mrf_sub_begin_kernel, dim3(2), dim3(256), 0, s, ctx->m_tmp_b.p, F, ctx->m_sub.p); MVS_LAUNCH_CHECK();
+        MVS_HIP(hipMemcpyAsync(ctx->m_sub_begin.data(), ctx->m_sub.p, (N_SUB + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MVS_HIP(hipStreamSynchronize(s));
-        ctx->m_colour_begin[65] = F;
-        uint32_t C = 0; while (C < 64 && ctx->m_colour_begin[C] < F) ++C;   // colours 0 .. C-1 are in use (greedy colours are dense)
+        const std::vector<uint32_t>& sb = ctx->m_sub_begin;
+        uint32_t C = 0;   // colours 0 .. C-1 are in use (greedy colours are dense)
+        for (uint32_t c = 0; c < 64; ++c) if (sb[4 * c + 4] > sb[4 * c] || sb[SUB_GENERIC + c + 1] > sb[SUB_GENERIC + c]) C = c + 1;
         ctx->m_colours = C;
-        ctx->m_colour_begin.resize(C + 1); ctx->m_colour_begin[C] = F;
+        ctx->m_n_fast = sb[SUB_GENERIC];
     }
     // message layout (sender-major, (colour, id) node order): in_off[e] for every directed edge e (adjacency order);
     // edges whose reverse is missing (asymmetric input) keep offset 0 and are disabled by mrf_edge_kernel
@@ -1060,25 +1110,27 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
     ctx->m_ident.ensure((size_t)E + 1);
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
-    ctx->m_fast = mrf_fast_path(ctx);
-    if (ctx->m_fast) {
-        // records + descriptors.  Upper bound of the record array (no read-back): labels nnz + 3 F, maps <= one byte per message element
+    ctx->m_fast = true;   // the sweep kernels of BOTH node classes accumulate the sweep's energy (callers no longer run the energy kernel per sweep)
+    const uint32_t n_fast = ctx->m_n_fast, n_generic = F - n_fast;
+    if (n_fast) {
+        // records + descriptors of the fast nodes.  Upper bound of the record array (no read-back): labels nnz + 3 F, maps <= one byte per message element
         const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + 1024;   // incl. slack for reads past the last record
         ctx->m_rec.ensure(rec_cap);
         MVS_HIP(hipMemsetAsync(ctx->m_rec.p, 0, REC_BASE * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_cls.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
         uint32_t* rsz = ctx->m_tmp_a.p; uint32_t* roff = ctx->m_tmp_b.p;   // F + 1 entries each
-        hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, F, rsz, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_perm.p, F, rsz, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, rsz, roff, (size_t)F + 1, nullptr);
         hipLaunchKernelGGL(mrf_record_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_tmp_c.p /* qpos */, roff, F, mrf_none_byte(ctx->m_kmax), ctx->m_rec.p); MVS_LAUNCH_CHECK();
+                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_tmp_c.p /* qpos */, roff, F, ctx->m_rec.p); MVS_LAUNCH_CHECK();
         ctx->m_desc.ensure((size_t)F + 1);
-        hipLaunchKernelGGL(mrf_desc_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, ctx->m_colour.p, roff, F, ctx->m_desc.p); MVS_LAUNCH_CHECK();
-    } else {
+        hipLaunchKernelGGL(mrf_desc_kernel, dim3((n_fast + 255) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, ctx->m_colour.p, roff, n_fast, ctx->m_desc.p); MVS_LAUNCH_CHECK();
+    }
+    if (n_generic) {
+        // 16-bit re-alignment maps of the runs the generic nodes SEND (indexed like the messages); only those elements are ever read
         ctx->m_map.ensure(ctx->m_total + 8);
-        MVS_HIP(hipMemsetAsync(ctx->m_map.p, 0, (ctx->m_total + 8) * sizeof(uint16_t), s));   // run padding is read (and ignored): keep it defined
-        hipLaunchKernelGGL(mrf_identity_kernel, dim3(1), dim3(MSG_BASE), 0, s, ctx->m_map.p); MVS_LAUNCH_CHECK();   // map[t] = t for t < MSG_BASE
-        if (F) { hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_map.p, ctx->m_ident.p, 0); MVS_LAUNCH_CHECK(); }
+        hipLaunchKernelGGL(mrf_map_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_cls.p, ctx->m_map.p); MVS_LAUNCH_CHECK();
+        ctx->pq.ensure(ctx->csr_nnz + 1);   // scratch row per generic node (the data-cost work buffer is free by now)
     }
     ctx->m_msg_a.ensure(ctx->m_total + 1024);   // slack: lanes beyond a run read on (up to 4 * 64 elements)
     MVS_HIP(hipMemsetAsync(ctx->m_msg_a.p, 0, (ctx->m_total + 1024) * sizeof(msg_t), s));   // zero codes, incl. the reserved zero run
@@ -1190,8 +1242,10 @@ void wait_report(mvs_ctx* ctx, uint32_t seq_slot, uint32_t seq) {
 // does not re-read its previous outgoing messages.
 static float sweep_alpha(const mvs_ctx* ctx) { return (ctx->m_sweep_no & 1u) ? ctx->m_params.damping : 0.0f; }
 
+// one launch of the fast kernel over positions [qb, qe) (one (colour, class) range of the schedule order); its per-block energy
+// partials go to slots [slot, slot + blocks) of the phase's region.  Returns the number of blocks (= slots) used.
 template <int G>
-static void launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t qe) {
+static unsigned launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t qe, unsigned slot, unsigned slot_cap) {
     constexpr int NPB = 256 / G;
     const unsigned need = (qe - qb + NPB - 1) / NPB;
     const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
@@ -1205,70 +1259,81 @@ static void launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t 
         resident = std::max(1, per_cu) * prop.multiProcessorCount;
     }
     unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
-    blocks = std::max(1u, std::min(std::min(need, blocks), EPART_BLOCKS));
+    blocks = std::max(1u, std::min(std::min(need, blocks), slot_cap));
     if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
     msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
-    unsigned long long* partial = ctx->m_energy.p + 4 + 2 * (size_t)EPART_BLOCKS * phase;
+    unsigned long long* partial = ctx->m_energy.p + 4 + 2 * ((size_t)EPART_BLOCKS * phase + slot);
 #define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->m_rec.p, msg, ctx->m_state.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_stride, qb, qe, rho, alpha, partial
     if (alpha != 0.0f) {
         if (ctx->mrf_late_old) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, true>), SWEEP4_ARGS); }
         else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, false>), SWEEP4_ARGS); }
     } else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, false, false, false>), SWEEP4_ARGS); }
 #undef SWEEP4_ARGS
+    MVS_LAUNCH_CHECK();
+    return blocks;
+}
+static unsigned launch_sweep_generic(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t qe, unsigned slot, unsigned slot_cap) {
+    const unsigned need = (qe - qb + 3) / 4;   // one wave per node, four waves per block
+    const unsigned blocks = std::max(1u, std::min(std::min(need, 256u * 4u), slot_cap));
+    const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
+    msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
+    unsigned long long* partial = ctx->m_energy.p + 4 + 2 * ((size_t)EPART_BLOCKS * phase + slot);
+#define GENERIC_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_map.p, ctx->m_colour.p, msg, ctx->m_perm.p, \
+                     ctx->m_state.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_stride, ctx->pq.p, qb, qe, rho, alpha, partial
+    if (alpha != 0.0f) hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, GENERIC_ARGS);
+    else hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, GENERIC_ARGS);
+#undef GENERIC_ARGS
+    MVS_LAUNCH_CHECK();
+    return blocks;
 }
 
-// positions [qb, qe) in the (colour, id) order of the nodes of colour `phase` whose id lies in [nb0, ne0)
-static void phase_range(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, uint32_t* qb, uint32_t* qe) {
-    const uint32_t cb = ctx->m_colour_begin[phase], ce = ctx->m_colour_begin[phase + 1];
-    if (nb0 == 0 && ne0 >= ctx->csr_faces) { *qb = cb; *qe = ce; return; }
-    if (ctx->m_range_nb != nb0 || ctx->m_range_ne != ne0 || ctx->m_range_q.size() != 2 * (size_t)ctx->m_colours) {
-        // a rank's own share of every colour class: one small kernel + read-back per (range, setup), then cached
-        const uint32_t C = ctx->m_colours;
-        ctx->m_moved.ensure(8 + 2 * 64);
-        uint32_t* d = ctx->m_moved.p + 8;
-        ctx->m_tmp_a.ensure(72);
-        MVS_HIP(hipMemcpyAsync(ctx->m_tmp_a.p, ctx->m_colour_begin.data(), (C + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(mrf_phase_range_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->m_perm.p, ctx->m_tmp_a.p, C, nb0, ne0, d);
+// positions [qb, qe) in the schedule order of the nodes of sub-class `sub` (key of mrf_sortkey_kernel) whose id lies in [nb0, ne0)
+static void sub_range(mvs_ctx* ctx, uint32_t sub, uint32_t nb0, uint32_t ne0, uint32_t* qb, uint32_t* qe) {
+    const uint32_t cb = ctx->m_sub_begin[sub], ce = ctx->m_sub_begin[sub + 1];
+    if (ce <= cb || (nb0 == 0 && ne0 >= ctx->csr_faces)) { *qb = cb; *qe = ce; return; }
+    if (ctx->m_range_nb != nb0 || ctx->m_range_ne != ne0 || ctx->m_range_q.size() != 2 * (size_t)N_SUB) {
+        // a rank's own share of every sub-class: one small kernel + read-back per (range, setup), then cached
+        ctx->m_sub.ensure(3 * (size_t)N_SUB + 4);
+        uint32_t* d = ctx->m_sub.p + N_SUB + 2;
+        hipLaunchKernelGGL(mrf_sub_range_kernel, dim3(2), dim3(256), 0, ctx->stream, ctx->m_perm.p, ctx->m_sub.p, nb0, ne0, d);
         MVS_LAUNCH_CHECK();
-        ctx->m_range_q.assign(2 * (size_t)C, 0);
-        MVS_HIP(hipMemcpyAsync(ctx->m_range_q.data(), d, 2 * C * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->m_range_q.assign(2 * (size_t)N_SUB, 0);
+        MVS_HIP(hipMemcpyAsync(ctx->m_range_q.data(), d, 2 * N_SUB * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         MVS_HIP(hipStreamSynchronize(ctx->stream));
         ctx->m_range_nb = nb0; ctx->m_range_ne = ne0;
     }
-    *qb = ctx->m_range_q[2 * phase]; *qe = ctx->m_range_q[2 * phase + 1];
+    *qb = ctx->m_range_q[2 * sub]; *qe = ctx->m_range_q[2 * sub + 1];
 }
 
-// one colour phase of a sweep over the nodes of that colour with id in [nb0, ne0): in place
+// one colour phase of a sweep over the nodes of that colour with id in [nb0, ne0): in place.  Up to five launches, one per node
+// class present in the colour (a uniform mesh has one); their energy partials share the phase's EPART_BLOCKS slots.
 void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
     if (phase == 0) ++ctx->m_sweep_no;      // sweeps are counted by their first phase (every caller runs the phases in order)
     if (phase >= ctx->m_colours || ne0 <= nb0) return;
-    uint32_t qb, qe;
-    phase_range(ctx, phase, nb0, ne0, &qb, &qe);
-    if (qe <= qb) return;
-    const uint32_t K = ctx->m_kmax;
-    if (ctx->m_fast) {
-        switch (mrf_group(K)) {
-            case 8: launch_sweep4_g<8>(ctx, phase, qb, qe); break;
-            case 16: launch_sweep4_g<16>(ctx, phase, qb, qe); break;
-            case 32: launch_sweep4_g<32>(ctx, phase, qb, qe); break;
-            default: launch_sweep4_g<64>(ctx, phase, qb, qe);      // one node per wave: scenes with several hundred views per face
-        }
-    } else {
-        ctx->pq.ensure(ctx->csr_nnz + 1);  // scratch row per node (data-cost work buffer is free by now)
-        const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
-        msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
-#define GENERIC_ARGS dim3(qe - qb), dim3(64), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_map.p, msg, ctx->m_perm.p, ctx->m_state.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_stride, ctx->pq.p, qb, qe, rho, alpha
-        if (alpha != 0.0f) hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, GENERIC_ARGS);
-        else hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, GENERIC_ARGS);
-#undef GENERIC_ARGS
+    uint32_t qb[5], qe[5]; int n_launch = 0;
+    for (uint32_t g = 0; g < 5; ++g) {
+        sub_range(ctx, g < 4 ? 4 * phase + g : SUB_GENERIC + phase, nb0, ne0, &qb[g], &qe[g]);
+        if (qe[g] > qb[g]) ++n_launch;
     }
-    MVS_LAUNCH_CHECK();
+    unsigned slot = 0;
+    for (uint32_t g = 0; g < 5; ++g) {
+        if (qe[g] <= qb[g]) continue;
+        --n_launch;
+        const unsigned cap = EPART_BLOCKS - slot - (unsigned)n_launch;   // leaves at least one slot for every launch still to come
+        switch (g) {
+            case 0: slot += launch_sweep4_g<8>(ctx, phase, qb[g], qe[g], slot, cap); break;
+            case 1: slot += launch_sweep4_g<16>(ctx, phase, qb[g], qe[g], slot, cap); break;
+            case 2: slot += launch_sweep4_g<32>(ctx, phase, qb[g], qe[g], slot, cap); break;
+            case 3: slot += launch_sweep4_g<64>(ctx, phase, qb[g], qe[g], slot, cap); break;      // one node per wave: several hundred views per face
+            default: slot += launch_sweep_generic(ctx, phase, qb[g], qe[g], slot, cap);
+        }
+    }
 }
 // one sweep = every colour phase in turn (callers that shard the nodes exchange halos between the phases themselves)
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     for (uint32_t ph = 0; ph < ctx->m_colours; ++ph) mrf_sweep_phase(ctx, ph, nb0, ne0);
-    // the fast-path kernels leave the sweep's energy behind as per-block partials (valid when the range is the whole graph)
-    ctx->m_energy_from_sweep = ctx->m_fast && nb0 == 0 && ne0 >= ctx->csr_faces && ctx->m_colours > 0;
+    // the sweep kernels leave the sweep's energy behind as per-block partials (valid when the range is the whole graph)
+    ctx->m_energy_from_sweep = nb0 == 0 && ne0 >= ctx->csr_faces && ctx->m_colours > 0;
 }
 
 // The solver tracks energies of the 16-bit unaries the sweeps see; the polish and everything reported use the exact costs:
@@ -1340,11 +1405,16 @@ void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
         MVS_LAUNCH_CHECK();
         return;
     }
-    if (ctx->m_fast && whole) {   // descriptors are in (colour, id) order: whole-graph calls only
-#define ICM_D(GG) hipLaunchKernelGGL(mrf_icm_gain_desc_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((n + (256 / GG) - 1) / (256 / GG), 256u * 8u))), dim3(256), 0, ctx->stream, \
-                                     ctx->m_desc.p, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->b_sel, ctx->b_lab, nb0, ne0, ctx->m_gain.p, ctx->m_cand.p)
-        if (K <= 8) ICM_D(8); else if (K <= 16) ICM_D(16); else if (K <= 48) ICM_D(16); else ICM_D(32);
+    if (whole) {   // whole-graph calls: the fast nodes through their descriptors (schedule positions [0, n_fast)), the generic nodes as a list
+        const uint32_t nf = ctx->m_n_fast;
+        if (nf) {
+#define ICM_D(GG) hipLaunchKernelGGL(mrf_icm_gain_desc_kernel<GG>, dim3(std::max(1u, std::min<unsigned>((nf + (256 / GG) - 1) / (256 / GG), 256u * 8u))), dim3(256), 0, ctx->stream, \
+                                     ctx->m_desc.p, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->b_sel, ctx->b_lab, 0u, nf, ctx->m_gain.p, ctx->m_cand.p)
+            if (K <= 8) ICM_D(8); else if (K <= 16) ICM_D(16); else if (K <= 48) ICM_D(16); else ICM_D(32);
 #undef ICM_D
+            MVS_LAUNCH_CHECK();
+        }
+        if (nf < n) ICM_G(64, nf, n, (const uint32_t*)ctx->m_perm.p);
     } else {
         const uint32_t* none = nullptr;
         if (K <= 8) ICM_G(8, nb0, ne0, none); else if (K <= 16) ICM_G(16, nb0, ne0, none); else if (K <= 32) ICM_G(32, nb0, ne0, none); else ICM_G(64, nb0, ne0, none);

@@ -322,6 +322,34 @@ def test_mrf_random_instances_all_kernel_paths(ctx, case):
     assert so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_mrf_mixed_node_classes_in_one_graph(seed):
+    """per-node routing of the sweep (k_mrf.hip mrf_node_class): short columns, columns of 100 / 200 / 300 labels and nodes of
+    degree up to 6 in ONE graph -- lane groups of 8, 16, 32 and 64 lanes and the generic kernel run side by side inside every
+    colour phase, fast nodes exchange messages with generic neighbours.  Labels, energy and sweeps equal the oracle's, and the
+    same solve with every node forced onto the generic kernel gives the same result (the split into launches is free: a colour
+    class is an independent set).  Reference: view_selection.cpp:27-82, build_adjacency_graph.cpp:31-47 (non-manifold edges)."""
+    from util_cases import random_mrf_mixed
+    n, V = 6000, 400
+    col_ptr, view_id, cost, adj_ptr, adj = random_mrf_mixed(n, V, seed)
+    K = np.diff(col_ptr.astype(np.int64)); deg = np.diff(adj_ptr.astype(np.int64))
+    assert K.max() > 255 and (K == 200).any() and deg.max() > 3 and np.median(K) <= 6
+    ref = O.CsrNp(n, V, col_ptr, view_id, cost)
+    p = dict(max_sweeps=30, min_sweeps=12)
+    lo, so = O.view_selection(ref, adj_ptr, adj, O.default_mrf_params(**p))
+    for force in (0, 1):
+        c = M.Context(0); c.set_option("mrf_force_generic", force)
+        try:
+            c.costs_upload(M.viewsel.DataCosts(n, V, col_ptr, view_id, cost))
+            lg, sg = c.view_selection(adj_ptr, adj, M.viewsel.default_mrf_params(**p))
+        finally:
+            c.close()
+        assert np.array_equal(lo, lg), "force_generic=%d" % force
+        assert (so["energy_fixed"], so["sweeps"], so["icm_iters"]) == (sg["energy_fixed"], sg["sweeps"], sg["icm_iters"]), "force_generic=%d" % force
+    e, cuts = energy_numpy(col_ptr, view_id, cost, adj_ptr, adj, lg)
+    assert e == sg["energy_fixed"]
+
+
 def test_one_shot_host_entry_points():
     """mvs_data_costs / mvs_view_selection: the host-pointer drop-ins the tex:: adapter calls"""
     s = get_scene("tiny")

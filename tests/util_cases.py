@@ -26,6 +26,32 @@ def random_mrf(n_nodes, n_views, max_k, max_deg, seed, p_empty=0.1):
     return (np.array(col_ptr, dtype=np.uint32), np.array(view_id, dtype=np.uint16), np.array(cost, dtype=np.float32), adj_ptr, adj)
 
 
+def random_mrf_mixed(n_nodes, n_views, seed, base_k=6, p_long=0.03, long_k=(100, 200, 300), p_hub=0.01, hub_deg=6):
+    """A mostly manifold-like instance (degree <= 3, columns of <= base_k labels) with a few LONG columns (long_k entries, some
+    beyond the 255 a fast node holds) and a few HUB nodes of degree > 3 (non-manifold edges): every node class of the solver's
+    per-node routing (k_mrf.hip mrf_node_class) occurs in one colour phase, next to each other."""
+    rng = np.random.default_rng(seed)
+    lists = [[] for _ in range(n_nodes)]
+    cap = np.where(rng.random(n_nodes) < p_hub, hub_deg, 3)
+    for _ in range(n_nodes * 4):
+        a, b = rng.integers(0, n_nodes, size=2)
+        if a == b or b in lists[a] or len(lists[a]) >= cap[a] or len(lists[b]) >= cap[b]:
+            continue
+        lists[a].append(int(b)); lists[b].append(int(a))
+    adj_ptr = np.zeros(n_nodes + 1, dtype=np.uint32)
+    adj_ptr[1:] = np.cumsum([len(l) for l in lists])
+    adj = np.array([x for l in lists for x in l], dtype=np.uint32)
+    col_ptr = [0]; view_id = []; cost = []
+    for i in range(n_nodes):
+        r = rng.random()
+        k = 0 if r < 0.05 else (int(rng.choice(long_k)) if r < 0.05 + p_long else int(rng.integers(1, base_k + 1)))
+        k = min(k, n_views)
+        v = np.sort(rng.choice(n_views, size=k, replace=False))
+        view_id += v.tolist(); cost += rng.random(k).astype(np.float32).tolist()
+        col_ptr.append(col_ptr[-1] + k)
+    return (np.array(col_ptr, dtype=np.uint32), np.array(view_id, dtype=np.uint16), np.array(cost, dtype=np.float32), adj_ptr, adj)
+
+
 def energy_numpy(col_ptr, view_id, cost, adj_ptr, adj, labels):
     """E(l) = sum_i D_i(l_i) + sum_{(i,j)} [l_i != l_j] in 32.32 fixed point, written independently."""
     F = len(col_ptr) - 1
