@@ -452,8 +452,11 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     const uint32_t ci = cls[i];
     if (K == 0 || ci == CLS_GENERIC) return;
-    // what "label absent at the sender" is stored as: the +inf slot of the node's sweep kernel (4 * G, G = 8 << class), 0xFF for G = 64
-    const uint32_t none_byte = ci < 3u ? (32u << ci) : 0xFFu;
+    // A map byte is the SLOT of the sweep kernel's LDS tile that holds the sender's label: the tile is row-major over r = label mod 4
+    // (slot = (at & 3) * G + (at >> 2) for position `at` in the sender's list, G = 8 << class lanes per node), so that the lanes of a
+    // group read consecutive banks.  "Label absent at the sender" is the +inf slot 4 * G; for G = 64 the slots fill the byte range
+    // 0 .. 254 and 0xFF marks absence (the kernel steers it to slot 256).
+    const uint32_t rs = 8u << ci, none_byte = ci < 3u ? 4u * rs : 0xFFu;
     const uint32_t q = qpos[i];
     uint16_t* tile = s_l[threadIdx.x >> 4];
     uint32_t* out = rec + REC_BASE + roff[q];
@@ -485,7 +488,7 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
             for (uint32_t r = 0; r < 4; ++r) {
                 // lo = the last candidate position: the key sits there, or one further (beyond the list), or nowhere
                 uint32_t at = lo[r] + (((uint32_t)tile[lo[r]] < key[r]) ? 1u : 0u);
-                const uint32_t byte = (at < K && (uint32_t)tile[at < K ? at : 0u] == key[r]) ? at : none_byte;
+                const uint32_t byte = (at < K && (uint32_t)tile[at < K ? at : 0u] == key[r]) ? (at & 3u) * rs + (at >> 2) : none_byte;
                 word |= byte << (8 * r);
             }
             out[pos + wI] = word;
@@ -550,11 +553,16 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     // written by another; a node reads its old outgoing run before it overwrites it
     const msg_t* mo = msg; msg_t* mn = msg;
     constexpr int NPB = 256 / G;
-    constexpr int TS = 4 * G + 4;                            // tile stride: 4G cavity values + the +inf slot (16-byte multiple)
-    __shared__ __attribute__((aligned(16))) float s_c[NPB * TS];
+    // Tile of a lane group: the 4G cavity values ROW-major over r = label mod 4 (label 4 * gl + r at slot r * G + gl) + the +inf slot 4G.
+    // A ds_read_b32 / ds_write_b32 serves lanes 0-31 and 32-63 in one LDS cycle each when they hit 32 different banks (bank = word
+    // address mod 32): with this layout the lanes of a group touch consecutive banks (exactly for identical label lists, 3/4 of the
+    // edges), and the stride puts the 32 / G groups of a half-wave on disjoint banks (TS = G mod 32 for G < 32).  The label-major tile
+    // (slot = label, one float4 write) made every gather a 4-way bank conflict: PMC SQ_LDS_BANK_CONFLICT = 56 % of the LDS cycles.
+    constexpr int TS = G == 8 ? 40 : G == 16 ? 80 : 4 * G + 4;
+    __shared__ float s_c[NPB * TS];
     __shared__ unsigned long long s_e[8];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    float* __restrict__ tile = s_c + grp * TS;               // this group's 4G values, label-major
+    float* __restrict__ tile = s_c + grp * TS;
     if (gl == 0) tile[4 * G] = INFINITY;
     __syncthreads();
     const uint32_t wofs = st->w * buf_stride;                // decode buffer of this sweep (flipped by the step kernel when a sweep improves the best energy)
@@ -570,7 +578,7 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     const uint32_t last = node_end - 1;
     const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
     const uint32_t t0 = 4u * gl;
-    const uint32_t ident_word = 0x03020100u + 0x04040404u * (uint32_t)gl;   // map bytes of an identical-list edge: t0 .. t0 + 3
+    const uint32_t ident_word = 0x03020100u * (uint32_t)G + 0x01010101u * (uint32_t)gl;   // map bytes of an identical-list edge: the slots r * G + gl of the lane's own labels
     // Software pipeline, two nodes deep: while a lane group computes node `it`, the loads of node `it + 1` (label words,
     // three incoming runs, three map words, three neighbour labels and -- damped sweeps -- the three old outgoing runs)
     // and the descriptor of node `it + 2` are in flight.  The kernel had been latency bound: waves parked on memory 65 %
@@ -648,7 +656,8 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
             const float* c = cv[d];
             const float cmin = cmin3[d];
             // the tile holds cs - cmin (the same subtraction the oracle performs after its gather); the extra slot stays +inf
-            *reinterpret_cast<float4*>(tile + t0) = make_float4(c[0] - cmin, c[1] - cmin, c[2] - cmin, c[3] - cmin);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[r * G + gl] = c[r] - cmin;
             const uint32_t mw = ident[d] ? ident_word : r_map[d];
             uint32_t w = 0u;
 #pragma unroll
@@ -687,11 +696,13 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
 }
 
 
-// generic nodes: any degree, any K.  One wave per node (persistent waves striding over the range), cavity vector through a global
-// scratch row (a wave's own stores and loads of that row are ordered by workgroup-scope fences; rows of different nodes are
-// disjoint).  Same arithmetic as the fast kernel / the oracle; the node's share of the sweep's tracking energy (cost code of
-// the decoded label + one cut per model edge to a lower-coloured neighbour whose label differs) goes into per-block partials
-// like the fast kernel's.
+// generic nodes: any degree, any K.  One BLOCK per node (persistent blocks striding over the range): the four waves split the
+// labels for the belief vector b (which goes through a global scratch row: K is unbounded here) and then take the out-edges in
+// turn, one edge per wave at a time -- a generic node is a chain of dependent gathers (edge record -> run -> map -> run), and
+// with a handful of generic nodes per colour phase (one non-manifold edge, one long column) the launch lasts as long as ONE
+// node's chain, so the chain is what is parallelised.  Same arithmetic as the fast kernel / the oracle; the node's share of the
+// sweep's tracking energy (cost code of the decoded label + one cut per model edge to a lower-coloured neighbour whose label
+// differs) goes into per-block partials like the fast kernel's.
 template <bool DAMP>
 __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                                 const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
@@ -701,27 +712,26 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
                                                                 float* scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha,
                                                                 unsigned long long* __restrict__ partial) {
     const msg_t* mo = msg; msg_t* mn = msg;                  // in place (one colour per launch)
-    __shared__ unsigned long long s_e[8];
+    __shared__ float s_b[4]; __shared__ uint32_t s_t[4]; __shared__ uint32_t s_cuts[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wofs = st->w * buf_stride;
     uint32_t* sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* selcost = cost2 + wofs;
     const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
     const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;
-    unsigned long long acc_e = 0ull, acc_c = 0ull;           // lane 0 of the wave accumulates
-    for (uint32_t q = node_begin + blockIdx.x * 4u + (uint32_t)wave; q < node_end; q += gridDim.x * 4u) {   // wave-uniform
+    unsigned long long acc_e = 0ull, acc_c = 0ull;           // thread 0 accumulates
+    for (uint32_t q = node_begin + blockIdx.x; q < node_end; q += gridDim.x) {   // block-uniform
         const uint32_t i = perm[q];
         const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
         if (K == 0) {   // the single label 0 with unary 1 (view_selection.cpp:50-51,70-71): cost code 65535, no model edge
-            if (lane == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; acc_e += 65535ull; }
+            if (threadIdx.x == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; acc_e += 65535ull; }
             continue;
         }
         const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
-        // b[t] goes through the scratch row (K is unbounded here)
         float bb = INFINITY; uint32_t bt = 0xFFFFFFFFu;
-        for (uint32_t t = lane; t < K; t += 64) {
+        for (uint32_t t = threadIdx.x; t < K; t += 256) {
             float Sc = 0.0f;
-            for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) Sc = Sc + (float)mo[m.in_off + t]; }
+            for (uint32_t e = e0; e < e1; ++e) { const MrfEdge m = edge[e]; if (m.kj) Sc = Sc + (float)mo[m.in_off + t]; }   // adjacency order, like the oracle
             const float b = __builtin_fmaf(kappa, Sc, cost_value(cost_code(cost[p0 + t])));   // the unaries as the sweeps see them: 16-bit fixed point
             scratch[p0 + t] = b;
             if (b < bb) { bb = b; bt = t; }
@@ -730,23 +740,24 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
             const float ob = __shfl_xor(bb, o, 64); const uint32_t ot = __shfl_xor(bt, o, 64);
             if (ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; }
         }
+        if (lane == 0) { s_b[wave] = bb; s_t[wave] = bt; }
+        __syncthreads();                                     // also orders the scratch row: written above, read below by other threads of the block
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const float ob = s_b[w]; const uint32_t ot = s_t[w]; if (w == 0 || ob < bb || (ob == bb && ot < bt)) { bb = ob; bt = ot; } }
         const uint32_t my_lab = (uint32_t)view_id[p0 + bt] + 1u, my_code = cost_code(cost[p0 + bt]);
-        if (lane == 0) { sel[i] = bt; lab[i] = my_lab; selcost[i] = cost_value(my_code); acc_e += my_code; }
-        // cut edges to lower-coloured neighbours (their labels of this sweep are final): one edge per lane
+        // cut edges to lower-coloured neighbours (their labels of this sweep are final): one edge per thread
         {
             const uint32_t ci = colour[i];
             uint32_t cuts = 0;
-            for (uint32_t e = e0 + lane; e < e1; e += 64) {
+            for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
                 const uint32_t j = adj[e];
                 if (edge[e].kj != 0u && colour[j] < ci && lab[j] != my_lab) ++cuts;
             }
             for (int o = 32; o > 0; o >>= 1) cuts += __shfl_xor(cuts, o, 64);
-            if (lane == 0) acc_c += cuts;
+            if (lane == 0) s_cuts[wave] = cuts;
         }
-        // the scratch row written above is read below by other lanes of this wave
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (uint32_t e = e0; e < e1; ++e) {
+        // the out-edges, one per wave at a time
+        for (uint32_t e = e0 + (uint32_t)wave; e < e1; e += 4) {
             const MrfEdge m = edge[e];
             if (!m.kj) continue;  // wave-uniform
             float cmin = INFINITY;
@@ -758,13 +769,13 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
                 mn[m.out_off + t2] = (msg_t)msg_pack_s<DAMP>(raw, alpha, (float)mo[m.out_off + t2], 0u, 0u);
             }
         }
+        __syncthreads();                                     // s_cuts complete; s_b / s_t free for the next node
+        if (threadIdx.x == 0) {
+            sel[i] = bt; lab[i] = my_lab; selcost[i] = cost_value(my_code);
+            acc_e += my_code; acc_c += (unsigned long long)s_cuts[0] + s_cuts[1] + s_cuts[2] + s_cuts[3];
+        }
     }
-    if (lane == 0) { s_e[wave] = acc_e; s_e[4 + wave] = acc_c; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long e = s_e[0] + s_e[1] + s_e[2] + s_e[3], c = s_e[4] + s_e[5] + s_e[6] + s_e[7];
-        partial[2 * blockIdx.x] = e + 65535ull * c; partial[2 * blockIdx.x + 1] = c;
-    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = acc_e + 65535ull * acc_c; partial[2 * blockIdx.x + 1] = acc_c; }
 }
 
 // ---- exact energy of a labeling (32.32 fixed point) over nodes [node_begin, node_end) ----
@@ -1072,7 +1083,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 9, s));
         ctx->sort_tmp.ensure(tmp_bytes + 16);
         MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 9, s));
-        ctx->m_sub.ensure(N_SUB + 2);
+        ctx->m_sub.ensure(3 * (size_t)N_SUB + 8);   // [0, N_SUB]: sub_begin; behind it the own-share ranges of sub_range()
         hipLaunchKernelGGL(mrf_sub_begin_kernel, dim3(2), dim3(256), 0, s, ctx->m_tmp_b.p, F, ctx->m_sub.p); MVS_LAUNCH_CHECK();
         MVS_HIP(hipMemcpyAsync(ctx->m_sub_begin.data(), ctx->m_sub.p, (N_SUB + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MVS_HIP(hipStreamSynchronize(s));
@@ -1273,7 +1284,7 @@ static unsigned launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint3
     return blocks;
 }
 static unsigned launch_sweep_generic(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t qe, unsigned slot, unsigned slot_cap) {
-    const unsigned need = (qe - qb + 3) / 4;   // one wave per node, four waves per block
+    const unsigned need = qe - qb;   // one block per node
     const unsigned blocks = std::max(1u, std::min(std::min(need, 256u * 4u), slot_cap));
     const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
     msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
@@ -1293,8 +1304,7 @@ static void sub_range(mvs_ctx* ctx, uint32_t sub, uint32_t nb0, uint32_t ne0, ui
     if (ce <= cb || (nb0 == 0 && ne0 >= ctx->csr_faces)) { *qb = cb; *qe = ce; return; }
     if (ctx->m_range_nb != nb0 || ctx->m_range_ne != ne0 || ctx->m_range_q.size() != 2 * (size_t)N_SUB) {
         // a rank's own share of every sub-class: one small kernel + read-back per (range, setup), then cached
-        ctx->m_sub.ensure(3 * (size_t)N_SUB + 4);
-        uint32_t* d = ctx->m_sub.p + N_SUB + 2;
+        uint32_t* d = ctx->m_sub.p + N_SUB + 2;   // (allocated by mrf_setup: ensure() here would drop sub_begin)
         hipLaunchKernelGGL(mrf_sub_range_kernel, dim3(2), dim3(256), 0, ctx->stream, ctx->m_perm.p, ctx->m_sub.p, nb0, ne0, d);
         MVS_LAUNCH_CHECK();
         ctx->m_range_q.assign(2 * (size_t)N_SUB, 0);
