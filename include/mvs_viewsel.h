@@ -299,6 +299,10 @@ mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32
  * independent set) and one sweep = for phase in 0 .. n_phases-1: the nodes of that colour recompute their outgoing
  * messages in place.  A sharded driver runs the phases itself and exchanges the halo after each one. */
 mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases);
+/* diagnostics of the last mvs_ctx_view_selection calls of this context: out[0] = hipGraph launches of the sweep loop (two sweeps each;
+ * option "mrf_graph", default 1), out[1] = re-captures pushed into the executable graph with hipGraphExecUpdate, out[2] = graph
+ * instantiations, out[3] = nodes the sweep routes to the generic kernel (degree > 3 or a column of > 255 labels at or next to the node) */
+mvs_status mvs_ctx_mrf_diagnostics(mvs_ctx* ctx, uint32_t out[4]);
 mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t node_begin, uint32_t node_end);
 /* all phases in turn over nodes [node_begin, node_end) (no exchange in between: unsharded use) */
 mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);

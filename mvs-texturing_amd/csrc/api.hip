@@ -63,6 +63,39 @@ void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, i
 }
 }  // namespace mvs
 
+// Captures two sweeps + steps (whatever `one_sweep` launches) on the context's private capture stream and makes ctx->sweep_exec
+// launch exactly that.  The capture executes nothing; host-side counters the launches advance are restored.  The graph is
+// re-captured for every solve (a dozen launches into a capturing stream) and pushed into the existing executable graph with
+// hipGraphExecUpdate; only a changed topology (another number of node classes per colour) instantiates a new one.
+// Returns false -- the caller then keeps launching directly -- if the runtime refuses any step.
+template <class Sweep>
+static bool prepare_sweep_graph(mvs_ctx* ctx, Sweep&& one_sweep) {
+    if (!ctx->cap_stream && hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->mrf_graph = 0; return false; }
+    const uint32_t steps0 = ctx->steps_issued, sweep0 = ctx->m_sweep_no;
+    hipStream_t user = ctx->stream;
+    hipGraph_t graph = nullptr;
+    bool ok = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        ctx->stream = ctx->cap_stream;
+        try { one_sweep(); one_sweep(); } catch (...) { ok = false; }
+        ctx->stream = user;
+        if (hipStreamEndCapture(ctx->cap_stream, &graph) != hipSuccess || !graph) ok = false;
+    }
+    ctx->steps_issued = steps0; ctx->m_sweep_no = sweep0;
+    if (ok && ctx->sweep_exec) {
+        hipGraphNode_t bad = nullptr; hipGraphExecUpdateResult res = hipGraphExecUpdateError;
+        if (hipGraphExecUpdate(ctx->sweep_exec, graph, &bad, &res) == hipSuccess && res == hipGraphExecUpdateSuccess) ++ctx->graph_updates;
+        else { (void)hipGetLastError(); (void)hipGraphExecDestroy(ctx->sweep_exec); ctx->sweep_exec = nullptr; }
+    }
+    if (ok && !ctx->sweep_exec) {
+        if (hipGraphInstantiate(&ctx->sweep_exec, graph, nullptr, nullptr, 0) == hipSuccess) ++ctx->graph_instantiations;
+        else { ctx->sweep_exec = nullptr; ok = false; }
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) { (void)hipGetLastError(); ctx->mrf_graph = 0; if (ctx->verbose) fprintf(stderr, "[mvs] hipGraph capture of the sweep loop failed: launching directly\n"); }
+    return ok;
+}
+
 extern "C" {
 
 const char* mvs_last_error(void) { return g_last_error.c_str(); }
@@ -115,6 +148,8 @@ void mvs_ctx_destroy(mvs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto* b : ctx->own_rgb) delete b;
+    if (ctx->sweep_exec) (void)hipGraphExecDestroy(ctx->sweep_exec);
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (ctx->h_icm) (void)hipHostFree(ctx->h_icm);
     if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
@@ -157,6 +192,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;
     else if (n == "mrf_lag") ctx->mrf_lag = (int)value;
     else if (n == "mrf_force_generic") ctx->mrf_force_generic = value != 0;
+    else if (n == "mrf_graph") ctx->mrf_graph = value != 0;
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
@@ -423,16 +459,37 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     };
     int issued = 0, polled = 0;
     ProfChain pc(ctx);
-    while (issued < P.max_sweeps && !pg.stopped) {
+    auto one_sweep = [&]() {
         pc.begin();
         mrf_sweep(ctx, 0, F);
         pc.mark("mrf_sweep");
-        // the fast-path sweep kernels accumulate the sweep's energy themselves; the generic path runs the energy kernel
+        // the sweep kernels accumulate the sweep's energy themselves; the step kernel sums their partials and applies the stop rule
         if (!ctx->m_energy_from_sweep) mrf_energy(ctx, false, 0, F, /*reduce=*/false);
         mrf_step(ctx, nullptr);
         pc.mark("mrf_energy");
-        ++issued;
+    };
+    // Sweeps 1 and 2 are launched directly.  From sweep 3 on the loop replays a hipGraph of TWO sweeps (a damped odd one, an undamped
+    // even one) with their steps: a small problem's sweep is a handful of 3 - 10 us kernels, and launching them one by one is bound by
+    // the host's ~3.5 us per launch (MI355X_MICROARCH.md "graph-replay-floor"), not by the GPU.  Every launch of the loop has
+    // the same arguments each time (the step kernel numbers its reports itself), sweeps queued after the device-side stop rule fired
+    // end at their first instruction, so replaying past the stop costs microseconds.  Not while profiling (stage marks are events).
+    bool graphs = ctx->mrf_graph != 0 && !ctx->profile && P.max_sweeps >= 6 && F > 0;
+    while (issued < std::min(2, P.max_sweeps) && !pg.stopped) {
+        one_sweep(); ++issued;
         if (issued - lag > polled) report((uint32_t)++polled);
+    }
+    if (graphs && issued == 2 && !pg.stopped) graphs = prepare_sweep_graph(ctx, one_sweep);
+    while (issued < P.max_sweeps && !pg.stopped) {
+        if (graphs && issued + 2 <= P.max_sweeps) {
+            MVS_HIP(hipGraphLaunch(ctx->sweep_exec, s));
+            ctx->steps_issued += 2; ctx->m_sweep_no += 2; issued += 2; ++ctx->graph_launches;
+            ctx->icm_dirty_valid = false; ctx->best_resolved = false;
+            // one whole graph stays queued behind the one whose reports are read
+            while (issued - lag - 2 > polled && !pg.stopped) report((uint32_t)++polled);
+        } else {
+            one_sweep(); ++issued;
+            if (issued - lag > polled) report((uint32_t)++polled);
+        }
     }
     while (polled < issued && !pg.stopped) report((uint32_t)++polled);
     if (issued > 0) mrf_poll(ctx, (uint32_t)issued, &pg);   // final state (drains the stream)

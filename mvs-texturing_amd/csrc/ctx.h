@@ -201,7 +201,10 @@ struct mvs_ctx {
     static constexpr uint32_t RING = 16;
     static constexpr uint32_t ICM_RING = 8;
     uint32_t* h_icm = nullptr; uint32_t* d_icm = nullptr; uint32_t icm_seq = 0;   // pinned "moved" counts of the ICM rounds, read a few rounds late
-    mvs::DBuf<mvs_mrf_progress> m_state; mvs::DBuf<unsigned long long> m_hist;
+    mvs::DBuf<mvs_mrf_progress> m_state; mvs::DBuf<unsigned long long> m_hist; mvs::DBuf<uint32_t> m_ctl;   // m_ctl: {steps of the solve, sequence base} read by the step kernel
+    // the sweep loop as a replayed hipGraph (api.hip): two sweeps (a damped and an undamped one) + their bookkeeping steps, captured on a
+    // private stream, launched on the context's stream; re-captured per solve and pushed into the instantiated graph with hipGraphExecUpdate
+    int mrf_graph = 1; hipStream_t cap_stream = nullptr; hipGraphExec_t sweep_exec = nullptr; uint32_t graph_launches = 0, graph_updates = 0, graph_instantiations = 0;
     mvs_mrf_progress* h_ring = nullptr; mvs_mrf_progress* d_ring = nullptr /* the same pinned slots as the device addresses them */; uint32_t steps_issued = 0; int mrf_lag = 1;
     // arrival of a report = its sequence number in the pinned word next to it (written after a system-scope fence): the host polls
     // memory, no event is recorded in the stream.  Sequence numbers never repeat within a context.

@@ -563,6 +563,9 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     __shared__ unsigned long long s_e[8];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     float* __restrict__ tile = s_c + grp * TS;
+    // The stop rule runs on the device (mrf_step_kernel) while the host queues sweeps ahead of the reports it reads: a sweep queued
+    // after the rule fired changes nothing anybody reads (the best labeling is frozen, the step kernel ignores its energy) -- it ends here
+    if (st->stopped) return;
     if (gl == 0) tile[4 * G] = INFINITY;
     __syncthreads();
     const uint32_t wofs = st->w * buf_stride;                // decode buffer of this sweep (flipped by the step kernel when a sweep improves the best energy)
@@ -714,6 +717,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
     const msg_t* mo = msg; msg_t* mn = msg;                  // in place (one colour per launch)
     __shared__ float s_b[4]; __shared__ uint32_t s_t[4]; __shared__ uint32_t s_cuts[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (st->stopped) return;                                 // a sweep queued after the stop rule fired (see mrf_sweep4_kernel)
     const uint32_t wofs = st->w * buf_stride;
     uint32_t* sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* selcost = cost2 + wofs;
     const float lam = 1.0f / rho;
@@ -976,10 +980,13 @@ __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t nod
 // "Keep the best labeling" is a flip of two indices: the sweep that improved the best energy wrote decode buffer w, which
 // becomes best_w, and the next sweeps write the other buffer -- nothing is copied.  The report goes straight into the
 // pinned ring slot (host memory), so a step is ONE launch.
+// The step's number (which ring slot its report goes to, which sequence number announces it) is device state too -- ctl[0] counts
+// the steps of the solve, ctl[1] is the solve's sequence base -- so a step's launch has the SAME arguments every time and the
+// sweep loop can be replayed from a hipGraph.
 __global__ void __launch_bounds__(1024) mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
                                 const unsigned long long* __restrict__ energy, const unsigned long long* __restrict__ partial, uint32_t n_partial,
-                                unsigned long long* __restrict__ energy_out, mvs_mrf_progress* __restrict__ report, uint32_t* __restrict__ report_seq, uint32_t seq,
-                                int max_sweeps, int min_sweeps, int window, float min_improvement) {
+                                unsigned long long* __restrict__ energy_out, mvs_mrf_progress* __restrict__ ring, uint32_t* __restrict__ ring_seq, uint32_t ring_slots,
+                                uint32_t* __restrict__ ctl, int max_sweeps, int min_sweeps, int window, float min_improvement) {
     __shared__ unsigned long long su[16], sc[16];
     unsigned long long e_sum = 0, c_sum = 0;
     if (partial) {
@@ -1016,10 +1023,12 @@ __global__ void __launch_bounds__(1024) mrf_step_kernel(mvs_mrf_progress* __rest
         if (stop) { p.stopped = 1u; p.stop_sweep = sw; }
     }
     *st = p;
-    if (report) {   // pinned host memory: the report, a system-scope fence, then its sequence number -- the host polls the number
-        *report = p;
+    const uint32_t n = ctl[0] + 1u; ctl[0] = n;
+    if (ring) {   // pinned host memory: the report, a system-scope fence, then its sequence number -- the host polls the number
+        const uint32_t slot = n % ring_slots;
+        ring[slot] = p;
         __threadfence_system();
-        __hip_atomic_store(report_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ring_seq + slot, ctl[1] + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // one value from device memory into a pinned slot, announced the same way (ICM "moved" counts)
@@ -1176,6 +1185,11 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->seq_base += ctx->steps_issued;   // sequence numbers of this solve: seq_base + step (never reused within the context)
     ctx->h_ring[mvs_ctx::RING] = init;   // staging slot for the upload
     MVS_HIP(hipMemcpyAsync(ctx->m_state.p, &ctx->h_ring[mvs_ctx::RING], sizeof(init), hipMemcpyHostToDevice, s));
+    // the step kernel's own counter: steps of this solve so far, and the solve's sequence base (staged in the pinned words behind the slots' sequence numbers)
+    ctx->m_ctl.ensure(4);
+    uint32_t* stage = ctx->h_seq + (mvs_ctx::RING + mvs_ctx::ICM_RING);
+    stage[0] = 0u; stage[1] = ctx->seq_base;
+    MVS_HIP(hipMemcpyAsync(ctx->m_ctl.p, stage, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     MVS_HIP(hipMemsetAsync(ctx->m_hist.p, 0xFF, sizeof(unsigned long long), s));
     ctx->steps_issued = 0; ctx->icm_dirty_valid = false;   // no synchronisation: the solver's launches queue behind the set-up on the same stream
 }
@@ -1201,8 +1215,9 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
     const uint32_t n = ++ctx->steps_issued, slot = n % mvs_ctx::RING;
     const unsigned long long* partial = nullptr; uint32_t n_partial = 0;
     if (!energy) { partial = ctx->m_energy.p + 4; n_partial = ctx->m_energy_from_sweep ? EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u) : ctx->m_energy_blocks; }
+    (void)n; (void)slot;   // the kernel derives both from its own step counter (ctl), which mirrors ctx->steps_issued
     hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(1024), 0, s, ctx->m_state.p, ctx->m_hist.p, energy, partial, n_partial, ctx->m_energy.p,
-                       ctx->d_ring + slot, ctx->d_seq + slot, ctx->seq_base + n, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
+                       ctx->d_ring, ctx->d_seq, (uint32_t)mvs_ctx::RING, ctx->m_ctl.p, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
     MVS_LAUNCH_CHECK();
     ctx->icm_dirty_valid = false; ctx->best_resolved = false;   // the best labeling may change
 }
@@ -1222,7 +1237,7 @@ void ensure_report_ring(mvs_ctx* ctx) {
     constexpr uint32_t NS = mvs_ctx::RING + mvs_ctx::ICM_RING;
     MVS_HIP(hipHostMalloc((void**)&ctx->h_ring, (mvs_ctx::RING + 1) * sizeof(mvs_mrf_progress), hipHostMallocCoherent));
     MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
-    MVS_HIP(hipHostMalloc((void**)&ctx->h_seq, NS * sizeof(uint32_t), hipHostMallocCoherent));
+    MVS_HIP(hipHostMalloc((void**)&ctx->h_seq, (NS + 2) * sizeof(uint32_t), hipHostMallocCoherent));   // + 2 staging words (mrf_setup)
     MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_seq, ctx->h_seq, 0));
     MVS_HIP(hipHostMalloc((void**)&ctx->h_icm, mvs_ctx::ICM_RING * sizeof(uint32_t), hipHostMallocCoherent));
     MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_icm, ctx->h_icm, 0));

@@ -146,6 +146,11 @@ mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases) {
     *n_phases = ctx->m_colours;
     return MVS_OK;
 }
+mvs_status mvs_ctx_mrf_diagnostics(mvs_ctx* ctx, uint32_t out[4]) {
+    if (!ctx || !out) return api_fail(MVS_ERR_INVALID, "null argument");
+    out[0] = ctx->graph_launches; out[1] = ctx->graph_updates; out[2] = ctx->graph_instantiations; out[3] = ctx->csr_faces - ctx->m_n_fast;
+    return MVS_OK;
+}
 mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
     if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces || phase >= ctx->m_colours) return api_fail(MVS_ERR_INVALID, "bad phase or node range");
     MVS_API_BEGIN

@@ -131,7 +131,7 @@ def load_library():
         "mvs_ctx_costs_upload": [vp, C.POINTER(CCsr), i32], "mvs_ctx_costs_export": [vp, vp, vp, vp],
         "mvs_ctx_view_selection": [vp, vp, vp, i32, C.POINTER(MrfParams), vp, i32, C.POINTER(MrfStats)],
         "mvs_ctx_mrf_setup": [vp, vp, vp, i32, C.POINTER(MrfParams)], "mvs_ctx_mrf_sweep": [vp, u32, u32],
-        "mvs_ctx_mrf_num_phases": [vp, C.POINTER(u32)], "mvs_ctx_mrf_sweep_phase": [vp, u32, u32, u32], "mvs_ctx_mrf_layout": [vp, vp, u64],
+        "mvs_ctx_mrf_num_phases": [vp, C.POINTER(u32)], "mvs_ctx_mrf_diagnostics": [vp, C.POINTER(u32)], "mvs_ctx_mrf_sweep_phase": [vp, u32, u32, u32], "mvs_ctx_mrf_layout": [vp, vp, u64],
         "mvs_ctx_mrf_gather": [vp, i32, vp, u64, vp], "mvs_ctx_mrf_scatter": [vp, i32, vp, u64, vp],
         "mvs_ctx_mrf_energy": [vp, i32, u32, u32, vp], "mvs_ctx_mrf_keep_best": [vp],
         "mvs_ctx_mrf_step": [vp, vp], "mvs_ctx_mrf_poll": [vp, u32, C.POINTER(MrfProgress)],
@@ -343,6 +343,12 @@ class Context:
         _check(self.L, self.L.mvs_ctx_view_selection(self.h, pa, pb, d0, C.byref(p), pl, dl, C.byref(ms)))
         return labels_out, _stats_dict(ms)
 
+
+    def mrf_diagnostics(self):
+        """{graph_launches, graph_updates, graph_instantiations, generic_nodes} of this context's view selections"""
+        out = (C.c_uint32 * 4)()
+        _check(self.L, self.L.mvs_ctx_mrf_diagnostics(self.h, out))
+        return dict(zip(("graph_launches", "graph_updates", "graph_instantiations", "generic_nodes"), [int(x) for x in out]))
 
     def get_subgraphs(self, adj_ptr, adj, labels, n_labels, on_device=False):
         """UniGraph::get_subgraphs for every label at once (row f3).  Host copies (label_ptr, comp_ptr, comp_faces), or

@@ -350,6 +350,43 @@ def test_mrf_mixed_node_classes_in_one_graph(seed):
     assert e == sg["energy_fixed"]
 
 
+def test_sweep_loop_as_a_replayed_graph_equals_direct_launches():
+    """the sweep loop replayed from a hipGraph (two sweeps + steps per launch; api.hip prepare_sweep_graph) against direct launches and
+    the oracle: same labels, energy, sweep count; the second solve on the context updates the executable graph instead of
+    instantiating a new one; an odd max_sweeps ends with a directly launched sweep; a mixed-class instance (another graph topology)
+    after a uniform one re-instantiates."""
+    s = get_scene("bumpy")
+    ref, _ = O.data_costs(s)
+    c = M.Context(0)
+    try:
+        c.costs_upload(M.viewsel.DataCosts(ref.n_faces, ref.n_views, ref.col_ptr, ref.view_id, ref.cost))
+        for p in (dict(), dict(max_sweeps=25, min_sweeps=25), dict(max_sweeps=7, min_sweeps=7)):
+            lo, so = O.view_selection(ref, s.adj_ptr, s.adj, O.default_mrf_params(**p))
+            c.set_option("mrf_graph", 0)
+            l0, s0 = c.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(**p))
+            before = c.mrf_diagnostics()
+            c.set_option("mrf_graph", 1)
+            l1, s1 = c.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(**p))
+            after = c.mrf_diagnostics()
+            assert after["graph_launches"] > before["graph_launches"], (before, after)
+            for lg, sg in ((l0, s0), (l1, s1)):
+                assert np.array_equal(lo, lg)
+                assert (so["energy_fixed"], so["sweeps"], so["icm_iters"]) == (sg["energy_fixed"], sg["sweeps"], sg["icm_iters"])
+        d = c.mrf_diagnostics()
+        assert d["graph_instantiations"] == 1 and d["graph_updates"] >= 2, d
+        from util_cases import random_mrf_mixed
+        col_ptr, view_id, cost, adj_ptr, adj = random_mrf_mixed(3000, 400, 21)
+        mref = O.CsrNp(3000, 400, col_ptr, view_id, cost)
+        lo, so = O.view_selection(mref, adj_ptr, adj)
+        c.costs_upload(M.viewsel.DataCosts(3000, 400, col_ptr, view_id, cost))
+        lg, sg = c.view_selection(adj_ptr, adj)
+        assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
+        d2 = c.mrf_diagnostics()
+        assert d2["generic_nodes"] > 0 and d2["graph_launches"] > d["graph_launches"]
+    finally:
+        c.close()
+
+
 def test_one_shot_host_entry_points():
     """mvs_data_costs / mvs_view_selection: the host-pointer drop-ins the tex:: adapter calls"""
     s = get_scene("tiny")
