@@ -276,6 +276,31 @@ def measure_issue(config, timeout_s=420):
     return per_stage, {k: dict(v[1], dispatches=v[0]) for k, v in acc.items()}
 
 
+def dropin_timing(cfg, reps=2, timeout_s=900):
+    """The path texrecon would link: tex::calculate_data_costs + tex::view_selection through include/tex_viewsel.hpp on HOST containers
+    (mesh vectors, TextureViews with bound images, DataCosts = SparseTable, UniGraph), timed by tests/cpp/bench_tex_api.cpp, which is
+    compiled here with g++ against the built library.  Everything is inside the window: context set-up, image upload (caller's
+    buffers pinned in place), the computation, the table download, SparseTable::set_value for every entry (the caller's container, two
+    push_backs per entry: sparse_table.h:105-110), the second call's flatten, the solve on the table still resident on the device.
+    Returns the LAST of `reps` runs (the first pays one-time initialisation) with its breakdown."""
+    import subprocess, tempfile
+    csrc = os.path.join(ROOT, "mvs-texturing_amd", "csrc")
+    tmp = tempfile.mkdtemp(prefix="mvs_dropin_", dir="/tmp")
+    exe, outj = os.path.join(tmp, "bench_tex_api"), os.path.join(tmp, "out.json")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "bench_tex_api.cpp"), "-o", exe,
+                           "-L" + csrc, "-lmvs_viewsel", "-lmvs_synth", "-Wl,-rpath," + csrc, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, str(cfg["n"]), str(cfg["n_views"]), str(cfg["width"]), str(cfg["height"]), str(reps), outj], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+    if r.returncode != 0:
+        raise RuntimeError("bench_tex_api rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:]))
+    d = json.load(open(outj))
+    last = d["runs"][-1]
+    last["runs"] = len(d["runs"]); last["first_run_dropin_ms"] = d["runs"][0]["dropin_ms"]
+    last["note"] = ("host containers in and out; table_fill_ms = SparseTable::set_value for every entry (the reference's own fill, calculate_data_costs.cpp:291-298, "
+                    "pays the same); dropin_core_ms = dropin_ms without table_fill_ms and flatten_ms (the caller's container traffic)")
+    last["dropin_core_ms"] = last["dropin_ms"] - last["calculate_data_costs"]["table_fill_ms"] - last["view_selection"]["flatten_ms"]
+    return last
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +314,7 @@ def main():
     ap.add_argument("--config5-n", type=int, default=250, help="icosphere frequency of the reduced config-5 run (250 = one rank's share of 8)")
     ap.add_argument("--no-real-like", action="store_true", help="skip the second workload (synth.CONFIGS['real']: a scene shaped like a real capture) reported beside the headline")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed step's table (N = 1 only)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the timing of the real drop-in path (tex:: adapter on host containers)")
     ap.add_argument("--parity-faces", type=int, default=100000)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -439,7 +465,6 @@ def main():
     for _ in range(n_prof if args.steps > 0 else 0):
         step()
     prof = ctx.get_profile()
-    ctx.set_option("profile", 0)
     # row f3 (outside the headline window, reported separately): UniGraph::get_subgraphs of the labeling, all labels at once
     post = {}
     if world == 1 and args.steps > 0 and not args.shard:
@@ -573,6 +598,12 @@ def main():
             out["real_like"] = real_like_workload(local_rank, dev, params)
         except Exception as e:  # noqa: BLE001 -- an extra, never at the expense of the headline
             out["real_like"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_dropin and not args.no_traffic and not args.shard and args.steps > 0 and args.config in (2, 3):
+        try:
+            out["dropin"] = dropin_timing(cfg)
+            out["dropin_ms"] = out["dropin"]["dropin_ms"]
+        except Exception as e:  # noqa: BLE001 -- an extra, never at the expense of the headline
+            out["dropin"] = {"error": repr(e)}
     rc = 0
     if rank == 0 and world == 1 and not args.no_parity and args.steps > 0 and not args.shard:
         try:

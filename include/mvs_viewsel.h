@@ -137,6 +137,14 @@ void mvs_default_settings(mvs_settings* s);
  * pointers borrowed for the duration of the call.
  * ------------------------------------------------------------------------ */
 
+/* The two drop-ins below are what texrecon calls back to back (texrecon.cpp:100,121).  mvs_data_costs parks its device context --
+ * table resident -- in a one-slot stash with a fingerprint of the table it handed out; mvs_view_selection solves on that context when
+ * the table it is given has the same fingerprint (no context set-up, no table upload), and uploads it as usual otherwise.
+ * Environment MVS_KEEP_TABLE=0 switches that off; mvs_release_cached() frees a parked context; mvs_last_call_profile() = wall-clock
+ * breakdown (JSON object) of the calling thread's last one-shot call. */
+void mvs_release_cached(void);
+const char* mvs_last_call_profile(void);
+
 /* replaces tex::calculate_data_costs (texturing.h:66-69).  `out` is library
  * allocated (nnz is unknown up front); release with mvs_csr_free. */
 mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views,

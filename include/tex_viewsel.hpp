@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -212,6 +213,12 @@ struct SimpleMesh {
 };
 
 namespace detail {
+/** wall-clock milliseconds of the adapter's own stages in the last calculate_data_costs / view_selection of this thread (the library's
+ *  share: mvs_last_call_profile()).  table_fill_ms is the caller's container: SparseTable::set_value, two push_backs per entry
+ *  (sparse_table.h:105-110) -- the reference's own fill at calculate_data_costs.cpp:291-298 pays the same. */
+struct AdapterTiming { double marshal_ms = 0, library_ms = 0, table_fill_ms = 0, flatten_ms = 0, graph_ms = 0, set_labels_ms = 0; std::string library_profile; };
+inline AdapterTiming& last_timing() { static thread_local AdapterTiming t; return t; }
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline void throw_status(mvs_status st) {
     /* the reference throws std::runtime_error with these texts (calculate_data_costs.cpp:315-318, view_selection.cpp:126-128) */
     switch (st) {
@@ -234,6 +241,7 @@ template <class V> const float* flat(V const& v) { return reinterpret_cast<const
  */
 template <class MeshConstPtr>
 void calculate_data_costs(MeshConstPtr mesh, TextureViews* texture_views, Settings const& settings, DataCosts* data_costs) {
+    double const t0 = detail::now_ms();
     std::size_t const num_faces = mesh->get_faces().size() / 3;
     std::size_t const num_views = texture_views->size();
     if (num_faces > std::numeric_limits<std::uint32_t>::max()) throw std::runtime_error("Exeeded maximal number of faces");
@@ -261,9 +269,15 @@ void calculate_data_costs(MeshConstPtr mesh, TextureViews* texture_views, Settin
     st.geometric_visibility_test = settings.geometric_visibility_test ? 1 : 0;
     mvs_csr csr; std::memset(&csr, 0, sizeof(csr));
     mvs_dc_stats stats;
+    detail::AdapterTiming& T = detail::last_timing(); T = detail::AdapterTiming();
+    double const t1 = detail::now_ms();
+    T.marshal_ms = t1 - t0;
     detail::throw_status(mvs_data_costs(&m, views.data(), static_cast<std::uint32_t>(num_views), &st, &csr, &stats));
+    double const t2 = detail::now_ms();
+    T.library_ms = t2 - t1; T.library_profile = mvs_last_call_profile();
     for (std::uint32_t i = 0; i < csr.n_faces; ++i)          /* calculate_data_costs.cpp:291-298 */
         for (std::uint32_t k = csr.col_ptr[i]; k < csr.col_ptr[i + 1]; ++k) data_costs->set_value(i, csr.view_id[k], csr.cost[k]);
+    T.table_fill_ms = detail::now_ms() - t2;
     mvs_csr_free(&csr);
     for (TextureView& tv : *texture_views) tv.release_image();  /* :231 */
     std::cout << "\tMaximum quality of a face within an image: " << stats.max_quality << std::endl;     /* :304-305 */
@@ -301,21 +315,28 @@ inline void postprocess_face_infos(Settings const& settings, FaceProjectionInfos
 
 /** Runs the view selection procedure and saves the labeling in the graph   (libs/tex/texturing.h:76-80) */
 inline void view_selection(DataCosts const& data_costs, UniGraph* graph, Settings const&) {
+    detail::AdapterTiming& T = detail::last_timing(); T = detail::AdapterTiming();
+    double const t0 = detail::now_ms();
     std::uint32_t const F = data_costs.cols();
     std::vector<std::uint32_t> col_ptr(F + 1, 0);
-    std::vector<std::uint16_t> view_id; std::vector<float> cost;
-    view_id.reserve(data_costs.get_nnz()); cost.reserve(data_costs.get_nnz());
-    for (std::uint32_t i = 0; i < F; ++i) {
-        for (auto const& e : data_costs.col(i)) { view_id.push_back(e.first); cost.push_back(e.second); }
-        col_ptr[i + 1] = static_cast<std::uint32_t>(view_id.size());
+    std::vector<std::uint16_t> view_id(data_costs.get_nnz() + 1); std::vector<float> cost(data_costs.get_nnz() + 1);
+    {   /* the table as CSR (view_selection.cpp:27-82 reads it column by column) */
+        std::size_t k = 0;
+        for (std::uint32_t i = 0; i < F; ++i) {
+            for (auto const& e : data_costs.col(i)) { view_id[k] = e.first; cost[k] = e.second; ++k; }
+            col_ptr[i + 1] = static_cast<std::uint32_t>(k);
+        }
     }
+    double const t1 = detail::now_ms();
+    T.flatten_ms = t1 - t0;
     std::vector<std::uint32_t> adj_ptr(F + 1, 0), adj;
     for (std::uint32_t i = 0; i < F; ++i) {
         for (std::size_t n : graph->get_adj_nodes(i)) adj.push_back(static_cast<std::uint32_t>(n));
         adj_ptr[i + 1] = static_cast<std::uint32_t>(adj.size());
     }
-    if (view_id.empty()) { view_id.push_back(0); cost.push_back(0.0f); }
     if (adj.empty()) adj.push_back(0);
+    double const t2 = detail::now_ms();
+    T.graph_ms = t2 - t1;
     mvs_csr csr;
     csr.n_faces = F; csr.n_views = data_costs.rows(); csr.nnz = col_ptr[F];
     csr.col_ptr = col_ptr.data(); csr.view_id = view_id.data(); csr.cost = cost.data();
@@ -323,8 +344,11 @@ inline void view_selection(DataCosts const& data_costs, UniGraph* graph, Setting
     mvs_mrf_stats stats;
     std::cout << "\tOptimizing:" << std::endl;
     detail::throw_status(mvs_view_selection(&csr, adj_ptr.data(), adj.data(), nullptr, labels.data(), &stats));
+    double const t3 = detail::now_ms();
+    T.library_ms = t3 - t2; T.library_profile = mvs_last_call_profile();
     std::cout << "\t\t" << stats.sweeps << " sweeps\t" << stats.energy << std::endl;
     for (std::uint32_t i = 0; i < F; ++i) graph->set_label(i, labels[i]);                  /* view_selection.cpp:130 */
+    T.set_labels_ms = detail::now_ms() - t3;
     std::cout << '\t' << stats.unseen << " faces have not been seen" << std::endl;      /* :132 */
 }
 

@@ -425,9 +425,17 @@ MVS_HD uint8_t luminance_u8(uint8_t r, uint8_t g, uint8_t b) {
 // floor(min(255, sqrt(n))) for 0 <= n < 2^24, exact
 MVS_HD uint8_t isqrt_clamp255(int n) {
     if (n >= 255 * 255) return 255;
+    // n < 2^16 is exact in fp32 and sqrt(n) of a non-square is at least 1 / 510 away from an integer, a thousand ulps: truncating ANY
+    // square root accurate to a few ulps gives floor(sqrt(n)).  On the device that is v_sqrt_f32 (1 ulp) instead of the correctly
+    // rounded sequence the compile flags would expand sqrtf into (ten instructions per pixel of the Sobel kernel); the two
+    // branch-free corrections keep the result exact whatever the root's last bits are.
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r = (int)__builtin_amdgcn_sqrtf((float)n);
+#else
     int r = (int)sqrtf((float)n);
-    while (r * r > n) --r;
-    while ((r + 1) * (r + 1) <= n) ++r;
+#endif
+    r -= (r * r > n) ? 1 : 0;
+    r += ((r + 1) * (r + 1) <= n) ? 1 : 0;
     return (uint8_t)r;
 }
 

@@ -105,6 +105,7 @@ def load_library():
     L = C.CDLL(_LIB_PATH)
     L.mvs_last_error.restype = C.c_char_p
     L.mvs_status_string.restype = C.c_char_p
+    L.mvs_last_call_profile.restype = C.c_char_p
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     sig = {
         "mvs_mrf_default_params": [C.POINTER(MrfParams)], "mvs_default_settings": [C.POINTER(Settings)],

@@ -416,6 +416,53 @@ def test_one_shot_host_entry_points():
     assert b"Exeeded maximal number of views" in L.mvs_last_error()
 
 
+def test_one_shot_calls_keep_the_table_on_the_device():
+    """mvs_data_costs parks its context (table resident) for the mvs_view_selection that follows -- texrecon.cpp:100,121 call them
+    back to back on the same DataCosts.  The parked table is used only for a table with the same fingerprint: the unmodified table
+    solves on the device copy, a modified one (one cost changed) is uploaded; results equal the plain path either way."""
+    import json
+    s = get_scene("bumpy")
+    L = M.load_library()
+    ref, _ = O.data_costs(s)
+
+    def dc():
+        mesh = M.viewsel.CMesh(s.verts.shape[0], s.n_faces, s.verts.ctypes.data, s.faces.ctypes.data, s.normals.ctypes.data)
+        views = (M.viewsel.CView * s.n_views)()
+        for j in range(s.n_views):
+            v = views[j]
+            v.pos[:] = s.cams["pos"][j].tolist(); v.viewdir[:] = s.cams["viewdir"][j].tolist()
+            v.K[:] = s.cams["K"][j].tolist(); v.w2c[:] = s.cams["w2c"][j].tolist()
+            v.width, v.height, v.rgb = int(s.cams["width"][j]), int(s.cams["height"][j]), s.images[j].ctypes.data
+        out = M.viewsel.CCsr(); st = M.Settings()
+        assert L.mvs_data_costs(C.byref(mesh), views, s.n_views, C.byref(st), C.byref(out), None) == 0, L.mvs_last_error()
+        prof = json.loads(L.mvs_last_call_profile().decode())
+        return out, prof
+
+    def vs(csr):
+        labels = np.zeros(s.n_faces, np.uint32); ms = M.viewsel.MrfStats()
+        assert L.mvs_view_selection(C.byref(csr), s.adj_ptr.ctypes.data, s.adj.ctypes.data, None, labels.ctypes.data, C.byref(ms)) == 0, L.mvs_last_error()
+        return labels, ms.energy_fixed, json.loads(L.mvs_last_call_profile().decode())
+
+    lo, so = O.view_selection(ref, s.adj_ptr, s.adj)
+    out, prof = dc()
+    assert prof["table_kept_on_device"] is True
+    l1, e1, p1 = vs(out)
+    assert p1["table_reused_on_device"] is True and np.array_equal(l1, lo) and e1 == so["energy_fixed"]
+    l2, e2, p2 = vs(out)                                   # the stash holds ONE solve's context: the second call uploads
+    assert p2["table_reused_on_device"] is False and np.array_equal(l2, lo)
+    L.mvs_csr_free(C.byref(out))
+    out, prof = dc()
+    cost = np.ctypeslib.as_array(C.cast(out.cost, C.POINTER(C.c_float)), (out.nnz,))
+    k = int(np.argmax(cost > 0.5)); old = float(cost[k]); cost[k] = 0.0     # the caller edits the table between the calls
+    l3, e3, p3 = vs(out)
+    assert p3["table_reused_on_device"] is False
+    mod = O.CsrNp(ref.n_faces, ref.n_views, ref.col_ptr, ref.view_id, ref.cost.copy()); mod.cost[k] = 0.0
+    lm, sm = O.view_selection(mod, s.adj_ptr, s.adj)
+    assert np.array_equal(l3, lm) and e3 == sm["energy_fixed"] and old > 0.5
+    L.mvs_csr_free(C.byref(out))
+    L.mvs_release_cached()
+
+
 def test_call_order_errors(ctx):
     c2 = M.Context(0)
     with pytest.raises(M.MvsError) as ei:
