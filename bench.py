@@ -194,7 +194,7 @@ def pmc_pass(config, counters, timeout_s=420, extra_args=()):
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         cmd = [rocprof, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-real-like"] + list(extra_args)
+               "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-real-like", "--pmc-child"] + list(extra_args)
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
@@ -287,7 +287,7 @@ def dropin_timing(cfg, reps=2, timeout_s=900):
     csrc = os.path.join(ROOT, "mvs-texturing_amd", "csrc")
     tmp = tempfile.mkdtemp(prefix="mvs_dropin_", dir="/tmp")
     exe, outj = os.path.join(tmp, "bench_tex_api"), os.path.join(tmp, "out.json")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "bench_tex_api.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fopenmp", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "bench_tex_api.cpp"), "-o", exe,
                            "-L" + csrc, "-lmvs_viewsel", "-lmvs_synth", "-Wl,-rpath," + csrc, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe, str(cfg["n"]), str(cfg["n_views"]), str(cfg["width"]), str(cfg["height"]), str(reps), outj], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
     if r.returncode != 0:
@@ -314,6 +314,7 @@ def main():
     ap.add_argument("--config5-n", type=int, default=250, help="icosphere frequency of the reduced config-5 run (250 = one rank's share of 8)")
     ap.add_argument("--no-real-like", action="store_true", help="skip the second workload (synth.CONFIGS['real']: a scene shaped like a real capture) reported beside the headline")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed step's table (N = 1 only)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the counter passes' own runs: exactly one step, nothing else
     ap.add_argument("--no-dropin", action="store_true", help="skip the timing of the real drop-in path (tex:: adapter on host containers)")
     ap.add_argument("--parity-faces", type=int, default=100000)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
@@ -432,7 +433,7 @@ def main():
 
     # row f1 (outside the headline window, reported separately): tex::build_adjacency_graph on the GPU
     pre = {}
-    if world == 1 and not args.shard:
+    if world == 1 and not args.shard and not args.pmc_child:
         ctx.build_adjacency(); ctx.get_profile()
         for _ in range(3):
             ctx.build_adjacency()
@@ -462,12 +463,12 @@ def main():
         info["timed"] = dict(labels=t_lab.cpu().numpy().view(np.uint32), energy_fixed=info["mrf"]["energy_fixed"], sweeps=info["mrf"]["sweeps"], icm_iters=info["mrf"]["icm_iters"])
     n_prof = min(max(args.steps, 1), 3)
     ctx.set_option("profile", 1)
-    for _ in range(n_prof if args.steps > 0 else 0):
+    for _ in range(n_prof if (args.steps > 0 and not args.pmc_child) else 0):
         step()
     prof = ctx.get_profile()
     # row f3 (outside the headline window, reported separately): UniGraph::get_subgraphs of the labeling, all labels at once
     post = {}
-    if world == 1 and args.steps > 0 and not args.shard:
+    if world == 1 and args.steps > 0 and not args.shard and not args.pmc_child:
         ctx.get_subgraphs(t_ap, t_ad, t_lab, V + 1, on_device=True); ctx.get_profile()
         for _ in range(3):
             sg = ctx.get_subgraphs(t_ap, t_ad, t_lab, V + 1, on_device=True)

@@ -140,7 +140,9 @@ void mvs_default_settings(mvs_settings* s);
 /* The two drop-ins below are what texrecon calls back to back (texrecon.cpp:100,121).  mvs_data_costs parks its device context --
  * table resident -- in a one-slot stash with a fingerprint of the table it handed out; mvs_view_selection solves on that context when
  * the table it is given has the same fingerprint (no context set-up, no table upload), and uploads it as usual otherwise.
- * Environment MVS_KEEP_TABLE=0 switches that off; mvs_release_cached() frees a parked context; mvs_last_call_profile() = wall-clock
+ * After its solve mvs_view_selection parks the context as a spare: the next one-shot call reuses its stream, device buffers and graph.
+ * At most two contexts are parked; their device memory stays allocated until mvs_release_cached() or the end of the process.
+ * Environment MVS_KEEP_TABLE=0 switches all of that off; mvs_release_cached() frees what is parked; mvs_last_call_profile() = wall-clock
  * breakdown (JSON object) of the calling thread's last one-shot call. */
 void mvs_release_cached(void);
 const char* mvs_last_call_profile(void);

@@ -28,6 +28,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -320,12 +321,19 @@ inline void view_selection(DataCosts const& data_costs, UniGraph* graph, Setting
     std::uint32_t const F = data_costs.cols();
     std::vector<std::uint32_t> col_ptr(F + 1, 0);
     std::vector<std::uint16_t> view_id(data_costs.get_nnz() + 1); std::vector<float> cost(data_costs.get_nnz() + 1);
-    {   /* the table as CSR (view_selection.cpp:27-82 reads it column by column) */
-        std::size_t k = 0;
-        for (std::uint32_t i = 0; i < F; ++i) {
-            for (auto const& e : data_costs.col(i)) { view_id[k] = e.first; cost[k] = e.second; ++k; }
-            col_ptr[i + 1] = static_cast<std::uint32_t>(k);
-        }
+    {   /* the table as CSR (view_selection.cpp:27-82 reads it column by column): column offsets first, then the copies on a few threads */
+        for (std::uint32_t i = 0; i < F; ++i) col_ptr[i + 1] = col_ptr[i] + static_cast<std::uint32_t>(data_costs.col(i).size());
+        unsigned const T = std::max(1u, std::min(8u, std::min(std::thread::hardware_concurrency(), static_cast<unsigned>(F / 65536u + 1u))));
+        auto copy = [&](unsigned t) {
+            for (std::uint32_t i = static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * t / T); i < static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * (t + 1) / T); ++i) {
+                std::size_t k = col_ptr[i];
+                for (auto const& e : data_costs.col(i)) { view_id[k] = e.first; cost[k] = e.second; ++k; }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(copy, t);
+        copy(0);
+        for (auto& x : th) x.join();
     }
     double const t1 = detail::now_ms();
     T.flatten_ms = t1 - t0;

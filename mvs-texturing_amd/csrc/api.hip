@@ -73,7 +73,18 @@ void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, i
 // config 3.  A table the caller changed, loaded from a file or computed elsewhere has another fingerprint and is uploaded as before.
 // MVS_KEEP_TABLE=0 switches the stash off; mvs_release_cached() empties it.
 namespace {
-struct Stash { std::mutex m; mvs_ctx* ctx = nullptr; uint64_t fp = 0, nnz = 0; uint32_t n_faces = 0, n_views = 0; } g_stash;
+struct Stash {
+    std::mutex m;
+    mvs_ctx* ctx = nullptr; uint64_t fp = 0, nnz = 0; uint32_t n_faces = 0, n_views = 0;   // a context whose device table has this fingerprint
+    mvs_ctx* spare = nullptr;   // a context without a table to keep: its stream, buffers and instantiated graph serve the next one-shot call
+} g_stash;
+mvs_ctx* take_spare() { std::lock_guard<std::mutex> lock(g_stash.m); mvs_ctx* c = g_stash.spare; g_stash.spare = nullptr; return c; }
+void park_spare(mvs_ctx* c) {
+    if (!c) return;
+    mvs_ctx* old = nullptr;
+    { std::lock_guard<std::mutex> lock(g_stash.m); old = g_stash.spare; g_stash.spare = c; }
+    if (old) mvs_ctx_destroy(old);
+}
 thread_local std::string g_call_profile = "{}";
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline uint64_t fp_mix(uint64_t k, uint64_t v) { uint64_t x = (k * 0x9E3779B97F4A7C15ull) ^ (v + 0x7F4A7C15D6E8FEB8ull); x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; return x; }
@@ -291,8 +302,9 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
     if (!ctx || (!views && n_views)) return fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
     MVS_HIP(hipSetDevice(ctx->device));
-    for (auto* b : ctx->own_rgb) delete b;
-    ctx->own_rgb.clear();
+    // image buffers of an earlier call are reused (a context that serves one scene after another allocates once)
+    if (rgb_on_device) { for (auto* b : ctx->own_rgb) delete b; ctx->own_rgb.clear(); }
+    else { while (ctx->own_rgb.size() > n_views) { delete ctx->own_rgb.back(); ctx->own_rgb.pop_back(); } }
     ctx->h_views.assign(n_views, ViewParams{});
     // Host images: the caller's buffers are pageable, and a pageable hipMemcpyAsync is staged through the driver's bounce
     // buffer at ~13 GB/s (1.9 GB of BASELINE config 3: 146 ms).  Pinning the caller's pages in place for the duration of the
@@ -313,8 +325,8 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
         p.width = v.width; p.height = v.height;
         if (rgb_on_device) p.rgb = v.rgb;
         else {
-            auto* b = new DBuf<uint8_t>();
-            ctx->own_rgb.push_back(b);
+            if (ctx->own_rgb.size() <= j) ctx->own_rgb.push_back(new DBuf<uint8_t>());
+            auto* b = ctx->own_rgb[j];
             const size_t bytes = (size_t)v.width * v.height * 3;
             b->ensure(bytes + 16);
             if (bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) pinned.ptrs.push_back(const_cast<uint8_t*>(v.rgb));
@@ -566,8 +578,9 @@ mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t 
     /* calculate_data_costs.cpp:315-318 */
     if (n_views > 65535u) return fail(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");
     double t[7]; t[0] = now_ms();
-    mvs_ctx* ctx = nullptr;
-    mvs_status st = mvs_ctx_create(0, &ctx);
+    mvs_ctx* ctx = stash_enabled() ? take_spare() : nullptr;
+    mvs_status st = MVS_OK;
+    if (!ctx) st = mvs_ctx_create(0, &ctx);
     if (st != MVS_OK) return st;
     t[1] = now_ms();
     st = mvs_scene_set_mesh(ctx, mesh, 0);
@@ -582,13 +595,15 @@ mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t 
     bool kept = false;
     if (st == MVS_OK && stash_enabled()) {   // park the context with its table for the mvs_view_selection that follows
         const uint64_t fp = csr_fingerprint(out);
+        mvs_ctx* old = nullptr;
+        { std::lock_guard<std::mutex> lock(g_stash.m); old = g_stash.ctx; g_stash.ctx = nullptr; }
+        if (old) mvs_ctx_destroy(old);
         std::lock_guard<std::mutex> lock(g_stash.m);
-        if (g_stash.ctx) mvs_ctx_destroy(g_stash.ctx);
         g_stash.ctx = ctx; g_stash.fp = fp; g_stash.nnz = out->nnz; g_stash.n_faces = out->n_faces; g_stash.n_views = out->n_views;
         kept = true;
     }
     t[6] = now_ms();
-    if (!kept) mvs_ctx_destroy(ctx);
+    if (!kept) { if (stash_enabled() && st == MVS_OK) park_spare(ctx); else mvs_ctx_destroy(ctx); }
     char buf[512];
     snprintf(buf, sizeof(buf), "{\"call\": \"mvs_data_costs\", \"ctx_ms\": %.3f, \"mesh_h2d_ms\": %.3f, \"images_h2d_ms\": %.3f, \"compute_ms\": %.3f, \"download_ms\": %.3f, "
              "\"fingerprint_ms\": %.3f, \"table_kept_on_device\": %s}", t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], kept ? "true" : "false");
@@ -598,9 +613,10 @@ mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t 
 /* wall-clock breakdown (JSON object) of the last one-shot call -- mvs_data_costs / mvs_view_selection -- of the calling thread */
 const char* mvs_last_call_profile(void) { return g_call_profile.c_str(); }
 void mvs_release_cached(void) {
-    std::lock_guard<std::mutex> lock(g_stash.m);
-    if (g_stash.ctx) mvs_ctx_destroy(g_stash.ctx);
-    g_stash.ctx = nullptr; g_stash.fp = 0;
+    mvs_ctx* a = nullptr; mvs_ctx* b = nullptr;
+    { std::lock_guard<std::mutex> lock(g_stash.m); a = g_stash.ctx; b = g_stash.spare; g_stash.ctx = nullptr; g_stash.spare = nullptr; g_stash.fp = 0; }
+    if (a) mvs_ctx_destroy(a);
+    if (b) mvs_ctx_destroy(b);
 }
 
 /* the undistortion step of from_images_and_camera_files (generate_texture_views.cpp:153-165) */
@@ -676,14 +692,15 @@ mvs_status mvs_view_selection(const mvs_csr* costs, const uint32_t* adj_ptr, con
     const bool reused = ctx != nullptr;
     mvs_status st = MVS_OK;
     if (!reused) {
-        st = mvs_ctx_create(0, &ctx);
+        ctx = stash_enabled() ? take_spare() : nullptr;
+        if (!ctx) st = mvs_ctx_create(0, &ctx);
         if (st != MVS_OK) return st;
         st = mvs_ctx_costs_upload(ctx, costs, 0);
     }
     t[2] = now_ms();
     if (st == MVS_OK) st = mvs_ctx_view_selection(ctx, adj_ptr, adj, 0, params, labels_out, 0, stats);
     t[3] = now_ms();
-    mvs_ctx_destroy(ctx);
+    if (stash_enabled() && st == MVS_OK) park_spare(ctx); else mvs_ctx_destroy(ctx);   // the next one-shot call starts from this context's buffers
     char buf[384];
     snprintf(buf, sizeof(buf), "{\"call\": \"mvs_view_selection\", \"fingerprint_ms\": %.3f, \"ctx_and_table_upload_ms\": %.3f, \"solve_ms\": %.3f, \"table_reused_on_device\": %s}",
              t[1] - t[0], t[2] - t[1], t[3] - t[2], reused ? "true" : "false");

@@ -748,8 +748,12 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
     } while (masks != 0ull);
 }
 
+// amdgpu_num_sgpr(80): a 256-thread block is admitted per CU up to floor(800 / (ceil16(sgpr) + 16)) times (MI355X_MICROARCH.md
+// "Residency"): the 98 SGPRs the compiler takes by itself allow 6 blocks, 80 allow 7 (the VGPRs then stop at 7 waves per SIMD).  The
+// kernel is a chain of dependent node and triangle fetches per wave -- PMC: vector issue 41 %, waves parked on memory 46 % of their
+// time -- so residency is throughput: 6.63 -> 6.33 ms at BASELINE config 3 (A/B of two builds on one box, scripts/ab_libs.py).
 template <bool XCD>
-__global__ void __launch_bounds__(256) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
                                                           const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
                                                           unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
                                                           const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {

@@ -32,7 +32,7 @@ def kernel_times(config):
     tmp = tempfile.mkdtemp(prefix="mvs_kt_", dir="/tmp")
     try:
         cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "kt", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-               "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-real-like"]
+               "--config", str(config), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--no-traffic", "--no-real-like", "--pmc-child"]
         subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         out = {}
         for f in glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True):

@@ -16,7 +16,7 @@ def _build(tmp_path):
     if not os.path.exists(M.lib_path()):
         pytest.skip("HIP library not built")
     exe = str(tmp_path / "test_tex_api")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_tex_api.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_tex_api.cpp"),
                            "-o", exe, "-L" + CSRC, "-lmvs_viewsel", "-lmvs_synth", "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
