@@ -393,38 +393,23 @@ def main():
             st = ctx.data_costs(settings)
             _, ms = ctx.view_selection(t_ap, t_ad, params, labels_out=t_lab)
             info["nnz_global"] = int(st["nnz"])
-        elif args.backend == "nccl" and info.get("path", "cpp") == "cpp":
+        elif args.backend == "nccl":
             # the product's sharded path: host side in C++ (csrc/shard.hip), halo exchange by RCCL over xGMI; nothing is
-            # cached between steps -- the halo plan is rebuilt on the device inside every step (reported as mrf_plan)
+            # cached between steps -- the halo plan is rebuilt on the device inside every step (reported as mrf_plan).
+            # A communicator that cannot be set up is an error (no second driver to fall back to).
             if "shard" not in info:
-                err = None
-                try:
-                    if os.environ.get("MVS_BENCH_FORCE_PY_SHARD"):   # test hook: exercise the fallback below
-                        raise RuntimeError("forced by MVS_BENCH_FORCE_PY_SHARD")
-                    uid = [M.shard.unique_id() if rank == 0 else None]
-                    if dist is not None:
-                        dist.broadcast_object_list(uid, src=0)
-                    info["comm"] = M.shard.Comm.rccl(local_rank, rank, world, uid[0])
-                    info["shard"] = M.shard.Shard(ctx, info["comm"], part, t_ap, t_ad)
-                    info["labels_own"] = torch.zeros(max(int(part[rank + 1] - part[rank]), 1), dtype=torch.int32, device=dev)
-                except Exception as e:   # noqa: BLE001 -- reported, and agreed on by all ranks below
-                    err = "%s: %s" % (type(e).__name__, e)
-                bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+                uid = [M.shard.unique_id() if rank == 0 else None]
                 if dist is not None:
-                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                if int(bad.item()):
-                    # the communicator could not be set up on some rank: every rank switches to the Python-driven sharded
-                    # pipeline (same kernels, halo exchange through torch.distributed = RCCL) and the JSON line says so
-                    info["path"] = "python"; info["path_error"] = err or "another rank failed"
-                    info.pop("shard", None); info.pop("comm", None)
-                    log("rank %d: C++/RCCL shard set-up failed (%s); using the torch.distributed pipeline" % (rank, info["path_error"]))
-                    return step()
+                    dist.broadcast_object_list(uid, src=0)
+                info["comm"] = M.shard.Comm.rccl(local_rank, rank, world, uid[0])
+                info["shard"] = M.shard.Shard(ctx, info["comm"], part, t_ap, t_ad)
+                info["labels_own"] = torch.zeros(max(int(part[rank + 1] - part[rank]), 1), dtype=torch.int32, device=dev)
             st, info["nnz_global"] = info["shard"].data_costs(settings)
             ms = info["shard"].view_selection(info["labels_own"], params)
             info["plan"] = info["shard"].plan_info()
         else:
-            # harness path for test boxes with one GPU (several ranks on cuda:0 cannot share an RCCL communicator):
-            # the same building blocks driven from Python over gloo (mvs-texturing_amd/multigpu.py)
+            # TEST HARNESS (--backend gloo with MVS_BENCH_ONE_GPU): several ranks on cuda:0 cannot share an RCCL communicator, so the
+            # contract test drives the same device building blocks from Python over gloo (mvs-texturing_amd/multigpu.py); never the product path
             if "pipe" not in info:
                 info["pipe"] = G.ShardedPipeline(ctx, part, rank, dist, dev, adj_ptr, adj, t_ap, t_ad, settings, params)
             labels, st, ms, dc = info["pipe"].step()
@@ -586,8 +571,7 @@ def main():
     if "plan" in info:
         out["halo"] = dict(info["plan"], driver="C++ (csrc/shard.hip), grouped ncclSend/ncclRecv per colour phase, bytes on the wire")
     if world > 1 or args.shard:
-        out["sharded_driver"] = "python/torch.distributed (C++ set-up failed: %s)" % info["path_error"] if info.get("path") == "python" else \
-                                ("C++ / RCCL (csrc/shard.hip)" if args.backend == "nccl" else "python/torch.distributed over %s (one-GPU test mode)" % args.backend)
+        out["sharded_driver"] = "C++ / RCCL (csrc/shard.hip)" if args.backend == "nccl" else "python test harness over %s (one-GPU test mode)" % args.backend
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(scene, faces, normals, adj_ptr, adj,

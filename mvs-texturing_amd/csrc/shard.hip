@@ -773,19 +773,36 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     resolve_best(ctx);
     if (S->P > 1 && issued == 0) exchange_nodes(S, ctx->b_lab);   // argmin-unary start: the halo labels
     mrf_exact_costs(ctx, nb, ne);
+    // ICM rounds: gains of the own nodes, gains of the boundary nodes to the neighbours, winners move, labels of the boundary nodes
+    // to the neighbours; the all-reduced "moved" count of a round reaches the host through the pinned ring two rounds late (as in
+    // the single-context polish, api.hip icm_polish), so no round waits for a read-back.  Every rank reads the same counts at the same
+    // round indices, hence takes the same decisions; a round queued after the one that moved nothing finds no positive gain anywhere.
     int it = 0;
-    for (; it < P.icm_iters; ++it) {
-        Prof pr(ctx, "mrf_icm");
-        mrf_icm_gain(ctx, nb, ne);
-        if (S->P > 1) exchange_nodes(S, (uint32_t*)ctx->m_gain.p);
-        mrf_icm_apply(ctx, nb, ne);
-        MVS_HIP(hipMemcpyAsync(S->d_moved.p, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        if (S->P > 1) { comm->allreduce(S->d_moved.p, 1, mvs_comm::U32, mvs_comm::SUM, s); exchange_nodes(S, ctx->b_lab); }
-        pr.end();
-        uint32_t moved = 0;
-        MVS_HIP(hipMemcpyAsync(&moved, S->d_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        MVS_HIP(hipStreamSynchronize(s));
-        if (moved == 0) break;
+    {
+        constexpr int RR = (int)mvs_ctx::ICM_RING, LAG = 2;
+        ensure_report_ring(ctx);
+        int issued = 0, polled_icm = 0, stop = -1;
+        const uint32_t seq0 = ctx->icm_seq;
+        auto poll = [&]() {
+            const int k = polled_icm++;
+            wait_report(ctx, mvs_ctx::RING + (uint32_t)(k % RR), seq0 + (uint32_t)k + 1u);
+            if (stop < 0 && ctx->h_icm[k % RR] == 0u) stop = k;
+        };
+        while (issued < P.icm_iters && stop < 0) {
+            Prof pr(ctx, "mrf_icm");
+            mrf_icm_gain(ctx, nb, ne);
+            if (S->P > 1) exchange_nodes(S, (uint32_t*)ctx->m_gain.p);
+            mrf_icm_apply(ctx, nb, ne);
+            MVS_HIP(hipMemcpyAsync(S->d_moved.p, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            if (S->P > 1) { comm->allreduce(S->d_moved.p, 1, mvs_comm::U32, mvs_comm::SUM, s); exchange_nodes(S, ctx->b_lab); }
+            report_u32(ctx, S->d_moved.p, ctx->d_icm + issued % RR, mvs_ctx::RING + (uint32_t)(issued % RR), seq0 + (uint32_t)issued + 1u);
+            pr.end();
+            ++issued;
+            if (issued - polled_icm > LAG) poll();
+        }
+        while (polled_icm < issued) poll();
+        ctx->icm_seq = seq0 + (uint32_t)issued;
+        it = stop >= 0 ? stop : P.icm_iters;
     }
     R.icm_iters = (uint32_t)it;
     mrf_energy(ctx, true, nb, ne, true);
