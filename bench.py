@@ -377,11 +377,9 @@ def main():
     ctx.set_option("profile", 1)   # (set-up measurements below; off for the timed steps)
     if max_labels:
         ctx.set_option("max_labels", max_labels)
-    for env, opt in (("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag"), ("MVS_LDS_BVH", "lds_bvh_levels")):
+    for env, opt in (("MVS_MRF_BPC", "mrf_blocks_per_cu"), ("MVS_MRF_XCD", "mrf_xcd"), ("MVS_RAY_XCD", "ray_xcd"), ("MVS_MRF_LAG", "mrf_lag")):
         if os.environ.get(env):   # tuning knobs for experiments
             ctx.set_option(opt, int(os.environ[env]))
-    if os.environ.get("MVS_RAY_MODE"):
-        ctx.set_option("ray_mode", int(os.environ["MVS_RAY_MODE"]))
     ctx.set_mesh(t_v, t_f, t_n)
     ctx.set_views(scene.cams, t_img)
     settings = M.Settings()                      # reference defaults: gmi / none / visibility test on
@@ -522,7 +520,8 @@ def main():
         n_nodes, n_tris, nnz_pre = int(cst["ray_nodes"]), int(cst["ray_tris"]), int(cst["nnz_pre"])
         whv = float(W) * H * V
         sweeps = int(mrf["sweeps"])
-        b_stage = {"dc_prep": 3.0 * whv + whv + whv / 8.0, "dc_cull": 60.0 * F, "dc_rays": 32.0 * n_nodes + 36.0 * n_tris,
+        # a node visit fetches 4 child boxes (the survey's 32-byte node each), a leaf visit 16 triangles (36 bytes each in the survey's BVH)
+        b_stage = {"dc_prep": 3.0 * whv + whv + whv / 8.0, "dc_cull": 60.0 * F, "dc_rays": 32.0 * 4.0 * n_nodes + 36.0 * n_tris,
                    "dc_face_info": 20.0 * nnz_pre, "dc_csr": 20.0 * nnz_pre + 6.0 * nnz_global + 4.0 * (F + 1),
                    "mrf_sweep": sweeps * (12.0 * nnz_global + 12.0 * F)}
         b_dc = sum(v for k, v in b_stage.items() if k.startswith("dc_"))
@@ -531,7 +530,8 @@ def main():
         roof_path = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "B_dc": b_dc, "B_mrf": b_mrf,
                      "B_mrf_survey_fp32_messages": sweeps * (30.0 * nnz_global + 12.0 * F),
                      "achieved": (b_dc + b_mrf) / t_s / 1e9, "frac": (b_dc + b_mrf) / t_s / 1e9 / HBM_PEAK_GBS,
-                     "N_ray_nodes": n_nodes, "N_ray_tris": n_tris, "rays": int(cst["rays"]), "nnz_pre": nnz_pre,
+                     "N_ray_nodes": 4 * n_nodes, "N_ray_tris": n_tris, "ray_node_visits": n_nodes, "ray_leaf_rounds": int(cst["ray_leaf_rounds"]),
+                     "rays": int(cst["rays"]), "ray_packets": int(cst["ray_packets"]), "nnz_pre": nnz_pre,
                      "note": "algorithmic bytes of BASELINE.md section 5 over the whole timed step; the data-cost half is bound by vector issue, "
                              "not by HBM (see stage_roofline[*].valu_issue_frac)"}
         issue, issue_kernels = measure_issue(args.config)

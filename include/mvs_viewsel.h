@@ -117,14 +117,15 @@ typedef struct {
     uint64_t nnz_pre;           /* FaceProjectionInfos emitted (:227-228) */
     uint64_t nnz;
     uint64_t rays;              /* (vertex, view) rays traced -- each distinct ray once */
-    uint64_t ray_nodes;         /* BVH nodes fetched  (only with mvs_set_option("count_rays", 1)) */
-    uint64_t ray_tris;          /* triangles tested   (idem) */
-    uint64_t ray_packets;         /* 64-ray packets traced (ray_mode 3 with "stats") */
+    uint64_t ray_nodes;         /* BVH node visits of the 64-ray packets: one 128-byte node = 4 child boxes each  (only with mvs_set_option("count_rays", 1)) */
+    uint64_t ray_tris;          /* triangles fetched: 16 per leaf a packet's rays enter   (idem) */
+    uint64_t ray_packets;         /* 64-ray packets traced (with "stats") */
     uint64_t ray_packets_generic; /* ... of which with mixed / degenerate direction signs: the unspecialised slab test */
     float max_quality;          /* :278-281 */
     float percentile;           /* :288 */
     uint64_t footprints_lane_group; /* sampled footprints above "info_wave_area" pixels: summed by a 16-lane group (integer pixel sums) */
     uint64_t footprints_rewalked;   /* ... of which the exactness certificate could not decide: re-walked in the reference's serial fp64 order */
+    uint64_t ray_leaf_rounds;       /* rounds of 4 candidate rays x 16 triangles at the leaves ("count_rays") */
 } mvs_dc_stats;
 
 const char* mvs_last_error(void);
@@ -211,13 +212,13 @@ void mvs_ctx_destroy(mvs_ctx* ctx);
 /* hipStream_t to launch on from now on (NULL = the device's default stream); a fresh context owns a private stream */
 mvs_status mvs_ctx_set_stream(mvs_ctx* ctx, void* hip_stream);
 mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
-/* integer options: "stats" (0/1: fill the cull-reason counters of mvs_dc_stats; default 0), "count_rays" (0/1), "lds_bvh_levels" (>=0), "verbose" (0/1), "profile" (0/1),
- * "ray_mode" (0 = one BVH traversal per ray, 1 = one shared traversal per 64-ray wave, 2 = shared traversal with
- * (ray, triangle) work redistribution at the leaves, 3 = 2 with the packed, direction-sign-specialised slab test -- the default;
- * identical results), "mrf_lag" (sweeps the host queues ahead of
- * the energy reports it reads, default 1, 0 = wait for every sweep; identical results), tuning knobs "mrf_xcd",
- * "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd", "prep_fused" (1 = luminance + Sobel in one pass through LDS,
- * the default; 0 = the two-pass kernels; identical output) */
+/* integer options: "stats" (0/1: fill the cull-reason counters of mvs_dc_stats; default 0), "count_rays" (0/1: node visits, triangles fetched
+ * and leaf rounds of the occlusion rays into mvs_dc_stats), "verbose" (0/1), "profile" (0/1), "info_wave_area" (sampled footprints above this
+ * many pixels are summed by a 16-lane group under an exactness certificate; default 32, 0 = every footprint in the reference's serial order;
+ * identical results), "max_labels" (label-space compression, 0 = off = the reference's model), "mrf_lag" (sweeps the host queues ahead of
+ * the energy reports it reads, default 1; identical results), "mrf_graph" (1 = the sweep loop is replayed from a hipGraph, the default;
+ * identical results), tuning knobs "mrf_xcd", "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd", "prep_fused" (1 = luminance +
+ * Sobel in one pass through LDS, the default; identical output), test hooks "info_cert_shift", "mrf_force_generic" */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 
 /* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,

@@ -228,13 +228,11 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "count_rays") ctx->count_rays = value != 0;
     else if (n == "stats") ctx->stats = value != 0;
-    else if (n == "lds_bvh_levels") ctx->lds_bvh_levels = (int)value;
     else if (n == "verbose") ctx->verbose = value != 0;
     else if (n == "info_wave_area") ctx->info_wave_area = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
     else if (n == "info_cert_shift") ctx->info_cert_shift = (int)std::max<int64_t>(0, std::min<int64_t>(value, 40));
     else if (n == "max_labels") { if (value < 0 || value > 65535) return fail(MVS_ERR_INVALID, "max_labels: 0 (off) .. 65535"); ctx->max_labels = (int)value; }
     else if (n == "profile") ctx->profile = value != 0;
-    else if (n == "ray_mode") ctx->ray_mode = (int)value;
     else if (n == "prep_fused") ctx->prep_fused = value != 0;
     else if (n == "ray_xcd") ctx->ray_xcd = (int)value;
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;

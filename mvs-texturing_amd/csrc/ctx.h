@@ -108,8 +108,6 @@ struct mvs_ctx {
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
-    int ray_mode = 3;        // 0 = one traversal per ray, 1 = shared traversal per wave (packet), 2 = packet + leaf work redistribution, 3 = 2 with the packed, sign-specialised slab test
-    int lds_bvh_levels = 0;
     int info_wave_area = 32;   // footprints (sampled ones) above this many pixels go to the wave-per-footprint kernel (k_dc.hip wave_info_kernel); 0 = every footprint serial = bit-exact with the reference's fp64 scan order
     int info_cert_shift = 0;   // test hook: widens the exactness certificate of wave_info_kernel by this many bits (forces its serial fallback)
     uint32_t dc_stats_deferred = 0;

@@ -315,314 +315,16 @@ __global__ void vf_fill_kernel(const uint32_t* __restrict__ faces, uint32_t n_fa
     vf[vf_ptr[v] + k] = i / 3;  // order within a vertex is irrelevant: only OR-ed
 }
 
-// ---- traversal ----
-// Slab test of one child box: t = (bound - o) * inv per axis (subtract first: bound * inv - o * inv would cancel
-// catastrophically for the nearby boxes that matter), interval [t0, t1] already widened by the caller.
-__device__ __forceinline__ bool box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 o, float t0, float t1) {
-    float ta = (lox - o.x) * inv.x, tb = (hix - o.x) * inv.x;
-    float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));   // fmin/fmax drop NaN (0 * inf)
-    ta = (loy - o.y) * inv.y; tb = (hiy - o.y) * inv.y;
-    tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-    ta = (loz - o.z) * inv.z; tb = (hiz - o.z) * inv.z;
-    tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-    return tn <= tf;
-}
-__device__ __forceinline__ uint32_t node_hits(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1) {
-    // 6 x 16-byte loads of one 128-byte line
-    const float4* p = reinterpret_cast<const float4*>(nd);
-    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
-    const uint32_t nchild = nd->nchild;
-    const V3 oi = o;
-    uint32_t m = 0;
-    if (box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oi, t0, t1)) m |= 1u;
-    if (box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oi, t0, t1)) m |= 2u;
-    if (box_hit(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, inv, oi, t0, t1)) m |= 4u;
-    if (box_hit(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, inv, oi, t0, t1)) m |= 8u;
-    return m & ((1u << nchild) - 1u);
-}
-
-__device__ __forceinline__ bool tri_pre_hit(const float4* __restrict__ tris, uint32_t t, const Ray& r) {
-    const float4* p = tris + TRI_F4 * (size_t)t;
-    return tri_hit(p[0], p[1], p[2], p[3], r);
-}
-
-template <bool COUNT>
-__device__ __forceinline__ bool any_hit(const BvhDev& bvh, const Ray& r, uint32_t& n_nodes, uint32_t& n_tris) {
-    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
-    int level = bvh.top;
-    uint32_t node = 0;
-    unsigned long long masks = (unsigned long long)node_hits(bvh.nodes + bvh.level_off[level], r.o, inv, t0, t1) << (4 * level);
-    if (COUNT) n_nodes++;
-    while (true) {
-        const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
-        if (m == 0) {
-            if (level == bvh.top) return false;
-            ++level; node >>= 2;
-            continue;
-        }
-        const int c = __builtin_ctz(m);
-        masks &= ~(1ull << (4 * level + c));
-        const uint32_t child = node * 4 + c;
-        if (level == 0) {
-#pragma unroll
-            for (uint32_t k = 0; k < LEAF_T; ++k) {
-                if (COUNT) n_tris++;
-                if (tri_pre_hit(bvh.tris, child * LEAF_T + k, r)) return true;
-            }
-        } else {
-            --level; node = child;
-            masks |= (unsigned long long)node_hits(bvh.nodes + bvh.level_off[level] + node, r.o, inv, t0, t1) << (4 * level);
-            if (COUNT) n_nodes++;
-        }
-    }
-}
-
-// one wave per (view, 64-vertex word); lanes whose need bit is clear idle
-template <bool COUNT>
-__global__ void __launch_bounds__(256) ray_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
-                                                  const ViewParams* __restrict__ views,
-                                                  const unsigned long long* __restrict__ need, unsigned long long* __restrict__ occl,
-                                                  uint32_t vwords, uint32_t n_verts, uint32_t n_views, const uint32_t* __restrict__ scene_box,
-                                                  unsigned long long* __restrict__ counters) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (wave >= (uint64_t)vwords * n_views) return;
-    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);   // view-major: needed patches form long runs (measured: patch-major is 40 % slower)
-    const unsigned long long word = need[(size_t)j * vwords + vw];
-    if (word == 0ull) return;  // occl is pre-zeroed
-    const uint32_t sp = vw * 64 + lane;
-    bool hit = false;
-    uint32_t nn = 0, nt = 0;
-    if (((word >> lane) & 1ull) && sp < n_verts) {
-        const uint32_t v = vperm[sp];
-        const ViewParams& vp = views[j];
-        const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
-        const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad_from_box(scene_box));
-        hit = any_hit<COUNT>(bvh, r, nn, nt);
-    }
-    const unsigned long long b = __ballot(hit);
-    if (lane == 0) occl[(size_t)j * vwords + vw] = b;
-    if (COUNT) {
-        for (int o = 32; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, 64); nt += __shfl_xor(nt, o, 64); }
-        if (lane == 0) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
-    }
-}
-
-// ---- packet traversal: one wave = 64 nearly parallel rays sharing ONE traversal ----
-// A node is visited when ANY still-active lane hits its box, so node and triangle addresses are
-// wave-uniform (scalar / broadcast loads instead of 64 divergent gathers).  Lanes test every
-// triangle of a visited leaf; testing a superset of triangles cannot change an any-hit result
-// (the predicate is exact per triangle), so the booleans equal the per-ray traversal's.
-__device__ __forceinline__ uint32_t node_hits_uniform(const Node4* __restrict__ nd, V3 o, V3 inv, float t0, float t1, bool active) {
-    uint32_t m = 0;
-    const uint32_t nchild = nd->nchild;
-    const V3 oi = o;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const bool h = box_hit(nd->lo(0, c), nd->lo(1, c), nd->lo(2, c), nd->hi(0, c), nd->hi(1, c), nd->hi(2, c), inv, oi, t0, t1);
-        if (__ballot(active && h) != 0ull) m |= 1u << c;
-    }
-    return m & ((1u << nchild) - 1u);
-}
-
-template <bool COUNT>
-__global__ void __launch_bounds__(256) ray_packet_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
-                                                         const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
-                                                         unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
-                                                         const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (wave >= (uint64_t)vwords * n_views) return;
-    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);   // view-major: needed patches form long runs (measured: patch-major is 40 % slower)
-    const unsigned long long word = need[(size_t)j * vwords + vw];
-    if (word == 0ull) return;  // occl is pre-zeroed
-    const uint32_t s = vw * 64 + lane;
-    bool active = ((word >> lane) & 1ull) && s < n_verts;
-    const uint32_t v = vperm[s < n_verts ? s : 0];
-    const ViewParams& vp = views[j];
-    const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
-    const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad_from_box(scene_box));
-    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
-    bool hit = false;
-    uint32_t nn = 0, nt = 0;
-    int level = bvh.top;
-    uint32_t node = 0;
-    unsigned long long masks = (unsigned long long)node_hits_uniform(bvh.nodes + bvh.level_off[level], r.o, inv, t0, t1, active) << (4 * level);
-    if (COUNT) nn++;
-    while (true) {
-        const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
-        if (m == 0) {
-            if (level == bvh.top) break;
-            ++level; node >>= 2;
-            continue;
-        }
-        const int c = __builtin_ctz(m);
-        masks &= ~(1ull << (4 * level + c));
-        const uint32_t child = node * 4 + c;   // wave-uniform
-        if (level == 0) {
-            const float4* __restrict__ tp = bvh.tris + TRI_F4 * (size_t)(child * LEAF_T);
-#pragma unroll
-            for (uint32_t k = 0; k < LEAF_T; ++k) {
-                if (active && tri_hit(tp[TRI_F4 * k], tp[TRI_F4 * k + 1], tp[TRI_F4 * k + 2], tp[TRI_F4 * k + 3], r)) hit = true;
-            }
-            if (COUNT) nt += LEAF_T;
-            active = active && !hit;
-            if (__ballot(active) == 0ull) break;
-        } else {
-            --level; node = child;
-            masks |= (unsigned long long)node_hits_uniform(bvh.nodes + bvh.level_off[level] + node, r.o, inv, t0, t1, active) << (4 * level);
-            if (COUNT) nn++;
-        }
-    }
-    const unsigned long long b = __ballot(hit);
-    if (lane == 0) {
-        occl[(size_t)j * vwords + vw] = b;
-        if (COUNT) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
-    }
-}
-
-// ---- packet traversal with leaf work redistribution (ray_mode 2) ----
-// Same shared traversal, but at a leaf only the lanes whose OWN ray hits the leaf box are candidates
-// (5-6 of 64 on average), so instead of 64 lanes x 4 triangles the wave tests (candidate, triangle)
-// PAIRS: lane L takes candidate L/4 and triangle L%4 (16 candidates per round).  Rays are parked in
-// LDS once; the candidate list goes through LDS; results return to the owning lanes through a ballot.
-// LDSN (mvs_set_option "lds_bvh_levels" > 0): the top levels of the tree (heap order: the first n_lds nodes) are staged in LDS by
-// every block and read from there.  Measured A/B at BASELINE config 3 (profiles/r02_lds_bvh_ab.txt): NOT faster -- a node read
-// from LDS lands in 32 VGPRs of every lane and is consumed as vector operands, whereas the default reads the node with two
-// wide scalar loads into SGPRs (served by the scalar cache, which the top levels never leave) and feeds the fma's scalar
-// operands.  Kept as an option for the record; the default is 0.
-template <bool COUNT, bool XCD, bool LDSN>
-__global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
-                                                          const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
-                                                          unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
-                                                          const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters, uint32_t n_lds) {
-    __shared__ float4 s_ray[4][64][2];
-    __shared__ uint8_t s_src[4][64];
-    extern __shared__ float4 s_top4[];
-    if (LDSN) {
-        for (uint32_t k = threadIdx.x; k < n_lds * 8u; k += 256u) s_top4[k] = reinterpret_cast<const float4*>(bvh.nodes)[k];
-        __syncthreads();
-    }
-    const Node4* s_top = reinterpret_cast<const Node4*>(s_top4);
-    // XCD-aware order: hardware block b runs on XCD b % 8 (observed; speed only), so each XCD gets a contiguous
-    // eighth of the (view, vertex patch) sequence and with it a compact part of the BVH in its L2
-    uint32_t vblk = blockIdx.x;
-    if (XCD && (gridDim.x & 7u) == 0u) vblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint64_t wave = ((uint64_t)vblk * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (wave >= (uint64_t)vwords * n_views) return;
-    const uint32_t j = (uint32_t)(wave / vwords), vw = (uint32_t)(wave % vwords);   // view-major: needed patches form long runs (measured: patch-major is 40 % slower)
-    const unsigned long long word = need[(size_t)j * vwords + vw];
-    if (word == 0ull) return;  // occl is pre-zeroed
-    const uint32_t s = vw * 64 + lane;
-    const bool active = ((word >> lane) & 1ull) && s < n_verts;
-    const uint32_t v = vperm[s < n_verts ? s : 0];
-    const ViewParams& vp = views[j];
-    const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
-    const float pad = pad_from_box(scene_box);
-    const Ray r = make_ray(o, V3{vp.pos[0], vp.pos[1], vp.pos[2]}, pad);
-    s_ray[wv][lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.tmin);
-    s_ray[wv][lane][1] = make_float4(r.d.x, r.d.y, r.d.z, r.tmax);
-    const V3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
-    const V3 oi = {r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z};
-    const float t0 = r.tmin * 0.999f, t1 = r.tmax * 1.001f;
-    uint32_t nn = 0, nt = 0;
-    int level = bvh.top;
-    // The kernel is VALU bound (SQ_ACTIVE_INST_VALU = 98 % of the SIMD cycles at C3), so everything that is the same for
-    // the whole wave lives in SGPRs: the set of live rays (actm) and of occluded rays (hitm) are 64-bit scalars, the four
-    // per-child hit ballots of a node ARE the per-lane hit bits (bit L = lane L; hm0: those of the current level-0 node,
-    // whose children are the leaves), a scalar mask becomes an execution mask again through inverse_ballot, ranks come
-    // from v_mbcnt on the scalar mask.  A ballot of a bare float compare is the compare itself (it writes an SGPR pair).
-    unsigned long long actm = __builtin_amdgcn_ballot_w64(active), hitm = 0ull;
-    unsigned long long hm0[4] = {0ull, 0ull, 0ull, 0ull};
-    auto visit = [&](uint32_t nidx, unsigned long long (&hm)[4]) -> uint32_t {
-        uint32_t m = 0;
-        Node4 ndv;
-        if (LDSN && nidx < n_lds) ndv = s_top[nidx];   // wave-uniform branch
-        else ndv = bvh.nodes[nidx];                    // the whole 128-byte line with two wide scalar loads
-        const Node4* nd = &ndv;
-        const uint32_t nchild = nd->nchild;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            // t = bound * inv - o * inv as ONE fma (the product is exact inside it; oi is rounded once per ray): 12 instead of
-            // 24 VALU operations per child.  Its absolute error, ulp(o * inv) <= 6e-8 |o| |inv|, is 400 times smaller than
-            // the margin the boxes carry for exactly this purpose (a hit point lies >= 3 pad = 3e-5 max|coord| inside its leaf
-            // box, i.e. 3 pad |inv| inside the slab), so the test stays conservative; inf - inf = NaN drops the axis (fmin/fmax).
-            float ta = __builtin_fmaf(nd->lo(0, c), inv.x, -oi.x), tb = __builtin_fmaf(nd->hi(0, c), inv.x, -oi.x);
-            float tn = fmaxf(t0, fminf(ta, tb)), tf = fminf(t1, fmaxf(ta, tb));
-            ta = __builtin_fmaf(nd->lo(1, c), inv.y, -oi.y); tb = __builtin_fmaf(nd->hi(1, c), inv.y, -oi.y);
-            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            ta = __builtin_fmaf(nd->lo(2, c), inv.z, -oi.z); tb = __builtin_fmaf(nd->hi(2, c), inv.z, -oi.z);
-            tn = fmaxf(tn, fminf(ta, tb)); tf = fminf(tf, fmaxf(ta, tb));
-            hm[c] = __builtin_amdgcn_ballot_w64(tn <= tf) & actm;
-            if (hm[c] != 0ull) m |= 1u << c;
-        }
-        return m & ((1u << nchild) - 1u);
-    };
-    unsigned long long hm_tmp[4];
-    unsigned long long masks;
-    const uint32_t off0 = bvh.level_off[0];   // heap index of the first level-0 node
-    uint32_t node = 1;   // heap index, root = 1 (see build_bvh)
-    if (level == 0) masks = (unsigned long long)visit(1u, hm0);
-    else masks = (unsigned long long)visit(1u, hm_tmp) << (4 * level);
-    if (COUNT) nn++;
-    while (true) {
-        const uint32_t m = (uint32_t)(masks >> (4 * level)) & 0xFu;
-        if (m == 0) {
-            if (level == bvh.top) break;
-            ++level; node >>= 2;
-            continue;
-        }
-        const int c = __builtin_ctz(m);
-        masks &= ~(1ull << (4 * level + c));
-        if (level == 0) {
-            const uint32_t child = (node - off0) * 4 + c;   // leaf index, wave-uniform
-            const unsigned long long hsel = (c == 0) ? hm0[0] : (c == 1) ? hm0[1] : (c == 2) ? hm0[2] : hm0[3];
-            const unsigned long long cb = hsel & actm;          // rays that are still live and enter this leaf's box
-            if (cb != 0ull) {
-                const bool cand = __builtin_amdgcn_inverse_ballot_w64(cb);
-                const int n = __builtin_popcountll(cb);
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
-                if (cand) s_src[wv][rank] = (uint8_t)lane;
-                const float4* __restrict__ tp = bvh.tris + TRI_F4 * (size_t)(child * LEAF_T + ((uint32_t)lane & (LEAF_T - 1u)));
-                const float4 A = tp[0], E1 = tp[1], E2 = tp[2], H = tp[3];
-                for (int base = 0; base < n; base += LEAF_SLOTS) {
-                    const int q = base + lane / (int)LEAF_T;
-                    const bool valid = q < n;
-                    const int sl = valid ? (int)s_src[wv][q] : lane;
-                    const float4 r0 = s_ray[wv][sl][0], r1 = s_ray[wv][sl][1];
-                    Ray rr; rr.o = V3{r0.x, r0.y, r0.z}; rr.tmin = r0.w; rr.d = V3{r1.x, r1.y, r1.z}; rr.tmax = r1.w; rr.pad = pad;
-                    const bool h = valid && tri_hit(A, E1, E2, H, rr);
-                    const unsigned long long hb = __builtin_amdgcn_ballot_w64(h);
-                    if (hb != 0ull) {   // wave-uniform and rare (hits are rare): the owner of slot (rank - base) reads its LEAF_T result bits
-                        const bool mine = cand && rank >= base && rank < base + LEAF_SLOTS &&
-                                          ((hb >> ((int)LEAF_T * (rank - base))) & ((1ull << LEAF_T) - 1ull)) != 0ull;
-                        hitm |= __builtin_amdgcn_ballot_w64(mine);
-                    }
-                    if (COUNT) nt += 1;
-                }
-                actm &= ~hitm;
-                if (actm == 0ull) break;
-            }
-        } else {
-            --level; node = node * 4 + c;
-            if (level == 0) masks |= (unsigned long long)visit(node, hm0);
-            else masks |= (unsigned long long)visit(node, hm_tmp) << (4 * level);
-            if (COUNT) nn++;
-        }
-    }
-    if (lane == 0) {
-        occl[(size_t)j * vwords + vw] = hitm;
-        if (COUNT) { atomicAdd(&counters[8], (unsigned long long)nn); atomicAdd(&counters[9], (unsigned long long)nt); }
-    }
-}
-
-
-// ---- packet traversal, round 3 (ray_mode 3, the default) ----
-// The same shared traversal, leaf redistribution and predicate as ray_packet2_kernel -- identical booleans -- with the
-// instruction count of a node visit cut by more than half (the kernel is issue bound on BOTH the vector and the scalar port):
+// ---- traversal: one wave = 64 rays from one surface patch to one camera sharing ONE traversal ----
+// The 64 rays of a wave (64 vertices consecutive on the Hilbert curve, one view) walk the tree together: a node is visited when
+// ANY live ray enters its box, so the node is one wave-uniform fetch (two wide scalar loads of the 128-byte line) and the child
+// boxes are tested by all lanes at once.  At a leaf only the rays that enter the leaf's box are candidates (5 - 6 of 64), so the
+// wave tests (candidate, triangle) PAIRS: a round = 4 candidates x 16 triangles, one pair per lane, rays parked in LDS, the
+// candidate list through LDS, results back to the owning lanes through ballots.  The occlusion predicate is the OR over all
+// triangles (dmath.h ray_tri: conservative box clause), so the booleans do not depend on the traversal -- the oracle's BVH and its
+// brute force give the same bits.  Earlier traversals of this file (one per ray; shared without redistribution; round 2 of this
+// one; top levels in LDS) are in the history -- profiles/r02_lds_bvh_ab.txt and DESIGN.md record what they measured.
+// Instruction diet of a node visit (the kernel had been issue bound on both ports):
 //  * slab test with packed math: a child's six bounds are three aligned SGPR pairs, so the six t = bound * inv - o * inv
 //    are three v_pk_fma_f32 (full rate with a scalar-pair operand on gfx950: scripts/probe/pk_probe.hip);
 //  * direction-sign specialisation: all rays of a packet go from one surface patch to one camera, so nearly always every
@@ -630,12 +332,13 @@ __global__ void __launch_bounds__(256) ray_packet2_kernel(const BvhDev bvh, cons
 //    d.x > 0 else hi.x -- and min / max per axis disappear: tn = max(max3(near), t0), tf = min(min3(far), t1), 5 instead of
 //    13 instructions per child after the fma's.  fma is monotone in the bound for a fixed finite multiplier, so
 //    min(t_lo, t_hi) IS t_near bit for bit: the hit masks equal the generic test's.  Packets with mixed signs, zero or
-//    tiny direction components (|1/d| >= 1e30 or non-finite) take the generic variant OCT = 8, which is the round-2 test;
+//    tiny direction components (|1/d| >= 1e30 or non-finite) take the generic variant OCT = 8 (fmin / fmax per axis);
 //  * no per-level climbing: the pending-children nibbles of all levels sit in one 64-bit mask, s_ff1 finds the deepest
 //    pending child, the ancestor's position in its level is a shift (heap order: node = (4^depth - 1) / 3 + position);
-//  * a level-0 node's leaves are processed right after its visit, from the hit ballots still in registers -- nothing
-//    per-node is carried around the loop (round 2 copied four 64-bit masks through every iteration);
+//  * a level-0 node's leaves are processed right after its visit, from the hit ballots still in registers;
 //  * absent children are far-away points (build kernels), so the child-count mask is not needed.
+// COUNT (option "count_rays"): node visits, leaf visits and leaf rounds of the launch -- the N_ray_nodes / N_ray_tris of the
+// roofline accounting -- at the price of three atomics per wave.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // m = 2 m + (mask != 0): shifts the "some live ray enters child c" bit into the child mask with two scalar instructions
@@ -648,10 +351,10 @@ __device__ __forceinline__ unsigned long long clear_bit(unsigned long long x, ui
     return x;
 }
 
-template <int OCT>
+template <int OCT, bool COUNT>
 __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4 (*s_ray)[2], uint8_t* s_src, const int lane, const float pad,
                                                  const V3 inv, const V3 oi, const float t0, float t1,
-                                                 unsigned long long& actm) {   // in: live rays; out: live rays never occluded
+                                                 unsigned long long& actm /* in: live rays; out: live rays never occluded */, uint32_t (&cnt)[3] /* node visits, leaf visits, rounds */) {
     constexpr bool SX = (OCT & 1) != 0, SY = (OCT & 2) != 0, SZ = (OCT & 4) != 0, GEN = OCT >= 8;
     const f2 I0 = {inv.x, inv.y}, I1 = {inv.z, inv.x}, I2 = {inv.y, inv.z};
     const f2 O0 = {-oi.x, -oi.y}, O1 = {-oi.z, -oi.x}, O2 = {-oi.y, -oi.z};
@@ -661,6 +364,7 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
     t1 = __builtin_amdgcn_inverse_ballot_w64(actm) ? t1 : -1.0f;
     unsigned long long hm0 = 0ull, hm1 = 0ull, hm2 = 0ull, hm3 = 0ull;   // separate scalars, never an indexed array (that would live in scratch)
     auto visit = [&](uint32_t h) -> uint32_t {   // h wave-uniform: the 96 bytes of bounds arrive with two wide scalar loads
+        if (COUNT) ++cnt[0];
         const Node4 nd = *reinterpret_cast<const Node4*>(reinterpret_cast<const char*>(nodes) + (h << 7));   // 32-bit byte offset (build_bvh bounds h): base + offset addressing
         uint32_t m = 0;
 #pragma unroll
@@ -708,6 +412,7 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
                 const float4* __restrict__ tp = bvh.tris + TRI_F4 * (size_t)((leaf0 + c) * LEAF_T + ((uint32_t)lane & (LEAF_T - 1u)));
                 const float4 A = tp[0], E1 = tp[1], E2 = tp[2], H = tp[3];
                 unsigned long long hitm = 0ull;
+                if (COUNT) { ++cnt[1]; cnt[2] += (uint32_t)((n + LEAF_SLOTS - 1) / LEAF_SLOTS); }
                 for (int base = 0; base < n; base += LEAF_SLOTS) {
                     const int q = base + lane / (int)LEAF_T;     // slots >= n hold lane numbers of earlier lists (or the initial ones): harmless work, masked below
                     const int sl = (int)s_src[q];
@@ -748,18 +453,21 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
     } while (masks != 0ull);
 }
 
-// amdgpu_num_sgpr(80): a 256-thread block is admitted per CU up to floor(800 / (ceil16(sgpr) + 16)) times (MI355X_MICROARCH.md
-// "Residency"): the 98 SGPRs the compiler takes by itself allow 6 blocks, 80 allow 7 (the VGPRs then stop at 7 waves per SIMD).  The
-// kernel is a chain of dependent node and triangle fetches per wave -- PMC: vector issue 41 %, waves parked on memory 46 % of their
-// time -- so residency is throughput: 6.63 -> 6.33 ms at BASELINE config 3 (A/B of two builds on one box, scripts/ab_libs.py).
-template <bool XCD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
+// Residency: a 256-thread block is admitted per CU up to floor(800 / (ceil16(sgpr) + 16)) times (MI355X_MICROARCH.md "Residency").  The 98
+// SGPRs the compiler takes by itself allow 6 blocks; amdgpu_num_sgpr(80) allows 8, and __launch_bounds__(256, 8) keeps the VGPRs at
+// the 64 that 8 waves per SIMD leave (no spills).  The kernel is a chain of dependent node and triangle fetches per wave -- PMC
+// (profiles/r03a_pmc_sq_c3.json): vector issue 41 %, waves parked on memory 46 % of their time -- so residency is throughput:
+// 6.63 -> 6.33 (7 blocks) -> 6.02 ms (8 blocks) at BASELINE config 3, A/B of builds on one box (scripts/ab_libs.py).
+template <bool XCD, bool COUNT>
+__global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
                                                           const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
                                                           unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
                                                           const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
     __shared__ float4 s_ray[4][64][2];
     __shared__ uint8_t s_src[4][80];   // candidate lists; a round reads up to LEAF_SLOTS - 1 slots past the list
-    uint32_t vblk = blockIdx.x;   // XCD-aware order, see ray_packet2_kernel
+    // XCD-aware order: blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2; with this map every
+    // XCD walks a contiguous eighth of the (view, patch) sequence, so neighbouring packets -- which visit the same nodes -- share an L2
+    uint32_t vblk = blockIdx.x;
     if (XCD && (gridDim.x & 7u) == 0u) vblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const uint64_t wave = ((uint64_t)vblk * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -791,7 +499,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) ray_
     if (okm == actm && (nxm == 0ull || nxm == actm) && (nym == 0ull || nym == actm) && (nzm == 0ull || nzm == actm))
         oct = (nxm ? 1 : 0) | (nym ? 2 : 0) | (nzm ? 4 : 0);
     if (counters && lane == 0) { atomicAdd(&counters[10], 1ull); if (oct == 8) atomicAdd(&counters[11], 1ull); }   // diagnostics ("stats" option)
-#define MVS_P3(O) packet3_traverse<O>(bvh, s_ray[wv], s_src[wv], lane, pad, inv, oi, t0, t1, live)
+    uint32_t cnt[3] = {0u, 0u, 0u};
+#define MVS_P3(O) packet3_traverse<O, COUNT>(bvh, s_ray[wv], s_src[wv], lane, pad, inv, oi, t0, t1, live, cnt)
     switch (oct) {
         case 0: MVS_P3(0); break; case 1: MVS_P3(1); break; case 2: MVS_P3(2); break; case 3: MVS_P3(3); break;
         case 4: MVS_P3(4); break; case 5: MVS_P3(5); break; case 6: MVS_P3(6); break; case 7: MVS_P3(7); break;
@@ -799,6 +508,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) ray_
     }
 #undef MVS_P3
     if (lane == 0) occl[(size_t)j * vwords + vw] = actm & ~live;
+    if (COUNT && lane == 0) { atomicAdd(&counters[8], (unsigned long long)cnt[0]); atomicAdd(&counters[9], (unsigned long long)cnt[1]); atomicAdd(&counters[13], (unsigned long long)cnt[2]); }
 }
 
 }  // namespace
@@ -888,35 +598,13 @@ void trace_rays(mvs_ctx* ctx) {
     const uint32_t vwords = (ctx->n_verts + 63) / 64;
     const uint64_t waves = (uint64_t)vwords * ctx->n_views;
     uint64_t blocks = (waves + 3) / 4;
-    if (ctx->ray_mode >= 2) blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
+    blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
     if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
+    unsigned long long* counters = (ctx->stats || ctx->count_rays) ? ctx->counters.p : nullptr;
 #define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
-                 vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p
-    if (ctx->ray_mode == 3 && !ctx->count_rays && ctx->lds_bvh_levels <= 0) {
-        blocks = (blocks + 7) & ~7ull;
-        if (ctx->ray_xcd) hipLaunchKernelGGL(ray_packet3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p,
-                                             ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->stats ? ctx->counters.p : nullptr);
-        else hipLaunchKernelGGL(ray_packet3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p,
-                                ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->stats ? ctx->counters.p : nullptr);
-    } else if (ctx->ray_mode >= 2) {
-        // top levels in LDS (option, default off): levels counted from the root; at most what 48 KB hold, never the leaves' parents' level and below
-        uint32_t n_lds = 0;
-        if (ctx->lds_bvh_levels > 0) {
-            const int lv = std::min(std::min(ctx->lds_bvh_levels, 4), (int)ctx->bvh.top);
-            uint32_t w = 1; for (int l = 1; l < lv; ++l) w *= 4;
-            n_lds = 2 * w;   // heap indices below 2 * 4^(lv - 1) hold the lv levels from the root (root = index 1)
-        }
-        const size_t lds = (size_t)n_lds * sizeof(Node4);
-        if (ctx->count_rays) hipLaunchKernelGGL((ray_packet2_kernel<true, false, false>), RAY_ARGS, 0u);
-        else if (n_lds) hipLaunchKernelGGL((ray_packet2_kernel<false, true, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p,
-                                           ctx->need_bits.p, ctx->occl_bits.p, vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, ctx->counters.p, n_lds);
-        else if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet2_kernel<false, true, false>), RAY_ARGS, 0u);
-        else hipLaunchKernelGGL((ray_packet2_kernel<false, false, false>), RAY_ARGS, 0u);
-    } else if (ctx->ray_mode == 1) {
-        if (ctx->count_rays) hipLaunchKernelGGL(ray_packet_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_packet_kernel<false>, RAY_ARGS);
-    } else {
-        if (ctx->count_rays) hipLaunchKernelGGL(ray_kernel<true>, RAY_ARGS); else hipLaunchKernelGGL(ray_kernel<false>, RAY_ARGS);
-    }
+                 vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, counters
+    if (ctx->count_rays) { if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet3_kernel<true, true>), RAY_ARGS); else hipLaunchKernelGGL((ray_packet3_kernel<false, true>), RAY_ARGS); }
+    else { if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet3_kernel<true, false>), RAY_ARGS); else hipLaunchKernelGGL((ray_packet3_kernel<false, false>), RAY_ARGS); }
 #undef RAY_ARGS
     MVS_LAUNCH_CHECK();
 }

@@ -1105,7 +1105,7 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     float mq, pc; { const uint32_t a = (uint32_t)hc[14], b = (uint32_t)hc[15]; memcpy(&mq, &a, 4); memcpy(&pc, &b, 4); }
     mvs_dc_stats& S = ctx->dc_stats;
     S.cull_backface = hc[C_BACK]; S.cull_angle = hc[C_ANGLE]; S.cull_outside = hc[C_OUTSIDE]; S.cull_occluded = hc[C_OCCL];
-    S.cull_zero_quality = hc[C_ZEROQ]; S.rays = hc[C_RAYS]; S.ray_nodes = hc[C_RNODES]; S.ray_tris = hc[C_RTRIS];
+    S.cull_zero_quality = hc[C_ZEROQ]; S.rays = hc[C_RAYS]; S.ray_nodes = hc[C_RNODES]; S.ray_tris = hc[C_RTRIS] * 16ull /* leaf visits -> triangles: 16 per leaf (k_bvh.hip MVS_LEAF_T) */; S.ray_leaf_rounds = hc[13];
     S.ray_packets = hc[10]; S.ray_packets_generic = hc[11]; S.footprints_lane_group = ctx->dc_stats_deferred; S.footprints_rewalked = hc[C_REWALK];
     S.nnz = ctx->csr_nnz; S.max_quality = mq; S.percentile = pc;
     ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p; ctx->csr_q_valid = true;

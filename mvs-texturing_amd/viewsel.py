@@ -74,7 +74,7 @@ class Subgraphs(C.Structure):
 class DcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("pairs", "cull_backface", "cull_angle", "cull_outside", "cull_occluded",
                                            "cull_zero_quality", "nnz_pre", "nnz", "rays", "ray_nodes", "ray_tris", "ray_packets", "ray_packets_generic")] + \
-               [("max_quality", C.c_float), ("percentile", C.c_float), ("footprints_lane_group", C.c_uint64), ("footprints_rewalked", C.c_uint64)]
+               [("max_quality", C.c_float), ("percentile", C.c_float), ("footprints_lane_group", C.c_uint64), ("footprints_rewalked", C.c_uint64), ("ray_leaf_rounds", C.c_uint64)]
 
 
 def _stats_dict(s):

@@ -215,33 +215,38 @@ def test_fused_image_prep_equals_the_two_pass_kernels_and_the_oracle():
     assert np.array_equal(tables[0].cost.view(np.uint32), tables[1].cost.view(np.uint32))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_ray_traversal_modes_give_the_oracle_booleans(mode):
-    """per-ray traversal, shared (packet) traversal, packet + leaf work redistribution, and the latter with the packed,
-    direction-sign-specialised slab test (the default): same occlusion decisions"""
+def test_packet_traversal_gives_the_oracle_booleans_and_counts_its_work():
+    """the 64-ray packet traversal (k_bvh.hip): same occlusion decisions as the oracle (whose BVH equals its own brute-force loop);
+    both slab tests ran -- direction-sign-specialised packets and packets with mixed signs; the counting build ("count_rays": node
+    visits, triangles fetched, leaf rounds for the roofline accounting) gives the same table"""
     s = get_scene("bumpy")
     ref, rst = O.data_costs(s)
-    c = M.Context(0); c.set_option("stats", 1); c.set_option("ray_mode", mode)
+    c = M.Context(0); c.set_option("stats", 1)
     _load_scene(c, s)
-    st = c.data_costs(M.Settings())
-    got = c.costs_download()
-    assert st["cull_occluded"] == rst["cull_occluded"] > 0
-    assert np.array_equal(got.col_ptr, ref.col_ptr) and np.array_equal(got.cost.view(np.uint32), ref.cost.view(np.uint32))
-    if mode == 3:   # both slab tests ran: sign-specialised packets and packets with mixed direction signs
+    for count in (0, 1):
+        c.set_option("count_rays", count)
+        st = c.data_costs(M.Settings())
+        got = c.costs_download()
+        assert st["cull_occluded"] == rst["cull_occluded"] > 0
+        assert np.array_equal(got.col_ptr, ref.col_ptr) and np.array_equal(got.cost.view(np.uint32), ref.cost.view(np.uint32))
         assert 0 < st["ray_packets_generic"] < st["ray_packets"]
+        if count:
+            assert st["ray_nodes"] >= st["ray_packets"] and st["ray_tris"] % 16 == 0 and st["ray_leaf_rounds"] * 16 >= st["ray_tris"] > 0, st
+        else:
+            assert st["ray_nodes"] == 0 and st["ray_tris"] == 0
     c.close()
 
 
 @pytest.mark.parametrize("name", ["spiky", "spiky32"])
 def test_heavy_occlusion_against_live_oracle(name):
     """strongly displaced surfaces (40 % of the candidate pairs occluded, rays grazing silhouettes, 20 480 triangles = 40
-    refinement windows and one more BVH level than the other scenes): the occlusion decisions of the packet traversal and
-    of the per-ray traversal equal the oracle's, whose BVH equals its own brute-force loop (tests/test_oracle.py)"""
+    refinement windows and one more BVH level than the other scenes): the occlusion decisions of the packet traversal equal the
+    oracle's, whose BVH equals its own brute-force loop (tests/test_oracle.py)"""
     s = get_scene(name)
     ref, rst = O.data_costs(s)
     assert rst["cull_occluded"] * 3 > ref.nnz
-    for mode in (3, 2, 0):
-        c = M.Context(0); c.set_option("stats", 1); c.set_option("ray_mode", mode)
+    for xcd in (1, 0):   # with and without the XCD-aware block order
+        c = M.Context(0); c.set_option("stats", 1); c.set_option("ray_xcd", xcd)
         _load_scene(c, s)
         st = c.data_costs(M.Settings())
         got = c.costs_download()
@@ -848,7 +853,7 @@ _real_cache = {}
 def test_real_like_scene_equals_the_oracle(kw):
     """the second workload of bench.py (synth.CONFIGS["real"]: 200 000 faces x 200 cropped views 2048x1536, bumps of 0.45 radii --
     31 % of the candidate pairs occluded, footprints of 50 - 4000 pixels, K = 14.6) at full size with the LIBRARY DEFAULTS
-    (lane-group footprint sampler, ray_mode 3): the regime where rays decide a third of the pairs and where almost every footprint
+    (lane-group footprint sampler, packet traversal): the regime where rays decide a third of the pairs and where almost every footprint
     takes the lane-group sampler.  Pattern, view ids, cull counters, qualities and costs bit for bit; labels, fixed-point energy,
     sweeps and ICM rounds of the GPU solver equal the oracle's.  References: texture_view.cpp:183-219,
     calculate_data_costs.cpp:194-222."""
@@ -1116,8 +1121,9 @@ def test_config3_full_size_properties():
     pct = np.float32(O.load().orc_percentile(dc.quality.ctypes.data, dc.nnz, C.c_float(st["max_quality"]), C.c_float(0.995)))
     assert np.float32(st["percentile"]) == pct
     assert np.array_equal(dc.cost.view(np.uint32), (np.float32(1.0) - np.minimum(np.float32(1.0), dc.quality / pct)).view(np.uint32))
-    c.set_option("ray_mode", 0)
+    c.set_option("count_rays", 1)
     st0 = c.data_costs(M.Settings()); dc0 = c.costs_download()
+    c.set_option("count_rays", 0)
     assert st0["cull_occluded"] == st["cull_occluded"] and np.array_equal(dc0.col_ptr, dc.col_ptr) and np.array_equal(dc0.cost.view(np.uint32), dc.cost.view(np.uint32))
     del dc0
     labels, ms = c.view_selection(s.adj_ptr, s.adj)
