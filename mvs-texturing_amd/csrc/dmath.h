@@ -93,10 +93,35 @@ MVS_HD bool valid_pixel(const ViewParams& v, V2 px) {
 // smallest float c with !(acosf(c) > 75 deg), found on the host with the host's
 // acosf, so `viewing_angle < cos_limit` decides identically (acosf is monotone).
 // the last cull (calculate_data_costs.cpp:191): all three vertices project onto valid pixels
+// valid_pixel of the three vertices at once, branch free: the reference's short-circuit chain (three vertices x four mask bits, each
+// read only if everything before it held) is twelve DEPENDENT memory latencies per (face, view) pair on the GPU -- the culls kernel
+// spent 72 % of its wave cycles parked on them (profiles/r03a_pmc_sq_c3.json).  Here the three range tests come first, then all
+// twelve mask words are requested together and ANDed: one latency.  Same boolean: a conjunction does not depend on the order of its
+// terms; for a position inside the range the reference's clamps are identities, and a position outside it (the result is false
+// already; the coordinate may be inf / NaN) reads pixel (0, 0) instead of being converted to an integer.
+MVS_HD bool valid_pixels3(const ViewParams& v, V2 a, V2 b, V2 c) {
+    const int width = v.width, height = v.height;
+    const float wm = (float)(width - 1), hm = (float)(height - 1);
+    const V2 p[3] = {a, b, c};
+    bool in[3];
+    for (int k = 0; k < 3; ++k) in[k] = (p[k].x >= 0.0f && p[k].x < wm && p[k].y >= 0.0f && p[k].y < hm);
+    bool valid = in[0] && in[1] && in[2];
+    if (v.mask) {
+        uint32_t bits = 1u;
+        for (int k = 0; k < 3; ++k) {
+            const float x = in[k] ? p[k].x : 0.0f, y = in[k] ? p[k].y : 0.0f;
+            const int fx = (int)x, fy = (int)y;
+            const int fx1 = imin(fx + 1, width - 1), fy1 = imin(fy + 1, height - 1);
+            const uint32_t* r0 = v.mask + (size_t)fy * v.mask_stride; const uint32_t* r1 = v.mask + (size_t)fy1 * v.mask_stride;
+            const uint32_t w00 = r0[fx >> 5], w01 = r1[fx >> 5], w10 = r0[fx1 >> 5], w11 = r1[fx1 >> 5];
+            bits &= (w00 >> (fx & 31)) & (w01 >> (fx & 31)) & (w10 >> (fx1 & 31)) & (w11 >> (fx1 & 31));
+        }
+        valid = valid && (bits & 1u) != 0u;
+    }
+    return valid;
+}
 MVS_HD int cull_pixels(const ViewParams& v, V3 v1, V3 v2, V3 v3) {
-    if (!(valid_pixel(v, pixel_coords(v, v1)) && valid_pixel(v, pixel_coords(v, v2)) &&
-          valid_pixel(v, pixel_coords(v, v3)))) return 3;
-    return 0;
+    return valid_pixels3(v, pixel_coords(v, v1), pixel_coords(v, v2), pixel_coords(v, v3)) ? 0 : 3;
 }
 MVS_HD int cull_pair(const ViewParams& v, V3 v1, V3 v2, V3 v3, V3 face_normal, float cos_limit) {
     const V3 view_pos = {v.pos[0], v.pos[1], v.pos[2]};
