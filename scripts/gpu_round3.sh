@@ -38,3 +38,7 @@ if has prof; then
   rm -rf gpurun_out/prof_${TAG}
 fi
 if [ -n "$EXTRA_CMD" ]; then echo "== extra: $EXTRA_CMD"; bash -c "$EXTRA_CMD" 2>&1 | tail -${EXTRA_TAIL:-30}; fi
+if has c2; then echo "== bench config 2"; ( time timeout 900 python bench.py --config 2 --steps 5 --warmup 2 ) > gpurun_out/${TAG}_bench_c2.json 2> gpurun_out/${TAG}_bench_c2.err; tail -2 gpurun_out/${TAG}_bench_c2.err; python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_c2.json')); print({k: d[k] for k in ('value','ms_per_step','parity_checked')}, 'frac', d['roofline']['frac'], 'dropin', d.get('dropin',{}).get('dropin_ms')); print({k: round(v['ms_per_step'],3) for k,v in d['stages'].items()})"; fi
+if has c5; then echo "== bench config 5 (one rank's share)"; ( time timeout 1200 python bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-traffic ) > gpurun_out/${TAG}_bench_c5_reduced.json 2> gpurun_out/${TAG}_bench_c5.err; tail -2 gpurun_out/${TAG}_bench_c5.err; python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_c5_reduced.json')); print({k: d[k] for k in ('value','ms_per_step','parity_checked')}); print({k: round(v['ms_per_step'],3) for k,v in d['stages'].items()})"; fi
