@@ -558,17 +558,18 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     // address mod 32): with this layout the lanes of a group touch consecutive banks (exactly for identical label lists, 3/4 of the
     // edges), and the stride puts the 32 / G groups of a half-wave on disjoint banks (TS = G mod 32 for G < 32).  The label-major tile
     // (slot = label, one float4 write) made every gather a 4-way bank conflict: PMC SQ_LDS_BANK_CONFLICT = 56 % of the LDS cycles.
-    // THREE tiles per group, one per out-edge: the three edges' writes are issued first, then all twelve gathers -- one LDS round trip
-    // per node instead of three (each gather used to wait for its own edge's writes: 3 x ~64 cycles of exposed LDS latency per node).
+    // (One tile per group, reused by the three out-edges.  A variant with three tiles -- all writes first, then all twelve gathers, one
+    // LDS round trip per node and 9 VGPRs fewer -- measured the same at C3 and 28 % slower where a quarter of the nodes take the
+    // 64-lane class: profiles/EXPERIMENTS.md.)
     constexpr int TS = G == 8 ? 40 : G == 16 ? 80 : 4 * G + 4;
-    __shared__ float s_c[NPB * 3 * TS];
+    __shared__ float s_c[NPB * TS];
     __shared__ unsigned long long s_e[8];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    float* __restrict__ tile = s_c + grp * (3 * TS);
+    float* __restrict__ tile = s_c + grp * TS;
     // The stop rule runs on the device (mrf_step_kernel) while the host queues sweeps ahead of the reports it reads: a sweep queued
     // after the rule fired changes nothing anybody reads (the best labeling is frozen, the step kernel ignores its energy) -- it ends here
     if (st->stopped) return;
-    if (gl < 3) tile[gl * TS + 4 * G] = INFINITY;
+    if (gl == 0) tile[4 * G] = INFINITY;
     __syncthreads();
     const uint32_t wofs = st->w * buf_stride;                // decode buffer of this sweep (flipped by the step kernel when a sweep improves the best energy)
     uint32_t* __restrict__ sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* __restrict__ selcost = cost2 + wofs;
@@ -658,27 +659,19 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         bt = group_min_fused<G>(bt);                          // every lane of the group holds the winner
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            // tile d holds cs - cmin of edge d (the same subtraction the oracle performs after its gather); its extra slot stays +inf
+            // the tile holds cs - cmin of edge d (the same subtraction the oracle performs after its gather); the extra slot stays +inf
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[d * TS + r * G + gl] = cv[d][r] - cmin3[d];
-        }
-        uint32_t wout[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float* td = tile + d * TS;
+            for (int r = 0; r < 4; ++r) tile[r * G + gl] = cv[d][r] - cmin3[d];
             const uint32_t mw = ident[d] ? ident_word : r_map[d];
             uint32_t w = 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t mp = (mw >> (8 * r)) & 0xFFu;
                 const uint32_t slot = (G < 64) ? mp : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // "absent at the sender" -> the +inf slot (G < 64: the records hold 4 * G)
-                w = msg_pack_s<DAMP>(min_raw(td[slot], lam_s), alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
+                w = msg_pack_s<DAMP>(min_raw(tile[slot], lam_s), alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
             }
-            wout[d] = w;
+            if (t0 < kj3[d]) st_off<uint32_t>(mn, o_out[d] + t0, w);      // one 4-byte store (runs are padded)
         }
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-            if (t0 < kj3[d]) st_off<uint32_t>(mn, o_out[d] + t0, wout[d]);      // one 4-byte store (runs are padded)
         // the lane that owns the winning label publishes the decode (K == 0: lane 0 publishes the single label 0 with
         // unary 1, view_selection.cpp:50-51,70-71) and accounts the node's share of the tracking energy (integer:
         // cost codes + 65535 per cut edge, oracle.cpp mrf_energy_sel)
