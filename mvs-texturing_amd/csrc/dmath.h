@@ -447,21 +447,18 @@ MVS_HD void rgb_to_ycbcr(float* v) {
 MVS_HD uint8_t luminance_u8(uint8_t r, uint8_t g, uint8_t b) {
     return (uint8_t)(0.30 * (double)r + (double)(0.59f * (float)g) + (double)(0.11f * (float)b));
 }
-// floor(min(255, sqrt(n))) for 0 <= n < 2^24, exact
+// floor(min(255, sqrt(n))) for n >= 0, exact
 MVS_HD uint8_t isqrt_clamp255(int n) {
-    if (n >= 255 * 255) return 255;
-    // n < 2^16 is exact in fp32 and sqrt(n) of a non-square is at least 1 / 510 away from an integer, a thousand ulps: truncating ANY
-    // square root accurate to a few ulps gives floor(sqrt(n)).  On the device that is v_sqrt_f32 (1 ulp) instead of the correctly
-    // rounded sequence the compile flags would expand sqrtf into (ten instructions per pixel of the Sobel kernel); the two
-    // branch-free corrections keep the result exact whatever the root's last bits are.
+    // m = min(n, 255^2) + 1/2 is exact in fp32 (17 bits).  For k^2 <= min(n, 255^2) < (k+1)^2:  k^2 + 1/2 <= m <= (k+1)^2 - 1/2, so
+    // k + 1/(4k+1) < sqrt(m) < (k+1) - 1/(4k+4): at k <= 255 both gaps are a thousand fp32 ulps, and truncating ANY square root
+    // accurate to a few ulps gives k -- perfect squares included, which is what the half is for.  On the device that root is
+    // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence the compile flags would expand sqrtf into.
+    const float m = (float)(n < 255 * 255 ? n : 255 * 255) + 0.5f;
 #if defined(__HIP_DEVICE_COMPILE__)
-    int r = (int)__builtin_amdgcn_sqrtf((float)n);
+    return (uint8_t)(int)__builtin_amdgcn_sqrtf(m);
 #else
-    int r = (int)sqrtf((float)n);
+    return (uint8_t)(int)sqrtf(m);
 #endif
-    r -= (r * r > n) ? 1 : 0;
-    r += ((r + 1) * (r + 1) <= n) ? 1 : 0;
-    return (uint8_t)r;
 }
 
 // Histogram::add_value bin index (histogram.cpp:28-30) for min = 0

@@ -142,4 +142,15 @@ void dmh_foot_cert_trials(uint64_t seed, uint32_t trials, uint32_t max_n, int sh
     out[0] = n_cert; out[1] = n_mis; out[2] = n_bad; out[3] = trials;
 }
 
+// isqrt_clamp255 against integer arithmetic for every n in [0, n_max): the number of disagreements (must be 0)
+uint64_t dmh_isqrt_mismatches(uint32_t n_max) {
+    uint64_t bad = 0;
+    uint32_t k = 0;                                    // k = floor(sqrt(n)), advanced incrementally
+    for (uint32_t n = 0; n < n_max; ++n) {
+        while ((uint64_t)(k + 1) * (k + 1) <= n) ++k;
+        bad += isqrt_clamp255((int)n) != (uint8_t)(k < 255u ? k : 255u);
+    }
+    return bad;
+}
+
 }  // extern "C"

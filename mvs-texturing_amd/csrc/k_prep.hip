@@ -302,10 +302,10 @@ __global__ void __launch_bounds__(256) lum_sobel_kernel(const ViewParams* __rest
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int x = x4 + k;
-                if (x == 0 || x == w - 1) continue;
                 const int sx = (l[0][k + 2] - l[0][k]) + 2 * (l[1][k + 2] - l[1][k]) + (l[2][k + 2] - l[2][k]);
                 const int sy = (l[2][k] - l[0][k]) + 2 * (l[2][k + 1] - l[0][k + 1]) + (l[2][k + 2] - l[0][k + 2]);
-                out |= (uint32_t)isqrt_clamp255(sx * sx + sy * sy) << (8 * k);
+                const uint32_t m = (uint32_t)isqrt_clamp255(sx * sx + sy * sy) << (8 * k);
+                out |= (x == 0 || x == w - 1) ? 0u : m;        // border columns stay 0; a select, not a branch per pixel
             }
         }
         *reinterpret_cast<uint32_t*>(gmi + (size_t)y * w + x4) = out;

@@ -17,11 +17,14 @@ def child(lib, scene, steps, mrf, q):
         if mrf:
             c.view_selection(scene.adj_ptr, scene.adj, M.viewsel.default_mrf_params())
     p = c.get_profile()
-    q.put({k: v[0] / steps for k, v in p.items()} | {"nnz": int(st["nnz"]), "occluded": int(st.get("cull_occluded", 0))})
+    import zlib
+    dc = c.costs_download()                                      # a checksum of the whole table: variants must agree bit for bit
+    crc = zlib.crc32(dc.cost.tobytes(), zlib.crc32(dc.view_id.tobytes(), zlib.crc32(dc.col_ptr.tobytes())))
+    q.put({"crc": crc} | {k: v[0] / steps for k, v in p.items()} | {"nnz": int(st["nnz"]), "occluded": int(st.get("cull_occluded", 0))})
 
 
 if __name__ == "__main__":
-    ap = argparse.ArgumentParser(); ap.add_argument("--config", type=int, default=3); ap.add_argument("--rounds", type=int, default=3)
+    ap = argparse.ArgumentParser(); ap.add_argument("--config", type=lambda v: int(v) if v.isdigit() else v, default=3); ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--mrf", action="store_true"); ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     scene = M.synth.make_scene(**M.synth.CONFIGS[a.config])
@@ -34,5 +37,5 @@ if __name__ == "__main__":
             res.setdefault(name, []).append(out)
     for name, runs in res.items():
         keys = [k for k in runs[0] if k.startswith("dc_") or k.startswith("mrf_")]
-        print(name, "nnz", runs[0]["nnz"], {k: round(statistics.median(x[k] for x in runs), 3) for k in keys},
+        print(name, "nnz", runs[0]["nnz"], "table crc %08x" % runs[0]["crc"], {k: round(statistics.median(x[k] for x in runs), 3) for k in keys},
               "rays all:", [round(x["dc_rays"], 2) for x in runs], flush=True)

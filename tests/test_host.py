@@ -331,3 +331,16 @@ def test_footprint_exactness_certificate_on_the_host():
         assert mis <= n - cert
     assert res[0][0] > 0.999 * res[0][3]          # at shift 0 almost everything is certified ...
     assert res[40][0] < 0.05 * res[40][3]         # ... and the GPU tests' hook (shift 40) certifies next to nothing
+
+
+def test_sobel_magnitude_root_is_exact_for_every_argument():
+    """dmath.h isqrt_clamp255 = floor(min(255, sqrt(n))), the cast of `std::sqrt` to the gradient image's byte
+    (texture_view.cpp:100-132 through mve's Sobel): every n a 3x3 Sobel of bytes can produce (2 * 1020^2 < 2^22) against integer
+    arithmetic.  The device takes the same expression with v_sqrt_f32 (1 ulp); the margin argued in the header covers it."""
+    import ctypes as C
+    path = os.path.join(ROOT, "mvs-texturing_amd", "csrc", "libmvs_dmath_host.so")
+    if not os.path.exists(path):
+        pytest.skip("libmvs_dmath_host.so not built")
+    L = C.CDLL(path)
+    L.dmh_isqrt_mismatches.argtypes = [C.c_uint32]; L.dmh_isqrt_mismatches.restype = C.c_uint64
+    assert L.dmh_isqrt_mismatches(1 << 22) == 0
