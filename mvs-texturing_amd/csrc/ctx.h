@@ -109,6 +109,7 @@ struct mvs_ctx {
     bool count_rays = false;
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
     int info_wave_area = 32;   // footprints (sampled ones) above this many pixels go to the wave-per-footprint kernel (k_dc.hip wave_info_kernel); 0 = every footprint serial = bit-exact with the reference's fp64 scan order
+    bool info_words = true;    // small footprints of the gradient term: integer word walk + certificate in info_kernel (option "info_words"; 0: serial fp64 walk)
     int info_cert_shift = 0;   // test hook: widens the exactness certificate of wave_info_kernel by this many bits (forces its serial fallback)
     uint32_t dc_stats_deferred = 0;
     int max_labels = 0;      // > 0: label-space compression after the data costs (k_dc.hip prune_write_kernel); 0 = the reference's model

@@ -368,23 +368,75 @@ MVS_HD void foot_finish(const ViewParams& view, const FootSetup& s, uint32_t num
     out->quality = (DATA_TERM == 0) ? s.area : (float)gmi;
 }
 
-// Exactness certificate for pixel sums that were NOT accumulated in the reference's order (the lane-group sampler adds the u8
-// values as integers and divides once: sum_k = fl(S_k / 255.0)).  The reference adds the n quotients fl(u / 255.0) one by one in
-// fp64; all terms are non-negative, so whatever the order its sum lies within (1 +- 2^-53)^(n + 1) of sum_k.  The expressions
-// above are monotone in the sum (division by n > 0, product with the area > 0, conversion to float): if both ends of
-// [sum (1 - eps), sum (1 + eps)], eps = (n + 4) 2^-53 (the rounding of the ends included), give the same float, every sum in
-// between does -- the serial walk's among them, and foot_finish(sum_k) IS the reference's result bit for bit.  False: the interval
-// straddles a float rounding boundary (probability ~ n 2^-28) and the caller has to repeat the walk serially.
-// shift > 0 widens eps by that many bits (test hook).  num_samples == 0: the sums are not used at all.
+// Exactness certificate for pixel sums that were NOT accumulated in the reference's order (the footprint samplers of k_dc.hip add
+// the u8 values as integers and divide once: sum_k = fl(S_k / 255.0)).  The reference adds the n quotients fl(u / 255.0) one by one
+// in fp64; all terms are non-negative, so whatever the order its sum R lies within (1 +- 2^-53)^(n + 1) of sum_k.  The expressions
+// above are a division by n > 0 and a product with the area > 0, each rounded once, then the conversion to float: with
+// Q = expr(sum_k), expr(R) lies within (1 +- 2^-53)^(n + 5) of Q, and the conversion to float is monotone.  So if both ends of
+// [Q (1 - eps), Q (1 + eps)], eps = (n + 12) 2^-53 rounded up to an even multiple (both factors exact; the slack covers the rounding
+// of the two products), give the same float, expr(R) gives it too: (float)Q IS the reference's result bit for bit, and foot_finish
+// (sum_k) returns exactly that.  False: the interval straddles a float rounding boundary (probability ~ n 2^-28) and the caller has
+// to repeat the walk serially.  shift > 0 widens eps by that many bits (test hook).  num_samples == 0: the sums are not used at all.
+MVS_HD bool foot_value_certified(double q, double dn, double up) { return (float)(q * dn) == (float)(q * up); }
 template <int DATA_TERM, bool OUTLIER>
 MVS_HD bool foot_sums_certified(const FootSetup& s, uint32_t num_samples, double col0, double col1, double col2, double gmi, int shift) {
     if (num_samples == 0) return true;
-    const double eps = ldexp((double)num_samples + 4.0, -53 + shift), dn = 1.0 - eps, up = 1.0 + eps;
+    const double eps = ldexp((double)((num_samples + 13u) & ~1u), -53 + shift), dn = 1.0 - eps, up = 1.0 + eps;
     bool ok = true;
-    if (DATA_TERM == 1) ok = (float)foot_gmi_term(gmi * dn, num_samples, s.area) == (float)foot_gmi_term(gmi * up, num_samples, s.area);
-    if (OUTLIER) ok = ok && foot_mean(col0 * dn, num_samples) == foot_mean(col0 * up, num_samples) && foot_mean(col1 * dn, num_samples) == foot_mean(col1 * up, num_samples) &&
-                      foot_mean(col2 * dn, num_samples) == foot_mean(col2 * up, num_samples);
+    if (DATA_TERM == 1) ok = foot_value_certified(foot_gmi_term(gmi, num_samples, s.area), dn, up);
+    if (OUTLIER) ok = ok && foot_value_certified(col0 / (double)num_samples, dn, up) && foot_value_certified(col1 / (double)num_samples, dn, up) &&
+                      foot_value_certified(col2 / (double)num_samples, dn, up);
     return ok;
+}
+
+// Integer walk of a `fast` footprint for the gradient term (one thread per footprint): the same pixels as the scan-line loop of
+// face_info below, read as aligned 32-bit words (four pixels; bytes outside the span masked) and added as integers -- what
+// wave_info_kernel does with a lane group, here with one lane.  ROWS scan lines per iteration, so that as many loads are in flight
+// where the serial walk waits for every pixel in turn (its fp64 sum is a dependent chain by definition).  The caller certifies the
+// sums (foot_sums_certified) before using them.  gmi must be readable up to three bytes before / after a span (the context's padded
+// buffer).
+MVS_HD uint32_t bytes_sum4(uint32_t v, uint32_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sad_u8(v, 0u, acc);
+#else
+    return acc + (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24);
+#endif
+}
+template <int ROWS = 2>
+MVS_HD void foot_walk_gmi_words(const ViewParams& view, const FootSetup& s, uint32_t* num_samples, uint32_t* gmi_sum) {
+    const uint8_t* gimg = view.gmi;
+    const int w = view.width;
+    uint32_t n = 0, g = 0;
+    const int y_end = (int)ceilf(s.aabb_max_y);                 // (float)y < ceilf(max): y < an integer-valued float
+    for (int y = (int)floorf(s.aabb_min_y); y < y_end; y += ROWS) {
+        int xb[ROWS], xe[ROWS], x0[ROWS];
+        const uint8_t* row0 = gimg + (size_t)y * w;
+        bool more = false;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if (y + r >= y_end || !foot_row(s, y + r, &xb[r], &xe[r]) || xe[r] <= xb[r]) { xb[r] = 0; xe[r] = 0; }
+            x0[r] = xb[r] - (int)(reinterpret_cast<uintptr_t>(row0 + r * w + xb[r]) & 3u);   // the aligned word that holds the first pixel
+            more = more || x0[r] < xe[r];
+        }
+        while (more) {
+            uint32_t v[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) v[r] = (x0[r] < xe[r]) ? *reinterpret_cast<const uint32_t*>(row0 + r * w + x0[r]) : 0u;
+            more = false;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                if (x0[r] < xe[r]) {
+                    const int lo = xb[r] > x0[r] ? xb[r] - x0[r] : 0, hi = xe[r] - x0[r] < 4 ? xe[r] - x0[r] : 4;   // bytes [lo, hi) are pixels of the span
+                    const uint32_t m = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+                    g = bytes_sum4(v[r] & m, g);
+                    n += (uint32_t)(hi - lo);
+                }
+                x0[r] += 4;
+                more = more || x0[r] < xe[r];
+            }
+        }
+    }
+    *num_samples = n; *gmi_sum = g;
 }
 
 constexpr float FOOT_DEFERRED = -1.0f;   // quality marker: "sampled by the wave-per-footprint kernel" (qualities are >= 0)

@@ -113,20 +113,26 @@ __global__ void popc_kernel(const unsigned long long* __restrict__ words, uint32
 }
 
 // ---- get_face_info for the visible pairs (calculate_data_costs.cpp:194-228) ----
-template <int DATA_TERM, bool OUTLIER, bool VISTEST, bool STATS>
-__global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
+// WORDS (gradient term without outlier removal, lane-group sampler enabled): a footprint's pixels are read four per load and added as
+// integers (dmath.h foot_walk_gmi_words) and the result is used iff foot_sums_certified proves it equal to the serial fp64 walk's;
+// what it cannot certify (~ n 2^-28 of the footprints) and footprints with a degenerate edge go the way of the large ones (deferred).
+template <int DATA_TERM, bool OUTLIER, bool VISTEST, bool STATS, bool WORDS>
+__global__ void __launch_bounds__(256, WORDS ? 6 : 1) info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
                                                    uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
                                                    const unsigned long long* __restrict__ pass, const unsigned long long* __restrict__ occl,
                                                    const uint32_t* __restrict__ vpos,
                                                    const uint32_t* __restrict__ pass_base, float* __restrict__ pq, float* __restrict__ pcol,
                                                    unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters,
                                                    float defer_area /* footprints above this area are left to wave_info_kernel (+inf: none) */,
-                                                   unsigned long long* __restrict__ defer_bits) {
-    // the walk adds (double)u8 / 255.0 per pixel and channel: the 256 possible quotients, correctly rounded by the same
+                                                   unsigned long long* __restrict__ defer_bits, int cert_shift) {
+    static_assert(!WORDS || (DATA_TERM == 1 && !OUTLIER), "the word walk sums gradient magnitudes only");
+    // the serial walk adds (double)u8 / 255.0 per pixel and channel: the 256 possible quotients, correctly rounded by the same
     // division, are looked up in LDS instead of divided (an fp64 division is ~15 double-precision instructions)
-    __shared__ double s_q255[256];
-    s_q255[threadIdx.x] = (double)threadIdx.x / 255.0;
-    __syncthreads();
+    __shared__ double s_q255[WORDS ? 1 : 256];
+    if (!WORDS) {
+        s_q255[threadIdx.x] = (double)threadIdx.x / 255.0;
+        __syncthreads();
+    }
     const uint32_t lf = blockIdx.x * 256 + threadIdx.x;
     const bool wave_ok = (lf >> 6) < fwords;  // false: whole wave beyond the face range
     const bool act = lf < nf;
@@ -138,10 +144,23 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t cnt[3] = {0, 0, 0};  // occluded, zero quality, survivors
-    for (uint32_t j = j0; wave_ok && j < j1; ++j) {
+    // the chunk's pass words and their ranks: lane l < 32 fetches those of view j0 + l -- one round trip instead of one per view; the
+    // views with an empty word (most of them: a wave's 64 faces see a fraction of the views) are finished here, by their lanes
+    static_assert(VIEW_CHUNK <= 64, "one lane per view of the chunk");
+    unsigned long long my_word = 0ull; uint32_t my_base = 0u;
+    if (wave_ok && j0 + (uint32_t)lane < j1 && lane < VIEW_CHUNK) {
+        const size_t widx = (size_t)(j0 + lane) * fwords + (lf >> 6);
+        my_word = pass[widx]; my_base = pass_base[widx];
+        if (my_word == 0ull) { surv[widx] = 0ull; if (defer_bits) defer_bits[widx] = 0ull; }
+    }
+    unsigned long long todo = __ballot(my_word != 0ull);
+    while (todo) {
+        const int jl = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t j = j0 + (uint32_t)jl;
         const size_t widx = (size_t)j * fwords + (lf >> 6);
-        const unsigned long long word = pass[widx];  // wave-uniform
-        if (word == 0ull) { if (lane == 0) { surv[widx] = 0ull; if (defer_bits) defer_bits[widx] = 0ull; } continue; }
+        const unsigned long long word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_word >> 32), jl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_word, jl);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)my_base, jl);
         bool keep = false, deferred = false;
         if ((word >> lane) & 1ull) {
             bool visible = true;
@@ -151,11 +170,28 @@ __global__ void __launch_bounds__(256) info_kernel(const float* __restrict__ ver
             }
             FaceInfoOut fi; fi.quality = 0.0f; fi.mean_color[0] = fi.mean_color[1] = fi.mean_color[2] = 0.0f;
             if (visible) {
-                face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi, defer_area, s_q255);
+                if (WORDS) {
+                    // face_info's control flow (dmath.h) around the integer walk
+                    const ViewParams& view = views[j];
+                    FootSetup fs;
+                    foot_setup(view, v1, v2, v3, fs);
+                    if (fs.area < FLT_EPSILON) {
+                    } else if (fs.area > 0.5f) {
+                        if (fs.area > defer_area) fi.quality = FOOT_DEFERRED;
+                        else {
+                            foot_edges(fs);
+                            uint32_t n = 0, g = 0;
+                            if (fs.fast) foot_walk_gmi_words(view, fs, &n, &g);
+                            const double CG = (double)g / 255.0;
+                            if (fs.fast && foot_sums_certified<1, false>(fs, n, 0.0, 0.0, 0.0, CG, cert_shift)) foot_finish<1, false>(view, fs, n, 0.0, 0.0, 0.0, CG, &fi);
+                            else fi.quality = FOOT_DEFERRED;
+                        }
+                    } else foot_finish<1, false>(view, fs, 0u, 0.0, 0.0, 0.0, 0.0, &fi);
+                } else face_info<DATA_TERM, OUTLIER>(views[j], v1, v2, v3, &fi, defer_area, s_q255);
                 if (fi.quality == FOOT_DEFERRED) deferred = true;   // quality, survivor bit and counters come from wave_info_kernel
                 else if (fi.quality == 0.0f) ++cnt[1]; else { keep = true; ++cnt[2]; }
             } else ++cnt[0];
-            const size_t r = (size_t)pass_base[widx] + __popcll(word & lt);
+            const size_t r = (size_t)base + __popcll(word & lt);
             pq[r] = fi.quality;
             if (OUTLIER) {
                 rgb_to_ycbcr(fi.mean_color);  // :225
@@ -818,16 +854,18 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     const float defer_area = defer ? (float)ctx->info_wave_area : INFINITY;
     unsigned long long* defer_bits = nullptr;
     if (defer) { ctx->defer_bits.ensure(pw + 1); defer_bits = ctx->defer_bits.p; }
-#define LAUNCH_INFO(DT, OL, VT)                                                                                              \
-    do { if (ctx->stats) LAUNCH_INFO2(DT, OL, VT, true); else LAUNCH_INFO2(DT, OL, VT, false); } while (0)
-#define LAUNCH_INFO2(DT, OL, VT, ST)                                                                                         \
-    hipLaunchKernelGGL((info_kernel<DT, OL, VT, ST>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
+#define LAUNCH_INFO(DT, OL, VT, WD)                                                                                          \
+    do { if (ctx->stats) LAUNCH_INFO2(DT, OL, VT, true, WD); else LAUNCH_INFO2(DT, OL, VT, false, WD); } while (0)
+#define LAUNCH_INFO2(DT, OL, VT, ST, WD)                                                                                     \
+    hipLaunchKernelGGL((info_kernel<DT, OL, VT, ST, WD>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
                        fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->vpos.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
-                       ctx->surv_bits.p, ctx->counters.p, defer_area, defer_bits)
-    if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true); else LAUNCH_INFO(1, true, false); }
-               else      { if (vis) LAUNCH_INFO(1, false, true); else LAUNCH_INFO(1, false, false); } }
-    else     { if (outl) { if (vis) LAUNCH_INFO(0, true, true); else LAUNCH_INFO(0, true, false); }
-               else      { if (vis) LAUNCH_INFO(0, false, true); else LAUNCH_INFO(0, false, false); } }
+                       ctx->surv_bits.p, ctx->counters.p, defer_area, defer_bits, ctx->info_cert_shift)
+    const bool words = defer && ctx->info_words;   // the integer walk needs the lane-group kernel behind it (for what it cannot certify)
+    if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true, false); else LAUNCH_INFO(1, true, false, false); }
+               else if (words) { if (vis) LAUNCH_INFO(1, false, true, true); else LAUNCH_INFO(1, false, false, true); }
+               else      { if (vis) LAUNCH_INFO(1, false, true, false); else LAUNCH_INFO(1, false, false, false); } }
+    else     { if (outl) { if (vis) LAUNCH_INFO(0, true, true, false); else LAUNCH_INFO(0, true, false, false); }
+               else      { if (vis) LAUNCH_INFO(0, false, true, false); else LAUNCH_INFO(0, false, false, false); } }
 #undef LAUNCH_INFO
 #undef LAUNCH_INFO2
     MVS_LAUNCH_CHECK();

@@ -813,30 +813,59 @@ def test_label_compression_with_ties_and_long_columns(kmax):
 def test_lane_group_footprint_sampler_is_bit_exact(name, kw):
     """the default path for large footprints (16 lanes per (face, view) pair, integer pixel sums; k_dc.hip wave_info_kernel)
     against the oracle's serial fp64 walk, BIT for bit: a footprint's result is taken from the integer sums only under the
-    exactness certificate of dmath.h foot_sums_certified, the others are re-walked serially by rewalk_info_kernel.  Three
-    configurations give the same table: the default, every certificate failing (info_cert_shift = 40: all large footprints
-    re-walked), the serial walker everywhere (info_wave_area = 0)."""
+    exactness certificate of dmath.h foot_sums_certified, the others are re-walked serially by rewalk_info_kernel.  The smaller
+    footprints of the gradient term take the same route with one lane each (info_kernel WORDS: four pixels per load, integer sums,
+    the same certificate; what it cannot certify joins the large ones).  Four configurations give the same table: the default, every
+    certificate failing (info_cert_shift = 40: every sampled footprint ends in the serial re-walk), the one-lane integer walk off
+    (info_words = 0), the serial walker everywhere (info_wave_area = 0)."""
     s = get_scene(name)
     c = M.Context(0); c.set_option("stats", 1)
     _load_scene(c, s)
     ref, rst = O.data_costs(s, **kw)
-    for opt, val in ((None, 0), ("info_cert_shift", 40), ("info_wave_area", 0)):
-        if opt:
+    n_group = {}
+    for tag, opts in (("default", {}), ("no certificate", {"info_cert_shift": 40}), ("words off", {"info_cert_shift": 0, "info_words": 0}), ("serial", {"info_wave_area": 0})):
+        for opt, val in opts.items():
             c.set_option(opt, val)
         st = c.data_costs(M.Settings(**kw))
         got = c.costs_download()
         _assert_costs(got, ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
         for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
-            assert st[k] == rst[k], (opt, k)
-        if opt is None:
-            assert st["footprints_lane_group"] > 0 and st["footprints_rewalked"] <= st["footprints_lane_group"] // 100 + 2, st
-        elif opt == "info_cert_shift":
+            assert st[k] == rst[k], (tag, k)
+        n_group[tag] = st["footprints_lane_group"]
+        if tag in ("default", "words off"):
+            assert st["footprints_lane_group"] > 0 and st["footprints_rewalked"] <= st["footprints_lane_group"] // 100 + 2, (tag, st)
+        elif tag == "no certificate":
             assert st["footprints_rewalked"] == st["footprints_lane_group"] > 0, st
         else:
             assert st["footprints_lane_group"] == 0 and st["footprints_rewalked"] == 0, st
+    # without a certificate the small sampled footprints of the gradient term join the large ones; with the word walk off none does
+    assert n_group["no certificate"] >= n_group["default"] >= n_group["words off"] > 0, n_group
     lo, so = O.view_selection(ref, s.adj_ptr, s.adj)
     lg, sg = c.view_selection(s.adj_ptr, s.adj)
     assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
+    c.close()
+
+
+def test_small_footprints_word_walk_equals_the_serial_walk():
+    """config 2 (footprints of a few pixels to a few dozen: none reaches the lane-group threshold of 32): the one-lane integer word
+    walk of info_kernel (default) against its serial fp64 walk (info_words = 0) and against every certificate failing
+    (info_cert_shift = 40: all sampled footprints deferred to the lane-group kernel, all re-walked serially) -- one table, the oracle's."""
+    s = M.synth.make_scene(**M.synth.CONFIGS[2])
+    ref, rst = O.data_costs(s)
+    c = M.Context(0); c.set_option("stats", 1)
+    _load_scene(c, s)
+    seen = {}
+    for tag, opts in (("default", {}), ("words off", {"info_words": 0}), ("no certificate", {"info_words": 1, "info_cert_shift": 40})):
+        for opt, val in opts.items():
+            c.set_option(opt, val)
+        st = c.data_costs(M.Settings())
+        got = c.costs_download()
+        _assert_costs(got, ref.col_ptr, ref.view_id, ref.cost, ref.quality, exact=True)
+        assert st["cull_zero_quality"] == rst["cull_zero_quality"] and st["nnz_pre"] == rst["nnz_pre"], tag
+        seen[tag] = (st["footprints_lane_group"], st["footprints_rewalked"])
+    assert seen["words off"][0] == 0 or seen["words off"][0] <= seen["default"][0], seen      # nothing (or only large footprints) deferred without the word walk
+    assert seen["default"][1] <= seen["default"][0] <= seen["no certificate"][0], seen
+    assert seen["no certificate"][0] == seen["no certificate"][1] > 1000, seen                # every sampled fast footprint went the long way round
     c.close()
 
 
