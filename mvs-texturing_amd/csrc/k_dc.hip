@@ -227,8 +227,8 @@ __global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict_
                                                         const unsigned long long* __restrict__ pass, const uint32_t* __restrict__ pass_base,
                                                         float* __restrict__ pq, float* __restrict__ pcol, unsigned long long* __restrict__ surv,
                                                         unsigned long long* __restrict__ counters, int cert_shift, uint32_t* __restrict__ rewalk) {
-    // 16 lanes per footprint (four footprints per wave), arranged as 2 scan lines x 8 pixels: a lane computes the span of its
-    // own scan line with the shared foot_row() and strides through it by 8 -- no staging, no search, coalesced row reads
+    // 16 lanes per footprint (four footprints per wave), arranged as 2 scan lines x 8 pixels (words of four pixels for the gradient
+    // term): the spans come from the shared foot_row(), the lanes stride through them -- no staging, no search, coalesced row reads
     constexpr int GL = 16, ROWS = 2, COLS = 8;
     const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) / GL;
     const bool act = k < n_list;
@@ -247,31 +247,56 @@ __global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict_
     const uint8_t* image = view.rgb; const uint8_t* gimg = view.gmi;
     uint32_t n = 0, c0 = 0, c1 = 0, c2 = 0, g = 0;             // per-lane integer sums: <= 255 * (pixels / 16) each
     const int y_begin = (int)floorf(s.aabb_min_y), y_end = act ? (int)ceilf(s.aabb_max_y) : y_begin;   // (float)y < ceilf(max): y < an integer-valued float
-    for (int y = y_begin + dy; y < y_end; y += ROWS) {
-        int xb, xe;
-        if (!foot_row(s, y, &xb, &xe)) continue;
-        if (DATA_TERM == 1 && !OUTLIER && s.fast && xe > xb) {
-            // gradient magnitudes only, whole spans: four pixels per load.  The groups are aligned in ADDRESS space (the first one
-            // starts at or up to three bytes before the span), bytes outside [xb, xe) are masked, v_sad_u8 adds the four bytes
-            // of a word in one instruction.  Integer sums of the same pixels: identical result.  (gmi points into the context's
-            // own padded buffer: an aligned word around a valid pixel is always inside it.)
-            const uint8_t* rowp = gimg + (size_t)y * w;
-            const int x_al = xb - (int)(reinterpret_cast<uintptr_t>(rowp + xb) & 3u);
-            for (int x0 = x_al + 4 * dx; x0 < xe; x0 += 4 * COLS) {
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + x0);
-                const int lo = max(xb - x0, 0), hi = min(xe - x0, 4);          // bytes [lo, hi) of the word are pixels of the span
-                const uint32_t m = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
-                g = __builtin_amdgcn_sad_u8(v & m, 0u, g);
-                n += (uint32_t)(hi - lo);
+    // Blocks of 16 scan lines: lane r of the group evaluates the span of line yb + r ONCE (foot_row: two correctly rounded divisions),
+    // the steps below fetch their line's span from that lane -- one pair of divisions per line instead of one per lane and line
+    const bool words = DATA_TERM == 1 && !OUTLIER && s.fast;   // group-uniform
+    for (int yb = y_begin; yb < y_end; yb += GL) {
+        int xb_own = 0, xe_own = 0;
+        if (yb + sub >= y_end || !foot_row(s, yb + sub, &xb_own, &xe_own) || xe_own <= xb_own) { xb_own = 0; xe_own = 0; }   // an empty span: the line is skipped
+        if (words) {
+            // gradient magnitudes only, whole spans: four pixels per load.  The words are aligned in ADDRESS space (the first one starts
+            // at or up to three bytes before the span), bytes outside [xb, xe) are masked, v_sad_u8 adds the four bytes of a word in one
+            // instruction.  Integer sums of the same pixels: identical result.  (gmi points into the context's own padded buffer: an
+            // aligned word around a valid pixel is always inside it.)  A step covers 2 x 2 lines (this lane: lines r0 + dy and
+            // r0 + 2 + dy), so that two loads are in flight per lane.
+            for (int r0 = 0; r0 < GL && yb + r0 < y_end; r0 += 2 * ROWS) {
+                int xb[2], xe[2], x0[2];
+                const uint8_t* rowp[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = r0 + ROWS * q + dy;                  // < 16: the lane that holds the line's span
+                    xb[q] = __shfl(xb_own, r, GL); xe[q] = __shfl(xe_own, r, GL);
+                    rowp[q] = gimg + (size_t)(yb + r) * w;
+                    x0[q] = xb[q] - (int)(reinterpret_cast<uintptr_t>(rowp[q] + xb[q]) & 3u) + 4 * dx;
+                }
+                while (x0[0] < xe[0] || x0[1] < xe[1]) {
+                    uint32_t v[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) v[q] = (x0[q] < xe[q]) ? *reinterpret_cast<const uint32_t*>(rowp[q] + x0[q]) : 0u;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (x0[q] < xe[q]) {
+                            const int lo = max(xb[q] - x0[q], 0), hi = min(xe[q] - x0[q], 4);      // bytes [lo, hi) of the word are pixels of the span
+                            const uint32_t m = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+                            g = __builtin_amdgcn_sad_u8(v[q] & m, 0u, g);
+                            n += (uint32_t)(hi - lo);
+                        }
+                        x0[q] += 4 * COLS;
+                    }
+                }
             }
             continue;
         }
-        for (int x = xb + dx; x < xe; x += COLS) {
-            if (!s.fast && !foot_inside(s, x, y)) continue;
-            const size_t pix = (size_t)x + (size_t)y * w;
-            if (OUTLIER) { c0 += image[pix * 3 + 0]; c1 += image[pix * 3 + 1]; c2 += image[pix * 3 + 2]; }
-            if (DATA_TERM == 1) g += gimg[pix];
-            ++n;
+        for (int r0 = 0; r0 < GL && yb + r0 < y_end; r0 += ROWS) {
+            const int y = yb + r0 + dy;
+            const int xb = __shfl(xb_own, r0 + dy, GL), xe = __shfl(xe_own, r0 + dy, GL);
+            for (int x = xb + dx; x < xe; x += COLS) {
+                if (!s.fast && !foot_inside(s, x, y)) continue;
+                const size_t pix = (size_t)x + (size_t)y * w;
+                if (OUTLIER) { c0 += image[pix * 3 + 0]; c1 += image[pix * 3 + 1]; c2 += image[pix * 3 + 2]; }
+                if (DATA_TERM == 1) g += gimg[pix];
+                ++n;
+            }
         }
     }
     for (int o = GL / 2; o > 0; o >>= 1) {
