@@ -285,8 +285,13 @@ struct FootSetup {
     float m1, b1, m2, b2, m3, b3;
     bool fast;
 };
+MVS_HD void foot_setup_px(FootSetup& s);
 MVS_HD void foot_setup(const ViewParams& view, V3 v1, V3 v2, V3 v3, FootSetup& s) {
     s.p1 = pixel_coords(view, v1); s.p2 = pixel_coords(view, v2); s.p3 = pixel_coords(view, v3);
+    foot_setup_px(s);
+}
+// the part of foot_setup after the projection (p1 .. p3 given in pixel coordinates)
+MVS_HD void foot_setup_px(FootSetup& s) {
     s.t1 = s.p1; s.t2 = s.p2; s.t3 = s.p3;
     const float T0 = s.t1.x - s.t3.x, T1 = s.t2.x - s.t3.x, T2 = s.t1.y - s.t3.y, T3 = s.t2.y - s.t3.y;
     s.detT = T0 * T3 - T2 * T1;

@@ -4,6 +4,7 @@
 // the product: nothing in the library or the Python package calls into this file.
 #include "dmath.h"
 #include <vector>
+#include <cstring>
 
 using namespace mvs;
 
@@ -151,6 +152,46 @@ uint64_t dmh_isqrt_mismatches(uint32_t n_max) {
         bad += isqrt_clamp255((int)n) != (uint8_t)(k < 255u ? k : 255u);
     }
     return bad;
+}
+
+// the integer word walk of the footprint samplers (foot_walk_gmi_words, 2 / 3 / 4 scan lines per iteration) against the plain loop over
+// the same spans, on random triangles in random images whose width is NOT a multiple of four (every alignment of a span's first and
+// last word occurs).  out[0] = trials with a sampled `fast` footprint, out[1] = disagreements in (pixel count, sum) -- must be 0,
+// out[2] = pixels walked
+void dmh_word_walk_trials(uint64_t seed, uint32_t trials, uint64_t* out) {
+    uint64_t n_fast = 0, n_bad = 0, n_px = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : n_fast, n_bad, n_px)
+    for (uint32_t t = 0; t < trials; ++t) {
+        uint64_t x = seed * 0x9E3779B97F4A7C15ull + (uint64_t)t * 0xD1B54A32D192ED03ull + 1ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+        auto unit = [&]() { return (float)(rnd() % 1000003u) / 1000003.0f; };
+        const int w = 33 + (int)(rnd() % 90u), h = 20 + (int)(rnd() % 60u);
+        std::vector<uint8_t> buf((size_t)w * h + 16);
+        for (auto& b : buf) b = (uint8_t)(rnd() >> 11);
+        ViewParams vp; memset(&vp, 0, sizeof(vp));
+        vp.width = w; vp.height = h; vp.gmi = buf.data() + 8;            // readable a few bytes before and after, like the context's buffer
+        FootSetup s{};
+        const float cx = 2.0f + unit() * (float)(w - 4), cy = 2.0f + unit() * (float)(h - 4), r = 0.6f + unit() * unit() * 30.0f;
+        auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        V2* p[3] = {&s.p1, &s.p2, &s.p3};
+        for (int k = 0; k < 3; ++k) { p[k]->x = clampf(cx + (2.0f * unit() - 1.0f) * r, 0.0f, (float)w - 1.01f); p[k]->y = clampf(cy + (2.0f * unit() - 1.0f) * r, 0.0f, (float)h - 1.01f); }
+        foot_setup_px(s);
+        if (s.area <= 0.5f) continue;
+        foot_edges(s);
+        if (!s.fast) continue;
+        uint32_t n0 = 0, g0 = 0;
+        const float y_end = ceilf(s.aabb_max_y);
+        for (int y = (int)floorf(s.aabb_min_y); (float)y < y_end; ++y) {
+            int xb, xe;
+            if (!foot_row(s, y, &xb, &xe)) continue;
+            for (int xx = xb; xx < xe; ++xx) { g0 += vp.gmi[(size_t)xx + (size_t)y * w]; ++n0; }
+        }
+        uint32_t n[3], g[3];
+        foot_walk_gmi_words<2>(vp, s, &n[0], &g[0]); foot_walk_gmi_words<3>(vp, s, &n[1], &g[1]); foot_walk_gmi_words<4>(vp, s, &n[2], &g[2]);
+        ++n_fast; n_px += n0;
+        for (int k = 0; k < 3; ++k) n_bad += (n[k] != n0 || g[k] != g0);
+    }
+    out[0] = n_fast; out[1] = n_bad; out[2] = n_px;
 }
 
 }  // extern "C"
