@@ -183,6 +183,42 @@ def real_like_workload(device, dev, params, steps=5, warmup=2, check=True):
         c.close()
 
 
+def shuffled_workload(device, dev, scene, t_img, settings, params, steps=5, warmup=2, check=True, n_check=100000):
+    """The headline scene with its faces AND vertices in random order (a decimated / cleaned mesh file): same path, same defaults.
+    Nothing outside the timed step sorts anything -- the library lays the mesh out itself inside every step (stage dc_order, and
+    order_adjacency inside mrf_setup).  Reported beside the headline: ms_per_step, the stage table, and the same check as the
+    headline (table window + the labeling of ALL faces against the oracle on the permuted input)."""
+    s = M.synth.permute_scene(scene, seed=11)
+    c = M.Context(device)
+    try:
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        c.set_mesh(torch.from_numpy(s.verts).to(dev), torch.from_numpy(s.faces.view(np.int32)).to(dev), torch.from_numpy(s.normals).to(dev))
+        c.set_views(s.cams, t_img)
+        t_ap, t_ad = torch.from_numpy(s.adj_ptr.view(np.int32)).to(dev), torch.from_numpy(s.adj.view(np.int32)).to(dev)
+        lab = torch.zeros(s.n_faces, dtype=torch.int32, device=dev)
+        for _ in range(warmup):
+            c.data_costs(settings); c.view_selection(t_ap, t_ad, params, labels_out=lab)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            c.data_costs(settings); _, ms = c.view_selection(t_ap, t_ad, params, labels_out=lab)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        timed_lab = lab.cpu().numpy().view(np.uint32)
+        c.set_option("profile", 1)
+        for _ in range(min(steps, 3)):
+            c.data_costs(settings); c.view_selection(t_ap, t_ad, params, labels_out=lab)
+        prof = c.get_profile(); c.set_option("profile", 0)
+        out = {"workload": "the headline scene with faces and vertices randomly permuted (seed 11); no sorting outside the timed step",
+               "faces": s.n_faces, "ms_per_step": 1000.0 * el / steps, "value": s.n_faces / (el / steps), "unit": "faces/s", "sweeps": int(ms["sweeps"]),
+               "stages": {k: v[0] / min(steps, 3) for k, v in prof.items()}}
+        if check:
+            timed = dict(labels=timed_lab, energy_fixed=ms["energy_fixed"], sweeps=ms["sweeps"], icm_iters=ms["icm_iters"])
+            out["parity"] = parity_check(c, s, s.faces, s.normals, s.adj_ptr, s.adj, params, n_check, timed)
+            out["parity_checked"] = bool(out["parity"]["ok"])
+        return out
+    finally:
+        c.close()
+
+
 def pmc_pass(config, counters, timeout_s=420, extra_args=()):
     """One `rocprofv3 --pmc <counters>` pass over ONE step of this script (no traces in the same run).  Returns
     {kernel short name: [dispatches, {counter: sum over dispatches}]} or raises."""
@@ -320,6 +356,8 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--shard", action="store_true", help="take the sharded C++ / RCCL path even at world size 1 (test of the N > 1 code path on one GPU)")
+    ap.add_argument("--shuffle-main", action="store_true", help="experiments: the main workload with faces and vertices in random order")
+    ap.add_argument("--no-shuffled", action="store_true", help="skip the extra leg that runs the headline scene with faces AND vertices randomly permuted")
     args = ap.parse_args()
     args.config = int(args.config) if args.config.isdigit() else args.config
 
@@ -354,22 +392,40 @@ def main():
     max_labels = max(max_labels, 0)
     t0 = time.time()
     scene = M.synth.make_scene(**cfg)
-    perm = G.morton_order(scene.verts, scene.faces)   # contiguous parts = compact patches (METIS stand-in; hilbert_order measured the same)
-    faces, normals, adj_ptr, adj, _ = G.renumber_faces(scene.faces, scene.normals, scene.adj_ptr, scene.adj, perm)
+    if args.shuffle_main:
+        scene = M.synth.permute_scene(scene, seed=11)   # experiments: the headline workload itself in random face / vertex order
+    # The mesh goes in AS BUILT (icosphere construction order), like a mesh file: the library lays it out itself, on the device, inside
+    # the timed step (csrc/k_bvh.hip build_scene_order), and the parts of the sharded path are contiguous ranges of ITS order
+    # (mvs_ctx_partition_faces).  The gloo test harness (mvs-texturing_amd/multigpu.py) cuts the caller's numbering itself (its parts
+    # are whatever the construction order makes them: a test of the collectives' call pattern, not of the partition).
+    harness = (world > 1 or args.shard) and args.backend != "nccl"
+    faces, normals, adj_ptr, adj = scene.faces, scene.normals, scene.adj_ptr, scene.adj
     F, V = len(faces), scene.n_views
     if rank == 0:
         log("scene: %d faces, %d views %dx%d, built in %.1fs" % (F, V, cfg["width"], cfg["height"], time.time() - t0))
-    part = G.equal_parts(F, world)
+    part = G.equal_parts(F, world)   # == the library's own equal cut (mvs_ctx_partition_faces) of its order
 
     # ---- inputs resident in HBM (the upload is timed and reported as h2d_ms; it is never part of `value`) ----
+    # the images (98 % of the bytes) are pinned in place for the copy, as the library's own host-pointer entry does (api.hip
+    # mvs_scene_set_views): a pageable torch .to() is staged through a bounce buffer at ~9 GB/s
+    rt = torch.cuda.cudart()
+    pinned = []
+    for i in scene.images:
+        try:
+            if int(rt.cudaHostRegister(i.ctypes.data, i.nbytes, 0)) == 0:
+                pinned.append(i)
+        except Exception:  # noqa: BLE001 -- pageable copy then
+            pass
     torch.cuda.synchronize(); t_h2d = time.perf_counter()
     t_v = torch.from_numpy(scene.verts).to(dev)
     t_f = torch.from_numpy(faces.view(np.int32)).to(dev)
     t_n = torch.from_numpy(normals).to(dev)
-    t_img = [torch.from_numpy(i).to(dev) for i in scene.images]
+    t_img = [torch.from_numpy(i).to(dev, non_blocking=True) for i in scene.images]
     t_ap = torch.from_numpy(adj_ptr.view(np.int32)).to(dev)
     t_ad = torch.from_numpy(adj.view(np.int32)).to(dev)
     torch.cuda.synchronize(); h2d_ms = 1000.0 * (time.perf_counter() - t_h2d)
+    for i in pinned:
+        rt.cudaHostUnregister(i.ctypes.data)
     h2d_bytes = scene.verts.nbytes + faces.nbytes + normals.nbytes + sum(i.nbytes for i in scene.images) + adj_ptr.nbytes + adj.nbytes
     t_lab = torch.zeros(F, dtype=torch.int32, device=dev)
     ctx = M.Context(local_rank)
@@ -400,8 +456,8 @@ def main():
                 if dist is not None:
                     dist.broadcast_object_list(uid, src=0)
                 info["comm"] = M.shard.Comm.rccl(local_rank, rank, world, uid[0])
-                info["shard"] = M.shard.Shard(ctx, info["comm"], part, t_ap, t_ad)
-                info["labels_own"] = torch.zeros(max(int(part[rank + 1] - part[rank]), 1), dtype=torch.int32, device=dev)
+                info["shard"] = M.shard.Shard(ctx, info["comm"], None, t_ap, t_ad)   # None: the library's equal cut of its own face order
+                info["labels_own"] = torch.zeros(max(info["shard"].n_own(), 1), dtype=torch.int32, device=dev)
             st, info["nnz_global"] = info["shard"].data_costs(settings)
             ms = info["shard"].view_selection(info["labels_own"], params)
             info["plan"] = info["shard"].plan_info()
@@ -416,6 +472,14 @@ def main():
 
     # row f1 (outside the headline window, reported separately): tex::build_adjacency_graph on the GPU
     pre = {}
+    if not harness:
+        # the partition the sharded path uses, as an entry point of its own: order + cut on the device (also part of every timed step:
+        # stage dc_order)
+        ctx.partition_faces(max(world, 1))   # (first call: allocations)
+        torch.cuda.synchronize(); tp0 = time.perf_counter()
+        ctx.partition_faces(max(world, 1))
+        pre["partition_ms"] = 1000.0 * (time.perf_counter() - tp0)   # wall clock incl. the copy of the permutation to the host
+        ctx.get_profile()
     if world == 1 and not args.shard and not args.pmc_child:
         ctx.build_adjacency(); ctx.get_profile()
         for _ in range(3):
@@ -472,9 +536,11 @@ def main():
         nph = C.c_uint32(0); ctx.L.mvs_ctx_mrf_num_phases(ctx.h, C.byref(nph)); n_phases = max(int(nph.value), 1)
         # one sweep = n_phases launches of the sweep kernel (one per colour class).  The profile span covers a whole
         # sweep on one GPU and a single phase in the sharded driver.
+        # (single context: the spans also count the sweep queued behind the device-side stop rule, which ends at its first instruction --
+        # the divisor is the number of sweeps the solve RAN, mrf["sweeps"], per profiled step)
         spans = prof["mrf_sweep"][1]
-        sweeps_run = spans if (world == 1 and not args.shard) else spans / n_phases
-        sweep_ms = prof["mrf_sweep"][0] / sweeps_run
+        sweeps_run = float(int(info["mrf"]["sweeps"]) * n_prof) if (world == 1 and not args.shard) else spans / n_phases
+        sweep_ms = prof["mrf_sweep"][0] / max(sweeps_run, 1.0)
         launch_ms = sweep_ms / n_phases
         nf_own = int(part[rank + 1] - part[rank])
         nnz_own = int(dc["nnz"])                             # entries of the nodes this rank sweeps
@@ -563,7 +629,7 @@ def main():
            "config": {"workload": "BASELINE config %s: displaced icosphere n=%d (%d faces), %d Fibonacci-sphere views %dx%d RGB8, "
                                   "settings gmi/none/visibility-test (reference defaults)" % (args.config, cfg["n"], F, V, cfg["width"], cfg["height"]),
                       "faces": F, "views": V, "nnz": nnz_global, "sweeps": int(mrf["sweeps"]), "icm_iters": int(mrf["icm_iters"]),
-                      "energy": float(mrf["energy"]), "partition": "morton-%d" % world, "msg_bits": 8, "max_labels": max_labels,
+                      "energy": float(mrf["energy"]), "partition": ("harness-caller-order-%d" if harness else "library-hilbert-%d") % world, "face_order_in": "shuffled" if args.shuffle_main else "as built", "msg_bits": 8, "max_labels": max_labels,
                       "arithmetic": "fp32 geometry and messages, fp64 footprint sums, 32.32 fixed-point energies; messages STORED as 8-bit codes"},
            "h2d_ms": h2d_ms, "h2d_GBps": h2d_bytes / max(h2d_ms, 1e-9) / 1e6,
            "pcie_inclusive_value": F / ((ms_per_step + h2d_ms) / 1000.0),
@@ -583,6 +649,12 @@ def main():
             out["real_like"] = real_like_workload(local_rank, dev, params)
         except Exception as e:  # noqa: BLE001 -- an extra, never at the expense of the headline
             out["real_like"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_shuffled and not args.no_traffic and not args.shard and args.steps > 0 and args.config in (2, 3) and not args.shuffle_main:
+        try:
+            out["shuffled"] = shuffled_workload(local_rank, dev, scene, t_img, settings, params, steps=min(max(args.steps, 1), 5), check=not args.no_parity, n_check=args.parity_faces)
+            out["shuffled"]["vs_headline_ms"] = out["shuffled"]["ms_per_step"] / ms_per_step
+        except Exception as e:  # noqa: BLE001 -- an extra, never at the expense of the headline
+            out["shuffled"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_dropin and not args.no_traffic and not args.shard and args.steps > 0 and args.config in (2, 3):
         try:
             out["dropin"] = dropin_timing(cfg)
@@ -596,7 +668,7 @@ def main():
             out["parity_checked"] = bool(out["parity"]["ok"])
         except Exception as e:  # noqa: BLE001
             out["parity"] = {"error": repr(e)}; out["parity_checked"] = False
-        if not out["parity_checked"]:
+        if not out["parity_checked"] or out.get("shuffled", {}).get("parity_checked") is False:
             rc = 3
     if rank == 0:
         print(json.dumps(out), flush=True)

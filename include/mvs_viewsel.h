@@ -219,7 +219,8 @@ mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
  * as integers under the same certificate, by one lane each; 0 = their serial fp64 walk; identical results), "max_labels" (label-space compression, 0 = off = the reference's model), "mrf_lag" (sweeps the host queues ahead of
  * the energy reports it reads, default 1; identical results), "mrf_graph" (1 = the sweep loop is replayed from a hipGraph, the default;
  * identical results), tuning knobs "mrf_xcd", "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd", "prep_fused" (1 = luminance +
- * Sobel in one pass through LDS, the default; identical output), test hooks "info_cert_shift", "mrf_force_generic" */
+ * Sobel in one pass through LDS, the default; identical output), "face_order" (1 = the library lays the faces out along a Hilbert curve, the
+ * default; 0 = the caller's face numbering is kept; identical results), test hooks "info_cert_shift", "mrf_force_generic" */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 
 /* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,
@@ -229,8 +230,8 @@ mvs_status mvs_ctx_get_profile(mvs_ctx* ctx, char* buf, size_t buf_size);
 mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device);
 /* views: HOST array of n structs; their rgb pointers are device pointers iff rgb_on_device */
 mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device);
-/* restrict the data-cost computation to faces [begin, end) (multi-GPU sharding);
- * the whole mesh stays the occluder set.  Default: all faces. */
+/* restrict the data-cost computation to the faces at POSITIONS [begin, end) of the library's face order (the caller's ids with
+ * option "face_order" = 0); the whole mesh stays the occluder set.  Default: all faces.  (Building block of the sharded drivers.) */
 mvs_status mvs_scene_set_face_range(mvs_ctx* ctx, uint32_t begin, uint32_t end);
 
 /* tex::calculate_data_costs on the resident scene; result stays on the device. */
@@ -252,13 +253,37 @@ mvs_status mvs_ctx_dc_get_histogram(mvs_ctx* ctx, uint32_t* dst_device);
 mvs_status mvs_ctx_dc_set_histogram(mvs_ctx* ctx, const uint32_t* src_device);
 mvs_status mvs_ctx_dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
 
-/* device-resident result of the last data-cost call (faces of the face range, local indices) */
+/* device-resident result of the last data-cost call AS THE LIBRARY KEEPS IT: column p is the face at position p of the library's
+ * own face order (see "Face order" below; mvs_ctx_table_order gives the caller's id of every column), for a face range the faces
+ * of the range with local indices.  mvs_ctx_costs_download returns the caller's numbering. */
 mvs_status mvs_ctx_costs_device(mvs_ctx* ctx, mvs_csr* device_view);
+/* *ordered = 1: the active table lives in the library's own order and perm_device[p] (caller-owned DEVICE array of n_faces words, may
+ * be NULL) receives the caller's face id of column p; *ordered = 0: the table is in the caller's order (uploaded tables, option
+ * "face_order" = 0, face ranges), nothing is written */
+mvs_status mvs_ctx_table_order(mvs_ctx* ctx, uint32_t* perm_device, int* ordered);
 /* copy it to freshly malloc'ed host arrays (release with mvs_csr_free); with
  * quality_out != NULL also returns the un-normalised qualities (malloc'ed, nnz floats) */
 mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* host_out, float** quality_out);
 /* replace the resident costs by caller-provided ones (host or device pointers) */
 mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device);
+
+/* ------------------------------------------------------------------------
+ * Face order and partition.  The reference hands the path its faces in mesh-file order (calculate_data_costs.cpp:136-138,
+ * texrecon.cpp:73-92); the library assumes nothing about that order.  Every data-cost pass first lays the resident mesh out along
+ * a Hilbert curve on the device (faces by centroid, vertices by position; csrc/k_bvh.hip build_scene_order) and works on that
+ * copy: culls, rays, footprints, the cost table, the solver's node order and the parts of the sharded path all follow it.
+ * Inputs and outputs keep the caller's numbering: adjacency lists are renumbered on entry (list order kept), the colouring of the
+ * solver is keyed on the caller's ids, labels and downloaded tables come back at the caller's face ids -- results are
+ * bit-identical whatever order the mesh arrives in.  mvs_set_option("face_order", 0) keeps the caller's face numbering as the
+ * internal order (a caller that laid the faces out itself).
+ *
+ * mvs_ctx_partition_faces: the order of the resident mesh -- perm_device[p] (device, n_faces words, may be NULL) = the caller's
+ * id of the face at position p -- and its cut part_begin[0 .. world] (host, may be NULL) into `world` contiguous parts of equal
+ * size: the partition of the sharded path below (METIS is not available; a contiguous range of a Hilbert order is
+ * a compact patch).  mvs_partition_faces: the same for host arrays (mesh->face_normals may be NULL); device = env MVS_DEVICE.
+ * ------------------------------------------------------------------------ */
+mvs_status mvs_ctx_partition_faces(mvs_ctx* ctx, int world, uint32_t* perm_device, uint32_t* part_begin);
+mvs_status mvs_partition_faces(const mvs_mesh* mesh, int world, uint32_t* perm_out /* [n_faces] */, uint32_t* part_begin_out /* [world + 1] */);
 
 /* tex::build_adjacency_graph on the resident mesh; the result stays on the device (pointers returned) */
 mvs_status mvs_ctx_build_adjacency(mvs_ctx* ctx, uint32_t** adj_ptr_device, uint32_t** adj_device, uint64_t* n_entries);
@@ -375,8 +400,9 @@ mvs_status mvs_postprocess_face_infos(uint32_t n_faces, uint32_t n_views, const 
                                       mvs_csr* out, mvs_dc_stats* stats);
 
 /* ---- sharded view selection: one rank per GPU, host side in C++, RCCL halo exchange (csrc/shard.hip; DESIGN.md "Multi-GPU") ----
- * Faces are cut into `world` contiguous parts part_begin[0 .. world] (the caller renumbers the faces along a space-filling
- * curve so that parts are compact).  Every rank holds the replicated scene and the full adjacency; it evaluates the data
+ * Faces are cut into `world` contiguous parts of the LIBRARY's face order ("Face order and partition" above: every rank derives
+ * the same Hilbert order from the replicated mesh, so the mesh may arrive in any order): part_begin[0 .. world] are cut points
+ * of that order, NULL = `world` equal parts.  Every rank holds the replicated scene and the full adjacency; it evaluates the data
  * costs of its part, keeps a cost table of the GLOBAL shape with only its own and its halo columns filled, sweeps its own
  * nodes and exchanges -- after every colour phase -- the message runs written in that phase over cut edges (as bytes) and the
  * labels of that phase's boundary nodes with the ranks that own the neighbours: grouped ncclSend / ncclRecv, neighbours
@@ -391,13 +417,16 @@ mvs_status mvs_comm_unique_id(uint8_t id_out[MVS_COMM_ID_BYTES]);
 mvs_status mvs_comm_create_rccl(int device, int rank, int world, const uint8_t id[MVS_COMM_ID_BYTES], mvs_comm** out);
 mvs_status mvs_comm_create_local(int world, mvs_comm** out /* [world] */);
 void mvs_comm_destroy(mvs_comm* comm);
-/* ctx: the rank's context with the FULL mesh and all views set; adjacency: device pointers to the full graph (borrowed) */
-mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_begin /* host, [world + 1] */,
+/* ctx: the rank's context with the FULL mesh and all views set; adjacency: device pointers to the full graph in the CALLER's face
+ * numbering (read once, at creation) */
+mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_begin /* host, [world + 1], or NULL */,
                             const uint32_t* adj_ptr_device, const uint32_t* adj_device, mvs_shard** out);
+/* the caller's ids of the faces this rank owns, in the order of the labels mvs_shard_view_selection returns (ids_device may be NULL) */
+mvs_status mvs_shard_own_faces(mvs_shard* shard, uint32_t* ids_device, uint32_t* n_own);
 void mvs_shard_destroy(mvs_shard* shard);
 /* tex::calculate_data_costs over all ranks; stats = this rank's pairs / culls, max_quality and percentile global */
 mvs_status mvs_shard_data_costs(mvs_shard* shard, const mvs_settings* settings, mvs_dc_stats* stats, uint64_t* nnz_global);
-/* tex::view_selection over all ranks; labels of the OWN nodes (part_begin[rank] ..) into labels_own_device; stats global */
+/* tex::view_selection over all ranks; labels of the OWN faces (in the order of mvs_shard_own_faces) into labels_own_device; stats global */
 mvs_status mvs_shard_view_selection(mvs_shard* shard, const mvs_mrf_params* params, uint32_t* labels_own_device, mvs_mrf_stats* stats);
 /* halo plan of the last view selection: message bytes this rank sends per sweep, its boundary nodes, device time of the planning */
 mvs_status mvs_shard_plan_info(mvs_shard* shard, uint64_t* msg_bytes_per_sweep, uint64_t* boundary_nodes, double* plan_ms);

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_SOURCES = ["scan.hip", "k_prep.hip", "k_bvh.hip", "k_dc.hip", "k_mrf.hip", "k_region.hip", "k_mesh.hip", "k_patch.hip", "mgpu.hip", "shard.hip", "api.hip"]
+HIP_SOURCES = ["scan.hip", "k_prep.hip", "k_bvh.hip", "k_dc.hip", "k_mrf.hip", "k_region.hip", "k_mesh.hip", "k_patch.hip", "k_order.hip", "mgpu.hip", "shard.hip", "api.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
              "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # per-file additions: the SLP vectoriser packs the ray / triangle arithmetic into v_pk_* operations at the price of ~50

@@ -30,7 +30,7 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
-void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2], bool caller_order = false);
 }  // namespace mvs
 
 using namespace mvs;
@@ -54,14 +54,32 @@ static float compute_cos_limit() {
 }
 
 namespace mvs {
-void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device) {
+bool table_to_caller_order(mvs_ctx* ctx, bool with_quality);
+void adjacency_to_table_order(mvs_ctx* ctx, const uint32_t* d_adj_ptr, const uint32_t* d_adj, size_t E);
+// The adjacency lists arrive in the caller's numbering (UniGraph, uni_graph.h:22).  A table that lives in the library's own order
+// (ctx->t_perm; k_order.hip) gets them renumbered on the device, list order kept; `table_order` = the lists already are in the
+// table's order (the sharded driver renumbers once for all its calls).
+void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device, bool table_order) {
     const size_t F = ctx->csr_faces;
-    if (on_device) { ctx->r_adj_ptr = adj_ptr; ctx->r_adj = adj; return; }
-    const size_t E = adj_ptr[F];
-    ctx->m_adj_ptr.ensure(F + 2); ctx->m_adj.ensure(E + 1);
-    MVS_HIP(hipMemcpyAsync(ctx->m_adj_ptr.p, adj_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (E) MVS_HIP(hipMemcpyAsync(ctx->m_adj.p, adj, E * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    const bool renumber = ctx->t_perm != nullptr && !table_order;
+    if (on_device && !renumber) { ctx->r_adj_ptr = adj_ptr; ctx->r_adj = adj; return; }
+    size_t E = 0;
+    if (on_device) {
+        uint32_t e32 = 0;
+        MVS_HIP(hipMemcpyAsync(&e32, adj_ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        E = e32;
+    } else E = adj_ptr[F];
+    const uint32_t* d_ptr = adj_ptr; const uint32_t* d_adj = adj;
+    if (!on_device) {
+        DBuf<uint32_t>& sp = renumber ? ctx->a_stage_ptr : ctx->m_adj_ptr; DBuf<uint32_t>& sa = renumber ? ctx->a_stage : ctx->m_adj;
+        sp.ensure(F + 2); sa.ensure(E + 1);
+        MVS_HIP(hipMemcpyAsync(sp.p, adj_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (E) MVS_HIP(hipMemcpyAsync(sa.p, adj, E * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        d_ptr = sp.p; d_adj = sa.p;
+    }
+    if (renumber) adjacency_to_table_order(ctx, d_ptr, d_adj, E);
     ctx->r_adj_ptr = ctx->m_adj_ptr.p; ctx->r_adj = ctx->m_adj.p;
 }
 }  // namespace mvs
@@ -243,6 +261,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
+    else if (n == "face_order") ctx->face_order = value != 0 ? 1 : 0;   // takes effect with the next data-cost pass (the active table keeps the order it was made in)
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
 }
@@ -402,19 +421,23 @@ mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* out, float** quality_ou
     MVS_API_BEGIN
     MVS_HIP(hipSetDevice(ctx->device));
     const size_t F = ctx->csr_faces, nnz = ctx->csr_nnz;
+    // a table kept in the library's own face order leaves in the caller's numbering (k_order.hip)
+    const bool reordered = table_to_caller_order(ctx, quality_out != nullptr);
+    const uint32_t* s_ptr = reordered ? ctx->u_ptr.p : ctx->r_ptr; const uint16_t* s_view = reordered ? ctx->u_view.p : ctx->r_view;
+    const float* s_cost = reordered ? ctx->u_cost.p : ctx->r_cost; const float* s_q = reordered ? ctx->u_q.p : ctx->csr_q.p;
     out->n_faces = ctx->csr_faces; out->n_views = ctx->csr_views; out->nnz = nnz;
     out->col_ptr = (uint32_t*)malloc((F + 1) * sizeof(uint32_t));
     out->view_id = (uint16_t*)malloc((nnz + 1) * sizeof(uint16_t));
     out->cost = (float*)malloc((nnz + 1) * sizeof(float));
-    MVS_HIP(hipMemcpyAsync(out->col_ptr, ctx->r_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipMemcpyAsync(out->col_ptr, s_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nnz) {
-        MVS_HIP(hipMemcpyAsync(out->view_id, ctx->r_view, nnz * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
-        MVS_HIP(hipMemcpyAsync(out->cost, ctx->r_cost, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(hipMemcpyAsync(out->view_id, s_view, nnz * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+        MVS_HIP(hipMemcpyAsync(out->cost, s_cost, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     if (quality_out) {
         *quality_out = (float*)malloc((nnz + 1) * sizeof(float));
         if (nnz && ctx->csr_q_valid)
-            MVS_HIP(hipMemcpyAsync(*quality_out, ctx->csr_q.p, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            MVS_HIP(hipMemcpyAsync(*quality_out, s_q, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     MVS_HIP(hipStreamSynchronize(ctx->stream));
     MVS_API_END
@@ -445,6 +468,7 @@ mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device)
     }
     ctx->csr_faces = csr->n_faces; ctx->csr_views = csr->n_views; ctx->csr_nnz = nnz;
     ctx->have_costs = true; ctx->csr_q_valid = false;
+    ctx->t_perm = nullptr; ctx->t_pos = nullptr; ctx->u_valid = false;   // the caller's table, the caller's order
     MVS_API_END
 }
 
@@ -492,8 +516,7 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     MVS_HIP(hipSetDevice(ctx->device));
     mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
     const uint32_t F = ctx->csr_faces;
-    set_adjacency(ctx, adj_ptr, adj, adj_on_device);
-    { Prof pr(ctx, "mrf_setup"); mrf_setup(ctx, &P); }
+    { Prof pr(ctx, "mrf_setup"); set_adjacency(ctx, adj_ptr, adj, adj_on_device, false); mrf_setup(ctx, &P); }
     hipStream_t s = ctx->stream;
     mvs_mrf_stats S; memset(&S, 0, sizeof(S));
     // The stop rule runs on the device (mrf_step); the host only polls the report of `lag` sweeps ago, so the next
@@ -559,7 +582,7 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     S.energy_fixed = e[0]; S.energy = (double)e[0] / 4294967296.0; S.cut_edges = e[1];
     uint32_t* d_labels = labels_on_device ? labels_out : ctx->m_cand.p;
     uint32_t bu[2];
-    mrf_labels(ctx, 0, F, d_labels, bu);
+    mrf_labels(ctx, 0, F, d_labels, bu, /*caller_order=*/true);
     S.unseen = bu[1];
     if (bu[0]) throw StatusError(MVS_ERR_LABELING, "Incorrect labeling");  /* view_selection.cpp:126-128 */
     if (!labels_on_device && F) {

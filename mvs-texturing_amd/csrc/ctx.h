@@ -131,13 +131,31 @@ struct mvs_ctx {
     mvs::DBuf<size_t> view_off;
     bool mesh_dirty = true, views_dirty = true;
 
+    // ---- the library's own mesh layout (k_bvh.hip build_scene_order; DESIGN.md "Face order") ----
+    // The caller's mesh arrives in file order (calculate_data_costs.cpp:136-138); nothing about it is assumed.  Every data-cost pass
+    // first lays the mesh out along a Hilbert curve: vertices by their position, faces by their centroid (refined by median splits
+    // inside 512-face windows: the BVH's leaf order).  i_verts / i_faces / i_normals are that copy -- vertex s of the copy is the
+    // s-th vertex of the curve, face p the p-th face -- and everything downstream (culls, rays, footprints, the cost table, the
+    // solver's nodes, the parts of the sharded path) is indexed by those positions.  f_perm[p] = the caller's id of face p, f_pos its
+    // inverse; results cross the ABI in the caller's numbering.  Option "face_order" = 0 keeps the caller's face numbering (a caller
+    // that laid the faces out itself; the building-block API of mgpu.hip); vertices are renumbered either way (invisible outside).
+    int face_order = 1;
+    mvs::DBuf<float> i_verts, i_normals; mvs::DBuf<uint32_t> i_faces, f_perm, f_pos, f_tmp;
+    const float* iv = nullptr; const uint32_t* ifc = nullptr; const float* inr = nullptr;   // the arrays the kernels read (i_* or the caller's)
+    bool mesh_ordered = false;        // f_perm / f_pos describe the resident mesh (set by build_scene_order when face_order != 0)
+    // order of the ACTIVE cost table (r_ptr ...): t_perm[p] = caller's id of column p (null: the table is in the caller's order)
+    const uint32_t* t_perm = nullptr; const uint32_t* t_pos = nullptr;
+    mvs::DBuf<uint32_t> u_ptr, u_cnt; mvs::DBuf<uint16_t> u_view; mvs::DBuf<float> u_cost, u_q;   // the table in the caller's order (built on demand)
+    bool u_valid = false;
+
     // ---- BVH + incidence ----
     mvs::DBuf<mvs::Node4> bvh_nodes; mvs::DBuf<float4> bvh_tris;
     mvs::DBuf<uint32_t> sort_k, sort_k2, sort_v, sort_v2; mvs::DBuf<char> sort_tmp;
     mvs::DBuf<float> lvl_box_a, lvl_box_b; mvs::DBuf<float> scene_box;
     mvs::BvhDev bvh{};
     mvs::DBuf<uint32_t> vf_ptr, vf_cursor, vf;
-    mvs::DBuf<uint32_t> vperm, vpos;   // vertices in Hilbert order and the inverse map
+    mvs::DBuf<uint32_t> vperm, vpos;   // vertices in Hilbert order and the inverse map (caller's vertex ids; used to build i_verts / i_faces only)
+    const uint32_t* tri_order = nullptr;   // BVH triangle slot -> face position (null: identity, the faces ARE in curve order)
 
     // ---- data costs work buffers ----
     mvs::DBuf<unsigned long long> pass_bits, need_bits, occl_bits, surv_bits;
@@ -168,11 +186,11 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> p_label_ptr, p_comp_ptr, p_comp_faces, p_parent, p_root, p_state, p_flag, p_pos, p_roots, p_roots2, p_rlab, p_rlab2, p_adj_ptr, p_adj, p_labels;
 
     // ---- region moves (k_region.hip) ----
-    mvs::DBuf<uint32_t> rg_parent, rg_root, rg_size, rg_bestl, rg_lose, rg_flag, rg_pos, rg_cstart, rg_have, rg_cfirst;
+    mvs::DBuf<uint32_t> rg_parent, rg_root, rg_size, rg_bestl, rg_lose, rg_flag, rg_pos, rg_cstart, rg_have, rg_cfirst, rg_name;
     mvs::DBuf<unsigned long long> rg_gain, rg_cur, rg_key, rg_key2, rg_ck, rg_sum; mvs::DBuf<long long> rg_cgain; mvs::DBuf<uint2> rg_cut;
 
     // ---- MRF ----
-    mvs::DBuf<uint32_t> m_adj_ptr, m_adj; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;
+    mvs::DBuf<uint32_t> m_adj_ptr, m_adj, a_stage_ptr, a_stage; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;   // a_stage*: host lists on their way into the table's order
     mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; mvs::DBuf<uint32_t> m_rec; uint64_t m_rec_words = 0; bool m_fast = false; int mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size; mvs::DBuf<uint16_t> m_map;
     mvs::DBuf<uint8_t> m_msg_a;    // messages as 8-bit fixed point over [0, 1/rho], updated in place (one colour class at a time)

@@ -221,7 +221,7 @@ __global__ void gather_tris_kernel(const float* __restrict__ verts, const uint32
     if (s >= n_slots) return;
     float4 a = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0}, h = {0, 0, 0, 0};
     if (s < n_faces) {
-        const uint32_t* fv = faces + 3 * (size_t)order[s];
+        const uint32_t* fv = faces + 3 * (size_t)(order ? order[s] : s);   // order == null: the faces are in curve order themselves
         const V3 pa = {verts[3 * (size_t)fv[0]], verts[3 * (size_t)fv[0] + 1], verts[3 * (size_t)fv[0] + 2]};
         const V3 pb = {verts[3 * (size_t)fv[1]], verts[3 * (size_t)fv[1] + 1], verts[3 * (size_t)fv[1] + 2]};
         const V3 pc = {verts[3 * (size_t)fv[2]], verts[3 * (size_t)fv[2] + 1], verts[3 * (size_t)fv[2] + 2]};
@@ -459,7 +459,7 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
 // (profiles/r03a_pmc_sq_c3.json): vector issue 41 %, waves parked on memory 46 % of their time -- so residency is throughput:
 // 6.63 -> 6.33 (7 blocks) -> 6.02 ms (8 blocks) at BASELINE config 3, A/B of builds on one box (scripts/ab_libs.py).
 template <bool XCD, bool COUNT>
-__global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts, const uint32_t* __restrict__ vperm,
+__global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) ray_packet3_kernel(const BvhDev bvh, const float* __restrict__ verts /* curve order: ctx->iv */,
                                                           const ViewParams* __restrict__ views, const unsigned long long* __restrict__ need,
                                                           unsigned long long* __restrict__ occl, uint32_t vwords, uint32_t n_verts, uint32_t n_views,
                                                           const uint32_t* __restrict__ scene_box, unsigned long long* __restrict__ counters) {
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) r
     if (word == 0ull) return;  // occl is pre-zeroed
     const uint32_t s = vw * 64 + lane;
     const bool active = ((word >> lane) & 1ull) && s < n_verts;
-    const uint32_t v = vperm[s < n_verts ? s : 0];
+    const uint32_t v = s < n_verts ? s : 0;
     const ViewParams& vp = views[j];
     const V3 o = {verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2]};
     const float pad = pad_from_box(scene_box);
@@ -524,30 +524,115 @@ void build_vertex_faces(mvs_ctx* ctx, const uint32_t* d_faces, uint32_t F, uint3
     if (F) { hipLaunchKernelGGL(vf_fill_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, s, d_faces, F, ctx->vf_ptr.p, ctx->vf_cursor.p, ctx->vf.p); MVS_LAUNCH_CHECK(); }
 }
 
-// Builds the BVH and the vertex->face incidence for the resident mesh.
+// ---- the library's own mesh layout (ctx.h "the library's own mesh layout") ----
+namespace {
+__global__ void gather_verts_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ vperm, uint32_t n_verts, float* __restrict__ out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_verts) return;
+    const size_t v = vperm[s];
+    out[3 * (size_t)s] = verts[3 * v]; out[3 * (size_t)s + 1] = verts[3 * v + 1]; out[3 * (size_t)s + 2] = verts[3 * v + 2];
+}
+// out[p] = the face order[p] (null: p) of `faces` with its vertex indices mapped through vpos (null: kept)
+__global__ void remap_faces_kernel(const uint32_t* __restrict__ faces, const uint32_t* __restrict__ order, const uint32_t* __restrict__ vpos, uint32_t n_faces,
+                                   uint32_t* __restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_faces) return;
+    const size_t f = order ? order[p] : p;
+    const uint32_t a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+    out[3 * (size_t)p] = vpos ? vpos[a] : a; out[3 * (size_t)p + 1] = vpos ? vpos[b] : b; out[3 * (size_t)p + 2] = vpos ? vpos[c] : c;
+}
+// f_perm[p] = first[loc[p]] (the caller's id of the face at position p), f_pos = its inverse, normals gathered along
+__global__ void finish_order_kernel(const uint32_t* __restrict__ first, const uint32_t* __restrict__ loc, const float* __restrict__ normals, uint32_t n_faces,
+                                    uint32_t* __restrict__ f_perm, uint32_t* __restrict__ f_pos, float* __restrict__ out_normals) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_faces) return;
+    const size_t f = first[loc[p]];
+    f_perm[p] = (uint32_t)f; f_pos[f] = p;
+    out_normals[3 * (size_t)p] = normals[3 * f]; out_normals[3 * (size_t)p + 1] = normals[3 * f + 1]; out_normals[3 * (size_t)p + 2] = normals[3 * f + 2];
+}
+__global__ void iota_kernel(uint32_t* __restrict__ v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+void sort_by_key30(mvs_ctx* ctx, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, uint32_t n) {
+    size_t tmp_bytes = 0;
+    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, n, 0, 30, ctx->stream));
+    ctx->sort_tmp.ensure(tmp_bytes + 16);
+    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, n, 0, 30, ctx->stream));
+}
+}  // namespace
+
+// Lays the resident mesh out along a Hilbert curve: ctx->iv / ifc / inr (see ctx.h) and, with option "face_order" != 0, the face
+// permutation f_perm / f_pos.  The caller's arrays are read with gathers exactly three times (the keys, the faces, the normals);
+// everything after this function streams the copy.  Deterministic (stable sorts, ties by id): every rank of a sharded run derives
+// the same order from the replicated mesh.
+void build_scene_order(mvs_ctx* ctx) {
+    const uint32_t F = ctx->n_faces, NV = ctx->n_verts;
+    hipStream_t s = ctx->stream;
+    ctx->scene_box.ensure(8);
+    uint32_t* box = (uint32_t*)ctx->scene_box.p;
+    const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
+    ctx->mesh_ordered = false; ctx->tri_order = nullptr;
+    ctx->iv = ctx->d_verts; ctx->ifc = ctx->d_faces; ctx->inr = ctx->d_normals;
+    if (F == 0 || NV == 0) return;
+    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 512u)), dim3(256), 0, s, ctx->d_verts, NV, box);
+    MVS_LAUNCH_CHECK();
+    const size_t n_max = std::max<size_t>(F, NV);
+    ctx->sort_k.ensure(n_max); ctx->sort_k2.ensure(n_max); ctx->sort_v.ensure(n_max); ctx->sort_v2.ensure(F);
+    // vertices along the curve (rays are launched in this order: 64 neighbouring vertices per wave = a compact patch of nearly parallel rays)
+    ctx->vperm.ensure((size_t)NV + 1); ctx->vpos.ensure((size_t)NV + 1); ctx->i_verts.ensure(3 * (size_t)NV + 4);
+    hipLaunchKernelGGL(vertex_key_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->d_verts, NV, box, ctx->sort_k.p, ctx->sort_v.p);
+    MVS_LAUNCH_CHECK();
+    sort_by_key30(ctx, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->vperm.p, NV);
+    hipLaunchKernelGGL(invert_perm_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->vperm.p, NV, ctx->vpos.p);
+    MVS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gather_verts_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->vperm.p, NV, ctx->i_verts.p);
+    MVS_LAUNCH_CHECK();
+    ctx->iv = ctx->i_verts.p;
+    ctx->i_faces.ensure(3 * (size_t)F + 4);
+    static_assert(RW == 2 * 256 && RW % (int)LEAF_T == 0, "one pair per thread");
+    const dim3 fg((F + 255) / 256), rg((F + RW - 1) / RW);
+    if (ctx->face_order != 0) {
+        // faces along the curve: keys from the caller's arrays, the refinement and everything later on the copy
+        ctx->f_tmp.ensure(3 * (size_t)F + 4); ctx->f_perm.ensure((size_t)F + 1); ctx->f_pos.ensure((size_t)F + 1); ctx->i_normals.ensure(3 * (size_t)F + 4);
+        hipLaunchKernelGGL(curve_key_kernel, fg, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, F, box, ctx->sort_k.p, ctx->sort_v.p);
+        MVS_LAUNCH_CHECK();
+        sort_by_key30(ctx, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F);
+        hipLaunchKernelGGL(remap_faces_kernel, fg, dim3(256), 0, s, ctx->d_faces, (const uint32_t*)ctx->sort_v2.p, (const uint32_t*)ctx->vpos.p, F, ctx->f_tmp.p);
+        MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(iota_kernel, fg, dim3(256), 0, s, ctx->sort_v.p, F);
+        MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(refine_order_kernel, rg, dim3(256), 0, s, (const float*)ctx->i_verts.p, (const uint32_t*)ctx->f_tmp.p, ctx->sort_v.p, F);
+        MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(remap_faces_kernel, fg, dim3(256), 0, s, (const uint32_t*)ctx->f_tmp.p, (const uint32_t*)ctx->sort_v.p, (const uint32_t*)nullptr, F, ctx->i_faces.p);
+        MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(finish_order_kernel, fg, dim3(256), 0, s, (const uint32_t*)ctx->sort_v2.p, (const uint32_t*)ctx->sort_v.p, ctx->d_normals, F, ctx->f_perm.p, ctx->f_pos.p, ctx->i_normals.p);
+        MVS_LAUNCH_CHECK();
+        ctx->ifc = ctx->i_faces.p; ctx->inr = ctx->i_normals.p; ctx->mesh_ordered = true;
+    } else {
+        // the caller's face numbering is kept: only the BVH's triangle slots follow the curve
+        hipLaunchKernelGGL(remap_faces_kernel, fg, dim3(256), 0, s, ctx->d_faces, (const uint32_t*)nullptr, (const uint32_t*)ctx->vpos.p, F, ctx->i_faces.p);
+        MVS_LAUNCH_CHECK();
+        ctx->ifc = ctx->i_faces.p;
+        hipLaunchKernelGGL(curve_key_kernel, fg, dim3(256), 0, s, ctx->iv, ctx->ifc, F, box, ctx->sort_k.p, ctx->sort_v.p);
+        MVS_LAUNCH_CHECK();
+        sort_by_key30(ctx, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F);
+        hipLaunchKernelGGL(refine_order_kernel, rg, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->sort_v2.p, F);
+        MVS_LAUNCH_CHECK();
+        ctx->tri_order = ctx->sort_v2.p;
+    }
+}
+
+// Builds the BVH and the vertex->face incidence for the resident mesh in the layout of build_scene_order.
 void build_bvh(mvs_ctx* ctx) {
     const uint32_t F = ctx->n_faces, NV = ctx->n_verts;
     hipStream_t s = ctx->stream;
     const uint32_t n_leaves = (F + LEAF_T - 1) / LEAF_T;
     const uint32_t n_slots = ((n_leaves + 3) / 4) * 4 * LEAF_T;  // triangles padded to whole level-0 nodes
-    ctx->scene_box.ensure(8);
     uint32_t* box = (uint32_t*)ctx->scene_box.p;
-    const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-    MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 512u)), dim3(256), 0, s, ctx->d_verts, NV, box);
-    MVS_LAUNCH_CHECK();
-    ctx->sort_k.ensure(std::max<size_t>(F, NV)); ctx->sort_k2.ensure(std::max<size_t>(F, NV)); ctx->sort_v.ensure(std::max<size_t>(F, NV)); ctx->sort_v2.ensure(F);
-    hipLaunchKernelGGL(curve_key_kernel, dim3((F + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, F, box, ctx->sort_k.p, ctx->sort_v.p);
-    MVS_LAUNCH_CHECK();
-    size_t tmp_bytes = 0;
-    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F, 0, 30, s));
-    ctx->sort_tmp.ensure(tmp_bytes + 16);
-    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F, 0, 30, s));
-    static_assert(RW == 2 * 256 && RW % (int)LEAF_T == 0, "one pair per thread");
-    hipLaunchKernelGGL(refine_order_kernel, dim3((F + RW - 1) / RW), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->sort_v2.p, F);
-    MVS_LAUNCH_CHECK();
     ctx->bvh_tris.ensure(TRI_F4 * (size_t)n_slots);
-    hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->sort_v2.p, F, n_slots, box, ctx->bvh_tris.p);
+    hipLaunchKernelGGL(gather_tris_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->tri_order, F, n_slots, box, ctx->bvh_tris.p);
     MVS_LAUNCH_CHECK();
     // level sizes
     BvhDev b{};
@@ -581,17 +666,7 @@ void build_bvh(mvs_ctx* ctx) {
     }
     b.nodes = ctx->bvh_nodes.p; b.tris = ctx->bvh_tris.p;
     ctx->bvh = b;
-    // vertices in Hilbert order (ray launch order)
-    ctx->vperm.ensure((size_t)NV + 1); ctx->vpos.ensure((size_t)NV + 1);
-    ctx->sort_k.ensure(std::max<size_t>(F, NV)); ctx->sort_k2.ensure(std::max<size_t>(F, NV)); ctx->sort_v.ensure(std::max<size_t>(F, NV));
-    hipLaunchKernelGGL(vertex_key_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->d_verts, NV, box, ctx->sort_k.p, ctx->sort_v.p);
-    MVS_LAUNCH_CHECK();
-    MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->vperm.p, NV, 0, 30, s));
-    ctx->sort_tmp.ensure(tmp_bytes + 16);
-    MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->vperm.p, NV, 0, 30, s));
-    hipLaunchKernelGGL(invert_perm_kernel, dim3((NV + 255) / 256), dim3(256), 0, s, ctx->vperm.p, NV, ctx->vpos.p);
-    MVS_LAUNCH_CHECK();
-    build_vertex_faces(ctx, ctx->d_faces, F, NV);
+    build_vertex_faces(ctx, ctx->ifc, F, NV);
 }
 
 void trace_rays(mvs_ctx* ctx) {
@@ -601,7 +676,7 @@ void trace_rays(mvs_ctx* ctx) {
     blocks = (blocks + 7) & ~7ull;   // multiple of 8 for the XCD-aware order (surplus waves exit)
     if (blocks > 0x7FFFFFFFull) throw HipError("ray grid too large");
     unsigned long long* counters = (ctx->stats || ctx->count_rays) ? ctx->counters.p : nullptr;
-#define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->d_verts, ctx->vperm.p, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
+#define RAY_ARGS dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->bvh, ctx->iv, ctx->d_views.p, ctx->need_bits.p, ctx->occl_bits.p, \
                  vwords, ctx->n_verts, ctx->n_views, (const uint32_t*)ctx->scene_box.p, counters
     if (ctx->count_rays) { if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet3_kernel<true, true>), RAY_ARGS); else hipLaunchKernelGGL((ray_packet3_kernel<false, true>), RAY_ARGS); }
     else { if (ctx->ray_xcd) hipLaunchKernelGGL((ray_packet3_kernel<true, false>), RAY_ARGS); else hipLaunchKernelGGL((ray_packet3_kernel<false, false>), RAY_ARGS); }

@@ -18,6 +18,7 @@
 namespace mvs {
 
 void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const size_t* d_mask_off);
+void build_scene_order(mvs_ctx* ctx);
 void build_bvh(mvs_ctx* ctx);
 void trace_rays(mvs_ctx* ctx);
 
@@ -80,16 +81,16 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
 }
 
 // ---- which (vertex, view) rays are needed: OR of the pass bits of the incident faces ----
-// (thread s handles the s-th vertex in Hilbert order: need / occluded bits are indexed by that position)
+// (thread s handles vertex s of the library's copy of the mesh = the s-th vertex of the Hilbert curve: need / occluded bits are indexed by it)
 template <bool STATS>
-__global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, const uint32_t* __restrict__ vperm, uint32_t n_verts, uint32_t n_views,
+__global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ vf_ptr, const uint32_t* __restrict__ vf, uint32_t n_verts, uint32_t n_views,
                                                    uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
                                                    const uint32_t* __restrict__ pass_face /* [view chunk][face]: the chunk's pass bits of a face (cull_kernel) */,
                                                    unsigned long long* __restrict__ need, unsigned long long* __restrict__ counters) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if ((v >> 6) >= vwords) return;  // whole wave beyond the vertex range
     const bool act = v < n_verts;
-    const uint32_t vid = act ? vperm[v] : 0;
+    const uint32_t vid = act ? v : 0;
     const uint32_t p0 = act ? vf_ptr[vid] : 0, p1 = act ? vf_ptr[vid + 1] : 0;
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
@@ -120,7 +121,6 @@ template <int DATA_TERM, bool OUTLIER, bool VISTEST, bool STATS, bool WORDS>
 __global__ void __launch_bounds__(256, WORDS ? 6 : 1) info_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const ViewParams* __restrict__ views,
                                                    uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords, uint32_t vwords,
                                                    const unsigned long long* __restrict__ pass, const unsigned long long* __restrict__ occl,
-                                                   const uint32_t* __restrict__ vpos,
                                                    const uint32_t* __restrict__ pass_base, float* __restrict__ pq, float* __restrict__ pcol,
                                                    unsigned long long* __restrict__ surv, unsigned long long* __restrict__ counters,
                                                    float defer_area /* footprints above this area are left to wave_info_kernel (+inf: none) */,
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256, WORDS ? 6 : 1) info_kernel(const float* _
     const size_t f = (size_t)fb + (act ? lf : 0);
     const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const V3 v1 = ld3(verts, i0), v2 = ld3(verts, i1), v3 = ld3(verts, i2);
-    const uint32_t s0 = VISTEST ? vpos[i0] : 0u, s1 = VISTEST ? vpos[i1] : 0u, s2 = VISTEST ? vpos[i2] : 0u;  // bit positions of the 3 rays
+    const uint32_t s0 = i0, s1 = i1, s2 = i2;  // bit positions of the 3 rays: the vertices of the library's copy are numbered along the curve the rays are launched in
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -806,6 +806,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     const uint32_t fwords = (nf + 63) / 64, vwords = (ctx->n_verts + 63) / 64;
     const bool gmi = st->data_term == MVS_DATA_TERM_GMI, outl = st->outlier_removal != MVS_OUTLIER_NONE, vis = st->geometric_visibility_test != 0;
     ctx->dc_settings = *st; ctx->have_costs = false;
+    ctx->t_perm = nullptr; ctx->t_pos = nullptr; ctx->u_valid = false;
     memset(&ctx->dc_stats, 0, sizeof(ctx->dc_stats));
     ctx->dc_stats.pairs = (uint64_t)nf * V;
     ctx->counters.ensure(64);
@@ -820,6 +821,10 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         ctx->max_q.ensure(4); MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 4 * sizeof(float), s));
         return;
     }
+    // the mesh in the library's own layout (faces [fb, fb + nf) are POSITIONS of that layout); a table over the whole mesh remembers
+    // its order so that it crosses the ABI in the caller's numbering
+    { Prof pr(ctx, "dc_order"); build_scene_order(ctx); }
+    if (ctx->mesh_ordered && fb == 0 && nf == ctx->n_faces) { ctx->t_perm = ctx->f_perm.p; ctx->t_pos = ctx->f_pos.p; }
     { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }   /* :157-163 */
     if (vis) { Prof pr(ctx, "dc_bvh_build"); build_bvh(ctx); }           /* :144 */
 
@@ -830,10 +835,10 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     if (vis) { ctx->pass_face.ensure((size_t)fgrid.y * fwords * 64u + 1); pass_face = ctx->pass_face.p; }
     Prof pr_cull(ctx, "dc_cull");
     if (ctx->stats)
-        hipLaunchKernelGGL(cull_kernel<true>, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
+        hipLaunchKernelGGL(cull_kernel<true>, fgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->inr, ctx->d_views.p, V, fb, nf, fwords,
                            ctx->cos_limit, ctx->pass_bits.p, pass_face, ctx->counters.p);
     else
-        hipLaunchKernelGGL(cull_kernel<false>, fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_normals, ctx->d_views.p, V, fb, nf, fwords,
+        hipLaunchKernelGGL(cull_kernel<false>, fgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->inr, ctx->d_views.p, V, fb, nf, fwords,
                            ctx->cos_limit, ctx->pass_bits.p, pass_face, ctx->counters.p);
     MVS_LAUNCH_CHECK();
     pr_cull.end();
@@ -844,10 +849,10 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         const dim3 vgrid((ctx->n_verts + 255) / 256, (V + VIEW_CHUNK - 1) / VIEW_CHUNK);
         Prof pr_need(ctx, "dc_need");
         if (ctx->stats)
-            hipLaunchKernelGGL(need_kernel<true>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
+            hipLaunchKernelGGL(need_kernel<true>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->n_verts, V, fb, nf, fwords, vwords,
                                pass_face, ctx->need_bits.p, ctx->counters.p);
         else
-            hipLaunchKernelGGL(need_kernel<false>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->vperm.p, ctx->n_verts, V, fb, nf, fwords, vwords,
+            hipLaunchKernelGGL(need_kernel<false>, vgrid, dim3(256), 0, s, ctx->vf_ptr.p, ctx->vf.p, ctx->n_verts, V, fb, nf, fwords, vwords,
                                pass_face, ctx->need_bits.p, ctx->counters.p);
         MVS_LAUNCH_CHECK();
         pr_need.end();
@@ -882,8 +887,8 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
 #define LAUNCH_INFO(DT, OL, VT, WD)                                                                                          \
     do { if (ctx->stats) LAUNCH_INFO2(DT, OL, VT, true, WD); else LAUNCH_INFO2(DT, OL, VT, false, WD); } while (0)
 #define LAUNCH_INFO2(DT, OL, VT, ST, WD)                                                                                     \
-    hipLaunchKernelGGL((info_kernel<DT, OL, VT, ST, WD>), fgrid, dim3(256), 0, s, ctx->d_verts, ctx->d_faces, ctx->d_views.p, V, fb, nf, \
-                       fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->vpos.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
+    hipLaunchKernelGGL((info_kernel<DT, OL, VT, ST, WD>), fgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->d_views.p, V, fb, nf, \
+                       fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
                        ctx->surv_bits.p, ctx->counters.p, defer_area, defer_bits, ctx->info_cert_shift)
     const bool words = defer && ctx->info_words;   // the integer walk needs the lane-group kernel behind it (for what it cannot certify)
     if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true, false); else LAUNCH_INFO(1, true, false, false); }
@@ -906,8 +911,8 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
             ctx->defer_list.ensure((size_t)n_def + 1);
             hipLaunchKernelGGL(defer_expand_kernel, dim3((unsigned)((pw + 255) / 256)), dim3(256), 0, s, defer_bits, ctx->defer_base.p, pw, ctx->defer_list.p); MVS_LAUNCH_CHECK();
             const dim3 wgrid((unsigned)(((size_t)n_def * 16 + 255) / 256));
-#define WAVE_ARGS ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, n_def, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p, ctx->info_cert_shift, ctx->rewalk_list.p
-#define REWALK_ARGS ctx->d_verts, ctx->d_faces, ctx->d_views.p, fb, fwords, ctx->defer_list.p, ctx->rewalk_list.p, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p
+#define WAVE_ARGS ctx->iv, ctx->ifc, ctx->d_views.p, fb, fwords, ctx->defer_list.p, n_def, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p, ctx->info_cert_shift, ctx->rewalk_list.p
+#define REWALK_ARGS ctx->iv, ctx->ifc, ctx->d_views.p, fb, fwords, ctx->defer_list.p, ctx->rewalk_list.p, ctx->pass_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p, ctx->surv_bits.p, ctx->counters.p
 #define LAUNCH_WAVE(DT, OL) do { if (ctx->stats) { hipLaunchKernelGGL((wave_info_kernel<DT, OL, true>), wgrid, dim3(256), 0, s, WAVE_ARGS); hipLaunchKernelGGL((rewalk_info_kernel<DT, OL, true>), rgrid, dim3(64), 0, s, REWALK_ARGS); } \
                                  else { hipLaunchKernelGGL((wave_info_kernel<DT, OL, false>), wgrid, dim3(256), 0, s, WAVE_ARGS); hipLaunchKernelGGL((rewalk_info_kernel<DT, OL, false>), rgrid, dim3(64), 0, s, REWALK_ARGS); } } while (0)
             ctx->rewalk_list.ensure((size_t)n_def + 1);
@@ -1081,6 +1086,7 @@ void dc_postprocess(mvs_ctx* ctx, uint32_t nf, uint32_t n_views, const uint32_t*
     const bool outl = st->outlier_removal != MVS_OUTLIER_NONE;
     const uint32_t n = h_ptr[nf];
     ctx->dc_settings = *st; ctx->have_costs = false;
+    ctx->t_perm = nullptr; ctx->t_pos = nullptr; ctx->u_valid = false;   // the caller's infos, the caller's order
     memset(&ctx->dc_stats, 0, sizeof(ctx->dc_stats));
     ctx->dc_stats.nnz_pre = n;
     ctx->counters.ensure(64);

@@ -215,16 +215,19 @@ __global__ void mrf_colour_init_kernel(uint32_t* __restrict__ colour, uint32_t* 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < F) { colour[i] = NO_COLOUR; iota[i] = i; }
 }
-__global__ void mrf_colour_round_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, uint32_t F,
+// `orig` (null: identity) = the caller's id of every node: the keys are those of the CALLER's numbering, so the colouring -- hence the
+// labeling -- does not depend on the order the library keeps the nodes in (ctx.h "the library's own mesh layout").
+__global__ void mrf_colour_round_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const uint32_t* __restrict__ orig, uint32_t F,
                                         uint32_t* colour, uint32_t* __restrict__ pending) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
     if (__hip_atomic_load(colour + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NO_COLOUR) return;
     unsigned long long used = 0ull;
     bool ready = true;
+    const uint32_t oi = orig ? orig[i] : i;
     for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
         const uint32_t j = adj[e];
-        if (j == i || !mrf_key_less(j, i)) continue;
+        if (j == i || !mrf_key_less(orig ? orig[j] : j, oi)) continue;
         const uint32_t cj = __hip_atomic_load(colour + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cj == NO_COLOUR) { ready = false; break; }
         used |= 1ull << cj;
@@ -916,7 +919,8 @@ __global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __re
                                                             const float* __restrict__ gain, const uint32_t* __restrict__ cand,
                                                             uint32_t* sel, uint32_t* lab, float* selcost,
                                                             uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ moved /* [0] nodes moved, [1] list length */,
-                                                            uint32_t* __restrict__ alist /* null, or: nodes whose gain has to be re-evaluated */) {
+                                                            uint32_t* __restrict__ alist /* null, or: nodes whose gain has to be re-evaluated */,
+                                                            const uint32_t* __restrict__ orig /* null: identity; ties between equal gains go to the smaller id of the CALLER's numbering */) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     bool mv = false;
     if (i < node_end) {
@@ -927,7 +931,7 @@ __global__ void __launch_bounds__(256) mrf_icm_apply_kernel(const uint32_t* __re
                 const uint32_t j = adj[e];
                 if (lab[j] == 0u) continue;               // edge not in the model (gain[j] is 0 anyway)
                 const float gj = gain[j];
-                if (gj > gi || (gj == gi && j < i)) win = false;
+                if (gj > gi || (gj == gi && (orig ? orig[j] < orig[i] : j < i))) win = false;
             }
             if (win) mv = true;
         }
@@ -963,13 +967,14 @@ __global__ void mrf_argmin_unary_kernel(const uint32_t* __restrict__ col_ptr, co
 
 /* label extraction (view_selection.cpp:120-132): labels are already decoded; range check + unseen count */
 __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t node_begin, uint32_t node_end, uint32_t n_views,
-                                  uint32_t* __restrict__ labels, uint32_t* __restrict__ bad_unseen /* [0] bad, [1] unseen */) {
+                                  uint32_t* __restrict__ labels, uint32_t* __restrict__ bad_unseen /* [0] bad, [1] unseen */,
+                                  const uint32_t* __restrict__ orig /* non-null: labels[orig[i]] = label of node i (the caller's numbering) */) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= node_end) return;
     const uint32_t label = lab[i];
     if (label > n_views) atomicAdd(&bad_unseen[0], 1u);       /* :126-128 "Incorrect labeling" */
     if (label == 0u) atomicAdd(&bad_unseen[1], 1u);            /* :129 */
-    labels[i - node_begin] = label;
+    labels[orig ? orig[i] : i - node_begin] = label;
 }
 
 
@@ -1079,7 +1084,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
             if (round >= 4096) throw StatusError(MVS_ERR_HIP, "graph colouring did not terminate");
             MVS_HIP(hipMemsetAsync(pending, 0, sizeof(uint32_t), s));
             // a batch of rounds per read-back: 8 first (large meshes need ~12 rounds, a round costs 10 us, a read-back 25), then 4
-            for (int k = 0; k < (round == 0 ? 8 : 4); ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
+            for (int k = 0; k < (round == 0 ? 8 : 4); ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, ctx->t_perm, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
             uint32_t hp[2] = {0, 0};   // set if any round of the batch left a node waiting
             MVS_HIP(hipMemcpyAsync(hp, pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             MVS_HIP(hipStreamSynchronize(s));
@@ -1461,16 +1466,17 @@ void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
         alist = ctx->m_alist.p;
     }
     hipLaunchKernelGGL(mrf_icm_apply_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                       ctx->m_gain.p, ctx->m_cand.p, ctx->b_sel, ctx->b_lab, ctx->b_cost, nb0, ne0, ctx->m_moved.p, alist);
+                       ctx->m_gain.p, ctx->m_cand.p, ctx->b_sel, ctx->b_lab, ctx->b_cost, nb0, ne0, ctx->m_moved.p, alist, ctx->t_perm);
     MVS_LAUNCH_CHECK();
 }
 // labels of nodes [nb0, ne0) of the best labeling into d_labels[0 .. ne0 - nb0); out = {bad, unseen}
-void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]) {
+// (caller_order: the whole graph's labels at the caller's face ids -- ctx->t_perm; otherwise positions nb0 .. of the table's order)
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2], bool caller_order) {
     uint32_t* bu = ctx->m_moved.p + 2;
     resolve_best(ctx);
     MVS_HIP(hipMemsetAsync(bu, 0, 2 * sizeof(uint32_t), ctx->stream));
     if (ne0 > nb0) {
-        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->b_lab, nb0, ne0, ctx->csr_views, d_labels, bu);
+        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->b_lab, nb0, ne0, ctx->csr_views, d_labels, bu, caller_order ? ctx->t_perm : (const uint32_t*)nullptr);
         MVS_LAUNCH_CHECK();
     }
     MVS_HIP(hipMemcpyAsync(out, bu, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

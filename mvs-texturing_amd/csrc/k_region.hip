@@ -165,12 +165,20 @@ __global__ void rg_label_kernel(const unsigned long long* __restrict__ ck, uint3
     const uint32_t R = (uint32_t)(ck[c] >> 16);
     if (cgain[c] > 0 && (unsigned long long)cgain[c] == gain[R]) atomicMin(&bestl[R], (uint32_t)(ck[c] & 0xFFFFull));
 }
-__global__ void rg_lose_kernel(const uint2* __restrict__ cut, uint32_t n_cut, const uint32_t* __restrict__ root, const unsigned long long* __restrict__ gain, uint32_t* __restrict__ lose) {
+// A region is NAMED by its smallest face in the caller's numbering (the oracle's): when the library keeps the nodes in its own order
+// (orig != null) the union-find root is the smallest POSITION, and the name -- needed only to break ties between equal gains --
+// is the minimum of the caller's ids over the region's faces.
+__global__ void rg_name_kernel(const uint32_t* __restrict__ root, const uint32_t* __restrict__ orig, uint32_t n, uint32_t* __restrict__ name) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMin(&name[root[i]], orig[i]);
+}
+__global__ void rg_lose_kernel(const uint2* __restrict__ cut, uint32_t n_cut, const uint32_t* __restrict__ root, const unsigned long long* __restrict__ gain,
+                               const uint32_t* __restrict__ name /* null: a region's name is its root */, uint32_t* __restrict__ lose) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_cut) return;
     const uint32_t R = root[cut[k].x], S = root[cut[k].y];
     const unsigned long long gR = gain[R], gS = gain[S];
-    if (gS > gR || (gS == gR && S < R)) lose[R] = 1u;      // racing stores of the same value
+    if (gS > gR || (gS == gR && (name ? name[S] < name[R] : S < R))) lose[R] = 1u;      // racing stores of the same value
 }
 __global__ void rg_apply_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost, const uint32_t* __restrict__ root,
                                 const unsigned long long* __restrict__ gain, const uint32_t* __restrict__ bestl, const uint32_t* __restrict__ lose, uint32_t n,
@@ -234,7 +242,14 @@ uint32_t mrf_region_round(mvs_ctx* ctx) {
     const unsigned cb = (nC + 255) / 256;
     hipLaunchKernelGGL(rg_gain_kernel, dim3(cb), dim3(256), 0, s, ctx->rg_ck.p, ctx->rg_cstart.p, nC, ctx->rg_size.p, ctx->rg_cur.p, ctx->rg_have.p, ctx->rg_sum.p, ctx->rg_cgain.p, ctx->rg_gain.p); MVS_LAUNCH_CHECK();
     hipLaunchKernelGGL(rg_label_kernel, dim3(cb), dim3(256), 0, s, ctx->rg_ck.p, nC, ctx->rg_cgain.p, ctx->rg_gain.p, ctx->rg_bestl.p); MVS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rg_lose_kernel, dim3((n_cut + 255) / 256), dim3(256), 0, s, ctx->rg_cut.p, n_cut, ctx->rg_root.p, ctx->rg_gain.p, ctx->rg_lose.p); MVS_LAUNCH_CHECK();
+    const uint32_t* name = nullptr;
+    if (ctx->t_perm) {
+        ctx->rg_name.ensure((size_t)F + 2);
+        MVS_HIP(hipMemsetAsync(ctx->rg_name.p, 0xFF, (size_t)F * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(rg_name_kernel, dim3(nb), dim3(256), 0, s, ctx->rg_root.p, ctx->t_perm, F, ctx->rg_name.p); MVS_LAUNCH_CHECK();
+        name = ctx->rg_name.p;
+    }
+    hipLaunchKernelGGL(rg_lose_kernel, dim3((n_cut + 255) / 256), dim3(256), 0, s, ctx->rg_cut.p, n_cut, ctx->rg_root.p, ctx->rg_gain.p, name, ctx->rg_lose.p); MVS_LAUNCH_CHECK();
     ctx->m_moved.ensure(8 + 2 * 64);
     MVS_HIP(hipMemsetAsync(ctx->m_moved.p + 7, 0, sizeof(uint32_t), s));
     hipLaunchKernelGGL(rg_apply_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->rg_root.p, ctx->rg_gain.p, ctx->rg_bestl.p, ctx->rg_lose.p, F,

@@ -15,9 +15,9 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
-void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2], bool caller_order = false);
 void resolve_best(mvs_ctx* ctx);
-void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device);
+void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device, bool table_order);
 mvs_status api_fail(mvs_status st, const std::string& msg);
 
 namespace {
@@ -128,7 +128,7 @@ mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32
     if (!ctx->have_costs) return api_fail(MVS_ERR_STATE, "mrf setup needs data costs");
     MVS_API_BEGIN
     mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
-    set_adjacency(ctx, adj_ptr, adj, adj_on_device);
+    set_adjacency(ctx, adj_ptr, adj, adj_on_device, false);
     mrf_setup(ctx, &P);
     MVS_API_END
 }

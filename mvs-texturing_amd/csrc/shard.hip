@@ -26,6 +26,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 
 namespace mvs {
@@ -41,9 +42,12 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
-void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2]);
+void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, uint32_t out[2], bool caller_order = false);
 void resolve_best(mvs_ctx* ctx);
-void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device);
+void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device, bool table_order);
+void build_scene_order(mvs_ctx* ctx);
+void renumber_adjacency(mvs_ctx* ctx, uint32_t F, const uint32_t* perm, const uint32_t* pos, const uint32_t* d_adj_ptr, const uint32_t* d_adj, size_t E,
+                        DBuf<uint32_t>& out_ptr, DBuf<uint32_t>& out_adj);
 mvs_status api_fail(mvs_status st, const std::string& msg);
 }  // namespace mvs
 
@@ -374,6 +378,10 @@ __global__ void unpack_columns_kernel(const uint32_t* __restrict__ faces, const 
     const uint32_t f = faces[k], p0 = col_ptr_l[f], K = col_ptr_l[f + 1] - p0, o = pos[k];
     for (uint32_t t = lane; t < K; t += 16) { const uint2 r = rec[o + t]; view_id[p0 + t] = (uint16_t)r.x; cost[p0 + t] = __uint_as_float(r.y); }
 }
+__global__ void iota_from_kernel(uint32_t* __restrict__ v, uint32_t first, uint32_t n) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) v[k] = first + k;
+}
 __global__ void face_len_kernel(const uint32_t* __restrict__ faces, uint32_t n, const uint32_t* __restrict__ counts_g, uint32_t* __restrict__ len) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k <= n) len[k] = k < n ? counts_g[faces[k]] : 0u;
@@ -387,7 +395,8 @@ __global__ void face_len_kernel(const uint32_t* __restrict__ faces, uint32_t n, 
 struct mvs_shard {
     mvs_ctx* ctx = nullptr; mvs_comm* comm = nullptr;
     Parts parts{}; int me = 0, P = 1; uint32_t F = 0, nb = 0, ne = 0;
-    const uint32_t* d_adj_ptr = nullptr; const uint32_t* d_adj = nullptr; uint32_t E = 0;
+    const uint32_t* d_adj_ptr = nullptr; const uint32_t* d_adj = nullptr; uint32_t E = 0;   // the adjacency lists in the LIBRARY's face order (see mvs_shard_create)
+    DBuf<uint32_t> own_adj_ptr, own_adj;
     // sharded table (global shape)
     DBuf<uint32_t> t_ptr; DBuf<uint16_t> t_view; DBuf<float> t_cost; DBuf<uint32_t> counts_g, keep, tmp_a, tmp_b, tmp_c;
     uint64_t nnz_global = 0;
@@ -619,19 +628,51 @@ mvs_status mvs_comm_create_local(int world, mvs_comm** out) {
 void mvs_comm_destroy(mvs_comm* comm) { delete comm; }
 
 mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_begin, const uint32_t* adj_ptr_device, const uint32_t* adj_device, mvs_shard** out) {
-    if (!ctx || !comm || !part_begin || !adj_ptr_device || !adj_device || !out) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (!ctx || !comm || !adj_ptr_device || !adj_device || !out) return api_fail(MVS_ERR_INVALID, "null argument");
     *out = nullptr;
     MVS_API_BEGIN
     MVS_HIP(hipSetDevice(ctx->device));
-    auto* S = new mvs_shard; S->ctx = ctx; S->comm = comm; S->me = comm->rank; S->P = comm->world;
+    if (!ctx->d_verts || !ctx->d_faces) throw StatusError(MVS_ERR_STATE, "the context needs the full mesh (mvs_scene_set_mesh) before a shard is made of it");
+    std::unique_ptr<mvs_shard> S(new mvs_shard); S->ctx = ctx; S->comm = comm; S->me = comm->rank; S->P = comm->world;
     S->parts.n = S->P;
-    for (int q = 0; q <= S->P; ++q) { S->parts.b[q] = part_begin[q]; if (q && part_begin[q] < part_begin[q - 1]) { delete S; throw StatusError(MVS_ERR_INVALID, "part_begin must ascend"); } }
-    S->F = part_begin[S->P]; S->nb = part_begin[S->me]; S->ne = part_begin[S->me + 1];
-    if (part_begin[0] != 0 || S->F != ctx->n_faces) { delete S; throw StatusError(MVS_ERR_INVALID, "the partition must cover the mesh of the context"); }
-    S->d_adj_ptr = adj_ptr_device; S->d_adj = adj_device;
+    S->F = ctx->n_faces;
+    // The parts are contiguous ranges of the LIBRARY's face order (k_bvh.hip build_scene_order: a Hilbert curve over the face
+    // centroids, derived identically by every rank from the replicated mesh): compact patches, short cuts -- whatever order the
+    // caller's mesh file has.  part_begin == null: `world` equal parts.
+    for (int q = 0; q <= S->P; ++q) {
+        S->parts.b[q] = part_begin ? part_begin[q] : (uint32_t)(((uint64_t)S->F * (uint64_t)q) / (uint64_t)S->P);
+        if (q && S->parts.b[q] < S->parts.b[q - 1]) throw StatusError(MVS_ERR_INVALID, "part_begin must ascend");
+    }
+    if (S->parts.b[0] != 0 || S->parts.b[S->P] != S->F) throw StatusError(MVS_ERR_INVALID, "the partition must cover the mesh of the context");
+    S->nb = S->parts.b[S->me]; S->ne = S->parts.b[S->me + 1];
     MVS_HIP(hipMemcpyAsync(&S->E, adj_ptr_device + S->F, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(hipStreamSynchronize(ctx->stream));
-    *out = S;
+    // the caller's adjacency lists (its own face numbering) once into the library's order, list order kept
+    build_scene_order(ctx);
+    if (ctx->mesh_ordered) {
+        renumber_adjacency(ctx, S->F, ctx->f_perm.p, ctx->f_pos.p, adj_ptr_device, adj_device, S->E, S->own_adj_ptr, S->own_adj);
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        S->d_adj_ptr = S->own_adj_ptr.p; S->d_adj = S->own_adj.p;
+    } else { S->d_adj_ptr = adj_ptr_device; S->d_adj = adj_device; }   // option "face_order" = 0: the caller's numbering is the order
+    *out = S.release();
+    MVS_API_END
+}
+
+/* the caller's ids of the faces this rank owns (positions part_begin[rank] .. of the library's order), in the order of the labels
+ * mvs_shard_view_selection returns */
+mvs_status mvs_shard_own_faces(mvs_shard* S, uint32_t* ids_device, uint32_t* n_own) {
+    if (!S) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (n_own) *n_own = S->ne - S->nb;
+    if (!ids_device) return MVS_OK;
+    MVS_API_BEGIN
+    mvs_ctx* ctx = S->ctx;
+    MVS_HIP(hipSetDevice(ctx->device));
+    const uint32_t n = S->ne - S->nb;
+    if (n) {
+        if (ctx->mesh_ordered) MVS_HIP(hipMemcpyAsync(ids_device, ctx->f_perm.p + S->nb, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        else { hipLaunchKernelGGL(iota_from_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ids_device, S->nb, n); MVS_LAUNCH_CHECK(); }
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+    }
     MVS_API_END
 }
 
@@ -731,6 +772,9 @@ mvs_status mvs_shard_data_costs(mvs_shard* S, const mvs_settings* settings, mvs_
     // the context's active table := the sharded one (its own buffers keep the own columns for the next step's reuse)
     ctx->r_ptr = S->t_ptr.p; ctx->r_view = S->t_view.p; ctx->r_cost = S->t_cost.p;
     ctx->csr_faces = F; ctx->csr_views = ctx->n_views; ctx->csr_nnz = nnz_l; ctx->have_costs = true; ctx->csr_q_valid = false;
+    // the table has the global shape, in the library's face order
+    ctx->u_valid = false;
+    if (ctx->mesh_ordered) { ctx->t_perm = ctx->f_perm.p; ctx->t_pos = ctx->f_pos.p; } else { ctx->t_perm = nullptr; ctx->t_pos = nullptr; }
     MVS_API_END
 }
 
@@ -744,7 +788,7 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
     if (P.region_rounds > 0) throw StatusError(MVS_ERR_UNSUPPORTED, "region moves (region_rounds > 0) are a single-context option");
     const uint32_t nb = S->nb, ne = S->ne;
-    set_adjacency(ctx, S->d_adj_ptr, S->d_adj, 1);
+    set_adjacency(ctx, S->d_adj_ptr, S->d_adj, 1, /*table_order=*/true);
     { Prof pr(ctx, "mrf_setup"); mrf_setup(ctx, &P); }
     { Prof pr(ctx, "mrf_plan"); build_plan(S); }
     mvs_mrf_stats R; memset(&R, 0, sizeof(R));

@@ -445,6 +445,7 @@ def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, dev
     L, h = ctx.L, ctx.h
     P = len(part_begin) - 1
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels, copies and RCCL ordered on one stream
+    ctx.set_option("face_order", 0)                         # part_begin cuts the CALLER's numbering (this harness renumbers the faces itself)
     ctx.set_face_range(int(part_begin[me]), int(part_begin[me + 1]))
     _check(L, L.mvs_ctx_dc_phase1(h, C.byref(settings)))
     mx = torch.zeros(1, dtype=torch.float32, device=device)
@@ -544,6 +545,9 @@ class ShardedPipeline:
         self.settings, self.params = settings, params
         self.plan = self.hx = self.boundary = None
         self.nnz_global = 0
+        # this harness numbers, cuts and plans the faces itself (morton_order / renumber_faces / HaloPlan): the library keeps the
+        # caller's face numbering instead of laying the faces out on its own curve
+        ctx.set_option("face_order", 0)
 
     def step(self):
         if self.boundary is None:   # from the adjacency and the partition alone (host logic, once)

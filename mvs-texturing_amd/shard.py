@@ -46,17 +46,32 @@ class Comm:
 
 class Shard:
     """One rank of the sharded path.  ctx: a viewsel.Context holding the FULL mesh and all views; part_begin: uint32
-    [world + 1]; adj_ptr / adj: device-resident (torch CUDA tensors) full adjacency."""
+    [world + 1] cut points of the LIBRARY's face order (None: equal parts); adj_ptr / adj: device-resident (torch CUDA
+    tensors) full adjacency in the caller's face numbering."""
 
     def __init__(self, ctx, comm, part_begin, adj_ptr_dev, adj_dev):
         self.L, self.ctx, self.comm = ctx.L, ctx, comm
-        self.part = np.ascontiguousarray(part_begin, dtype=np.uint32)
+        self.part = None if part_begin is None else np.ascontiguousarray(part_begin, dtype=np.uint32)
         self._keep = (adj_ptr_dev, adj_dev)
         pa, d0 = _ptr(adj_ptr_dev); pb, d1 = _ptr(adj_dev)
         assert d0 == 1 and d1 == 1, "the adjacency must be device resident"
         h = C.c_void_p()
-        _check(self.L, self.L.mvs_shard_create(ctx.h, comm.h, self.part.ctypes.data_as(C.c_void_p), pa, pb, C.byref(h)))
+        _check(self.L, self.L.mvs_shard_create(ctx.h, comm.h, None if self.part is None else self.part.ctypes.data_as(C.c_void_p), pa, pb, C.byref(h)))
         self.h = h
+
+    def n_own(self):
+        n = C.c_uint32(0)
+        _check(self.L, self.L.mvs_shard_own_faces(self.h, None, C.byref(n)))
+        return int(n.value)
+
+    def own_faces(self):
+        """uint32[n_own]: the caller's ids of the faces this rank owns, in the order of the labels view_selection returns"""
+        import torch
+        n = self.n_own()
+        t = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()   # the library writes on the context's stream, torch filled on its own
+        _check(self.L, self.L.mvs_shard_own_faces(self.h, C.c_void_p(t.data_ptr()), None))
+        return t.cpu().numpy().view(np.uint32)[:n].copy()
 
     def close(self):
         if getattr(self, "h", None):

@@ -119,3 +119,28 @@ CONFIGS = {
     # average (max 26).  bench.py reports it beside the headline (key "real_like"), never instead of it.
     "real": dict(n=100, n_views=200, width=2048, height=1536, displacement=0.45, layout=1, zoom=1.5, zoom_odd=3.3),
 }
+
+
+def permute_scene(scene, seed=1):
+    """The same scene with its faces AND vertices in random order (a decimated / cleaned mesh file in arbitrary order): faces,
+    normals and adjacency lists renumbered (list order kept, build_adjacency_graph.cpp:16-53 semantics), vertex indices remapped.
+    Attributes face_perm / vert_perm: new face k = old face face_perm[k], new vertex k = old vertex vert_perm[k]."""
+    rng = np.random.default_rng(seed)
+    F, NV = scene.faces.shape[0], scene.verts.shape[0]
+    fp = rng.permutation(F).astype(np.uint32)
+    vp = rng.permutation(NV).astype(np.uint32)
+    vinv = np.empty(NV, dtype=np.uint32); vinv[vp] = np.arange(NV, dtype=np.uint32)
+    finv = np.empty(F, dtype=np.uint32); finv[fp] = np.arange(F, dtype=np.uint32)
+    s = Scene()
+    s.verts = np.ascontiguousarray(scene.verts[vp])
+    s.faces = np.ascontiguousarray(vinv[scene.faces[fp]])
+    s.normals = np.ascontiguousarray(scene.normals[fp])
+    if scene.adj_ptr is not None:
+        deg = np.diff(scene.adj_ptr.astype(np.int64))
+        nd = deg[fp]
+        s.adj_ptr = np.zeros(F + 1, dtype=np.uint32); s.adj_ptr[1:] = np.cumsum(nd)
+        src = np.repeat(scene.adj_ptr[:-1].astype(np.int64)[fp], nd) + (np.arange(int(s.adj_ptr[-1]), dtype=np.int64) - np.repeat(s.adj_ptr[:-1].astype(np.int64), nd))
+        s.adj = np.ascontiguousarray(finv[scene.adj[src]])
+    s.cams, s.images = scene.cams, scene.images
+    s.face_perm, s.vert_perm = fp, vp
+    return s

@@ -145,6 +145,9 @@ def load_library():
         "mvs_shard_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats), C.POINTER(u64)],
         "mvs_shard_view_selection": [vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
         "mvs_shard_plan_info": [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)],
+        "mvs_shard_own_faces": [vp, vp, C.POINTER(u32)],
+        "mvs_ctx_partition_faces": [vp, i32, vp, vp], "mvs_partition_faces": [C.POINTER(CMesh), i32, vp, vp],
+        "mvs_ctx_table_order": [vp, vp, C.POINTER(i32)],
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)
@@ -295,7 +298,29 @@ class Context:
         _check(self.L, self.L.mvs_scene_set_views(self.h, arr, V, dev or 0))
 
     def set_face_range(self, begin, end):
+        """positions [begin, end) of the library's face order (the caller's ids with option face_order = 0)"""
         _check(self.L, self.L.mvs_scene_set_face_range(self.h, begin, end))
+
+    def partition_faces(self, world=1):
+        """the library's own face order of the resident mesh and its cut into `world` equal contiguous parts:
+        (perm uint32[F]: perm[p] = the caller's id of the face at position p, part_begin uint32[world + 1])"""
+        import torch
+        F = self.n_faces
+        perm = torch.zeros(max(F, 1), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()   # the library writes on the context's stream, torch filled on its own
+        part = np.zeros(world + 1, dtype=np.uint32)
+        _check(self.L, self.L.mvs_ctx_partition_faces(self.h, int(world), C.c_void_p(perm.data_ptr()), part.ctypes.data_as(C.c_void_p)))
+        return perm.cpu().numpy().view(np.uint32)[:F].copy(), part
+
+    def table_order(self):
+        """uint32[F]: the caller's face id of every column of the resident table as the library keeps it, or None (caller's order)"""
+        import torch
+        F = self.n_faces
+        out = torch.zeros(max(F, 1), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()   # the library writes on the context's stream, torch filled on its own
+        flag = C.c_int(0)
+        _check(self.L, self.L.mvs_ctx_table_order(self.h, C.c_void_p(out.data_ptr()), C.byref(flag)))
+        return out.cpu().numpy().view(np.uint32)[:F].copy() if flag.value else None
 
     def build_adjacency(self):
         """tex::build_adjacency_graph on the resident mesh; returns device-resident (adj_ptr, adj) usable by view_selection"""
@@ -439,6 +464,16 @@ def undistort_image(rgb, flen, dist0, dist1):
     out = np.empty_like(rgb)
     _check(L, L.mvs_undistort_image(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], float(flen), float(dist0), float(dist1), out.ctypes.data))
     return out
+
+
+def partition_faces(verts, faces, world=1):
+    """mvs_partition_faces on host arrays: (perm, part_begin) -- see Context.partition_faces"""
+    L = load_library()
+    verts = np.ascontiguousarray(verts, dtype=np.float32); faces = np.ascontiguousarray(faces, dtype=np.uint32)
+    m = CMesh(int(verts.shape[0]), int(faces.shape[0]), verts.ctypes.data, faces.ctypes.data, None)
+    perm = np.zeros(max(faces.shape[0], 1), dtype=np.uint32); part = np.zeros(world + 1, dtype=np.uint32)
+    _check(L, L.mvs_partition_faces(C.byref(m), int(world), perm.ctypes.data_as(C.c_void_p), part.ctypes.data_as(C.c_void_p)))
+    return perm[:faces.shape[0]], part
 
 
 def prepare_mesh(verts, faces):
