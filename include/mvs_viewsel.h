@@ -340,6 +340,9 @@ mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases);
  * option "mrf_graph", default 1), out[1] = re-captures pushed into the executable graph with hipGraphExecUpdate, out[2] = graph
  * instantiations, out[3] = nodes the sweep routes to the generic kernel (degree > 3 or a column of > 255 labels at or next to the node) */
 mvs_status mvs_ctx_mrf_diagnostics(mvs_ctx* ctx, uint32_t out[4]);
+/* NOTE: once the device-side stop rule has fired (mvs_mrf_progress.stopped, set by mvs_ctx_mrf_step) every later sweep / sweep phase
+ * ends at its first instruction -- it changes no message, no decode and no energy partial: the best labeling is frozen.  A driver that
+ * wants more sweeps than the rule allows raises max_sweeps / min_sweeps in the params of mvs_ctx_mrf_setup instead. */
 mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t node_begin, uint32_t node_end);
 /* all phases in turn over nodes [node_begin, node_end) (no exchange in between: unsharded use) */
 mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);

@@ -28,6 +28,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -323,16 +324,19 @@ inline void view_selection(DataCosts const& data_costs, UniGraph* graph, Setting
     std::vector<std::uint16_t> view_id(data_costs.get_nnz() + 1); std::vector<float> cost(data_costs.get_nnz() + 1);
     {   /* the table as CSR (view_selection.cpp:27-82 reads it column by column): column offsets first, then the copies on a few threads */
         for (std::uint32_t i = 0; i < F; ++i) col_ptr[i + 1] = col_ptr[i] + static_cast<std::uint32_t>(data_costs.col(i).size());
-        unsigned const T = std::max(1u, std::min(8u, std::min(std::thread::hardware_concurrency(), static_cast<unsigned>(F / 65536u + 1u))));
-        auto copy = [&](unsigned t) {
-            for (std::uint32_t i = static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * t / T); i < static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * (t + 1) / T); ++i) {
+        unsigned const n_threads = std::max(1u, std::min(8u, std::min(std::thread::hardware_concurrency(), static_cast<unsigned>(F / 65536u + 1u))));
+        auto copy = [&](unsigned t, unsigned of) {
+            for (std::uint32_t i = static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * t / of); i < static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * (t + 1) / of); ++i) {
                 std::size_t k = col_ptr[i];
                 for (auto const& e : data_costs.col(i)) { view_id[k] = e.first; cost[k] = e.second; ++k; }
             }
         };
         std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(copy, t);
-        copy(0);
+        unsigned started = 1;   // slice 0 is the caller's
+        try { for (; started < n_threads; ++started) th.emplace_back(copy, started, n_threads); }
+        catch (std::system_error const&) {}   // built without -pthread or out of threads: the slices that got no thread are copied here
+        copy(0, n_threads);
+        for (unsigned t = started; t < n_threads; ++t) copy(t, n_threads);
         for (auto& x : th) x.join();
     }
     double const t1 = detail::now_ms();

@@ -47,6 +47,31 @@ namespace mvs { mvs_status api_fail(mvs_status st, const std::string& msg) { ret
       catch (const std::exception& e) { return fail(MVS_ERR_HIP, e.what()); } \
     return MVS_OK;
 
+#include <dlfcn.h>
+namespace mvs {
+namespace {
+struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const Roctx& roctx() {
+    static Roctx R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = getenv("MVS_ROCTX");
+        if (e && e[0] == '0') return;
+        void* h = nullptr;
+        for (const char* name : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return;
+        R.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        R.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!R.push || !R.pop) { R.push = nullptr; R.pop = nullptr; }
+    });
+    return R;
+}
+}  // namespace
+RoctxRange::RoctxRange(const char* name) : on(false) { const Roctx& R = roctx(); if (R.push) { (void)R.push(name); on = true; } }
+RoctxRange::~RoctxRange() { if (on) (void)roctx().pop(); }
+int default_device() { const char* e = getenv("MVS_DEVICE"); return e ? std::max(0, atoi(e)) : 0; }
+}  // namespace mvs
+
 static float compute_cos_limit() {
     const float c = host_cos_limit();  // dmath.h
     if (!(c == c)) throw StatusError(MVS_ERR_UNSUPPORTED, "host acosf is not monotone around cos(75 deg)");
@@ -393,6 +418,7 @@ mvs_status mvs_ctx_data_costs(mvs_ctx* ctx, const mvs_settings* settings, mvs_dc
     if (!ctx || !settings) return fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
     MVS_HIP(hipSetDevice(ctx->device));
+    RoctxRange range("Calculating data costs");   /* texrecon.cpp:118 */
     dc_phase1(ctx, settings);
     dc_phase2(ctx);
     dc_phase3(ctx, stats);
@@ -514,6 +540,7 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     if (!ctx->have_costs) return fail(MVS_ERR_STATE, "view selection needs data costs (mvs_ctx_data_costs or mvs_ctx_costs_upload)");
     MVS_API_BEGIN
     MVS_HIP(hipSetDevice(ctx->device));
+    RoctxRange range("Running MRF optimization");   /* texrecon.cpp:126 */
     mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
     const uint32_t F = ctx->csr_faces;
     { Prof pr(ctx, "mrf_setup"); set_adjacency(ctx, adj_ptr, adj, adj_on_device, false); mrf_setup(ctx, &P); }
@@ -522,7 +549,9 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     // The stop rule runs on the device (mrf_step); the host only polls the report of `lag` sweeps ago, so the next
     // sweep is already queued when a sweep's energy becomes known.  Sweeps issued after the rule fired are no-ops
     // for the result (the best labeling is frozen on the device).
-    const int lag = std::max(0, std::min(ctx->mrf_lag, (int)mvs_ctx::RING - 2));
+    // reports outstanding at any time: lag + 2 with direct launches, up to lag + 4 under graph replay (a graph issues two steps before
+    // the host polls, and one more graph stays queued behind it): the ring of RING slots must hold them all
+    const int lag = std::max(0, std::min(ctx->mrf_lag, (int)mvs_ctx::RING - 5));
     mvs_mrf_progress pg; memset(&pg, 0, sizeof(pg));
     auto report = [&](uint32_t n) {
         mrf_poll(ctx, n, &pg);
@@ -601,8 +630,12 @@ mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t 
     if (n_views > 65535u) return fail(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");
     double t[7]; t[0] = now_ms();
     mvs_ctx* ctx = stash_enabled() ? take_spare() : nullptr;
+    if (!ctx && stash_enabled()) {   // no spare: a context still parked with an OLD table becomes the working context (never two scenes resident at once)
+        std::lock_guard<std::mutex> lock(g_stash.m);
+        ctx = g_stash.ctx; g_stash.ctx = nullptr; g_stash.fp = 0;
+    }
     mvs_status st = MVS_OK;
-    if (!ctx) st = mvs_ctx_create(0, &ctx);
+    if (!ctx) st = mvs_ctx_create(default_device(), &ctx);
     if (st != MVS_OK) return st;
     t[1] = now_ms();
     st = mvs_scene_set_mesh(ctx, mesh, 0);
@@ -648,7 +681,7 @@ mvs_status mvs_undistort_image(const uint8_t* rgb, int32_t width, int32_t height
     if (dist0 == 0.0f) { memcpy(out, rgb, bytes); return MVS_OK; }        /* :153 -- only a non-zero first coefficient undistorts */
     if (!(flen > 0.0f)) return fail(MVS_ERR_INVALID, "undistortion needs a positive focal length");
     mvs_ctx* ctx = nullptr;
-    mvs_status st = mvs_ctx_create(0, &ctx);
+    mvs_status st = mvs_ctx_create(default_device(), &ctx);
     if (st != MVS_OK) return st;
     try {
         DBuf<uint8_t> a, b; a.ensure(bytes + 16); b.ensure(bytes + 16);
@@ -672,7 +705,7 @@ mvs_status mvs_postprocess_face_infos(uint32_t n_faces, uint32_t n_views, const 
     for (uint32_t i = 0; i < n_faces; ++i) if (info_ptr[i + 1] < info_ptr[i]) return fail(MVS_ERR_INVALID, "info_ptr must ascend");
     for (size_t k = 0; k < n; ++k) if (view_id[k] >= n_views) return fail(MVS_ERR_INVALID, "view id out of range");
     mvs_ctx* ctx = nullptr;
-    mvs_status st = mvs_ctx_create(0, &ctx);
+    mvs_status st = mvs_ctx_create(default_device(), &ctx);
     if (st != MVS_OK) return st;
     try {
         // every face's list reversed (see dc_postprocess)
@@ -715,7 +748,7 @@ mvs_status mvs_view_selection(const mvs_csr* costs, const uint32_t* adj_ptr, con
     mvs_status st = MVS_OK;
     if (!reused) {
         ctx = stash_enabled() ? take_spare() : nullptr;
-        if (!ctx) st = mvs_ctx_create(0, &ctx);
+        if (!ctx) st = mvs_ctx_create(default_device(), &ctx);
         if (st != MVS_OK) return st;
         st = mvs_ctx_costs_upload(ctx, costs, 0);
     }

@@ -127,7 +127,8 @@ struct mvs_ctx {
     mvs::DBuf<uint8_t> lum_all;      // luminance planes (vectorised prep path)
     mvs::DBuf<uint32_t> mask_all;    // all views' bit-packed validity masks
     mvs::DBuf<uint32_t> mask_zero, mask_tmp;
-    std::vector<size_t> gmi_off, mask_off;
+    mvs::DBuf<uint32_t> msum_all;    // all views' mask tile summaries (dmath.h ViewParams::msum)
+    std::vector<size_t> gmi_off, mask_off, msum_off;
     mvs::DBuf<size_t> view_off;
     bool mesh_dirty = true, views_dirty = true;
 
@@ -259,6 +260,11 @@ struct ProfChain {
     }
     bool first = false;
 };
+// roctx range around the two windows the reference times (apps/texrecon/texrecon.cpp:118 "Calculating data costs", :126 "Running MRF
+// optimization"): visible to rocprofv3 --marker-trace; libroctx64 is resolved at run time (no link-time dependency), absent = no-op
+struct RoctxRange { explicit RoctxRange(const char* name); ~RoctxRange(); bool on; };
+// device for the one-shot host entry points (mvs_data_costs, mvs_view_selection, ...): environment MVS_DEVICE, default 0
+int default_device();
 // reports through pinned host memory (k_mrf.hip)
 void ensure_report_ring(mvs_ctx* ctx);
 void report_u32(mvs_ctx* ctx, const uint32_t* d_src, uint32_t* d_dst, uint32_t seq_slot, uint32_t seq);

@@ -22,8 +22,8 @@ static ViewParams to_vp(const dmh_view* v) {
     ViewParams p;
     memcpy(p.pos, v->pos, sizeof(p.pos)); memcpy(p.viewdir, v->viewdir, sizeof(p.viewdir));
     memcpy(p.K, v->K, sizeof(p.K)); memcpy(p.w2c, v->w2c, sizeof(p.w2c));
-    p.width = v->width; p.height = v->height; p.mask_stride = (v->width + 31) / 32; p.pad_ = 0;
-    p.rgb = v->rgb; p.gmi = v->gmi; p.mask = v->mask;
+    p.width = v->width; p.height = v->height; p.mask_stride = (v->width + 31) / 32;
+    p.rgb = v->rgb; p.gmi = v->gmi; p.mask = v->mask; p.msum = nullptr; p.msum_stride = 0;
     return p;
 }
 

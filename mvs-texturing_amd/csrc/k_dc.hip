@@ -211,9 +211,10 @@ __global__ void __launch_bounds__(256, WORDS ? 6 : 1) info_kernel(const float* _
 // footprint is walked by 16 lanes (2 scan lines x 8 pixels at a time; the spans come from the shared foot_row()), its pixels
 // are read along rows and summed as INTEGERS (u8 values: exact, order independent); only the final division by 255 is fp64.  The
 // reference adds the quotients u / 255.0 one by one in fp64, so its sum differs from this one by a few fp64 roundings
-// (~n * 2^-53 relative) -- far inside the 1e-4 bar of the data costs, and after the conversion to float the quality is
-// bit-equal except where that difference straddles a float rounding boundary (probability ~ n * 2^-29 per footprint).
-// Footprints up to `defer_area` pixels keep the bit-exact serial walk (mvs_set_option "info_wave_area"; 0 = all serial).
+// (~n * 2^-53 relative).  The result is USED only under a certificate (dmath.h foot_sums_certified) that the conversion to float
+// cannot tell the two apart -- it then IS the reference's value, bit for bit; the ~n * 2^-28 of the footprints the certificate
+// cannot decide are re-walked in the reference's serial order (rewalk_info_kernel).  Footprints up to `defer_area` pixels take
+// info_kernel (mvs_set_option "info_wave_area"; 0 = every footprint in the serial walk).
 __global__ void defer_expand_kernel(const unsigned long long* __restrict__ defer_bits, const uint32_t* __restrict__ base, size_t n_words, uint2* __restrict__ list) {
     const size_t wi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= n_words) return;
@@ -268,6 +269,7 @@ __global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict_
                     xb[q] = __shfl(xb_own, r, GL); xe[q] = __shfl(xe_own, r, GL);
                     rowp[q] = gimg + (size_t)(yb + r) * w;
                     x0[q] = xb[q] - (int)(reinterpret_cast<uintptr_t>(rowp[q] + xb[q]) & 3u) + 4 * dx;
+                    if (xe[q] <= xb[q]) x0[q] = xe[q];              // an empty span (a skipped line, a line past y_end): nothing is fetched
                 }
                 while (x0[0] < xe[0] || x0[1] < xe[1]) {
                     uint32_t v[2];
@@ -770,20 +772,24 @@ static void launch_outlier(mvs_ctx* ctx, const uint32_t* ptr, const uint32_t* co
 // (re)compute per-view derived images and upload the view table
 static void upload_views_and_prepare(mvs_ctx* ctx, bool need_gmi) {
     const uint32_t V = ctx->n_views;
-    ctx->gmi_off.assign(V + 1, 0); ctx->mask_off.assign(V + 1, 0);
+    ctx->gmi_off.assign(V + 1, 0); ctx->mask_off.assign(V + 1, 0); ctx->msum_off.assign(V + 1, 0);
     for (uint32_t j = 0; j < V; ++j) {
         auto& v = ctx->h_views[j];
         v.mask_stride = (v.width + 31) / 32;
+        v.msum_stride = ((v.mask_stride + 63) / 64) * 2;   // one bit per 32-pixel tile column, rows padded to 64 tiles (a wave's ballot)
         ctx->gmi_off[j + 1] = ctx->gmi_off[j] + (need_gmi ? (((size_t)v.width * v.height + 15) & ~(size_t)15) : 0);
         ctx->mask_off[j + 1] = ctx->mask_off[j] + (size_t)v.mask_stride * v.height;
+        ctx->msum_off[j + 1] = ctx->msum_off[j] + (size_t)v.msum_stride * ((v.height + 31) / 32);
     }
     ctx->gmi_all.ensure(std::max<size_t>(ctx->gmi_off[V], 16));
     ctx->mask_all.ensure(std::max<size_t>(ctx->mask_off[V], 16));
     ctx->mask_zero.ensure(std::max<size_t>(ctx->mask_off[V], 16));
     ctx->mask_tmp.ensure(std::max<size_t>(ctx->mask_off[V], 16));
+    ctx->msum_all.ensure(std::max<size_t>(ctx->msum_off[V], 16));
     for (uint32_t j = 0; j < V; ++j) {
         ctx->h_views[j].gmi = need_gmi ? ctx->gmi_all.p + ctx->gmi_off[j] : nullptr;
         ctx->h_views[j].mask = ctx->mask_all.p + ctx->mask_off[j];
+        ctx->h_views[j].msum = ctx->msum_all.p + ctx->msum_off[j];
     }
     ctx->d_views.ensure(V);
     MVS_HIP(hipMemcpyAsync(ctx->d_views.p, ctx->h_views.data(), V * sizeof(ViewParams), hipMemcpyHostToDevice, ctx->stream));

@@ -273,7 +273,7 @@ mvs_status mvs_ctx_build_adjacency(mvs_ctx* ctx, uint32_t** adj_ptr_device, uint
 mvs_status mvs_build_adjacency_graph(uint32_t n_verts, uint32_t n_faces, const uint32_t* faces, uint32_t* adj_ptr_out, uint32_t** adj_out, uint64_t* n_entries) {
     if ((!faces && n_faces) || !adj_ptr_out || !adj_out) return api_fail(MVS_ERR_INVALID, "null argument");
     mvs_ctx* ctx = nullptr;
-    mvs_status st = mvs_ctx_create(0, &ctx);
+    mvs_status st = mvs_ctx_create(mvs::default_device(), &ctx);
     if (st != MVS_OK) return st;
     try {
         DBuf<uint32_t> d_faces; d_faces.ensure(3 * (size_t)n_faces + 4);
@@ -293,7 +293,7 @@ mvs_status mvs_build_adjacency_graph(uint32_t n_verts, uint32_t n_faces, const u
 mvs_status mvs_prepare_mesh(uint32_t n_verts, const float* verts, uint32_t n_faces, const uint32_t* faces, uint32_t* faces_out, float* normals_out, uint32_t* n_kept) {
     if ((!verts && n_verts) || (!faces && n_faces) || !faces_out || !normals_out || !n_kept) return api_fail(MVS_ERR_INVALID, "null argument");
     mvs_ctx* ctx = nullptr;
-    mvs_status st = mvs_ctx_create(0, &ctx);
+    mvs_status st = mvs_ctx_create(mvs::default_device(), &ctx);
     if (st != MVS_OK) return st;
     try {
         DBuf<uint32_t> d_faces; DBuf<float> d_verts; d_faces.ensure(3 * (size_t)n_faces + 4); d_verts.ensure(3 * (size_t)n_verts + 4);

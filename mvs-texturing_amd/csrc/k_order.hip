@@ -141,8 +141,7 @@ mvs_status mvs_ctx_partition_faces(mvs_ctx* ctx, int world, uint32_t* perm_devic
 mvs_status mvs_partition_faces(const mvs_mesh* mesh, int world, uint32_t* perm_out, uint32_t* part_begin_out) {
     if (!mesh || world < 1 || !perm_out || !part_begin_out || !mesh->verts || !mesh->faces) return api_fail(MVS_ERR_INVALID, "bad argument");
     mvs_ctx* ctx = nullptr;
-    const char* dev_env = getenv("MVS_DEVICE");
-    mvs_status st = mvs_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx);
+    mvs_status st = mvs_ctx_create(default_device(), &ctx);
     if (st != MVS_OK) return st;
     try {
         const size_t NV = mesh->n_verts, F = mesh->n_faces;

@@ -261,7 +261,7 @@ mvs_status mvs_ctx_get_subgraphs(mvs_ctx* ctx, uint32_t n_faces, const uint32_t*
 mvs_status mvs_get_subgraphs(uint32_t n_faces, const uint32_t* adj_ptr, const uint32_t* adj, const uint32_t* labels, uint32_t n_labels, mvs_subgraphs* out) {
     if (!out || (n_faces && (!adj_ptr || !adj || !labels))) return api_fail(MVS_ERR_INVALID, "null argument");
     mvs_ctx* ctx = nullptr;
-    mvs_status st = mvs_ctx_create(0, &ctx);
+    mvs_status st = mvs_ctx_create(mvs::default_device(), &ctx);
     if (st != MVS_OK) return st;
     st = mvs_ctx_get_subgraphs(ctx, n_faces, adj_ptr, adj, 0, labels, 0, n_labels, out, 0);
     mvs_ctx_destroy(ctx);

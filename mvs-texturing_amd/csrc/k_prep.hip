@@ -158,6 +158,51 @@ __global__ void mask_final_kernel(const ViewParams* __restrict__ views, const ui
     mask_all[base + (size_t)y * wpr + wx] = valid;
 }
 
+// ---- tile summary of the final mask (dmath.h ViewParams::msum / valid_pixels3) ----
+// One thread per 32 x 32 tile: bit (tx, ty) = every mask bit of the pixels [32 tx, 32 tx + 32] x [32 ty, 32 ty + 32] clipped to
+// the image is set, i.e. the four bits valid_pixel (texture_view.cpp:253-281) reads around any position whose integer part lies in
+// the tile.  A wave holds 64 consecutive tiles of one tile row: its ballot is two words of the summary.
+__global__ void __launch_bounds__(64) mask_summary_kernel(const ViewParams* __restrict__ views, const uint32_t* __restrict__ mask_all, const size_t* __restrict__ mask_off) {
+    const ViewParams& vp = views[blockIdx.z];
+    const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
+    const int tx = blockIdx.x * 64 + threadIdx.x, ty = blockIdx.y;
+    if (blockIdx.x * 64 >= wpr || ty * 32 >= h) return;           // wave-uniform: no tile of this view here
+    bool all = false;
+    if (tx < wpr) {
+        const uint32_t* __restrict__ m = mask_all + mask_off[blockIdx.z];
+        const int rem = w - tx * 32;
+        const uint32_t inb = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);      // bits of the tile's word that are real pixels (rem >= 1)
+        const bool next = (tx + 1) * 32 <= w - 1;                               // pixel column 32 tx + 32 exists
+        const int y1 = min(ty * 32 + 32, h - 1);
+        uint32_t acc = 0xFFFFFFFFu, accn = 1u;
+        for (int y = ty * 32; y <= y1; ++y) {
+            acc &= m[(size_t)y * wpr + tx] | ~inb;
+            if (next) accn &= m[(size_t)y * wpr + tx + 1];
+        }
+        all = acc == 0xFFFFFFFFu && (accn & 1u) != 0u;
+    }
+    const unsigned long long b = __ballot(all);
+    if (threadIdx.x == 0) {
+        uint32_t* out = const_cast<uint32_t*>(vp.msum) + (size_t)ty * vp.msum_stride + blockIdx.x * 2;
+        out[0] = (uint32_t)b; out[1] = (uint32_t)(b >> 32);
+    }
+}
+// A view whose summary is all ones has an all-ones mask: its device-side ViewParams drops the mask pointer and the last cull
+// (calculate_data_costs.cpp:191) becomes pure arithmetic for it.  One block per view.
+__global__ void __launch_bounds__(256) mask_trivial_kernel(ViewParams* __restrict__ views) {
+    ViewParams& vp = views[blockIdx.x];
+    const int wpr = vp.mask_stride, th = (vp.height + 31) / 32, ms = vp.msum_stride;
+    bool ok = true;
+    for (int k = threadIdx.x; k < th * ms; k += 256) {
+        const int c = k % ms;                                       // summary word c of its row: tiles 32 c .. 32 c + 31
+        const int n = wpr - 32 * c;                                 // real tiles in it
+        const uint32_t want = n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u));
+        ok = ok && (vp.msum[k] & want) == want;
+    }
+    const int bad = __syncthreads_or(ok ? 0 : 1);
+    if (threadIdx.x == 0 && !bad) vp.mask = nullptr;
+}
+
 // ---- vectorised fast path (image width a multiple of 32, 4-byte aligned rows) ----
 // One pass over the RGB image does the luminance plane (4 pixels = three 32-bit loads per thread) AND
 // the zero map + corner seeds of the validity flood fill; a second pass does the Sobel magnitude on
@@ -376,6 +421,11 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
     MVS_LAUNCH_CHECK();
     if (out != ctx->mask_all.p)
         MVS_HIP(hipMemcpyAsync(ctx->mask_all.p, out, ctx->mask_off.back() * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    // tile summary of the mask + "this view's mask is all ones" (see mask_summary_kernel)
+    hipLaunchKernelGGL(mask_summary_kernel, dim3((maxwpr + 63) / 64, (maxh + 31) / 32, V), dim3(64), 0, s, ctx->d_views.p, (const uint32_t*)ctx->mask_all.p, d_mask_off);
+    MVS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mask_trivial_kernel, dim3(V), dim3(256), 0, s, ctx->d_views.p);
+    MVS_LAUNCH_CHECK();
 }
 
 

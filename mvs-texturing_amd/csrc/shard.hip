@@ -695,6 +695,7 @@ mvs_status mvs_shard_data_costs(mvs_shard* S, const mvs_settings* settings, mvs_
     MVS_API_BEGIN
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
     MVS_HIP(hipSetDevice(ctx->device));
+    RoctxRange range("Calculating data costs");   /* texrecon.cpp:118 */
     const uint32_t F = S->F, nb = S->nb, ne = S->ne, nf = ne - nb; const int P = S->P, me = S->me;
     ctx->face_begin = nb; ctx->face_end = ne; ctx->have_costs = false; ctx->dc_phase = 0;
     dc_phase1(ctx, settings);
@@ -785,6 +786,7 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     MVS_API_BEGIN
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
     MVS_HIP(hipSetDevice(ctx->device));
+    RoctxRange range("Running MRF optimization");   /* texrecon.cpp:126 */
     mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
     if (P.region_rounds > 0) throw StatusError(MVS_ERR_UNSUPPORTED, "region moves (region_rounds > 0) are a single-context option");
     const uint32_t nb = S->nb, ne = S->ne;

@@ -118,6 +118,10 @@ def hostile_images(rng, w, h):
     img = noise(); img[0, 0] = (0, 0, 0); img[0, w - 1] = (0, 0, 1); img[h - 1, 0] = (1, 0, 0)
     img[h - 1, w - 1] = 0; img[h - 1, w - 40:] = 0                 # one black corner pixel, two almost-black corners, a strip from the fourth
     out["corners"] = img
+    # an L-shaped black border whose rims sit ON the 32-pixel tile grid of the mask summary (k_prep.hip mask_summary_kernel: a tile
+    # answers for pixels 32 t .. 32 t + 32): rims at columns 32 / 33 / 64 / 65 and rows 31 / 32 / 63 / 64, eroded by one pixel
+    img = noise(); img[:65, :33] = 0; img[:32, :65] = 0; img[64:66, :20] = 0
+    out["tile_rims"] = img
     return {k: np.ascontiguousarray(v) for k, v in out.items()}
 
 
