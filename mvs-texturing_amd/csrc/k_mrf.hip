@@ -547,8 +547,26 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // and one cut per model edge to a neighbour of a LOWER colour whose label differs -- that neighbour was swept in an
 // earlier phase of this sweep, so its label is final, and every edge has exactly one higher-coloured end.  Integer sums:
 // the per-block partials (partial[2 * block]) add up to the oracle's energy of the sweep whatever the launch geometry.
+// MVS_SWEEP_EXP (scripts/sweep_probe.py; never defined in the product build): 1 = every data load / store of the sweep lands in a 64 KB
+// window (cache hot: the kernel's non-memory floor), 2 = loads and stores only (no arithmetic, no LDS: the memory floor), 3 / 4 = three /
+// two waves per SIMD (sensitivity to residency).  Results are garbage for 1 and 2.
+#ifndef MVS_SWEEP_EXP
+#define MVS_SWEEP_EXP 0
+#endif
+#if MVS_SWEEP_EXP == 1
+#define MVS_XO(o) ((o) & 0xFFF0u)
+#else
+#define MVS_XO(o) (o)
+#endif
+#if MVS_SWEEP_EXP == 3
+#define MVS_SWEEP_WAVES __attribute__((amdgpu_waves_per_eu(3, 3)))
+#elif MVS_SWEEP_EXP == 4
+#define MVS_SWEEP_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define MVS_SWEEP_WAVES
+#endif
 template <int G, bool DAMP, bool XCD, bool LATE_OLD>
-__global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ rec, msg_t* msg,
+__global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ rec, msg_t* msg,
                                                          const mvs_mrf_progress* __restrict__ st, uint32_t* sel2, uint32_t* lab2, float* cost2, uint32_t buf_stride,
                                                          uint32_t node_begin /* positions in the (colour, id) order */, uint32_t node_end, float rho, float alpha,
                                                          unsigned long long* __restrict__ partial) {
@@ -600,15 +618,15 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
     const uint32_t t0b = 4u * t0, glb = 4u * (uint32_t)gl;   // byte offsets of the lane's label words / map word inside a record
     auto issue = [&](const NodeDesc& d, Raw& r) {
         const uint32_t K = d.kk & 0xFFu, recb = 4u * d.rec;
-        r.lw = ld_off<uint4>(rec, recb + t0b);
+        r.lw = ld_off<uint4>(rec, MVS_XO(recb + t0b));
         uint32_t mposb = recb + 4u * ((K + 3u) & ~3u) + glb;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            r.in[e] = ld_off<uint32_t>(mo, (d.in_off[e] & ~3u) + t0);
-            r.map[e] = ld_off<uint32_t>(rec, mposb);
+            r.in[e] = ld_off<uint32_t>(mo, MVS_XO((d.in_off[e] & ~3u) + t0));
+            r.map[e] = ld_off<uint32_t>(rec, MVS_XO(mposb));
             if (!(d.out_off[e] & 1u)) mposb += (((d.kk >> (8 + 8 * e)) & 0xFFu) + 3u) & ~3u;   // 4 bytes per 4 map entries
-            r.nl[e] = ld_off<uint32_t>(lab, 4u * d.nbr[e]);     // an absent neighbour is recorded as the node itself
-            if (DAMP) r.old[e] = ld_off<uint32_t>(mo, (d.out_off[e] & ~3u) + t0); else r.old[e] = 0u;
+            r.nl[e] = ld_off<uint32_t>(lab, MVS_XO(4u * d.nbr[e]));     // an absent neighbour is recorded as the node itself
+            if (DAMP) r.old[e] = ld_off<uint32_t>(mo, MVS_XO((d.out_off[e] & ~3u) + t0)); else r.old[e] = 0u;
         }
     };
     NodeDesc cur = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i, last));
@@ -633,6 +651,16 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
         }
         const uint32_t lw[4] = {rw.lw.x, rw.lw.y, rw.lw.z, rw.lw.w};
         const uint32_t* r_in = rw.in; const uint32_t* r_map = rw.map; const uint32_t* nl = rw.nl; const uint32_t* r_old = rw.old;
+#if MVS_SWEEP_EXP == 2
+        {   // memory floor: every loaded word is consumed, every store is made, nothing is computed
+            const uint32_t x = ((lw[0] ^ lw[1]) ^ (lw[2] ^ lw[3])) ^ ((r_in[0] ^ r_in[1]) ^ (r_in[2] ^ r_map[0])) ^ ((r_map[1] ^ r_map[2]) ^ (nl[0] ^ nl[1])) ^ (nl[2] ^ r_old[0] ^ r_old[1] ^ r_old[2]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) if (t0 < kj3[d]) st_off<uint32_t>(mn, o_out[d] + t0, x);
+            if (node_ok && gl == 0) { const uint32_t idb = 4u * cur.id; st_off<uint32_t>(sel, idb, x & 3u); st_off<uint32_t>(lab, idb, (x & 15u) + 1u); st_off<float>(selcost, idb, 0.5f); acc_e += x & 1u; }
+            cur = nxt; rw = rn; nxt = nn;
+            continue;
+        }
+#endif
         // The update on the 8-bit codes (oracle.cpp mrf_sweep is the definition): Sc = sum of the incoming codes (exact),
         // b = fma(rho * step, Sc, D), cs_e = fma(-step, code_e, b) * oms -- the reweighted cavity D + rho * sum_all - m_e in
         // damped code units, oms = (1 - alpha) * scale -- code' = rne(fma(old, alpha, min(cs[p] - cmin, lam * oms))).
@@ -673,7 +701,7 @@ __global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restr
                 const uint32_t slot = (G < 64) ? mp : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // "absent at the sender" -> the +inf slot (G < 64: the records hold 4 * G)
                 w = msg_pack_s<DAMP>(min_raw(tile[slot], lam_s), alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
             }
-            if (t0 < kj3[d]) st_off<uint32_t>(mn, o_out[d] + t0, w);      // one 4-byte store (runs are padded)
+            if (t0 < kj3[d]) st_off<uint32_t>(mn, MVS_XO(o_out[d] + t0), w);      // one 4-byte store (runs are padded)
         }
         // the lane that owns the winning label publishes the decode (K == 0: lane 0 publishes the single label 0 with
         // unary 1, view_selection.cpp:50-51,70-71) and accounts the node's share of the tracking energy (integer:

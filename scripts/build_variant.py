@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mvs-texturing_amd"))
 import build as B
 name, rest = sys.argv[1], sys.argv[2:]
+defines = [a for a in rest if a.startswith("-D")]            # e.g. -DMVS_SWEEP_EXP=1: rebuilds the files named FILE:-  (FILE '' '' keeps the text)
+rest = [a for a in rest if not a.startswith("-D")]
 assert len(rest) % 3 == 0 and rest
 B.build_hip()
 out_dir = os.path.join(B.CSRC, "variants"); os.makedirs(out_dir, exist_ok=True)
@@ -17,14 +19,14 @@ try:
         f, old, new = rest[k:k + 3]
         src = edits.get(f) or open(os.path.join(B.CSRC, f)).read()
         assert old in src, "text not found in %s: %r" % (f, old)
-        edits[f] = src.replace(old, new)
+        edits[f] = src.replace(old, new) if old else src
     for f, src in edits.items():
         if f.endswith(".h"):
             raise SystemExit("header variants: edit every includer instead")
         p = os.path.join(B.CSRC, "_variant_" + name + "_" + f)
         open(p, "w").write(src)
         o = os.path.join(tmp, f.replace(".hip", ".o"))
-        subprocess.check_call([B._hipcc()] + B.HIP_FLAGS + B.EXTRA_FLAGS.get(f, []) + ["-c", "-x", "hip", p, "-o", o])
+        subprocess.check_call([B._hipcc()] + B.HIP_FLAGS + B.EXTRA_FLAGS.get(f, []) + defines + ["-c", "-x", "hip", p, "-o", o])
         os.remove(p)
         objs[f] = o
     lib = os.path.join(out_dir, "libmvs_viewsel_%s.so" % name)
