@@ -161,6 +161,28 @@ mvs_status mvs_view_selection(const mvs_csr* costs, const uint32_t* adj_ptr, con
                               const mvs_mrf_params* params, uint32_t* labels_out,
                               mvs_mrf_stats* stats);
 
+/* ---- the same two drop-ins without the bulk copies (what include/tex_viewsel.hpp calls) ----
+ * mvs_data_costs_stream: tex::calculate_data_costs whose result is handed over in CHUNKS of consecutive faces while the next chunk is
+ * still on its way from the device -- the caller's container fill (SparseTable::set_value, calculate_data_costs.cpp:291-298) hides the
+ * download.  fn(user, first_face, n_faces, col_ptr, view_id, cost): col_ptr[0 .. n_faces] are ABSOLUTE entry offsets of the faces
+ * first_face .. first_face + n_faces - 1, view_id / cost hold the chunk's entries from offset col_ptr[0] on (entry k of the table is
+ * view_id[k - col_ptr[0]]); the arrays are valid during the call only.  shape_out (may be NULL) receives n_faces / n_views / nnz (its
+ * pointers stay NULL).  The table stays parked on the device with its fingerprint, computed on the device.
+ * mvs_view_selection_cached: tex::view_selection on the parked table whose fingerprint the caller computed from ITS container -- no
+ * table crosses the bus; MVS_ERR_STATE when no parked table has that fingerprint and shape (the caller then flattens its container
+ * and calls mvs_view_selection).  Fingerprint of a table of F faces, V views, n entries (order independent, so it can be summed in
+ * pieces):  mvs_fp_mix(F, V) + mvs_fp_mix(n, 1) + sum_{i < F} mvs_fp_mix(i, col_ptr[i + 1])
+ *           + sum_{k < n} mvs_fp_mix(2^40 + k, view_id[k] << 32 | bits(cost[k])),   all arithmetic modulo 2^64. */
+static inline uint64_t mvs_fp_mix(uint64_t k, uint64_t v) {
+    uint64_t x = (k * 0x9E3779B97F4A7C15ull) ^ (v + 0x7F4A7C15D6E8FEB8ull); x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; return x;
+}
+typedef void (*mvs_csr_chunk_fn)(void* user, uint32_t first_face, uint32_t n_faces, const uint32_t* col_ptr, const uint16_t* view_id, const float* cost);
+mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_settings* settings,
+                                 mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats);
+mvs_status mvs_view_selection_cached(uint64_t fingerprint, uint32_t n_faces, uint32_t n_views, uint64_t nnz,
+                                     const uint32_t* adj_ptr, const uint32_t* adj, const mvs_mrf_params* params,
+                                     uint32_t* labels_out, mvs_mrf_stats* stats);
+
 /* File-level boundary against an UNMODIFIED texrecon (-D / -L flags):
  * SparseTable::save_to_file (sparse_table.h:112-136) and
  * vector_to_file<std::size_t> (util.h:104-113, texrecon.cpp:130-136). */

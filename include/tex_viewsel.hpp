@@ -21,6 +21,7 @@
 #include <array>
 #include <cstdint>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -232,6 +233,23 @@ inline void throw_status(mvs_status st) {
     }
 }
 template <class V> const float* flat(V const& v) { return reinterpret_cast<const float*>(v.data()); }  // vector<float> or vector<math::Vec3f>
+/** fn(slice, n_slices) for every slice, on up to `want` threads; slices that get no thread (built without -pthread, thread limit) run here */
+template <class Fn> void for_slices(unsigned want, Fn fn) {
+    unsigned const n = std::max(1u, std::min(want, std::max(1u, std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    unsigned started = 1;   // slice 0 is the caller's
+    try { for (; started < n; ++started) th.emplace_back(fn, started, n); } catch (std::system_error const&) {}
+    fn(0u, n);
+    for (unsigned t = started; t < n; ++t) fn(t, n);
+    for (auto& x : th) x.join();
+}
+/** the caller's chunk of the streamed table into its SparseTable (calculate_data_costs.cpp:291-298) */
+inline void fill_chunk(void* user, std::uint32_t first_face, std::uint32_t n_faces, const std::uint32_t* col_ptr, const std::uint16_t* view_id, const float* cost) {
+    DataCosts* dc = static_cast<DataCosts*>(user);
+    std::uint32_t const base = col_ptr[0];
+    for (std::uint32_t i = 0; i < n_faces; ++i)
+        for (std::uint32_t k = col_ptr[i]; k < col_ptr[i + 1]; ++k) dc->set_value(first_face + i, view_id[k - base], cost[k - base]);
+}
 }  // namespace detail
 
 /**
@@ -269,18 +287,21 @@ void calculate_data_costs(MeshConstPtr mesh, TextureViews* texture_views, Settin
     mvs_settings st;
     st.data_term = settings.data_term; st.outlier_removal = settings.outlier_removal;
     st.geometric_visibility_test = settings.geometric_visibility_test ? 1 : 0;
-    mvs_csr csr; std::memset(&csr, 0, sizeof(csr));
     mvs_dc_stats stats;
     detail::AdapterTiming& T = detail::last_timing(); T = detail::AdapterTiming();
     double const t1 = detail::now_ms();
     T.marshal_ms = t1 - t0;
-    detail::throw_status(mvs_data_costs(&m, views.data(), static_cast<std::uint32_t>(num_views), &st, &csr, &stats));
+    /* the table arrives in chunks of faces while the next chunk is still on the bus: the fill below (the caller's container, :291-298)
+     * hides the download; the table also stays on the device for the view_selection that follows (texrecon.cpp:100,121) */
+    detail::throw_status(mvs_data_costs_stream(&m, views.data(), static_cast<std::uint32_t>(num_views), &st, &detail::fill_chunk, data_costs, nullptr, &stats));
     double const t2 = detail::now_ms();
-    T.library_ms = t2 - t1; T.library_profile = mvs_last_call_profile();
-    for (std::uint32_t i = 0; i < csr.n_faces; ++i)          /* calculate_data_costs.cpp:291-298 */
-        for (std::uint32_t k = csr.col_ptr[i]; k < csr.col_ptr[i + 1]; ++k) data_costs->set_value(i, csr.view_id[k], csr.cost[k]);
-    T.table_fill_ms = detail::now_ms() - t2;
-    mvs_csr_free(&csr);
+    T.library_profile = mvs_last_call_profile();
+    /* library_ms = up to the first chunk; table_fill_ms = the chunk loop (set_value for every entry + whatever of the download it did not hide) */
+    {
+        double chunks = 0.0; std::size_t const at = T.library_profile.find("\"chunks_and_callbacks_ms\": ");
+        if (at != std::string::npos) chunks = std::atof(T.library_profile.c_str() + at + 27);
+        T.table_fill_ms = chunks; T.library_ms = (t2 - t1) - chunks;
+    }
     for (TextureView& tv : *texture_views) tv.release_image();  /* :231 */
     std::cout << "\tMaximum quality of a face within an image: " << stats.max_quality << std::endl;     /* :304-305 */
     std::cout << "\tClamping qualities to " << stats.percentile << " within normalization." << std::endl;
@@ -320,44 +341,66 @@ inline void view_selection(DataCosts const& data_costs, UniGraph* graph, Setting
     detail::AdapterTiming& T = detail::last_timing(); T = detail::AdapterTiming();
     double const t0 = detail::now_ms();
     std::uint32_t const F = data_costs.cols();
+    /* Is this the table calculate_data_costs just handed out (texrecon.cpp:100,121)?  Then it is still on the device.  Its fingerprint
+     * (mvs_viewsel.h) is summed over the caller's container column by column -- the container is READ once, nothing is copied. */
     std::vector<std::uint32_t> col_ptr(F + 1, 0);
-    std::vector<std::uint16_t> view_id(data_costs.get_nnz() + 1); std::vector<float> cost(data_costs.get_nnz() + 1);
-    {   /* the table as CSR (view_selection.cpp:27-82 reads it column by column): column offsets first, then the copies on a few threads */
-        for (std::uint32_t i = 0; i < F; ++i) col_ptr[i + 1] = col_ptr[i] + static_cast<std::uint32_t>(data_costs.col(i).size());
-        unsigned const n_threads = std::max(1u, std::min(8u, std::min(std::thread::hardware_concurrency(), static_cast<unsigned>(F / 65536u + 1u))));
-        auto copy = [&](unsigned t, unsigned of) {
+    for (std::uint32_t i = 0; i < F; ++i) col_ptr[i + 1] = col_ptr[i] + static_cast<std::uint32_t>(data_costs.col(i).size());
+    std::uint64_t const nnz = col_ptr[F];
+    unsigned const want = static_cast<unsigned>(std::min<std::uint64_t>(32u, nnz / (1u << 20) + 1u));
+    std::vector<std::uint64_t> part(std::max(1u, std::min(want, std::max(1u, std::thread::hardware_concurrency()))), 0);
+    detail::for_slices(static_cast<unsigned>(part.size()), [&](unsigned t, unsigned of) {
+        std::uint64_t h = 0;
+        for (std::uint32_t i = static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * t / of); i < static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * (t + 1) / of); ++i) {
+            h += mvs_fp_mix(i, col_ptr[i + 1]);
+            std::uint64_t k = col_ptr[i];
+            for (auto const& e : data_costs.col(i)) {
+                std::uint32_t bits; std::memcpy(&bits, &e.second, 4);
+                h += mvs_fp_mix((1ull << 40) + k, (static_cast<std::uint64_t>(e.first) << 32) | bits); ++k;
+            }
+        }
+        part[t] = h;
+    });
+    std::uint64_t fp = mvs_fp_mix(F, data_costs.rows()) + mvs_fp_mix(nnz, 1);
+    for (std::uint64_t v : part) fp += v;
+    double const t1 = detail::now_ms();
+    T.flatten_ms = t1 - t0;   /* the time spent READING the caller's container (fingerprint walk; plus the flatten below if the table is not the parked one) */
+    /* UniGraph adjacency lists flattened in list order */
+    std::vector<std::uint32_t> adj_ptr(F + 1, 0);
+    for (std::uint32_t i = 0; i < F; ++i) adj_ptr[i + 1] = adj_ptr[i] + static_cast<std::uint32_t>(graph->get_adj_nodes(i).size());
+    std::vector<std::uint32_t> adj(static_cast<std::size_t>(adj_ptr[F]) + 1, 0);
+    detail::for_slices(static_cast<unsigned>(std::min<std::uint32_t>(16u, F / 65536u + 1u)), [&](unsigned t, unsigned of) {
+        for (std::uint32_t i = static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * t / of); i < static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * (t + 1) / of); ++i) {
+            std::size_t k = adj_ptr[i];
+            for (std::size_t n : graph->get_adj_nodes(i)) adj[k++] = static_cast<std::uint32_t>(n);
+        }
+    });
+    double const t2 = detail::now_ms();
+    T.graph_ms = t2 - t1;
+    std::vector<std::uint32_t> labels(F, 0);
+    mvs_mrf_stats stats;
+    std::cout << "\tOptimizing:" << std::endl;
+    mvs_status st = mvs_view_selection_cached(fp, F, data_costs.rows(), nnz, adj_ptr.data(), adj.data(), nullptr, labels.data(), &stats);
+    double t3 = detail::now_ms();
+    if (st == MVS_ERR_STATE) {
+        /* not the parked table (changed by the caller, loaded from a file, computed elsewhere): flatten it and hand it over */
+        std::vector<std::uint16_t> view_id(nnz + 1); std::vector<float> cost(nnz + 1);
+        detail::for_slices(static_cast<unsigned>(std::min<std::uint32_t>(8u, F / 65536u + 1u)), [&](unsigned t, unsigned of) {
             for (std::uint32_t i = static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * t / of); i < static_cast<std::uint32_t>(static_cast<std::uint64_t>(F) * (t + 1) / of); ++i) {
                 std::size_t k = col_ptr[i];
                 for (auto const& e : data_costs.col(i)) { view_id[k] = e.first; cost[k] = e.second; ++k; }
             }
-        };
-        std::vector<std::thread> th;
-        unsigned started = 1;   // slice 0 is the caller's
-        try { for (; started < n_threads; ++started) th.emplace_back(copy, started, n_threads); }
-        catch (std::system_error const&) {}   // built without -pthread or out of threads: the slices that got no thread are copied here
-        copy(0, n_threads);
-        for (unsigned t = started; t < n_threads; ++t) copy(t, n_threads);
-        for (auto& x : th) x.join();
-    }
-    double const t1 = detail::now_ms();
-    T.flatten_ms = t1 - t0;
-    std::vector<std::uint32_t> adj_ptr(F + 1, 0), adj;
-    for (std::uint32_t i = 0; i < F; ++i) {
-        for (std::size_t n : graph->get_adj_nodes(i)) adj.push_back(static_cast<std::uint32_t>(n));
-        adj_ptr[i + 1] = static_cast<std::uint32_t>(adj.size());
-    }
-    if (adj.empty()) adj.push_back(0);
-    double const t2 = detail::now_ms();
-    T.graph_ms = t2 - t1;
-    mvs_csr csr;
-    csr.n_faces = F; csr.n_views = data_costs.rows(); csr.nnz = col_ptr[F];
-    csr.col_ptr = col_ptr.data(); csr.view_id = view_id.data(); csr.cost = cost.data();
-    std::vector<std::uint32_t> labels(F, 0);
-    mvs_mrf_stats stats;
-    std::cout << "\tOptimizing:" << std::endl;
-    detail::throw_status(mvs_view_selection(&csr, adj_ptr.data(), adj.data(), nullptr, labels.data(), &stats));
-    double const t3 = detail::now_ms();
-    T.library_ms = t3 - t2; T.library_profile = mvs_last_call_profile();
+        });
+        double const tf = detail::now_ms();
+        T.flatten_ms += tf - t3;
+        mvs_csr csr;
+        csr.n_faces = F; csr.n_views = data_costs.rows(); csr.nnz = nnz;
+        csr.col_ptr = col_ptr.data(); csr.view_id = view_id.data(); csr.cost = cost.data();
+        st = mvs_view_selection(&csr, adj_ptr.data(), adj.data(), nullptr, labels.data(), &stats);
+        t3 = detail::now_ms();
+        T.library_ms = t3 - tf;
+    } else T.library_ms = t3 - t2;
+    detail::throw_status(st);
+    T.library_profile = mvs_last_call_profile();
     std::cout << "\t\t" << stats.sweeps << " sweeps\t" << stats.energy << std::endl;
     for (std::uint32_t i = 0; i < F; ++i) graph->set_label(i, labels[i]);                  /* view_selection.cpp:130 */
     T.set_labels_ms = detail::now_ms() - t3;

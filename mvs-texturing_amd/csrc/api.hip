@@ -130,7 +130,23 @@ void park_spare(mvs_ctx* c) {
 }
 thread_local std::string g_call_profile = "{}";
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-inline uint64_t fp_mix(uint64_t k, uint64_t v) { uint64_t x = (k * 0x9E3779B97F4A7C15ull) ^ (v + 0x7F4A7C15D6E8FEB8ull); x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; return x; }
+inline uint64_t fp_mix(uint64_t k, uint64_t v) { return mvs_fp_mix(k, v); }   // (mvs_viewsel.h: the adapter sums the same terms over the caller's container)
+// the entry / column terms of the fingerprint of a DEVICE table: per-block sums, one 64-bit atomic each (wrap-around sums: any order)
+__device__ __forceinline__ unsigned long long fp_mix_dev(unsigned long long k, unsigned long long v) {   // == mvs_fp_mix (a host inline in the C header)
+    unsigned long long x = (k * 0x9E3779B97F4A7C15ull) ^ (v + 0x7F4A7C15D6E8FEB8ull); x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; return x;
+}
+__global__ void __launch_bounds__(256) fingerprint_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                          uint32_t F, uint64_t n, unsigned long long* __restrict__ out) {
+    unsigned long long h = 0ull;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i = t; i < F; i += stride) h += fp_mix_dev(i, col_ptr[i + 1]);
+    for (uint64_t k = t; k < n; k += stride) h += fp_mix_dev((1ull << 40) + k, ((unsigned long long)view_id[k] << 32) | __float_as_uint(cost[k]));
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    __shared__ unsigned long long sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
 // order-independent 64-bit sum of per-element mixes of (position, value) over col_ptr, view ids and cost bits: chunks add up, so it threads
 uint64_t csr_fingerprint(const mvs_csr* c) {
     const size_t F = c->n_faces, n = c->nnz;
@@ -672,6 +688,109 @@ void mvs_release_cached(void) {
     { std::lock_guard<std::mutex> lock(g_stash.m); a = g_stash.ctx; b = g_stash.spare; g_stash.ctx = nullptr; g_stash.spare = nullptr; g_stash.fp = 0; }
     if (a) mvs_ctx_destroy(a);
     if (b) mvs_ctx_destroy(b);
+}
+
+/* tex::calculate_data_costs with the result streamed out in chunks of faces (see mvs_viewsel.h) */
+mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_settings* settings,
+                                 mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats) {
+    if (!mesh || !views || !settings || !fn) return fail(MVS_ERR_INVALID, "null argument");
+    if (n_views > 65535u) return fail(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");   /* calculate_data_costs.cpp:315-318 */
+    double t[7]; t[0] = now_ms();
+    mvs_ctx* ctx = stash_enabled() ? take_spare() : nullptr;
+    if (!ctx && stash_enabled()) { std::lock_guard<std::mutex> lock(g_stash.m); ctx = g_stash.ctx; g_stash.ctx = nullptr; g_stash.fp = 0; }
+    mvs_status st = MVS_OK;
+    if (!ctx) st = mvs_ctx_create(default_device(), &ctx);
+    if (st != MVS_OK) return st;
+    t[1] = now_ms();
+    st = mvs_scene_set_mesh(ctx, mesh, 0);
+    t[2] = now_ms();
+    if (st == MVS_OK) st = mvs_scene_set_views(ctx, views, n_views, 0);
+    t[3] = now_ms();
+    if (st == MVS_OK) st = mvs_ctx_data_costs(ctx, settings, stats);
+    uint64_t fp = 0; double first_chunk_ms = 0.0;
+    if (st == MVS_OK) {
+        try {
+            hipStream_t s = ctx->stream;
+            const uint32_t F = ctx->csr_faces; const uint64_t nnz = ctx->csr_nnz;
+            const bool reordered = table_to_caller_order(ctx, false);
+            const uint32_t* d_ptr = reordered ? ctx->u_ptr.p : ctx->r_ptr; const uint16_t* d_view = reordered ? ctx->u_view.p : ctx->r_view;
+            const float* d_cost = reordered ? ctx->u_cost.p : ctx->r_cost;
+            // fingerprint of the table as it leaves, on the device
+            ctx->fp_acc.ensure(2);
+            MVS_HIP(hipMemsetAsync(ctx->fp_acc.p, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(fingerprint_kernel, dim3(2048), dim3(256), 0, s, d_ptr, d_view, d_cost, F, nnz, ctx->fp_acc.p); MVS_LAUNCH_CHECK();
+            // pinned staging: the column offsets whole, the entries in two buffers of one chunk each
+            ctx->stage_ptr.ensure((size_t)F + 2);
+            unsigned long long h_fp = 0;
+            MVS_HIP(hipMemcpyAsync(ctx->stage_ptr.p, d_ptr, ((size_t)F + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            MVS_HIP(hipMemcpyAsync(&h_fp, ctx->fp_acc.p, sizeof(h_fp), hipMemcpyDeviceToHost, s));
+            MVS_HIP(hipStreamSynchronize(s));
+            t[4] = now_ms();
+            fp = fp_mix(F, ctx->csr_views) + fp_mix(nnz, 1) + (uint64_t)h_fp;
+            const uint32_t* hp = ctx->stage_ptr.p;
+            constexpr uint32_t CHUNK = 1u << 16;   // faces per chunk
+            uint64_t max_entries = 1;
+            for (uint32_t f0 = 0; f0 < F; f0 += CHUNK) max_entries = std::max<uint64_t>(max_entries, (uint64_t)hp[std::min(F, f0 + CHUNK)] - hp[f0]);
+            for (int b = 0; b < 2; ++b) { ctx->stage_view[b].ensure(max_entries + 8); ctx->stage_cost[b].ensure(max_entries + 8); }
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            for (int b = 0; b < 2; ++b) MVS_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+            auto issue = [&](uint32_t f0, int b) {
+                const uint32_t f1 = std::min(F, f0 + CHUNK); const uint64_t e0 = hp[f0], ne = (uint64_t)hp[f1] - e0;
+                if (ne) {
+                    MVS_HIP(hipMemcpyAsync(ctx->stage_view[b].p, d_view + e0, ne * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+                    MVS_HIP(hipMemcpyAsync(ctx->stage_cost[b].p, d_cost + e0, ne * sizeof(float), hipMemcpyDeviceToHost, s));
+                }
+                MVS_HIP(hipEventRecord(ev[b], s));
+            };
+            try {
+                if (F) issue(0, 0);
+                int b = 0;
+                for (uint32_t f0 = 0; f0 < F; f0 += CHUNK, b ^= 1) {
+                    if (f0 + CHUNK < F) issue(f0 + CHUNK, b ^ 1);        // the next chunk travels while the caller consumes this one
+                    MVS_HIP(hipEventSynchronize(ev[b]));
+                    if (f0 == 0) first_chunk_ms = now_ms() - t[4];
+                    fn(user, f0, std::min(F, f0 + CHUNK) - f0, hp + f0, ctx->stage_view[b].p, ctx->stage_cost[b].p);
+                }
+            } catch (...) { for (int k = 0; k < 2; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]); throw; }
+            for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[k]);
+            if (shape_out) { memset(shape_out, 0, sizeof(*shape_out)); shape_out->n_faces = F; shape_out->n_views = ctx->csr_views; shape_out->nnz = nnz; }
+        } catch (const StatusError& e) { st = fail(e.st, e.what()); }
+          catch (const std::exception& e) { st = fail(MVS_ERR_HIP, e.what()); }
+    } else t[4] = now_ms();
+    t[5] = now_ms();
+    bool kept = false;
+    if (st == MVS_OK && stash_enabled()) {
+        std::lock_guard<std::mutex> lock(g_stash.m);
+        g_stash.ctx = ctx; g_stash.fp = fp; g_stash.nnz = ctx->csr_nnz; g_stash.n_faces = ctx->csr_faces; g_stash.n_views = ctx->csr_views;
+        kept = true;
+    }
+    if (!kept) { if (stash_enabled() && st == MVS_OK) park_spare(ctx); else mvs_ctx_destroy(ctx); }
+    char buf[640];
+    snprintf(buf, sizeof(buf), "{\"call\": \"mvs_data_costs_stream\", \"ctx_ms\": %.3f, \"mesh_h2d_ms\": %.3f, \"images_h2d_ms\": %.3f, \"compute_ms\": %.3f, \"first_chunk_ms\": %.3f, "
+             "\"chunks_and_callbacks_ms\": %.3f, \"fingerprint\": \"device\", \"table_kept_on_device\": %s}", t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], first_chunk_ms, t[5] - t[4], kept ? "true" : "false");
+    g_call_profile = buf;
+    return st;
+}
+
+/* tex::view_selection on the table parked by mvs_data_costs / mvs_data_costs_stream, identified by its fingerprint (see mvs_viewsel.h) */
+mvs_status mvs_view_selection_cached(uint64_t fingerprint, uint32_t n_faces, uint32_t n_views, uint64_t nnz, const uint32_t* adj_ptr, const uint32_t* adj,
+                                     const mvs_mrf_params* params, uint32_t* labels_out, mvs_mrf_stats* stats) {
+    if (!adj_ptr || !adj || !labels_out) return fail(MVS_ERR_INVALID, "null argument");
+    double t[3]; t[0] = now_ms();
+    mvs_ctx* ctx = nullptr;
+    if (stash_enabled()) {
+        std::lock_guard<std::mutex> lock(g_stash.m);
+        if (g_stash.ctx && g_stash.fp == fingerprint && g_stash.nnz == nnz && g_stash.n_faces == n_faces && g_stash.n_views == n_views) { ctx = g_stash.ctx; g_stash.ctx = nullptr; g_stash.fp = 0; }
+    }
+    if (!ctx) return fail(MVS_ERR_STATE, "no parked table with this fingerprint");
+    t[1] = now_ms();
+    mvs_status st = mvs_ctx_view_selection(ctx, adj_ptr, adj, 0, params, labels_out, 0, stats);
+    t[2] = now_ms();
+    if (st == MVS_OK) park_spare(ctx); else mvs_ctx_destroy(ctx);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "{\"call\": \"mvs_view_selection_cached\", \"lookup_ms\": %.3f, \"solve_ms\": %.3f, \"table_reused_on_device\": true}", t[1] - t[0], t[2] - t[1]);
+    g_call_profile = buf;
+    return st;
 }
 
 /* the undistortion step of from_images_and_camera_files (generate_texture_views.cpp:153-165) */

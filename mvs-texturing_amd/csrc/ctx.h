@@ -52,6 +52,25 @@ struct DBuf {
     DBuf& operator=(const DBuf&) = delete;
 };
 
+// Growable PINNED host buffer (device-to-host staging of the streamed table download, api.hip)
+template <class T>
+struct HBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) MVS_HIP(hipHostFree(p));
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        MVS_HIP(hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+    }
+    ~HBuf() { if (p) (void)hipHostFree(p); }
+    HBuf() = default;
+    HBuf(const HBuf&) = delete;
+    HBuf& operator=(const HBuf&) = delete;
+};
+
 // ---- implicit 4-ary BVH over Hilbert-sorted triangles (k_bvh.hip) ----
 struct alignas(128) Node4 {
     float b[4][6];            // child c: lo.x lo.y lo.z hi.x hi.y hi.z -- child-major, so that (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z) are
@@ -147,7 +166,9 @@ struct mvs_ctx {
     // order of the ACTIVE cost table (r_ptr ...): t_perm[p] = caller's id of column p (null: the table is in the caller's order)
     const uint32_t* t_perm = nullptr; const uint32_t* t_pos = nullptr;
     mvs::DBuf<uint32_t> u_ptr, u_cnt; mvs::DBuf<uint16_t> u_view; mvs::DBuf<float> u_cost, u_q;   // the table in the caller's order (built on demand)
-    bool u_valid = false;
+    bool u_valid = false, u_q_valid = false;
+    mvs::DBuf<unsigned long long> fp_acc;   // device-side fingerprint of the table handed out (api.hip mvs_data_costs_stream)
+    mvs::HBuf<uint32_t> stage_ptr; mvs::HBuf<uint16_t> stage_view[2]; mvs::HBuf<float> stage_cost[2];   // pinned staging of the chunked download
 
     // ---- BVH + incidence ----
     mvs::DBuf<mvs::Node4> bvh_nodes; mvs::DBuf<float4> bvh_tris;

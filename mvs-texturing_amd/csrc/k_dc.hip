@@ -1226,7 +1226,7 @@ void dc_prune_labels(mvs_ctx* ctx, uint32_t kmax) {
         MVS_HIP(hipMemcpyAsync(ctx->csr_cost.p, ctx->pcol.p, (size_t)nnz2 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (have_q) MVS_HIP(hipMemcpyAsync(ctx->csr_q.p, ctx->pre_q.p, (size_t)nnz2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    ctx->csr_nnz = nnz2; ctx->dc_stats.nnz = nnz2;
+    ctx->csr_nnz = nnz2; ctx->dc_stats.nnz = nnz2; ctx->u_valid = false;
     ctx->r_ptr = ctx->csr_ptr.p; ctx->r_view = ctx->csr_view.p; ctx->r_cost = ctx->csr_cost.p;
 }
 

@@ -553,6 +553,9 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 #ifndef MVS_SWEEP_EXP
 #define MVS_SWEEP_EXP 0
 #endif
+#ifndef MVS_SWEEP_DROP   // probe only: bit 0 = no neighbour-label gathers, 1 = no incoming runs, 2 = no record, 3 = no stores, 4 = no old runs
+#define MVS_SWEEP_DROP 0
+#endif
 #if MVS_SWEEP_EXP == 1
 #define MVS_XO(o) ((o) & 0xFFF0u)
 #else
@@ -618,15 +621,15 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
     const uint32_t t0b = 4u * t0, glb = 4u * (uint32_t)gl;   // byte offsets of the lane's label words / map word inside a record
     auto issue = [&](const NodeDesc& d, Raw& r) {
         const uint32_t K = d.kk & 0xFFu, recb = 4u * d.rec;
-        r.lw = ld_off<uint4>(rec, MVS_XO(recb + t0b));
+        if (MVS_SWEEP_DROP & 4) r.lw = make_uint4(recb, K, 0u, 0u); else r.lw = ld_off<uint4>(rec, MVS_XO(recb + t0b));
         uint32_t mposb = recb + 4u * ((K + 3u) & ~3u) + glb;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            r.in[e] = ld_off<uint32_t>(mo, MVS_XO((d.in_off[e] & ~3u) + t0));
-            r.map[e] = ld_off<uint32_t>(rec, MVS_XO(mposb));
+            if (MVS_SWEEP_DROP & 2) r.in[e] = d.in_off[e]; else r.in[e] = ld_off<uint32_t>(mo, MVS_XO((d.in_off[e] & ~3u) + t0));
+            if (MVS_SWEEP_DROP & 4) r.map[e] = mposb; else r.map[e] = ld_off<uint32_t>(rec, MVS_XO(mposb));
             if (!(d.out_off[e] & 1u)) mposb += (((d.kk >> (8 + 8 * e)) & 0xFFu) + 3u) & ~3u;   // 4 bytes per 4 map entries
-            r.nl[e] = ld_off<uint32_t>(lab, MVS_XO(4u * d.nbr[e]));     // an absent neighbour is recorded as the node itself
-            if (DAMP) r.old[e] = ld_off<uint32_t>(mo, MVS_XO((d.out_off[e] & ~3u) + t0)); else r.old[e] = 0u;
+            if (MVS_SWEEP_DROP & 1) r.nl[e] = d.nbr[e]; else r.nl[e] = ld_off<uint32_t>(lab, MVS_XO(4u * d.nbr[e]));     // an absent neighbour is recorded as the node itself
+            if (DAMP && !(MVS_SWEEP_DROP & 16)) r.old[e] = ld_off<uint32_t>(mo, MVS_XO((d.out_off[e] & ~3u) + t0)); else r.old[e] = d.out_off[e];
         }
     };
     NodeDesc cur = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i, last));
@@ -655,7 +658,8 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
         {   // memory floor: every loaded word is consumed, every store is made, nothing is computed
             const uint32_t x = ((lw[0] ^ lw[1]) ^ (lw[2] ^ lw[3])) ^ ((r_in[0] ^ r_in[1]) ^ (r_in[2] ^ r_map[0])) ^ ((r_map[1] ^ r_map[2]) ^ (nl[0] ^ nl[1])) ^ (nl[2] ^ r_old[0] ^ r_old[1] ^ r_old[2]);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) if (t0 < kj3[d]) st_off<uint32_t>(mn, o_out[d] + t0, x);
+            for (int d = 0; d < 3; ++d) if (t0 < kj3[d] && !(MVS_SWEEP_DROP & 8)) st_off<uint32_t>(mn, o_out[d] + t0, x);
+            if ((MVS_SWEEP_DROP & 8) && x == 0x12345u) st_off<uint32_t>(mn, o_out[0] + t0, x);   // (keeps the loads alive)
             if (node_ok && gl == 0) { const uint32_t idb = 4u * cur.id; st_off<uint32_t>(sel, idb, x & 3u); st_off<uint32_t>(lab, idb, (x & 15u) + 1u); st_off<float>(selcost, idb, 0.5f); acc_e += x & 1u; }
             cur = nxt; rw = rn; nxt = nn;
             continue;

@@ -67,7 +67,7 @@ __global__ void iota_u32_kernel(uint32_t* __restrict__ v, uint32_t n) {
 bool table_to_caller_order(mvs_ctx* ctx, bool with_quality) {
     if (!ctx->t_perm) return false;
     const bool want_q = with_quality && ctx->csr_q_valid;
-    if (ctx->u_valid && (!want_q || ctx->u_q.cap)) return true;
+    if (ctx->u_valid && (!want_q || ctx->u_q_valid)) return true;
     hipStream_t s = ctx->stream;
     const uint32_t F = ctx->csr_faces; const size_t nnz = ctx->csr_nnz;
     Prof pr(ctx, "order_table_out");
@@ -80,7 +80,7 @@ bool table_to_caller_order(mvs_ctx* ctx, bool with_quality) {
                            want_q ? (const float*)ctx->csr_q.p : (const float*)nullptr, ctx->t_pos, (const uint32_t*)ctx->u_ptr.p, F, ctx->u_view.p, ctx->u_cost.p, ctx->u_q.p);
         MVS_LAUNCH_CHECK();
     }
-    ctx->u_valid = true;
+    ctx->u_valid = true; ctx->u_q_valid = want_q;
     return true;
 }
 

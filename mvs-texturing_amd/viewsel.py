@@ -148,6 +148,8 @@ def load_library():
         "mvs_shard_own_faces": [vp, vp, C.POINTER(u32)],
         "mvs_ctx_partition_faces": [vp, i32, vp, vp], "mvs_partition_faces": [C.POINTER(CMesh), i32, vp, vp],
         "mvs_ctx_table_order": [vp, vp, C.POINTER(i32)],
+        "mvs_data_costs_stream": [C.POINTER(CMesh), C.POINTER(CView), u32, C.POINTER(Settings), vp, vp, C.POINTER(CCsr), C.POINTER(DcStats)],
+        "mvs_view_selection_cached": [u64, u32, u32, u64, vp, vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)

@@ -9,7 +9,7 @@ import numpy as np
 import mvs_texturing_amd as M
 
 
-def child(lib, scene, sweeps, q):
+def child(lib, scene, sweeps, kernel, q):
     try:
         if lib:
             M.viewsel._LIB_PATH = os.path.abspath(lib)
@@ -38,7 +38,7 @@ def child(lib, scene, sweeps, q):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(); ap.add_argument("--config", type=lambda v: int(v) if v.isdigit() else v, default=3)
-    ap.add_argument("--sweeps", type=int, default=20); ap.add_argument("--rounds", type=int, default=2); ap.add_argument("libs", nargs="+")
+    ap.add_argument("--sweeps", type=int, default=20); ap.add_argument("--kernel", type=int, default=4); ap.add_argument("--rounds", type=int, default=2); ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     scene = M.synth.make_scene(**M.synth.CONFIGS[a.config])
     ctx = mp.get_context("fork")
@@ -46,6 +46,6 @@ if __name__ == "__main__":
     for r in range(a.rounds):
         for spec in a.libs:
             name, _, path = spec.partition("=")
-            q = ctx.Queue(); p = ctx.Process(target=child, args=(path, scene, a.sweeps, q)); p.start(); out = q.get(timeout=150); p.join(timeout=30)
+            q = ctx.Queue(); p = ctx.Process(target=child, args=(path, scene, a.sweeps, a.kernel, q)); p.start(); out = q.get(timeout=150); p.join(timeout=30)
             res.setdefault(name, []).append(out)
     print(json.dumps({"config": a.config, "faces": scene.n_faces, "results": {k: {"ms_per_sweep": [round(x["ms_per_sweep"], 4) for x in v], "sweeps": v[0]["sweeps"], "nnz": v[0]["nnz"]} for k, v in res.items()}}), flush=True)

@@ -50,6 +50,9 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "\tOptimization failed: %s\n", e.what());                                                  /* :123 */
         return 1;
     }
+    /* the table calculate_data_costs handed out was still on the device: view_selection found it by its fingerprint */
+    bool const cached = tex::detail::last_timing().library_profile.find("mvs_view_selection_cached") != std::string::npos;
+    std::printf("view_selection on the parked table: %s\n", cached ? "yes" : "no");
     std::vector<std::size_t> labeling(graph.num_nodes());                         /* :130-136 */
     for (std::size_t i = 0; i < graph.num_nodes(); ++i) labeling[i] = graph.get_label(i);
     std::ofstream out((prefix + "_labeling.vec").c_str(), std::ios::binary);
@@ -58,6 +61,15 @@ int main(int argc, char** argv) {
     tex::DataCosts reload(static_cast<std::uint32_t>(num_faces), static_cast<std::uint16_t>(texture_views.size()));
     tex::DataCosts::load_from_file(prefix + "_data_costs.spt", &reload);          /* texrecon.cpp:110 */
     if (reload.get_nnz() != data_costs.get_nnz()) return 5;
+    {   /* the same table again (nothing is parked any more) and a table loaded from the file: both take the flatten-and-upload route, same labels */
+        tex::Graph g2(num_faces);
+        for (uint32_t i = 0; i < sm.n_faces; ++i)
+            for (uint32_t e = sm.adj_ptr[i]; e < sm.adj_ptr[i + 1]; ++e) g2.add_edge(i, sm.adj[e]);
+        tex::view_selection(reload, &g2, settings);
+        bool const uploaded = tex::detail::last_timing().library_profile.find("\"mvs_view_selection\"") != std::string::npos;
+        for (std::size_t i = 0; i < graph.num_nodes(); ++i) if (g2.get_label(i) != graph.get_label(i)) return 7;
+        std::printf("view_selection on a reloaded table: %s, same labels\n", uploaded ? "uploaded" : "parked");
+    }
     /* generate_texture_patches.cpp:469-475: subgraphs of every label == the reference's loop (uni_graph.cpp:21-55) */
     std::size_t n_patches = 0;
     for (std::size_t label = 0; label <= texture_views.size(); ++label) {

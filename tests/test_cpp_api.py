@@ -38,6 +38,8 @@ def test_texrecon_call_sequence_matches_oracle(tmp_path):
     r = subprocess.run([exe, prefix, "8", "8"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "faces have not been seen" in r.stdout and "Clamping qualities to" in r.stdout
+    assert "view_selection on the parked table: yes" in r.stdout                 # the table never crossed the bus a second time
+    assert "view_selection on a reloaded table: uploaded, same labels" in r.stdout
     s = M.synth.make_scene(n=8, n_views=8, width=320, height=240, displacement=0.2, layout=1, zoom_odd=1.4, black_corner=20)
     ref, _ = O.data_costs(s)
     lo, so = O.view_selection(ref, s.adj_ptr, s.adj)

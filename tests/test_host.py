@@ -24,7 +24,7 @@ def _lib_or_skip():
 def test_header_symbols_exported():
     L = _lib_or_skip()
     header = open(os.path.join(ROOT, "include", "mvs_viewsel.h")).read()
-    declared = sorted(set(re.findall(r"\b(mvs_[a-z0-9_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(mvs_[a-z0-9_]+)\s*\(", header)) - {"mvs_fp_mix"})   # (a static inline of the header, not an export)
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(L, name), "missing export " + name
