@@ -448,8 +448,9 @@ def main():
             _, ms = ctx.view_selection(t_ap, t_ad, params, labels_out=t_lab)
             info["nnz_global"] = int(st["nnz"])
         elif args.backend == "nccl":
-            # the product's sharded path: host side in C++ (csrc/shard.hip), halo exchange by RCCL over xGMI; nothing is
-            # cached between steps -- the halo plan is rebuilt on the device inside every step (reported as mrf_plan).
+            # the product's sharded path: host side in C++ (csrc/shard.hip), halo exchange by RCCL over xGMI.  What follows from
+            # (adjacency, partition, column LENGTHS) alone -- the shape of the sharded table, the halo plan -- is kept from step to step
+            # while the all-gathered column lengths stay the same (compared on the device every step); costs, messages, labels are not.
             # A communicator that cannot be set up is an error (no second driver to fall back to).
             if "shard" not in info:
                 uid = [M.shard.unique_id() if rank == 0 else None]

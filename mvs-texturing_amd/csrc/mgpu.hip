@@ -4,6 +4,7 @@
 // on caller-owned device buffers; these entry points only move data between
 // those buffers and the solver's arrays and run the per-range kernels.
 #include "ctx.h"
+#include <vector>
 
 namespace mvs {
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);

@@ -1555,7 +1555,9 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     ds = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert ds["config"]["nnz"] == d1["config"]["nnz"] and ds["config"]["sweeps"] == d1["config"]["sweeps"] and abs(ds["config"]["energy"] - d1["config"]["energy"]) < 1e-6
-    assert "mrf_plan" in ds["stages"] and ds["halo"]["driver"].startswith("C++")
+    # (the halo plan and the sharded table's shape are kept from step to step while the column lengths stay the same: the profiled
+    # steps no longer contain an mrf_plan stage, and the plan of the last step cost nothing)
+    assert ds["halo"]["driver"].startswith("C++") and ds["halo"]["plan_ms"] == 0.0 and ds["halo"]["boundary_nodes"] == 0
     assert ds["sharded_driver"].startswith("C++")
     env["MVS_BENCH_ONE_GPU"] = "1"
     port = 29600 + os.getpid() % 2000
