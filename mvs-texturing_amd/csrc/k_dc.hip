@@ -49,6 +49,9 @@ __device__ __forceinline__ void block_count_add(const uint32_t (&c)[N], unsigned
 }
 
 // ---- culls (calculate_data_costs.cpp:171-191) ----
+// A block holds 256 faces in registers (vertices, normal, centre: gathered ONCE) and walks ALL views, 32 at a time: the face-major copy
+// of a chunk's pass bits is one word per face.  (Until round 4 the grid had a second dimension over the view chunks, and every chunk's
+// block gathered the same vertices again: 7 times at 200 views -- 0.5 GB of the kernel's 0.69 GB of HBM traffic at config 3.)
 template <bool STATS>
 __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, const float* __restrict__ normals,
                                                    const ViewParams* __restrict__ views, uint32_t n_views, uint32_t fb, uint32_t nf, uint32_t fwords,
@@ -60,22 +63,27 @@ __global__ void __launch_bounds__(256) cull_kernel(const float* __restrict__ ver
     const size_t f = (size_t)fb + (act ? lf : 0);
     const uint32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     const V3 v1 = ld3(verts, i0), v2 = ld3(verts, i1), v3 = ld3(verts, i2), nrm = ld3(normals, f);
-    uint32_t mine = 0;   // this face's pass bits for the views of the chunk (face-major copy for need_kernel: one load instead of 32)
-    const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     uint32_t cnt[4] = {0, 0, 0, 0};
     // the clear cases of the first two culls are decided without normalisations: dmath.h cull_pair_prefiltered
     const V3 centre = ((v1 + v2) + v3) / 3.0f;
     if (wave_ok) {
-        for (uint32_t j = j0; j < j1; ++j) {
-            const ViewParams& vw = views[j];
-            const int reason = act ? cull_pair_prefiltered(vw, v1, v2, v3, nrm, centre, cos_limit) : -1;
-            if (STATS) { cnt[0] += reason == 1; cnt[1] += reason == 2; cnt[2] += reason == 3; cnt[3] += reason == 0; }
-            const unsigned long long b = __ballot(reason == 0);
-            if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
-            mine |= (reason == 0 ? 1u : 0u) << (j - j0);
+        // (blockIdx.y splits the chunks only when there are too few face blocks to fill the chip: a small mesh under many views)
+        const uint32_t n_chunks = (n_views + VIEW_CHUNK - 1) / VIEW_CHUNK, per = (n_chunks + gridDim.y - 1) / gridDim.y;
+        const uint32_t c_begin = blockIdx.y * per, c_end = min(c_begin + per, n_chunks);
+        for (uint32_t chunk = c_begin, j0 = c_begin * VIEW_CHUNK; chunk < c_end; j0 += VIEW_CHUNK, ++chunk) {
+            const uint32_t j1 = min(j0 + VIEW_CHUNK, n_views);
+            uint32_t mine = 0;   // this face's pass bits for the views of the chunk (face-major copy for need_kernel: one load instead of 32)
+            for (uint32_t j = j0; j < j1; ++j) {
+                const ViewParams& vw = views[j];
+                const int reason = act ? cull_pair_prefiltered(vw, v1, v2, v3, nrm, centre, cos_limit) : -1;
+                if (STATS) { cnt[0] += reason == 1; cnt[1] += reason == 2; cnt[2] += reason == 3; cnt[3] += reason == 0; }
+                const unsigned long long b = __ballot(reason == 0);
+                if (lane == 0) pass[(size_t)j * fwords + (lf >> 6)] = b;
+                mine |= (reason == 0 ? 1u : 0u) << (j - j0);
+            }
+            if (pass_face) pass_face[(size_t)chunk * ((size_t)fwords * 64u) + lf] = mine;
         }
-        if (pass_face) pass_face[(size_t)blockIdx.y * ((size_t)fwords * 64u) + lf] = mine;
     }
     if (STATS) { const int slot[4] = {C_BACK, C_ANGLE, C_OUTSIDE, C_PASS}; block_count_add<4>(cnt, counters, slot); }
 }
@@ -840,11 +848,13 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     uint32_t* pass_face = nullptr;
     if (vis) { ctx->pass_face.ensure((size_t)fgrid.y * fwords * 64u + 1); pass_face = ctx->pass_face.p; }
     Prof pr_cull(ctx, "dc_cull");
+    // one block per 256 faces walks all view chunks; the chunks are split over blockIdx.y only to reach ~4096 blocks on small meshes
+    const dim3 cgrid(fgrid.x, std::max(1u, std::min<unsigned>(fgrid.y, (4096u + fgrid.x - 1) / fgrid.x)));
     if (ctx->stats)
-        hipLaunchKernelGGL(cull_kernel<true>, fgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->inr, ctx->d_views.p, V, fb, nf, fwords,
+        hipLaunchKernelGGL(cull_kernel<true>, cgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->inr, ctx->d_views.p, V, fb, nf, fwords,
                            ctx->cos_limit, ctx->pass_bits.p, pass_face, ctx->counters.p);
     else
-        hipLaunchKernelGGL(cull_kernel<false>, fgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->inr, ctx->d_views.p, V, fb, nf, fwords,
+        hipLaunchKernelGGL(cull_kernel<false>, cgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->inr, ctx->d_views.p, V, fb, nf, fwords,
                            ctx->cos_limit, ctx->pass_bits.p, pass_face, ctx->counters.p);
     MVS_LAUNCH_CHECK();
     pr_cull.end();
