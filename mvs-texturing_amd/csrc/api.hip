@@ -756,6 +756,7 @@ mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, ui
             if (shape_out) { memset(shape_out, 0, sizeof(*shape_out)); shape_out->n_faces = F; shape_out->n_views = ctx->csr_views; shape_out->nnz = nnz; }
         } catch (const StatusError& e) { st = fail(e.st, e.what()); }
           catch (const std::exception& e) { st = fail(MVS_ERR_HIP, e.what()); }
+          catch (...) { st = fail(MVS_ERR_INVALID, "the chunk callback threw"); }   // nothing may unwind through the C ABI
     } else t[4] = now_ms();
     t[5] = now_ms();
     bool kept = false;

@@ -1,15 +1,15 @@
 #!/bin/bash
-# one GPU-box session of round 3.  Steps are selected by STEPS="smoke tests bench cliffs pmc prof c2 real" (default: all of the
-# first line); every step has its own timeout and writes under gpurun_out/ (tag: $TAG, default r03).
+# one GPU-box session.  Steps are selected by STEPS="smoke tests bench cliffs pmc prof c2 real" (default: all of the
+# first line); every step has its own timeout and writes under gpurun_out/ (tag: $TAG, default r04).
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 STEPS=${STEPS:-"smoke tests bench cliffs pmc prof"}
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has smoke; then echo "== smoke + quick bench (config 2)"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
   ( time timeout 600 python bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline ) > gpurun_out/${TAG}_bench_c2.json 2> gpurun_out/${TAG}_bench_c2.err; tail -2 gpurun_out/${TAG}_bench_c2.err; head -c 1500 gpurun_out/${TAG}_bench_c2.json; echo; fi
-if has tests; then echo "== pytest -m gpu ${PYTEST_K:+-k $PYTEST_K}"; ( time timeout 1500 python -m pytest tests -q -x -m gpu ${PYTEST_K:+-k "$PYTEST_K"} ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -15 gpurun_out/${TAG}_pytest_gpu.log; fi
-if has bench; then echo "== bench config 3"; ( time timeout 1500 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 ) > gpurun_out/${TAG}_bench_c3.json 2> gpurun_out/${TAG}_bench_c3.err; tail -4 gpurun_out/${TAG}_bench_c3.err; python - <<P
+if has tests; then echo "== pytest -m gpu ${PYTEST_K:+-k $PYTEST_K}"; ( time timeout ${TEST_TIMEOUT:-1000} python -m pytest tests -q -x -m gpu -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -15 gpurun_out/${TAG}_pytest_gpu.log; fi
+if has bench; then echo "== bench config 3"; ( time timeout 600 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 ) > gpurun_out/${TAG}_bench_c3.json 2> gpurun_out/${TAG}_bench_c3.err; tail -4 gpurun_out/${TAG}_bench_c3.err; python - <<P
 import json
 try:
     d = json.load(open("gpurun_out/${TAG}_bench_c3.json"))
@@ -28,12 +28,12 @@ try:
 except Exception as e: print("cliffs output unreadable:", e)
 P
 fi
-if has pmc; then echo "== SQ counters (config 3)"; ( time timeout 1200 python scripts/pmc_sq.py --config 3 --out gpurun_out/${TAG}_pmc_sq_c3.json ) 2>&1 | tail -14; fi
-if has pmcreal; then echo "== SQ counters (real-like)"; ( time timeout 900 python scripts/pmc_sq.py --config real --groups 2 --out gpurun_out/${TAG}_pmc_sq_real.json ) 2>&1 | tail -12; fi
+if has pmc; then echo "== SQ counters (config 3)"; ( time timeout 500 python scripts/pmc_sq.py --config 3 --out gpurun_out/${TAG}_pmc_sq_c3.json ) 2>&1 | tail -14; fi
+if has pmcreal; then echo "== SQ counters (real-like)"; ( time timeout 300 python scripts/pmc_sq.py --config real --groups 2 --out gpurun_out/${TAG}_pmc_sq_real.json ) 2>&1 | tail -12; fi
 if has prof; then
   echo "== rocprofv3 kernel trace"
   REPO=$PWD; cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_${TAG} -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-parity --no-real-like > $REPO/gpurun_out/${TAG}_prof_bench.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_${TAG} -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-parity --no-real-like --no-shuffled --no-dropin > $REPO/gpurun_out/${TAG}_prof_bench.log 2>&1
   cd $REPO; f=$(find gpurun_out/prof_${TAG} -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/${TAG}_bench_c3_kernel_stats.csv && head -12 $f | cut -c1-160
   rm -rf gpurun_out/prof_${TAG}
 fi
