@@ -5,7 +5,7 @@ Images are uploaded once and shared by the ranks' contexts (each rank of a real 
 The mesh goes in as built: the parts are the library's own equal cut of its own face order (mvs_ctx_partition_faces).
 Checks: every face labelled with a view of its (compressed) column, all-reduced energy identical on every rank; with a second
 partition (--also P2) labels, energy, sweeps identical for both partitions; with --oracle-window W every rank's table against the LIVE
-ORACLE on a window of W of its own faces (pattern and view ids of the compressed columns; costs bit for bit, restated from the oracle's
+ORACLE on a window of W / P of its own faces (pattern and view ids of the compressed columns; costs bit for bit, restated from the oracle's
 qualities with the run's global percentile and pruned by orc_prune_labels).  Prints one JSON line.
 usage: python scripts/config5_full.py [--n 707] [--views 1000] [--parts 8] [--also 4] [--max-labels 64] [--oracle-window 100000]"""
 import argparse, json, os, sys, threading, time
@@ -34,28 +34,38 @@ tap, tad = torch.from_numpy(adj_ptr.view(np.int32)).to(dev), torch.from_numpy(ad
 params = M.viewsel.default_mrf_params()
 
 
-def oracle_window(own, tab, pct):
-    """the first W own faces of a rank (consecutive on the library's curve: a compact patch) against the live oracle"""
+def oracle_windows(ranks, W):
+    """the first W own faces of EVERY rank (consecutive on the library's curve: compact patches) against the live oracle, in ONE oracle
+    call (the oracle's BVH over all faces and its image preparation are paid once)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     O.build_oracle()
-    W = min(a.oracle_window, len(own))
-    ids = own[:W].astype(np.int64)
+    wins = [o["own"][:min(W, len(o["own"]))].astype(np.int64) for o in ranks]
+    ids = np.concatenate(wins)
     rest = np.setdiff1d(np.arange(F, dtype=np.int64), ids)
+    pct = ranks[0]["percentile"]
+    assert all(o["percentile"] == pct for o in ranks)          # the all-reduced histogram gives every rank the same percentile
 
-    class S2:   # the window's faces first, the rest of the mesh behind them (the occluder set is unchanged)
+    class S2:   # the windows' faces first, the rest of the mesh behind them (the occluder set is unchanged)
         pass
     s2 = S2(); s2.verts = s.verts; s2.faces = np.ascontiguousarray(np.concatenate([faces[ids], faces[rest]])); s2.normals = np.ascontiguousarray(np.concatenate([normals[ids], normals[rest]]))
     s2.cams, s2.images, s2.n_views, s2.n_faces = s.cams, s.images, s.n_views, F
-    ref, _ = O.data_costs(s2, face_range=(0, W), n_threads=max(1, min(32, len(os.sched_getaffinity(0)))))
+    ref, _ = O.data_costs(s2, face_range=(0, len(ids)), n_threads=max(1, min(64, len(os.sched_getaffinity(0)))))
     refc = O.CsrNp(ref.n_faces, ref.n_views, ref.col_ptr, ref.view_id, np.float32(1.0) - np.minimum(np.float32(1.0), ref.quality / np.float32(pct)), ref.quality)
     refp = O.prune_labels(refc, a.max_labels) if a.max_labels else refc
-    cp = tab.col_ptr.astype(np.int64); rp = refp.col_ptr.astype(np.int64)
-    ok = bool(np.array_equal(np.diff(rp), cp[ids + 1] - cp[ids]))
-    if ok:
-        idx = np.repeat(cp[ids], np.diff(rp)) + (np.arange(int(rp[-1])) - np.repeat(rp[:-1], np.diff(rp)))
-        ok = bool(np.array_equal(refp.view_id, tab.view_id[idx]) and np.array_equal(refp.cost.view(np.uint32), tab.cost[idx].view(np.uint32)))
-    return dict(faces=int(W), entries=int(rp[-1]), equal=ok)
+    rp = refp.col_ptr.astype(np.int64)
+    out, at = [], 0
+    for o, w in zip(ranks, wins):
+        tab = o["table"]; cp = tab.col_ptr.astype(np.int64)
+        r0, r1 = int(rp[at]), int(rp[at + len(w)])
+        lens = np.diff(rp[at:at + len(w) + 1])
+        ok = bool(np.array_equal(lens, cp[w + 1] - cp[w]))
+        if ok:
+            idx = np.repeat(cp[w], lens) + (np.arange(r1 - r0) - np.repeat(rp[at:at + len(w)] - r0, lens))
+            ok = bool(np.array_equal(refp.view_id[r0:r1], tab.view_id[idx]) and np.array_equal(refp.cost[r0:r1].view(np.uint32), tab.cost[idx].view(np.uint32)))
+        out.append(dict(rank=o["rank"], faces=int(len(w)), entries=r1 - r0, equal=ok))
+        at += len(w)
+    return out
 
 
 def run(P):
@@ -118,7 +128,7 @@ o1, w1 = run(a.parts)
 lab1 = all_labels(o1)
 if a.oracle_window:
     t = time.time()
-    wins = [oracle_window(o["own"], o["table"], o["percentile"]) for o in o1]
+    wins = oracle_windows(o1, max(1, a.oracle_window // a.parts))
     res["oracle_windows"] = wins; res["oracle_windows_equal"] = bool(all(w["equal"] for w in wins)); res["oracle_s"] = time.time() - t
 res["P"] = a.parts; res["wall_s_all_ranks_on_one_gpu"] = w1
 res["ranks"] = [{k: v for k, v in o.items() if k not in ("labels", "own", "table")} for o in o1]
