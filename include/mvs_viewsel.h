@@ -242,7 +242,9 @@ mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
  * the energy reports it reads, default 1; identical results), "mrf_graph" (1 = the sweep loop is replayed from a hipGraph, the default;
  * identical results), tuning knobs "mrf_xcd", "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd", "prep_fused" (1 = luminance +
  * Sobel in one pass through LDS, the default; identical output), "face_order" (1 = the library lays the faces out along a Hilbert curve, the
- * default; 0 = the caller's face numbering is kept; identical results), test hooks "info_cert_shift", "mrf_force_generic" */
+ * default; 0 = the caller's face numbering is kept; identical results), "shard_peer_push" (sharded sweep loop: 1 = boundary runs are stored straight into the
+ * neighbours' arrays where the communicator's ranks can address each other's memory, the default; 0 = pack / exchange / unpack through the
+ * communicator; must agree on all ranks; identical results), test hooks "info_cert_shift", "mrf_force_generic" */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 
 /* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,
@@ -433,6 +435,11 @@ mvs_status mvs_postprocess_face_infos(uint32_t n_faces, uint32_t n_views, const 
  * labels of that phase's boundary nodes with the ranks that own the neighbours: grouped ncclSend / ncclRecv, neighbours
  * only.  Results are bit-identical to the single-GPU path for any number of parts.
  *
+ * Transport of the sweep loop: through the communicator (one pack launch, one grouped exchange, one unpack launch per colour phase), or
+ * -- where the ranks can address each other's device memory (today: the in-process communicator) -- "peer push": one launch per phase
+ * stores the runs at their final places in the neighbours' arrays, ordering is by one stream event per phase and rank (waited for on
+ * the stream, never on the host), the sweep's energy pair is published the same way and summed by every rank on the device.
+ *
  * Communicators: RCCL (mvs_comm_unique_id on rank 0, the 128 bytes travel by any means, mvs_comm_create_rccl on every
  * rank) or an in-process one for `world` host threads sharing a device (mvs_comm_create_local: tests on a 1-GPU box). */
 #define MVS_COMM_ID_BYTES 128
@@ -455,6 +462,9 @@ mvs_status mvs_shard_data_costs(mvs_shard* shard, const mvs_settings* settings, 
 mvs_status mvs_shard_view_selection(mvs_shard* shard, const mvs_mrf_params* params, uint32_t* labels_own_device, mvs_mrf_stats* stats);
 /* halo plan of the last view selection: message bytes this rank sends per sweep, its boundary nodes, device time of the planning */
 mvs_status mvs_shard_plan_info(mvs_shard* shard, uint64_t* msg_bytes_per_sweep, uint64_t* boundary_nodes, double* plan_ms);
+/* transport of the last view selection: peer_push = 1 if the runs were stored into the peers' arrays; colour phases pushed so far (all solves);
+ * ranks this one shares a cut with; colour phases per sweep */
+mvs_status mvs_shard_transport_info(mvs_shard* shard, int* peer_push, uint64_t* phases_pushed, int* neighbours, uint32_t* colour_phases);
 
 #ifdef __cplusplus
 }

@@ -297,6 +297,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "ray_xcd") ctx->ray_xcd = (int)value;
     else if (n == "mrf_xcd") ctx->mrf_xcd = (int)value;
     else if (n == "mrf_lag") ctx->mrf_lag = (int)value;
+    else if (n == "shard_peer_push") ctx->shard_peer_push = value != 0;
     else if (n == "mrf_force_generic") ctx->mrf_force_generic = value != 0;
     else if (n == "mrf_graph") ctx->mrf_graph = value != 0;
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;

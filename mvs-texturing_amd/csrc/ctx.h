@@ -245,6 +245,7 @@ struct mvs_ctx {
     // private stream, launched on the context's stream; re-captured per solve and pushed into the instantiated graph with hipGraphExecUpdate
     int mrf_graph = 1; hipStream_t cap_stream = nullptr; hipGraphExec_t sweep_exec = nullptr; uint32_t graph_launches = 0, graph_updates = 0, graph_instantiations = 0;
     mvs_mrf_progress* h_ring = nullptr; mvs_mrf_progress* d_ring = nullptr /* the same pinned slots as the device addresses them */; uint32_t steps_issued = 0; int mrf_lag = 1;
+    int shard_peer_push = 1;   // sharded sweep loop: boundary runs stored straight into the peers' arrays where the communicator allows it (shard.hip PeerHub)
     // arrival of a report = its sequence number in the pinned word next to it (written after a system-scope fence): the host polls
     // memory, no event is recorded in the stream.  Sequence numbers never repeat within a context.
     uint32_t* h_seq = nullptr; uint32_t* d_seq = nullptr; uint32_t seq_base = 0;   // [0, RING): solver steps; [RING, RING + ICM_RING): ICM rounds

@@ -1480,7 +1480,9 @@ void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
         if (nf < n) ICM_G(64, nf, n, (const uint32_t*)ctx->m_perm.p);
     } else {
         const uint32_t* none = nullptr;
-        if (K <= 8) ICM_G(8, nb0, ne0, none); else if (K <= 16) ICM_G(16, nb0, ne0, none); else if (K <= 32) ICM_G(32, nb0, ne0, none); else ICM_G(64, nb0, ne0, none);
+        // lanes per node: the label loop strides by the group size, so any size is exact; 16 lanes keep four nodes per wave busy up to
+        // 64 labels (a 64-lane group would idle most of its lanes on the usual 40 - 50 candidates)
+        if (K <= 8) ICM_G(8, nb0, ne0, none); else if (K <= 64) ICM_G(16, nb0, ne0, none); else if (K <= 128) ICM_G(32, nb0, ne0, none); else ICM_G(64, nb0, ne0, none);
     }
 #undef ICM_G
     MVS_LAUNCH_CHECK();

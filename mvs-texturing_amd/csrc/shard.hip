@@ -25,9 +25,12 @@
 #include <dlfcn.h>
 #include <rocprim/rocprim.hpp>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 namespace mvs {
 void dc_phase1(mvs_ctx* ctx, const mvs_settings* st);
@@ -56,9 +59,39 @@ using namespace mvs;
 // ---------------------------------------------------------------------------------------------------------------
 // communicators
 // ---------------------------------------------------------------------------------------------------------------
+// ---- peer-push transport (ranks that can address each other's device memory) ----
+// What a rank publishes for its peers at the start of a solve: where ITS halo lives.  A sender gathers the boundary runs / labels of a
+// colour phase out of its own arrays and stores them straight at their final places in the receiver's arrays (one kernel per phase,
+// no staging buffers, no unpack launch); ordering is by stream events: a rank records one event per colour phase behind its push and
+// waits -- on its stream, never on the host -- for the previous phase's events of the ranks it shares a cut with; the per-sweep
+// energy pair is published the same way and summed by every rank on the device.  The host side of a wait only makes sure the
+// event it is about to wait for has been RECORDED (enqueued) by its owner: a counter per rank, no device round trip.
+struct PeerSlot {
+    uint8_t* msg = nullptr; uint32_t* lab = nullptr; uint32_t stride = 0;             // message codes, decode buffers (2 x stride words)
+    const uint32_t* msg_recv_idx = nullptr; const uint32_t* node_recv_idx = nullptr;   // device: where element k of a (phase, peer) chunk goes
+    const uint64_t* msg_recv_off = nullptr; const uint64_t* node_recv_off = nullptr;   // host: [phase * P + peer] element offsets of the lists
+    const uint64_t* msg_send_off = nullptr;                                            // host: the owner's SEND offsets (who shares a cut with whom)
+    unsigned long long* energy = nullptr;                                              // device: [parity][2] the rank's share of a sweep's energy pair
+    uint32_t* gain = nullptr; uint32_t* blab = nullptr; uint32_t* moved = nullptr;     // ICM: gains (as words), labels of the best labeling, [parity] nodes moved
+    const uint32_t* all_recv_idx = nullptr; const uint64_t* all_recv_off = nullptr;    // every halo node, peer-major: device list, host offsets [peer]
+    uint32_t phases = 0;
+    std::vector<hipEvent_t> ev;                                                        // ring of phase events
+};
+struct PeerHub {
+    int world;
+    std::vector<PeerSlot> slot;
+    std::unique_ptr<std::atomic<uint64_t>[]> recorded;     // events recorded by a rank in the current solve
+    std::atomic<bool> failed{false};
+    explicit PeerHub(int w) : world(w), slot(w), recorded(new std::atomic<uint64_t>[w]) { for (int r = 0; r < w; ++r) recorded[r].store(0); }
+    ~PeerHub() { for (PeerSlot& p : slot) for (hipEvent_t e : p.ev) (void)hipEventDestroy(e); }
+};
+
 struct mvs_comm {
     int rank = 0, world = 1;
     virtual ~mvs_comm() {}
+    // non-null: the ranks of this communicator can store into each other's device memory (see PeerHub); barrier() = host rendezvous
+    virtual PeerHub* peers() { return nullptr; }
+    virtual void barrier() {}
     enum Type { U32, U64, F32 };
     enum Op { SUM, MAX };
     virtual void allreduce(void* buf, size_t n, Type t, Op op, hipStream_t s) = 0;          // in place, device buffer
@@ -148,7 +181,8 @@ struct LocalHub {
     std::vector<const uint8_t*> send_a, send_b; std::vector<const uint64_t*> soff_a, soff_b;
     std::vector<hipEvent_t> ready, done;
     std::vector<std::vector<uint8_t>> host;
-    explicit LocalHub(int w) : world(w), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w), done(w), host(w) {}
+    PeerHub peer;
+    explicit LocalHub(int w) : world(w), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w), done(w), host(w), peer(w) {}
     void barrier() {
         std::unique_lock<std::mutex> l(m);
         const uint64_t g = generation;
@@ -160,6 +194,8 @@ struct LocalComm : mvs_comm {
     std::shared_ptr<LocalHub> hub;
     ~LocalComm() override {}
     bool exchange_is_collective() const override { return true; }
+    PeerHub* peers() override { return &hub->peer; }
+    void barrier() override { hub->barrier(); }
     void rendezvous_copy(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
                          const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {
         LocalHub& H = *hub;
@@ -329,6 +365,43 @@ __global__ void unpack_phase_kernel(uint8_t* __restrict__ msg, const uint32_t* _
     }
 }
 
+// ---- peer push (see PeerHub): one launch per colour phase; blockIdx.y = the peer's segment ----
+constexpr int PUSH_SEGS = 8;
+struct PushSeg {
+    const uint32_t* sidx; const uint32_t* didx; uint8_t* dmsg; uint32_t nm;        // message bytes: dmsg[didx[k]] = msg[sidx[k]]
+    const uint32_t* nsidx; const uint32_t* ndidx; uint32_t* dlab; uint32_t nn;     // labels:        dlab[w * dstride + ndidx[k]] = lab[w * stride + nsidx[k]]
+    uint32_t dstride;
+};
+struct PushArgs { PushSeg seg[PUSH_SEGS]; };
+__global__ void push_phase_kernel(const uint8_t* __restrict__ msg, const uint32_t* __restrict__ lab, const mvs_mrf_progress* __restrict__ st, uint32_t stride, PushArgs a) {
+    const PushSeg& g = a.seg[blockIdx.y];
+    const uint32_t w = st->w;                          // the current decode buffer: the same index on every rank (identical decisions)
+    const uint32_t* src = lab + (size_t)w * stride; uint32_t* dst = g.dlab + (size_t)w * g.dstride;
+    const uint32_t n = g.nm > g.nn ? g.nm : g.nn;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        if (k < g.nm) g.dmsg[g.didx[k]] = msg[g.sidx[k]];
+        if (k < g.nn) dst[g.ndidx[k]] = src[g.nsidx[k]];
+    }
+}
+struct PushWSeg { const uint32_t* sidx; const uint32_t* didx; uint32_t* dst; uint32_t n; };
+struct PushWArgs { PushWSeg seg[PUSH_SEGS]; };
+__global__ void push_words_kernel(const uint32_t* __restrict__ src, PushWArgs a) {   // dst[didx[k]] = src[sidx[k]]: gains / labels of boundary nodes (ICM)
+    const PushWSeg& g = a.seg[blockIdx.y];
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < g.n; k += gridDim.x * blockDim.x) g.dst[g.didx[k]] = src[g.sidx[k]];
+}
+struct WordPtrs { const uint32_t* p[MAX_PARTS]; int n; };
+__global__ void publish_word_kernel(const uint32_t* __restrict__ v, uint32_t* __restrict__ pub, uint32_t parity) { if (threadIdx.x == 0) pub[parity] = v[0]; }
+__global__ void sum_words_kernel(WordPtrs e, uint32_t parity, uint32_t* __restrict__ out) {
+    if (threadIdx.x == 0) { uint32_t a = 0u; for (int q = 0; q < e.n; ++q) a += e.p[q][parity]; out[0] = a; }
+}
+struct EnergyPtrs { const unsigned long long* p[MAX_PARTS]; int n; };
+__global__ void publish_energy_kernel(const unsigned long long* __restrict__ pair, unsigned long long* __restrict__ pub, uint32_t parity) {
+    if (threadIdx.x < 2) pub[2 * parity + threadIdx.x] = pair[threadIdx.x];
+}
+__global__ void sum_energy_kernel(EnergyPtrs e, uint32_t parity, unsigned long long* __restrict__ out) {
+    if (threadIdx.x < 2) { unsigned long long a = 0ull; for (int q = 0; q < e.n; ++q) a += e.p[q][2 * parity + threadIdx.x]; out[threadIdx.x] = a; }
+}
+
 // ---- sharded cost table ----
 __global__ void counts_kernel(const uint32_t* __restrict__ col_ptr, uint32_t n, uint32_t* __restrict__ counts) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -424,6 +497,8 @@ struct mvs_shard {
     Lists fs, fr; DBuf<uint32_t> pos_s, pos_r; std::vector<uint64_t> col_so, col_ro; uint64_t rec_s = 0, rec_r = 0;
     uint32_t nnz_l = 0, own_start = 0; bool tables_valid = false;
     bool plan_valid = false; uint32_t plan_colours = 0; uint64_t plan_total = 0; uint32_t plans_built = 0, plans_reused = 0;
+    // peer-push transport of the sweep loop (PeerHub): on when the communicator offers it and option "shard_peer_push" is set
+    bool peer = false; DBuf<unsigned long long> e_pub; DBuf<uint32_t> m_pub; uint64_t n_ev = 0; std::vector<int> nbr; uint32_t ev_ring = 0; uint64_t peer_phases = 0;
 };
 
 namespace {
@@ -591,6 +666,124 @@ void exchange_nodes(mvs_shard* S, uint32_t* arr) {
     if (ns) { hipLaunchKernelGGL(pack_words_kernel, dim3(grid_for(ns)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->all_send.idx.p, ns, S->sbuf_node.p); MVS_LAUNCH_CHECK(); }
     S->comm->exchange((const uint8_t*)S->sbuf_node.p, so.data(), (uint8_t*)S->rbuf_node.p, ro.data(), s);
     if (nr) { hipLaunchKernelGGL(unpack_words_kernel, dim3(grid_for(nr)), dim3(256), 0, s, arr, (const mvs_mrf_progress*)nullptr, 0u, S->all_recv.idx.p, nr, S->rbuf_node.p); MVS_LAUNCH_CHECK(); }
+}
+
+// ---- the peer-push transport ----
+// start of a solve: every rank publishes where its halo lives (after mrf_setup and the plan, so the pointers are final), learns its
+// neighbours (ranks it shares any cut edge with) and checks that both ends of every (phase, pair) chunk agree on its size
+void peer_publish(mvs_shard* S) {
+    mvs_ctx* ctx = S->ctx; mvs_comm* comm = S->comm; PeerHub& H = *comm->peers();
+    const int P = S->P, me = S->me; const uint32_t C = S->phases;
+    S->e_pub.ensure(4);
+    MVS_HIP(hipMemsetAsync(S->e_pub.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));     // set-up, plan and the zeroed messages are in place before any peer may store into them
+    comm->barrier();                                // nobody still uses the previous solve's slots or events
+    PeerSlot& mine = H.slot[me];
+    mine.msg = ctx->m_msg_a.p; mine.lab = ctx->m_lab.p; mine.stride = ctx->m_stride; mine.phases = C;
+    mine.msg_recv_idx = S->msg_recv.idx.p; mine.node_recv_idx = S->node_recv.idx.p;
+    mine.msg_recv_off = S->msg_recv.off.data(); mine.node_recv_off = S->node_recv.off.data(); mine.msg_send_off = S->msg_send.off.data();
+    mine.energy = S->e_pub.p;
+    const uint32_t ring = 2u * std::max<uint32_t>(C, 1u) + 2u;     // a rank is never more than one sweep ahead of a rank that waits for it
+    while (mine.ev.size() < ring) { hipEvent_t e; MVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); mine.ev.push_back(e); }
+    S->ev_ring = ring; S->n_ev = 0;
+    H.recorded[me].store(0, std::memory_order_release);
+    comm->barrier();
+    S->nbr.clear();
+    for (int q = 0; q < P; ++q) {
+        if (q == me) continue;
+        const PeerSlot& o = H.slot[q];
+        if (o.phases != C) throw HipError("peer push: the ranks disagree on the number of colour phases");
+        uint64_t traffic = 0;
+        for (uint32_t ph = 0; ph < C; ++ph) {
+            const size_t a = (size_t)ph * P;
+            const uint64_t sm = S->msg_send.off[a + q + 1] - S->msg_send.off[a + q], rm = o.msg_recv_off[a + me + 1] - o.msg_recv_off[a + me];
+            const uint64_t sn = S->node_send.off[a + q + 1] - S->node_send.off[a + q], rn = o.node_recv_off[a + me + 1] - o.node_recv_off[a + me];
+            if (sm != rm || sn != rn) throw HipError("peer push: send / receive sizes disagree");
+            traffic += sm + sn + (o.msg_send_off[a + me + 1] - o.msg_send_off[a + me]);
+        }
+        if (traffic) S->nbr.push_back(q);
+    }
+}
+// after colour phase `ph`: this rank's boundary runs and labels of the phase, stored at their places in the neighbours' arrays
+void peer_push_phase(mvs_shard* S, uint32_t ph) {
+    mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; PeerHub& H = *S->comm->peers();
+    const int P = S->P, me = S->me; const size_t a = (size_t)ph * P;
+    PushArgs args; int n = 0; uint64_t longest = 0;
+    auto flush = [&]() {
+        if (!n) return;
+        const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((longest + 255) / 256, 256));
+        hipLaunchKernelGGL(push_phase_kernel, dim3(gx, (unsigned)n), dim3(256), 0, s, ctx->m_msg_a.p, ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, args);
+        MVS_LAUNCH_CHECK();
+        n = 0; longest = 0;
+    };
+    for (int q : S->nbr) {
+        const uint64_t sm = S->msg_send.off[a + q + 1] - S->msg_send.off[a + q], sn = S->node_send.off[a + q + 1] - S->node_send.off[a + q];
+        if (sm + sn == 0) continue;
+        const PeerSlot& o = H.slot[q];
+        PushSeg& g = args.seg[n++];
+        g.sidx = S->msg_send.idx.p + S->msg_send.off[a + q]; g.didx = o.msg_recv_idx + o.msg_recv_off[a + me]; g.dmsg = o.msg; g.nm = (uint32_t)sm;
+        g.nsidx = S->node_send.idx.p + S->node_send.off[a + q]; g.ndidx = o.node_recv_idx + o.node_recv_off[a + me]; g.dlab = o.lab; g.nn = (uint32_t)sn; g.dstride = o.stride;
+        longest = std::max(longest, std::max(sm, sn));
+        if (n == PUSH_SEGS) flush();
+    }
+    flush();
+}
+// ICM rounds: where this rank's halo gains / labels live (the best labeling's buffer is known only after the sweeps)
+void peer_publish_icm(mvs_shard* S) {
+    mvs_ctx* ctx = S->ctx; PeerHub& H = *S->comm->peers();
+    S->m_pub.ensure(4);
+    MVS_HIP(hipMemsetAsync(S->m_pub.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    PeerSlot& mine = H.slot[S->me];
+    mine.gain = (uint32_t*)ctx->m_gain.p; mine.blab = ctx->b_lab; mine.moved = S->m_pub.p;
+    mine.all_recv_idx = S->all_recv.idx.p; mine.all_recv_off = S->all_recv.off.data();
+    S->comm->barrier();
+    for (int q : S->nbr) {
+        const PeerSlot& o = H.slot[q];
+        if (S->all_send.off[q + 1] - S->all_send.off[q] != o.all_recv_off[S->me + 1] - o.all_recv_off[S->me]) throw HipError("peer push: send / receive sizes disagree (ICM)");
+    }
+}
+// every boundary node's word of `src` (this rank's gains, or its labels of the best labeling) to its place in the neighbours' arrays
+void peer_push_nodes(mvs_shard* S, const uint32_t* src, bool labels) {
+    hipStream_t s = S->ctx->stream; PeerHub& H = *S->comm->peers();
+    PushWArgs args; int n = 0; uint64_t longest = 0;
+    auto flush = [&]() {
+        if (!n) return;
+        const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((longest + 255) / 256, 256));
+        hipLaunchKernelGGL(push_words_kernel, dim3(gx, (unsigned)n), dim3(256), 0, s, src, args); MVS_LAUNCH_CHECK();
+        n = 0; longest = 0;
+    };
+    for (int q : S->nbr) {
+        const uint64_t cnt = S->all_send.off[q + 1] - S->all_send.off[q];
+        if (!cnt) continue;
+        const PeerSlot& o = H.slot[q];
+        PushWSeg& g = args.seg[n++];
+        g.sidx = S->all_send.idx.p + S->all_send.off[q]; g.didx = o.all_recv_idx + o.all_recv_off[S->me]; g.dst = labels ? o.blab : o.gain; g.n = (uint32_t)cnt;
+        longest = std::max(longest, cnt);
+        if (n == PUSH_SEGS) flush();
+    }
+    flush();
+}
+// one event behind everything this rank queued so far; its index (the same on every rank: one event per colour phase) is returned
+uint64_t peer_record(mvs_shard* S) {
+    PeerHub& H = *S->comm->peers();
+    const uint64_t idx = S->n_ev++;
+    MVS_HIP(hipEventRecord(H.slot[S->me].ev[idx % S->ev_ring], S->ctx->stream));
+    H.recorded[S->me].store(idx + 1, std::memory_order_release);
+    return idx;
+}
+// this rank's stream waits for event `idx` of rank q; the host only waits until q has RECORDED it (so that the stream wait refers to that record)
+void peer_wait(mvs_shard* S, int q, uint64_t idx) {
+    PeerHub& H = *S->comm->peers();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0; H.recorded[q].load(std::memory_order_acquire) <= idx; ++spin) {
+        if (H.failed.load(std::memory_order_relaxed)) throw HipError("peer push: another rank failed");
+        if ((spin & 1023u) == 1023u) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { H.failed.store(true); throw HipError("peer push: a rank did not reach its next colour phase within 120 s"); }
+            std::this_thread::yield();
+        }
+    }
+    MVS_HIP(hipStreamWaitEvent(S->ctx->stream, H.slot[q].ev[idx % S->ev_ring], 0));
 }
 
 }  // namespace
@@ -829,17 +1022,51 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     const int lag = std::max(0, std::min(std::max(ctx->mrf_lag, 2), (int)mvs_ctx::RING - 2));
     mvs_mrf_progress pg; memset(&pg, 0, sizeof(pg));
     int issued = 0, polled = 0;
+    S->peer = S->P > 1 && comm->peers() != nullptr && ctx->shard_peer_push != 0 && S->phases > 0;
+    if (comm->peers()) {
+        // every rank takes the same route (the option is per context): a rank that stored into peers which expect an exchange would corrupt them
+        S->d_moved.ensure(4);
+        const uint32_t mine = S->peer ? 1u : 0u; uint32_t all[2] = {mine, mine};
+        MVS_HIP(hipMemcpyAsync(S->d_moved.p, &mine, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        if (S->P > 1) {
+            comm->allreduce(S->d_moved.p, 1, mvs_comm::U32, mvs_comm::SUM, s);
+            MVS_HIP(hipMemcpyAsync(&all[0], S->d_moved.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); MVS_HIP(hipStreamSynchronize(s));
+            if (all[0] != 0u && all[0] != (uint32_t)S->P) throw StatusError(MVS_ERR_INVALID, "option shard_peer_push differs between the ranks");
+        }
+    }
+    if (S->peer) peer_publish(S);
+    PeerHub* hub = S->peer ? comm->peers() : nullptr;
+    try {
     while (issued < P.max_sweeps && !pg.stopped) {
         for (uint32_t ph = 0; ph < S->phases; ++ph) {
+            if (S->peer && ph > 0) {   // the neighbours' runs of the previous phase are in place (phase 0: the all-rank wait of the last sweep's energy)
+                Prof pr(ctx, "mrf_halo");
+                for (int q : S->nbr) peer_wait(S, q, S->n_ev - 1);
+            }
             { Prof pr(ctx, "mrf_sweep"); mrf_sweep_phase(ctx, ph, nb, ne); }
-            if (S->P > 1) { Prof pr(ctx, "mrf_halo"); exchange_phase(S, ph); }
+            if (S->peer) {
+                Prof pr(ctx, "mrf_halo");
+                peer_push_phase(S, ph);
+                if (ph + 1 < S->phases) peer_record(S);
+            } else if (S->P > 1) { Prof pr(ctx, "mrf_halo"); exchange_phase(S, ph); }
         }
         {   // the sweep's energy: own share (accumulated by the sweep kernels, or the energy kernel on the generic path),
             // all-reduced, fed to the device-side stop rule -- the host polls the report of `lag` sweeps ago
             Prof pr(ctx, "mrf_energy");
             if (ctx->m_fast) mrf_sweep_energy_reduce(ctx); else mrf_energy(ctx, false, nb, ne, true);
-            MVS_HIP(hipMemcpyAsync(S->d_energy.p, ctx->m_energy.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
-            if (S->P > 1) comm->allreduce(S->d_energy.p, 2, mvs_comm::U64, mvs_comm::SUM, s);
+            if (S->peer) {
+                // the rank's pair next to its peers', one event behind the last phase's push AND the pair, every rank sums all of them:
+                // the wait for ALL ranks is also what lets the next sweep's first phase start (and store into its neighbours)
+                const uint32_t parity = (uint32_t)(issued & 1);
+                hipLaunchKernelGGL(publish_energy_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)ctx->m_energy.p, S->e_pub.p, parity); MVS_LAUNCH_CHECK();
+                const uint64_t idx = peer_record(S);
+                EnergyPtrs ep; ep.n = S->P;
+                for (int q = 0; q < S->P; ++q) { if (q != S->me) peer_wait(S, q, idx); ep.p[q] = hub->slot[q].energy; }
+                hipLaunchKernelGGL(sum_energy_kernel, dim3(1), dim3(64), 0, s, ep, parity, S->d_energy.p); MVS_LAUNCH_CHECK();
+            } else {
+                MVS_HIP(hipMemcpyAsync(S->d_energy.p, ctx->m_energy.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+                if (S->P > 1) comm->allreduce(S->d_energy.p, 2, mvs_comm::U64, mvs_comm::SUM, s);
+            }
             mrf_step(ctx, S->d_energy.p);
         }
         ++issued;
@@ -847,6 +1074,8 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     }
     while (polled < issued && !pg.stopped) mrf_poll(ctx, (uint32_t)++polled, &pg);
     if (issued > 0) mrf_poll(ctx, (uint32_t)issued, &pg);
+    } catch (...) { if (hub) hub->failed.store(true); throw; }   // the other ranks' host-side waits end with an error instead of spinning
+    if (S->peer) { MVS_HIP(hipStreamSynchronize(s)); comm->barrier(); S->peer_phases += (uint64_t)issued * S->phases; }   // every rank's stores into this rank have landed
     R.sweeps = issued > 0 ? pg.stop_sweep : 0u;
     resolve_best(ctx);
     if (S->P > 1 && issued == 0) exchange_nodes(S, ctx->b_lab);   // argmin-unary start: the halo labels
@@ -866,19 +1095,39 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
             wait_report(ctx, mvs_ctx::RING + (uint32_t)(k % RR), seq0 + (uint32_t)k + 1u);
             if (stop < 0 && ctx->h_icm[k % RR] == 0u) stop = k;
         };
+        if (S->peer && P.icm_iters > 0) peer_publish_icm(S);
+        try {
         while (issued < P.icm_iters && stop < 0) {
             Prof pr(ctx, "mrf_icm");
             mrf_icm_gain(ctx, nb, ne);
-            if (S->P > 1) exchange_nodes(S, (uint32_t*)ctx->m_gain.p);
-            mrf_icm_apply(ctx, nb, ne);
-            MVS_HIP(hipMemcpyAsync(S->d_moved.p, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-            if (S->P > 1) { comm->allreduce(S->d_moved.p, 1, mvs_comm::U32, mvs_comm::SUM, s); exchange_nodes(S, ctx->b_lab); }
+            if (S->peer) {
+                // gains of the boundary nodes into the neighbours' arrays; the winners move once the neighbours' gains are in; labels of the
+                // boundary nodes and the rank's "moved" count behind ONE event that every rank waits for (apply only tests halo labels
+                // against 0, which no move changes: a neighbour's label store may overlap it); the counts are summed on the device
+                peer_push_nodes(S, (const uint32_t*)ctx->m_gain.p, false);
+                const uint64_t ig = peer_record(S);
+                for (int q : S->nbr) peer_wait(S, q, ig);
+                mrf_icm_apply(ctx, nb, ne);
+                peer_push_nodes(S, ctx->b_lab, true);
+                const uint32_t parity = (uint32_t)(issued & 1);
+                hipLaunchKernelGGL(publish_word_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)ctx->m_moved.p, S->m_pub.p, parity); MVS_LAUNCH_CHECK();
+                const uint64_t im = peer_record(S);
+                WordPtrs wp; wp.n = S->P;
+                for (int q = 0; q < S->P; ++q) { if (q != S->me) peer_wait(S, q, im); wp.p[q] = hub->slot[q].moved; }
+                hipLaunchKernelGGL(sum_words_kernel, dim3(1), dim3(64), 0, s, wp, parity, S->d_moved.p); MVS_LAUNCH_CHECK();
+            } else {
+                if (S->P > 1) exchange_nodes(S, (uint32_t*)ctx->m_gain.p);
+                mrf_icm_apply(ctx, nb, ne);
+                MVS_HIP(hipMemcpyAsync(S->d_moved.p, ctx->m_moved.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                if (S->P > 1) { comm->allreduce(S->d_moved.p, 1, mvs_comm::U32, mvs_comm::SUM, s); exchange_nodes(S, ctx->b_lab); }
+            }
             report_u32(ctx, S->d_moved.p, ctx->d_icm + issued % RR, mvs_ctx::RING + (uint32_t)(issued % RR), seq0 + (uint32_t)issued + 1u);
             pr.end();
             ++issued;
             if (issued - polled_icm > LAG) poll();
         }
         while (polled_icm < issued) poll();
+        } catch (...) { if (hub) hub->failed.store(true); throw; }
         ctx->icm_seq = seq0 + (uint32_t)issued;
         it = stop >= 0 ? stop : P.icm_iters;
     }
@@ -907,6 +1156,15 @@ mvs_status mvs_shard_plan_info(mvs_shard* S, uint64_t* msg_bytes_per_sweep, uint
     if (msg_bytes_per_sweep) *msg_bytes_per_sweep = S->msg_send.total;
     if (boundary_nodes) *boundary_nodes = S->node_send.total;
     if (plan_ms) *plan_ms = S->plan_ms;
+    return MVS_OK;
+}
+
+mvs_status mvs_shard_transport_info(mvs_shard* S, int* peer_push, uint64_t* phases_pushed, int* neighbours, uint32_t* colour_phases) {
+    if (!S) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (peer_push) *peer_push = S->peer ? 1 : 0;
+    if (phases_pushed) *phases_pushed = S->peer_phases;
+    if (neighbours) *neighbours = (int)S->nbr.size();
+    if (colour_phases) *colour_phases = S->phases;
     return MVS_OK;
 }
 

@@ -96,3 +96,9 @@ class Shard:
         b, n, t = C.c_uint64(0), C.c_uint64(0), C.c_double(0.0)
         _check(self.L, self.L.mvs_shard_plan_info(self.h, C.byref(b), C.byref(n), C.byref(t)))
         return {"msg_bytes_per_sweep": int(b.value), "boundary_nodes": int(n.value), "plan_ms": float(t.value)}
+
+    def transport_info(self):
+        """{"peer_push": the last view selection stored its runs straight into the peers' arrays, "phases_pushed", "neighbours", "colour_phases"}"""
+        pp, ph, nb, cp = C.c_int32(0), C.c_uint64(0), C.c_int32(0), C.c_uint32(0)
+        _check(self.L, self.L.mvs_shard_transport_info(self.h, C.byref(pp), C.byref(ph), C.byref(nb), C.byref(cp)))
+        return {"peer_push": bool(pp.value), "phases_pushed": int(ph.value), "neighbours": int(nb.value), "colour_phases": int(cp.value)}

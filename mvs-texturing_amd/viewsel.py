@@ -145,6 +145,7 @@ def load_library():
         "mvs_shard_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats), C.POINTER(u64)],
         "mvs_shard_view_selection": [vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
         "mvs_shard_plan_info": [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)],
+        "mvs_shard_transport_info": [vp, C.POINTER(i32), C.POINTER(u64), C.POINTER(i32), C.POINTER(u32)],
         "mvs_shard_own_faces": [vp, vp, C.POINTER(u32)],
         "mvs_ctx_partition_faces": [vp, i32, vp, vp], "mvs_partition_faces": [C.POINTER(CMesh), i32, vp, vp],
         "mvs_ctx_table_order": [vp, vp, C.POINTER(i32)],

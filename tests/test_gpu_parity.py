@@ -741,7 +741,7 @@ def test_cpp_sharded_path_equals_single_gpu(name, P):
         assert cut_share < 0.25, cut_share
 
 
-def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check_oracle_labels=False):
+def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check_oracle_labels=False, peer_push=None):
     """runs the scene through a single context and through P thread-ranks of csrc/shard.hip; asserts equality (see the callers);
     returns the share of faces that are halo faces of some rank"""
     import threading
@@ -786,6 +786,7 @@ def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check
             torch.cuda.set_device(0)
             c = M.Context(0); c.set_mesh(tv, tf, tn); c.set_views(s.cams, timg)
             if max_labels: c.set_option("max_labels", max_labels)
+            if peer_push is not None: c.set_option("shard_peer_push", peer_push)
             sh = M.shard.Shard(c, comms[r], pb_arg, tap, tad)
             own = sh.own_faces()
             for rep in range(reps):                                # twice: steady-state reuse of plan buffers and tables
@@ -795,7 +796,7 @@ def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check
                 torch.cuda.synchronize()
                 ms = sh.view_selection(labels)
                 c.synchronize()
-            out[r] = (st, nnz_global, table, labels.cpu().numpy().view(np.uint32)[:len(own)], ms, sh.plan_info(), own)
+            out[r] = (st, nnz_global, table, labels.cpu().numpy().view(np.uint32)[:len(own)], ms, dict(sh.plan_info(), **sh.transport_info()), own)
             sh.close(); c.close()
         except Exception as e:  # noqa: BLE001
             err[r] = e
@@ -822,10 +823,19 @@ def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check
         assert (ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"], ms["unseen"]) == \
                (st0["energy_fixed"], st0["cut_edges"], st0["sweeps"], st0["icm_iters"], st0["unseen"]), "rank %d" % r
         assert (info["boundary_nodes"] > 0 and info["msg_bytes_per_sweep"] > 0) or len(own) < 100
+        # the sweep loop's transport: runs stored straight into the peers' arrays unless switched off (the in-process ranks share an address space)
+        assert info["peer_push"] == (P > 1 and peer_push != 0) and (info["phases_pushed"] > 0) == info["peer_push"], info
         got[own] = labels
     assert np.array_equal(got, lab0), "labels depend on the partition"
     for c in comms: c.close()
     return halo_total / max(F, 1)
+
+
+@pytest.mark.parametrize("name,P", [("bumpy", 3), ("spiky32", 4), ("bumpy", (0.0, 0.5, 0.5, 1.0))], ids=["bumpy-3", "spiky32-4", "bumpy-empty-part"])
+def test_cpp_sharded_path_through_the_communicators_exchange(name, P):
+    """the same runs with option shard_peer_push = 0: pack launch, exchange through the communicator (what the RCCL communicator does
+    with grouped ncclSend / ncclRecv), unpack launch per colour phase instead of stores into the peers' arrays -- identical results"""
+    _cpp_shards_equal_single(get_scene(name), P, reps=2, peer_push=0)
 
 
 def test_config4_eight_parts_through_the_sharded_path():
