@@ -143,6 +143,9 @@ void mvs_default_settings(mvs_settings* s);
  * the table it is given has the same fingerprint (no context set-up, no table upload), and uploads it as usual otherwise.
  * After its solve mvs_view_selection parks the context as a spare: the next one-shot call reuses its stream, device buffers and graph.
  * At most two contexts are parked; their device memory stays allocated until mvs_release_cached() or the end of the process.
+ * The stash is per PROCESS (texrecon's pattern: one caller thread, one scene): concurrent callers are safe -- it is locked, and every
+ * thread has its own call profile -- but only the last table handed out stays parked; the one-shot calls run on the device named by
+ * the environment variable MVS_DEVICE (default 0).
  * Environment MVS_KEEP_TABLE=0 switches all of that off; mvs_release_cached() frees what is parked; mvs_last_call_profile() = wall-clock
  * breakdown (JSON object) of the calling thread's last one-shot call. */
 void mvs_release_cached(void);
