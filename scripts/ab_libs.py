@@ -33,7 +33,12 @@ if __name__ == "__main__":
     for r in range(a.rounds):
         for spec in a.libs:
             name, _, path = spec.partition("=")
-            q = ctx.Queue(); p = ctx.Process(target=child, args=(path, scene, a.steps, a.mrf, q)); p.start(); out = q.get(); p.join()
+            q = ctx.Queue(); p = ctx.Process(target=child, args=(path, scene, a.steps, a.mrf, q)); p.start()
+            try:
+                out = q.get(timeout=240)          # a child that died never answers: no waiting for ever on a GPU box
+            except Exception:  # noqa: BLE001
+                p.kill(); p.join(); raise SystemExit("variant %s: the child did not answer (exit code %s)" % (name, p.exitcode))
+            p.join()
             res.setdefault(name, []).append(out)
     for name, runs in res.items():
         keys = [k for k in runs[0] if k.startswith("dc_") or k.startswith("mrf_")]
