@@ -10,8 +10,7 @@ from mvs_texturing_amd import multigpu as G
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 s = M.synth.make_scene(**M.synth.CONFIGS[cfg])
-perm = G.morton_order(s.verts, s.faces)
-faces, normals, adj_ptr, adj, _ = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)
+faces, normals, adj_ptr, adj = s.faces, s.normals, s.adj_ptr, s.adj      # the mesh as built: the parts are the library's own equal cut of its own order
 F = len(faces); pb = G.equal_parts(F, P)
 dev = torch.device("cuda:0")
 tv, tf, tn = torch.from_numpy(s.verts).to(dev), torch.from_numpy(faces.view(np.int32)).to(dev), torch.from_numpy(normals).to(dev)
@@ -22,13 +21,13 @@ out = [None] * P
 def rank_main(r):
     torch.cuda.set_device(0)
     c = M.Context(0); c.set_mesh(tv, tf, tn); c.set_views(s.cams, timg)
-    sh = M.shard.Shard(c, comms[r], pb, tap, tad)
+    sh = M.shard.Shard(c, comms[r], None, tap, tad)
     lab = torch.zeros(int(pb[r + 1] - pb[r]), dtype=torch.int32, device=dev)
     for rep in range(2):
         t = time.perf_counter()
         st, nnz_g = sh.data_costs(M.Settings()); ms = sh.view_selection(lab); c.synchronize()
         dt = time.perf_counter() - t
-    out[r] = dict(rank=r, faces=int(pb[r + 1] - pb[r]), nnz_own=st["nnz"], sweeps=ms["sweeps"], energy=ms["energy"], step_ms=dt * 1e3, **sh.plan_info())
+    out[r] = dict(rank=r, faces=int(pb[r + 1] - pb[r]), nnz_own=st["nnz"], sweeps=ms["sweeps"], energy=ms["energy"], step_ms=dt * 1e3, **sh.plan_info(), **sh.transport_info())
     sh.close(); c.close()
 th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
 for t in th: t.start()
