@@ -460,7 +460,7 @@ def main():
                 info["labels_own"] = torch.zeros(max(info["shard"].n_own(), 1), dtype=torch.int32, device=dev)
             st, info["nnz_global"] = info["shard"].data_costs(settings)
             ms = info["shard"].view_selection(info["labels_own"], params)
-            info["plan"] = info["shard"].plan_info()
+            info["plan"] = dict(info["shard"].plan_info(), **info["shard"].transport_info())
         else:
             # TEST HARNESS (--backend gloo with MVS_BENCH_ONE_GPU): several ranks on cuda:0 cannot share an RCCL communicator, so the
             # contract test drives the same device building blocks from Python over gloo (mvs-texturing_amd/multigpu.py); never the product path
@@ -638,7 +638,8 @@ def main():
            "pcie_inclusive_value": F / ((ms_per_step + h2d_ms) / 1000.0),
            "roofline": roof, "roofline_path": roof_path, "stages": stages, "pre_path": pre, "post_path": post}
     if "plan" in info:
-        out["halo"] = dict(info["plan"], driver="C++ (csrc/shard.hip), grouped ncclSend/ncclRecv per colour phase, bytes on the wire")
+        out["halo"] = dict(info["plan"], driver="C++ (csrc/shard.hip); sweep transport: " + ("peer push (stores into the neighbours' arrays, one stream event per colour phase)"
+                                                                                               if info["plan"].get("peer_push") else "grouped ncclSend/ncclRecv per colour phase, bytes on the wire"))
     if world > 1 or args.shard:
         out["sharded_driver"] = "C++ / RCCL (csrc/shard.hip)" if args.backend == "nccl" else "python test harness over %s (one-GPU test mode)" % args.backend
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
