@@ -376,6 +376,10 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
         hipStream_t s; std::vector<void*> ptrs;
         ~Pinned() { if (ptrs.empty()) return; (void)hipStreamSynchronize(s); for (void* p : ptrs) (void)hipHostUnregister(p); }
     } pinned{ctx->stream, {}};
+    // MVS_PIN_HOST_IMAGES=0: never register the caller's pages (user-pointer registrations are at the mercy of the kernel moving those
+    // pages under memory pressure): every image goes the pageable way
+    const char* pin_env = getenv("MVS_PIN_HOST_IMAGES");
+    const bool pin_images = !(pin_env && pin_env[0] == '0');
     for (uint32_t j = 0; j < n_views; ++j) {
         const mvs_view& v = views[j];
         if (v.width < 2 || v.height < 2 || !v.rgb) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image");
@@ -389,7 +393,7 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
             auto* b = ctx->own_rgb[j];
             const size_t bytes = (size_t)v.width * v.height * 3;
             b->ensure(bytes + 16);
-            if (bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) pinned.ptrs.push_back(const_cast<uint8_t*>(v.rgb));
+            if (pin_images && bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) pinned.ptrs.push_back(const_cast<uint8_t*>(v.rgb));
             else (void)hipGetLastError();   // not registered: clear the sticky error, copy from pageable memory
             MVS_HIP(hipMemcpyAsync(b->p, v.rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
             p.rgb = b->p;

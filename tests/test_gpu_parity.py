@@ -13,7 +13,7 @@ import pytest
 import mvs_texturing_amd as M
 import oracle_py as O
 from conftest import get_scene
-from util_cases import energy_numpy, random_mrf
+from util_cases import energy_numpy, isolated, random_mrf
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -85,6 +85,19 @@ def test_data_costs_and_labels_against_golden(ctx, name):
             labels, ms = ctx.view_selection(s.adj_ptr, s.adj)
             assert np.array_equal(labels, g[mode + "/labels"]), "labels differ from the golden labeling"
             assert [ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"]] == g[mode + "/energy_fixed"].tolist()
+
+
+def test_host_images_pinned_in_place_or_pageable_give_the_same_table(monkeypatch):
+    """mvs_scene_set_views pins the caller's image buffers in place for the upload (hipHostRegister; images of 1 MB and more); with
+    MVS_PIN_HOST_IMAGES=0 -- this suite's default, tests/conftest.py -- they go the pageable way.  Same table either way."""
+    s = get_scene("bigfoot")                       # 1024x768 images: 2.4 MB each
+    tables = []
+    for pin in ("1", "0"):
+        monkeypatch.setenv("MVS_PIN_HOST_IMAGES", pin)
+        c = M.Context(0)
+        _load_scene(c, s); c.data_costs(M.Settings()); tables.append(c.costs_download()); c.close()
+    a, b = tables
+    assert a.nnz == b.nnz > 0 and np.array_equal(a.col_ptr, b.col_ptr) and np.array_equal(a.view_id, b.view_id) and np.array_equal(a.cost.view(np.uint32), b.cost.view(np.uint32))
 
 
 @pytest.mark.parametrize("mode", list(MODES))
@@ -838,6 +851,7 @@ def test_cpp_sharded_path_through_the_communicators_exchange(name, P):
     _cpp_shards_equal_single(get_scene(name), P, reps=2, peer_push=0)
 
 
+@isolated
 def test_config4_eight_parts_through_the_sharded_path():
     """BASELINE config 4 = the config-3 scene (1 997 120 faces, 200 views 2048x1536) cut into 8 parts: the C++ sharded path with 8
     thread-ranks on the one GPU a test box has (in-process communicator; copies instead of xGMI) -- every rank's table (own + halo
@@ -849,6 +863,7 @@ def test_config4_eight_parts_through_the_sharded_path():
     assert halo_share < 0.02, halo_share                            # compact parts: ~0.5 % of the faces are halo faces at 8 parts
 
 
+@isolated
 def test_config5_one_ranks_share_against_the_oracle():
     """BASELINE config 5 at the size ONE of its eight ranks holds (n = 250: 1 250 000 faces x all 1000 views 2048x1536, label-space
     compression to 64 candidates -- `bench.py --config 5`): three 8 000-face windows of columns (start, middle, end of the caller's
@@ -890,6 +905,7 @@ def test_config5_one_ranks_share_against_the_oracle():
         assert so[k] == sg[k], k
 
 
+@isolated
 def test_cpp_sharded_path_over_rccl_world_size_one():
     """the RCCL communicator end to end on the one GPU a test box has: ncclGetUniqueId / ncclCommInitRank, the all-reduces
     of the data-cost barrier and of the per-sweep energy run through RCCL (world size 1: no peers), result == single context"""
@@ -1301,6 +1317,7 @@ def test_config2_equals_the_oracle_entry_for_entry(ctx):
 
 
 @pytest.mark.parametrize("order", ["as_built", "shuffled"])
+@isolated
 def test_config3_equals_the_oracle_on_labels_and_sampled_columns(order):
     """("shuffled": the same scene with its faces AND vertices in random order -- the library lays the mesh out itself, so the
     order a mesh file happens to have changes neither the results nor, by more than the cost of that pass, the time.)
@@ -1340,6 +1357,7 @@ def test_config3_equals_the_oracle_on_labels_and_sampled_columns(order):
         assert so[k] == sg[k], k
 
 
+@isolated
 def test_config3_full_size_properties():
     """BASELINE config 3 (1 997 120 faces, 200 views 2048x1536 -- the bench workload): size-independent properties.
     The per-entry oracle comparison happens at the small sizes above; here: conservation of pairs, sorted columns,

@@ -169,3 +169,21 @@ def soup_scene(seed=0, n_verts=60, n_faces=250, n_views=7, w=200, h=150, spread=
         s.images.append(np.ascontiguousarray(img))
     s.cams = {k: np.ascontiguousarray(np.array(v, dtype=np.int32 if k in ("width", "height") else np.float32)) for k, v in cams.items()}
     return s
+
+
+def isolated(fn):
+    """Runs a heavy test in a process of its own (`python -m pytest <this node>` with MVS_TEST_ISOLATED=1): gigabytes of host images,
+    eight contexts or an RCCL communicator do not stay behind in the process that runs the rest of the suite.  The child executes the
+    undecorated body; the parent only checks its exit code and shows its output on failure."""
+    import functools, os, subprocess, sys
+
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        if os.environ.get("MVS_TEST_ISOLATED") == "1":
+            return fn(*a, **kw)
+        node = os.environ["PYTEST_CURRENT_TEST"].rsplit(" (", 1)[0]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-m", "pytest", node, "-q", "-x", "-p", "no:cacheprovider", "--tb=short"], cwd=root,
+                           env=dict(os.environ, MVS_TEST_ISOLATED="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+        assert r.returncode == 0 and " passed" in r.stdout, "isolated run of %s failed (exit code %d):\n%s" % (node, r.returncode, r.stdout[-6000:])
+    return wrapper
