@@ -146,6 +146,8 @@ void mvs_default_settings(mvs_settings* s);
  * The stash is per PROCESS (texrecon's pattern: one caller thread, one scene): concurrent callers are safe -- it is locked, and every
  * thread has its own call profile -- but only the last table handed out stays parked; the one-shot calls run on the device named by
  * the environment variable MVS_DEVICE (default 0).
+ * Host images (mvs_scene_set_views with host pointers, hence every one-shot call) are pinned in place for the upload; environment
+ * MVS_PIN_HOST_IMAGES=0 sends them from pageable memory instead (no user-pointer registration; ~4x slower upload).
  * Environment MVS_KEEP_TABLE=0 switches all of that off; mvs_release_cached() frees what is parked; mvs_last_call_profile() = wall-clock
  * breakdown (JSON object) of the calling thread's last one-shot call. */
 void mvs_release_cached(void);
