@@ -77,6 +77,62 @@ def cpu_baseline(scene, faces, normals, adj_ptr, adj, params_kw, budget_s=25.0):
             "host_cpus": ncpu}
 
 
+def reference_leg(scene, faces, normals, n_faces=8192):
+    """The data-cost half through the REFERENCE'S OWN calculate_data_costs.cpp -- compiled where it lies by `make -C oracle ref`
+    (oracle/_ref/libtexref.so: single-threaded, stand-ins for the absent MVE / rayint headers, each any-hit ray answered by the
+    oracle's BVH) -- on the first n_faces faces as a mesh of their own, next to the port on the same sub-mesh with one thread:
+    how far the port's baseline is from upstream's code."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    lib = os.path.join(ROOT, "oracle", "_ref", "libtexref.so")
+    if not os.path.exists(lib):
+        return {"skipped": "oracle/_ref/libtexref.so not built"}
+    R = C.CDLL(lib); OL = O.load()
+    n = int(min(n_faces, len(faces)))
+
+    class S:
+        pass
+    s = S(); s.verts, s.faces, s.normals, s.cams, s.images = scene.verts, np.ascontiguousarray(faces[:n]), np.ascontiguousarray(normals[:n]), scene.cams, scene.images
+    s.n_views, s.n_faces = scene.n_views, n
+    V = s.n_views
+    t = time.time(); _, st = O.data_costs(s, n_threads=1, timing=True); t_port = st["t_infos"] + st["t_post"]
+    OL.orc_ray_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int]; OL.orc_ray_hit.restype = C.c_int
+    mesh = O.mesh_struct(s); views = O.view_structs(s)
+    gmis, gptr = [], (C.c_void_p * V)()
+    for j in range(V):
+        w, h = int(s.cams["width"][j]), int(s.cams["height"][j])
+        g = np.zeros(w * h, np.uint8)
+        OL.orc_gradient_magnitude(s.images[j].ctypes.data, w, h, g.ctypes.data)
+        gmis.append(g); gptr[j] = g.ctypes.data
+    OL.orc_bvh_build.restype = C.c_void_p
+    bvh = OL.orc_bvh_build(C.byref(mesh))
+    cap = n * V
+    col_ptr = np.zeros(n + 1, np.uint32); vid = np.zeros(cap, np.uint16); cost = np.zeros(cap, np.float32)
+    rays = C.c_uint64(0)
+    R.ref_calculate_data_costs.restype = C.c_int64
+    R.ref_calculate_data_costs.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1); os.dup2(2, 1)      # the reference prints its progress on stdout: this program's stdout is ONE JSON line
+    try:
+        t = time.time()
+        m = R.ref_calculate_data_costs(s.verts.shape[0], vp(s.verts), n, vp(s.faces), vp(s.normals), C.cast(views, C.c_void_p), C.cast(gptr, C.c_void_p), V,
+                                       1, 0, 1, C.cast(OL.orc_ray_hit, C.c_void_p), C.c_void_p(bvh), C.cast(C.pointer(mesh), C.c_void_p), 0,
+                                       vp(col_ptr), vp(vid), vp(cost), cap, C.cast(C.pointer(rays), C.c_void_p))
+        t_ref = time.time() - t
+    finally:
+        os.dup2(saved_stdout, 1); os.close(saved_stdout)
+        OL.orc_bvh_free.argtypes = [C.c_void_p]; OL.orc_bvh_free(C.c_void_p(bvh))
+    return {"what": "tex::calculate_data_costs of the reference (oracle/_ref: upstream's calculate_data_costs.cpp / texture_view.cpp / tri.cpp compiled in place, "
+                    "1 thread, stand-in MVE containers, rays answered by the oracle's BVH; includes its image copies and gradient look-ups) on the first "
+                    "%d faces as a mesh of their own, all %d views" % (n, V),
+            "faces": n, "entries": int(m), "reference_s": t_ref, "reference_faces_per_s_1_core": n / max(t_ref, 1e-9),
+            "port_s_1_thread": t_port, "port_faces_per_s_1_thread": n / max(t_port, 1e-9), "rays_cast_by_the_reference": int(rays.value)}
+
+
 def induced_subgraph(adj_ptr, adj, n):
     """adjacency CSR of the first n faces restricted to neighbours < n (list order kept)"""
     ap = adj_ptr[:n + 1].astype(np.int64)
@@ -648,6 +704,11 @@ def main():
                                                dict(max_sweeps=params.max_sweeps, min_sweeps=params.min_sweeps), args.cpu_budget)
         except Exception as e:  # the baseline is reporting only; never lose the measurement
             out["cpu_baseline"] = {"error": repr(e)}
+        try:   # the reference's own code for the data-cost half, on a small sample (single-threaded build: oracle/Makefile)
+            if "error" not in out["cpu_baseline"]:
+                out["cpu_baseline"]["reference_data_costs"] = reference_leg(scene, faces, normals)
+        except Exception as e:  # noqa: BLE001
+            log("reference leg failed:", e)
     if rank == 0 and world == 1 and not args.no_real_like and not args.shard and args.config == 3 and args.steps > 0:
         try:
             out["real_like"] = real_like_workload(local_rank, dev, params)
