@@ -168,6 +168,29 @@ def test_bench_cli_contract():
         assert flag in r.stdout
 
 
+def test_bench_reference_leg_keeps_stdout_clean(capfd):
+    """bench.py's stdout is ONE JSON line; its cpu_baseline leg runs the reference's own calculate_data_costs.cpp (oracle/_ref), which
+    prints progress on stdout -- redirected while it runs.  The leg reports the reference's and the port's single-thread rates on the
+    same sub-mesh, and both fill the same number of table entries (the pin of tests/test_reference_pins.py, seen from the bench)."""
+    import importlib.util
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libtexref.so")):
+        pytest.skip("oracle/_ref/libtexref.so not built (the reference sources are not on this machine)")
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    s = get_scene("bumpy")
+    capfd.readouterr()
+    r = bench.reference_leg(s, s.faces, s.normals, n_faces=1500)
+    out = capfd.readouterr().out
+    assert out == "", "the reference's progress output reached stdout: %r" % out[:200]
+    assert r["faces"] == 1500 and r["reference_faces_per_s_1_core"] > 0 and r["port_faces_per_s_1_thread"] > 0
+    class Sub:
+        pass
+    sub = Sub(); sub.verts, sub.faces, sub.normals, sub.cams, sub.images = s.verts, np.ascontiguousarray(s.faces[:1500]), np.ascontiguousarray(s.normals[:1500]), s.cams, s.images
+    sub.n_views, sub.n_faces = s.n_views, 1500
+    ref, _ = O.data_costs(sub, n_threads=1)
+    assert r["entries"] == ref.nnz > 0
+
+
 def test_row_f2_scene_folder_round_trip(tmp_path):
     """a scene written as <name>.cam + <name>.png (+ PLY mesh) reads back to the same camera
     arrays (TextureView constructor, texture_view.cpp:35-38), pixels and mesh; folder pairing follows
