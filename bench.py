@@ -8,7 +8,8 @@ sweeps to convergence, ICM polish, labels) -- the window the reference times at
 apps/texrecon/texrecon.cpp:96-127.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                  (no launcher: ONE process, one host thread per GPU, peer-push transport)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (one process per GPU, RCCL)
 
 Prints ONE JSON line (rank 0).  `value` = faces of the scene / max-over-ranks seconds per
 step.  N > 1 runs the SAME scene partitioned over the ranks (BASELINE.json config 4):
@@ -393,6 +394,139 @@ def dropin_timing(cfg, reps=2, timeout_s=900):
     return last
 
 
+def run_inproc(args, cfg, max_labels):
+    """`--gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): the single-node route of the sharded path.  ONE process,
+    N host threads, thread r drives the context of GPU r through csrc/shard.hip over the in-process communicator
+    (mvs_comm_create_local_devices: peer access between the GPUs, halo runs stored straight into the neighbours' arrays, collectives as
+    peer copies over xGMI -- no RCCL, no IPC).  MVS_BENCH_ONE_GPU=1 puts every rank on cuda:0 (the test of this path on a 1-GPU box;
+    the ranks then time-slice one device and the number says nothing about scaling).  Timing: barrier, K steps, per-rank stream
+    synchronisation, barrier; elapsed = until the LAST rank is through.  Parity: the labels of all ranks, assembled, against a
+    single-context solve of the same scene on rank 0's GPU (which bench.py --gpus 1 checks against the oracle)."""
+    import threading
+    N = args.gpus
+    ndev = torch.cuda.device_count()
+    one_gpu = bool(os.environ.get("MVS_BENCH_ONE_GPU"))
+    if not one_gpu and ndev < N:
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible (MVS_BENCH_ONE_GPU=1 runs all ranks on cuda:0 as a test)" % (N, ndev))
+    devices = [0] * N if one_gpu else list(range(N))
+    t0 = time.time()
+    scene = M.synth.make_scene(**cfg)
+    if args.shuffle_main:
+        scene = M.synth.permute_scene(scene, seed=11)
+    F, V = len(scene.faces), scene.n_views
+    log("scene: %d faces, %d views %dx%d, built in %.1fs; %d in-process ranks on devices %r" % (F, V, cfg["width"], cfg["height"], time.time() - t0, N, devices))
+    comms = M.shard.Comm.local(N, devices)
+    peer_ok = comms[0].info()["peer_push"]
+    settings = M.Settings(); params = M.viewsel.default_mrf_params()
+    gate = threading.Barrier(N)
+    res, err = [None] * N, [None] * N
+    n_prof = min(max(args.steps, 1), 3)
+
+    def rank_main(r):
+        try:
+            d = devices[r]
+            torch.cuda.set_device(d); dev = torch.device("cuda", d)
+            t_v = torch.from_numpy(scene.verts).to(dev); t_f = torch.from_numpy(scene.faces.view(np.int32)).to(dev); t_n = torch.from_numpy(scene.normals).to(dev)
+            t_img = [torch.from_numpy(i).to(dev) for i in scene.images]
+            t_ap = torch.from_numpy(scene.adj_ptr.view(np.int32)).to(dev); t_ad = torch.from_numpy(scene.adj.view(np.int32)).to(dev)
+            torch.cuda.synchronize(d)
+            ctx = M.Context(d)     # (its own stream: N ranks on torch's per-device default stream would serialise in the one-GPU test mode)
+            if max_labels:
+                ctx.set_option("max_labels", max_labels)
+            ctx.set_mesh(t_v, t_f, t_n); ctx.set_views(scene.cams, t_img)
+            sh = M.shard.Shard(ctx, comms[r], None, t_ap, t_ad)      # None: the library's equal cut of its own face order
+            own = sh.own_faces()
+            lab = torch.zeros(max(len(own), 1), dtype=torch.int32, device=dev)
+            box = {}
+
+            def step():
+                box["dc"], box["nnz_global"] = sh.data_costs(settings)
+                box["mrf"] = sh.view_selection(lab, params)
+            for _ in range(args.warmup):
+                step()
+            ctx.synchronize(); gate.wait()
+            t = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            ctx.synchronize(); gate.wait()
+            elapsed = time.perf_counter() - t
+            labels = lab.cpu().numpy().view(np.uint32)[:len(own)].copy()
+            ctx.set_option("profile", 1); ctx.get_profile()
+            for _ in range(n_prof if args.steps > 0 else 0):
+                step()
+            prof = ctx.get_profile()
+            nph = __import__("ctypes").c_uint32(0); ctx.L.mvs_ctx_mrf_num_phases(ctx.h, __import__("ctypes").byref(nph))
+            res[r] = dict(elapsed=elapsed, own=own, labels=labels, prof=prof, n_phases=max(int(nph.value), 1), plan=dict(sh.plan_info(), **sh.transport_info()), **box)
+            if r == 0 and not args.no_parity and args.steps > 0:
+                # the single-context reference on this rank's GPU, while the other ranks are done with their device work
+                c1 = M.Context(d)
+                try:
+                    if max_labels:
+                        c1.set_option("max_labels", max_labels)
+                    c1.set_mesh(t_v, t_f, t_n); c1.set_views(scene.cams, t_img); c1.data_costs(settings)
+                    l1 = torch.zeros(F, dtype=torch.int32, device=dev)
+                    _, m1 = c1.view_selection(t_ap, t_ad, params, labels_out=l1); c1.synchronize()
+                    res[r]["single"] = dict(labels=l1.cpu().numpy().view(np.uint32), energy_fixed=m1["energy_fixed"], sweeps=m1["sweeps"], icm_iters=m1["icm_iters"])
+                finally:
+                    c1.close()
+            sh.close(); ctx.close()
+        except BaseException as e:  # noqa: BLE001
+            err[r] = repr(e); gate.abort(); raise
+    th = [threading.Thread(target=rank_main, args=(r,), name="rank%d" % r) for r in range(N)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for c in comms:
+        c.close()
+    if any(err):
+        raise SystemExit("bench.py --gpus %d (in-process ranks) failed: %r" % (N, err))
+    elapsed = max(o["elapsed"] for o in res)
+    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
+    r0 = res[0]; mrf = r0["mrf"]; prof = r0["prof"]
+    stages = {k: {"ms_per_step": v[0] / n_prof, "launches_per_step": v[1] / n_prof} for k, v in prof.items()}
+    roof = None
+    if prof.get("mrf_sweep", [0, 0])[1] > 0 and int(r0["dc"]["nnz"]):
+        n_phases = r0["n_phases"]; sweeps_run = prof["mrf_sweep"][1] / n_phases      # (sharded driver: one span per colour phase)
+        sweep_ms = prof["mrf_sweep"][0] / max(sweeps_run, 1.0)
+        b_sweep = 12.0 * int(r0["dc"]["nnz"]) + 12.0 * len(r0["own"])
+        ach = b_sweep / (sweep_ms * 1e-3) / 1e9
+        roof = {"kernel": "mrf_sweep4_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": sweep_ms / n_phases, "algorithmic_bytes_per_launch": b_sweep / n_phases, "launches_per_sweep": n_phases, "sweep_ms": sweep_ms,
+                "note": "rank 0's share: 12 nnz_own + 12 F_own bytes per sweep over the GPU time of its sweep launches (hipEvent spans of extra, untimed steps)"}
+    out = {"metric": "faces/sec through view-selection (data-cost + MRF)", "value": F / (ms_per_step / 1000.0), "unit": "faces/s", "n_gpus": N,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE config %s: displaced icosphere n=%d (%d faces), %d Fibonacci-sphere views %dx%d RGB8, settings gmi/none/visibility-test "
+                                  "(reference defaults), cut into %d parts of the library's face order" % (args.config, cfg["n"], F, V, cfg["width"], cfg["height"], N),
+                      "faces": F, "views": V, "nnz": int(r0["nnz_global"]), "sweeps": int(mrf["sweeps"]), "icm_iters": int(mrf["icm_iters"]), "energy": float(mrf["energy"]),
+                      "partition": "library-hilbert-%d" % N, "face_order_in": "shuffled" if args.shuffle_main else "as built", "msg_bits": 8, "max_labels": max_labels,
+                      "arithmetic": "fp32 geometry and messages, fp64 footprint sums, 32.32 fixed-point energies; messages STORED as 8-bit codes"},
+           "launch": "in-process: 1 process, %d host threads, one per GPU%s" % (N, " (MVS_BENCH_ONE_GPU: all ranks time-slice cuda:0 -- a test, not a scaling number)" if one_gpu else ""),
+           "devices": devices, "roofline": roof, "stages": stages, "per_rank_ms_per_step": [1000.0 * o["elapsed"] / max(args.steps, 1) for o in res],
+           "halo": dict(r0["plan"], peer_access=bool(peer_ok), driver="C++ (csrc/shard.hip); sweep transport: " +
+                        ("peer push (stores into the neighbours' arrays, one stream event per colour phase)" if r0["plan"].get("peer_push") else "pack / rendezvous copies / unpack per colour phase")),
+           "sharded_driver": "C++ / in-process communicator (csrc/shard.hip)", "cpu_baseline": None}
+    rc = 0
+    if "single" in r0:
+        got = np.zeros(F, dtype=np.uint32)
+        for o in res:
+            got[o["own"]] = o["labels"]
+        sg = r0["single"]
+        same = bool(np.array_equal(got, sg["labels"]))
+        stats_same = (int(mrf["energy_fixed"]), int(mrf["sweeps"]), int(mrf["icm_iters"])) == (int(sg["energy_fixed"]), int(sg["sweeps"]), int(sg["icm_iters"]))
+        out["parity"] = {"ok": same and stats_same, "labels_equal_single_context": same, "energy_sweeps_icm_equal_single_context": stats_same,
+                         "note": "labels of all ranks of the last timed step, assembled, against one context solving the whole scene on rank 0's GPU "
+                                 "(the single context is what bench.py --gpus 1 checks against the oracle)"}
+        out["parity_checked"] = out["parity"]["ok"]
+        if not out["parity_checked"]:
+            rc = 3
+    print(json.dumps(out), flush=True)
+    if rc:
+        log("PARITY CHECK FAILED: %r" % (out.get("parity"),))
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -414,10 +548,26 @@ def main():
     ap.add_argument("--shard", action="store_true", help="take the sharded C++ / RCCL path even at world size 1 (test of the N > 1 code path on one GPU)")
     ap.add_argument("--shuffle-main", action="store_true", help="experiments: the main workload with faces and vertices in random order")
     ap.add_argument("--no-shuffled", action="store_true", help="skip the extra leg that runs the headline scene with faces AND vertices randomly permuted")
+    ap.add_argument("--launch", default="inproc", choices=["inproc", "torchrun"],
+                    help="--gpus N > 1 started without a launcher: 'inproc' = one process, one host thread per GPU, peer-push transport (the single-node route); "
+                         "'torchrun' = re-execute under torch.distributed.run, one process per GPU, RCCL")
     args = ap.parse_args()
     args.config = int(args.config) if args.config.isdigit() else args.config
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.launch == "torchrun":
+        # one process per GPU over RCCL: the launcher the driver would use, started from here
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                os.path.abspath(__file__)] + sys.argv[1:]
+        log("re-executing:", " ".join(argv))
+        os.execv(sys.executable, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MVS_BENCH_ONE_GPU"):   # test mode: every rank on cuda:0 (use with --backend gloo)
@@ -446,6 +596,8 @@ def main():
         if max_labels < 0:
             max_labels = 64
     max_labels = max(max_labels, 0)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return run_inproc(args, cfg, max_labels)     # --gpus N without a launcher: N in-process ranks, one per GPU
     t0 = time.time()
     scene = M.synth.make_scene(**cfg)
     if args.shuffle_main:

@@ -146,8 +146,11 @@ void mvs_default_settings(mvs_settings* s);
  * The stash is per PROCESS (texrecon's pattern: one caller thread, one scene): concurrent callers are safe -- it is locked, and every
  * thread has its own call profile -- but only the last table handed out stays parked; the one-shot calls run on the device named by
  * the environment variable MVS_DEVICE (default 0).
- * Host images (mvs_scene_set_views with host pointers, hence every one-shot call) are pinned in place for the upload; environment
- * MVS_PIN_HOST_IMAGES=0 sends them from pageable memory instead (no user-pointer registration; ~4x slower upload).
+ * Host images (mvs_scene_set_views with host pointers, hence every one-shot call) reach the device through a ring of library-owned
+ * pinned buffers filled by host threads (MVS_UPLOAD_THREADS, default min(16, cores / 2); 128 MB of pinned memory per device, kept
+ * until mvs_release_cached()); nothing of the caller's address space is registered with the driver.  Environment
+ * MVS_HOST_UPLOAD=register pins the caller's pages in place instead (hipHostRegister; opt-in: see csrc/api.hip), =pageable copies
+ * from pageable memory (~4x slower).  (MVS_PIN_HOST_IMAGES=1 / 0 are the older spellings of register / pageable.)
  * Environment MVS_KEEP_TABLE=0 switches all of that off; mvs_release_cached() frees what is parked; mvs_last_call_profile() = wall-clock
  * breakdown (JSON object) of the calling thread's last one-shot call. */
 void mvs_release_cached(void);
@@ -287,11 +290,14 @@ mvs_status mvs_ctx_dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
  * of the range with local indices.  mvs_ctx_costs_download returns the caller's numbering. */
 mvs_status mvs_ctx_costs_device(mvs_ctx* ctx, mvs_csr* device_view);
 /* *ordered = 1: the active table lives in the library's own order and perm_device[p] (caller-owned DEVICE array of n_faces words, may
- * be NULL) receives the caller's face id of column p; *ordered = 0: the table is in the caller's order (uploaded tables, option
- * "face_order" = 0, face ranges), nothing is written */
+ * be NULL) receives the caller's face id of column p -- for the table of a face range (mvs_scene_set_face_range: end - begin columns,
+ * the positions [begin, end) of the order) that many words; *ordered = 0: the table is in the caller's order (uploaded tables,
+ * option "face_order" = 0), nothing is written */
 mvs_status mvs_ctx_table_order(mvs_ctx* ctx, uint32_t* perm_device, int* ordered);
 /* copy it to freshly malloc'ed host arrays (release with mvs_csr_free); with
- * quality_out != NULL also returns the un-normalised qualities (malloc'ed, nnz floats) */
+ * quality_out != NULL also returns the un-normalised qualities (malloc'ed, nnz floats).  The table of the whole mesh leaves in the
+ * caller's numbering; the table of a face range leaves as it is: column k = the face at position begin + k of the library's order,
+ * i.e. the caller's face perm[begin + k] (mvs_ctx_table_order / mvs_ctx_partition_faces). */
 mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* host_out, float** quality_out);
 /* replace the resident costs by caller-provided ones (host or device pointers) */
 mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device);
@@ -399,7 +405,9 @@ mvs_status mvs_ctx_mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 /* ICM on the best labeling: gains of own nodes; then (after the GAIN halo exchange) apply in place */
 mvs_status mvs_ctx_mrf_icm_gain(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
 mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* moved_device);
-/* labels (view_selection.cpp:120-132) of own nodes of the best labeling into labels_device[node_end - node_begin] */
+/* labels (view_selection.cpp:120-132) of own nodes of the best labeling into labels_device[node_end - node_begin]: nodes are COLUMNS
+ * of the active table, i.e. positions of the library's face order after mvs_ctx_data_costs (mvs_ctx_table_order names the caller's
+ * ids), the caller's ids after mvs_ctx_costs_upload or with option "face_order" = 0; mvs_ctx_view_selection returns the caller's ids */
 mvs_status mvs_ctx_mrf_labels(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* labels_device,
                               uint32_t* unseen_out);
 
@@ -441,18 +449,26 @@ mvs_status mvs_postprocess_face_infos(uint32_t n_faces, uint32_t n_views, const 
  * only.  Results are bit-identical to the single-GPU path for any number of parts.
  *
  * Transport of the sweep loop: through the communicator (one pack launch, one grouped exchange, one unpack launch per colour phase), or
- * -- where the ranks can address each other's device memory (today: the in-process communicator) -- "peer push": one launch per phase
+ * -- where the ranks can address each other's device memory (the in-process communicator: one process, one host thread per GPU of
+ * a node, peer access between the GPUs) -- "peer push": one launch per phase
  * stores the runs at their final places in the neighbours' arrays, ordering is by one stream event per phase and rank (waited for on
  * the stream, never on the host), the sweep's energy pair is published the same way and summed by every rank on the device.
  *
- * Communicators: RCCL (mvs_comm_unique_id on rank 0, the 128 bytes travel by any means, mvs_comm_create_rccl on every
- * rank) or an in-process one for `world` host threads sharing a device (mvs_comm_create_local: tests on a 1-GPU box). */
+ * Communicators: RCCL (one process per GPU: mvs_comm_unique_id on rank 0, the 128 bytes travel by any means, mvs_comm_create_rccl
+ * on every rank) or the in-process one (mvs_comm_create_local_devices: `world` host threads of ONE process, rank r driving a context
+ * on devices[r]; distinct GPUs get hipDeviceEnablePeerAccess in both directions and the collectives are peer copies -- the
+ * single-node route; devices == NULL or all equal: the ranks time-slice one device, which is how a 1-GPU box tests it).
+ * A rank whose call fails makes the other ranks' host-side waits of that call end with an error (no rank is left blocked); the
+ * communicator stays usable for the next call. */
 #define MVS_COMM_ID_BYTES 128
 typedef struct mvs_comm mvs_comm;
 typedef struct mvs_shard mvs_shard;
 mvs_status mvs_comm_unique_id(uint8_t id_out[MVS_COMM_ID_BYTES]);
 mvs_status mvs_comm_create_rccl(int device, int rank, int world, const uint8_t id[MVS_COMM_ID_BYTES], mvs_comm** out);
-mvs_status mvs_comm_create_local(int world, mvs_comm** out /* [world] */);
+mvs_status mvs_comm_create_local(int world, mvs_comm** out /* [world] */);                                /* all ranks on the current device */
+mvs_status mvs_comm_create_local_devices(int world, const int* devices /* [world] or NULL */, mvs_comm** out /* [world] */);
+/* *peer_push = 1: the ranks can store into each other's device memory (the sweep loop takes the peer-push transport); any out may be NULL */
+mvs_status mvs_comm_info(mvs_comm* comm, int* rank, int* world, int* peer_push);
 void mvs_comm_destroy(mvs_comm* comm);
 /* ctx: the rank's context with the FULL mesh and all views set; adjacency: device pointers to the full graph in the CALLER's face
  * numbering (read once, at creation) */

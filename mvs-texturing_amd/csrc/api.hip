@@ -3,6 +3,7 @@
 // the solver's host loop and the .spt / .vec writers.
 #include "ctx.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +87,8 @@ void adjacency_to_table_order(mvs_ctx* ctx, const uint32_t* d_adj_ptr, const uin
 // table's order (the sharded driver renumbers once for all its calls).
 void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device, bool table_order) {
     const size_t F = ctx->csr_faces;
+    if (ctx->t_perm && !ctx->t_pos && !table_order)
+        throw StatusError(MVS_ERR_STATE, "the active table covers a face range of the library's order: view selection needs the table of the whole mesh (or option face_order = 0)");
     const bool renumber = ctx->t_perm != nullptr && !table_order;
     if (on_device && !renumber) { ctx->r_adj_ptr = adj_ptr; ctx->r_adj = adj; return; }
     size_t E = 0;
@@ -127,6 +130,17 @@ void park_spare(mvs_ctx* c) {
     mvs_ctx* old = nullptr;
     { std::lock_guard<std::mutex> lock(g_stash.m); old = g_stash.spare; g_stash.spare = c; }
     if (old) mvs_ctx_destroy(old);
+}
+// parks `c` (table resident, fingerprint fp) for the mvs_view_selection that follows; a context parked earlier -- by another thread, or by a
+// call whose view selection never came -- is destroyed, outside the lock: the stash never orphans a scene on the device
+void park_table(mvs_ctx* c, uint64_t fp) {
+    mvs_ctx* old = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_stash.m);
+        old = g_stash.ctx;
+        g_stash.ctx = c; g_stash.fp = fp; g_stash.nnz = c->csr_nnz; g_stash.n_faces = c->csr_faces; g_stash.n_views = c->csr_views;
+    }
+    if (old && old != c) mvs_ctx_destroy(old);
 }
 thread_local std::string g_call_profile = "{}";
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -202,6 +216,80 @@ static bool prepare_sweep_graph(mvs_ctx* ctx, Sweep&& one_sweep) {
     if (!ok) { (void)hipGetLastError(); ctx->mrf_graph = 0; if (ctx->verbose) fprintf(stderr, "[mvs] hipGraph capture of the sweep loop failed: launching directly\n"); }
     return ok;
 }
+
+// ---- host images -> device through a ring of library-owned pinned buffers (mvs_scene_set_views) ----
+namespace {
+enum class UploadRoute { Ring, Register, Pageable };
+UploadRoute upload_route() {
+    if (const char* e = getenv("MVS_HOST_UPLOAD")) {
+        if (!strcmp(e, "register")) return UploadRoute::Register;
+        if (!strcmp(e, "pageable")) return UploadRoute::Pageable;
+        return UploadRoute::Ring;
+    }
+    if (const char* e = getenv("MVS_PIN_HOST_IMAGES")) return e[0] == '0' ? UploadRoute::Pageable : UploadRoute::Register;
+    return UploadRoute::Ring;
+}
+struct UploadPiece { const uint8_t* src; uint8_t* dst; size_t bytes; };
+// One ring per device and process (an upload holds its mutex: uploads to one device share one PCIe link anyway): two pinned slots of
+// SLOT bytes per copy thread, an event per slot.
+struct UploadRing {
+    static constexpr size_t SLOT = 4u << 20; static constexpr unsigned MAX_THREADS = 16, SLOTS = 2 * MAX_THREADS;
+    std::mutex m; uint8_t* buf[SLOTS] = {}; hipEvent_t ev[SLOTS] = {}; bool used[SLOTS] = {};
+    void ensure(unsigned slots) {
+        for (unsigned k = 0; k < slots; ++k) {
+            if (!buf[k]) MVS_HIP(hipHostMalloc((void**)&buf[k], SLOT, hipHostMallocPortable));
+            if (!ev[k]) MVS_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+    }
+    void release() {
+        std::lock_guard<std::mutex> lock(m);
+        for (unsigned k = 0; k < SLOTS; ++k) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (buf[k]) (void)hipHostFree(buf[k]); ev[k] = nullptr; buf[k] = nullptr; used[k] = false; }
+    }
+};
+constexpr int RING_DEVICES = 16;
+UploadRing g_ring[RING_DEVICES];
+unsigned upload_threads() {
+    if (const char* e = getenv("MVS_UPLOAD_THREADS")) return (unsigned)std::max(1, std::min(atoi(e), (int)UploadRing::MAX_THREADS));
+    return std::max(1u, std::min(UploadRing::MAX_THREADS, std::thread::hardware_concurrency() / 2));
+}
+// The images are cut into SLOT-sized chunks; copy thread t takes the chunks t, t + T, ... and alternates between its two slots: wait
+// until the slot's previous copy has left it (its event), fill it from the caller's pageable memory, queue the slot's copy to the
+// device and the event behind it.  No thread waits for another one: while the copy engine drains one slot of a thread the thread
+// fills its other slot, and T threads keep T copies in flight.  (Copies of different chunks write different ranges: their order on
+// the stream does not matter; the stream is drained before the function returns.)
+void upload_through_ring(mvs_ctx* ctx, const std::vector<UploadPiece>& pieces) {
+    if (ctx->device < 0 || ctx->device >= RING_DEVICES) throw StatusError(MVS_ERR_UNSUPPORTED, "upload ring: device index out of range");
+    UploadRing& R = g_ring[ctx->device];
+    std::lock_guard<std::mutex> lock(R.m);
+    struct Chunk { const uint8_t* src; uint8_t* dst; size_t n; };
+    std::vector<Chunk> chunks;
+    for (const UploadPiece& p : pieces) for (size_t o = 0; o < p.bytes; o += UploadRing::SLOT) chunks.push_back(Chunk{p.src + o, p.dst + o, std::min(UploadRing::SLOT, p.bytes - o)});
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(upload_threads(), chunks.size()));
+    R.ensure(2 * T);
+    hipStream_t s = ctx->stream; const int device = ctx->device;
+    struct Drain { hipStream_t s; UploadRing& R; ~Drain() { (void)hipStreamSynchronize(s); for (bool& u : R.used) u = false; } } drain{s, R};   // no copy still reads a slot when the lock is released
+    std::mutex em; std::string error; std::atomic<bool> failed{false};
+    auto work = [&](unsigned t) {
+        try {
+            MVS_HIP(hipSetDevice(device));
+            unsigned turn = 0;
+            for (size_t c = t; c < chunks.size() && !failed.load(std::memory_order_relaxed); c += T, turn ^= 1u) {
+                const unsigned k = 2 * t + turn;
+                if (R.used[k]) MVS_HIP(hipEventSynchronize(R.ev[k]));
+                memcpy(R.buf[k], chunks[c].src, chunks[c].n);
+                MVS_HIP(hipMemcpyAsync(chunks[c].dst, R.buf[k], chunks[c].n, hipMemcpyHostToDevice, s));
+                MVS_HIP(hipEventRecord(R.ev[k], s));
+                R.used[k] = true;
+            }
+        } catch (const std::exception& e) { failed.store(true); std::lock_guard<std::mutex> l(em); if (error.empty()) error = e.what(); }
+    };
+    std::vector<std::thread> th; th.reserve(T);
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (failed.load()) throw HipError("image upload: " + error);
+}
+}  // namespace
 
 extern "C" {
 
@@ -366,20 +454,23 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
     if (rgb_on_device) { for (auto* b : ctx->own_rgb) delete b; ctx->own_rgb.clear(); }
     else { while (ctx->own_rgb.size() > n_views) { delete ctx->own_rgb.back(); ctx->own_rgb.pop_back(); } }
     ctx->h_views.assign(n_views, ViewParams{});
-    // Host images: the caller's buffers are pageable, and a pageable hipMemcpyAsync is staged through the driver's bounce
-    // buffer at ~13 GB/s (1.9 GB of BASELINE config 3: 146 ms).  Pinning the caller's pages in place for the duration of the
-    // call (hipHostRegister) lets the copy engine read them directly; all copies are queued back to back, one wait at the
-    // end.  A buffer that cannot be registered (read-only mapping, limit reached) goes the pageable way.
+    // Host images.  The caller's buffers are pageable, and a pageable hipMemcpyAsync is staged through the driver's bounce buffer at
+    // ~13 GB/s (1.9 GB of BASELINE config 3: 146 ms).  Three routes (environment MVS_HOST_UPLOAD; DESIGN.md "Boundary"):
+    //   ring      (default) host threads copy the images, cut into 32 MB pieces, into a ring of LIBRARY-OWNED pinned buffers
+    //             (hipHostMalloc, allocated once per process) while the copy engine drains the pieces filled before: nothing of
+    //             the caller's address space is ever registered with the driver;
+    //   register  the caller's pages pinned in place for the duration of the call (hipHostRegister; MVS_PIN_HOST_IMAGES=1 is the
+    //             older spelling): the fastest route, but user-pointer registrations of pages the process keeps churning ended
+    //             GPU test runs with an abort() inside the runtime (profiles/EXPERIMENTS.md) -- opt-in only;
+    //   pageable  plain copies from the caller's memory (MVS_PIN_HOST_IMAGES=0).
     // every exit path -- a bad image, an allocation or copy that throws -- first drains the stream (copies may still read the
     // pinned pages) and then unregisters what was registered: the caller's memory never stays pinned behind a failed call
     struct Pinned {
         hipStream_t s; std::vector<void*> ptrs;
         ~Pinned() { if (ptrs.empty()) return; (void)hipStreamSynchronize(s); for (void* p : ptrs) (void)hipHostUnregister(p); }
     } pinned{ctx->stream, {}};
-    // MVS_PIN_HOST_IMAGES=0: never register the caller's pages (user-pointer registrations are at the mercy of the kernel moving those
-    // pages under memory pressure): every image goes the pageable way
-    const char* pin_env = getenv("MVS_PIN_HOST_IMAGES");
-    const bool pin_images = !(pin_env && pin_env[0] == '0');
+    const UploadRoute route = rgb_on_device ? UploadRoute::Pageable : upload_route();
+    std::vector<UploadPiece> pieces;
     for (uint32_t j = 0; j < n_views; ++j) {
         const mvs_view& v = views[j];
         if (v.width < 2 || v.height < 2 || !v.rgb) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image");
@@ -393,12 +484,14 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
             auto* b = ctx->own_rgb[j];
             const size_t bytes = (size_t)v.width * v.height * 3;
             b->ensure(bytes + 16);
-            if (pin_images && bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) pinned.ptrs.push_back(const_cast<uint8_t*>(v.rgb));
+            p.rgb = b->p;
+            if (route == UploadRoute::Ring && bytes >= (1u << 18)) { pieces.push_back(UploadPiece{v.rgb, b->p, bytes}); continue; }
+            if (route == UploadRoute::Register && bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) pinned.ptrs.push_back(const_cast<uint8_t*>(v.rgb));
             else (void)hipGetLastError();   // not registered: clear the sticky error, copy from pageable memory
             MVS_HIP(hipMemcpyAsync(b->p, v.rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
-            p.rgb = b->p;
         }
     }
+    if (!pieces.empty()) upload_through_ring(ctx, pieces);
     MVS_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_views = n_views;
     ctx->have_costs = false; ctx->dc_phase = 0;
@@ -670,12 +763,7 @@ mvs_status mvs_data_costs(const mvs_mesh* mesh, const mvs_view* views, uint32_t 
     t[5] = now_ms();
     bool kept = false;
     if (st == MVS_OK && stash_enabled()) {   // park the context with its table for the mvs_view_selection that follows
-        const uint64_t fp = csr_fingerprint(out);
-        mvs_ctx* old = nullptr;
-        { std::lock_guard<std::mutex> lock(g_stash.m); old = g_stash.ctx; g_stash.ctx = nullptr; }
-        if (old) mvs_ctx_destroy(old);
-        std::lock_guard<std::mutex> lock(g_stash.m);
-        g_stash.ctx = ctx; g_stash.fp = fp; g_stash.nnz = out->nnz; g_stash.n_faces = out->n_faces; g_stash.n_views = out->n_views;
+        park_table(ctx, csr_fingerprint(out));
         kept = true;
     }
     t[6] = now_ms();
@@ -693,6 +781,7 @@ void mvs_release_cached(void) {
     { std::lock_guard<std::mutex> lock(g_stash.m); a = g_stash.ctx; b = g_stash.spare; g_stash.ctx = nullptr; g_stash.spare = nullptr; g_stash.fp = 0; }
     if (a) mvs_ctx_destroy(a);
     if (b) mvs_ctx_destroy(b);
+    for (auto& r : g_ring) r.release();   // (a pinned upload ring is allocated again by the next host-image upload to its device)
 }
 
 /* tex::calculate_data_costs with the result streamed out in chunks of faces (see mvs_viewsel.h) */
@@ -765,11 +854,7 @@ mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, ui
     } else t[4] = now_ms();
     t[5] = now_ms();
     bool kept = false;
-    if (st == MVS_OK && stash_enabled()) {
-        std::lock_guard<std::mutex> lock(g_stash.m);
-        g_stash.ctx = ctx; g_stash.fp = fp; g_stash.nnz = ctx->csr_nnz; g_stash.n_faces = ctx->csr_faces; g_stash.n_views = ctx->csr_views;
-        kept = true;
-    }
+    if (st == MVS_OK && stash_enabled()) { park_table(ctx, fp); kept = true; }
     if (!kept) { if (stash_enabled() && st == MVS_OK) park_spare(ctx); else mvs_ctx_destroy(ctx); }
     char buf[640];
     snprintf(buf, sizeof(buf), "{\"call\": \"mvs_data_costs_stream\", \"ctx_ms\": %.3f, \"mesh_h2d_ms\": %.3f, \"images_h2d_ms\": %.3f, \"compute_ms\": %.3f, \"first_chunk_ms\": %.3f, "

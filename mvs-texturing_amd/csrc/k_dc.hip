@@ -838,7 +838,12 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     // the mesh in the library's own layout (faces [fb, fb + nf) are POSITIONS of that layout); a table over the whole mesh remembers
     // its order so that it crosses the ABI in the caller's numbering
     { Prof pr(ctx, "dc_order"); build_scene_order(ctx); }
-    if (ctx->mesh_ordered && fb == 0 && nf == ctx->n_faces) { ctx->t_perm = ctx->f_perm.p; ctx->t_pos = ctx->f_pos.p; }
+    // (a face RANGE's table remembers which faces its columns belong to -- t_perm = the range's slice of the order -- but has no inverse:
+    //  it leaves as it is, columns in position order, and mvs_ctx_table_order names the faces)
+    if (ctx->mesh_ordered) {
+        if (fb == 0 && nf == ctx->n_faces) { ctx->t_perm = ctx->f_perm.p; ctx->t_pos = ctx->f_pos.p; }
+        else { ctx->t_perm = ctx->f_perm.p + fb; ctx->t_pos = nullptr; }
+    }
     { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }   /* :157-163 */
     if (vis) { Prof pr(ctx, "dc_bvh_build"); build_bvh(ctx); }           /* :144 */
 

@@ -65,7 +65,7 @@ __global__ void iota_u32_kernel(uint32_t* __restrict__ v, uint32_t n) {
 // The active table in the caller's order -> ctx->u_ptr / u_view / u_cost (/ u_q); cached until the table changes.  A table that
 // already is in the caller's order (t_perm == null) is not copied: the function then returns false and the caller reads r_*.
 bool table_to_caller_order(mvs_ctx* ctx, bool with_quality) {
-    if (!ctx->t_perm) return false;
+    if (!ctx->t_perm || !ctx->t_pos) return false;   // (no inverse: the table of a face range, whose columns stay in position order)
     const bool want_q = with_quality && ctx->csr_q_valid;
     if (ctx->u_valid && (!want_q || ctx->u_q_valid)) return true;
     hipStream_t s = ctx->stream;
@@ -161,7 +161,8 @@ mvs_status mvs_partition_faces(const mvs_mesh* mesh, int world, uint32_t* perm_o
 }
 
 /* order of the ACTIVE cost table: *ordered = 1 and perm_device[p] (caller-owned DEVICE array of n_faces words, may be NULL) = the
- * caller's face id of column p when the table lives in the library's own order; *ordered = 0 (nothing written): the caller's order */
+ * caller's face id of column p when the table lives in the library's own order; *ordered = 0 (nothing written): the caller's order.
+ * The table of a face range (mvs_scene_set_face_range) has end - begin columns, in position order: ordered = 1 and that many words. */
 mvs_status mvs_ctx_table_order(mvs_ctx* ctx, uint32_t* perm_device, int* ordered) {
     if (!ctx || !ordered) return api_fail(MVS_ERR_INVALID, "null argument");
     *ordered = ctx->t_perm ? 1 : 0;

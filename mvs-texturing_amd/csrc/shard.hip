@@ -81,7 +81,6 @@ struct PeerHub {
     int world;
     std::vector<PeerSlot> slot;
     std::unique_ptr<std::atomic<uint64_t>[]> recorded;     // events recorded by a rank in the current solve
-    std::atomic<bool> failed{false};
     explicit PeerHub(int w) : world(w), slot(w), recorded(new std::atomic<uint64_t>[w]) { for (int r = 0; r < w; ++r) recorded[r].store(0); }
     ~PeerHub() { for (PeerSlot& p : slot) for (hipEvent_t e : p.ev) (void)hipEventDestroy(e); }
 };
@@ -89,6 +88,14 @@ struct PeerHub {
 struct mvs_comm {
     int rank = 0, world = 1;
     virtual ~mvs_comm() {}
+    // Failure of one rank must not leave the others waiting for it.  Every sharded entry point is a CALL that all ranks make in the
+    // same order: begin_call() numbers it (the same number on every rank), fail() marks the current call as failed for everybody,
+    // and a host-side wait inside the call (barrier, peer_wait) ends with an error once aborted() says so.  The mark names the call,
+    // so the next call starts clean on every rank without anybody resetting anything.
+    uint64_t call_no = 0;
+    void begin_call() { ++call_no; }
+    virtual void fail() {}
+    virtual bool aborted() const { return false; }
     // non-null: the ranks of this communicator can store into each other's device memory (see PeerHub); barrier() = host rendezvous
     virtual PeerHub* peers() { return nullptr; }
     virtual void barrier() {}
@@ -172,56 +179,74 @@ struct RcclComm : mvs_comm {
     }
 };
 
-// ---- in-process communicator: `world` host threads, one per rank, sharing a device ----
-// Every operation is a rendezvous: post the pointers, barrier, copy (device to device, on the own stream, after the
-// owner's "data ready" event), barrier, wait for the readers of the own send buffer.  Small reductions go through the host.
+// ---- in-process communicator: `world` host threads of ONE process, one per rank ----
+// The ranks' contexts live on the devices named at creation: distinct GPUs of one node (the product's single-node route: peer access
+// is switched on between all of them, halo data is STORED into the neighbours' arrays -- PeerHub -- and the collectives below are
+// peer copies over xGMI) or one shared device (tests on a 1-GPU box: the same code, the ranks time-slice the device).
+// Every collective is a rendezvous: post the pointers, barrier, copy (device to device, on the own stream, after the owner's "data
+// ready" event), barrier, wait for the readers of the own send buffer.
+__global__ void reduce_gathered_kernel(const uint8_t* __restrict__ gathered, size_t n, int world, int type /* 0 u32, 1 u64, 2 f32 */, int op /* 0 sum, 1 max */, void* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (type == 0) { const uint32_t* g = (const uint32_t*)gathered; uint32_t a = 0; for (int q = 0; q < world; ++q) { const uint32_t v = g[(size_t)q * n + k]; a = op == 0 ? a + v : (v > a ? v : a); } ((uint32_t*)out)[k] = a; }
+    else if (type == 1) { const unsigned long long* g = (const unsigned long long*)gathered; unsigned long long a = 0; for (int q = 0; q < world; ++q) { const unsigned long long v = g[(size_t)q * n + k]; a = op == 0 ? a + v : (v > a ? v : a); } ((unsigned long long*)out)[k] = a; }
+    else { const float* g = (const float*)gathered; float a = g[k]; for (int q = 1; q < world; ++q) { const float v = g[(size_t)q * n + k]; a = op == 0 ? a + v : fmaxf(a, v); } ((float*)out)[k] = a; }   // rank order on every rank: identical sums
+}
 struct LocalHub {
     int world;
+    std::vector<int> device;                 // device of rank r
+    bool peer_ok = true;                     // every rank can address every other rank's device memory
     std::mutex m; std::condition_variable cv; int waiting = 0; uint64_t generation = 0;
+    std::atomic<uint64_t> failed_call{0};    // number of the call some rank failed in (mvs_comm::call_no), 0 = none
     std::vector<const uint8_t*> send_a, send_b; std::vector<const uint64_t*> soff_a, soff_b;
     std::vector<hipEvent_t> ready, done;
-    std::vector<std::vector<uint8_t>> host;
     PeerHub peer;
-    explicit LocalHub(int w) : world(w), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w), done(w), host(w), peer(w) {}
-    void barrier() {
+    explicit LocalHub(int w) : world(w), device(w, 0), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w, nullptr), done(w, nullptr), peer(w) {}
+    ~LocalHub() { for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e); }
+    // a rendezvous of all ranks that gives up -- on every rank still inside -- when a rank failed in call `call_no`
+    void barrier(uint64_t call_no) {
         std::unique_lock<std::mutex> l(m);
         const uint64_t g = generation;
-        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); }
-        else cv.wait(l, [&] { return generation != g; });
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); return; }
+        while (!cv.wait_for(l, std::chrono::milliseconds(50), [&] { return generation != g; }))
+            if (failed_call.load(std::memory_order_acquire) == call_no && call_no != 0) { --waiting; throw HipError("sharded call: another rank failed"); }
     }
 };
 struct LocalComm : mvs_comm {
     std::shared_ptr<LocalHub> hub;
+    DBuf<uint8_t> gathered;                  // all-reduce scratch (world x the operand) on this rank's device
     ~LocalComm() override {}
     bool exchange_is_collective() const override { return true; }
-    PeerHub* peers() override { return &hub->peer; }
-    void barrier() override { hub->barrier(); }
+    PeerHub* peers() override { return hub->peer_ok ? &hub->peer : nullptr; }
+    void barrier() override { hub->barrier(call_no); }
+    void fail() override { hub->failed_call.store(call_no, std::memory_order_release); hub->cv.notify_all(); }
+    bool aborted() const override { return call_no != 0 && hub->failed_call.load(std::memory_order_acquire) == call_no; }
     void rendezvous_copy(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
                          const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {
         LocalHub& H = *hub;
         H.send_a[rank] = sa; H.soff_a[rank] = soa; H.send_b[rank] = sb; H.soff_b[rank] = sob;
         MVS_HIP(hipEventRecord(H.ready[rank], s));
-        H.barrier();
+        barrier();
         for (int q = 0; q < world; ++q) {
             if (q == rank) continue;
             MVS_HIP(hipStreamWaitEvent(s, H.ready[q], 0));
             const uint64_t na = roa[q + 1] - roa[q];
             if (na) {
                 if (H.soff_a[q][rank + 1] - H.soff_a[q][rank] != na) throw HipError("local exchange: send / receive sizes disagree");
-                MVS_HIP(hipMemcpyAsync(ra + roa[q], H.send_a[q] + H.soff_a[q][rank], na, hipMemcpyDeviceToDevice, s));
+                MVS_HIP(hipMemcpyAsync(ra + roa[q], H.send_a[q] + H.soff_a[q][rank], na, hipMemcpyDefault, s));
             }
             if (rb) {
                 const uint64_t nb = rob[q + 1] - rob[q];
                 if (nb) {
                     if (H.soff_b[q][rank + 1] - H.soff_b[q][rank] != nb) throw HipError("local exchange: send / receive sizes disagree");
-                    MVS_HIP(hipMemcpyAsync(rb + rob[q], H.send_b[q] + H.soff_b[q][rank], nb, hipMemcpyDeviceToDevice, s));
+                    MVS_HIP(hipMemcpyAsync(rb + rob[q], H.send_b[q] + H.soff_b[q][rank], nb, hipMemcpyDefault, s));
                 }
             }
         }
         MVS_HIP(hipEventRecord(H.done[rank], s));
-        H.barrier();
+        barrier();
         for (int q = 0; q < world; ++q) if (q != rank) MVS_HIP(hipStreamWaitEvent(s, H.done[q], 0));   // my send buffers are free again
-        H.barrier();   // nobody re-posts before everybody has queued its waits on this round's events
+        barrier();   // nobody re-posts before everybody has queued its waits on this round's events
     }
     void exchange(const uint8_t* send, const uint64_t* soff, uint8_t* recv, const uint64_t* roff, hipStream_t s) override {
         rendezvous_copy(send, soff, recv, roff, nullptr, nullptr, nullptr, nullptr, s);
@@ -230,32 +255,30 @@ struct LocalComm : mvs_comm {
                    const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) override {
         rendezvous_copy(sa, soa, ra, roa, sb, sob, rb, rob, s);
     }
+    // every rank's `bytes` into every rank's recv (rank-major): peer copies, nothing through the host
     void allgather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
         LocalHub& H = *hub;
-        H.host[rank].resize(bytes);
-        MVS_HIP(hipMemcpyAsync(H.host[rank].data(), send, bytes, hipMemcpyDeviceToHost, s));
-        MVS_HIP(hipStreamSynchronize(s));
-        H.barrier();
-        for (int q = 0; q < world; ++q) MVS_HIP(hipMemcpyAsync((uint8_t*)recv + (size_t)q * bytes, H.host[q].data(), bytes, hipMemcpyHostToDevice, s));
-        MVS_HIP(hipStreamSynchronize(s));
-        H.barrier();
+        H.send_a[rank] = (const uint8_t*)send;
+        MVS_HIP(hipEventRecord(H.ready[rank], s));
+        barrier();
+        for (int q = 0; q < world; ++q) {
+            if (q != rank) MVS_HIP(hipStreamWaitEvent(s, H.ready[q], 0));
+            if (bytes) MVS_HIP(hipMemcpyAsync((uint8_t*)recv + (size_t)q * bytes, H.send_a[q], bytes, hipMemcpyDefault, s));
+        }
+        MVS_HIP(hipEventRecord(H.done[rank], s));
+        barrier();
+        for (int q = 0; q < world; ++q) if (q != rank) MVS_HIP(hipStreamWaitEvent(s, H.done[q], 0));   // the peers have read `send`: it may change again
+        barrier();
     }
     void allreduce(void* buf, size_t n, Type t, Op op, hipStream_t s) override {
-        LocalHub& H = *hub;
         const size_t es = t == U64 ? 8 : 4, bytes = n * es;
-        H.host[rank].resize(bytes);
-        MVS_HIP(hipMemcpyAsync(H.host[rank].data(), buf, bytes, hipMemcpyDeviceToHost, s));
-        MVS_HIP(hipStreamSynchronize(s));
-        H.barrier();
-        std::vector<uint8_t> out(bytes);
-        for (size_t k = 0; k < n; ++k) {
-            if (t == U32) { uint32_t a = 0; for (int q = 0; q < world; ++q) { const uint32_t v = ((const uint32_t*)H.host[q].data())[k]; a = op == SUM ? a + v : std::max(a, v); } ((uint32_t*)out.data())[k] = a; }
-            else if (t == U64) { uint64_t a = 0; for (int q = 0; q < world; ++q) { const uint64_t v = ((const uint64_t*)H.host[q].data())[k]; a = op == SUM ? a + v : std::max(a, v); } ((uint64_t*)out.data())[k] = a; }
-            else { float a = ((const float*)H.host[0].data())[k]; for (int q = 1; q < world; ++q) { const float v = ((const float*)H.host[q].data())[k]; a = op == SUM ? a + v : std::max(a, v); } ((float*)out.data())[k] = a; }
+        gathered.ensure((size_t)world * bytes + 16);
+        allgather(buf, gathered.p, bytes, s);       // (returns with the waits for the peers' reads of `buf` queued: the kernel below may overwrite it)
+        if (n) {
+            hipLaunchKernelGGL(reduce_gathered_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t*)gathered.p, n, world,
+                               t == U32 ? 0 : t == U64 ? 1 : 2, op == SUM ? 0 : 1, buf);
+            MVS_LAUNCH_CHECK();
         }
-        H.barrier();   // everybody has read every host copy
-        MVS_HIP(hipMemcpyAsync(buf, out.data(), bytes, hipMemcpyHostToDevice, s));
-        MVS_HIP(hipStreamSynchronize(s));
     }
 };
 
@@ -777,10 +800,10 @@ void peer_wait(mvs_shard* S, int q, uint64_t idx) {
     PeerHub& H = *S->comm->peers();
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spin = 0; H.recorded[q].load(std::memory_order_acquire) <= idx; ++spin) {
-        if (H.failed.load(std::memory_order_relaxed)) throw HipError("peer push: another rank failed");
-        if ((spin & 1023u) == 1023u) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { H.failed.store(true); throw HipError("peer push: a rank did not reach its next colour phase within 120 s"); }
-            std::this_thread::yield();
+        if ((spin & 255u) == 255u) {
+            if (S->comm->aborted()) throw HipError("peer push: another rank failed");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) throw HipError("peer push: a rank did not reach its next colour phase within 120 s");
+            if ((spin & 4095u) == 4095u) std::this_thread::yield();
         }
     }
     MVS_HIP(hipStreamWaitEvent(S->ctx->stream, H.slot[q].ev[idx % S->ev_ring], 0));
@@ -819,16 +842,48 @@ mvs_status mvs_comm_create_rccl(int device, int rank, int world, const uint8_t i
     MVS_API_END
 }
 
-mvs_status mvs_comm_create_local(int world, mvs_comm** out) {
+/* `world` communicators for as many host threads of this process; rank r drives a context on devices[r] (NULL: all on the current
+ * device).  Distinct devices get peer access switched on in both directions between every pair; where a pair cannot address each
+ * other the peer-push transport is off for this communicator (the exchange route copies through the runtime instead). */
+mvs_status mvs_comm_create_local_devices(int world, const int* devices, mvs_comm** out) {
     if (!out || world < 1 || world > MAX_PARTS) return api_fail(MVS_ERR_INVALID, "bad argument");
     MVS_API_BEGIN
+    int cur = 0, ndev = 0;
+    MVS_HIP(hipGetDevice(&cur));
+    MVS_HIP(hipGetDeviceCount(&ndev));
     auto hub = std::make_shared<LocalHub>(world);
     for (int r = 0; r < world; ++r) {
-        MVS_HIP(hipEventCreateWithFlags(&hub->ready[r], hipEventDisableTiming));
+        hub->device[r] = devices ? devices[r] : cur;
+        if (hub->device[r] < 0 || hub->device[r] >= ndev) throw StatusError(MVS_ERR_INVALID, "bad device index");
+    }
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{cur};
+    for (int r = 0; r < world; ++r) {
+        const int a = hub->device[r];
+        MVS_HIP(hipSetDevice(a));
+        MVS_HIP(hipEventCreateWithFlags(&hub->ready[r], hipEventDisableTiming));   // an event belongs to the device that is current when it is made
         MVS_HIP(hipEventCreateWithFlags(&hub->done[r], hipEventDisableTiming));
+        for (int q = 0; q < world; ++q) {
+            const int b = hub->device[q];
+            if (b == a) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { (void)hipGetLastError(); hub->peer_ok = false; continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hub->peer_ok = false;
+            (void)hipGetLastError();
+        }
     }
     for (int r = 0; r < world; ++r) { auto* c = new LocalComm; c->rank = r; c->world = world; c->hub = hub; out[r] = c; }
     MVS_API_END
+}
+mvs_status mvs_comm_create_local(int world, mvs_comm** out) { return mvs_comm_create_local_devices(world, nullptr, out); }
+
+/* *peer_push = 1: the ranks of this communicator can store into each other's device memory (the sweep loop's peer-push transport) */
+mvs_status mvs_comm_info(mvs_comm* comm, int* rank, int* world, int* peer_push) {
+    if (!comm) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (rank) *rank = comm->rank;
+    if (world) *world = comm->world;
+    if (peer_push) *peer_push = comm->peers() ? 1 : 0;
+    return MVS_OK;
 }
 
 void mvs_comm_destroy(mvs_comm* comm) { delete comm; }
@@ -899,6 +954,8 @@ void mvs_shard_destroy(mvs_shard* shard) {
 mvs_status mvs_shard_data_costs(mvs_shard* S, const mvs_settings* settings, mvs_dc_stats* stats, uint64_t* nnz_global) {
     if (!S || !settings) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
+    S->comm->begin_call();
+    try {   // (a failure on this rank ends the other ranks' host-side waits of this call: mvs_comm::fail)
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
     MVS_HIP(hipSetDevice(ctx->device));
     RoctxRange range("Calculating data costs");   /* texrecon.cpp:118 */
@@ -996,6 +1053,7 @@ mvs_status mvs_shard_data_costs(mvs_shard* S, const mvs_settings* settings, mvs_
     // the table has the global shape, in the library's face order
     ctx->u_valid = false;
     if (ctx->mesh_ordered) { ctx->t_perm = ctx->f_perm.p; ctx->t_pos = ctx->f_pos.p; } else { ctx->t_perm = nullptr; ctx->t_pos = nullptr; }
+    } catch (...) { S->comm->fail(); throw; }
     MVS_API_END
 }
 
@@ -1004,6 +1062,8 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     if (!S || !labels_own_device) return api_fail(MVS_ERR_INVALID, "null argument");
     if (!S->ctx->have_costs) return api_fail(MVS_ERR_STATE, "view selection needs data costs (mvs_shard_data_costs)");
     MVS_API_BEGIN
+    S->comm->begin_call();
+    try {
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
     MVS_HIP(hipSetDevice(ctx->device));
     RoctxRange range("Running MRF optimization");   /* texrecon.cpp:126 */
@@ -1036,7 +1096,6 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     }
     if (S->peer) peer_publish(S);
     PeerHub* hub = S->peer ? comm->peers() : nullptr;
-    try {
     while (issued < P.max_sweeps && !pg.stopped) {
         for (uint32_t ph = 0; ph < S->phases; ++ph) {
             if (S->peer && ph > 0) {   // the neighbours' runs of the previous phase are in place (phase 0: the all-rank wait of the last sweep's energy)
@@ -1074,7 +1133,6 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     }
     while (polled < issued && !pg.stopped) mrf_poll(ctx, (uint32_t)++polled, &pg);
     if (issued > 0) mrf_poll(ctx, (uint32_t)issued, &pg);
-    } catch (...) { if (hub) hub->failed.store(true); throw; }   // the other ranks' host-side waits end with an error instead of spinning
     if (S->peer) { MVS_HIP(hipStreamSynchronize(s)); comm->barrier(); S->peer_phases += (uint64_t)issued * S->phases; }   // every rank's stores into this rank have landed
     R.sweeps = issued > 0 ? pg.stop_sweep : 0u;
     resolve_best(ctx);
@@ -1096,7 +1154,6 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
             if (stop < 0 && ctx->h_icm[k % RR] == 0u) stop = k;
         };
         if (S->peer && P.icm_iters > 0) peer_publish_icm(S);
-        try {
         while (issued < P.icm_iters && stop < 0) {
             Prof pr(ctx, "mrf_icm");
             mrf_icm_gain(ctx, nb, ne);
@@ -1127,7 +1184,6 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
             if (issued - polled_icm > LAG) poll();
         }
         while (polled_icm < issued) poll();
-        } catch (...) { if (hub) hub->failed.store(true); throw; }
         ctx->icm_seq = seq0 + (uint32_t)issued;
         it = stop >= 0 ? stop : P.icm_iters;
     }
@@ -1148,6 +1204,7 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     R.unseen = bu[1];
     if (stats) *stats = R;
     if (bu[0]) throw StatusError(MVS_ERR_LABELING, "Incorrect labeling");  /* view_selection.cpp:126-128 */
+    } catch (...) { S->comm->fail(); throw; }
     MVS_API_END
 }
 

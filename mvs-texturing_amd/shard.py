@@ -31,12 +31,22 @@ class Comm:
         return cls(h)
 
     @classmethod
-    def local(cls, world):
-        """`world` communicators for as many host threads sharing a device (tests)"""
+    def local(cls, world, devices=None):
+        """`world` communicators for as many host threads of this process; rank r drives a context on devices[r] (one GPU each:
+        the single-node route, peer access switched on between them; None: all ranks share the current device -- tests)"""
         L = load_library()
         arr = (C.c_void_p * world)()
-        _check(L, L.mvs_comm_create_local(int(world), arr))
+        dv = None
+        if devices is not None:
+            assert len(devices) == world
+            dv = (C.c_int32 * world)(*[int(d) for d in devices])
+        _check(L, L.mvs_comm_create_local_devices(int(world), dv, arr))
         return [cls(C.c_void_p(arr[r])) for r in range(world)]
+
+    def info(self):
+        r, w, p = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(self.L, self.L.mvs_comm_info(self.h, C.byref(r), C.byref(w), C.byref(p)))
+        return {"rank": int(r.value), "world": int(w.value), "peer_push": bool(p.value)}
 
     def close(self):
         if self.h:
@@ -68,8 +78,8 @@ class Shard:
         """uint32[n_own]: the caller's ids of the faces this rank owns, in the order of the labels view_selection returns"""
         import torch
         n = self.n_own()
-        t = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()   # the library writes on the context's stream, torch filled on its own
+        t = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda:%d" % self.ctx.device)
+        torch.cuda.synchronize(self.ctx.device)   # the library writes on the context's stream, torch filled on its own
         _check(self.L, self.L.mvs_shard_own_faces(self.h, C.c_void_p(t.data_ptr()), None))
         return t.cpu().numpy().view(np.uint32)[:n].copy()
 

@@ -140,7 +140,8 @@ def load_library():
         "mvs_ctx_mrf_labels": [vp, u32, u32, vp, C.POINTER(u32)],
         "mvs_ctx_prune_labels": [vp, u32], "mvs_undistort_image": [vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, vp],
         "mvs_postprocess_face_infos": [u32, u32, vp, vp, vp, vp, C.POINTER(Settings), C.POINTER(CCsr), C.POINTER(DcStats)],
-        "mvs_comm_unique_id": [vp], "mvs_comm_create_rccl": [i32, i32, i32, vp, C.POINTER(vp)], "mvs_comm_create_local": [i32, C.POINTER(vp)],
+        "mvs_comm_unique_id": [vp], "mvs_comm_create_rccl": [i32, i32, i32, vp, C.POINTER(vp)], "mvs_comm_create_local": [i32, C.POINTER(vp)], "mvs_comm_create_local_devices": [i32, vp, C.POINTER(vp)],
+        "mvs_comm_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "mvs_comm_destroy": [vp], "mvs_shard_create": [vp, vp, vp, vp, vp, C.POINTER(vp)], "mvs_shard_destroy": [vp],
         "mvs_shard_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats), C.POINTER(u64)],
         "mvs_shard_view_selection": [vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
@@ -247,6 +248,7 @@ class Context:
         h = C.c_void_p()
         _check(self.L, self.L.mvs_ctx_create(device, C.byref(h)))
         self.h = h
+        self.device = int(device)
         self._keep = {}
 
     def close(self):
@@ -309,18 +311,19 @@ class Context:
         (perm uint32[F]: perm[p] = the caller's id of the face at position p, part_begin uint32[world + 1])"""
         import torch
         F = self.n_faces
-        perm = torch.zeros(max(F, 1), dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()   # the library writes on the context's stream, torch filled on its own
+        perm = torch.zeros(max(F, 1), dtype=torch.int32, device="cuda:%d" % self.device)
+        torch.cuda.synchronize(self.device)   # the library writes on the context's stream, torch filled on its own
         part = np.zeros(world + 1, dtype=np.uint32)
         _check(self.L, self.L.mvs_ctx_partition_faces(self.h, int(world), C.c_void_p(perm.data_ptr()), part.ctypes.data_as(C.c_void_p)))
         return perm.cpu().numpy().view(np.uint32)[:F].copy(), part
 
     def table_order(self):
-        """uint32[F]: the caller's face id of every column of the resident table as the library keeps it, or None (caller's order)"""
+        """uint32[F]: the caller's face id of every column of the resident table as the library keeps it, or None (caller's order);
+        after set_face_range(b, e) only the first e - b entries are meaningful (the columns of the range)"""
         import torch
         F = self.n_faces
-        out = torch.zeros(max(F, 1), dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()   # the library writes on the context's stream, torch filled on its own
+        out = torch.zeros(max(F, 1), dtype=torch.int32, device="cuda:%d" % self.device)
+        torch.cuda.synchronize(self.device)   # the library writes on the context's stream, torch filled on its own
         flag = C.c_int(0)
         _check(self.L, self.L.mvs_ctx_table_order(self.h, C.c_void_p(out.data_ptr()), C.byref(flag)))
         return out.cpu().numpy().view(np.uint32)[:F].copy() if flag.value else None

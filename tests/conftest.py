@@ -14,11 +14,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 # qualities are compared BIT for bit with the oracle's serial fp64 scan-line sums in every test.  Tests that want the serial
 # walker everywhere, or every certificate to fail, say so (set_option("info_wave_area", 0) / ("info_cert_shift", 40)).
 os.environ.pop("MVS_INFO_WAVE_AREA", None)
-# Host images go to the device from pageable memory in this suite: pinning the caller's buffers in place (hipHostRegister, the library's
-# default for images of 1 MB and more) registers user pointers, and after the 10 - 20 GB of host images the config-4 / config-5 tests
-# churn through, two of five full runs of the suite on the GPU boxes ended with a silent abort() on a ROCm-runtime thread while the
-# main thread sat in mvs_scene_set_views -- the only place that registers host memory.  One test turns the pinning on explicitly.
-os.environ.setdefault("MVS_PIN_HOST_IMAGES", "0")
+# Host images take the library's DEFAULT upload route in this suite (a ring of library-owned pinned buffers, csrc/api.hip
+# upload_through_ring: nothing of the caller's address space is registered with the driver).  Earlier rounds pinned the caller's
+# buffers in place by default and this suite had to switch that off (two of five full runs ended with an abort() inside the ROCm
+# runtime); the in-place registration is opt-in now (MVS_HOST_UPLOAD=register) and one test compares all three routes.
+os.environ.pop("MVS_PIN_HOST_IMAGES", None)
+os.environ.pop("MVS_HOST_UPLOAD", None)
 
 
 def pytest_configure(config):

@@ -87,17 +87,29 @@ def test_data_costs_and_labels_against_golden(ctx, name):
             assert [ms["energy_fixed"], ms["cut_edges"], ms["sweeps"], ms["icm_iters"]] == g[mode + "/energy_fixed"].tolist()
 
 
-def test_host_images_pinned_in_place_or_pageable_give_the_same_table(monkeypatch):
-    """mvs_scene_set_views pins the caller's image buffers in place for the upload (hipHostRegister; images of 1 MB and more); with
-    MVS_PIN_HOST_IMAGES=0 -- this suite's default, tests/conftest.py -- they go the pageable way.  Same table either way."""
+def test_host_image_upload_routes_give_the_same_table(monkeypatch):
+    """mvs_scene_set_views sends host images through a ring of library-owned pinned buffers filled by host threads (the default),
+    from the caller's pages pinned in place (MVS_HOST_UPLOAD=register) or from pageable memory (=pageable).  Same table every way --
+    also with one copy thread, with images smaller than a ring slot, and with images that are no multiple of it."""
     s = get_scene("bigfoot")                       # 1024x768 images: 2.4 MB each
     tables = []
-    for pin in ("1", "0"):
-        monkeypatch.setenv("MVS_PIN_HOST_IMAGES", pin)
+    for route, threads in (("ring", None), ("ring", "1"), ("ring", "3"), ("register", None), ("pageable", None)):
+        monkeypatch.setenv("MVS_HOST_UPLOAD", route)
+        if threads: monkeypatch.setenv("MVS_UPLOAD_THREADS", threads)
+        else: monkeypatch.delenv("MVS_UPLOAD_THREADS", raising=False)
         c = M.Context(0)
-        _load_scene(c, s); c.data_costs(M.Settings()); tables.append(c.costs_download()); c.close()
-    a, b = tables
-    assert a.nnz == b.nnz > 0 and np.array_equal(a.col_ptr, b.col_ptr) and np.array_equal(a.view_id, b.view_id) and np.array_equal(a.cost.view(np.uint32), b.cost.view(np.uint32))
+        _load_scene(c, s); c.data_costs(M.Settings()); tables.append(c.costs_download())
+        _load_scene(c, s); c.data_costs(M.Settings()); tables.append(c.costs_download())     # a second upload through the same ring
+        c.close()
+    a = tables[0]
+    for b in tables[1:]:
+        assert a.nnz == b.nnz > 0 and np.array_equal(a.col_ptr, b.col_ptr) and np.array_equal(a.view_id, b.view_id) and np.array_equal(a.cost.view(np.uint32), b.cost.view(np.uint32))
+    monkeypatch.setenv("MVS_HOST_UPLOAD", "ring"); monkeypatch.delenv("MVS_UPLOAD_THREADS", raising=False)
+    s2 = get_scene("wide")                          # 2080x70 images (437 KB): above the ring's floor, far below a slot
+    ref, _ = O.data_costs(s2)
+    c = M.Context(0); _load_scene(c, s2); c.data_costs(M.Settings()); t = c.costs_download(); c.close()
+    assert np.array_equal(t.col_ptr, ref.col_ptr) and np.array_equal(t.view_id, ref.view_id) and np.array_equal(t.cost.view(np.uint32), ref.cost.view(np.uint32))
+
 
 
 @pytest.mark.parametrize("mode", list(MODES))
@@ -327,6 +339,9 @@ def test_face_range_sharding_of_data_costs(ctx):
     ctx.data_costs(M.Settings())
     part = ctx.costs_download()
     assert part.n_faces == 2001
+    assert np.array_equal(ctx.table_order()[:2001], perm[1000:3001])      # the range's table names its faces
+    with pytest.raises(M.viewsel.MvsError):                               # ... and is no input for the solver (no whole-mesh table)
+        ctx.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params())
     pc = part.col_ptr.astype(np.int64)
     for k, f in enumerate(perm[1000:3001].tolist()):
         assert np.array_equal(part.view_id[pc[k]:pc[k + 1]], full.view_id[cp[f]:cp[f + 1]])
@@ -849,6 +864,63 @@ def test_cpp_sharded_path_through_the_communicators_exchange(name, P):
     """the same runs with option shard_peer_push = 0: pack launch, exchange through the communicator (what the RCCL communicator does
     with grouped ncclSend / ncclRecv), unpack launch per colour phase instead of stores into the peers' arrays -- identical results"""
     _cpp_shards_equal_single(get_scene(name), P, reps=2, peer_push=0)
+
+
+def test_a_failing_rank_does_not_leave_the_others_blocked():
+    """one rank of the in-process communicator fails inside a sharded call (bad settings: it throws before the call's first
+    collective): the other rank's host-side wait ends with an error instead of blocking, and the communicator serves the next call --
+    on both transports"""
+    import threading
+    import time
+    import torch
+    s = get_scene("bumpy")
+    dev = torch.device("cuda:0")
+    tv, tf, tn = torch.from_numpy(s.verts).to(dev), torch.from_numpy(s.faces.view(np.int32)).to(dev), torch.from_numpy(s.normals).to(dev)
+    timg = [torch.from_numpy(i).to(dev) for i in s.images]
+    tap, tad = torch.from_numpy(s.adj_ptr.view(np.int32)).to(dev), torch.from_numpy(s.adj.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    c0 = M.Context(0); c0.set_mesh(tv, tf, tn); c0.set_views(s.cams, timg); c0.data_costs(M.Settings())
+    lab0, st0 = c0.view_selection(s.adj_ptr, s.adj); c0.close()
+    P = 2
+    comms = M.shard.Comm.local(P, [0, 0])
+    assert comms[0].info() == {"rank": 0, "world": 2, "peer_push": True}
+    out, first, err = [None] * P, [None] * P, [None] * P
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            c = M.Context(0); c.set_mesh(tv, tf, tn); c.set_views(s.cams, timg)
+            sh = M.shard.Shard(c, comms[r], None, tap, tad)
+            own = sh.own_faces()
+            labels = torch.zeros(max(len(own), 1), dtype=torch.int32, device=dev)
+            bad = M.Settings(); bad.data_term = 7
+            t = time.time()
+            try:
+                sh.data_costs(bad if r == 1 else M.Settings())
+                first[r] = "no error"
+            except M.MvsError as e:
+                first[r] = (str(e), time.time() - t)
+            for push in (1, 0):                                    # the communicator is not poisoned: the next calls run, on either transport
+                c.set_option("shard_peer_push", push)
+                sh.data_costs(M.Settings()); ms = sh.view_selection(labels); c.synchronize()
+                assert sh.transport_info()["peer_push"] == bool(push)
+            out[r] = (own, labels.cpu().numpy().view(np.uint32)[:len(own)], ms)
+            sh.close(); c.close()
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+            raise
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=300)
+    assert all(e is None for e in err), err
+    assert "bad data_term" in first[1][0], first
+    assert "another rank failed" in first[0][0] and first[0][1] < 30.0, first
+    got = np.zeros(s.n_faces, dtype=np.uint32)
+    for own, labels, ms in out:
+        got[own] = labels
+        assert (ms["energy_fixed"], ms["sweeps"], ms["icm_iters"]) == (st0["energy_fixed"], st0["sweeps"], st0["icm_iters"])
+    assert np.array_equal(got, lab0)
+    for c in comms: c.close()
 
 
 @isolated
@@ -1598,6 +1670,22 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     d2 = json.loads(lines[0])
     assert d2["n_gpus"] == 2 and d2["config"]["nnz"] == d1["config"]["nnz"]
     assert d2["config"]["sweeps"] == d1["config"]["sweeps"] and abs(d2["config"]["energy"] - d1["config"]["energy"]) < 1e-6   # partition invariance
+    # the command the driver runs for a scaling point -- `python bench.py --gpus N`, no launcher: N in-process ranks (one host thread per GPU,
+    # peer-push transport; here all of them on cuda:0), n_gpus = N, labels of all ranks equal to a single context's
+    for n in (2, 3):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        dn = json.loads(lines[0])
+        assert dn["n_gpus"] == n and dn["devices"] == [0] * n and dn["launch"].startswith("in-process") and dn["scaling"] == "strong"
+        assert dn["parity_checked"] is True and dn["parity"]["labels_equal_single_context"] and dn["halo"]["peer_push"] is True and dn["halo"]["boundary_nodes"] > 0
+        assert dn["config"]["nnz"] == d1["config"]["nnz"] and dn["config"]["sweeps"] == d1["config"]["sweeps"] and abs(dn["config"]["energy"] - d1["config"]["energy"]) < 1e-6
+        assert dn["roofline"]["bound"] == "hbm" and 0.0 < dn["roofline"]["frac"] < 1.0
+    # a launcher whose world size disagrees with --gpus is refused instead of silently running something else
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "1"], capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr
 
 
 @pytest.mark.parametrize("seed,spread", [(0, 0.0), (2, 0.12), (3, 0.05)])
