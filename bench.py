@@ -471,12 +471,15 @@ def run_inproc(args, cfg, max_labels):
                     c1.close()
             sh.close(); ctx.close()
         except BaseException as e:  # noqa: BLE001
-            err[r] = repr(e); gate.abort(); raise
-    th = [threading.Thread(target=rank_main, args=(r,), name="rank%d" % r) for r in range(N)]
+            err[r] = repr(e); gate.abort(); comms[r].abort(); raise      # (peers inside a sharded call are released with an error)
+    th = [threading.Thread(target=rank_main, args=(r,), name="rank%d" % r, daemon=True) for r in range(N)]
     for x in th:
         x.start()
+    deadline = time.time() + 3000.0
     for x in th:
-        x.join()
+        x.join(timeout=max(1.0, deadline - time.time()))
+    if any(x.is_alive() for x in th):
+        raise SystemExit("bench.py --gpus %d (in-process ranks): a rank did not finish: %r" % (N, err))
     for c in comms:
         c.close()
     if any(err):

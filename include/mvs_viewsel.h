@@ -147,7 +147,7 @@ void mvs_default_settings(mvs_settings* s);
  * thread has its own call profile -- but only the last table handed out stays parked; the one-shot calls run on the device named by
  * the environment variable MVS_DEVICE (default 0).
  * Host images (mvs_scene_set_views with host pointers, hence every one-shot call) reach the device through a ring of library-owned
- * pinned buffers filled by host threads (MVS_UPLOAD_THREADS, default min(16, cores / 2); 128 MB of pinned memory per device, kept
+ * pinned buffers filled by host threads (MVS_UPLOAD_THREADS, default min(8, cores / 2); up to 256 MB of pinned memory per device, kept
  * until mvs_release_cached()); nothing of the caller's address space is registered with the driver.  Environment
  * MVS_HOST_UPLOAD=register pins the caller's pages in place instead (hipHostRegister; opt-in: see csrc/api.hip), =pageable copies
  * from pageable memory (~4x slower).  (MVS_PIN_HOST_IMAGES=1 / 0 are the older spellings of register / pageable.)
@@ -467,6 +467,9 @@ mvs_status mvs_comm_unique_id(uint8_t id_out[MVS_COMM_ID_BYTES]);
 mvs_status mvs_comm_create_rccl(int device, int rank, int world, const uint8_t id[MVS_COMM_ID_BYTES], mvs_comm** out);
 mvs_status mvs_comm_create_local(int world, mvs_comm** out /* [world] */);                                /* all ranks on the current device */
 mvs_status mvs_comm_create_local_devices(int world, const int* devices /* [world] or NULL */, mvs_comm** out /* [world] */);
+/* gives an in-process communicator up: the host-side waits of all its ranks inside sharded calls end with an error from now on (for a
+ * rank whose driver failed outside the library: its peers are released instead of waiting for it) */
+void mvs_comm_abort(mvs_comm* comm);
 /* *peer_push = 1: the ranks can store into each other's device memory (the sweep loop takes the peer-push transport); any out may be NULL */
 mvs_status mvs_comm_info(mvs_comm* comm, int* rank, int* world, int* peer_push);
 void mvs_comm_destroy(mvs_comm* comm);

@@ -151,12 +151,14 @@ namespace tex {
 enum DataTerm { DATA_TERM_AREA = 0, DATA_TERM_GMI = 1 };
 enum SmoothnessTerm { SMOOTHNESS_TERM_POTTS = 0 };
 enum OutlierRemoval { OUTLIER_REMOVAL_NONE = 0, OUTLIER_REMOVAL_GAUSS_DAMPING = 1, OUTLIER_REMOVAL_GAUSS_CLAMPING = 2 };
+enum ToneMapping { TONE_MAPPING_NONE = 0, TONE_MAPPING_GAMMA = 1 };
 
 struct Settings {
     bool verbose = false;
     DataTerm data_term = DATA_TERM_GMI;
     SmoothnessTerm smoothness_term = SMOOTHNESS_TERM_POTTS;
     OutlierRemoval outlier_removal = OUTLIER_REMOVAL_NONE;
+    ToneMapping tone_mapping = TONE_MAPPING_NONE;   /* settings.h:86 (read downstream of the path: texture patch generation) */
     bool geometric_visibility_test = true;
     bool global_seam_leveling = true;
     bool local_seam_leveling = true;

@@ -233,7 +233,9 @@ struct UploadPiece { const uint8_t* src; uint8_t* dst; size_t bytes; };
 // One ring per device and process (an upload holds its mutex: uploads to one device share one PCIe link anyway): two pinned slots of
 // SLOT bytes per copy thread, an event per slot.
 struct UploadRing {
-    static constexpr size_t SLOT = 4u << 20; static constexpr unsigned MAX_THREADS = 16, SLOTS = 2 * MAX_THREADS;
+    // 16 MB per copy: at 4 MB the per-copy overhead of the runtime showed (42.7 GB/s whatever the thread count, against 52.5 GB/s for copies
+    // from caller pages pinned in place, BASELINE config 3's 1.89 GB of images; profiles/EXPERIMENTS.md round 5)
+    static constexpr size_t SLOT = 16u << 20; static constexpr unsigned MAX_THREADS = 8, SLOTS = 2 * MAX_THREADS;
     std::mutex m; uint8_t* buf[SLOTS] = {}; hipEvent_t ev[SLOTS] = {}; bool used[SLOTS] = {};
     void ensure(unsigned slots) {
         for (unsigned k = 0; k < slots; ++k) {

@@ -363,9 +363,12 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
     // box, so the hit ballots need no masking.
     t1 = __builtin_amdgcn_inverse_ballot_w64(actm) ? t1 : -1.0f;
     unsigned long long hm0 = 0ull, hm1 = 0ull, hm2 = 0ull, hm3 = 0ull;   // separate scalars, never an indexed array (that would live in scratch)
-    auto visit = [&](uint32_t h) -> uint32_t {   // h wave-uniform: the 96 bytes of bounds arrive with two wide scalar loads
+    // fetch(h): the 96 bytes of bounds of node h (h wave-uniform) arrive with two wide scalar loads; test(nd): the slab tests of its four children
+    auto fetch = [&](uint32_t h) -> Node4 {
         if (COUNT) ++cnt[0];
-        const Node4 nd = *reinterpret_cast<const Node4*>(reinterpret_cast<const char*>(nodes) + (h << 7));   // 32-bit byte offset (build_bvh bounds h): base + offset addressing
+        return *reinterpret_cast<const Node4*>(reinterpret_cast<const char*>(nodes) + (h << 7));   // 32-bit byte offset (build_bvh bounds h): base + offset addressing
+    };
+    auto test = [&](const Node4& nd) -> uint32_t {
         uint32_t m = 0;
 #pragma unroll
         for (int c = 3; c >= 0; --c) {
@@ -391,6 +394,7 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
         }
         return m;
     };
+    auto visit = [&](uint32_t h) -> uint32_t { const Node4 nd = fetch(h); return test(nd); };
     // the leaves (children c of the level-0 node h0, c in m) whose boxes some live ray enters; stops when no ray is left (actm == 0)
     auto leaves = [&](uint32_t h0, uint32_t m) {
         const uint32_t leaf0 = (h0 - bvh.level_off[0]) * 4u;
@@ -442,6 +446,7 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
     if (masks == 0ull) return;
     const char* __restrict__ nbase = reinterpret_cast<const char*>(nodes);
     (void)nbase;
+#ifndef MVS_RAY_PREFETCH
     do {
         const uint32_t idx = (uint32_t)__builtin_ctzll(masks);        // deepest level first = depth first
         masks = clear_bit(masks, idx);
@@ -451,6 +456,35 @@ __device__ __forceinline__ void packet3_traverse(const BvhDev& bvh, const float4
         if (lv != 1u) { masks |= (unsigned long long)m << (4u * (lv - 1u)); h = ch; level = lv - 1u; }
         else { h = ch >> 2; level = 1u; leaves(ch, m); masks = (actm == 0ull) ? 0ull : masks; }
     } while (masks != 0ull);
+#else
+    // (experiment, round 5: the node that follows a level-0 node in the walk does not depend on that node's leaves -- its fetch is issued
+    //  BEFORE the leaves are processed, so its latency hides behind the triangle fetches and the rounds; profiles/EXPERIMENTS.md)
+    uint32_t idx = (uint32_t)__builtin_ctzll(masks);
+    masks = clear_bit(masks, idx);
+    uint32_t lv = idx >> 2, ch = ((h >> (2u * (lv - level))) << 2) | (idx & 3u);
+    Node4 nd = fetch(ch);
+    for (;;) {
+        m = test(nd);
+        if (lv != 1u) {
+            masks |= (unsigned long long)m << (4u * (lv - 1u)); h = ch; level = lv - 1u;
+            if (masks == 0ull) break;
+            idx = (uint32_t)__builtin_ctzll(masks); masks = clear_bit(masks, idx);
+            lv = idx >> 2; ch = ((h >> (2u * (lv - level))) << 2) | (idx & 3u);
+            nd = fetch(ch);
+        } else {
+            const uint32_t leaf_node = ch;
+            h = ch >> 2; level = 1u;
+            const bool more = masks != 0ull;
+            if (more) {
+                idx = (uint32_t)__builtin_ctzll(masks); masks = clear_bit(masks, idx);
+                lv = idx >> 2; ch = ((h >> (2u * (lv - level))) << 2) | (idx & 3u);
+                nd = fetch(ch);
+            }
+            leaves(leaf_node, m);
+            if (!more || actm == 0ull) break;
+        }
+    }
+#endif
 }
 
 // Residency: a 256-thread block is admitted per CU up to floor(800 / (ceil16(sgpr) + 16)) times (MI355X_MICROARCH.md "Residency").  The 98

@@ -550,6 +550,14 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // MVS_SWEEP_EXP (scripts/sweep_probe.py; never defined in the product build): 1 = every data load / store of the sweep lands in a 64 KB
 // window (cache hot: the kernel's non-memory floor), 2 = loads and stores only (no arithmetic, no LDS: the memory floor), 3 / 4 = three /
 // two waves per SIMD (sensitivity to residency).  Results are garbage for 1 and 2.
+// Round-5 probes of an EDGE-PAIR message layout (m(i->j) stored next to m(j->i), the two interleaved word by word) and of the decode as
+// one record in schedule order -- access pattern only, results are garbage (scripts/sweep_probe.py, profiles/r05_sweep_probe.json):
+// 5 = a node's incoming word and its old outgoing word of an edge come from ONE 8-byte load (three load instructions fewer on damped
+// sweeps); 6 = 5 + the outgoing word is stored into the line the pair was loaded from; 7 = the decode triple as one 8-byte store at the
+// node's schedule position instead of three 4-byte stores by node id; 8 = 6 + 7.
+#define MVS_PROBE_PAIR (MVS_SWEEP_EXP == 5 || MVS_SWEEP_EXP == 6 || MVS_SWEEP_EXP == 8)
+#define MVS_PROBE_PAIR_ST (MVS_SWEEP_EXP == 6 || MVS_SWEEP_EXP == 8)
+#define MVS_PROBE_DECODE (MVS_SWEEP_EXP == 7 || MVS_SWEEP_EXP == 8)
 #ifndef MVS_SWEEP_EXP
 #define MVS_SWEEP_EXP 0
 #endif
@@ -625,11 +633,17 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
         uint32_t mposb = recb + 4u * ((K + 3u) & ~3u) + glb;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
+#if MVS_PROBE_PAIR
+            { const uint2 pr = ld_off<uint2>(mo, (d.in_off[e] & ~7u) + 2u * t0); r.in[e] = pr.x; r.old[e] = pr.y; }
+#else
             if (MVS_SWEEP_DROP & 2) r.in[e] = d.in_off[e]; else r.in[e] = ld_off<uint32_t>(mo, MVS_XO((d.in_off[e] & ~3u) + t0));
+#endif
             if (MVS_SWEEP_DROP & 4) r.map[e] = mposb; else r.map[e] = ld_off<uint32_t>(rec, MVS_XO(mposb));
             if (!(d.out_off[e] & 1u)) mposb += (((d.kk >> (8 + 8 * e)) & 0xFFu) + 3u) & ~3u;   // 4 bytes per 4 map entries
             if (MVS_SWEEP_DROP & 1) r.nl[e] = d.nbr[e]; else r.nl[e] = ld_off<uint32_t>(lab, MVS_XO(4u * d.nbr[e]));     // an absent neighbour is recorded as the node itself
+#if !MVS_PROBE_PAIR
             if (DAMP && !(MVS_SWEEP_DROP & 16)) r.old[e] = ld_off<uint32_t>(mo, MVS_XO((d.out_off[e] & ~3u) + t0)); else r.old[e] = d.out_off[e];
+#endif
         }
     };
     NodeDesc cur = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i, last));
@@ -705,7 +719,11 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
                 const uint32_t slot = (G < 64) ? mp : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // "absent at the sender" -> the +inf slot (G < 64: the records hold 4 * G)
                 w = msg_pack_s<DAMP>(min_raw(tile[slot], lam_s), alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
             }
+#if MVS_PROBE_PAIR_ST
+            if (t0 < kj3[d]) st_off<uint32_t>(mn, (cur.in_off[d] & ~7u) + 2u * t0 + 4u, w);   // (probe: into the line the pair came from)
+#else
             if (t0 < kj3[d]) st_off<uint32_t>(mn, MVS_XO(o_out[d] + t0), w);      // one 4-byte store (runs are padded)
+#endif
         }
         // the lane that owns the winning label publishes the decode (K == 0: lane 0 publishes the single label 0 with
         // unary 1, view_selection.cpp:50-51,70-71) and accounts the node's share of the tracking energy (integer:
@@ -717,7 +735,11 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
             const uint32_t my_lab = (K > 0u) ? (wsel & 0xFFFFu) + 1u : 0u;
             const uint32_t my_code = (K > 0u) ? (wsel >> 16) : 65535u;
             const uint32_t idb = 4u * cur.id;
+#if MVS_PROBE_DECODE
+            st_off<uint2>(sel, 8u * (i - node_begin), make_uint2(((K > 0u) ? bt : 0u) | (my_lab << 8), my_code)); (void)idb;   // (probe: one record in schedule order; sel2 holds 2 (F + 1) words)
+#else
             st_off<uint32_t>(sel, idb, (K > 0u) ? bt : 0u); st_off<uint32_t>(lab, idb, my_lab); st_off<float>(selcost, idb, cost_value(my_code));
+#endif
             acc_e += my_code;
             acc_c += (low[0] && nl[0] != my_lab) + (low[1] && nl[1] != my_lab) + (low[2] && nl[2] != my_lab);
         }

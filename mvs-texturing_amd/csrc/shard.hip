@@ -93,9 +93,10 @@ struct mvs_comm {
     // and a host-side wait inside the call (barrier, peer_wait) ends with an error once aborted() says so.  The mark names the call,
     // so the next call starts clean on every rank without anybody resetting anything.
     uint64_t call_no = 0;
-    void begin_call() { ++call_no; }
+    virtual void begin_call() { ++call_no; }
     virtual void fail() {}
     virtual bool aborted() const { return false; }
+    virtual void abort_all() {}          // the caller gives this communicator up (mvs_comm_abort): every rank's waits end with an error, for good
     // non-null: the ranks of this communicator can store into each other's device memory (see PeerHub); barrier() = host rendezvous
     virtual PeerHub* peers() { return nullptr; }
     virtual void barrier() {}
@@ -196,20 +197,35 @@ struct LocalHub {
     int world;
     std::vector<int> device;                 // device of rank r
     bool peer_ok = true;                     // every rank can address every other rank's device memory
-    std::mutex m; std::condition_variable cv; int waiting = 0; uint64_t generation = 0;
+    std::mutex m; std::condition_variable cv; int waiting = 0; uint64_t generation = 0, bar_call = 0 /* the call the ranks now waiting belong to */;
     std::atomic<uint64_t> failed_call{0};    // number of the call some rank failed in (mvs_comm::call_no), 0 = none
+    std::atomic<uint64_t> max_call{0};       // the latest call any rank has begun
+    std::atomic<bool> dead{false};           // mvs_comm_abort: the communicator was given up
     std::vector<const uint8_t*> send_a, send_b; std::vector<const uint64_t*> soff_a, soff_b;
     std::vector<hipEvent_t> ready, done;
     PeerHub peer;
     explicit LocalHub(int w) : world(w), device(w, 0), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w, nullptr), done(w, nullptr), peer(w) {}
     ~LocalHub() { for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e); }
-    // a rendezvous of all ranks that gives up -- on every rank still inside -- when a rank failed in call `call_no`
+    // A call is abandoned -- for every rank still inside it -- once a rank failed in it or a rank has begun a later call (it left this
+    // one, with or without an error, and will never come back to it).
+    bool abandoned(uint64_t call_no) const {
+        if (dead.load(std::memory_order_acquire)) return true;
+        return call_no != 0 && (failed_call.load(std::memory_order_acquire) == call_no || max_call.load(std::memory_order_acquire) > call_no);
+    }
+    // A rendezvous of all ranks INSIDE ONE CALL: ranks of an abandoned call give up instead of waiting, and a rank that arrives for a
+    // later call first lets the waiters of the earlier (abandoned) call drain -- it never completes THEIR rendezvous.
     void barrier(uint64_t call_no) {
         std::unique_lock<std::mutex> l(m);
+        while (waiting > 0 && bar_call != call_no) {
+            if (bar_call > call_no || abandoned(call_no)) throw HipError("sharded call: another rank failed");
+            cv.wait_for(l, std::chrono::milliseconds(20));
+        }
+        if (abandoned(call_no)) throw HipError("sharded call: another rank failed");
+        bar_call = call_no;
         const uint64_t g = generation;
         if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); return; }
-        while (!cv.wait_for(l, std::chrono::milliseconds(50), [&] { return generation != g; }))
-            if (failed_call.load(std::memory_order_acquire) == call_no && call_no != 0) { --waiting; throw HipError("sharded call: another rank failed"); }
+        while (!cv.wait_for(l, std::chrono::milliseconds(20), [&] { return generation != g; }))
+            if (abandoned(call_no)) { --waiting; cv.notify_all(); throw HipError("sharded call: another rank failed"); }
     }
 };
 struct LocalComm : mvs_comm {
@@ -219,8 +235,14 @@ struct LocalComm : mvs_comm {
     bool exchange_is_collective() const override { return true; }
     PeerHub* peers() override { return hub->peer_ok ? &hub->peer : nullptr; }
     void barrier() override { hub->barrier(call_no); }
+    void begin_call() override {
+        ++call_no;
+        uint64_t seen = hub->max_call.load(std::memory_order_relaxed);
+        while (seen < call_no && !hub->max_call.compare_exchange_weak(seen, call_no, std::memory_order_release)) {}
+    }
     void fail() override { hub->failed_call.store(call_no, std::memory_order_release); hub->cv.notify_all(); }
-    bool aborted() const override { return call_no != 0 && hub->failed_call.load(std::memory_order_acquire) == call_no; }
+    bool aborted() const override { return hub->abandoned(call_no); }
+    void abort_all() override { hub->dead.store(true, std::memory_order_release); hub->cv.notify_all(); }
     void rendezvous_copy(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
                          const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {
         LocalHub& H = *hub;
@@ -876,6 +898,10 @@ mvs_status mvs_comm_create_local_devices(int world, const int* devices, mvs_comm
     MVS_API_END
 }
 mvs_status mvs_comm_create_local(int world, mvs_comm** out) { return mvs_comm_create_local_devices(world, nullptr, out); }
+
+/* gives the communicator up: every host-side wait of every rank inside a sharded call -- now or later -- ends with an error instead of
+ * blocking (a rank's driver that dies OUTSIDE the library calls this so that its peers are released).  In-process communicators only. */
+void mvs_comm_abort(mvs_comm* comm) { if (comm) comm->abort_all(); }
 
 /* *peer_push = 1: the ranks of this communicator can store into each other's device memory (the sweep loop's peer-push transport) */
 mvs_status mvs_comm_info(mvs_comm* comm, int* rank, int* world, int* peer_push) {

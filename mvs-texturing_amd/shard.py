@@ -48,6 +48,11 @@ class Comm:
         _check(self.L, self.L.mvs_comm_info(self.h, C.byref(r), C.byref(w), C.byref(p)))
         return {"rank": int(r.value), "world": int(w.value), "peer_push": bool(p.value)}
 
+    def abort(self):
+        """give the (in-process) communicator up: peers blocked in a sharded call get an error instead of waiting for this rank"""
+        if self.h:
+            self.L.mvs_comm_abort(self.h)
+
     def close(self):
         if self.h:
             self.L.mvs_comm_destroy(self.h)

@@ -142,7 +142,7 @@ def load_library():
         "mvs_postprocess_face_infos": [u32, u32, vp, vp, vp, vp, C.POINTER(Settings), C.POINTER(CCsr), C.POINTER(DcStats)],
         "mvs_comm_unique_id": [vp], "mvs_comm_create_rccl": [i32, i32, i32, vp, C.POINTER(vp)], "mvs_comm_create_local": [i32, C.POINTER(vp)], "mvs_comm_create_local_devices": [i32, vp, C.POINTER(vp)],
         "mvs_comm_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
-        "mvs_comm_destroy": [vp], "mvs_shard_create": [vp, vp, vp, vp, vp, C.POINTER(vp)], "mvs_shard_destroy": [vp],
+        "mvs_comm_destroy": [vp], "mvs_comm_abort": [vp], "mvs_shard_create": [vp, vp, vp, vp, vp, C.POINTER(vp)], "mvs_shard_destroy": [vp],
         "mvs_shard_data_costs": [vp, C.POINTER(Settings), C.POINTER(DcStats), C.POINTER(u64)],
         "mvs_shard_view_selection": [vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
         "mvs_shard_plan_info": [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)],
@@ -156,7 +156,7 @@ def load_library():
     for name, argtypes in sig.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
-        if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_subgraphs_free", "mvs_ctx_destroy", "mvs_comm_destroy", "mvs_shard_destroy"):
+        if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_subgraphs_free", "mvs_ctx_destroy", "mvs_comm_destroy", "mvs_comm_abort", "mvs_shard_destroy"):
             fn.restype = C.c_int
     L._declared = sorted(list(sig.keys()) + ["mvs_last_error", "mvs_status_string"])
     _lib = L

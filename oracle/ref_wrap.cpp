@@ -30,6 +30,7 @@
 #include <cstdio>
 
 // defined (not static) in libs/tex/calculate_data_costs.cpp:35 but declared in no header
+// (MVS_DROPIN_BUILD: this file compiled against integration/view_selection_mi355x.cpp instead of upstream's two sources)
 namespace tex { bool photometric_outlier_detection(std::vector<FaceProjectionInfo>* infos, Settings const& settings); }
 
 typedef SparseTable<std::uint32_t, std::uint16_t, float> RefDataCosts;   // == tex::DataCosts (libs/tex/texturing.h:36)
@@ -264,6 +265,7 @@ std::int64_t ref_postprocess_face_infos(std::uint32_t n_faces, std::uint32_t n_v
     } catch (std::exception& e) { std::fprintf(stderr, "ref_postprocess_face_infos: %s\n", e.what()); return -1; }
 }
 
+#ifndef MVS_DROPIN_BUILD   // (the drop-in build -- Makefile target `dropin` -- has no calculate_data_costs.cpp, hence no such internal symbol)
 // photometric_outlier_detection (calculate_data_costs.cpp:35-129) on one face's infos in the order given
 int ref_outlier_detection(std::uint32_t n, const float* mean_color, float* quality, int outlier_removal) {
     std::vector<tex::FaceProjectionInfo> infos(n);
@@ -276,6 +278,7 @@ int ref_outlier_detection(std::uint32_t n, const float* mean_color, float* quali
     for (std::uint32_t i = 0; i < n; ++i) quality[i] = infos[i].quality;
     return ok ? 1 : 0;
 }
+#endif
 
 // ---- the path's labeling half: tex::view_selection (view_selection.cpp:18-133), the reference's own model construction
 // (edges between faces that both have candidate views, label sets view_id + 1 / {0}, unary tables, Potts weight) and its

@@ -3,7 +3,7 @@
 # usage: scripts/kernel_regs.sh k_dc.hip [name filter]      (KEEP_ASM=path keeps the assembly)
 SRC=$1; FILTER=${2:-.}
 CSRC=$(dirname "$0")/../mvs-texturing_amd/csrc
-EXTRA=""; [ "$SRC" = "k_bvh.hip" ] && EXTRA="-fno-slp-vectorize"
+EXTRA="${DEFS:-}"; [ "$SRC" = "k_bvh.hip" ] && EXTRA="$EXTRA -fno-slp-vectorize"
 OUT=${KEEP_ASM:-${TMPDIR:-/tmp}/regs_$$.s}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math $EXTRA --cuda-device-only -S "$CSRC/$SRC" -o "$OUT" 2>/dev/null || exit 1
 awk '

@@ -828,10 +828,12 @@ def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check
             sh.close(); c.close()
         except Exception as e:  # noqa: BLE001
             err[r] = e
+            comms[r].abort()          # peers blocked in a sharded call get an error instead of waiting for this rank
             raise
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(P)]
     for t in th: t.start()
     for t in th: t.join(timeout=900)
+    assert not any(t.is_alive() for t in th), "a rank is blocked"
     assert all(e is None for e in err), err
     Kf = np.diff(full.col_ptr.astype(np.int64))
     got = np.full(F, 0xFFFFFFFF, dtype=np.uint32)
@@ -909,9 +911,10 @@ def test_a_failing_rank_does_not_leave_the_others_blocked():
         except Exception as e:  # noqa: BLE001
             err[r] = e
             raise
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(P)]   # daemon: a rank that did block must not keep the interpreter alive
     for t in th: t.start()
-    for t in th: t.join(timeout=300)
+    for t in th: t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is blocked"
     assert all(e is None for e in err), err
     assert "bad data_term" in first[1][0], first
     assert "another rank failed" in first[0][0] and first[0][1] < 30.0, first
