@@ -78,60 +78,84 @@ def cpu_baseline(scene, faces, normals, adj_ptr, adj, params_kw, budget_s=25.0):
             "host_cpus": ncpu}
 
 
-def reference_leg(scene, faces, normals, n_faces=8192):
-    """The data-cost half through the REFERENCE'S OWN calculate_data_costs.cpp -- compiled where it lies by `make -C oracle ref`
-    (oracle/_ref/libtexref.so: single-threaded, stand-ins for the absent MVE / rayint headers, each any-hit ray answered by the
-    oracle's BVH) -- on the first n_faces faces as a mesh of their own, next to the port on the same sub-mesh with one thread:
-    how far the port's baseline is from upstream's code."""
+def reference_leg(scene, faces, normals, n_faces=65536):
+    """The data-cost half through the REFERENCE'S OWN calculate_data_costs.cpp -- compiled where it lies by `make -C oracle ref ref_omp`
+    (oracle/_ref: stand-ins for the absent MVE / rayint headers, each any-hit ray answered by the oracle's BVH) -- on the first
+    n_faces faces as a mesh of their own: (a) the OpenMP build with the reference's own parallel loops (calculate_data_costs.cpp:148-153
+    over views, :260 over faces) on all host threads, next to the port on the same sub-mesh at the same thread count; (b) one thread of
+    each on an eighth of the sample (the per-core rates).  How far the port's baseline is from upstream's code."""
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
-    lib = os.path.join(ROOT, "oracle", "_ref", "libtexref.so")
-    if not os.path.exists(lib):
-        return {"skipped": "oracle/_ref/libtexref.so not built"}
-    R = C.CDLL(lib); OL = O.load()
-    n = int(min(n_faces, len(faces)))
-
-    class S:
-        pass
-    s = S(); s.verts, s.faces, s.normals, s.cams, s.images = scene.verts, np.ascontiguousarray(faces[:n]), np.ascontiguousarray(normals[:n]), scene.cams, scene.images
-    s.n_views, s.n_faces = scene.n_views, n
-    V = s.n_views
-    t = time.time(); _, st = O.data_costs(s, n_threads=1, timing=True); t_port = st["t_infos"] + st["t_post"]
+    OL = O.load()
     OL.orc_ray_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int]; OL.orc_ray_hit.restype = C.c_int
-    mesh = O.mesh_struct(s); views = O.view_structs(s)
+    OL.orc_bvh_build.restype = C.c_void_p; OL.orc_bvh_free.argtypes = [C.c_void_p]
+    V = scene.n_views
     gmis, gptr = [], (C.c_void_p * V)()
     for j in range(V):
-        w, h = int(s.cams["width"][j]), int(s.cams["height"][j])
+        w, h = int(scene.cams["width"][j]), int(scene.cams["height"][j])
         g = np.zeros(w * h, np.uint8)
-        OL.orc_gradient_magnitude(s.images[j].ctypes.data, w, h, g.ctypes.data)
+        OL.orc_gradient_magnitude(scene.images[j].ctypes.data, w, h, g.ctypes.data)
         gmis.append(g); gptr[j] = g.ctypes.data
-    OL.orc_bvh_build.restype = C.c_void_p
-    bvh = OL.orc_bvh_build(C.byref(mesh))
-    cap = n * V
-    col_ptr = np.zeros(n + 1, np.uint32); vid = np.zeros(cap, np.uint16); cost = np.zeros(cap, np.float32)
-    rays = C.c_uint64(0)
-    R.ref_calculate_data_costs.restype = C.c_int64
-    R.ref_calculate_data_costs.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
-                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    sys.stdout.flush()
-    saved_stdout = os.dup(1); os.dup2(2, 1)      # the reference prints its progress on stdout: this program's stdout is ONE JSON line
-    try:
-        t = time.time()
-        m = R.ref_calculate_data_costs(s.verts.shape[0], vp(s.verts), n, vp(s.faces), vp(s.normals), C.cast(views, C.c_void_p), C.cast(gptr, C.c_void_p), V,
-                                       1, 0, 1, C.cast(OL.orc_ray_hit, C.c_void_p), C.c_void_p(bvh), C.cast(C.pointer(mesh), C.c_void_p), 0,
-                                       vp(col_ptr), vp(vid), vp(cost), cap, C.cast(C.pointer(rays), C.c_void_p))
-        t_ref = time.time() - t
-    finally:
-        os.dup2(saved_stdout, 1); os.close(saved_stdout)
-        OL.orc_bvh_free.argtypes = [C.c_void_p]; OL.orc_bvh_free(C.c_void_p(bvh))
-    return {"what": "tex::calculate_data_costs of the reference (oracle/_ref: upstream's calculate_data_costs.cpp / texture_view.cpp / tri.cpp compiled in place, "
-                    "1 thread, stand-in MVE containers, rays answered by the oracle's BVH; includes its image copies and gradient look-ups) on the first "
-                    "%d faces as a mesh of their own, all %d views" % (n, V),
-            "faces": n, "entries": int(m), "reference_s": t_ref, "reference_faces_per_s_1_core": n / max(t_ref, 1e-9),
-            "port_s_1_thread": t_port, "port_faces_per_s_1_thread": n / max(t_port, 1e-9), "rays_cast_by_the_reference": int(rays.value)}
+
+    def sub(n):
+        class S:
+            pass
+        s = S(); s.verts, s.faces, s.normals, s.cams, s.images = scene.verts, np.ascontiguousarray(faces[:n]), np.ascontiguousarray(normals[:n]), scene.cams, scene.images
+        s.n_views, s.n_faces = scene.n_views, n
+        return s
+
+    def run_reference(lib, s, threads):
+        R = C.CDLL(lib)
+        R.ref_set_threads.argtypes = [C.c_int]; R.ref_set_threads.restype = C.c_int
+        used = R.ref_set_threads(int(threads))
+        n = s.n_faces
+        mesh = O.mesh_struct(s); views = O.view_structs(s)
+        bvh = OL.orc_bvh_build(C.byref(mesh))
+        cap = n * V
+        col_ptr = np.zeros(n + 1, np.uint32); vid = np.zeros(cap, np.uint16); cost = np.zeros(cap, np.float32)
+        rays = C.c_uint64(0)
+        R.ref_calculate_data_costs.restype = C.c_int64
+        R.ref_calculate_data_costs.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        sys.stdout.flush()
+        saved_stdout = os.dup(1); os.dup2(2, 1)      # the reference prints its progress on stdout: this program's stdout is ONE JSON line
+        try:
+            t = time.time()
+            m = R.ref_calculate_data_costs(s.verts.shape[0], vp(s.verts), n, vp(s.faces), vp(s.normals), C.cast(views, C.c_void_p), C.cast(gptr, C.c_void_p), V,
+                                           1, 0, 1, C.cast(OL.orc_ray_hit, C.c_void_p), C.c_void_p(bvh), C.cast(C.pointer(mesh), C.c_void_p), 0,
+                                           vp(col_ptr), vp(vid), vp(cost), cap, C.cast(C.pointer(rays), C.c_void_p))
+            dt = time.time() - t
+        finally:
+            os.dup2(saved_stdout, 1); os.close(saved_stdout)
+            OL.orc_bvh_free(C.c_void_p(bvh))
+        return dt, int(m), int(rays.value), int(used)
+
+    out = {"what": "tex::calculate_data_costs of the reference (oracle/_ref: upstream's calculate_data_costs.cpp / texture_view.cpp / tri.cpp compiled in place, "
+                   "stand-in MVE containers, rays answered by the oracle's BVH; includes its image copies and gradient look-ups) on the first faces of the scene "
+                   "as a mesh of their own, all %d views; the port = the oracle's orc_data_costs on the same sub-mesh" % V}
+    serial, omp = os.path.join(ROOT, "oracle", "_ref", "libtexref.so"), os.path.join(ROOT, "oracle", "_ref", "libtexref_omp.so")
+    if not os.path.exists(serial):
+        return {"skipped": "oracle/_ref/libtexref.so not built"}
+    n1 = int(min(max(n_faces // 8, 1024), len(faces)))
+    s1 = sub(n1)
+    _, st = O.data_costs(s1, n_threads=1, timing=True); t_port1 = st["t_infos"] + st["t_post"]
+    t_ref1, m1, rays1, _ = run_reference(serial, s1, 1)
+    out.update({"faces": n1, "entries": m1, "reference_s": t_ref1, "reference_faces_per_s_1_core": n1 / max(t_ref1, 1e-9),
+                "port_s_1_thread": t_port1, "port_faces_per_s_1_thread": n1 / max(t_port1, 1e-9), "rays_cast_by_the_reference": rays1})
+    if os.path.exists(omp):
+        nt = len(os.sched_getaffinity(0))
+        n = int(min(n_faces, len(faces)))
+        sN = sub(n)
+        tbl, st = O.data_costs(sN, n_threads=nt, timing=True); t_portN = st["t_infos"] + st["t_post"]
+        t_refN, mN, raysN, used = run_reference(omp, sN, nt)
+        out["openmp"] = {"faces": n, "threads": used, "entries": mN, "entries_port": int(tbl.nnz), "reference_s": t_refN, "reference_faces_per_s": n / max(t_refN, 1e-9),
+                         "port_s": t_portN, "port_faces_per_s": n / max(t_portN, 1e-9), "rays_cast_by_the_reference": raysN,
+                         "note": "the reference's own OpenMP loops (calculate_data_costs.cpp:148-153: one view per iteration, dynamic schedule, the scatter in a critical "
+                                 "section; :260 over faces) at %d threads against the port at the same count" % used}
+    return out
 
 
 def induced_subgraph(adj_ptr, adj, n):
@@ -388,6 +412,19 @@ def dropin_timing(cfg, reps=2, timeout_s=900):
     d = json.load(open(outj))
     last = d["runs"][-1]
     last["runs"] = len(d["runs"]); last["first_run_dropin_ms"] = d["runs"][0]["dropin_ms"]
+    # where a cold process pays more than a warm one: the first run's own breakdown next to the last one's (the library's per-call
+    # profiles: context + device buffers + the pinned upload ring + graph instantiation are first-run costs)
+    f0 = d["runs"][0]
+    last["first_run"] = {"dropin_ms": f0["dropin_ms"], "calculate_data_costs": f0["calculate_data_costs"], "view_selection": f0["view_selection"]}
+    def lib(run, call, key):
+        return float(run[call].get("library", {}).get(key, 0.0))
+    last["first_run_extra_ms"] = {"total": f0["dropin_ms"] - last["dropin_ms"],
+                                  "table_fill (first-touch of the caller's container)": f0["calculate_data_costs"]["table_fill_ms"] - last["calculate_data_costs"]["table_fill_ms"],
+                                  "context": lib(f0, "calculate_data_costs", "ctx_ms") - lib(last, "calculate_data_costs", "ctx_ms"),
+                                  "images_h2d (device buffers + pinned ring allocated)": lib(f0, "calculate_data_costs", "images_h2d_ms") - lib(last, "calculate_data_costs", "images_h2d_ms"),
+                                  "mesh_h2d": lib(f0, "calculate_data_costs", "mesh_h2d_ms") - lib(last, "calculate_data_costs", "mesh_h2d_ms"),
+                                  "compute (work buffers allocated)": lib(f0, "calculate_data_costs", "compute_ms") - lib(last, "calculate_data_costs", "compute_ms"),
+                                  "view_selection library (solver buffers, graph instantiation)": f0["view_selection"]["library_ms"] - last["view_selection"]["library_ms"]}
     last["note"] = ("host containers in and out; table_fill_ms = SparseTable::set_value for every entry (the reference's own fill, calculate_data_costs.cpp:291-298, "
                     "pays the same); dropin_core_ms = dropin_ms without table_fill_ms and flatten_ms (the caller's container traffic)")
     last["dropin_core_ms"] = last["dropin_ms"] - last["calculate_data_costs"]["table_fill_ms"] - last["view_selection"]["flatten_ms"]

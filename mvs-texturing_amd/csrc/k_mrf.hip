@@ -177,9 +177,11 @@ __device__ __forceinline__ uint32_t mrf_node_class(uint32_t kmx, uint32_t deg, u
     if (force_generic || deg > 3u || kmx > 255u) return CLS_GENERIC;
     return kmx <= 32u ? 0u : kmx <= 64u ? 1u : kmx <= 128u ? 2u : 3u;
 }
+// (also rev[e] = position of the reverse directed edge (j -> i as an in-edge of j) of the in-edge e = (i <- j), 0xFFFFFFFF when the input is
+//  asymmetric: found once here, read by the layout kernels below instead of being searched for again by each of them)
 __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                 uint32_t F, uint32_t pad_mask, uint32_t force_generic, uint32_t* __restrict__ size, uint8_t* __restrict__ cls,
-                                uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */) {
+                                uint32_t* __restrict__ maxes /* [0]=kmax [1]=degmax */, uint32_t* __restrict__ rev) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t k = 0, deg = 0;
     if (i < F) {
@@ -192,6 +194,7 @@ __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint
             const uint32_t kj = col_ptr[j + 1] - col_ptr[j];
             size[e] = (k > 0 && kj > 0) ? ((k + pad_mask) & ~pad_mask) : 0u;   // runs padded to a multiple of 4 (8-byte quads) or 16 elements (32-byte sectors)
             if (k > 0) kmx = max(kmx, kj);
+            { uint32_t r = adj_ptr[j]; const uint32_t r1 = adj_ptr[j + 1]; while (r < r1 && adj[r] != i) ++r; rev[e] = r < r1 ? r : 0xFFFFFFFFu; }
         }
         cls[i] = (uint8_t)mrf_node_class(kmx, deg, force_generic);
     }
@@ -273,12 +276,6 @@ __global__ void mrf_sub_range_kernel(const uint32_t* __restrict__ perm, const ui
 // therefore streams its previous-outgoing reads and its stores through one contiguous region (2 of the 3 message
 // accesses per label); only the incoming reads gather 1 run out of each neighbour's block.
 // size[e] belongs to the in-edge e = (i <- j) of its receiver i; the out-edge r = (j -> i) of j owns the same run.
-__device__ __forceinline__ uint32_t mrf_reverse_edge(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, uint32_t from, uint32_t to) {
-    uint32_t r = adj_ptr[to];
-    const uint32_t r1 = adj_ptr[to + 1];
-    while (r < r1 && adj[r] != from) ++r;
-    return r < r1 ? r : 0xFFFFFFFFu;                          // position of `from` in the list of `to`
-}
 // nsz[b * (F + 1) + q] = message elements node perm[q] sends to receivers of colour b (b < n_col; with n_col == 1 all
 // receivers count as colour 0 = plain sender-major).  One exclusive scan over the n_col * (F + 1) entries then yields the
 // layout  [receiver colour][sender in (colour, id) order][out-edge in list order]:
@@ -288,7 +285,7 @@ __device__ __forceinline__ uint32_t mrf_reverse_edge(const uint32_t* __restrict_
 //     sender-major layout gathers one 90-byte run out of each neighbour's 270-byte block: 2x the bytes at C3).
 constexpr int MAX_LAYOUT_COLOURS = 8;
 __global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ colour, const uint32_t* __restrict__ adj_ptr,
-                                    const uint32_t* __restrict__ adj, const uint32_t* __restrict__ size, uint32_t F, uint32_t n_col,
+                                    const uint32_t* __restrict__ adj, const uint32_t* __restrict__ size, const uint32_t* __restrict__ rev, uint32_t F, uint32_t n_col,
                                     uint32_t* __restrict__ nsz) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > F) return;
@@ -298,7 +295,7 @@ __global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uin
     if (q < F) {
         const uint32_t j = perm[q];
         for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) {
-            const uint32_t i = adj[r], e = mrf_reverse_edge(adj_ptr, adj, j, i);
+            const uint32_t i = adj[r], e = rev[r];            // e = (i <- j): the in-edge of the receiver that owns this run
             if (e == 0xFFFFFFFFu) continue;
             const uint32_t b = (n_col > 1) ? colour[i] : 0u, sz = size[e];
 #pragma unroll
@@ -309,7 +306,7 @@ __global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uin
     for (int b = 0; b < MAX_LAYOUT_COLOURS; ++b) if ((uint32_t)b < n_col) nsz[(size_t)b * (F + 1) + q] = acc[b];
 }
 __global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ colour, const uint32_t* __restrict__ adj_ptr,
-                                 const uint32_t* __restrict__ adj, const uint32_t* __restrict__ size, const uint32_t* __restrict__ noff,
+                                 const uint32_t* __restrict__ adj, const uint32_t* __restrict__ size, const uint32_t* __restrict__ rev, const uint32_t* __restrict__ noff,
                                  uint32_t F, uint32_t n_col, uint32_t* __restrict__ in_off) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= F) return;
@@ -318,7 +315,7 @@ __global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32
 #pragma unroll
     for (int b = 0; b < MAX_LAYOUT_COLOURS; ++b) off[b] = ((uint32_t)b < n_col) ? noff[(size_t)b * (F + 1) + q] : 0u;
     for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) {
-        const uint32_t i = adj[r], e = mrf_reverse_edge(adj_ptr, adj, j, i);
+        const uint32_t i = adj[r], e = rev[r];
         if (e == 0xFFFFFFFFu) continue;
         const uint32_t b = (n_col > 1) ? colour[i] : 0u, sz = size[e];
         uint32_t o = 0;
@@ -329,18 +326,16 @@ __global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32
 }
 
 __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
-                                uint32_t F, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ size, MrfEdge* __restrict__ edge) {
+                                uint32_t F, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ size, const uint32_t* __restrict__ rev, MrfEdge* __restrict__ edge) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
     for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
-        const uint32_t j = adj[e];
-        uint32_t r = adj_ptr[j];
-        const uint32_t r1 = adj_ptr[j + 1];
-        while (r < r1 && adj[r] != i) ++r;
+        const uint32_t j = adj[e], r = rev[e];
+        const bool has = r != 0xFFFFFFFFu;
         MrfEdge m;
         m.in_off = MSG_BASE + in_off[e];                       // [0, MSG_BASE) is the reserved zero / identity run
-        m.out_off = (r < r1) ? MSG_BASE + in_off[r] : 0u;
-        m.kj = (size[e] > 0 && r < r1) ? (col_ptr[j + 1] - col_ptr[j]) : 0u;
+        m.out_off = has ? MSG_BASE + in_off[r] : 0u;
+        m.kj = (size[e] > 0 && has) ? (col_ptr[j + 1] - col_ptr[j]) : 0u;
         edge[e] = m;
     }
 }
@@ -388,6 +383,14 @@ constexpr uint32_t REC_BASE = 256;            // words [0, REC_BASE) of the reco
 constexpr float COST_SCALE = 65535.0f;
 __device__ __forceinline__ uint32_t cost_code(float c) { return (uint32_t)(c * COST_SCALE + 0.5f); }   // c in [0, 1]
 __device__ __forceinline__ float cost_value(uint32_t code) { return (float)code * (1.0f / 65535.0f); }
+// position of label `l` (> 0: view id l - 1) in the ascending view list of a column (calculate_data_costs.cpp:272); a labeling only ever
+// holds labels of the node's own column, so the search finds it
+__device__ __forceinline__ uint32_t label_position(const uint16_t* __restrict__ view_id, uint32_t p0, uint32_t K, uint32_t l) {
+    uint32_t lo = 0, hi = K;
+    const uint32_t key = l - 1u;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)view_id[p0 + mid] < key) lo = mid + 1; else hi = mid; }
+    return lo < K ? lo : K - 1u;
+}
 
 // ident[e] = 1 iff the two label lists of the (valid) directed edge e are identical; 16 lanes per node.  The kernel is a chain
 // of dependent gathers (edge -> neighbour -> its column -> its view ids), so three edges are in flight at a time.
@@ -550,14 +553,13 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // MVS_SWEEP_EXP (scripts/sweep_probe.py; never defined in the product build): 1 = every data load / store of the sweep lands in a 64 KB
 // window (cache hot: the kernel's non-memory floor), 2 = loads and stores only (no arithmetic, no LDS: the memory floor), 3 / 4 = three /
 // two waves per SIMD (sensitivity to residency).  Results are garbage for 1 and 2.
-// Round-5 probes of an EDGE-PAIR message layout (m(i->j) stored next to m(j->i), the two interleaved word by word) and of the decode as
-// one record in schedule order -- access pattern only, results are garbage (scripts/sweep_probe.py, profiles/r05_sweep_probe.json):
-// 5 = a node's incoming word and its old outgoing word of an edge come from ONE 8-byte load (three load instructions fewer on damped
-// sweeps); 6 = 5 + the outgoing word is stored into the line the pair was loaded from; 7 = the decode triple as one 8-byte store at the
-// node's schedule position instead of three 4-byte stores by node id; 8 = 6 + 7.
-#define MVS_PROBE_PAIR (MVS_SWEEP_EXP == 5 || MVS_SWEEP_EXP == 6 || MVS_SWEEP_EXP == 8)
-#define MVS_PROBE_PAIR_ST (MVS_SWEEP_EXP == 6 || MVS_SWEEP_EXP == 8)
-#define MVS_PROBE_DECODE (MVS_SWEEP_EXP == 7 || MVS_SWEEP_EXP == 8)
+// Round-5 probes of an EDGE-PAIR message layout (m(i->j) stored next to m(j->i), the two interleaved word by word) -- access pattern
+// only, results are garbage (scripts/sweep_probe.py, profiles/r05_sweep_probe.json): 5 = a node's incoming word and its old outgoing
+// word of an edge come from ONE 8-byte load (three load instructions fewer on damped sweeps); 6 = 5 + the outgoing word is stored
+// into the line the pair was loaded from.  (Probes 7 / 8 of that run -- the decode triple as one 8-byte store in schedule order --
+// led to the label-only decode of the product kernel and are gone.)
+#define MVS_PROBE_PAIR (MVS_SWEEP_EXP == 5 || MVS_SWEEP_EXP == 6)
+#define MVS_PROBE_PAIR_ST (MVS_SWEEP_EXP == 6)
 #ifndef MVS_SWEEP_EXP
 #define MVS_SWEEP_EXP 0
 #endif
@@ -578,7 +580,7 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 #endif
 template <int G, bool DAMP, bool XCD, bool LATE_OLD>
 __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ rec, msg_t* msg,
-                                                         const mvs_mrf_progress* __restrict__ st, uint32_t* sel2, uint32_t* lab2, float* cost2, uint32_t buf_stride,
+                                                         const mvs_mrf_progress* __restrict__ st, uint32_t* lab2, uint32_t buf_stride,
                                                          uint32_t node_begin /* positions in the (colour, id) order */, uint32_t node_end, float rho, float alpha,
                                                          unsigned long long* __restrict__ partial) {
     // in place: the nodes of one launch share a colour (an independent set), so no run is read by one node and
@@ -604,7 +606,7 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
     if (gl == 0) tile[4 * G] = INFINITY;
     __syncthreads();
     const uint32_t wofs = st->w * buf_stride;                // decode buffer of this sweep (flipped by the step kernel when a sweep improves the best energy)
-    uint32_t* __restrict__ sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* __restrict__ selcost = cost2 + wofs;
+    uint32_t* lab = lab2 + wofs;
     const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
     const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;   // the oracle's constants, fp32
@@ -674,7 +676,7 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
 #pragma unroll
             for (int d = 0; d < 3; ++d) if (t0 < kj3[d] && !(MVS_SWEEP_DROP & 8)) st_off<uint32_t>(mn, o_out[d] + t0, x);
             if ((MVS_SWEEP_DROP & 8) && x == 0x12345u) st_off<uint32_t>(mn, o_out[0] + t0, x);   // (keeps the loads alive)
-            if (node_ok && gl == 0) { const uint32_t idb = 4u * cur.id; st_off<uint32_t>(sel, idb, x & 3u); st_off<uint32_t>(lab, idb, (x & 15u) + 1u); st_off<float>(selcost, idb, 0.5f); acc_e += x & 1u; }
+            if (node_ok && gl == 0) { const uint32_t idb = 4u * cur.id; st_off<uint32_t>(lab, idb, (x & 15u) + 1u); acc_e += x & 1u; }
             cur = nxt; rw = rn; nxt = nn;
             continue;
         }
@@ -735,11 +737,9 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
             const uint32_t my_lab = (K > 0u) ? (wsel & 0xFFFFu) + 1u : 0u;
             const uint32_t my_code = (K > 0u) ? (wsel >> 16) : 65535u;
             const uint32_t idb = 4u * cur.id;
-#if MVS_PROBE_DECODE
-            st_off<uint2>(sel, 8u * (i - node_begin), make_uint2(((K > 0u) ? bt : 0u) | (my_lab << 8), my_code)); (void)idb;   // (probe: one record in schedule order; sel2 holds 2 (F + 1) words)
-#else
-            st_off<uint32_t>(sel, idb, (K > 0u) ? bt : 0u); st_off<uint32_t>(lab, idb, my_lab); st_off<float>(selcost, idb, cost_value(my_code));
-#endif
+            // ONE store: the label.  The position in the column and the unary of the decoded label are not kept per sweep: whoever
+            // needs them -- the polish, the reported energy -- derives them from the label once, after the sweeps (mrf_exact_cost_kernel)
+            st_off<uint32_t>(lab, idb, my_lab);
             acc_e += my_code;
             acc_c += (low[0] && nl[0] != my_lab) + (low[1] && nl[1] != my_lab) + (low[2] && nl[2] != my_lab);
         }
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
                                                                 const uint16_t* __restrict__ map, const uint32_t* __restrict__ colour,
                                                                 msg_t* msg, const uint32_t* __restrict__ perm, const mvs_mrf_progress* __restrict__ st,
-                                                                uint32_t* sel2, uint32_t* lab2, float* cost2, uint32_t buf_stride,
+                                                                uint32_t* lab2, uint32_t buf_stride,
                                                                 float* scratch, uint32_t node_begin, uint32_t node_end, float rho, float alpha,
                                                                 unsigned long long* __restrict__ partial) {
     const msg_t* mo = msg; msg_t* mn = msg;                  // in place (one colour per launch)
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (st->stopped) return;                                 // a sweep queued after the stop rule fired (see mrf_sweep4_kernel)
     const uint32_t wofs = st->w * buf_stride;
-    uint32_t* sel = sel2 + wofs; uint32_t* lab = lab2 + wofs; float* selcost = cost2 + wofs;
+    uint32_t* lab = lab2 + wofs;
     const float lam = 1.0f / rho;
     const MsgQ mq = msg_q(lam);
     const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;
@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
         const uint32_t i = perm[q];
         const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
         if (K == 0) {   // the single label 0 with unary 1 (view_selection.cpp:50-51,70-71): cost code 65535, no model edge
-            if (threadIdx.x == 0) { sel[i] = 0u; lab[i] = 0u; selcost[i] = 1.0f; acc_e += 65535ull; }
+            if (threadIdx.x == 0) { lab[i] = 0u; acc_e += 65535ull; }
             continue;
         }
         const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
         }
         __syncthreads();                                     // s_cuts complete; s_b / s_t free for the next node
         if (threadIdx.x == 0) {
-            sel[i] = bt; lab[i] = my_lab; selcost[i] = cost_value(my_code);
+            lab[i] = my_lab;   // (position and unary of the label: derived after the sweeps, see mrf_sweep4_kernel)
             acc_e += my_code; acc_c += (unsigned long long)s_cuts[0] + s_cuts[1] + s_cuts[2] + s_cuts[3];
         }
     }
@@ -843,17 +843,20 @@ __global__ void __launch_bounds__(256) mrf_sweep_generic_kernel(const uint32_t* 
 // ---- exact energy of a labeling (32.32 fixed point) over nodes [node_begin, node_end) ----
 // needs only the labels and selected unary costs: an edge is in the model iff both labels are
 // non-zero (both columns non-empty, view_selection.cpp:29-42)
-__global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
+__global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                                         const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj,
                                                          const uint32_t* __restrict__ lab, const float* __restrict__ selcost,
                                                          const mvs_mrf_progress* __restrict__ st /* non-null: the decode buffer st->w of lab / selcost */, uint32_t buf_stride,
                                                          uint32_t node_begin, uint32_t node_end, unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
     // st != null: the TRACKING energy of the current decode (its unaries are dequantised 16-bit codes: integer units of
     // 1 / 65535, 65535 per cut edge); else the exact 32.32 fixed-point energy of the labeling given
-    if (st) { const uint32_t wofs = st->w * buf_stride; lab += wofs; selcost += wofs; }
+    // (the sweeps keep only labels: the tracking energy looks the label's unary up in the table -- the 16-bit code the records hold)
+    if (st) { const uint32_t wofs = st->w * buf_stride; lab += wofs; }
     unsigned long long unary = 0, cuts = 0;
     for (uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x; i < node_end; i += gridDim.x * blockDim.x) {
-        unary += st ? (unsigned long long)cost_code(selcost[i]) : fix32(selcost[i]);
         const uint32_t li = lab[i];
+        if (st) { const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0; unary += (K && li) ? (unsigned long long)cost_code(cost[p0 + label_position(view_id, p0, K, li)]) : 65535ull; }
+        else unary += fix32(selcost[i]);
         if (li == 0u) continue;
         for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
             const uint32_t j = adj[e];
@@ -902,7 +905,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
         const uint32_t p0 = col_ptr[i];
         const uint32_t K = col_ptr[i + 1] - p0;
         const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
-        const uint32_t cur_t = (K > 0) ? sel[i] : 0u;
+        const uint32_t cur_l = (K > 0) ? lab[i] : 0u;   // the node's current label (labels of a column are distinct: it names one position)
         float best = INFINITY, cur = 0.0f; uint32_t bt = 0xFFFFFFFFu;
         // neighbour labels: the first three once (the manifold case), any further ones inside the loop
         uint32_t nl[3];
@@ -914,7 +917,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_kernel(const uint32_t* __res
             for (uint32_t e = e0 + 3; e < e1; ++e) { const uint32_t lj = lab[adj[e]]; diff += (lj != 0u && lj != l); }
             const float en = cost[p0 + t] + (float)diff;
             if (en < best) { best = en; bt = t; }
-            if (t == cur_t) cur = en;
+            if (l == cur_l) cur = en;
         }
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) {
@@ -946,7 +949,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
         const uint32_t K = node_ok ? (cur.kk & 0xFFu) : 0u;
         const uint32_t id = cur.id;
         const uint32_t p0 = (K > 0) ? col_ptr[id] : 0u;
-        const uint32_t cur_t = (K > 0) ? sel[id] : 0u;
+        const uint32_t cur_l = (K > 0) ? lab[id] : 0u;
         uint32_t nl[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) nl[d] = (K > 0 && ((cur.kk >> (8 + 8 * d)) & 0xFFu)) ? lab[cur.nbr[d]] : 0u;
@@ -956,7 +959,7 @@ __global__ void __launch_bounds__(256) mrf_icm_gain_desc_kernel(const NodeDesc* 
             const uint32_t diff = (nl[0] != 0u && nl[0] != l) + (nl[1] != 0u && nl[1] != l) + (nl[2] != 0u && nl[2] != l);
             const float en = cost[p0 + t] + (float)diff;
             if (en < best) { best = en; bt = t; }
-            if (t == cur_t) cur_e = en;
+            if (l == cur_l) cur_e = en;
         }
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) {
@@ -1126,7 +1129,8 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     // degenerate inputs (fewer than four table entries, no edge at all) take the generic kernel throughout; "mrf_force_generic" is a test hook
     const uint32_t force_generic = (ctx->csr_nnz < 4 || E == 0 || ctx->mrf_force_generic) ? 1u : 0u;
     ctx->m_cls.ensure((size_t)F + 4);
-    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), force_generic, ctx->m_size.p, ctx->m_cls.p, maxes); MVS_LAUNCH_CHECK(); }
+    ctx->m_rev.ensure((size_t)E + 2);
+    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), force_generic, ctx->m_size.p, ctx->m_cls.p, maxes, ctx->m_rev.p); MVS_LAUNCH_CHECK(); }
     // ---- colour-phased schedule: colouring (Jones-Plassmann rounds), nodes in (colour, id) order ----
     ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 72); ctx->m_tmp_b.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
     ctx->m_colours = 0; ctx->m_sub_begin.assign(N_SUB + 1, 0); ctx->m_n_fast = 0; ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
@@ -1178,16 +1182,16 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         const uint32_t n_col = (ctx->m_colours >= 2 && ctx->m_colours <= (uint32_t)MAX_LAYOUT_COLOURS) ? ctx->m_colours : 1u;
         const size_t n_ent = (size_t)n_col * ((size_t)F + 1);
         ctx->m_tmp_a.ensure(n_ent + 72); ctx->m_tmp_b.ensure(n_ent + 2);
-        hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, F, n_col, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_rev.p, F, n_col, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, ctx->m_tmp_a.p, ctx->m_tmp_b.p, n_ent, nullptr);   // the last entry of every colour segment is 0, so scan[last] = total
-        hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_tmp_b.p, F, n_col, in_off.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_rev.p, ctx->m_tmp_b.p, F, n_col, in_off.p); MVS_LAUNCH_CHECK();
         MVS_HIP(hipMemcpyAsync(&h[0], ctx->m_tmp_b.p + (n_ent - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     MVS_HIP(hipMemcpyAsync(&h[1], maxes, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     MVS_HIP(hipStreamSynchronize(s));
     ctx->m_total = (uint64_t)MSG_BASE + h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
     if (ctx->m_total >= 0xFFFFFFF0ull) throw StatusError(MVS_ERR_UNSUPPORTED, "message array exceeds 2^32 elements");
-    if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
+    if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_rev.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
     ctx->m_ident.ensure((size_t)E + 1);
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
     ctx->m_fast = true;   // the sweep kernels of BOTH node classes accumulate the sweep's energy (callers no longer run the energy kernel per sweep)
@@ -1349,7 +1353,7 @@ static unsigned launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint3
     if (blocks > 8) blocks &= ~7u;   // multiple of the 8 XCDs
     msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
     unsigned long long* partial = ctx->m_energy.p + 4 + 2 * ((size_t)EPART_BLOCKS * phase + slot);
-#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->m_rec.p, msg, ctx->m_state.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_stride, qb, qe, rho, alpha, partial
+#define SWEEP4_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->m_rec.p, msg, ctx->m_state.p, ctx->m_lab.p, ctx->m_stride, qb, qe, rho, alpha, partial
     if (alpha != 0.0f) {
         if (ctx->mrf_late_old) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, true>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, true>), SWEEP4_ARGS); }
         else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, true, false>), SWEEP4_ARGS); else hipLaunchKernelGGL((mrf_sweep4_kernel<G, true, false, false>), SWEEP4_ARGS); }
@@ -1365,7 +1369,7 @@ static unsigned launch_sweep_generic(mvs_ctx* ctx, uint32_t phase, uint32_t qb, 
     msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
     unsigned long long* partial = ctx->m_energy.p + 4 + 2 * ((size_t)EPART_BLOCKS * phase + slot);
 #define GENERIC_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_map.p, ctx->m_colour.p, msg, ctx->m_perm.p, \
-                     ctx->m_state.p, ctx->m_sel.p, ctx->m_lab.p, ctx->m_cost.p, ctx->m_stride, ctx->pq.p, qb, qe, rho, alpha, partial
+                     ctx->m_state.p, ctx->m_lab.p, ctx->m_stride, ctx->pq.p, qb, qe, rho, alpha, partial
     if (alpha != 0.0f) hipLaunchKernelGGL(mrf_sweep_generic_kernel<true>, GENERIC_ARGS);
     else hipLaunchKernelGGL(mrf_sweep_generic_kernel<false>, GENERIC_ARGS);
 #undef GENERIC_ARGS
@@ -1423,17 +1427,21 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
 
 // The solver tracks energies of the 16-bit unaries the sweeps see; the polish and everything reported use the exact costs:
 // best_cost[i] := cost[col_ptr[i] + best_sel[i]] (1.0 for an empty column)
-__global__ void mrf_exact_cost_kernel(const uint32_t* __restrict__ col_ptr, const float* __restrict__ cost, const uint32_t* __restrict__ sel,
-                                      uint32_t node_begin, uint32_t node_end, float* __restrict__ selcost) {
+// The sweeps keep ONE word per node, its label.  Whatever works on the best labeling afterwards (polish, region moves, reported energy)
+// needs the label's position in the column and its EXACT unary as well: derived here, once, from the label (idempotent).
+__global__ void mrf_exact_cost_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
+                                      const uint32_t* __restrict__ lab, uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ sel, float* __restrict__ selcost) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= node_end) return;
-    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
-    selcost[i] = K ? cost[p0 + sel[i]] : 1.0f;
+    const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0, l = lab[i];
+    const uint32_t t = (K && l) ? label_position(view_id, p0, K, l) : 0u;
+    sel[i] = t;
+    selcost[i] = K ? cost[p0 + t] : 1.0f;
 }
 void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     resolve_best(ctx);
     if (ne0 <= nb0) return;
-    hipLaunchKernelGGL(mrf_exact_cost_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_cost, ctx->b_sel, nb0, ne0, ctx->b_cost);
+    hipLaunchKernelGGL(mrf_exact_cost_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, (const uint32_t*)ctx->b_lab, nb0, ne0, ctx->b_sel, ctx->b_cost);
     MVS_LAUNCH_CHECK();
 }
 
@@ -1445,8 +1453,8 @@ void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce
     unsigned long long* partial = ctx->m_energy.p + 4;
     if (best) mrf_exact_costs(ctx, nb0, ne0);   // idempotent: whatever is reported about the best labeling uses the exact costs
     if (blocks) {
-        if (best) hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj, ctx->b_lab, ctx->b_cost, (const mvs_mrf_progress*)nullptr, 0u, nb0, ne0, partial);
-        else hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_adj_ptr, ctx->r_adj, ctx->m_lab.p, ctx->m_cost.p, ctx->m_state.p, ctx->m_stride, nb0, ne0, partial);
+        if (best) hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->b_lab, ctx->b_cost, (const mvs_mrf_progress*)nullptr, 0u, nb0, ne0, partial);
+        else hipLaunchKernelGGL(mrf_energy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj, ctx->m_lab.p, ctx->m_cost.p, ctx->m_state.p, ctx->m_stride, nb0, ne0, partial);
         MVS_LAUNCH_CHECK();
     }
     if (!reduce) return;   // the caller's mrf_step sums the partials

@@ -26,7 +26,7 @@ public:
     bool intersect(Ray const& ray, Hit*) const {
         RayHook& h = ray_hook();
         if (!h.fn) throw std::runtime_error("oracle/_ref: no ray hook installed");
-        ++h.calls;
+        __atomic_fetch_add(&h.calls, (std::uint64_t)1, __ATOMIC_RELAXED);   // (the OpenMP build of oracle/_ref calls this from many threads)
         const float o[3] = {ray.origin[0], ray.origin[1], ray.origin[2]}, d[3] = {ray.dir[0], ray.dir[1], ray.dir[2]};
         return h.fn(h.bvh, h.mesh, o, d, ray.tmin, ray.tmax, h.brute) != 0;
     }

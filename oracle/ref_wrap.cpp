@@ -35,7 +35,22 @@ namespace tex { bool photometric_outlier_detection(std::vector<FaceProjectionInf
 
 typedef SparseTable<std::uint32_t, std::uint16_t, float> RefDataCosts;   // == tex::DataCosts (libs/tex/texturing.h:36)
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 extern "C" {
+
+// threads of the reference's own OpenMP loops (calculate_data_costs.cpp:148-153,260) in the OpenMP build of this library
+// (oracle/Makefile target `ref_omp`: bench.py's baseline leg); returns the count in effect (1 in the serial build)
+int ref_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
 
 // postprocess_face_infos' percentile (calculate_data_costs.cpp:283-288): Histogram(0, max, bins), add_value, get_approx_percentile
 float ref_percentile(const float* v, std::uint64_t n, float min, float max, std::uint32_t bins, float percentile) {

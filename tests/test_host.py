@@ -179,16 +179,22 @@ def test_bench_reference_leg_keeps_stdout_clean(capfd):
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     s = get_scene("bumpy")
     capfd.readouterr()
-    r = bench.reference_leg(s, s.faces, s.normals, n_faces=1500)
+    r = bench.reference_leg(s, s.faces, s.normals, n_faces=12000)      # 1 500 faces on one thread, 12 000 through the OpenMP build
     out = capfd.readouterr().out
     assert out == "", "the reference's progress output reached stdout: %r" % out[:200]
     assert r["faces"] == 1500 and r["reference_faces_per_s_1_core"] > 0 and r["port_faces_per_s_1_thread"] > 0
     class Sub:
         pass
-    sub = Sub(); sub.verts, sub.faces, sub.normals, sub.cams, sub.images = s.verts, np.ascontiguousarray(s.faces[:1500]), np.ascontiguousarray(s.normals[:1500]), s.cams, s.images
-    sub.n_views, sub.n_faces = s.n_views, 1500
-    ref, _ = O.data_costs(sub, n_threads=1)
+    def sub_scene(n):
+        sub = Sub(); sub.verts, sub.faces, sub.normals, sub.cams, sub.images = s.verts, np.ascontiguousarray(s.faces[:n]), np.ascontiguousarray(s.normals[:n]), s.cams, s.images
+        sub.n_views, sub.n_faces = s.n_views, n
+        return sub
+    ref, _ = O.data_costs(sub_scene(1500), n_threads=1)
     assert r["entries"] == ref.nnz > 0
+    # the reference's own OpenMP loops (oracle/_ref/libtexref_omp.so) fill the same table as the port at the same thread count
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libtexref_omp.so")):
+        o = r["openmp"]
+        assert o["faces"] == min(12000, s.n_faces) and o["threads"] >= 1 and o["entries"] == o["entries_port"] > 0 and o["reference_faces_per_s"] > 0
 
 
 def test_row_f2_scene_folder_round_trip(tmp_path):
