@@ -393,7 +393,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
-    else if (n == "face_order") ctx->face_order = value != 0 ? 1 : 0;   // takes effect with the next data-cost pass (the active table keeps the order it was made in)
+    else if (n == "face_order") { ctx->face_order = value != 0 ? 1 : 0; ctx->order_pinned = false; }   // takes effect with the next data-cost pass (the active table keeps the order it was made in)
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
 }
@@ -445,6 +445,7 @@ mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device)
     ctx->n_verts = mesh->n_verts; ctx->n_faces = mesh->n_faces;
     ctx->face_begin = 0; ctx->face_end = mesh->n_faces;
     ctx->have_costs = false; ctx->dc_phase = 0;
+    ctx->order_pinned = false; ctx->iv = nullptr;   // another mesh: whatever layout a shard pinned is gone
     MVS_API_END
 }
 
@@ -699,7 +700,7 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
         if (graphs && issued + 2 <= P.max_sweeps) {
             MVS_HIP(hipGraphLaunch(ctx->sweep_exec, s));
             ctx->steps_issued += 2; ctx->m_sweep_no += 2; issued += 2; ++ctx->graph_launches;
-            ctx->icm_dirty_valid = false; ctx->best_resolved = false;
+            ctx->icm_dirty_valid = false; ctx->best_resolved = false; ctx->exact_valid = false;
             // one whole graph stays queued behind the one whose reports are read
             while (issued - lag - 2 > polled && !pg.stopped) report((uint32_t)++polled);
         } else {

@@ -163,6 +163,8 @@ struct mvs_ctx {
     mvs::DBuf<float> i_verts, i_normals; mvs::DBuf<uint32_t> i_faces, f_perm, f_pos, f_tmp;
     const float* iv = nullptr; const uint32_t* ifc = nullptr; const float* inr = nullptr;   // the arrays the kernels read (i_* or the caller's)
     bool mesh_ordered = false;        // f_perm / f_pos describe the resident mesh (set by build_scene_order when face_order != 0)
+    bool order_pinned = false;        // a shard was made of this mesh (mvs_shard_create): its parts, its renumbered adjacency and its halo plan ARE this
+                                      // layout, so the data-cost passes of the sharded path keep it instead of deriving it again (mvs_scene_set_mesh un-pins)
     // order of the ACTIVE cost table (r_ptr ...): t_perm[p] = caller's id of column p (null: the table is in the caller's order)
     const uint32_t* t_perm = nullptr; const uint32_t* t_pos = nullptr;
     mvs::DBuf<uint32_t> u_ptr, u_cnt; mvs::DBuf<uint16_t> u_view; mvs::DBuf<float> u_cost, u_q;   // the table in the caller's order (built on demand)
@@ -222,6 +224,7 @@ struct mvs_ctx {
     mvs::DBuf<uint32_t> m_sel, m_sel2, m_cand; mvs::DBuf<float> m_gain;
     mvs::DBuf<uint32_t> m_lab; mvs::DBuf<float> m_cost;
     uint32_t m_stride = 0;      // F + 1: offset of the second buffer
+    bool exact_valid = false; uint32_t exact_nb = 0, exact_ne = 0;   // b_sel / b_cost of nodes [exact_nb, exact_ne) are derived from b_lab (k_mrf.hip mrf_exact_costs)
     uint32_t* b_sel = nullptr; uint32_t* b_lab = nullptr; float* b_cost = nullptr; bool best_resolved = false;   // the best buffer, once the host knows which one it is (resolve_best)
     mvs::DBuf<unsigned long long> m_energy; mvs::DBuf<uint32_t> m_moved; mvs::DBuf<uint32_t> m_alist; bool icm_dirty_valid = false;   // ICM active set: nodes whose gain the next pass re-evaluates
     uint32_t m_n_adj = 0;      // directed edges of the adjacency given to mrf_setup

@@ -837,7 +837,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     }
     // the mesh in the library's own layout (faces [fb, fb + nf) are POSITIONS of that layout); a table over the whole mesh remembers
     // its order so that it crosses the ABI in the caller's numbering
-    { Prof pr(ctx, "dc_order"); build_scene_order(ctx); }
+    if (!(ctx->order_pinned && ctx->iv)) { Prof pr(ctx, "dc_order"); build_scene_order(ctx); }   // (pinned: a shard owns this layout, see ctx.h)
     // (a face RANGE's table remembers which faces its columns belong to -- t_perm = the range's slice of the order -- but has no inverse:
     //  it leaves as it is, columns in position order, and mvs_ctx_table_order names the faces)
     if (ctx->mesh_ordered) {

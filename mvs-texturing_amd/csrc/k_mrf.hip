@@ -1255,7 +1255,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     stage[0] = 0u; stage[1] = ctx->seq_base;
     MVS_HIP(hipMemcpyAsync(ctx->m_ctl.p, stage, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     MVS_HIP(hipMemsetAsync(ctx->m_hist.p, 0xFF, sizeof(unsigned long long), s));
-    ctx->steps_issued = 0; ctx->icm_dirty_valid = false;   // no synchronisation: the solver's launches queue behind the set-up on the same stream
+    ctx->steps_issued = 0; ctx->icm_dirty_valid = false; ctx->exact_valid = false;   // no synchronisation: the solver's launches queue behind the set-up on the same stream
 }
 
 // the best labeling's buffer, once the host needs it (ICM, final energy, labels): one read-back of the solver state
@@ -1283,7 +1283,7 @@ void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
     hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(1024), 0, s, ctx->m_state.p, ctx->m_hist.p, energy, partial, n_partial, ctx->m_energy.p,
                        ctx->d_ring, ctx->d_seq, (uint32_t)mvs_ctx::RING, ctx->m_ctl.p, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
     MVS_LAUNCH_CHECK();
-    ctx->icm_dirty_valid = false; ctx->best_resolved = false;   // the best labeling may change
+    ctx->icm_dirty_valid = false; ctx->best_resolved = false; ctx->exact_valid = false;   // the best labeling may change
 }
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out) {
     if (step == 0 || step > ctx->steps_issued || step + mvs_ctx::RING <= ctx->steps_issued)
@@ -1441,6 +1441,9 @@ __global__ void mrf_exact_cost_kernel(const uint32_t* __restrict__ col_ptr, cons
 void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     resolve_best(ctx);
     if (ne0 <= nb0) return;
+    // the polish and the region moves keep position / label / unary of the best labeling consistent: derived once per labeling and range
+    if (ctx->exact_valid && ctx->exact_nb == nb0 && ctx->exact_ne == ne0) return;
+    ctx->exact_valid = true; ctx->exact_nb = nb0; ctx->exact_ne = ne0;
     hipLaunchKernelGGL(mrf_exact_cost_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, (const uint32_t*)ctx->b_lab, nb0, ne0, ctx->b_sel, ctx->b_cost);
     MVS_LAUNCH_CHECK();
 }
@@ -1471,7 +1474,7 @@ void mrf_sweep_energy_reduce(mvs_ctx* ctx) {
 
 // best labeling := the current decode (an index flip on the device)
 void mrf_keep_best(mvs_ctx* ctx) {
-    ctx->icm_dirty_valid = false; ctx->best_resolved = false;
+    ctx->icm_dirty_valid = false; ctx->best_resolved = false; ctx->exact_valid = false;
     if (!ctx->m_state.p) throw StatusError(MVS_ERR_STATE, "mrf setup first");
     hipLaunchKernelGGL(mrf_flip_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->m_state.p);
     MVS_LAUNCH_CHECK();

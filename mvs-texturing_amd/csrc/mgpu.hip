@@ -188,7 +188,7 @@ mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx, uint
 mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx, uint64_t n, const void* src) {
     if (!ctx || (n && (!idx || !src))) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
-    if (n) ctx->icm_dirty_valid = false;   // labels changed behind the ICM active set
+    if (n) { ctx->icm_dirty_valid = false; ctx->exact_valid = false; }   // labels changed behind the ICM active set
     if (n && which == MVS_MRF_MSG_LAB) {
         hipLaunchKernelGGL(scatter2_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, mrf_msg(ctx), ctx->m_lab.p, ctx->m_state.p, ctx->m_stride, idx, n, (const uint32_t*)src);
         MVS_LAUNCH_CHECK();

@@ -941,6 +941,9 @@ mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_b
         MVS_HIP(hipStreamSynchronize(ctx->stream));
         S->d_adj_ptr = S->own_adj_ptr.p; S->d_adj = S->own_adj.p;
     } else { S->d_adj_ptr = adj_ptr_device; S->d_adj = adj_device; }   // option "face_order" = 0: the caller's numbering is the order
+    // The shard IS this layout (parts, renumbered lists, later the halo plan): the context keeps it for the shard's data-cost passes
+    // instead of deriving the same order from the same mesh in every step; mvs_scene_set_mesh (another mesh) un-pins it.
+    ctx->order_pinned = true;
     *out = S.release();
     MVS_API_END
 }
@@ -967,6 +970,7 @@ void mvs_shard_destroy(mvs_shard* shard) {
     if (!shard) return;
     // the context's active table may point into this shard's buffers (mvs_shard_data_costs): no dangling pointers behind
     mvs_ctx* ctx = shard->ctx;
+    if (ctx) ctx->order_pinned = false;
     if (ctx && (ctx->r_ptr == shard->t_ptr.p || ctx->r_view == shard->t_view.p || ctx->r_cost == shard->t_cost.p)) {
         (void)hipStreamSynchronize(ctx->stream);
         ctx->have_costs = false; ctx->dc_phase = 0; ctx->csr_q_valid = false;
