@@ -269,20 +269,16 @@ mvs_status mvs_scene_set_face_range(mvs_ctx* ctx, uint32_t begin, uint32_t end);
 /* tex::calculate_data_costs on the resident scene; result stays on the device. */
 mvs_status mvs_ctx_data_costs(mvs_ctx* ctx, const mvs_settings* settings, mvs_dc_stats* stats);
 /* The same, split at the global barrier of postprocess_face_infos
- * (calculate_data_costs.cpp:278-288) so that a multi-GPU driver can all-reduce
- * the maximum quality and the 10000-bin histogram between the phases:
+ * (calculate_data_costs.cpp:278-288): csrc/shard.hip all-reduces the maximum quality and the
+ * 10000-bin histogram between the phases (a driver of its own reaches the two buffers through
+ * include/mvs_viewsel_blocks.h):
  *   phase1: everything up to the per-face sorted infos + local max quality
  *   phase2: histogram of local qualities against the (global) max
  *   phase3: percentile from the (globally summed) histogram + cost write   */
 mvs_status mvs_ctx_dc_phase1(mvs_ctx* ctx, const mvs_settings* settings);
-/* copy the local max quality (1 float) to / from a caller-owned DEVICE buffer, stream-ordered */
-mvs_status mvs_ctx_dc_get_max(mvs_ctx* ctx, float* dst_device);
-mvs_status mvs_ctx_dc_set_max(mvs_ctx* ctx, const float* src_device);
 mvs_status mvs_ctx_dc_phase2(mvs_ctx* ctx);
-/* the same for the histogram: MVS_HIST_WORDS u32 = 10000 bins + [10000] = number of values */
+/* the histogram travels as MVS_HIST_WORDS u32 = 10000 bins + [10000] = number of values */
 #define MVS_HIST_WORDS 10001
-mvs_status mvs_ctx_dc_get_histogram(mvs_ctx* ctx, uint32_t* dst_device);
-mvs_status mvs_ctx_dc_set_histogram(mvs_ctx* ctx, const uint32_t* src_device);
 mvs_status mvs_ctx_dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
 
 /* device-resident result of the last data-cost call AS THE LIBRARY KEEPS IT: column p is the face at position p of the library's
@@ -329,11 +325,6 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
                                   int adj_on_device, const mvs_mrf_params* params,
                                   uint32_t* labels_out, int labels_on_device, mvs_mrf_stats* stats);
 
-/* copy the resident costs into caller-owned DEVICE arrays (stream-ordered):
- * counts[n_faces] = column lengths, view_id[nnz], cost[nnz] -- the pieces a multi-GPU
- * driver all-gathers into the global table */
-mvs_status mvs_ctx_costs_export(mvs_ctx* ctx, uint32_t* counts_device, uint16_t* view_id_device, float* cost_device);
-
 /* solver progress as tracked on the device (mvs_ctx_mrf_step) */
 typedef struct mvs_mrf_progress {
     uint32_t sweep;        /* sweeps accounted so far (stops counting once `stopped`) */
@@ -348,68 +339,20 @@ typedef struct mvs_mrf_progress {
     uint32_t best_w;       /* decode buffer holding the best labeling so far: "keep the best" flips the two indices, nothing is copied */
 } mvs_mrf_progress;
 
-/* ---- multi-GPU MRF building blocks (one context per rank; DESIGN.md "Multi-GPU") ----
- * Every rank holds the FULL cost table and adjacency (288 GB of HBM make the
- * metadata cheap to replicate) and owns a contiguous node range.  The sweep is
- * colour-phased: within a phase a node's update depends only on nodes of other colours, which are
- * exchanged before their next use: results are bit-identical for any partition.  One sweep on rank r:
- *   for every colour phase: mrf_sweep_phase(own range) -> mrf_gather(MSG | LAB, boundary index lists) ->
- *   RCCL all-to-all by the driver -> mrf_scatter;  then mrf_energy(own range) ->
- *   all-reduce of the two u64 -> mrf_step.  The index lists are planned on the host from
- * col_ptr + adjacency alone (mvs-texturing_amd/multigpu.py). */
-/* solver arrays addressable by the halo exchange: messages, decoded labels (view + 1) of the current
- * sweep, ICM gains, labels of the best labeling so far */
-/* message element index of the first real run: elements [0, MVS_MRF_MSG_BASE) of the message arrays are a reserved
- * all-zero run (and of the map array the identity), see k_mrf.hip; halo index lists start from here */
+/* message element index of the first real run: elements [0, MVS_MRF_MSG_BASE) of the solver's message array are a reserved all-zero
+ * run (k_mrf.hip): halo index lists start from here */
 #define MVS_MRF_MSG_BASE 256u
-enum { MVS_MRF_MSG = 0, MVS_MRF_LAB = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_LAB = 3,
-       /* combined addressing for one exchange per sweep: index < 2^31 -> MSG[index], else LAB[index & 0x7FFFFFFF] */
-       MVS_MRF_MSG_LAB = 4 };
-mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
-                             const mvs_mrf_params* params);
-/* The sweep is colour-phased Gauss-Seidel: the adjacency graph is coloured at setup (n_phases colours, each an
- * independent set) and one sweep = for phase in 0 .. n_phases-1: the nodes of that colour recompute their outgoing
- * messages in place.  A sharded driver runs the phases itself and exchanges the halo after each one. */
+/* The sweep is colour-phased Gauss-Seidel: the adjacency graph is coloured at set-up (n_phases colours, each an independent set) and
+ * one sweep = for phase in 0 .. n_phases - 1: the nodes of that colour recompute their outgoing messages in place. */
 mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases);
 /* diagnostics of the last mvs_ctx_view_selection calls of this context: out[0] = hipGraph launches of the sweep loop (two sweeps each;
  * option "mrf_graph", default 1), out[1] = re-captures pushed into the executable graph with hipGraphExecUpdate, out[2] = graph
  * instantiations, out[3] = nodes the sweep routes to the generic kernel (degree > 3 or a column of > 255 labels at or next to the node) */
 mvs_status mvs_ctx_mrf_diagnostics(mvs_ctx* ctx, uint32_t out[4]);
-/* NOTE: once the device-side stop rule has fired (mvs_mrf_progress.stopped, set by mvs_ctx_mrf_step) every later sweep / sweep phase
- * ends at its first instruction -- it changes no message, no decode and no energy partial: the best labeling is frozen.  A driver that
- * wants more sweeps than the rule allows raises max_sweeps / min_sweeps in the params of mvs_ctx_mrf_setup instead. */
-mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t node_begin, uint32_t node_end);
-/* all phases in turn over nodes [node_begin, node_end) (no exchange in between: unsharded use) */
-mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
-/* message layout for the halo planner: in_off_host[e] = first message element of the run of directed edge e
- * (adjacency-list order, e < adj_ptr[n_faces]); runs are laid out in (colour, face id) node order */
-mvs_status mvs_ctx_mrf_layout(mvs_ctx* ctx, uint32_t* in_off_host, uint64_t n_edges);
-/* dst[k] = array[idx[k]] / array[idx[k]] = src[k] in 4-byte exchange words (message elements are 8-bit codes and travel
- * zero-extended); MSG = the buffer the last sweep wrote */
-mvs_status mvs_ctx_mrf_gather(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, void* dst_device);
-mvs_status mvs_ctx_mrf_scatter(mvs_ctx* ctx, int which, const uint32_t* idx_device, uint64_t n, const void* src_device);
-/* partial energy (32.32 fixed point) + cut count of labeling LAB or BEST_LAB over own nodes -> dst_device[2] */
-mvs_status mvs_ctx_mrf_energy(mvs_ctx* ctx, int which_sel, uint32_t node_begin, uint32_t node_end, uint64_t* dst_device);
-/* best labeling := current decode (call on every rank when the all-reduced energy improved) */
-mvs_status mvs_ctx_mrf_keep_best(mvs_ctx* ctx);
-/* Device-side bookkeeping of one sweep, so that the host never has to wait for a sweep's energy before it
- * enqueues the next one: given the (all-reduced) energy pair in energy_device (NULL = the context's own energy of
- * the last mvs_ctx_mrf_energy), a one-thread kernel advances the sweep counter, tracks the best energy, applies
- * the stop rule (StopWhenReturnsDiminish-style, view_selection.cpp:84) and, if the energy improved, a second kernel
- * copies the current decode into the best labeling.  Once the rule has fired every later step is a no-op, so the
- * host may run `lag` sweeps ahead and poll old reports.  The report of step n (1-based count of mvs_ctx_mrf_step
- * calls since mvs_ctx_mrf_setup) travels through a pinned ring of 16 slots. */
-mvs_status mvs_ctx_mrf_step(mvs_ctx* ctx, const uint64_t* energy_device);
-/* wait for the report of step `step` (must be within the last 16 issued) */
-mvs_status mvs_ctx_mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
-/* ICM on the best labeling: gains of own nodes; then (after the GAIN halo exchange) apply in place */
-mvs_status mvs_ctx_mrf_icm_gain(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
-mvs_status mvs_ctx_mrf_icm_apply(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* moved_device);
-/* labels (view_selection.cpp:120-132) of own nodes of the best labeling into labels_device[node_end - node_begin]: nodes are COLUMNS
- * of the active table, i.e. positions of the library's face order after mvs_ctx_data_costs (mvs_ctx_table_order names the caller's
- * ids), the caller's ids after mvs_ctx_costs_upload or with option "face_order" = 0; mvs_ctx_view_selection returns the caller's ids */
-mvs_status mvs_ctx_mrf_labels(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end, uint32_t* labels_device,
-                              uint32_t* unseen_out);
+/* The sharded path -- the product's only multi-GPU driver -- is mvs_comm_* / mvs_shard_* below (csrc/shard.hip).  The per-phase
+ * BUILDING BLOCKS a driver of its own would be made of (sweep one colour phase of a node range, gather / scatter halo elements,
+ * step, poll, ICM gain / apply, ...) are declared in include/mvs_viewsel_blocks.h and live in a library of their own,
+ * libmvs_blocks.so: the harness of the CPU multi-process tests (mvs-texturing_amd/multigpu.py) is built on them. */
 
 
 /* row f3 on a context: inputs host or device (flags); with out_on_device the three arrays of `out` are device

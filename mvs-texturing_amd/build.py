@@ -1,6 +1,7 @@
 """Build the native code of this repository (in-tree, gfx950 only).
 
   csrc/*.hip          -> csrc/libmvs_viewsel.so   (hipcc --offload-arch=gfx950; the product)
+  csrc/mgpu.hip       -> csrc/libmvs_blocks.so    (building blocks of include/mvs_viewsel_blocks.h: the test harness's library, links the product)
   csrc/scene_synth.cpp-> csrc/libmvs_synth.so     (g++; synthetic input producer)
   csrc/dmath_host.cpp -> csrc/libmvs_dmath_host.so(g++; CPU build of dmath.h for the arithmetic unit test)
 
@@ -14,7 +15,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_SOURCES = ["scan.hip", "k_prep.hip", "k_bvh.hip", "k_dc.hip", "k_mrf.hip", "k_region.hip", "k_mesh.hip", "k_patch.hip", "k_order.hip", "mgpu.hip", "shard.hip", "api.hip"]
+HIP_SOURCES = ["scan.hip", "k_prep.hip", "k_bvh.hip", "k_dc.hip", "k_mrf.hip", "k_region.hip", "k_mesh.hip", "k_patch.hip", "k_order.hip", "shard.hip", "api.hip"]
+BLOCKS_SOURCES = ["mgpu.hip"]                       # NOT in the product library
+BLOCKS_LIB = os.path.join(CSRC, "libmvs_blocks.so")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
              "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # per-file additions: the SLP vectoriser packs the ray / triangle arithmetic into v_pk_* operations at the price of ~50
@@ -37,12 +40,12 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
-    headers = [os.path.join(CSRC, h) for h in ("ctx.h", "dmath.h")] + [os.path.join(HERE, "..", "include", "mvs_viewsel.h")]
-    objs, jobs = [], []
-    for src in HIP_SOURCES:
+    headers = [os.path.join(CSRC, h) for h in ("ctx.h", "dmath.h")] + [os.path.join(HERE, "..", "include", h) for h in ("mvs_viewsel.h", "mvs_viewsel_blocks.h")]
+    objs, bobjs, jobs = [], [], []
+    for src in HIP_SOURCES + BLOCKS_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
-        objs.append(o)
+        (bobjs if src in BLOCKS_SOURCES else objs).append(o)
         if force or _newer(o, [s, os.path.abspath(__file__)] + headers):
             jobs.append([_hipcc()] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
@@ -55,6 +58,8 @@ def build_hip(force=False, verbose=False):
         list(ex.map(run, jobs))
     if jobs or force or _newer(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    if jobs or force or _newer(BLOCKS_LIB, bobjs + [LIB]):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", BLOCKS_LIB] + bobjs + ["-L" + CSRC, "-lmvs_viewsel", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

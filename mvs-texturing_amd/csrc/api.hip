@@ -1044,6 +1044,18 @@ mvs_status mvs_write_labeling_vec(const uint32_t* labels, uint32_t n_faces, cons
     return ok ? MVS_OK : fail(MVS_ERR_INVALID, std::string("write error on ") + path);
 }
 
-// ---------------- multi-GPU MRF building blocks: see mgpu.hip ----------------
+/* colour phases of the solver's schedule / diagnostics of the last solves of this context (mvs_viewsel.h) */
+mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases) {
+    if (!ctx || !n_phases) return fail(MVS_ERR_INVALID, "null argument");
+    *n_phases = ctx->m_colours;
+    return MVS_OK;
+}
+mvs_status mvs_ctx_mrf_diagnostics(mvs_ctx* ctx, uint32_t out[4]) {
+    if (!ctx || !out) return fail(MVS_ERR_INVALID, "null argument");
+    out[0] = ctx->graph_launches; out[1] = ctx->graph_updates; out[2] = ctx->graph_instantiations; out[3] = ctx->csr_faces - ctx->m_n_fast;
+    return MVS_OK;
+}
+
+// ---------------- per-phase building blocks of a sharded driver: a library of their own (mgpu.hip -> libmvs_blocks.so) ----------------
 
 }  // extern "C"

@@ -1,9 +1,9 @@
-// mgpu.hip -- multi-GPU building blocks of the C ABI (include/mvs_viewsel.h,
-// "multi-GPU MRF building blocks" and the data-cost reduce hooks).  The RCCL
-// calls themselves are issued by the driver (mvs-texturing_amd/multigpu.py)
-// on caller-owned device buffers; these entry points only move data between
-// those buffers and the solver's arrays and run the per-range kernels.
+// mgpu.hip -- libmvs_blocks.so: the building blocks of include/mvs_viewsel_blocks.h (per-phase sweeps of a node range, gather /
+// scatter of halo elements, the data-cost reduce hooks).  NOT in the product library: the product's sharded driver is csrc/shard.hip.
+// The collectives themselves are issued by whoever drives these blocks (the test harness mvs-texturing_amd/multigpu.py) on its own
+// device buffers; these entry points only move data between those buffers and the solver's arrays and run the per-range kernels.
 #include "ctx.h"
+#include "../../include/mvs_viewsel_blocks.h"
 #include <vector>
 
 namespace mvs {
@@ -142,16 +142,6 @@ mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     MVS_API_END
 }
 
-mvs_status mvs_ctx_mrf_num_phases(mvs_ctx* ctx, uint32_t* n_phases) {
-    if (!ctx || !n_phases) return api_fail(MVS_ERR_INVALID, "null argument");
-    *n_phases = ctx->m_colours;
-    return MVS_OK;
-}
-mvs_status mvs_ctx_mrf_diagnostics(mvs_ctx* ctx, uint32_t out[4]) {
-    if (!ctx || !out) return api_fail(MVS_ERR_INVALID, "null argument");
-    out[0] = ctx->graph_launches; out[1] = ctx->graph_updates; out[2] = ctx->graph_instantiations; out[3] = ctx->csr_faces - ctx->m_n_fast;
-    return MVS_OK;
-}
 mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
     if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces || phase >= ctx->m_colours) return api_fail(MVS_ERR_INVALID, "bad phase or node range");
     MVS_API_BEGIN

@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_VIEWSEL_LIB: another build of the same library (A/B experiments on one GPU box: scripts/variants.sh)
 _LIB_PATH = os.environ.get("MVS_VIEWSEL_LIB") or os.path.join(_HERE, "csrc", "libmvs_viewsel.so")
+_BLOCKS_PATH = os.path.join(_HERE, "csrc", "libmvs_blocks.so")
 
 
 class MvsError(RuntimeError):
@@ -85,6 +86,18 @@ def lib_path():
     return _LIB_PATH
 
 
+def blocks_lib_path():
+    return _BLOCKS_PATH
+
+
+# entry points of include/mvs_viewsel_blocks.h (libmvs_blocks.so), everything else is the product library's
+BLOCK_SYMBOLS = frozenset((
+    "mvs_ctx_dc_get_max", "mvs_ctx_dc_set_max", "mvs_ctx_dc_get_histogram", "mvs_ctx_dc_set_histogram", "mvs_ctx_costs_export",
+    "mvs_ctx_mrf_setup", "mvs_ctx_mrf_sweep", "mvs_ctx_mrf_sweep_phase", "mvs_ctx_mrf_layout", "mvs_ctx_mrf_gather", "mvs_ctx_mrf_scatter",
+    "mvs_ctx_mrf_energy", "mvs_ctx_mrf_keep_best", "mvs_ctx_mrf_step", "mvs_ctx_mrf_poll", "mvs_ctx_mrf_icm_gain", "mvs_ctx_mrf_icm_apply",
+    "mvs_ctx_mrf_labels"))
+
+
 _lib = None
 
 
@@ -153,12 +166,30 @@ def load_library():
         "mvs_data_costs_stream": [C.POINTER(CMesh), C.POINTER(CView), u32, C.POINTER(Settings), vp, vp, C.POINTER(CCsr), C.POINTER(DcStats)],
         "mvs_view_selection_cached": [u64, u32, u32, u64, vp, vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
     }
+    # The per-phase building blocks (include/mvs_viewsel_blocks.h) live in a library of their own, libmvs_blocks.so -- the harness of
+    # the CPU multi-process tests (multigpu.py) and a few measuring scripts use them, the product does not.  Their entry points are
+    # attached to the same handle; without that library (a variant build, a product-only install) they are simply absent.
+    blocks = None
+    if os.path.exists(_BLOCKS_PATH):
+        try:
+            blocks = C.CDLL(_BLOCKS_PATH, mode=C.RTLD_GLOBAL)
+        except OSError:
+            blocks = None
+    L._blocks_declared = []
     for name, argtypes in sig.items():
-        fn = getattr(L, name)
+        if name in BLOCK_SYMBOLS:
+            if blocks is None:
+                continue
+            fn = getattr(blocks, name)
+            setattr(L, name, fn)
+            L._blocks_declared.append(name)
+        else:
+            fn = getattr(L, name)
         fn.argtypes = argtypes
         if name not in ("mvs_mrf_default_params", "mvs_default_settings", "mvs_csr_free", "mvs_subgraphs_free", "mvs_ctx_destroy", "mvs_comm_destroy", "mvs_comm_abort", "mvs_shard_destroy"):
             fn.restype = C.c_int
-    L._declared = sorted(list(sig.keys()) + ["mvs_last_error", "mvs_status_string"])
+    L._declared = sorted([k for k in sig.keys() if k not in BLOCK_SYMBOLS] + ["mvs_last_error", "mvs_status_string"])
+    L._blocks = blocks
     _lib = L
     return L
 

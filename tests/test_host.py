@@ -22,13 +22,26 @@ def _lib_or_skip():
 
 
 def test_header_symbols_exported():
+    """every symbol include/mvs_viewsel.h declares is exported by the PRODUCT library, every symbol of include/mvs_viewsel_blocks.h by
+    libmvs_blocks.so -- and by that library only: the per-phase building blocks (the test harness's API) are not part of the product"""
+    import ctypes as C
     L = _lib_or_skip()
+    product = C.CDLL(M.lib_path())      # a plain handle: the binding's own handle has the blocks attached
     header = open(os.path.join(ROOT, "include", "mvs_viewsel.h")).read()
     declared = sorted(set(re.findall(r"\b(mvs_[a-z0-9_]+)\s*\(", header)) - {"mvs_fp_mix"})   # (a static inline of the header, not an export)
     assert len(declared) >= 35
     for name in declared:
-        assert hasattr(L, name), "missing export " + name
+        assert hasattr(product, name), "missing export " + name
     assert set(L._declared) <= set(declared)
+    bheader = open(os.path.join(ROOT, "include", "mvs_viewsel_blocks.h")).read()
+    bdeclared = sorted(set(re.findall(r"\b(mvs_[a-z0-9_]+)\s*\(", bheader)))
+    assert set(bdeclared) == set(M.viewsel.BLOCK_SYMBOLS) and not (set(bdeclared) & set(declared))
+    assert os.path.exists(M.viewsel.blocks_lib_path()), "libmvs_blocks.so not built"
+    blocks = C.CDLL(M.viewsel.blocks_lib_path())
+    for name in bdeclared:
+        assert hasattr(blocks, name), "missing export " + name
+        assert not hasattr(product, name), "the product library exports the building block " + name
+    assert sorted(L._blocks_declared) == bdeclared
 
 
 def test_no_gpu_means_loud_failure():
