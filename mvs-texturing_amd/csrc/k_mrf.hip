@@ -394,21 +394,27 @@ __device__ __forceinline__ uint32_t label_position(const uint16_t* __restrict__ 
 
 // ident[e] = 1 iff the two label lists of the (valid) directed edge e are identical; 16 lanes per node.  The kernel is a chain
 // of dependent gathers (edge -> neighbour -> its column -> its view ids), so three edges are in flight at a time.
+// "Identical lists" is symmetric: of a clean pair of fast nodes (each the other's reverse edge) only the node with the SMALLER id compares
+// the lists and writes the flag of both directed edges -- half the gathers.
 __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
                                                         const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ cls,
-                                                        uint8_t* __restrict__ ident) {
+                                                        const uint32_t* __restrict__ rev, uint8_t* __restrict__ ident) {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
     if (i >= F || cls[i] == CLS_GENERIC) return;               // only fast nodes have records
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
     for (uint32_t e = e0; e < e1; e += 3) {
-        uint32_t kj[3], q0[3];
+        uint32_t kj[3], q0[3], twin[3];   // twin: the reverse edge whose flag this node writes as well (0xFFFFFFFF: none)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const bool on = e + k < e1;
-            kj[k] = on ? edge[e + k].kj : 0u;
-            q0[k] = col_ptr[on ? adj[e + k] : i];
+            const uint32_t j = on ? adj[e + k] : i;
+            const uint32_t r = on ? rev[e + k] : 0xFFFFFFFFu;
+            const bool pair = on && r != 0xFFFFFFFFu && j != i && cls[j] != CLS_GENERIC && rev[r] == e + k;   // a clean pair of fast nodes
+            kj[k] = (on && !(pair && j < i)) ? edge[e + k].kj : 0u;      // the smaller id of a pair does the work
+            twin[k] = (pair && i < j) ? r : 0xFFFFFFFFu;
+            q0[k] = col_ptr[j];
         }
         uint32_t same = 0;   // bit k: edge e + k still looks identical
 #pragma unroll
@@ -422,7 +428,11 @@ __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restri
             }
             for (int o = 8; o > 0; o >>= 1) same &= __shfl_xor(same, o, 16);
         }
-        if (gl < 3 && e + gl < e1 && kj[gl] != 0u) ident[e + gl] = (uint8_t)((same >> gl) & 1u);
+        if (gl < 3 && e + gl < e1 && kj[gl] != 0u) {
+            const uint8_t f = (uint8_t)((same >> gl) & 1u);
+            ident[e + gl] = f;
+            if (twin[gl] != 0xFFFFFFFFu) ident[twin[gl]] = f;
+        }
     }
 }
 // rsz[q] = words of the record of node perm[q] (rsz[F] = 0)
@@ -560,6 +570,11 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // led to the label-only decode of the product kernel and are gone.)
 #define MVS_PROBE_PAIR (MVS_SWEEP_EXP == 5 || MVS_SWEEP_EXP == 6)
 #define MVS_PROBE_PAIR_ST (MVS_SWEEP_EXP == 6)
+// 9 = the three map words of a lane in ONE 16-byte load (a record interleaved per lane: label words, then map words -- 2 instead of 4
+// loads of the record, at +150 B per node because identical-list edges would carry explicit maps); 10 = the three neighbour labels
+// fetched by lanes 0 .. 2 of the group with ONE load instruction (access pattern only: garbage results)
+#define MVS_PROBE_MAP16 (MVS_SWEEP_EXP == 9 || MVS_SWEEP_EXP == 11)
+#define MVS_PROBE_NL1 (MVS_SWEEP_EXP == 10 || MVS_SWEEP_EXP == 11)
 #ifndef MVS_SWEEP_EXP
 #define MVS_SWEEP_EXP 0
 #endif
@@ -633,6 +648,12 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
         const uint32_t K = d.kk & 0xFFu, recb = 4u * d.rec;
         if (MVS_SWEEP_DROP & 4) r.lw = make_uint4(recb, K, 0u, 0u); else r.lw = ld_off<uint4>(rec, MVS_XO(recb + t0b));
         uint32_t mposb = recb + 4u * ((K + 3u) & ~3u) + glb;
+#if MVS_PROBE_MAP16
+        { const uint4 mm = ld_off<uint4>(rec, recb + 4u * ((K + 3u) & ~3u) + 4u * glb); r.map[0] = mm.x; r.map[1] = mm.y; r.map[2] = mm.z ^ mm.w; }
+#endif
+#if MVS_PROBE_NL1
+        { const uint32_t nb1 = gl == 0 ? d.nbr[0] : gl == 1 ? d.nbr[1] : d.nbr[2]; uint32_t v = 0u; if (gl < 3) v = ld_off<uint32_t>(lab, 4u * nb1); r.nl[0] = v; r.nl[1] = v + 1u; r.nl[2] = v + 2u; }
+#endif
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
 #if MVS_PROBE_PAIR
@@ -640,9 +661,13 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
 #else
             if (MVS_SWEEP_DROP & 2) r.in[e] = d.in_off[e]; else r.in[e] = ld_off<uint32_t>(mo, MVS_XO((d.in_off[e] & ~3u) + t0));
 #endif
+#if !MVS_PROBE_MAP16
             if (MVS_SWEEP_DROP & 4) r.map[e] = mposb; else r.map[e] = ld_off<uint32_t>(rec, MVS_XO(mposb));
+#endif
             if (!(d.out_off[e] & 1u)) mposb += (((d.kk >> (8 + 8 * e)) & 0xFFu) + 3u) & ~3u;   // 4 bytes per 4 map entries
+#if !MVS_PROBE_NL1
             if (MVS_SWEEP_DROP & 1) r.nl[e] = d.nbr[e]; else r.nl[e] = ld_off<uint32_t>(lab, MVS_XO(4u * d.nbr[e]));     // an absent neighbour is recorded as the node itself
+#endif
 #if !MVS_PROBE_PAIR
             if (DAMP && !(MVS_SWEEP_DROP & 16)) r.old[e] = ld_off<uint32_t>(mo, MVS_XO((d.out_off[e] & ~3u) + t0)); else r.old[e] = d.out_off[e];
 #endif
@@ -1201,7 +1226,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + 1024;   // incl. slack for reads past the last record
         ctx->m_rec.ensure(rec_cap);
         MVS_HIP(hipMemsetAsync(ctx->m_rec.p, 0, REC_BASE * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_cls.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_cls.p, (const uint32_t*)ctx->m_rev.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
         uint32_t* rsz = ctx->m_tmp_a.p; uint32_t* roff = ctx->m_tmp_b.p;   // F + 1 entries each
         hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_perm.p, F, rsz, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, rsz, roff, (size_t)F + 1, nullptr);

@@ -97,6 +97,7 @@ struct mvs_comm {
     virtual void fail() {}
     virtual bool aborted() const { return false; }
     virtual void abort_all() {}          // the caller gives this communicator up (mvs_comm_abort): every rank's waits end with an error, for good
+    virtual int device() const { return -1; }   // the device this rank's context has to live on (-1: any -- the communicator does not care)
     // non-null: the ranks of this communicator can store into each other's device memory (see PeerHub); barrier() = host rendezvous
     virtual PeerHub* peers() { return nullptr; }
     virtual void barrier() {}
@@ -243,6 +244,7 @@ struct LocalComm : mvs_comm {
     void fail() override { hub->failed_call.store(call_no, std::memory_order_release); hub->cv.notify_all(); }
     bool aborted() const override { return hub->abandoned(call_no); }
     void abort_all() override { hub->dead.store(true, std::memory_order_release); hub->cv.notify_all(); }
+    int device() const override { return hub->device[rank]; }
     void rendezvous_copy(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
                          const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {
         LocalHub& H = *hub;
@@ -920,6 +922,9 @@ mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_b
     MVS_API_BEGIN
     MVS_HIP(hipSetDevice(ctx->device));
     if (!ctx->d_verts || !ctx->d_faces) throw StatusError(MVS_ERR_STATE, "the context needs the full mesh (mvs_scene_set_mesh) before a shard is made of it");
+    // peers store into this rank's arrays through the peer access the communicator set up between ITS devices
+    if (comm->device() >= 0 && comm->device() != ctx->device)
+        throw StatusError(MVS_ERR_INVALID, "rank " + std::to_string(comm->rank) + " of this communicator drives device " + std::to_string(comm->device()) + ", the context lives on device " + std::to_string(ctx->device));
     std::unique_ptr<mvs_shard> S(new mvs_shard); S->ctx = ctx; S->comm = comm; S->me = comm->rank; S->P = comm->world;
     S->parts.n = S->P;
     S->F = ctx->n_faces;
