@@ -595,15 +595,19 @@ def main():
     args.config = int(args.config) if args.config.isdigit() else args.config
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.launch == "torchrun":
+    def exec_torchrun():
         # one process per GPU over RCCL: the launcher the driver would use, started from here
         import socket
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        rest = [a for a in sys.argv[1:]]
         argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
-                os.path.abspath(__file__)] + sys.argv[1:]
+                os.path.abspath(__file__)] + rest
         log("re-executing:", " ".join(argv))
+        sys.stdout.flush(); sys.stderr.flush()
         os.execv(sys.executable, argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.launch == "torchrun":
+        exec_torchrun()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" in os.environ and world != args.gpus:
@@ -637,7 +641,15 @@ def main():
             max_labels = 64
     max_labels = max(max_labels, 0)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return run_inproc(args, cfg, max_labels)     # --gpus N without a launcher: N in-process ranks, one per GPU
+        # --gpus N without a launcher: N in-process ranks, one per GPU.  Should that route fail to come up on this node (no peer access,
+        # a runtime that refuses it) the run is not lost: it starts again as one process per GPU over RCCL.  A parity failure is final.
+        try:
+            return run_inproc(args, cfg, max_labels)
+        except SystemExit as e:
+            if e.code == 3 or os.environ.get("MVS_BENCH_ONE_GPU") or os.environ.get("MVS_BENCH_NO_FALLBACK"):
+                raise
+            log("in-process ranks failed (%r): falling back to one process per GPU (torch.distributed.run, RCCL)" % (e.code,))
+            exec_torchrun()
     t0 = time.time()
     scene = M.synth.make_scene(**cfg)
     if args.shuffle_main:

@@ -394,27 +394,23 @@ __device__ __forceinline__ uint32_t label_position(const uint16_t* __restrict__ 
 
 // ident[e] = 1 iff the two label lists of the (valid) directed edge e are identical; 16 lanes per node.  The kernel is a chain
 // of dependent gathers (edge -> neighbour -> its column -> its view ids), so three edges are in flight at a time.
-// "Identical lists" is symmetric: of a clean pair of fast nodes (each the other's reverse edge) only the node with the SMALLER id compares
-// the lists and writes the flag of both directed edges -- half the gathers.
+// (Round 5 tried the symmetry -- of a pair only the node with the smaller id compares the lists and writes both flags: half the list
+// gathers, but three more dependent look-ups per edge in front of them: 0.375 -> 0.52 ms.  Reverted.)
 __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const uint32_t* __restrict__ adj_ptr,
                                                         const uint32_t* __restrict__ adj, uint32_t F, const MrfEdge* __restrict__ edge, const uint8_t* __restrict__ cls,
-                                                        const uint32_t* __restrict__ rev, uint8_t* __restrict__ ident) {
+                                                        uint8_t* __restrict__ ident) {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
     if (i >= F || cls[i] == CLS_GENERIC) return;               // only fast nodes have records
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0;
     const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
     for (uint32_t e = e0; e < e1; e += 3) {
-        uint32_t kj[3], q0[3], twin[3];   // twin: the reverse edge whose flag this node writes as well (0xFFFFFFFF: none)
+        uint32_t kj[3], q0[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const bool on = e + k < e1;
-            const uint32_t j = on ? adj[e + k] : i;
-            const uint32_t r = on ? rev[e + k] : 0xFFFFFFFFu;
-            const bool pair = on && r != 0xFFFFFFFFu && j != i && cls[j] != CLS_GENERIC && rev[r] == e + k;   // a clean pair of fast nodes
-            kj[k] = (on && !(pair && j < i)) ? edge[e + k].kj : 0u;      // the smaller id of a pair does the work
-            twin[k] = (pair && i < j) ? r : 0xFFFFFFFFu;
-            q0[k] = col_ptr[j];
+            kj[k] = on ? edge[e + k].kj : 0u;
+            q0[k] = col_ptr[on ? adj[e + k] : i];
         }
         uint32_t same = 0;   // bit k: edge e + k still looks identical
 #pragma unroll
@@ -428,11 +424,7 @@ __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restri
             }
             for (int o = 8; o > 0; o >>= 1) same &= __shfl_xor(same, o, 16);
         }
-        if (gl < 3 && e + gl < e1 && kj[gl] != 0u) {
-            const uint8_t f = (uint8_t)((same >> gl) & 1u);
-            ident[e + gl] = f;
-            if (twin[gl] != 0xFFFFFFFFu) ident[twin[gl]] = f;
-        }
+        if (gl < 3 && e + gl < e1 && kj[gl] != 0u) ident[e + gl] = (uint8_t)((same >> gl) & 1u);
     }
 }
 // rsz[q] = words of the record of node perm[q] (rsz[F] = 0)
@@ -1226,7 +1218,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + 1024;   // incl. slack for reads past the last record
         ctx->m_rec.ensure(rec_cap);
         MVS_HIP(hipMemsetAsync(ctx->m_rec.p, 0, REC_BASE * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_cls.p, (const uint32_t*)ctx->m_rev.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_cls.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
         uint32_t* rsz = ctx->m_tmp_a.p; uint32_t* roff = ctx->m_tmp_b.p;   // F + 1 entries each
         hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_perm.p, F, rsz, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, rsz, roff, (size_t)F + 1, nullptr);
