@@ -404,3 +404,42 @@ def test_integer_word_walk_reads_exactly_the_span_pixels():
     fast, bad, px = [int(v) for v in out]
     assert fast > 200000 and px > 20 * fast, (fast, px)
     assert bad == 0, (fast, bad)
+
+
+def test_bench_refuses_a_launcher_whose_world_size_disagrees_with_gpus():
+    """`bench.py --gpus N` under a launcher with another WORLD_SIZE would measure something else than it reports: refused up front (no GPU
+    needed to find out).  Without a launcher --gpus N > 1 starts N in-process ranks itself (GPU test: test_bench_contract_...)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr, r.stderr[-500:]
+    assert r.stdout.strip() == ""      # and no JSON line that a driver could mistake for a measurement
+
+
+def test_drop_in_translation_unit_defines_upstreams_symbols():
+    """integration/view_selection_mi355x.cpp, compiled against the reference's OWN libs/tex/texturing.h (make -C oracle dropin), defines
+    exactly the three tex:: symbols upstream's calculate_data_costs.cpp + view_selection.cpp define -- the same mangled names the
+    reference's library exports (oracle/_ref/libtexref.so), so the rest of libs/tex and apps/texrecon link against either -- and needs
+    nothing from the files it replaces."""
+    import subprocess
+    ref, drop = os.path.join(ROOT, "oracle", "_ref", "libtexref.so"), os.path.join(ROOT, "oracle", "_ref", "libtexdrop.so")
+    if os.path.isdir("/root/reference/libs/tex") and os.path.exists(M.lib_path()):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref", "dropin"])
+    if not (os.path.exists(ref) and os.path.exists(drop)):
+        pytest.skip("oracle/_ref libraries not built (the reference sources are not on this machine)")
+
+    def defined(lib):
+        out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if l.strip()}
+    a, b = defined(ref), defined(drop)
+    want = [x for x in a if x.startswith("_ZN3tex") and any(k in x for k in ("20calculate_data_costs", "22postprocess_face_infos", "14view_selection"))]
+    assert len(want) == 3, want
+    for sym in want:
+        assert sym in b, "the drop-in does not define " + sym
+    # what upstream's two files define beyond the header's three symbols (photometric_outlier_detection, calculate_face_projection_infos)
+    # is internal to them: the replacement has no use for it
+    assert not any("photometric_outlier_detection" in x or "calculate_face_projection_infos" in x for x in b)
+    und = subprocess.run(["nm", "-D", "--undefined-only", drop], capture_output=True, text=True, check=True).stdout
+    for f in ("mvs_data_costs_stream", "mvs_view_selection_cached", "mvs_view_selection", "mvs_postprocess_face_infos"):
+        assert f in und, "the drop-in does not call " + f
