@@ -987,10 +987,11 @@ void mvs_shard_destroy(mvs_shard* shard) {
 /* tex::calculate_data_costs over all ranks (calculate_data_costs.cpp:308-323): afterwards the context holds the cost table
  * of the GLOBAL shape with the own and the halo columns filled */
 mvs_status mvs_shard_data_costs(mvs_shard* S, const mvs_settings* settings, mvs_dc_stats* stats, uint64_t* nnz_global) {
-    if (!S || !settings) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (!S) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
-    S->comm->begin_call();
+    S->comm->begin_call();   // every call is numbered on every rank -- also one that fails its own argument checks below
     try {   // (a failure on this rank ends the other ranks' host-side waits of this call: mvs_comm::fail)
+    if (!settings) throw StatusError(MVS_ERR_INVALID, "null argument");
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
     MVS_HIP(hipSetDevice(ctx->device));
     RoctxRange range("Calculating data costs");   /* texrecon.cpp:118 */
@@ -1094,11 +1095,12 @@ mvs_status mvs_shard_data_costs(mvs_shard* S, const mvs_settings* settings, mvs_
 
 /* tex::view_selection over all ranks (view_selection.cpp:18-133): labels of the own nodes into labels_own_device */
 mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, uint32_t* labels_own_device, mvs_mrf_stats* stats) {
-    if (!S || !labels_own_device) return api_fail(MVS_ERR_INVALID, "null argument");
-    if (!S->ctx->have_costs) return api_fail(MVS_ERR_STATE, "view selection needs data costs (mvs_shard_data_costs)");
+    if (!S) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
     S->comm->begin_call();
     try {
+    if (!labels_own_device) throw StatusError(MVS_ERR_INVALID, "null argument");
+    if (!S->ctx->have_costs) throw StatusError(MVS_ERR_STATE, "view selection needs data costs (mvs_shard_data_costs)");   // (e.g. this rank's data costs failed: its peers are released)
     mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream; mvs_comm* comm = S->comm;
     MVS_HIP(hipSetDevice(ctx->device));
     RoctxRange range("Running MRF optimization");   /* texrecon.cpp:126 */

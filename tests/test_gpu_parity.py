@@ -902,6 +902,8 @@ def test_a_failing_rank_does_not_leave_the_others_blocked():
                 first[r] = "no error"
             except M.MvsError as e:
                 first[r] = (str(e), time.time() - t)
+            with pytest.raises(M.MvsError, match="needs data costs"):   # neither rank has a table now: a call that fails its own checks is
+                sh.view_selection(labels)                               # numbered like any other (the ranks stay in step)
             for push in (1, 0):                                    # the communicator is not poisoned: the next calls run, on either transport
                 c.set_option("shard_peer_push", push)
                 sh.data_costs(M.Settings()); ms = sh.view_selection(labels); c.synchronize()
