@@ -40,7 +40,7 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
-    headers = [os.path.join(CSRC, h) for h in ("ctx.h", "dmath.h")] + [os.path.join(HERE, "..", "include", h) for h in ("mvs_viewsel.h", "mvs_viewsel_blocks.h")]
+    headers = [os.path.join(CSRC, h) for h in ("ctx.h", "dmath.h", "call_barrier.h")] + [os.path.join(HERE, "..", "include", h) for h in ("mvs_viewsel.h", "mvs_viewsel_blocks.h")]
     objs, bobjs, jobs = [], [], []
     for src in HIP_SOURCES + BLOCKS_SOURCES:
         s = os.path.join(CSRC, src)

@@ -20,6 +20,7 @@
 // dependency and shares whatever RCCL the process already loaded, e.g. PyTorch's) and an in-process one for `world` host
 // threads sharing a device (tests on a 1-GPU box: the same planner, pack / unpack kernels and loops, copies instead of xGMI).
 #include "ctx.h"
+#include "call_barrier.h"
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -198,36 +199,12 @@ struct LocalHub {
     int world;
     std::vector<int> device;                 // device of rank r
     bool peer_ok = true;                     // every rank can address every other rank's device memory
-    std::mutex m; std::condition_variable cv; int waiting = 0; uint64_t generation = 0, bar_call = 0 /* the call the ranks now waiting belong to */;
-    std::atomic<uint64_t> failed_call{0};    // number of the call some rank failed in (mvs_comm::call_no), 0 = none
-    std::atomic<uint64_t> max_call{0};       // the latest call any rank has begun
-    std::atomic<bool> dead{false};           // mvs_comm_abort: the communicator was given up
+    CallBarrier calls;                       // the ranks' rendezvous and its failure semantics (call_barrier.h: unit-tested on the CPU)
     std::vector<const uint8_t*> send_a, send_b; std::vector<const uint64_t*> soff_a, soff_b;
     std::vector<hipEvent_t> ready, done;
     PeerHub peer;
-    explicit LocalHub(int w) : world(w), device(w, 0), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w, nullptr), done(w, nullptr), peer(w) {}
+    explicit LocalHub(int w) : world(w), device(w, 0), calls(w), send_a(w), send_b(w), soff_a(w), soff_b(w), ready(w, nullptr), done(w, nullptr), peer(w) {}
     ~LocalHub() { for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e); }
-    // A call is abandoned -- for every rank still inside it -- once a rank failed in it or a rank has begun a later call (it left this
-    // one, with or without an error, and will never come back to it).
-    bool abandoned(uint64_t call_no) const {
-        if (dead.load(std::memory_order_acquire)) return true;
-        return call_no != 0 && (failed_call.load(std::memory_order_acquire) == call_no || max_call.load(std::memory_order_acquire) > call_no);
-    }
-    // A rendezvous of all ranks INSIDE ONE CALL: ranks of an abandoned call give up instead of waiting, and a rank that arrives for a
-    // later call first lets the waiters of the earlier (abandoned) call drain -- it never completes THEIR rendezvous.
-    void barrier(uint64_t call_no) {
-        std::unique_lock<std::mutex> l(m);
-        while (waiting > 0 && bar_call != call_no) {
-            if (bar_call > call_no || abandoned(call_no)) throw HipError("sharded call: another rank failed");
-            cv.wait_for(l, std::chrono::milliseconds(20));
-        }
-        if (abandoned(call_no)) throw HipError("sharded call: another rank failed");
-        bar_call = call_no;
-        const uint64_t g = generation;
-        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); return; }
-        while (!cv.wait_for(l, std::chrono::milliseconds(20), [&] { return generation != g; }))
-            if (abandoned(call_no)) { --waiting; cv.notify_all(); throw HipError("sharded call: another rank failed"); }
-    }
 };
 struct LocalComm : mvs_comm {
     std::shared_ptr<LocalHub> hub;
@@ -235,15 +212,11 @@ struct LocalComm : mvs_comm {
     ~LocalComm() override {}
     bool exchange_is_collective() const override { return true; }
     PeerHub* peers() override { return hub->peer_ok ? &hub->peer : nullptr; }
-    void barrier() override { hub->barrier(call_no); }
-    void begin_call() override {
-        ++call_no;
-        uint64_t seen = hub->max_call.load(std::memory_order_relaxed);
-        while (seen < call_no && !hub->max_call.compare_exchange_weak(seen, call_no, std::memory_order_release)) {}
-    }
-    void fail() override { hub->failed_call.store(call_no, std::memory_order_release); hub->cv.notify_all(); }
-    bool aborted() const override { return hub->abandoned(call_no); }
-    void abort_all() override { hub->dead.store(true, std::memory_order_release); hub->cv.notify_all(); }
+    void barrier() override { hub->calls.arrive(call_no); }
+    void begin_call() override { hub->calls.begin(++call_no); }
+    void fail() override { hub->calls.fail(call_no); }
+    bool aborted() const override { return hub->calls.abandoned(call_no); }
+    void abort_all() override { hub->calls.abort_all(); }
     int device() const override { return hub->device[rank]; }
     void rendezvous_copy(const uint8_t* sa, const uint64_t* soa, uint8_t* ra, const uint64_t* roa,
                          const uint8_t* sb, const uint64_t* sob, uint8_t* rb, const uint64_t* rob, hipStream_t s) {

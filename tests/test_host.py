@@ -443,3 +443,16 @@ def test_drop_in_translation_unit_defines_upstreams_symbols():
     und = subprocess.run(["nm", "-D", "--undefined-only", drop], capture_output=True, text=True, check=True).stdout
     for f in ("mvs_data_costs_stream", "mvs_view_selection_cached", "mvs_view_selection", "mvs_postprocess_face_infos"):
         assert f in und, "the drop-in does not call " + f
+
+
+def test_call_barrier_failure_semantics(tmp_path):
+    """csrc/call_barrier.h -- the rendezvous of the in-process communicator's ranks (shard.hip) -- on the CPU, ranks as threads
+    (tests/cpp/test_call_barrier.cpp): plain rendezvous; a rank that fails inside a call releases the ranks waiting in it; a failing
+    rank that is already waiting in the NEXT call never completes the rendezvous of the failed one; a rank that leaves a call silently
+    abandons it for the others; abort_all ends every wait.  (The GPU suite exercises the same through mvs_shard_*:
+    test_a_failing_rank_does_not_leave_the_others_blocked.)"""
+    import subprocess
+    exe = str(tmp_path / "test_call_barrier")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_call_barrier.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-800:]
