@@ -335,6 +335,7 @@ mvs_status mvs_ctx_create(int device, mvs_ctx** out) {
     // MVS_INFO_WAVE_AREA overrides the default footprint area above which the lane-group sampler takes over (0: every
     // footprint in the reference's serial fp64 order, i.e. bit-exact qualities); mvs_set_option("info_wave_area") still wins
     if (const char* e = getenv("MVS_INFO_WAVE_AREA")) c->info_wave_area = std::max(0, atoi(e));
+    if (const char* e = getenv("MVS_MRF_WIDE")) c->mrf_wide = atoi(e) != 0;   // (A/B of the sweep kernel variants without touching callers)
     c->counters.ensure(64);
     *out = c;
     MVS_API_END
@@ -389,6 +390,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_lag") ctx->mrf_lag = (int)value;
     else if (n == "shard_peer_push") ctx->shard_peer_push = value != 0;
     else if (n == "mrf_force_generic") ctx->mrf_force_generic = value != 0;
+    else if (n == "mrf_wide") ctx->mrf_wide = value != 0;   // takes effect with the next solve's set-up
     else if (n == "mrf_graph") ctx->mrf_graph = value != 0;
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;

@@ -429,8 +429,10 @@ __global__ void __launch_bounds__(256) mrf_ident_kernel(const uint32_t* __restri
 }
 // rsz[q] = words of the record of node perm[q] (rsz[F] = 0)
 // qpos[i] = position of node i in the (colour, id) order (the inverse of perm)
+// (wide: class-1 nodes are swept by mrf_sweep8_kernel, whose lanes read 8 map bytes at once: their map sections are padded to 8 bytes)
 __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const uint32_t* __restrict__ adj_ptr, const MrfEdge* __restrict__ edge,
-                                   const uint8_t* __restrict__ ident, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ perm, uint32_t F, uint32_t* __restrict__ rsz, uint32_t* __restrict__ qpos) {
+                                   const uint8_t* __restrict__ ident, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ perm, uint32_t F, uint32_t wide,
+                                   uint32_t* __restrict__ rsz, uint32_t* __restrict__ qpos) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > F) return;
     uint32_t w = 0;
@@ -439,7 +441,8 @@ __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const u
         qpos[i] = q;
         if (K && cls[i] != CLS_GENERIC) {
             w = (K + 3u) & ~3u;
-            for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { const uint32_t kj = edge[e].kj; if (kj && !ident[e]) w += (kj + 3u) >> 2; }
+            const bool w8 = wide != 0u && cls[i] == 1u;
+            for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { const uint32_t kj = edge[e].kj; if (kj && !ident[e]) w += w8 ? 2u * ((kj + 7u) >> 3) : (kj + 3u) >> 2; }
             w = (w + 3u) & ~3u;
         }
     }
@@ -452,7 +455,7 @@ __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const u
 __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
                                                          const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, const MrfEdge* __restrict__ edge,
                                                          const uint8_t* __restrict__ ident, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ qpos, const uint32_t* __restrict__ roff,
-                                                         uint32_t F, uint32_t* __restrict__ rec) {
+                                                         uint32_t F, uint32_t wide, uint32_t* __restrict__ rec) {
     __shared__ uint16_t s_l[16][256];
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t gl = threadIdx.x & 15;
@@ -464,7 +467,11 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
     // (slot = (at & 3) * G + (at >> 2) for position `at` in the sender's list, G = 8 << class lanes per node), so that the lanes of a
     // group read consecutive banks.  "Label absent at the sender" is the +inf slot 4 * G; for G = 64 the slots fill the byte range
     // 0 .. 254 and 0xFF marks absence (the kernel steers it to slot 256).
-    const uint32_t rs = 8u << ci, none_byte = ci < 3u ? 4u * rs : 0xFFu;
+    // (a WIDE class-1 node -- mrf_sweep8_kernel: 8 lanes x 8 labels -- has the tile row-major over label mod 8: slot = (at & 7) * 8 + (at >> 3),
+    //  "absent" = slot 64, and its map sections padded to 8 bytes)
+    const bool w8 = wide != 0u && ci == 1u;
+    const uint32_t rs = w8 ? 8u : 8u << ci, none_byte = w8 ? 64u : (ci < 3u ? 4u * rs : 0xFFu);
+    const uint32_t lmask = w8 ? 7u : 3u, lshift = w8 ? 3u : 2u;
     const uint32_t q = qpos[i];
     uint16_t* tile = s_l[threadIdx.x >> 4];
     uint32_t* out = rec + REC_BASE + roff[q];
@@ -478,7 +485,7 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
     for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
         const uint32_t kj = edge[e].kj;
         if (kj == 0 || ident[e]) continue;                     // group-uniform
-        const uint32_t q0 = col_ptr[adj[e]], nw = (kj + 3u) >> 2;
+        const uint32_t q0 = col_ptr[adj[e]], nw = w8 ? 2u * ((kj + 7u) >> 3) : (kj + 3u) >> 2;
         for (uint32_t wI = gl; wI < nw; wI += 16) {
             // positions of the RECEIVER's labels 4 wI .. 4 wI + 3 in this (the sender's) list: four lower-bound searches in
             // lockstep (the step count depends on K only), so their LDS reads are independent
@@ -496,7 +503,7 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
             for (uint32_t r = 0; r < 4; ++r) {
                 // lo = the last candidate position: the key sits there, or one further (beyond the list), or nowhere
                 uint32_t at = lo[r] + (((uint32_t)tile[lo[r]] < key[r]) ? 1u : 0u);
-                const uint32_t byte = (at < K && (uint32_t)tile[at < K ? at : 0u] == key[r]) ? (at & 3u) * rs + (at >> 2) : none_byte;
+                const uint32_t byte = (at < K && (uint32_t)tile[at < K ? at : 0u] == key[r]) ? (at & lmask) * rs + (at >> lshift) : none_byte;
                 word |= byte << (8 * r);
             }
             out[pos + wI] = word;
@@ -773,6 +780,138 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
     }
 }
 
+
+// ---- the same update with EIGHT labels per lane (class 1: neighbourhood columns of 33 .. 64 labels; option "mrf_wide") ----
+// mrf_sweep4_kernel spends one memory instruction on 4 bytes of a run per lane: a 64-lane wave sweeps 4 nodes of this class per iteration
+// and issues 20 loads / stores for them.  The probes of rounds 4 and 5 (EXPERIMENTS.md) say the kernel is bound by the NUMBER of memory
+// instructions and requests per node, not by their bytes.  Here a node takes 8 lanes and a lane 8 consecutive labels: the three incoming
+// runs, the three old outgoing runs, the three map words and the three stores are 8-byte accesses, the label words two 16-byte loads, and
+// a wave sweeps 8 nodes per iteration with 21 memory instructions -- half the instructions per node, the same bytes, the same lines.
+// Arithmetic, reduction results (min / first argmin are exact in any order), sums (adjacency order per label) and the message / record /
+// decode layouts are those of mrf_sweep4_kernel: bit-identical results; only the map BYTES differ (a byte is the slot of THIS kernel's
+// LDS tile: row-major over label mod 8, slot = (at & 7) * 8 + (at >> 3), "absent" = slot 64 -- mrf_record_kernel writes them per class).
+template <bool DAMP, bool XCD>
+__global__ void __launch_bounds__(256) mrf_sweep8_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ rec, msg_t* msg,
+                                                         const mvs_mrf_progress* __restrict__ st, uint32_t* lab2, uint32_t buf_stride,
+                                                         uint32_t node_begin, uint32_t node_end, float rho, float alpha,
+                                                         unsigned long long* __restrict__ partial) {
+    const msg_t* mo = msg; msg_t* mn = msg;                    // in place: one colour per launch (see mrf_sweep4_kernel)
+    constexpr int G = 8, L = 8, NPB = 256 / G;
+    constexpr int TS = 72;                                     // 8 x 8 slots + the +inf slot; 72 mod 32 = 8: the 4 groups of a half-wave sit on disjoint banks
+    __shared__ float s_c[NPB * TS];
+    __shared__ unsigned long long s_e[8];
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    float* __restrict__ tile = s_c + grp * TS;
+    if (st->stopped) return;
+    if (gl == 0) tile[L * G] = INFINITY;
+    __syncthreads();
+    const uint32_t wofs = st->w * buf_stride;
+    uint32_t* lab = lab2 + wofs;
+    const float lam = 1.0f / rho;
+    const MsgQ mq = msg_q(lam);
+    const float kappa = rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;
+    constexpr float HUGE_COST = 1e30f;
+    const uint32_t stride = gridDim.x * NPB;
+    uint32_t vb = blockIdx.x;
+    if (XCD && (gridDim.x & 7u) == 0u) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    uint32_t i = node_begin + vb * NPB + grp;
+    const uint32_t last = node_end - 1;
+    const uint32_t n_iter = (node_end - node_begin + stride - 1) / stride;
+    const uint32_t t0 = (uint32_t)L * gl;
+    // map bytes of an identical-list edge: the slots r * G + gl of the lane's own labels r = 0 .. 7
+    const uint32_t ident_lo = 0x18100800u + 0x01010101u * (uint32_t)gl, ident_hi = 0x38302820u + 0x01010101u * (uint32_t)gl;
+    struct Raw { uint4 lw0, lw1; uint2 in[3], map[3], old[3]; uint32_t nl[3]; };
+    auto issue = [&](const NodeDesc& d, Raw& r) {
+        const uint32_t K = d.kk & 0xFFu, recb = 4u * d.rec;
+        r.lw0 = ld_off<uint4>(rec, recb + 32u * (uint32_t)gl);
+        r.lw1 = ld_off<uint4>(rec, recb + 32u * (uint32_t)gl + 16u);
+        uint32_t mposb = recb + 4u * ((K + 3u) & ~3u) + 8u * (uint32_t)gl;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            r.in[e] = ld_off<uint2>(mo, (d.in_off[e] & ~3u) + t0);
+            r.map[e] = ld_off<uint2>(rec, mposb);
+            if (!(d.out_off[e] & 1u)) mposb += (((d.kk >> (8 + 8 * e)) & 0xFFu) + 7u) & ~7u;   // (a wide node's map sections are padded to 8 bytes)
+            r.nl[e] = ld_off<uint32_t>(lab, 4u * d.nbr[e]);
+            if (DAMP) r.old[e] = ld_off<uint2>(mo, (d.out_off[e] & ~3u) + t0); else r.old[e] = make_uint2(0u, 0u);
+        }
+    };
+    NodeDesc cur = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i, last));
+    Raw rw; issue(cur, rw);
+    NodeDesc nxt = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i + stride, last));
+    uint32_t acc_e = 0u, acc_c = 0u;
+    for (uint32_t it = 0; it < n_iter; ++it, i += stride) {
+        const bool node_ok = i < node_end;
+        Raw rn; issue(nxt, rn);
+        const NodeDesc nn = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i + 2u * stride, last));
+        const uint32_t K = node_ok ? (cur.kk & 0xFFu) : 0u;
+        uint32_t kj3[3], o_out[3]; bool ident[3], low[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            kj3[d] = node_ok ? ((cur.kk >> (8 + 8 * d)) & 0xFFu) : 0u;
+            ident[d] = (cur.out_off[d] & 1u) != 0u; low[d] = (cur.in_off[d] & 1u) != 0u && kj3[d] != 0u;
+            o_out[d] = cur.out_off[d] & ~3u;
+        }
+        const uint32_t lw[8] = {rw.lw0.x, rw.lw0.y, rw.lw0.z, rw.lw0.w, rw.lw1.x, rw.lw1.y, rw.lw1.z, rw.lw1.w};
+        // (the update on the 8-bit codes: see mrf_sweep4_kernel; oracle.cpp mrf_sweep is the definition)
+        float b[8], cv[3][8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float cf[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) cf[d] = (float)((((r < 4) ? rw.in[d].x : rw.in[d].y) >> (8 * (r & 3))) & 0xFFu);
+            const float D = (t0 + r < K) ? cost_value(lw[r] >> 16) : HUGE_COST;
+            b[r] = __builtin_fmaf(kappa, (cf[0] + cf[1]) + cf[2], D);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) cv[d][r] = __builtin_fmaf(nstep, cf[d], b[r]) * oms;
+        }
+        float gm = fminf(fminf(fminf(b[0], b[1]), fminf(b[2], b[3])), fminf(fminf(b[4], b[5]), fminf(b[6], b[7])));
+        float cm[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) cm[d] = fminf(fminf(fminf(cv[d][0], cv[d][1]), fminf(cv[d][2], cv[d][3])), fminf(fminf(cv[d][4], cv[d][5]), fminf(cv[d][6], cv[d][7])));
+        group_min_fused4<G>(gm, cm[0], cm[1], cm[2]);
+        // decode: first argmin_t b[t] (the group minimum, then the smallest label attaining it)
+        uint32_t bt = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 7; r >= 0; --r) bt = (b[r] == gm) ? t0 + (uint32_t)r : bt;
+        bt = group_min_fused<G>(bt);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tile[r * G + gl] = cv[d][r] - cm[d];
+            const uint32_t mlo = ident[d] ? ident_lo : rw.map[d].x, mhi = ident[d] ? ident_hi : rw.map[d].y;
+            uint32_t w0 = 0u, w1 = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t s0 = (mlo >> (8 * r)) & 0xFFu, s1 = (mhi >> (8 * r)) & 0xFFu;   // slots (64 = the +inf slot: "absent at the sender")
+                w0 = msg_pack_s<DAMP>(min_raw(tile[s0], lam_s), alpha, (float)((rw.old[d].x >> (8 * r)) & 0xFFu), (uint32_t)r, w0);
+                w1 = msg_pack_s<DAMP>(min_raw(tile[s1], lam_s), alpha, (float)((rw.old[d].y >> (8 * r)) & 0xFFu), (uint32_t)r, w1);
+            }
+            if (t0 < kj3[d]) st_off<uint2>(mn, o_out[d] + t0, make_uint2(w0, w1));   // one 8-byte store: with "mrf_wide" the runs are padded to 8 elements
+
+        }
+        const bool owner = node_ok && ((K > 0u) ? ((bt >> 3) == (uint32_t)gl) : (gl == 0));
+        if (owner) {
+            const uint32_t r = bt & 7u;
+            uint32_t wsel = lw[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) wsel = (r == (uint32_t)k) ? lw[k] : wsel;
+            const uint32_t my_lab = (K > 0u) ? (wsel & 0xFFFFu) + 1u : 0u;
+            const uint32_t my_code = (K > 0u) ? (wsel >> 16) : 65535u;
+            st_off<uint32_t>(lab, 4u * cur.id, my_lab);
+            acc_e += my_code;
+            acc_c += (low[0] && rw.nl[0] != my_lab) + (low[1] && rw.nl[1] != my_lab) + (low[2] && rw.nl[2] != my_lab);
+        }
+        cur = nxt; rw = rn; nxt = nn;
+    }
+    unsigned long long e = acc_e, c = acc_c;
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_e[threadIdx.x >> 6] = e; s_e[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        e = s_e[0] + s_e[1] + s_e[2] + s_e[3]; c = s_e[4] + s_e[5] + s_e[6] + s_e[7];
+        partial[2 * blockIdx.x] = e + 65535ull * c; partial[2 * blockIdx.x + 1] = c;
+    }
+}
 
 // generic nodes: any degree, any K.  One BLOCK per node (persistent blocks striding over the range): the four waves split the
 // labels for the belief vector b (which goes through a global scratch row: K is unbounded here) and then take the out-edges in
@@ -1147,7 +1286,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     const uint32_t force_generic = (ctx->csr_nnz < 4 || E == 0 || ctx->mrf_force_generic) ? 1u : 0u;
     ctx->m_cls.ensure((size_t)F + 4);
     ctx->m_rev.ensure((size_t)E + 2);
-    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : 3), force_generic, ctx->m_size.p, ctx->m_cls.p, maxes, ctx->m_rev.p); MVS_LAUNCH_CHECK(); }
+    if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : (ctx->mrf_wide ? 7 : 3)), force_generic, ctx->m_size.p, ctx->m_cls.p, maxes, ctx->m_rev.p); MVS_LAUNCH_CHECK(); }
     // ---- colour-phased schedule: colouring (Jones-Plassmann rounds), nodes in (colour, id) order ----
     ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 72); ctx->m_tmp_b.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
     ctx->m_colours = 0; ctx->m_sub_begin.assign(N_SUB + 1, 0); ctx->m_n_fast = 0; ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
@@ -1212,18 +1351,19 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     ctx->m_ident.ensure((size_t)E + 1);
     MVS_HIP(hipMemsetAsync(ctx->m_ident.p, 0, (size_t)E + 1, s));
     ctx->m_fast = true;   // the sweep kernels of BOTH node classes accumulate the sweep's energy (callers no longer run the energy kernel per sweep)
+    ctx->m_wide_layout = ctx->mrf_wide != 0;   // the records / runs built below are those of this variant: the sweeps follow the set-up, not the option
     const uint32_t n_fast = ctx->m_n_fast, n_generic = F - n_fast;
     if (n_fast) {
         // records + descriptors of the fast nodes.  Upper bound of the record array (no read-back): labels nnz + 3 F, maps <= one byte per message element
-        const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + 1024;   // incl. slack for reads past the last record
+        const size_t rec_cap = (size_t)REC_BASE + ctx->csr_nnz + 8 * (size_t)F + ctx->m_total / 4 + (ctx->mrf_wide ? (size_t)ctx->m_n_adj : 0) + 1024;   // incl. slack for reads past the last record
         ctx->m_rec.ensure(rec_cap);
         MVS_HIP(hipMemsetAsync(ctx->m_rec.p, 0, REC_BASE * sizeof(uint32_t), s));
         hipLaunchKernelGGL(mrf_ident_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_adj_ptr, ctx->r_adj, F, ctx->m_edge.p, ctx->m_cls.p, ctx->m_ident.p); MVS_LAUNCH_CHECK();
         uint32_t* rsz = ctx->m_tmp_a.p; uint32_t* roff = ctx->m_tmp_b.p;   // F + 1 entries each
-        hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_perm.p, F, rsz, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_recsize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_perm.p, F, (uint32_t)(ctx->mrf_wide ? 1 : 0), rsz, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, rsz, roff, (size_t)F + 1, nullptr);
         hipLaunchKernelGGL(mrf_record_kernel, dim3((unsigned)(((size_t)F * 16 + 255) / 256)), dim3(256), 0, s, ctx->r_ptr, ctx->r_view, ctx->r_cost, ctx->r_adj_ptr, ctx->r_adj,
-                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_tmp_c.p /* qpos */, roff, F, ctx->m_rec.p); MVS_LAUNCH_CHECK();
+                           ctx->m_edge.p, ctx->m_ident.p, ctx->m_cls.p, ctx->m_tmp_c.p /* qpos */, roff, F, (uint32_t)(ctx->mrf_wide ? 1 : 0), ctx->m_rec.p); MVS_LAUNCH_CHECK();
         ctx->m_desc.ensure((size_t)F + 1);
         hipLaunchKernelGGL(mrf_desc_kernel, dim3((n_fast + 255) / 256), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, ctx->m_edge.p, ctx->m_ident.p, ctx->m_perm.p, ctx->m_colour.p, roff, n_fast, ctx->m_desc.p); MVS_LAUNCH_CHECK();
     }
@@ -1379,6 +1519,30 @@ static unsigned launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint3
     MVS_LAUNCH_CHECK();
     return blocks;
 }
+// class 1 through mrf_sweep8_kernel (option "mrf_wide"): 8 lanes per node, 32 nodes per block
+static unsigned launch_sweep8(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t qe, unsigned slot, unsigned slot_cap) {
+    constexpr int NPB = 256 / 8;
+    const unsigned need = (qe - qb + NPB - 1) / NPB;
+    const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0; hipDeviceProp_t prop;
+        MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep8_kernel<true, true>, 256, 0));
+        MVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        resident = std::max(1, per_cu) * prop.multiProcessorCount;
+    }
+    unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
+    blocks = std::max(1u, std::min(std::min(need, blocks), slot_cap));
+    if (blocks > 8) blocks &= ~7u;
+    msg_t* msg = reinterpret_cast<msg_t*>(ctx->m_msg_a.p);
+    unsigned long long* partial = ctx->m_energy.p + 4 + 2 * ((size_t)EPART_BLOCKS * phase + slot);
+#define SWEEP8_ARGS dim3(blocks), dim3(256), 0, ctx->stream, ctx->m_desc.p, ctx->m_rec.p, msg, ctx->m_state.p, ctx->m_lab.p, ctx->m_stride, qb, qe, rho, alpha, partial
+    if (alpha != 0.0f) { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep8_kernel<true, true>), SWEEP8_ARGS); else hipLaunchKernelGGL((mrf_sweep8_kernel<true, false>), SWEEP8_ARGS); }
+    else { if (ctx->mrf_xcd) hipLaunchKernelGGL((mrf_sweep8_kernel<false, true>), SWEEP8_ARGS); else hipLaunchKernelGGL((mrf_sweep8_kernel<false, false>), SWEEP8_ARGS); }
+#undef SWEEP8_ARGS
+    MVS_LAUNCH_CHECK();
+    return blocks;
+}
 static unsigned launch_sweep_generic(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_t qe, unsigned slot, unsigned slot_cap) {
     const unsigned need = qe - qb;   // one block per node
     const unsigned blocks = std::max(1u, std::min(std::min(need, 256u * 4u), slot_cap));
@@ -1428,7 +1592,7 @@ void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
         const unsigned cap = EPART_BLOCKS - slot - (unsigned)n_launch;   // leaves at least one slot for every launch still to come
         switch (g) {
             case 0: slot += launch_sweep4_g<8>(ctx, phase, qb[g], qe[g], slot, cap); break;
-            case 1: slot += launch_sweep4_g<16>(ctx, phase, qb[g], qe[g], slot, cap); break;
+            case 1: slot += ctx->m_wide_layout ? launch_sweep8(ctx, phase, qb[g], qe[g], slot, cap) : launch_sweep4_g<16>(ctx, phase, qb[g], qe[g], slot, cap); break;
             case 2: slot += launch_sweep4_g<32>(ctx, phase, qb[g], qe[g], slot, cap); break;
             case 3: slot += launch_sweep4_g<64>(ctx, phase, qb[g], qe[g], slot, cap); break;      // one node per wave: several hundred views per face
             default: slot += launch_sweep_generic(ctx, phase, qb[g], qe[g], slot, cap);
