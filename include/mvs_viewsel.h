@@ -252,7 +252,9 @@ mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
  * Sobel in one pass through LDS, the default; identical output), "face_order" (1 = the library lays the faces out along a Hilbert curve, the
  * default; 0 = the caller's face numbering is kept; identical results), "shard_peer_push" (sharded sweep loop: 1 = boundary runs are stored straight into the
  * neighbours' arrays where the communicator's ranks can address each other's memory, the default; 0 = pack / exchange / unpack through the
- * communicator; must agree on all ranks; identical results), test hooks "info_cert_shift", "mrf_force_generic" */
+ * communicator; must agree on all ranks; identical results), "mrf_wide" (1 = nodes whose neighbourhood columns hold 33 .. 64 labels are swept
+ * with 8 lanes x 8 labels per node, the default; 0 = 16 lanes x 4 labels; environment MVS_MRF_WIDE; takes effect with the next solve;
+ * identical results), test hooks "info_cert_shift", "mrf_force_generic" */
 mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value);
 
 /* with option "profile": per-stage GPU time from hipEvents recorded on the context's stream,
