@@ -49,7 +49,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="3"); ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_pmc_sq.json"))
     ap.add_argument("--groups", type=int, default=len(GROUPS), help="only the first N counter groups")
-    ap.add_argument("--kernels", default="mrf_sweep4_kernel,ray_packet3_kernel,info_kernel,wave_info_kernel,cull_kernel,lum_sobel_kernel,csr_write_staged_kernel,outlier_kernel")
+    ap.add_argument("--kernels", default="mrf_sweep8_kernel,mrf_sweep4_kernel,ray_packet3_kernel,info_kernel,wave_info_kernel,cull_kernel,lum_sobel_kernel,csr_write_staged_kernel,outlier_kernel")
     args = ap.parse_args()
     acc, failed = {}, []
     for g in GROUPS[:args.groups]:
