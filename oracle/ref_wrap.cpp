@@ -387,4 +387,48 @@ std::uint64_t ref_build_adjacency(std::uint32_t n_verts, std::uint32_t n_faces, 
     return graph.num_edges();
 }
 
+// ---- row f2: tex::generate_texture_views on a SCENE FOLDER (generate_texture_views.cpp:67-157 from_images_and_camera_files: the pairing of
+// <prefix>.cam with the image file next to it in the sorted listing, the two-line .cam parsing, the choice of the undistortion model, the
+// view ids, the name of the rewritten image) -- the reference's own code on real files of a test directory.  Everything it parsed comes
+// back as one JSON text: per view (in id order) {id, image_file, trans, rot, flen, dist, paspect, ppoint}, then the undistortion calls and
+// the files handed to save_png_file.  (mve::CameraInfo's fields and string setters, util::Tokenizer and the directory listing are
+// stand-ins: oracle/ref_stubs.)  Returns the text's length, -1 on an exception, -2 if `cap` is too small.
+#ifndef MVS_DROPIN_BUILD
+int ref_scene_folder_views(const char* path, const char* tmp_dir, char* out, int cap) {
+    try {
+        mve::camera_log().clear(); mve::image::header_requests().clear(); mve::image::undistort_log().clear(); mve::image::saved_files().clear();
+        std::vector<tex::TextureView> views;
+        tex::generate_texture_views(path, &views, tmp_dir);
+        std::vector<mve::CameraInfo> const& cams = mve::camera_log();
+        std::vector<std::string> const& files = mve::image::header_requests();
+        if (cams.size() != views.size() || files.size() != views.size()) return -1;
+        std::string js = "{\"views\": [";
+        char buf[256];
+        // generate_texture_views sorts the views by id; the logs are in construction order = id order for a scene folder (no OpenMP here)
+        for (std::size_t k = 0; k < views.size(); ++k) {
+            mve::CameraInfo const& c = cams[k];
+            std::snprintf(buf, sizeof(buf), "%s{\"id\": %zu, \"image_file\": \"", k ? ", " : "", views[k].get_id()); js += buf; js += files[k]; js += "\", \"trans\": [";
+            for (int i = 0; i < 3; ++i) { std::snprintf(buf, sizeof(buf), "%s%.9g", i ? ", " : "", (double)c.trans[i]); js += buf; }
+            js += "], \"rot\": [";
+            for (int i = 0; i < 9; ++i) { std::snprintf(buf, sizeof(buf), "%s%.9g", i ? ", " : "", (double)c.rot[i]); js += buf; }
+            std::snprintf(buf, sizeof(buf), "], \"flen\": %.9g, \"dist\": [%.9g, %.9g], \"paspect\": %.9g, \"ppoint\": [%.9g, %.9g]}",
+                          (double)c.flen, (double)c.dist[0], (double)c.dist[1], (double)c.paspect, (double)c.ppoint[0], (double)c.ppoint[1]);
+            js += buf;
+        }
+        js += "], \"undistort\": [";
+        for (std::size_t k = 0; k < mve::image::undistort_log().size(); ++k) {
+            mve::image::UndistortCall const& u = mve::image::undistort_log()[k];
+            std::snprintf(buf, sizeof(buf), "%s{\"model\": \"%s\", \"flen\": %.9g, \"d0\": %.9g, \"d1\": %.9g}", k ? ", " : "", u.model == 0 ? "k2k4" : "vsfm", (double)u.flen, (double)u.d0, (double)u.d1);
+            js += buf;
+        }
+        js += "], \"saved\": [";
+        for (std::size_t k = 0; k < mve::image::saved_files().size(); ++k) { js += k ? ", \"" : "\""; js += mve::image::saved_files()[k]; js += "\""; }
+        js += "]}";
+        if ((int)js.size() + 1 > cap) return -2;
+        std::memcpy(out, js.c_str(), js.size() + 1);
+        return (int)js.size();
+    } catch (std::exception& e) { std::fprintf(stderr, "ref_scene_folder_views: %s\n", e.what()); return -1; }
+}
+#endif
+
 }  // extern "C"

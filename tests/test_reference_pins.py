@@ -559,3 +559,58 @@ def test_prepare_mesh_and_adjacency_equal_the_reference_functions(R):
     s = get_scene("bumpy")
     ap_o, ad_o = O.build_adjacency(s.faces)
     assert np.array_equal(ap_o, s.adj_ptr) and np.array_equal(ad_o, s.adj)     # what every other test feeds view selection with
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# row f2: the reference's OWN scene-folder ingest (generate_texture_views.cpp:67-157), compiled where it lies
+# ---------------------------------------------------------------------------------------------------------------------
+def test_scene_folder_ingest_equals_the_reference_generate_texture_views(R, tmp_path):
+    """row f2: mvs-texturing_amd/ingest.py pairs <prefix>.cam files with images, parses the two .cam lines, numbers the views and picks
+    the undistortion model exactly like upstream's tex::generate_texture_views does on the same directory -- upstream's
+    generate_texture_views.cpp compiled in place (stand-ins for util::fs / util::Tokenizer / mve::CameraInfo's plain-data members:
+    oracle/ref_stubs), run on real files: images that sort before and after their .cam, upper-case and four-letter extensions, a
+    non-image file in between, a prefix that is a prefix of another name, an orphan .cam, a directory called *.cam, a file called
+    ".cam", .cam files with one to six (and more) intrinsics, trailing blanks and CRLF line ends."""
+    import json
+    from mvs_texturing_amd import ingest
+    d = tmp_path / "scene"; d.mkdir()
+    tmp = tmp_path / "tmp"; tmp.mkdir()
+    ext = "0.5 -1.25 2 1 0 0 0 0.6 -0.8 0 0.8 0.6"
+    files = {
+        "64x48_a.cam": ext + "\n0.9\n", "64x48_a.png": "",
+        "64x48_b.cam": ext + "\n0.9 0.1\n", "64x48_b.JPG": "",                                  # one coefficient: the VisualSFM model
+        "64x48_c.cam": ext + "\n0.9 0.1 0.02\n", "64x48_c.txt": "x", "64x48_c.tiff": "",         # two: k2k4; a non-image file in between
+        "64x48_d.cam": ext + "\n0.9 0 0 1.2 0.4 0.6\n", "64x48_d.PNG": "",                        # the image sorts BEFORE its .cam
+        "64x48_e.cam": ext + "\n1.5 0 0.3 \n", "64x48_e2.jpeg": "",                               # prefix of another name; d0 = 0: no undistortion whatever d1 says
+        "64x48_f.cam": ext + "\r\n0.7 0.05 0 1 0.5 0.5 99 98\r\n", "64x48_f.png": "",            # CRLF, surplus tokens
+        "64x48_z.cam": ext + "\n1\n",                                                           # no image with this prefix: skipped
+        ".cam": ext + "\n1\n", "notes.txt": "x",
+    }
+    for name, text in files.items():
+        (d / name).write_bytes(text.encode())
+    (d / "64x48_dir.cam").mkdir()
+    R.ref_scene_folder_views.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]; R.ref_scene_folder_views.restype = C.c_int
+    buf = C.create_string_buffer(1 << 16)
+    n = R.ref_scene_folder_views(str(d).encode(), str(tmp).encode(), buf, len(buf))
+    assert n > 0, n
+    ref = json.loads(buf.value.decode())
+    pairs = ingest.list_scene_folder(str(d))
+    assert [os.path.basename(c) for c, _ in pairs] == ["64x48_%s.cam" % k for k in "abcdef"]
+    assert len(ref["views"]) == len(pairs) == 6
+    models = []
+    for k, ((cam_path, img_path), v) in enumerate(zip(pairs, ref["views"])):
+        assert v["id"] == k                                                                  # generate_texture_views.cpp:149: id = pair index
+        cam = ingest.read_cam_file(cam_path)
+        f32 = lambda x: np.asarray(x, dtype=np.float32)
+        assert np.array_equal(f32(v["trans"]), cam.trans) and np.array_equal(f32(v["rot"]), cam.rot.reshape(-1)), cam_path
+        assert f32(v["flen"]) == cam.flen and np.array_equal(f32(v["dist"]), cam.dist), cam_path
+        assert f32(v["paspect"]) == cam.paspect and np.array_equal(f32(v["ppoint"]), cam.ppoint), cam_path
+        if cam.dist[0] != 0.0:                                                                # :153-165 (ingest.load_scene takes the same branch)
+            models.append({"model": "k2k4" if cam.dist[1] != 0.0 else "vsfm", "flen": float(cam.flen), "d0": float(cam.dist[0]), "d1": float(cam.dist[1]) if cam.dist[1] != 0.0 else 0.0})
+            assert v["image_file"] == os.path.join(str(tmp), os.path.splitext(os.path.basename(img_path))[0] + ".png")   # rewritten into tmp_dir as .png
+        else:
+            assert os.path.realpath(v["image_file"]) == os.path.realpath(img_path), (v["image_file"], img_path)
+    assert [(u["model"], np.float32(u["flen"]), np.float32(u["d0"]), np.float32(u["d1"])) for u in ref["undistort"]] == \
+           [(m["model"], np.float32(m["flen"]), np.float32(m["d0"]), np.float32(m["d1"])) for m in models]
+    assert [m["model"] for m in models] == ["vsfm", "k2k4", "vsfm"]
+    assert ref["saved"] == [v["image_file"] for v in ref["views"] if v["image_file"].startswith(str(tmp))]
