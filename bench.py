@@ -591,8 +591,11 @@ def main():
     ap.add_argument("--launch", default="inproc", choices=["inproc", "torchrun"],
                     help="--gpus N > 1 started without a launcher: 'inproc' = one process, one host thread per GPU, peer-push transport (the single-node route); "
                          "'torchrun' = re-execute under torch.distributed.run, one process per GPU, RCCL")
+    ap.add_argument("--inproc", action="store_true", help="same as --launch inproc (the default for --gpus N > 1 without a launcher)")
     args = ap.parse_args()
     args.config = int(args.config) if args.config.isdigit() else args.config
+    if args.inproc:
+        args.launch = "inproc"
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     def exec_torchrun():
