@@ -439,6 +439,7 @@ def run_inproc(args, cfg, max_labels):
     the ranks then time-slice one device and the number says nothing about scaling).  Timing: barrier, K steps, per-rank stream
     synchronisation, barrier; elapsed = until the LAST rank is through.  Parity: the labels of all ranks, assembled, against a
     single-context solve of the same scene on rank 0's GPU (which bench.py --gpus 1 checks against the oracle)."""
+    import ctypes as C
     import threading
     N = args.gpus
     ndev = torch.cuda.device_count()
@@ -492,7 +493,7 @@ def run_inproc(args, cfg, max_labels):
             for _ in range(n_prof if args.steps > 0 else 0):
                 step()
             prof = ctx.get_profile()
-            nph = __import__("ctypes").c_uint32(0); ctx.L.mvs_ctx_mrf_num_phases(ctx.h, __import__("ctypes").byref(nph))
+            nph = C.c_uint32(0); ctx.L.mvs_ctx_mrf_num_phases(ctx.h, C.byref(nph))
             res[r] = dict(elapsed=elapsed, own=own, labels=labels, prof=prof, n_phases=max(int(nph.value), 1), plan=dict(sh.plan_info(), **sh.transport_info()), **box)
             if r == 0 and not args.no_parity and args.steps > 0:
                 # the single-context reference on this rank's GPU, while the other ranks are done with their device work
