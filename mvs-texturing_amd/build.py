@@ -74,8 +74,18 @@ def build_host(force=False):
     return out
 
 
+def build_test_tools(force=False):
+    """tests/tools/librccl_fake.so: the test double the RCCL communicator of csrc/shard.hip binds when MVS_RCCL_LIB names it (thread-ranks on
+    one device; see tests/tools/fake_rccl.hip).  Test infrastructure: nothing of the product links or loads it by itself."""
+    tools = os.path.join(os.path.dirname(HERE), "tests", "tools")
+    src, lib = os.path.join(tools, "fake_rccl.hip"), os.path.join(tools, "librccl_fake.so")
+    if os.path.exists(src) and (force or _newer(lib, [src])):
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, src])
+    return [lib]
+
+
 def build_all(force=False, verbose=False):
-    return [build_hip(force, verbose)] + build_host(force)
+    return [build_hip(force, verbose)] + build_host(force) + build_test_tools(force)
 
 
 if __name__ == "__main__":

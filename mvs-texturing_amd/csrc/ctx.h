@@ -235,6 +235,7 @@ struct mvs_ctx {
     // sorted by sub-class key (fast nodes by (colour, class, id), then generic nodes by (colour, id)); m_sub_begin[key] = first position
     // of a key >= `key` (host copy of m_sub); positions [0, m_n_fast) are the fast nodes
     mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c, m_sub; mvs::DBuf<uint8_t> m_cls; uint32_t m_colours = 0, m_n_fast = 0; std::vector<uint32_t> m_sub_begin;
+    const uint8_t* m_bnd = nullptr;   // per node: 1 = boundary node of a sharded caller (own node with an edge into another rank's part) -> zone 0 of the schedule (k_mrf.hip); null: no marks
     int mrf_force_generic = 0;   // test hook: every node takes the generic sweep kernel
     int mrf_wide = 1;            // class-1 nodes (neighbourhood columns of 33 .. 64 labels) through mrf_sweep8_kernel: 8 lanes x 8 labels (k_mrf.hip); 0: mrf_sweep4_kernel<16>
     bool m_wide_layout = false;  // ... as the last mrf_setup laid the records and runs out
@@ -292,6 +293,8 @@ struct ProfChain {
 struct RoctxRange { explicit RoctxRange(const char* name); ~RoctxRange(); bool on; };
 // device for the one-shot host entry points (mvs_data_costs, mvs_view_selection, ...): environment MVS_DEVICE, default 0
 int default_device();
+// which zone(s) of a colour phase mrf_sweep_phase sweeps (k_mrf.hip)
+enum { MRF_PART_ALL = 0, MRF_PART_BOUNDARY = 1, MRF_PART_INTERIOR = 2 };
 // reports through pinned host memory (k_mrf.hip)
 void ensure_report_ring(mvs_ctx* ctx);
 void report_u32(mvs_ctx* ctx, const uint32_t* d_src, uint32_t* d_dst, uint32_t seq_slot, uint32_t seq);

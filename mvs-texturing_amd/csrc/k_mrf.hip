@@ -244,25 +244,31 @@ __global__ void mrf_colour_round_kernel(const uint32_t* __restrict__ adj_ptr, co
 // Schedule order = nodes sorted by SUB-CLASS key: fast nodes first, by (colour, class, id) -- key = 4 * colour + class < 256 --
 // then the generic nodes by (colour, id) -- key = 256 + colour.  Every (colour, class) pair is one contiguous range of the
 // order = one launch; the fast nodes (their records and descriptors) are positions [0, n_fast).
-constexpr uint32_t N_SUB = 320;            // keys 0 .. 319 (64 colours x 4 fast classes, 64 generic colour classes)
+constexpr uint32_t N_SUB = 320;            // sub-classes 0 .. 319 (64 colours x 4 fast classes, 64 generic colour classes)
 constexpr uint32_t SUB_GENERIC = 256;
-__global__ void mrf_sortkey_kernel(const uint32_t* __restrict__ colour, const uint8_t* __restrict__ cls, uint32_t F, uint32_t* __restrict__ key) {
+// Every sub-class has two ZONES (sort key = 2 * sub-class + zone): zone 0 = the nodes a sharded caller marked as its BOUNDARY nodes
+// (own nodes with an edge into another rank's part: ctx->m_bnd, shard.hip), zone 1 = everybody else.  A sharded rank sweeps the
+// boundary zone of a colour first, hands its runs to the neighbours, and sweeps the interior while they travel; a colour class is an
+// independent set, so the split changes no value.  Without marks (single context, building blocks) zone 0 is empty and the order is
+// the plain (colour, class, id) order.
+constexpr uint32_t N_KEY = 2 * N_SUB;
+__global__ void mrf_sortkey_kernel(const uint32_t* __restrict__ colour, const uint8_t* __restrict__ cls, const uint8_t* __restrict__ bnd, uint32_t F, uint32_t* __restrict__ key) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < F) { const uint32_t c = colour[i], k = cls[i]; key[i] = (k == CLS_GENERIC) ? SUB_GENERIC + c : 4u * c + k; }
+    if (i < F) { const uint32_t c = colour[i], k = cls[i]; key[i] = 2u * ((k == CLS_GENERIC) ? SUB_GENERIC + c : 4u * c + k) + ((bnd && bnd[i]) ? 0u : 1u); }
 }
-// sub_begin[k] = first position of a key >= k in the sorted key array, k = 0 .. N_SUB
+// sub_begin[k] = first position of a key >= k in the sorted key array, k = 0 .. N_KEY
 __global__ void mrf_sub_begin_kernel(const uint32_t* __restrict__ sorted, uint32_t F, uint32_t* __restrict__ sub_begin) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > N_SUB) return;
+    if (c > N_KEY) return;
     uint32_t lo = 0, hi = F;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted[mid] < c) lo = mid + 1; else hi = mid; }
     sub_begin[c] = lo;
 }
-// own share of every sub-class: positions of the ids in [nb, ne) inside perm[sb[k], sb[k + 1]) (ids ascending inside a sub-class)
+// own share of every (sub-class, zone): positions of the ids in [nb, ne) inside perm[sb[k], sb[k + 1]) (ids ascending inside a key)
 __global__ void mrf_sub_range_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sub_begin,
                                      uint32_t nb, uint32_t ne, uint32_t* __restrict__ out) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N_SUB) return;
+    if (c >= N_KEY) return;
     const uint32_t cb = sub_begin[c], ce = sub_begin[c + 1];
     uint32_t lo = cb, hi = ce;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (perm[mid] < nb) lo = mid + 1; else hi = mid; }
@@ -1289,7 +1295,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     if (F) { hipLaunchKernelGGL(mrf_size_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, (uint32_t)(ctx->mrf_run_pad == 16 ? 15 : (ctx->mrf_wide ? 7 : 3)), force_generic, ctx->m_size.p, ctx->m_cls.p, maxes, ctx->m_rev.p); MVS_LAUNCH_CHECK(); }
     // ---- colour-phased schedule: colouring (Jones-Plassmann rounds), nodes in (colour, id) order ----
     ctx->m_colour.ensure((size_t)F + 2); ctx->m_perm.ensure((size_t)F + 2); ctx->m_tmp_a.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 72); ctx->m_tmp_b.ensure((size_t)MAX_LAYOUT_COLOURS * ((size_t)F + 1) + 2); ctx->m_tmp_c.ensure((size_t)F + 2);
-    ctx->m_colours = 0; ctx->m_sub_begin.assign(N_SUB + 1, 0); ctx->m_n_fast = 0; ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
+    ctx->m_colours = 0; ctx->m_sub_begin.assign(N_KEY + 1, 0); ctx->m_n_fast = 0; ctx->m_range_q.clear(); ctx->m_range_nb = ctx->m_range_ne = 0;
     ctx->m_sweep_no = 0;
     if (F) {
         uint32_t* pending = ctx->m_moved.p + 1;   // [0] a node is still waiting, [1] a node saw all 64 colours around it
@@ -1307,20 +1313,20 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         }
         MVS_HIP(hipMemsetAsync(ctx->m_moved.p, 0, 4 * sizeof(uint32_t), s));
         // stable sort of the node ids by sub-class key: perm = the schedule order; every (colour, class) pair is a contiguous range
-        hipLaunchKernelGGL(mrf_sortkey_kernel, dim3(nb), dim3(256), 0, s, ctx->m_colour.p, ctx->m_cls.p, F, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mrf_sortkey_kernel, dim3(nb), dim3(256), 0, s, ctx->m_colour.p, ctx->m_cls.p, ctx->m_bnd, F, ctx->m_tmp_c.p); MVS_LAUNCH_CHECK();
         size_t tmp_bytes = 0;
-        MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 9, s));
+        MVS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 10, s));
         ctx->sort_tmp.ensure(tmp_bytes + 16);
-        MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 9, s));
-        ctx->m_sub.ensure(3 * (size_t)N_SUB + 8);   // [0, N_SUB]: sub_begin; behind it the own-share ranges of sub_range()
-        hipLaunchKernelGGL(mrf_sub_begin_kernel, dim3(2), dim3(256), 0, s, ctx->m_tmp_b.p, F, ctx->m_sub.p); MVS_LAUNCH_CHECK();
-        MVS_HIP(hipMemcpyAsync(ctx->m_sub_begin.data(), ctx->m_sub.p, (N_SUB + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 10, s));
+        ctx->m_sub.ensure(3 * (size_t)N_KEY + 8);   // [0, N_KEY]: sub_begin; behind it the own-share ranges of sub_range()
+        hipLaunchKernelGGL(mrf_sub_begin_kernel, dim3((N_KEY + 256) / 256), dim3(256), 0, s, ctx->m_tmp_b.p, F, ctx->m_sub.p); MVS_LAUNCH_CHECK();
+        MVS_HIP(hipMemcpyAsync(ctx->m_sub_begin.data(), ctx->m_sub.p, (N_KEY + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MVS_HIP(hipStreamSynchronize(s));
         const std::vector<uint32_t>& sb = ctx->m_sub_begin;
         uint32_t C = 0;   // colours 0 .. C-1 are in use (greedy colours are dense)
-        for (uint32_t c = 0; c < 64; ++c) if (sb[4 * c + 4] > sb[4 * c] || sb[SUB_GENERIC + c + 1] > sb[SUB_GENERIC + c]) C = c + 1;
+        for (uint32_t c = 0; c < 64; ++c) if (sb[2 * (4 * c + 4)] > sb[2 * (4 * c)] || sb[2 * (SUB_GENERIC + c + 1)] > sb[2 * (SUB_GENERIC + c)]) C = c + 1;
         ctx->m_colours = C;
-        ctx->m_n_fast = sb[SUB_GENERIC];
+        ctx->m_n_fast = sb[2 * SUB_GENERIC];
     }
     // message layout (sender-major, (colour, id) node order): in_off[e] for every directed edge e (adjacency order);
     // edges whose reverse is missing (asymmetric input) keep offset 0 and are disabled by mrf_edge_kernel
@@ -1558,50 +1564,62 @@ static unsigned launch_sweep_generic(mvs_ctx* ctx, uint32_t phase, uint32_t qb, 
     return blocks;
 }
 
-// positions [qb, qe) in the schedule order of the nodes of sub-class `sub` (key of mrf_sortkey_kernel) whose id lies in [nb0, ne0)
-static void sub_range(mvs_ctx* ctx, uint32_t sub, uint32_t nb0, uint32_t ne0, uint32_t* qb, uint32_t* qe) {
-    const uint32_t cb = ctx->m_sub_begin[sub], ce = ctx->m_sub_begin[sub + 1];
+// positions [qb, qe) in the schedule order of the nodes of (sub-class `sub`, zone) whose id lies in [nb0, ne0)
+static void sub_range(mvs_ctx* ctx, uint32_t sub, uint32_t zone, uint32_t nb0, uint32_t ne0, uint32_t* qb, uint32_t* qe) {
+    const uint32_t key = 2u * sub + zone;
+    const uint32_t cb = ctx->m_sub_begin[key], ce = ctx->m_sub_begin[key + 1];
     if (ce <= cb || (nb0 == 0 && ne0 >= ctx->csr_faces)) { *qb = cb; *qe = ce; return; }
-    if (ctx->m_range_nb != nb0 || ctx->m_range_ne != ne0 || ctx->m_range_q.size() != 2 * (size_t)N_SUB) {
-        // a rank's own share of every sub-class: one small kernel + read-back per (range, setup), then cached
-        uint32_t* d = ctx->m_sub.p + N_SUB + 2;   // (allocated by mrf_setup: ensure() here would drop sub_begin)
-        hipLaunchKernelGGL(mrf_sub_range_kernel, dim3(2), dim3(256), 0, ctx->stream, ctx->m_perm.p, ctx->m_sub.p, nb0, ne0, d);
+    if (ctx->m_range_nb != nb0 || ctx->m_range_ne != ne0 || ctx->m_range_q.size() != 2 * (size_t)N_KEY) {
+        // a rank's own share of every (sub-class, zone): one small kernel + read-back per (range, setup), then cached
+        uint32_t* d = ctx->m_sub.p + N_KEY + 2;   // (allocated by mrf_setup: ensure() here would drop sub_begin)
+        hipLaunchKernelGGL(mrf_sub_range_kernel, dim3((N_KEY + 255) / 256), dim3(256), 0, ctx->stream, ctx->m_perm.p, ctx->m_sub.p, nb0, ne0, d);
         MVS_LAUNCH_CHECK();
-        ctx->m_range_q.assign(2 * (size_t)N_SUB, 0);
-        MVS_HIP(hipMemcpyAsync(ctx->m_range_q.data(), d, 2 * N_SUB * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->m_range_q.assign(2 * (size_t)N_KEY, 0);
+        MVS_HIP(hipMemcpyAsync(ctx->m_range_q.data(), d, 2 * N_KEY * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         MVS_HIP(hipStreamSynchronize(ctx->stream));
         ctx->m_range_nb = nb0; ctx->m_range_ne = ne0;
     }
-    *qb = ctx->m_range_q[2 * sub]; *qe = ctx->m_range_q[2 * sub + 1];
+    *qb = ctx->m_range_q[2 * key]; *qe = ctx->m_range_q[2 * key + 1];
 }
 
-// one colour phase of a sweep over the nodes of that colour with id in [nb0, ne0): in place.  Up to five launches, one per node
-// class present in the colour (a uniform mesh has one); their energy partials share the phase's EPART_BLOCKS slots.
-void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0) {
-    if (phase == 0) ++ctx->m_sweep_no;      // sweeps are counted by their first phase (every caller runs the phases in order)
+// one colour phase of a sweep over the nodes of that colour with id in [nb0, ne0): in place.  Up to five launches per zone, one per node
+// class present in the colour (a uniform mesh has one); their energy partials share the phase's EPART_BLOCKS slots: the boundary zone's
+// launches take slots [0, EPART_BOUNDARY), the interior's the rest (a slot nobody writes stays zero; the geometry of a phase's launches
+// is the same in every sweep, so every slot that is ever written is rewritten by every sweep).
+// part: MRF_PART_ALL = both zones, slots from 0 (one launch where the zones are adjacent in the schedule),
+//       MRF_PART_BOUNDARY / MRF_PART_INTERIOR = one zone -- a sharded caller runs BOUNDARY, hands over, then INTERIOR.
+// A solve keeps to one of the two modes (the slots of a launch differ between them).
+void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, int part) {
+    if (phase == 0 && part != MRF_PART_INTERIOR) ++ctx->m_sweep_no;      // sweeps are counted by their first phase (every caller runs the phases in order, a split phase boundary first)
     if (phase >= ctx->m_colours || ne0 <= nb0) return;
-    uint32_t qb[5], qe[5]; int n_launch = 0;
+    constexpr unsigned EPART_BOUNDARY = 256;
+    struct Launch { uint32_t g, qb, qe; } L[10]; int n = 0;
     for (uint32_t g = 0; g < 5; ++g) {
-        sub_range(ctx, g < 4 ? 4 * phase + g : SUB_GENERIC + phase, nb0, ne0, &qb[g], &qe[g]);
-        if (qe[g] > qb[g]) ++n_launch;
+        const uint32_t sub = g < 4 ? 4 * phase + g : SUB_GENERIC + phase;
+        uint32_t b0 = 0, b1 = 0, i0 = 0, i1 = 0;
+        if (part != MRF_PART_INTERIOR) sub_range(ctx, sub, 0, nb0, ne0, &b0, &b1);
+        if (part != MRF_PART_BOUNDARY) sub_range(ctx, sub, 1, nb0, ne0, &i0, &i1);
+        if (b1 > b0 && i1 > i0 && b1 == i0) { L[n++] = {g, b0, i1}; continue; }   // both zones, adjacent in the schedule (a single context's marks): one launch
+        if (b1 > b0) L[n++] = {g, b0, b1};
+        if (i1 > i0) L[n++] = {g, i0, i1};
     }
-    unsigned slot = 0;
-    for (uint32_t g = 0; g < 5; ++g) {
-        if (qe[g] <= qb[g]) continue;
-        --n_launch;
-        const unsigned cap = EPART_BLOCKS - slot - (unsigned)n_launch;   // leaves at least one slot for every launch still to come
-        switch (g) {
-            case 0: slot += launch_sweep4_g<8>(ctx, phase, qb[g], qe[g], slot, cap); break;
-            case 1: slot += ctx->m_wide_layout ? launch_sweep8(ctx, phase, qb[g], qe[g], slot, cap) : launch_sweep4_g<16>(ctx, phase, qb[g], qe[g], slot, cap); break;
-            case 2: slot += launch_sweep4_g<32>(ctx, phase, qb[g], qe[g], slot, cap); break;
-            case 3: slot += launch_sweep4_g<64>(ctx, phase, qb[g], qe[g], slot, cap); break;      // one node per wave: several hundred views per face
-            default: slot += launch_sweep_generic(ctx, phase, qb[g], qe[g], slot, cap);
+    unsigned slot = part == MRF_PART_INTERIOR ? EPART_BOUNDARY : 0u;
+    const unsigned slot_end = part == MRF_PART_BOUNDARY ? EPART_BOUNDARY : EPART_BLOCKS;
+    for (int k = 0; k < n; ++k) {
+        const unsigned cap = slot_end - slot - (unsigned)(n - 1 - k);   // leaves at least one slot for every launch still to come
+        const uint32_t qb = L[k].qb, qe = L[k].qe;
+        switch (L[k].g) {
+            case 0: slot += launch_sweep4_g<8>(ctx, phase, qb, qe, slot, cap); break;
+            case 1: slot += ctx->m_wide_layout ? launch_sweep8(ctx, phase, qb, qe, slot, cap) : launch_sweep4_g<16>(ctx, phase, qb, qe, slot, cap); break;
+            case 2: slot += launch_sweep4_g<32>(ctx, phase, qb, qe, slot, cap); break;
+            case 3: slot += launch_sweep4_g<64>(ctx, phase, qb, qe, slot, cap); break;      // one node per wave: several hundred views per face
+            default: slot += launch_sweep_generic(ctx, phase, qb, qe, slot, cap);
         }
     }
 }
 // one sweep = every colour phase in turn (callers that shard the nodes exchange halos between the phases themselves)
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
-    for (uint32_t ph = 0; ph < ctx->m_colours; ++ph) mrf_sweep_phase(ctx, ph, nb0, ne0);
+    for (uint32_t ph = 0; ph < ctx->m_colours; ++ph) mrf_sweep_phase(ctx, ph, nb0, ne0, MRF_PART_ALL);
     // the sweep kernels leave the sweep's energy behind as per-block partials (valid when the range is the whole graph)
     ctx->m_energy_from_sweep = nb0 == 0 && ne0 >= ctx->csr_faces && ctx->m_colours > 0;
 }

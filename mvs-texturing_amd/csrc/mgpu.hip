@@ -11,7 +11,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
 void mrf_keep_best(mvs_ctx* ctx);
-void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0);
+void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, int part = MRF_PART_ALL);
 void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);

@@ -38,7 +38,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st);
 void dc_phase2(mvs_ctx* ctx);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
-void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0);
+void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, int part = MRF_PART_ALL);
 void mrf_sweep_energy_reduce(mvs_ctx* ctx);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
 void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
@@ -138,8 +138,12 @@ Rccl& rccl() {
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
-        // the soname first: a process that already loaded an RCCL (PyTorch ships its own next to its HIP runtime) gets that one
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (R.h) break; }
+        // MVS_RCCL_LIB names the library to bind instead (tests: tests/tools/librccl_fake.so runs the ranks of this communicator as threads
+        // sharing one device, so that the send / receive path below executes with real peers on a 1-GPU box); RTLD_LOCAL: its nccl* symbols
+        // must not shadow those of an RCCL the process loaded already.  Otherwise the soname first: a process that already loaded an RCCL
+        // (PyTorch ships its own next to its HIP runtime) gets that one.
+        if (const char* over = getenv("MVS_RCCL_LIB")) { if (over[0]) { R.h = dlopen(over, RTLD_NOW | RTLD_LOCAL); if (!R.h) return; } }
+        if (!R.h) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (R.h) break; }
         if (!R.h) return;
 #define MVS_SYM(f) R.f = reinterpret_cast<decltype(R.f)>(dlsym(R.h, "nccl" #f))
         MVS_SYM(GetUniqueId); MVS_SYM(CommInitRank); MVS_SYM(CommDestroy); MVS_SYM(AllReduce); MVS_SYM(AllGather); MVS_SYM(Send); MVS_SYM(Recv);
@@ -452,6 +456,14 @@ __global__ void halo_mark_kernel(const uint32_t* __restrict__ adj_ptr, const uin
         k_recv[atomicAdd(&counters[1], 1u)] = plan_key(q, 0u, j);          // column j comes from q
     }
 }
+// bnd[i] = 1 for an own node with an edge into another rank's part (a BOUNDARY node: its runs / label travel); everybody else 0
+__global__ void boundary_mark_kernel(const uint32_t* __restrict__ adj_ptr, const uint32_t* __restrict__ adj, Parts parts, int me, uint32_t nb, uint32_t ne, uint8_t* __restrict__ bnd) {
+    const uint32_t i = nb + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ne) return;
+    uint8_t b = 0;
+    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) if (part_of(parts, adj[e]) != me) b = 1;
+    bnd[i] = b;
+}
 __global__ void masked_counts_kernel(const uint32_t* __restrict__ counts_g, const uint32_t* __restrict__ keep, uint32_t F, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= F) out[i] = (i < F && keep[i]) ? counts_g[i] : 0u;
@@ -495,6 +507,12 @@ struct mvs_shard {
     Parts parts{}; int me = 0, P = 1; uint32_t F = 0, nb = 0, ne = 0;
     const uint32_t* d_adj_ptr = nullptr; const uint32_t* d_adj = nullptr; uint32_t E = 0;   // the adjacency lists in the LIBRARY's face order (see mvs_shard_create)
     DBuf<uint32_t> own_adj_ptr, own_adj;
+    // Boundary-first colour phases: bnd marks the own nodes with a cut edge (from adjacency + partition alone: made once, at creation).  The
+    // solver's schedule puts them in front of their colour class (k_mrf.hip "zones"), a phase sweeps them first, hands their runs and
+    // labels to the neighbours and sweeps the interior -- which reads nothing a peer writes -- while they travel.
+    DBuf<uint8_t> bnd;
+    hipStream_t comm_stream = nullptr; hipEvent_t ev_main = nullptr, ev_comm = nullptr;   // exchange route: pack / send-recv / unpack of a phase run beside its interior launch
+    ~mvs_shard() { if (ev_main) (void)hipEventDestroy(ev_main); if (ev_comm) (void)hipEventDestroy(ev_comm); if (comm_stream) (void)hipStreamDestroy(comm_stream); }
     // sharded table (global shape)
     DBuf<uint32_t> t_ptr; DBuf<uint16_t> t_view; DBuf<float> t_cost; DBuf<uint32_t> counts_g, keep, tmp_a, tmp_b, tmp_c;
     uint64_t nnz_global = 0;
@@ -648,8 +666,8 @@ void build_plan(mvs_shard* S) {
 unsigned grid_for(uint64_t n) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 4096)); }
 
 // after colour phase `ph`: message runs written in this phase over cut edges + labels of this phase's boundary nodes
-void exchange_phase(mvs_shard* S, uint32_t ph) {
-    mvs_ctx* ctx = S->ctx; hipStream_t s = ctx->stream;
+void exchange_phase(mvs_shard* S, uint32_t ph, hipStream_t s) {
+    mvs_ctx* ctx = S->ctx;
     const int P = S->P; const uint32_t C = S->phases;
     std::vector<uint64_t> so_m, ro_m, so_n, ro_n;
     phase_offsets(S->msg_send, P, C, ph, 1, so_m); phase_offsets(S->msg_recv, P, C, ph, 1, ro_m);
@@ -922,6 +940,16 @@ mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_b
     // The shard IS this layout (parts, renumbered lists, later the halo plan): the context keeps it for the shard's data-cost passes
     // instead of deriving the same order from the same mesh in every step; mvs_scene_set_mesh (another mesh) un-pins it.
     ctx->order_pinned = true;
+    S->bnd.ensure((size_t)S->F + 4);
+    MVS_HIP(hipMemsetAsync(S->bnd.p, 0, (size_t)S->F + 4, ctx->stream));
+    if (S->ne > S->nb && S->P > 1) {
+        hipLaunchKernelGGL(boundary_mark_kernel, dim3((S->ne - S->nb + 255) / 256), dim3(256), 0, ctx->stream, S->d_adj_ptr, S->d_adj, S->parts, S->me, S->nb, S->ne, S->bnd.p);
+        MVS_LAUNCH_CHECK();
+    }
+    MVS_HIP(hipStreamCreateWithFlags(&S->comm_stream, hipStreamNonBlocking));
+    MVS_HIP(hipEventCreateWithFlags(&S->ev_main, hipEventDisableTiming));
+    MVS_HIP(hipEventCreateWithFlags(&S->ev_comm, hipEventDisableTiming));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
     *out = S.release();
     MVS_API_END
 }
@@ -1081,7 +1109,10 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     if (P.region_rounds > 0) throw StatusError(MVS_ERR_UNSUPPORTED, "region moves (region_rounds > 0) are a single-context option");
     const uint32_t nb = S->nb, ne = S->ne;
     set_adjacency(ctx, S->d_adj_ptr, S->d_adj, 1, /*table_order=*/true);
-    { Prof pr(ctx, "mrf_setup"); mrf_setup(ctx, &P); }
+    { Prof pr(ctx, "mrf_setup");
+      struct Marks { mvs_ctx* c; ~Marks() { c->m_bnd = nullptr; } } marks{ctx};   // the set-up is the only reader: no pointer into this shard stays behind
+      ctx->m_bnd = S->P > 1 ? S->bnd.p : nullptr;
+      mrf_setup(ctx, &P); }
     // the halo plan follows from adjacency, partition, colouring and the message layout, i.e. from the column lengths: kept while
     // mvs_shard_data_costs found them unchanged (the layout's size is checked as well)
     if (!S->plan_valid || S->plan_colours != ctx->m_colours || S->plan_total != ctx->m_total) {
@@ -1106,19 +1137,36 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     }
     if (S->peer) peer_publish(S);
     PeerHub* hub = S->peer ? comm->peers() : nullptr;
+    // A colour phase: BOUNDARY nodes first, their runs and labels leave, then the INTERIOR -- whose nodes have no neighbour on another rank,
+    // so their launch neither waits for a peer nor reads anything a peer stores; the hand-over of phase c has the whole interior launch of
+    // phase c to land before this rank's boundary nodes of colour c + 1 need it.  (A colour class is an independent set: same values.)
+    const bool split = S->P > 1;
+    bool comm_busy = false;
     while (issued < P.max_sweeps && !pg.stopped) {
         for (uint32_t ph = 0; ph < S->phases; ++ph) {
             if (S->peer && ph > 0) {   // the neighbours' runs of the previous phase are in place (phase 0: the all-rank wait of the last sweep's energy)
                 Prof pr(ctx, "mrf_halo");
                 for (int q : S->nbr) peer_wait(S, q, S->n_ev - 1);
+            } else if (comm_busy) {    // exchange route: the previous phase's unpack is behind ev_comm
+                MVS_HIP(hipStreamWaitEvent(s, S->ev_comm, 0)); comm_busy = false;
             }
-            { Prof pr(ctx, "mrf_sweep"); mrf_sweep_phase(ctx, ph, nb, ne); }
+            if (!split) { Prof pr(ctx, "mrf_sweep"); mrf_sweep_phase(ctx, ph, nb, ne, MRF_PART_ALL); continue; }
+            { Prof pr(ctx, "mrf_sweep_boundary"); mrf_sweep_phase(ctx, ph, nb, ne, MRF_PART_BOUNDARY); }
             if (S->peer) {
                 Prof pr(ctx, "mrf_halo");
                 peer_push_phase(S, ph);
                 if (ph + 1 < S->phases) peer_record(S);
-            } else if (S->P > 1) { Prof pr(ctx, "mrf_halo"); exchange_phase(S, ph); }
+            } else {
+                // pack, grouped send / recv and unpack on the shard's second stream, beside the interior launch
+                MVS_HIP(hipEventRecord(S->ev_main, s));
+                MVS_HIP(hipStreamWaitEvent(S->comm_stream, S->ev_main, 0));
+                exchange_phase(S, ph, S->comm_stream);
+                MVS_HIP(hipEventRecord(S->ev_comm, S->comm_stream));
+                comm_busy = true;
+            }
+            { Prof pr(ctx, "mrf_sweep"); mrf_sweep_phase(ctx, ph, nb, ne, MRF_PART_INTERIOR); }
         }
+        if (comm_busy) { MVS_HIP(hipStreamWaitEvent(s, S->ev_comm, 0)); comm_busy = false; }   // (the all-reduce below runs on the main stream: one communicator, one order)
         {   // the sweep's energy: own share (accumulated by the sweep kernels, or the energy kernel on the generic path),
             // all-reduced, fed to the device-side stop rule -- the host polls the report of `lag` sweeps ago
             Prof pr(ctx, "mrf_energy");

@@ -3,7 +3,7 @@
 # first line); every step has its own timeout and writes under gpurun_out/ (tag: $TAG, default r05).
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 STEPS=${STEPS:-"smoke tests bench cliffs pmc prof"}
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has smoke; then echo "== smoke + quick bench (config 2)"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2

@@ -769,9 +769,10 @@ def test_cpp_sharded_path_equals_single_gpu(name, P):
         assert cut_share < 0.25, cut_share
 
 
-def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check_oracle_labels=False, peer_push=None):
+def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check_oracle_labels=False, peer_push=None, rccl_uid=None):
     """runs the scene through a single context and through P thread-ranks of csrc/shard.hip; asserts equality (see the callers);
-    returns the share of faces that are halo faces of some rank"""
+    returns the share of faces that are halo faces of some rank.  rccl_uid: every rank makes its communicator with mvs_comm_create_rccl
+    from this unique id (inside the rank's thread: ncclCommInitRank blocks until all ranks joined) instead of the in-process one."""
     import threading
     import torch
     faces, normals, adj_ptr, adj = s.faces, s.normals, s.adj_ptr, s.adj
@@ -806,12 +807,15 @@ def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check
         pb_arg = pb
     else:
         pb, pb_arg = eq, None                                      # the library's own equal cut
-    comms = M.shard.Comm.local(P)
+    comms = M.shard.Comm.local(P) if rccl_uid is None else [None] * P
     out, err = [None] * P, [None] * P
 
     def rank_main(r):
         try:
             torch.cuda.set_device(0)
+            if rccl_uid is not None:
+                comms[r] = M.shard.Comm.rccl(0, r, P, rccl_uid)
+                assert comms[r].info() == {"rank": r, "world": P, "peer_push": False}
             c = M.Context(0); c.set_mesh(tv, tf, tn); c.set_views(s.cams, timg)
             if max_labels: c.set_option("max_labels", max_labels)
             if peer_push is not None: c.set_option("shard_peer_push", peer_push)
@@ -828,7 +832,7 @@ def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check
             sh.close(); c.close()
         except Exception as e:  # noqa: BLE001
             err[r] = e
-            comms[r].abort()          # peers blocked in a sharded call get an error instead of waiting for this rank
+            if comms[r] is not None: comms[r].abort()          # peers blocked in a sharded call get an error instead of waiting for this rank
             raise
     th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(P)]
     for t in th: t.start()
@@ -854,7 +858,7 @@ def _cpp_shards_equal_single(s, P, reps=2, settings_kw=None, max_labels=0, check
                (st0["energy_fixed"], st0["cut_edges"], st0["sweeps"], st0["icm_iters"], st0["unseen"]), "rank %d" % r
         assert (info["boundary_nodes"] > 0 and info["msg_bytes_per_sweep"] > 0) or len(own) < 100
         # the sweep loop's transport: runs stored straight into the peers' arrays unless switched off (the in-process ranks share an address space)
-        assert info["peer_push"] == (P > 1 and peer_push != 0) and (info["phases_pushed"] > 0) == info["peer_push"], info
+        assert info["peer_push"] == (P > 1 and peer_push != 0 and rccl_uid is None) and (info["phases_pushed"] > 0) == info["peer_push"], info
         got[own] = labels
     assert np.array_equal(got, lab0), "labels depend on the partition"
     for c in comms: c.close()
@@ -980,6 +984,32 @@ def test_config5_one_ranks_share_against_the_oracle():
     assert np.array_equal(lo, lg), "labels differ from the oracle at config 5's per-rank size (%d faces)" % int((lo != lg).sum())
     for k in ("energy_fixed", "cut_edges", "sweeps", "icm_iters", "unseen"):
         assert so[k] == sg[k], k
+
+
+@isolated
+@pytest.mark.parametrize("name,P", [("bumpy", 2), ("bumpy", 3), ("spiky32", 8), ("bumpy", (0.0, 0.5, 0.5, 1.0)), ("bumpy-shuffled", 3)],
+                         ids=["bumpy-2", "bumpy-3", "spiky32-8", "bumpy-empty-part", "bumpy-shuffled-3"])
+def test_cpp_sharded_path_over_the_rccl_communicator_with_peers(name, P):
+    """The RCCL communicator of csrc/shard.hip (mvs_comm_create_rccl; RcclComm::post / exchange2: one ncclGroup of sends and receives per
+    colour phase on the shard's second stream, beside the interior launch; ncclAllReduce of the data-cost barrier, of the per-sweep energy
+    and of the ICM counts; ncclAllGather of the column lengths; the neighbour exchange of the halo columns) at world size 2, 3, 4 and 8
+    WITH PEERS: the library binds tests/tools/librccl_fake.so (MVS_RCCL_LIB), a test double that runs the ranks as threads sharing the
+    one device of a test box and moves the bytes with hipMemcpyAsync under NCCL's matching / group / stream-order contract.  Tables
+    (own + halo columns), labels of all faces, energy, sweeps and ICM rounds equal the single context's."""
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "librccl_fake.so")
+    assert os.path.exists(fake), "tests/tools/librccl_fake.so is not built (__graft_entry__.build())"
+    assert os.environ.get("MVS_TEST_ISOLATED") == "1"      # a process of its own: the product binds its RCCL once per process
+    os.environ["MVS_RCCL_LIB"] = fake
+    uid = M.shard.unique_id()
+    assert uid.startswith(b"FAKE-RCCL"), "the product did not bind the test double"
+    s = get_scene(name.replace("-shuffled", ""))
+    if name.endswith("-shuffled"):
+        s = M.synth.permute_scene(s, seed=5)
+    _cpp_shards_equal_single(s, P, reps=2, rccl_uid=uid)
+    st = (C.c_uint64 * 4)()
+    C.CDLL(fake).fake_rccl_stats(st)
+    n_ranks = P if isinstance(P, int) else len(P) - 1
+    assert st[0] > 100 and st[1] > 0 and st[2] > 50 and st[3] > 20 * n_ranks, list(st)   # sends, bytes, groups, collectives that went through it
 
 
 @isolated
