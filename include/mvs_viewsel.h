@@ -81,13 +81,15 @@ typedef struct {
  * (view_selection.cpp:84,103-115); mapMAP is replaced by a GPU-resident
  * tree-reweighted max-product solver -- colour-phased Gauss-Seidel sweeps + monotone ICM polish --
  * whose knobs are below.  mvs_mrf_default_params gives the shipped defaults
- * (200 / 20 / 5 / 0.002 / 0.2 / 0.8 / 50 / 0). */
+ * (200 / 20 / 5 / 0.005 / 0.2 / 0.8 / 50 / 0).  Round 6 scored damping schedule x stop rule in milliseconds
+ * (profiles/r06_schedule_score_c3.json): alpha = 0.2 on every fourth sweep with window 5 / 0.5 % reaches +0.99 % over the LP bound
+ * in 39 sweeps at BASELINE config 3, where rounds 1 - 5 (alpha on odd sweeps, 0.2 %) took 44 sweeps to +0.94 %. */
 typedef struct {
     int32_t max_sweeps;
     int32_t min_sweeps;
     int32_t window;         /* stop when the best energy gained < min_improvement over `window` sweeps; cf. StopWhenReturnsDiminish(5, 0.01) view_selection.cpp:84 */
     float min_improvement;
-    float damping;          /* alpha of m' = (1 - alpha) new + alpha old on ODD sweeps (1st, 3rd, ...); even sweeps are undamped */
+    float damping;          /* alpha of m' = (1 - alpha) new + alpha old on every FOURTH sweep (1st, 5th, 9th, ...); the others are undamped */
     float rho;
     int32_t icm_iters;
     int32_t region_rounds;  /* > 0: after the ICM polish, up to this many rounds of REGION MOVES (a connected same-label patch takes a

@@ -43,6 +43,12 @@ mvs_status mvs_ctx_mrf_setup(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32
  * ends at its first instruction -- it changes no message, no decode and no energy partial: the best labeling is frozen.  A driver that
  * wants more sweeps than the rule allows raises max_sweeps / min_sweeps in the params of mvs_ctx_mrf_setup instead. */
 mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t node_begin, uint32_t node_end);
+/* Boundary-first phases (what csrc/shard.hip does per rank): marks_device[i] != 0 puts node i into the BOUNDARY zone of its colour class
+ * (own nodes with an edge into another rank's part); a phase then runs as part 1 (boundary zone) -> hand-over -> part 2 (interior zone).
+ * part 0 = both zones.  A solve keeps to one of the two modes.  Same values either way: a colour class is an independent set. */
+mvs_status mvs_ctx_mrf_setup_marked(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device,
+                                    const mvs_mrf_params* params, const uint8_t* marks_device);
+mvs_status mvs_ctx_mrf_sweep_phase_part(mvs_ctx* ctx, uint32_t phase, uint32_t node_begin, uint32_t node_end, int part);
 /* all phases in turn over nodes [node_begin, node_end) (no exchange in between: unsharded use) */
 mvs_status mvs_ctx_mrf_sweep(mvs_ctx* ctx, uint32_t node_begin, uint32_t node_end);
 /* message layout for the halo planner: in_off_host[e] = first message element of the run of directed edge e

@@ -190,7 +190,7 @@ bool stash_enabled() { const char* e = getenv("MVS_KEEP_TABLE"); return !(e && e
 // hipGraphExecUpdate; only a changed topology (another number of node classes per colour) instantiates a new one.
 // Returns false -- the caller then keeps launching directly -- if the runtime refuses any step.
 template <class Sweep>
-static bool prepare_sweep_graph(mvs_ctx* ctx, Sweep&& one_sweep) {
+static bool prepare_sweep_graph(mvs_ctx* ctx, Sweep&& one_sweep, int n_sweeps = 2) {
     if (!ctx->cap_stream && hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->mrf_graph = 0; return false; }
     const uint32_t steps0 = ctx->steps_issued, sweep0 = ctx->m_sweep_no;
     hipStream_t user = ctx->stream;
@@ -198,7 +198,7 @@ static bool prepare_sweep_graph(mvs_ctx* ctx, Sweep&& one_sweep) {
     bool ok = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {
         ctx->stream = ctx->cap_stream;
-        try { one_sweep(); one_sweep(); } catch (...) { ok = false; }
+        try { for (int k = 0; k < n_sweeps; ++k) one_sweep(); } catch (...) { ok = false; }
         ctx->stream = user;
         if (hipStreamEndCapture(ctx->cap_stream, &graph) != hipSuccess || !graph) ok = false;
     }
@@ -312,7 +312,7 @@ const char* mvs_status_string(mvs_status s) {
 }
 
 void mvs_mrf_default_params(mvs_mrf_params* p) {
-    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
+    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.005f;
     p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50; p->region_rounds = 0;
 }
 void mvs_default_settings(mvs_settings* s) {  /* settings.h:85-90 */
@@ -393,6 +393,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_wide") ctx->mrf_wide = value != 0;   // takes effect with the next solve's set-up
     else if (n == "mrf_graph") ctx->mrf_graph = value != 0;
     else if (n == "mrf_late_old") ctx->mrf_late_old = (int)value;
+    else if (n == "mrf_damp_period") ctx->mrf_damp_period = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
     else if (n == "face_order") { ctx->face_order = value != 0 ? 1 : 0; ctx->order_pinned = false; }   // takes effect with the next data-cost pass (the active table keeps the order it was made in)
@@ -670,7 +671,9 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     // for the result (the best labeling is frozen on the device).
     // reports outstanding at any time: lag + 2 with direct launches, up to lag + 4 under graph replay (a graph issues two steps before
     // the host polls, and one more graph stays queued behind it): the ring of RING slots must hold them all
-    const int lag = std::max(0, std::min(ctx->mrf_lag, (int)mvs_ctx::RING - 5));
+    // sweeps per graph = one period of the damping schedule (2: a damped and an undamped sweep)
+    const int GS = ctx->mrf_damp_period > 2 ? ctx->mrf_damp_period : 2;
+    const int lag = std::max(0, std::min(ctx->mrf_lag, (int)mvs_ctx::RING - 2 * GS - 1));
     mvs_mrf_progress pg; memset(&pg, 0, sizeof(pg));
     auto report = [&](uint32_t n) {
         mrf_poll(ctx, n, &pg);
@@ -692,19 +695,19 @@ mvs_status mvs_ctx_view_selection(mvs_ctx* ctx, const uint32_t* adj_ptr, const u
     // the host's ~3.5 us per launch (MI355X_MICROARCH.md "graph-replay-floor"), not by the GPU.  Every launch of the loop has
     // the same arguments each time (the step kernel numbers its reports itself), sweeps queued after the device-side stop rule fired
     // end at their first instruction, so replaying past the stop costs microseconds.  Not while profiling (stage marks are events).
-    bool graphs = ctx->mrf_graph != 0 && !ctx->profile && P.max_sweeps >= 6 && F > 0;
-    while (issued < std::min(2, P.max_sweeps) && !pg.stopped) {
+    bool graphs = ctx->mrf_graph != 0 && !ctx->profile && P.max_sweeps >= 3 * GS && F > 0 && GS <= 4;
+    while (issued < std::min(GS, P.max_sweeps) && !pg.stopped) {
         one_sweep(); ++issued;
         if (issued - lag > polled) report((uint32_t)++polled);
     }
-    if (graphs && issued == 2 && !pg.stopped) graphs = prepare_sweep_graph(ctx, one_sweep);
+    if (graphs && issued == GS && !pg.stopped) graphs = prepare_sweep_graph(ctx, one_sweep, GS);
     while (issued < P.max_sweeps && !pg.stopped) {
-        if (graphs && issued + 2 <= P.max_sweeps) {
+        if (graphs && issued + GS <= P.max_sweeps) {
             MVS_HIP(hipGraphLaunch(ctx->sweep_exec, s));
-            ctx->steps_issued += 2; ctx->m_sweep_no += 2; issued += 2; ++ctx->graph_launches;
+            ctx->steps_issued += (uint32_t)GS; ctx->m_sweep_no += (uint32_t)GS; issued += GS; ++ctx->graph_launches;
             ctx->icm_dirty_valid = false; ctx->best_resolved = false; ctx->exact_valid = false;
             // one whole graph stays queued behind the one whose reports are read
-            while (issued - lag - 2 > polled && !pg.stopped) report((uint32_t)++polled);
+            while (issued - lag - GS > polled && !pg.stopped) report((uint32_t)++polled);
         } else {
             one_sweep(); ++issued;
             if (issued - lag > polled) report((uint32_t)++polled);

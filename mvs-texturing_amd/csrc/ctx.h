@@ -236,11 +236,12 @@ struct mvs_ctx {
     // of a key >= `key` (host copy of m_sub); positions [0, m_n_fast) are the fast nodes
     mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c, m_sub; mvs::DBuf<uint8_t> m_cls; uint32_t m_colours = 0, m_n_fast = 0; std::vector<uint32_t> m_sub_begin;
     const uint8_t* m_bnd = nullptr;   // per node: 1 = boundary node of a sharded caller (own node with an edge into another rank's part) -> zone 0 of the schedule (k_mrf.hip); null: no marks
+    int mrf_damp_period = 4;     // damped sweeps: 1, 1 + p, 1 + 2p, ... (4: the solver's definition, restated in the oracle; other values are experiment knobs)
     int mrf_force_generic = 0;   // test hook: every node takes the generic sweep kernel
     int mrf_wide = 1;            // class-1 nodes (neighbourhood columns of 33 .. 64 labels) through mrf_sweep8_kernel: 8 lanes x 8 labels (k_mrf.hip); 0: mrf_sweep4_kernel<16>
     bool m_wide_layout = false;  // ... as the last mrf_setup laid the records and runs out
     uint32_t m_range_nb = 0, m_range_ne = 0; std::vector<uint32_t> m_range_q;   // cached own share of every sub-class
-    uint32_t m_sweep_no = 0;   // sweeps started since mrf_setup (1-based inside a sweep): odd sweeps are damped
+    uint32_t m_sweep_no = 0;   // sweeps started since mrf_setup (1-based inside a sweep): sweeps 1, 5, 9, ... are damped
     mvs_mrf_params m_params{};
     // device-side stop rule (k_mrf.hip mrf_step): solver state in HBM, per-step reports through a pinned ring
     static constexpr uint32_t RING = 16;

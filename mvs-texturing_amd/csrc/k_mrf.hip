@@ -1493,7 +1493,14 @@ void wait_report(mvs_ctx* ctx, uint32_t seq_slot, uint32_t seq) {
 // (C3: 0.9 % higher final energy), but damping every second sweep suppresses that just as well as damping every sweep
 // (C3: 44 sweeps to E = 1 111 890 with 0.2 on odd sweeps vs 47 to 1 110 970 with 0.1 on all) -- and an undamped sweep
 // does not re-read its previous outgoing messages.
-static float sweep_alpha(const mvs_ctx* ctx) { return (ctx->m_sweep_no & 1u) ? ctx->m_params.damping : 0.0f; }
+// Round 6 re-scored the schedule in milliseconds (scripts/schedule_score.py, profiles/r06_schedule_score_*.json): an undamped launch is 14 %
+// cheaper than a damped one, and damping every FOURTH sweep (1st, 5th, ...) holds the oscillation as well: the definition is period 4.
+// (option "mrf_damp_period", an experiment knob: 4 = the definition; p damps sweeps 1, p + 1, 2p + 1, ...; 1 every sweep; 0 none)
+static float sweep_alpha(const mvs_ctx* ctx) {
+    const uint32_t p = (uint32_t)std::max(ctx->mrf_damp_period, 0);
+    if (p == 0) return 0.0f;
+    return (p == 1 || ctx->m_sweep_no % p == 1u) ? ctx->m_params.damping : 0.0f;
+}
 
 // one launch of the fast kernel over positions [qb, qe) (one (colour, class) range of the schedule order); its per-block energy
 // partials go to slots [slot, slot + blocks) of the phase's region.  Returns the number of blocks (= slots) used.

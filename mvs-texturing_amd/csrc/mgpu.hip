@@ -149,6 +149,26 @@ mvs_status mvs_ctx_mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, u
     mrf_sweep_phase(ctx, phase, nb0, ne0);
     MVS_API_END
 }
+/* the set-up with BOUNDARY MARKS (marks_device[i] != 0: node i goes to the boundary zone of its colour class, see k_mrf.hip "zones") and one
+ * zone of a colour phase: what csrc/shard.hip does per rank, for drivers / measuring scripts one level below it */
+mvs_status mvs_ctx_mrf_setup_marked(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int adj_on_device, const mvs_mrf_params* params, const uint8_t* marks_device) {
+    if (!ctx || !adj_ptr || !adj) return api_fail(MVS_ERR_INVALID, "null argument");
+    if (!ctx->have_costs) return api_fail(MVS_ERR_STATE, "mrf setup needs data costs");
+    MVS_API_BEGIN
+    mvs_mrf_params P; if (params) P = *params; else mvs_mrf_default_params(&P);
+    set_adjacency(ctx, adj_ptr, adj, adj_on_device, false);
+    struct Marks { mvs_ctx* c; ~Marks() { c->m_bnd = nullptr; } } marks{ctx};
+    ctx->m_bnd = marks_device;
+    mrf_setup(ctx, &P);
+    MVS_API_END
+}
+mvs_status mvs_ctx_mrf_sweep_phase_part(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, int part) {
+    if (!ctx || nb0 > ne0 || ne0 > ctx->csr_faces || phase >= ctx->m_colours || part < 0 || part > 2) return api_fail(MVS_ERR_INVALID, "bad phase, node range or part");
+    MVS_API_BEGIN
+    Prof pr(ctx, part == MRF_PART_BOUNDARY ? "mrf_sweep_boundary" : "mrf_sweep");
+    mrf_sweep_phase(ctx, phase, nb0, ne0, part);
+    MVS_API_END
+}
 mvs_status mvs_ctx_mrf_layout(mvs_ctx* ctx, uint32_t* in_off_host, uint64_t n_edges) {
     if (!ctx || (n_edges && !in_off_host)) return api_fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN

@@ -93,7 +93,7 @@ def blocks_lib_path():
 # entry points of include/mvs_viewsel_blocks.h (libmvs_blocks.so), everything else is the product library's
 BLOCK_SYMBOLS = frozenset((
     "mvs_ctx_dc_get_max", "mvs_ctx_dc_set_max", "mvs_ctx_dc_get_histogram", "mvs_ctx_dc_set_histogram", "mvs_ctx_costs_export",
-    "mvs_ctx_mrf_setup", "mvs_ctx_mrf_sweep", "mvs_ctx_mrf_sweep_phase", "mvs_ctx_mrf_layout", "mvs_ctx_mrf_gather", "mvs_ctx_mrf_scatter",
+    "mvs_ctx_mrf_setup", "mvs_ctx_mrf_setup_marked", "mvs_ctx_mrf_sweep", "mvs_ctx_mrf_sweep_phase", "mvs_ctx_mrf_sweep_phase_part", "mvs_ctx_mrf_layout", "mvs_ctx_mrf_gather", "mvs_ctx_mrf_scatter",
     "mvs_ctx_mrf_energy", "mvs_ctx_mrf_keep_best", "mvs_ctx_mrf_step", "mvs_ctx_mrf_poll", "mvs_ctx_mrf_icm_gain", "mvs_ctx_mrf_icm_apply",
     "mvs_ctx_mrf_labels"))
 
@@ -145,6 +145,7 @@ def load_library():
         "mvs_ctx_costs_upload": [vp, C.POINTER(CCsr), i32], "mvs_ctx_costs_export": [vp, vp, vp, vp],
         "mvs_ctx_view_selection": [vp, vp, vp, i32, C.POINTER(MrfParams), vp, i32, C.POINTER(MrfStats)],
         "mvs_ctx_mrf_setup": [vp, vp, vp, i32, C.POINTER(MrfParams)], "mvs_ctx_mrf_sweep": [vp, u32, u32],
+        "mvs_ctx_mrf_setup_marked": [vp, vp, vp, i32, C.POINTER(MrfParams), vp], "mvs_ctx_mrf_sweep_phase_part": [vp, u32, u32, u32, i32],
         "mvs_ctx_mrf_num_phases": [vp, C.POINTER(u32)], "mvs_ctx_mrf_diagnostics": [vp, C.POINTER(u32)], "mvs_ctx_mrf_sweep_phase": [vp, u32, u32, u32], "mvs_ctx_mrf_layout": [vp, vp, u64],
         "mvs_ctx_mrf_gather": [vp, i32, vp, u64, vp], "mvs_ctx_mrf_scatter": [vp, i32, vp, u64, vp],
         "mvs_ctx_mrf_energy": [vp, i32, u32, u32, vp], "mvs_ctx_mrf_keep_best": [vp],

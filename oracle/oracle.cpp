@@ -874,7 +874,7 @@ void orc_csr_free(orc_csr* c) {
 //          ( c and lam taken in damped code units: cs = c * oms, lam_s = lam * oms, oms = (1 - alpha) * scale )
 //          raw   = (p == NONE) ? lam_s : fminf(cs[p] - cmin_s, lam_s)
 //          code' = rne( fma(old code, alpha, raw) ), saturated at 255
-//        with alpha = damping on ODD sweeps (1st, 3rd, ...) and 0 on even sweeps.
+//        with alpha = damping on every fourth sweep (1st, 5th, ...: MRF_DAMP_PERIOD) and 0 on the others.
 //  * After each sweep the decoded labeling's energy is evaluated exactly in
 //    32.32 fixed point (integer sums are order independent); the best labeling
 //    so far is kept.  Stop like StopWhenReturnsDiminish(5, 0.01)
@@ -988,9 +988,12 @@ int mrf_colour(const Mrf& g, std::vector<uint8_t>& colour) {
     return n_colours;
 }
 
+constexpr uint32_t MRF_DAMP_PERIOD = 4u;   // damped sweeps: 1, 5, 9, ... (csrc/k_mrf.hip sweep_alpha restates it)
+
 // One phase of a sweep: all nodes of colour `phase` (an independent set) recompute their outgoing messages IN PLACE
 // from the current messages -- colour-phased Gauss-Seidel.  Within a phase no node reads what another writes.
-// Damping schedule: alpha = P.damping on ODD sweeps (1st, 3rd, ...), none on even sweeps.
+// Damping schedule: alpha = P.damping on every FOURTH sweep (1st, 5th, 9th, ...), none on the others (round 6: scored in milliseconds
+// on configs 2, 3 and the real-like scene -- profiles/r06_schedule_score_*.json; rounds 1 - 5 damped the odd sweeps).
 // Messages live as their 8-bit codes (value = code * step); the update is written on the codes, with explicit fused
 // multiply-adds (IEEE fma: one rounding, identical on the CPU and the GPU):
 //   Sc[t] = sum of the incoming codes (small integers: exact in fp32 in any order)
@@ -1002,7 +1005,7 @@ int mrf_colour(const Mrf& g, std::vector<uint8_t>& colour) {
 void mrf_sweep(const Mrf& g, const orc_mrf_params& P, std::vector<uint8_t>& msg,
                std::vector<uint32_t>& sel, int n_threads, const uint8_t* colour, int phase, uint32_t sweep_no) {
     const float lam = 1.0f / P.rho;
-    const float alpha = (sweep_no & 1u) ? P.damping : 0.0f;
+    const float alpha = (sweep_no % MRF_DAMP_PERIOD == 1u) ? P.damping : 0.0f;
     const MsgQ mq = msg_q(lam);
     const float kappa = P.rho * mq.step, nstep = -mq.step, oms = (1.0f - alpha) * mq.scale, lam_s = lam * oms;
 #pragma omp parallel num_threads(n_threads)
@@ -1202,7 +1205,7 @@ uint32_t orc_msg_code(float raw, float rho, float alpha, uint32_t old_code) {
 void orc_mrf_set_trace(uint64_t* buf, int len) { g_trace = buf; g_trace_len = len; }
 
 void orc_mrf_default_params(orc_mrf_params* p) {
-    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.002f;
+    p->max_sweeps = 200; p->min_sweeps = 20; p->window = 5; p->min_improvement = 0.005f;
     p->damping = 0.2f; p->rho = 0.8f; p->icm_iters = 50; p->region_rounds = 0;
 }
 

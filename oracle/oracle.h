@@ -118,7 +118,7 @@ typedef struct {
     int32_t min_sweeps;
     int32_t window;          /* StopWhenReturnsDiminish(5, 0.01): window ...   (view_selection.cpp:84) */
     float min_improvement;   /* ... and relative improvement                                            */
-    float damping;           /* message damping alpha in [0,1), applied on odd sweeps (1st, 3rd, ...); even sweeps are undamped */
+    float damping;           /* message damping alpha in [0,1), applied on every fourth sweep (1st, 5th, ...); the others are undamped */
     float rho;               /* edge appearance probability (1 = max-product BP, <1 = tree-reweighted) */
     int32_t icm_iters;       /* monotone ICM polish iterations after decoding */
     int32_t region_rounds;   /* > 0: up to this many rounds of region moves (+ ICM) after the polish; 0 = off (default) */

@@ -50,19 +50,34 @@ def timed(fn, c, reps=5):
     return float(np.median(out[1:]))
 
 
-def measure(nb, ne, keep):
+def measure(nb, ne, keep, marks=None):
     c = M.Context(0)
     c.costs_upload(table(keep))
     ops = G.GpuShardOps(c, t_ap, t_ad, M.viewsel.default_mrf_params())
     res = {"faces_own": int(ne - nb), "columns_filled": int(keep.sum()), "entries": int(K2[keep].sum())}
-    res["mrf_setup_ms"] = timed(ops.setup, c)
+    L = c.L
+    if marks is not None:   # the set-up csrc/shard.hip runs: boundary nodes in front of their colour class
+        t_marks = torch.from_numpy(marks.astype(np.uint8)).to(dev)
+        params = M.viewsel.default_mrf_params()
+        setup = lambda: M.viewsel._check(L, L.mvs_ctx_mrf_setup_marked(c.h, C.c_void_p(t_ap.data_ptr()), C.c_void_p(t_ad.data_ptr()), 1, C.byref(params), C.c_void_p(t_marks.data_ptr())))
+        res["boundary_nodes"] = int(marks.sum())
+    else:
+        setup = ops.setup
+    res["mrf_setup_ms"] = timed(setup, c)
     nph = ops.n_phases()
 
-    def sweeps():
+    def sweeps(part=None):
         for _ in range(a.sweeps):
             for ph in range(nph):
-                ops.sweep_phase(ph, nb, ne)
-    res["sweep_ms"] = timed(sweeps, c, reps=3) / a.sweeps
+                if part is None: ops.sweep_phase(ph, nb, ne)
+                else:
+                    for p in part: M.viewsel._check(L, L.mvs_ctx_mrf_sweep_phase_part(c.h, ph, nb, ne, p))
+    if marks is None:
+        res["sweep_ms"] = timed(sweeps, c, reps=3) / a.sweeps
+    else:   # launches back to back on one stream, no hand-over in between: the GPU work of a rank's phase by zone
+        res["sweep_ms"] = timed(lambda: sweeps((1, 2)), c, reps=3) / a.sweeps
+        res["boundary_launch_us"] = timed(lambda: sweeps((1,)), c, reps=3) / a.sweeps / nph * 1e3
+        res["interior_launch_us"] = timed(lambda: sweeps((2,)), c, reps=3) / a.sweeps / nph * 1e3
     res["colour_phases"] = nph
     res["icm_gain_full_pass_ms"] = timed(lambda: ops.icm_gain(nb, ne), c)
     c.close()
@@ -73,7 +88,10 @@ whole = measure(0, F, np.ones(F, bool))
 nb, ne = int(cut[0]), int(cut[1])
 own = np.zeros(F, bool); own[nb:ne] = True
 halo = np.zeros(F, bool); halo[adj2[aptr2[nb]:aptr2[ne]]] = True
-share = measure(nb, ne, own | halo)
+bnd = np.zeros(F, bool)
+src_face = np.repeat(np.arange(F), np.diff(aptr2.astype(np.int64)))
+bnd[src_face[(~own[adj2]) & own[src_face]]] = True      # own faces with a neighbour in another part
+share = measure(nb, ne, own | halo, marks=bnd)
 share["halo_faces"] = int((halo & ~own).sum())
 print(json.dumps({"workload": "config %s, MRF half: the whole table and one rank's share of %d (own + halo columns of the global-shape table, nodes [0, F/%d) of the library's order), "
                               "each alone on one MI355X; wall clock around synchronised calls of the building-block API (launch gaps included)" % (a.config, a.parts, a.parts),
