@@ -28,7 +28,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: the HIP runtime torch ships is the one the library binds to)
 
 import mvs_texturing_amd as M  # noqa: E402
-from mvs_texturing_amd import multigpu as G  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+import multigpu as G  # noqa: E402  (test harness, tests/tools: the gloo contract mode and equal_parts only; never the product path)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
@@ -660,7 +661,7 @@ def main():
         scene = M.synth.permute_scene(scene, seed=11)   # experiments: the headline workload itself in random face / vertex order
     # The mesh goes in AS BUILT (icosphere construction order), like a mesh file: the library lays it out itself, on the device, inside
     # the timed step (csrc/k_bvh.hip build_scene_order), and the parts of the sharded path are contiguous ranges of ITS order
-    # (mvs_ctx_partition_faces).  The gloo test harness (mvs-texturing_amd/multigpu.py) cuts the caller's numbering itself (its parts
+    # (mvs_ctx_partition_faces).  The gloo test harness (tests/tools/multigpu.py) cuts the caller's numbering itself (its parts
     # are whatever the construction order makes them: a test of the collectives' call pattern, not of the partition).
     harness = (world > 1 or args.shard) and args.backend != "nccl"
     faces, normals, adj_ptr, adj = scene.faces, scene.normals, scene.adj_ptr, scene.adj
@@ -727,7 +728,7 @@ def main():
             info["plan"] = dict(info["shard"].plan_info(), **info["shard"].transport_info())
         else:
             # TEST HARNESS (--backend gloo with MVS_BENCH_ONE_GPU): several ranks on cuda:0 cannot share an RCCL communicator, so the
-            # contract test drives the same device building blocks from Python over gloo (mvs-texturing_amd/multigpu.py); never the product path
+            # contract test drives the same device building blocks from Python over gloo (tests/tools/multigpu.py); never the product path
             if "pipe" not in info:
                 info["pipe"] = G.ShardedPipeline(ctx, part, rank, dist, dev, adj_ptr, adj, t_ap, t_ad, settings, params)
             labels, st, ms, dc = info["pipe"].step()

@@ -55,6 +55,21 @@ typedef struct {
     const uint8_t* rgb; /* width*height*3 interleaved RGB8 (mve::ByteImage layout) */
 } mvs_view;
 
+/* Host images that exist only while they are needed.  tex::calculate_data_costs loads and releases ONE view's image per iteration
+ * (calculate_data_costs.cpp:157 tv.load_image() ... :231 tv.release_image()): its host peak is one decoded image, whatever the number of
+ * views.  An entry point that takes an image source asks for the pixels view by view -- acquire(user, j) returns the RGB8 pixels of view j
+ * (width / height as in views[j]; mvs_view.rgb is ignored), release(user, j) hands them back -- both on the CALLING thread, with at most
+ * max_in_flight (0 = 4) views acquired at any time: a batch is acquired, copied to the device and released.  acquire returns NULL when the
+ * image cannot be produced: the call fails with MVS_ERR_INVALID after releasing every view acquired so far (as every failure does). */
+typedef const uint8_t* (*mvs_image_acquire_fn)(void* user, uint32_t view);
+typedef void (*mvs_image_release_fn)(void* user, uint32_t view);
+typedef struct {
+    mvs_image_acquire_fn acquire;
+    mvs_image_release_fn release;
+    void* user;
+    uint32_t max_in_flight;
+} mvs_image_source;
+
 /* tex::Settings fields the path reads (settings.h:85,87,90; enums settings.h:59-74) */
 enum { MVS_DATA_TERM_AREA = 0, MVS_DATA_TERM_GMI = 1 };
 enum { MVS_OUTLIER_NONE = 0, MVS_OUTLIER_GAUSS_DAMPING = 1, MVS_OUTLIER_GAUSS_CLAMPING = 2 };
@@ -189,6 +204,10 @@ static inline uint64_t mvs_fp_mix(uint64_t k, uint64_t v) {
 typedef void (*mvs_csr_chunk_fn)(void* user, uint32_t first_face, uint32_t n_faces, const uint32_t* col_ptr, const uint16_t* view_id, const float* cost);
 mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_settings* settings,
                                  mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats);
+/* the same with the host images supplied view by view through an mvs_image_source (above): host memory is bounded by max_in_flight decoded
+ * images instead of the whole scene's -- what the replacement of tex::calculate_data_costs calls (integration/view_selection_mi355x.cpp) */
+mvs_status mvs_data_costs_stream_from(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_image_source* images,
+                                      const mvs_settings* settings, mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats);
 mvs_status mvs_view_selection_cached(uint64_t fingerprint, uint32_t n_faces, uint32_t n_views, uint64_t nnz,
                                      const uint32_t* adj_ptr, const uint32_t* adj, const mvs_mrf_params* params,
                                      uint32_t* labels_out, mvs_mrf_stats* stats);
@@ -266,6 +285,8 @@ mvs_status mvs_ctx_get_profile(mvs_ctx* ctx, char* buf, size_t buf_size);
 mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device);
 /* views: HOST array of n structs; their rgb pointers are device pointers iff rgb_on_device */
 mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device);
+/* host images supplied view by view (mvs_image_source): mvs_view.rgb is ignored */
+mvs_status mvs_scene_set_views_from(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, const mvs_image_source* images);
 /* restrict the data-cost computation to the faces at POSITIONS [begin, end) of the library's face order (the caller's ids with
  * option "face_order" = 0); the whole mesh stays the occluder set.  Default: all faces.  (Building block of the sharded drivers.) */
 mvs_status mvs_scene_set_face_range(mvs_ctx* ctx, uint32_t begin, uint32_t end);
@@ -356,7 +377,7 @@ mvs_status mvs_ctx_mrf_diagnostics(mvs_ctx* ctx, uint32_t out[4]);
 /* The sharded path -- the product's only multi-GPU driver -- is mvs_comm_* / mvs_shard_* below (csrc/shard.hip).  The per-phase
  * BUILDING BLOCKS a driver of its own would be made of (sweep one colour phase of a node range, gather / scatter halo elements,
  * step, poll, ICM gain / apply, ...) are declared in include/mvs_viewsel_blocks.h and live in a library of their own,
- * libmvs_blocks.so: the harness of the CPU multi-process tests (mvs-texturing_amd/multigpu.py) is built on them. */
+ * libmvs_blocks.so: the harness of the CPU multi-process tests (tests/tools/multigpu.py) is built on them. */
 
 
 /* row f3 on a context: inputs host or device (flags); with out_on_device the three arrays of `out` are device

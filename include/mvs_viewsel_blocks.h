@@ -3,7 +3,7 @@
  * NOT part of the product library.  The product's multi-GPU path is mvs_comm_* / mvs_shard_* of mvs_viewsel.h (csrc/shard.hip in
  * libmvs_viewsel.so).  These entry points expose the same device code one step lower -- one colour phase of a node range, gather /
  * scatter of halo elements by index list, the device-side step, ICM gain / apply -- so that a driver written elsewhere can own the
- * exchange.  In this repository they carry the Python harness of the CPU multi-process tests (mvs-texturing_amd/multigpu.py over
+ * exchange.  In this repository they carry the Python harness of the CPU multi-process tests (tests/tools/multigpu.py over
  * torch.distributed / gloo: the collectives' call pattern at world size 2 and 4 without a second GPU) and scripts/rank_share_mrf.py.
  * Link order: libmvs_blocks.so needs libmvs_viewsel.so. */
 #ifndef MVS_VIEWSEL_BLOCKS_H
@@ -31,7 +31,7 @@ mvs_status mvs_ctx_costs_export(mvs_ctx* ctx, uint32_t* counts_device, uint16_t*
  *   for every colour phase: mrf_sweep_phase(own range) -> mrf_gather(MSG | LAB, boundary index lists) ->
  *   RCCL all-to-all by the driver -> mrf_scatter;  then mrf_energy(own range) ->
  *   all-reduce of the two u64 -> mrf_step.  The index lists are planned on the host from
- * col_ptr + adjacency alone (mvs-texturing_amd/multigpu.py). */
+ * col_ptr + adjacency alone (tests/tools/multigpu.py). */
 /* solver arrays addressable by the halo exchange: messages, decoded labels (view + 1) of the current
  * sweep, ICM gains, labels of the best labeling so far */
 enum { MVS_MRF_MSG = 0, MVS_MRF_LAB = 1, MVS_MRF_GAIN = 2, MVS_MRF_BEST_LAB = 3,

@@ -101,34 +101,46 @@ class UniGraph {
     std::vector<std::vector<std::size_t> > adj_lists;
     std::vector<std::size_t> labels;
     std::size_t edges;
+    /* All labels' subgraphs come out of ONE GPU pass; generate_texture_patches.cpp:469-475 asks label by label (once per view), so the
+     * result of the pass is kept until a label or an edge changes (set_label / add_edge are the only mutators): V calls cost one pass. */
+    mutable bool cache_valid = false;
+    mutable std::size_t cache_labels = 0;
+    mutable mvs_subgraphs cache{};
+    void drop_cache() const { if (cache_valid) { mvs_subgraphs_free(&cache); cache_valid = false; } }
 
 public:
     explicit UniGraph(std::size_t nodes) : edges(0) { adj_lists.resize(nodes); labels.resize(nodes); }
+    UniGraph(const UniGraph& o) : adj_lists(o.adj_lists), labels(o.labels), edges(o.edges) {}
+    UniGraph& operator=(const UniGraph& o) { if (this != &o) { drop_cache(); adj_lists = o.adj_lists; labels = o.labels; edges = o.edges; } return *this; }
+    ~UniGraph() { drop_cache(); }
     bool has_edge(std::size_t n1, std::size_t n2) const {
         auto const& l = adj_lists[n1];
         return std::find(l.begin(), l.end(), n2) != l.end();
     }
     void add_edge(std::size_t n1, std::size_t n2) {
-        if (!has_edge(n1, n2)) { adj_lists[n1].push_back(n2); adj_lists[n2].push_back(n1); ++edges; }
+        if (!has_edge(n1, n2)) { drop_cache(); adj_lists[n1].push_back(n2); adj_lists[n2].push_back(n1); ++edges; }
     }
     std::size_t num_edges() const { return edges; }
     std::size_t num_nodes() const { return adj_lists.size(); }
-    void set_label(std::size_t n, std::size_t label) { labels[n] = label; }
+    void set_label(std::size_t n, std::size_t label) { if (labels[n] != label) drop_cache(); labels[n] = label; }
     std::size_t get_label(std::size_t n) const { return labels[n]; }
     std::vector<std::size_t> const& get_adj_nodes(std::size_t node) const { return adj_lists[node]; }
 
     /* uni_graph.cpp:21-55: the connected subgraphs of nodes labelled `label`, appended to *subgraphs in ascending
      * order of their smallest node, each in BFS queue order.  generate_texture_patches.cpp:469-475 asks for every
-     * label in turn; the GPU computes all labels in one pass (mvs_get_subgraphs), so ask through
-     * get_all_subgraphs() once and slice, or call this per label (one pass each). */
+     * label in turn; the GPU computes all labels in one pass (mvs_get_subgraphs) whose result is kept (see above):
+     * the first call pays the pass, the following ones slice it.  (Not thread safe, like the reference's member.) */
     void get_subgraphs(std::size_t label, std::vector<std::vector<std::size_t> >* subgraphs) const {
-        std::size_t n_labels = label + 1;
-        for (std::size_t l : labels) n_labels = std::max(n_labels, l + 1);
-        mvs_subgraphs sg;
-        get_all_subgraphs(n_labels, &sg);
+        if (!cache_valid || label >= cache_labels) {
+            drop_cache();
+            std::size_t n_labels = label + 1;
+            for (std::size_t l : labels) n_labels = std::max(n_labels, l + 1);
+            get_all_subgraphs(n_labels, &cache);
+            cache_valid = true; cache_labels = n_labels;
+        }
+        const mvs_subgraphs& sg = cache;
         for (std::uint32_t c = sg.label_ptr[label]; c < sg.label_ptr[label + 1]; ++c)
             subgraphs->push_back(std::vector<std::size_t>(sg.comp_faces + sg.comp_ptr[c], sg.comp_faces + sg.comp_ptr[c + 1]));
-        mvs_subgraphs_free(&sg);
     }
     /* all labels 0 .. n_labels - 1 in one GPU pass; free with mvs_subgraphs_free */
     void get_all_subgraphs(std::size_t n_labels, mvs_subgraphs* out) const {
@@ -275,6 +287,9 @@ void calculate_data_costs(MeshConstPtr mesh, TextureViews* texture_views, Settin
     m.verts = detail::flat(mesh->get_vertices());
     m.faces = mesh->get_faces().data();
     m.face_normals = detail::flat(mesh->get_face_normals());
+    /* the images of this mirror type are bound by the caller before the call and released here on EVERY exit path (:231); the replacement
+     * translation unit for the real tex::TextureView loads them view by view instead (integration/view_selection_mi355x.cpp, mvs_image_source) */
+    struct ReleaseAll { std::vector<TextureView>* v; ~ReleaseAll() { for (TextureView& tv : *v) tv.release_image(); } } release_all{texture_views};
     std::vector<mvs_view> views(num_views);
     for (std::size_t j = 0; j < num_views; ++j) {
         TextureView const& tv = texture_views->at(j);
@@ -304,7 +319,6 @@ void calculate_data_costs(MeshConstPtr mesh, TextureViews* texture_views, Settin
         if (at != std::string::npos) chunks = std::atof(T.library_profile.c_str() + at + 27);
         T.table_fill_ms = chunks; T.library_ms = (t2 - t1) - chunks;
     }
-    for (TextureView& tv : *texture_views) tv.release_image();  /* :231 */
     std::cout << "\tMaximum quality of a face within an image: " << stats.max_quality << std::endl;     /* :304-305 */
     std::cout << "\tClamping qualities to " << stats.percentile << " within normalization." << std::endl;
 }

@@ -18,6 +18,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <iostream>
 #include <limits>
 #include <stdexcept>
@@ -87,29 +88,45 @@ calculate_data_costs(mve::TriangleMesh::ConstPtr mesh, std::vector<TextureView> 
     std::vector<mvs_view> views(num_views);
     for (std::size_t j = 0; j < num_views; ++j) {
         TextureView & tv = texture_views->at(j);
-        tv.load_image();                                                      // :157 (decoding stays on the host)
         math::Vec3f const pos = tv.get_pos(), dir = tv.get_viewing_direction();
         std::memcpy(views[j].pos, *pos, sizeof(views[j].pos));
         std::memcpy(views[j].viewdir, *dir, sizeof(views[j].viewdir));
         std::memcpy(views[j].K, *projection_of(tv), sizeof(views[j].K));      // row major, like math::Matrix
         std::memcpy(views[j].w2c, *world_to_cam_of(tv), sizeof(views[j].w2c));
-        views[j].width = tv.get_width(); views[j].height = tv.get_height();
-        views[j].rgb = tv.get_image()->get_data_pointer();                    // mve::ByteImage, three interleaved channels
+        views[j].width = tv.get_width(); views[j].height = tv.get_height();   // (known from the image header: texture_view.cpp:21-40)
+        views[j].rgb = nullptr;                                               // the pixels come through the image source below
     }
+    // Upstream holds ONE decoded image at a time (:157 tv.load_image() ... :231 tv.release_image()).  The library asks for the pixels view by
+    // view, on this thread, a few views at a time, and hands every one back as soon as it is on the device -- also when something fails
+    // half way (a missing file throws inside load_image: the exception is kept, the views loaded so far are released, then it is rethrown).
+    struct Images {
+        std::vector<TextureView> * views; std::exception_ptr error;
+        static std::uint8_t const * acquire(void * user, std::uint32_t j) {
+            Images * self = static_cast<Images *>(user);
+            try {
+                TextureView & tv = self->views->at(j);
+                tv.load_image();                                              // :157 (decoding stays on the host)
+                return tv.get_image()->get_data_pointer();                    // mve::ByteImage, three interleaved channels
+            } catch (...) { self->error = std::current_exception(); return nullptr; }
+        }
+        static void release(void * user, std::uint32_t j) { static_cast<Images *>(user)->views->at(j).release_image(); }   // :231
+    } images{texture_views, nullptr};
+    mvs_image_source source;
+    source.acquire = &Images::acquire; source.release = &Images::release; source.user = &images; source.max_in_flight = 4;
     mvs_settings st = c_settings(settings);
     mvs_dc_stats stats;
     std::memset(&stats, 0, sizeof(stats));
     mvs_view const no_view = mvs_view();
     // The table arrives in chunks of 65 536 faces while the next chunk is still on the bus: this fill (:291-298) hides the download.
     // The table also stays on the device, fingerprinted there, for the tex::view_selection that follows (texrecon.cpp:100,121).
-    mvs_status const rc = mvs_data_costs_stream(&m, num_views ? views.data() : &no_view, static_cast<std::uint32_t>(num_views), &st,
+    mvs_status const rc = mvs_data_costs_stream_from(&m, num_views ? views.data() : &no_view, static_cast<std::uint32_t>(num_views), &source, &st,
         [](void * user, std::uint32_t first, std::uint32_t n, std::uint32_t const * ptr, std::uint16_t const * view, float const * cost) {
             DataCosts * dc = static_cast<DataCosts *>(user);
             for (std::uint32_t i = 0; i < n; ++i)
                 for (std::uint32_t k = ptr[i]; k < ptr[i + 1]; ++k)
                     dc->set_value(first + i, view[k - ptr[0]], cost[k - ptr[0]]);
         }, data_costs, nullptr, &stats);
-    for (TextureView & tv : *texture_views) tv.release_image();               // :231
+    if (images.error) std::rethrow_exception(images.error);                   // upstream's own exception (e.g. util::Exception of a missing image)
     check(rc);
 
     std::cout << "\tMaximum quality of a face within an image: " << stats.max_quality << std::endl;       // :304-305

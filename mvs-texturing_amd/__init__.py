@@ -5,8 +5,8 @@ tex::view_selection interface.
 The product is the C-ABI shared library csrc/libmvs_viewsel.so (hand-written HIP
 for gfx950, declared in include/mvs_viewsel.h); the C++ mirror of the reference
 API is include/tex_viewsel.hpp.  This Python package is plumbing for tests and
-bench.py: ctypes bindings (viewsel.py), the synthetic input producer (synth.py)
-and the multi-GPU driver over torch.distributed / RCCL (multigpu.py).
+bench.py: ctypes bindings (viewsel.py, shard.py) and the synthetic input producer (synth.py).
+(The Python restatement of the sharded loop that the CPU gloo tests drive lives under tests/tools/multigpu.py.)
 
 There is NO CPU fallback: importing works without a GPU (so that symbol and
 host-logic tests can run), but every compute entry point raises when the HIP

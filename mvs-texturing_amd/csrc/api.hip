@@ -27,7 +27,7 @@ void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce
 void mrf_keep_best(mvs_ctx* ctx);
 void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 uint32_t mrf_region_round(mvs_ctx* ctx);
-void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy, const unsigned long long* const* peer_tab = nullptr, uint32_t n_peer = 0, uint32_t peer_off = 0);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
@@ -452,7 +452,14 @@ mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device)
     MVS_API_END
 }
 
-mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device) {
+static mvs_status set_views_impl(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device, const mvs_image_source* src);
+mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device) { return set_views_impl(ctx, views, n_views, rgb_on_device, nullptr); }
+/* the same with host images that exist only while they are needed: see mvs_image_source in the header */
+mvs_status mvs_scene_set_views_from(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, const mvs_image_source* src) {
+    if (!src || !src->acquire || !src->release) return fail(MVS_ERR_INVALID, "null argument");
+    return set_views_impl(ctx, views, n_views, 0, src);
+}
+static mvs_status set_views_impl(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device, const mvs_image_source* src) {
     if (!ctx || (!views && n_views)) return fail(MVS_ERR_INVALID, "null argument");
     MVS_API_BEGIN
     MVS_HIP(hipSetDevice(ctx->device));
@@ -475,10 +482,33 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
         hipStream_t s; std::vector<void*> ptrs;
         ~Pinned() { if (ptrs.empty()) return; (void)hipStreamSynchronize(s); for (void* p : ptrs) (void)hipHostUnregister(p); }
     } pinned{ctx->stream, {}};
-    const UploadRoute route = rgb_on_device ? UploadRoute::Pageable : upload_route();
+    UploadRoute route = rgb_on_device ? UploadRoute::Pageable : upload_route();
+    if (src && route == UploadRoute::Register) route = UploadRoute::Ring;   // (pages that are handed back batch by batch are never registered)
     std::vector<UploadPiece> pieces;
+    // Image SOURCE (mvs_scene_set_views_from): the caller's images exist only between acquire(j) and release(j), both called on THIS thread,
+    // at most `max_in_flight` views at a time (calculate_data_costs.cpp:157-231 holds one decoded image at a time; a caller that loads all of
+    // them first needs the whole scene's pixels in host memory).  A batch is acquired, copied to the device through the pinned ring and
+    // released; whatever fails -- an image the caller cannot produce, a copy -- every view acquired so far is released before the call returns.
+    struct Held {
+        const mvs_image_source* src; std::vector<uint32_t> views;
+        void release_all() { for (uint32_t j : views) src->release(src->user, j); views.clear(); }
+        ~Held() { if (src) release_all(); }
+    } held{src, {}};
+    const uint32_t in_flight = src ? std::max<uint32_t>(1u, src->max_in_flight ? src->max_in_flight : 4u) : 0u;
+    auto flush_batch = [&]() {
+        if (!pieces.empty()) upload_through_ring(ctx, pieces);      // (returns with the stream drained: the caller's pixels are no longer read)
+        pieces.clear();
+        MVS_HIP(hipStreamSynchronize(ctx->stream));
+        held.release_all();
+    };
     for (uint32_t j = 0; j < n_views; ++j) {
-        const mvs_view& v = views[j];
+        mvs_view v = views[j];
+        if (src) {
+            if (v.width < 2 || v.height < 2) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image");
+            v.rgb = src->acquire(src->user, j);
+            if (!v.rgb) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": the image source has no image");
+            held.views.push_back(j);
+        }
         if (v.width < 2 || v.height < 2 || !v.rgb) throw StatusError(MVS_ERR_INVALID, "view " + std::to_string(j) + ": bad image");
         ViewParams& p = ctx->h_views[j];
         memcpy(p.pos, v.pos, sizeof(p.pos)); memcpy(p.viewdir, v.viewdir, sizeof(p.viewdir));
@@ -491,12 +521,14 @@ mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_v
             const size_t bytes = (size_t)v.width * v.height * 3;
             b->ensure(bytes + 16);
             p.rgb = b->p;
-            if (route == UploadRoute::Ring && bytes >= (1u << 18)) { pieces.push_back(UploadPiece{v.rgb, b->p, bytes}); continue; }
+            if (route == UploadRoute::Ring && bytes >= (1u << 18)) { pieces.push_back(UploadPiece{v.rgb, b->p, bytes}); if (src && held.views.size() >= in_flight) flush_batch(); continue; }
             if (route == UploadRoute::Register && bytes >= (1u << 20) && hipHostRegister(const_cast<uint8_t*>(v.rgb), bytes, hipHostRegisterDefault) == hipSuccess) pinned.ptrs.push_back(const_cast<uint8_t*>(v.rgb));
             else (void)hipGetLastError();   // not registered: clear the sticky error, copy from pageable memory
             MVS_HIP(hipMemcpyAsync(b->p, v.rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+            if (src && held.views.size() >= in_flight) flush_batch();
         }
     }
+    if (src) flush_batch();
     if (!pieces.empty()) upload_through_ring(ctx, pieces);
     MVS_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_views = n_views;
@@ -571,21 +603,31 @@ mvs_status mvs_ctx_costs_download(mvs_ctx* ctx, mvs_csr* out, float** quality_ou
     const bool reordered = table_to_caller_order(ctx, quality_out != nullptr);
     const uint32_t* s_ptr = reordered ? ctx->u_ptr.p : ctx->r_ptr; const uint16_t* s_view = reordered ? ctx->u_view.p : ctx->r_view;
     const float* s_cost = reordered ? ctx->u_cost.p : ctx->r_cost; const float* s_q = reordered ? ctx->u_q.p : ctx->csr_q.p;
+    // the caller's arrays: all of them or none (a failed allocation, copy or synchronisation hands everything back and reports it)
     out->n_faces = ctx->csr_faces; out->n_views = ctx->csr_views; out->nnz = nnz;
+    out->col_ptr = nullptr; out->view_id = nullptr; out->cost = nullptr;
+    if (quality_out) *quality_out = nullptr;
+    struct Guard {
+        mvs_csr* o; float** q; bool keep = false;
+        ~Guard() { if (keep) return; free(o->col_ptr); free(o->view_id); free(o->cost); if (q) { free(*q); *q = nullptr; } memset(o, 0, sizeof(*o)); }
+    } guard{out, quality_out};
     out->col_ptr = (uint32_t*)malloc((F + 1) * sizeof(uint32_t));
     out->view_id = (uint16_t*)malloc((nnz + 1) * sizeof(uint16_t));
     out->cost = (float*)malloc((nnz + 1) * sizeof(float));
+    if (quality_out) *quality_out = (float*)malloc((nnz + 1) * sizeof(float));
+    if (!out->col_ptr || !out->view_id || !out->cost || (quality_out && !*quality_out))
+        throw StatusError(MVS_ERR_INVALID, "out of host memory for the downloaded table (" + std::to_string((F + 1) * 4 + (nnz + 1) * (quality_out ? 10 : 6)) + " bytes)");
     MVS_HIP(hipMemcpyAsync(out->col_ptr, s_ptr, (F + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nnz) {
         MVS_HIP(hipMemcpyAsync(out->view_id, s_view, nnz * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
         MVS_HIP(hipMemcpyAsync(out->cost, s_cost, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     if (quality_out) {
-        *quality_out = (float*)malloc((nnz + 1) * sizeof(float));
-        if (nnz && ctx->csr_q_valid)
-            MVS_HIP(hipMemcpyAsync(*quality_out, s_q, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (nnz && ctx->csr_q_valid) MVS_HIP(hipMemcpyAsync(*quality_out, s_q, nnz * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        else memset(*quality_out, 0, (nnz + 1) * sizeof(float));
     }
     MVS_HIP(hipStreamSynchronize(ctx->stream));
+    guard.keep = true;
     MVS_API_END
 }
 
@@ -793,8 +835,20 @@ void mvs_release_cached(void) {
 }
 
 /* tex::calculate_data_costs with the result streamed out in chunks of faces (see mvs_viewsel.h) */
+static mvs_status data_costs_stream_impl(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_image_source* images, const mvs_settings* settings,
+                                         mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats);
 mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_settings* settings,
                                  mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats) {
+    return data_costs_stream_impl(mesh, views, n_views, nullptr, settings, fn, user, shape_out, stats);
+}
+/* ... with the host images supplied view by view (mvs_image_source): host memory bounded by max_in_flight decoded images */
+mvs_status mvs_data_costs_stream_from(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_image_source* images, const mvs_settings* settings,
+                                      mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats) {
+    if (!images || !images->acquire || !images->release) return fail(MVS_ERR_INVALID, "null argument");
+    return data_costs_stream_impl(mesh, views, n_views, images, settings, fn, user, shape_out, stats);
+}
+static mvs_status data_costs_stream_impl(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_image_source* images, const mvs_settings* settings,
+                                         mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats) {
     if (!mesh || !views || !settings || !fn) return fail(MVS_ERR_INVALID, "null argument");
     if (n_views > 65535u) return fail(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");   /* calculate_data_costs.cpp:315-318 */
     double t[7]; t[0] = now_ms();
@@ -806,7 +860,7 @@ mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, ui
     t[1] = now_ms();
     st = mvs_scene_set_mesh(ctx, mesh, 0);
     t[2] = now_ms();
-    if (st == MVS_OK) st = mvs_scene_set_views(ctx, views, n_views, 0);
+    if (st == MVS_OK) st = set_views_impl(ctx, views, n_views, 0, images);
     t[3] = now_ms();
     if (st == MVS_OK) st = mvs_ctx_data_costs(ctx, settings, stats);
     uint64_t fp = 0; double first_chunk_ms = 0.0;

@@ -235,6 +235,7 @@ struct mvs_ctx {
     // sorted by sub-class key (fast nodes by (colour, class, id), then generic nodes by (colour, id)); m_sub_begin[key] = first position
     // of a key >= `key` (host copy of m_sub); positions [0, m_n_fast) are the fast nodes
     mvs::DBuf<uint32_t> m_colour, m_perm, m_tmp_a, m_tmp_b, m_tmp_c, m_sub; mvs::DBuf<uint8_t> m_cls; uint32_t m_colours = 0, m_n_fast = 0; std::vector<uint32_t> m_sub_begin;
+    const uint32_t* m_colour_in = nullptr;   // colours of all nodes kept by a sharded caller (null: mrf_setup colours the graph)
     const uint8_t* m_bnd = nullptr;   // per node: 1 = boundary node of a sharded caller (own node with an edge into another rank's part) -> zone 0 of the schedule (k_mrf.hip); null: no marks
     int mrf_damp_period = 4;     // damped sweeps: 1, 1 + p, 1 + 2p, ... (4: the solver's definition, restated in the oracle; other values are experiment knobs)
     int mrf_force_generic = 0;   // test hook: every node takes the generic sweep kernel

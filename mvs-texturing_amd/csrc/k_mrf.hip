@@ -565,41 +565,11 @@ __global__ void mrf_desc_kernel(const uint32_t* __restrict__ col_ptr, const uint
 // and one cut per model edge to a neighbour of a LOWER colour whose label differs -- that neighbour was swept in an
 // earlier phase of this sweep, so its label is final, and every edge has exactly one higher-coloured end.  Integer sums:
 // the per-block partials (partial[2 * block]) add up to the oracle's energy of the sweep whatever the launch geometry.
-// MVS_SWEEP_EXP (scripts/sweep_probe.py; never defined in the product build): 1 = every data load / store of the sweep lands in a 64 KB
-// window (cache hot: the kernel's non-memory floor), 2 = loads and stores only (no arithmetic, no LDS: the memory floor), 3 / 4 = three /
-// two waves per SIMD (sensitivity to residency).  Results are garbage for 1 and 2.
-// Round-5 probes of an EDGE-PAIR message layout (m(i->j) stored next to m(j->i), the two interleaved word by word) -- access pattern
-// only, results are garbage (scripts/sweep_probe.py, profiles/r05_sweep_probe.json): 5 = a node's incoming word and its old outgoing
-// word of an edge come from ONE 8-byte load (three load instructions fewer on damped sweeps); 6 = 5 + the outgoing word is stored
-// into the line the pair was loaded from.  (Probes 7 / 8 of that run -- the decode triple as one 8-byte store in schedule order --
-// led to the label-only decode of the product kernel and are gone.)
-#define MVS_PROBE_PAIR (MVS_SWEEP_EXP == 5 || MVS_SWEEP_EXP == 6)
-#define MVS_PROBE_PAIR_ST (MVS_SWEEP_EXP == 6)
-// 9 = the three map words of a lane in ONE 16-byte load (a record interleaved per lane: label words, then map words -- 2 instead of 4
-// loads of the record, at +150 B per node because identical-list edges would carry explicit maps); 10 = the three neighbour labels
-// fetched by lanes 0 .. 2 of the group with ONE load instruction (access pattern only: garbage results)
-#define MVS_PROBE_MAP16 (MVS_SWEEP_EXP == 9 || MVS_SWEEP_EXP == 11)
-#define MVS_PROBE_NL1 (MVS_SWEEP_EXP == 10 || MVS_SWEEP_EXP == 11)
-#ifndef MVS_SWEEP_EXP
-#define MVS_SWEEP_EXP 0
-#endif
-#ifndef MVS_SWEEP_DROP   // probe only: bit 0 = no neighbour-label gathers, 1 = no incoming runs, 2 = no record, 3 = no stores, 4 = no old runs
-#define MVS_SWEEP_DROP 0
-#endif
-#if MVS_SWEEP_EXP == 1
-#define MVS_XO(o) ((o) & 0xFFF0u)
-#else
-#define MVS_XO(o) (o)
-#endif
-#if MVS_SWEEP_EXP == 3
-#define MVS_SWEEP_WAVES __attribute__((amdgpu_waves_per_eu(3, 3)))
-#elif MVS_SWEEP_EXP == 4
-#define MVS_SWEEP_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
-#define MVS_SWEEP_WAVES
-#endif
+// (The access-pattern probes of rounds 4 and 5 -- scripts/sweep_probe.py: all accesses inside a 64 KB window, arithmetic removed, one stream
+// dropped at a time, an edge-pair message layout, wider map loads -- are a PATCH on this kernel, scripts/probe/sweep4_probes.patch, which
+// scripts/build_variant.py --patch applies to a copy of this file; the product source carries none of them.)
 template <int G, bool DAMP, bool XCD, bool LATE_OLD>
-__global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ rec, msg_t* msg,
+__global__ void __launch_bounds__(256) mrf_sweep4_kernel(const NodeDesc* __restrict__ desc, const uint32_t* __restrict__ rec, msg_t* msg,
                                                          const mvs_mrf_progress* __restrict__ st, uint32_t* lab2, uint32_t buf_stride,
                                                          uint32_t node_begin /* positions in the (colour, id) order */, uint32_t node_end, float rho, float alpha,
                                                          unsigned long long* __restrict__ partial) {
@@ -651,31 +621,15 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
     const uint32_t t0b = 4u * t0, glb = 4u * (uint32_t)gl;   // byte offsets of the lane's label words / map word inside a record
     auto issue = [&](const NodeDesc& d, Raw& r) {
         const uint32_t K = d.kk & 0xFFu, recb = 4u * d.rec;
-        if (MVS_SWEEP_DROP & 4) r.lw = make_uint4(recb, K, 0u, 0u); else r.lw = ld_off<uint4>(rec, MVS_XO(recb + t0b));
+        r.lw = ld_off<uint4>(rec, recb + t0b);
         uint32_t mposb = recb + 4u * ((K + 3u) & ~3u) + glb;
-#if MVS_PROBE_MAP16
-        { const uint4 mm = ld_off<uint4>(rec, recb + 4u * ((K + 3u) & ~3u) + 4u * glb); r.map[0] = mm.x; r.map[1] = mm.y; r.map[2] = mm.z ^ mm.w; }
-#endif
-#if MVS_PROBE_NL1
-        { const uint32_t nb1 = gl == 0 ? d.nbr[0] : gl == 1 ? d.nbr[1] : d.nbr[2]; uint32_t v = 0u; if (gl < 3) v = ld_off<uint32_t>(lab, 4u * nb1); r.nl[0] = v; r.nl[1] = v + 1u; r.nl[2] = v + 2u; }
-#endif
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-#if MVS_PROBE_PAIR
-            { const uint2 pr = ld_off<uint2>(mo, (d.in_off[e] & ~7u) + 2u * t0); r.in[e] = pr.x; r.old[e] = pr.y; }
-#else
-            if (MVS_SWEEP_DROP & 2) r.in[e] = d.in_off[e]; else r.in[e] = ld_off<uint32_t>(mo, MVS_XO((d.in_off[e] & ~3u) + t0));
-#endif
-#if !MVS_PROBE_MAP16
-            if (MVS_SWEEP_DROP & 4) r.map[e] = mposb; else r.map[e] = ld_off<uint32_t>(rec, MVS_XO(mposb));
-#endif
+            r.in[e] = ld_off<uint32_t>(mo, (d.in_off[e] & ~3u) + t0);
+            r.map[e] = ld_off<uint32_t>(rec, mposb);
             if (!(d.out_off[e] & 1u)) mposb += (((d.kk >> (8 + 8 * e)) & 0xFFu) + 3u) & ~3u;   // 4 bytes per 4 map entries
-#if !MVS_PROBE_NL1
-            if (MVS_SWEEP_DROP & 1) r.nl[e] = d.nbr[e]; else r.nl[e] = ld_off<uint32_t>(lab, MVS_XO(4u * d.nbr[e]));     // an absent neighbour is recorded as the node itself
-#endif
-#if !MVS_PROBE_PAIR
-            if (DAMP && !(MVS_SWEEP_DROP & 16)) r.old[e] = ld_off<uint32_t>(mo, MVS_XO((d.out_off[e] & ~3u) + t0)); else r.old[e] = d.out_off[e];
-#endif
+            r.nl[e] = ld_off<uint32_t>(lab, 4u * d.nbr[e]);     // an absent neighbour is recorded as the node itself
+            if (DAMP) r.old[e] = ld_off<uint32_t>(mo, (d.out_off[e] & ~3u) + t0); else r.old[e] = d.out_off[e];
         }
     };
     NodeDesc cur = ld_off<NodeDesc>(desc, (uint32_t)sizeof(NodeDesc) * min(i, last));
@@ -700,17 +654,6 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
         }
         const uint32_t lw[4] = {rw.lw.x, rw.lw.y, rw.lw.z, rw.lw.w};
         const uint32_t* r_in = rw.in; const uint32_t* r_map = rw.map; const uint32_t* nl = rw.nl; const uint32_t* r_old = rw.old;
-#if MVS_SWEEP_EXP == 2
-        {   // memory floor: every loaded word is consumed, every store is made, nothing is computed
-            const uint32_t x = ((lw[0] ^ lw[1]) ^ (lw[2] ^ lw[3])) ^ ((r_in[0] ^ r_in[1]) ^ (r_in[2] ^ r_map[0])) ^ ((r_map[1] ^ r_map[2]) ^ (nl[0] ^ nl[1])) ^ (nl[2] ^ r_old[0] ^ r_old[1] ^ r_old[2]);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) if (t0 < kj3[d] && !(MVS_SWEEP_DROP & 8)) st_off<uint32_t>(mn, o_out[d] + t0, x);
-            if ((MVS_SWEEP_DROP & 8) && x == 0x12345u) st_off<uint32_t>(mn, o_out[0] + t0, x);   // (keeps the loads alive)
-            if (node_ok && gl == 0) { const uint32_t idb = 4u * cur.id; st_off<uint32_t>(lab, idb, (x & 15u) + 1u); acc_e += x & 1u; }
-            cur = nxt; rw = rn; nxt = nn;
-            continue;
-        }
-#endif
         // The update on the 8-bit codes (oracle.cpp mrf_sweep is the definition): Sc = sum of the incoming codes (exact),
         // b = fma(rho * step, Sc, D), cs_e = fma(-step, code_e, b) * oms -- the reweighted cavity D + rho * sum_all - m_e in
         // damped code units, oms = (1 - alpha) * scale -- code' = rne(fma(old, alpha, min(cs[p] - cmin, lam * oms))).
@@ -751,11 +694,7 @@ __global__ void __launch_bounds__(256) MVS_SWEEP_WAVES mrf_sweep4_kernel(const N
                 const uint32_t slot = (G < 64) ? mp : ((mp == 0xFFu) ? (uint32_t)(4 * G) : mp);   // "absent at the sender" -> the +inf slot (G < 64: the records hold 4 * G)
                 w = msg_pack_s<DAMP>(min_raw(tile[slot], lam_s), alpha, (float)((r_old[d] >> (8 * r)) & 0xFFu), (uint32_t)r, w);
             }
-#if MVS_PROBE_PAIR_ST
-            if (t0 < kj3[d]) st_off<uint32_t>(mn, (cur.in_off[d] & ~7u) + 2u * t0 + 4u, w);   // (probe: into the line the pair came from)
-#else
-            if (t0 < kj3[d]) st_off<uint32_t>(mn, MVS_XO(o_out[d] + t0), w);      // one 4-byte store (runs are padded)
-#endif
+            if (t0 < kj3[d]) st_off<uint32_t>(mn, o_out[d] + t0, w);      // one 4-byte store (runs are padded)
         }
         // the lane that owns the winning label publishes the decode (K == 0: lane 0 publishes the single label 0 with
         // unary 1, view_selection.cpp:50-51,70-71) and accounts the node's share of the tracking energy (integer:
@@ -1039,7 +978,8 @@ __global__ void __launch_bounds__(256) mrf_energy_kernel(const uint32_t* __restr
     }
 }
 __global__ void __launch_bounds__(1024) mrf_energy_reduce_kernel(const unsigned long long* __restrict__ partial, uint32_t n_blocks,
-                                                                 unsigned long long* __restrict__ out /* [0] energy, [1] cuts */) {
+                                                                 unsigned long long* __restrict__ out /* [0] energy, [1] cuts */,
+                                                                 unsigned long long* __restrict__ out2 = nullptr /* a second copy (sharded solves: the slot the peers read) */) {
     unsigned long long e = 0, c = 0;
     const ulonglong2* pp = reinterpret_cast<const ulonglong2*>(partial);
 #pragma unroll 8
@@ -1048,7 +988,7 @@ __global__ void __launch_bounds__(1024) mrf_energy_reduce_kernel(const unsigned 
     for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o, 64); c += __shfl_xor(c, o, 64); }
     if ((threadIdx.x & 63) == 0) { su[threadIdx.x >> 6] = e; sc[threadIdx.x >> 6] = c; }
     __syncthreads();
-    if (threadIdx.x == 0) { e = 0; c = 0; for (int k = 0; k < 16; ++k) { e += su[k]; c += sc[k]; } out[0] = e; out[1] = c; }
+    if (threadIdx.x == 0) { e = 0; c = 0; for (int k = 0; k < 16; ++k) { e += su[k]; c += sc[k]; } out[0] = e; out[1] = c; if (out2) { out2[0] = e; out2[1] = c; } }
 }
 
 // ---- ICM polish: G lanes per node over its labels ----
@@ -1211,7 +1151,10 @@ __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t nod
 __global__ void __launch_bounds__(1024) mrf_step_kernel(mvs_mrf_progress* __restrict__ st, unsigned long long* __restrict__ hist,
                                 const unsigned long long* __restrict__ energy, const unsigned long long* __restrict__ partial, uint32_t n_partial,
                                 unsigned long long* __restrict__ energy_out, mvs_mrf_progress* __restrict__ ring, uint32_t* __restrict__ ring_seq, uint32_t ring_slots,
-                                uint32_t* __restrict__ ctl, int max_sweeps, int min_sweeps, int window, float min_improvement) {
+                                uint32_t* __restrict__ ctl, int max_sweeps, int min_sweeps, int window, float min_improvement,
+                                const unsigned long long* const* __restrict__ peer_tab = nullptr, uint32_t n_peer = 0, uint32_t peer_off = 0) {
+    // peer_tab (sharded solves, peer-push transport): the energy pair of the sweep = the sum over the ranks' published pairs
+    // peer_tab[q][peer_off], [peer_off + 1] -- read here, so that summing them is no launch of its own
     __shared__ unsigned long long su[16], sc[16];
     unsigned long long e_sum = 0, c_sum = 0;
     if (partial) {
@@ -1229,12 +1172,16 @@ __global__ void __launch_bounds__(1024) mrf_step_kernel(mvs_mrf_progress* __rest
         e_sum = 0; c_sum = 0;
         for (int k = 0; k < 16; ++k) { e_sum += su[k]; c_sum += sc[k]; }
         energy_out[0] = e_sum; energy_out[1] = c_sum;
+    } else if (peer_tab) {
+        e_sum = 0; c_sum = 0;
+        for (uint32_t q = 0; q < n_peer; ++q) { e_sum += peer_tab[q][peer_off]; c_sum += peer_tab[q][peer_off + 1u]; }
+        energy_out[0] = e_sum; energy_out[1] = c_sum;
     }
     mvs_mrf_progress p = *st;
     if (p.stopped) { p.improved = 0u; }
     else {
         const uint32_t sw = p.sweep + 1u;
-        const unsigned long long e0 = partial ? e_sum : energy[0];
+        const unsigned long long e0 = (partial || peer_tab) ? e_sum : energy[0];
         const bool imp = e0 < p.best;
         if (imp) { p.best = e0; p.best_w = p.w; p.w ^= 1u; }
         p.sweep = sw; p.improved = imp ? 1u : 0u; p.energy = e0;
@@ -1300,7 +1247,10 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     if (F) {
         uint32_t* pending = ctx->m_moved.p + 1;   // [0] a node is still waiting, [1] a node saw all 64 colours around it
         hipLaunchKernelGGL(mrf_colour_init_kernel, dim3(nb), dim3(256), 0, s, ctx->m_colour.p, ctx->m_tmp_a.p /* iota */, F); MVS_LAUNCH_CHECK();
-        for (int round = 0;; ++round) {
+        // a sharded caller hands in the colouring it kept from its first solve (the colours follow from the adjacency alone, which a
+        // shard pins at creation, like its layout): no rounds
+        if (ctx->m_colour_in) MVS_HIP(hipMemcpyAsync(ctx->m_colour.p, ctx->m_colour_in, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        for (int round = 0; !ctx->m_colour_in; ++round) {
             if (round >= 4096) throw StatusError(MVS_ERR_HIP, "graph colouring did not terminate");
             MVS_HIP(hipMemsetAsync(pending, 0, sizeof(uint32_t), s));
             // a batch of rounds per read-back: 8 first (large meshes need ~12 rounds, a round costs 10 us, a read-back 25), then 4
@@ -1435,16 +1385,16 @@ void resolve_best(mvs_ctx* ctx) {
 
 // One bookkeeping step (see mrf_step_kernel); energy = device pointer to the (all-reduced) energy pair, or null: the pair is
 // still in per-block partials -- the sweep kernels' (fast path) or mrf_energy(..., reduce = false)'s -- summed by the step kernel.
-void mrf_step(mvs_ctx* ctx, const unsigned long long* energy) {
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy, const unsigned long long* const* peer_tab, uint32_t n_peer, uint32_t peer_off) {
     hipStream_t s = ctx->stream;
     const mvs_mrf_params& P = ctx->m_params;
     if (!ctx->h_ring) throw StatusError(MVS_ERR_STATE, "mrf step before mrf setup");
     const uint32_t n = ++ctx->steps_issued, slot = n % mvs_ctx::RING;
     const unsigned long long* partial = nullptr; uint32_t n_partial = 0;
-    if (!energy) { partial = ctx->m_energy.p + 4; n_partial = ctx->m_energy_from_sweep ? EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u) : ctx->m_energy_blocks; }
+    if (!energy && !peer_tab) { partial = ctx->m_energy.p + 4; n_partial = ctx->m_energy_from_sweep ? EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u) : ctx->m_energy_blocks; }
     (void)n; (void)slot;   // the kernel derives both from its own step counter (ctl), which mirrors ctx->steps_issued
     hipLaunchKernelGGL(mrf_step_kernel, dim3(1), dim3(1024), 0, s, ctx->m_state.p, ctx->m_hist.p, energy, partial, n_partial, ctx->m_energy.p,
-                       ctx->d_ring, ctx->d_seq, (uint32_t)mvs_ctx::RING, ctx->m_ctl.p, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement);
+                       ctx->d_ring, ctx->d_seq, (uint32_t)mvs_ctx::RING, ctx->m_ctl.p, P.max_sweeps, P.min_sweeps, P.window, P.min_improvement, peer_tab, n_peer, peer_off);
     MVS_LAUNCH_CHECK();
     ctx->icm_dirty_valid = false; ctx->best_resolved = false; ctx->exact_valid = false;   // the best labeling may change
 }
@@ -1667,14 +1617,14 @@ void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce
         MVS_LAUNCH_CHECK();
     }
     if (!reduce) return;   // the caller's mrf_step sums the partials
-    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, partial, blocks, ctx->m_energy.p);
+    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, partial, blocks, ctx->m_energy.p, (unsigned long long*)nullptr);
     MVS_LAUNCH_CHECK();
 }
 // the energy pair the fast-path sweep kernels of the last sweep left behind as per-block partials (own node range of a
 // sharded caller, or the whole graph) -> ctx->m_energy (device), asynchronous
-void mrf_sweep_energy_reduce(mvs_ctx* ctx) {
+void mrf_sweep_energy_reduce(mvs_ctx* ctx, unsigned long long* out2) {
     const uint32_t n = EPART_BLOCKS * std::max<uint32_t>(ctx->m_colours, 1u);
-    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->m_energy.p + 4, n, ctx->m_energy.p);
+    hipLaunchKernelGGL(mrf_energy_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->m_energy.p + 4, n, ctx->m_energy.p, out2);
     MVS_LAUNCH_CHECK();
 }
 

@@ -1,6 +1,6 @@
 // mgpu.hip -- libmvs_blocks.so: the building blocks of include/mvs_viewsel_blocks.h (per-phase sweeps of a node range, gather /
 // scatter of halo elements, the data-cost reduce hooks).  NOT in the product library: the product's sharded driver is csrc/shard.hip.
-// The collectives themselves are issued by whoever drives these blocks (the test harness mvs-texturing_amd/multigpu.py) on its own
+// The collectives themselves are issued by whoever drives these blocks (the test harness tests/tools/multigpu.py) on its own
 // device buffers; these entry points only move data between those buffers and the solver's arrays and run the per-range kernels.
 #include "ctx.h"
 #include "../../include/mvs_viewsel_blocks.h"
@@ -12,7 +12,7 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
 void mrf_keep_best(mvs_ctx* ctx);
 void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, int part = MRF_PART_ALL);
-void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy, const unsigned long long* const* peer_tab = nullptr, uint32_t n_peer = 0, uint32_t peer_off = 0);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);

@@ -39,10 +39,10 @@ void dc_phase2(mvs_ctx* ctx);
 void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats);
 void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params);
 void mrf_sweep_phase(mvs_ctx* ctx, uint32_t phase, uint32_t nb0, uint32_t ne0, int part = MRF_PART_ALL);
-void mrf_sweep_energy_reduce(mvs_ctx* ctx);
+void mrf_sweep_energy_reduce(mvs_ctx* ctx, unsigned long long* out2 = nullptr);
 void mrf_energy(mvs_ctx* ctx, bool best, uint32_t nb0, uint32_t ne0, bool reduce = true);
 void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
-void mrf_step(mvs_ctx* ctx, const unsigned long long* energy);
+void mrf_step(mvs_ctx* ctx, const unsigned long long* energy, const unsigned long long* const* peer_tab = nullptr, uint32_t n_peer = 0, uint32_t peer_off = 0);
 void mrf_poll(mvs_ctx* ctx, uint32_t step, mvs_mrf_progress* out);
 void mrf_icm_gain(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
 void mrf_icm_apply(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0);
@@ -511,6 +511,7 @@ struct mvs_shard {
     // solver's schedule puts them in front of their colour class (k_mrf.hip "zones"), a phase sweeps them first, hands their runs and
     // labels to the neighbours and sweeps the interior -- which reads nothing a peer writes -- while they travel.
     DBuf<uint8_t> bnd;
+    DBuf<uint32_t> colours; bool colours_valid = false;   // the greedy colouring (a function of the pinned adjacency and the caller's ids): made by the first solve, kept
     hipStream_t comm_stream = nullptr; hipEvent_t ev_main = nullptr, ev_comm = nullptr;   // exchange route: pack / send-recv / unpack of a phase run beside its interior launch
     ~mvs_shard() { if (ev_main) (void)hipEventDestroy(ev_main); if (ev_comm) (void)hipEventDestroy(ev_comm); if (comm_stream) (void)hipStreamDestroy(comm_stream); }
     // sharded table (global shape)
@@ -536,6 +537,7 @@ struct mvs_shard {
     uint32_t nnz_l = 0, own_start = 0; bool tables_valid = false;
     bool plan_valid = false; uint32_t plan_colours = 0; uint64_t plan_total = 0; uint32_t plans_built = 0, plans_reused = 0;
     // peer-push transport of the sweep loop (PeerHub): on when the communicator offers it and option "shard_peer_push" is set
+    DBuf<const unsigned long long*> e_tab;   // device table of the ranks' published energy pairs (read by the step kernel)
     bool peer = false; DBuf<unsigned long long> e_pub; DBuf<uint32_t> m_pub; uint64_t n_ev = 0; std::vector<int> nbr; uint32_t ev_ring = 0; uint64_t peer_phases = 0;
 };
 
@@ -741,6 +743,11 @@ void peer_publish(mvs_shard* S) {
         }
         if (traffic) S->nbr.push_back(q);
     }
+    std::vector<const unsigned long long*> tab((size_t)P);
+    for (int q = 0; q < P; ++q) tab[q] = H.slot[q].energy;
+    S->e_tab.ensure((size_t)P + 1);
+    MVS_HIP(hipMemcpyAsync(S->e_tab.p, tab.data(), (size_t)P * sizeof(tab[0]), hipMemcpyHostToDevice, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
 }
 // after colour phase `ph`: this rank's boundary runs and labels of the phase, stored at their places in the neighbours' arrays
 void peer_push_phase(mvs_shard* S, uint32_t ph) {
@@ -1110,9 +1117,15 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
     const uint32_t nb = S->nb, ne = S->ne;
     set_adjacency(ctx, S->d_adj_ptr, S->d_adj, 1, /*table_order=*/true);
     { Prof pr(ctx, "mrf_setup");
-      struct Marks { mvs_ctx* c; ~Marks() { c->m_bnd = nullptr; } } marks{ctx};   // the set-up is the only reader: no pointer into this shard stays behind
+      struct Marks { mvs_ctx* c; ~Marks() { c->m_bnd = nullptr; c->m_colour_in = nullptr; } } marks{ctx};   // the set-up is the only reader: no pointer into this shard stays behind
       ctx->m_bnd = S->P > 1 ? S->bnd.p : nullptr;
-      mrf_setup(ctx, &P); }
+      ctx->m_colour_in = S->colours_valid ? S->colours.p : nullptr;
+      mrf_setup(ctx, &P);
+      if (!S->colours_valid && S->F) {
+          S->colours.ensure((size_t)S->F + 2);
+          MVS_HIP(hipMemcpyAsync(S->colours.p, ctx->m_colour.p, (size_t)S->F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+          S->colours_valid = true;
+      } }
     // the halo plan follows from adjacency, partition, colouring and the message layout, i.e. from the column lengths: kept while
     // mvs_shard_data_costs found them unchanged (the layout's size is checked as well)
     if (!S->plan_valid || S->plan_colours != ctx->m_colours || S->plan_total != ctx->m_total) {
@@ -1170,21 +1183,21 @@ mvs_status mvs_shard_view_selection(mvs_shard* S, const mvs_mrf_params* params, 
         {   // the sweep's energy: own share (accumulated by the sweep kernels, or the energy kernel on the generic path),
             // all-reduced, fed to the device-side stop rule -- the host polls the report of `lag` sweeps ago
             Prof pr(ctx, "mrf_energy");
-            if (ctx->m_fast) mrf_sweep_energy_reduce(ctx); else mrf_energy(ctx, false, nb, ne, true);
             if (S->peer) {
-                // the rank's pair next to its peers', one event behind the last phase's push AND the pair, every rank sums all of them:
-                // the wait for ALL ranks is also what lets the next sweep's first phase start (and store into its neighbours)
+                // the rank's pair next to its peers' (written by the reduction itself), one event behind the last phase's push AND the pair;
+                // the step kernel of every rank sums all of them: TWO launches per sweep.  The wait for ALL ranks is also what lets the next
+                // sweep's first phase start (and store into its neighbours)
                 const uint32_t parity = (uint32_t)(issued & 1);
-                hipLaunchKernelGGL(publish_energy_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)ctx->m_energy.p, S->e_pub.p, parity); MVS_LAUNCH_CHECK();
+                if (ctx->m_fast) mrf_sweep_energy_reduce(ctx, S->e_pub.p + 2 * parity);
+                else { mrf_energy(ctx, false, nb, ne, true); hipLaunchKernelGGL(publish_energy_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)ctx->m_energy.p, S->e_pub.p, parity); MVS_LAUNCH_CHECK(); }
                 const uint64_t idx = peer_record(S);
-                EnergyPtrs ep; ep.n = S->P;
-                for (int q = 0; q < S->P; ++q) { if (q != S->me) peer_wait(S, q, idx); ep.p[q] = hub->slot[q].energy; }
-                hipLaunchKernelGGL(sum_energy_kernel, dim3(1), dim3(64), 0, s, ep, parity, S->d_energy.p); MVS_LAUNCH_CHECK();
+                for (int q = 0; q < S->P; ++q) if (q != S->me) peer_wait(S, q, idx);
+                mrf_step(ctx, nullptr, S->e_tab.p, (uint32_t)S->P, 2u * parity);
             } else {
-                MVS_HIP(hipMemcpyAsync(S->d_energy.p, ctx->m_energy.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+                if (ctx->m_fast) mrf_sweep_energy_reduce(ctx, S->d_energy.p); else { mrf_energy(ctx, false, nb, ne, true); MVS_HIP(hipMemcpyAsync(S->d_energy.p, ctx->m_energy.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s)); }
                 if (S->P > 1) comm->allreduce(S->d_energy.p, 2, mvs_comm::U64, mvs_comm::SUM, s);
+                mrf_step(ctx, S->d_energy.p);
             }
-            mrf_step(ctx, S->d_energy.p);
         }
         ++issued;
         if (issued - lag > polled) mrf_poll(ctx, (uint32_t)++polled, &pg);

@@ -168,7 +168,7 @@ def load_library():
         "mvs_view_selection_cached": [u64, u32, u32, u64, vp, vp, C.POINTER(MrfParams), vp, C.POINTER(MrfStats)],
     }
     # The per-phase building blocks (include/mvs_viewsel_blocks.h) live in a library of their own, libmvs_blocks.so -- the harness of
-    # the CPU multi-process tests (multigpu.py) and a few measuring scripts use them, the product does not.  Their entry points are
+    # the CPU multi-process tests (tests/tools/multigpu.py) and a few measuring scripts use them, the product does not.  Their entry points are
     # attached to the same handle; without that library (a variant build, a product-only install) they are simply absent.
     blocks = None
     if os.path.exists(_BLOCKS_PATH):

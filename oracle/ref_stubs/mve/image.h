@@ -5,13 +5,20 @@
 #ifndef MVS_REF_STUB_MVE_IMAGE_H
 #define MVS_REF_STUB_MVE_IMAGE_H
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <vector>
 namespace mve {
+// how many images exist right now / existed at most (tests of the image lifetime inside tex::calculate_data_costs: ref_wrap.cpp ref_image_lifetime)
+struct ImageCensus { static std::atomic<long>& live() { static std::atomic<long> n(0); return n; } static std::atomic<long>& peak() { static std::atomic<long> n(0); return n; }
+                     static void born() { const long n = ++live(); long p = peak().load(); while (n > p && !peak().compare_exchange_weak(p, n)) {} } static void gone() { --live(); } };
 template <typename T>
 class Image {
 public:
+    Image() { ImageCensus::born(); }
+    Image(Image const& o) : w(o.w), h(o.h), c(o.c), data(o.data) { ImageCensus::born(); }
+    ~Image() { ImageCensus::gone(); }
     typedef std::shared_ptr<Image<T> > Ptr;
     typedef std::shared_ptr<Image<T> const> ConstPtr;
     static Ptr create(int w, int h, int c) { Ptr p(new Image<T>()); p->w = w; p->h = h; p->c = c; p->data.assign((std::size_t)w * h * c, T(0)); return p; }

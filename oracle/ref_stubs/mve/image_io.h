@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include "mve/image.h"
@@ -21,9 +22,12 @@ inline ImageHeaders load_file_headers(std::string const& name) {
     return h;
 }
 inline std::map<std::string, ByteImage::Ptr>& file_registry() { static std::map<std::string, ByteImage::Ptr> r; return r; }
+inline bool& load_copies() { static bool b = false; return b; }                        // true: load_file returns a fresh COPY of the registered image (as decoding a file does)
+inline std::set<std::string>& unreadable_files() { static std::set<std::string> s; return s; }   // names load_file refuses (a file that went missing)
 inline ByteImage::Ptr load_file(std::string const& name) {
+    if (unreadable_files().count(name)) throw util::Exception("Cannot open file: " + name);
     std::map<std::string, ByteImage::Ptr>::const_iterator it = file_registry().find(name);
-    if (it != file_registry().end()) return it->second;
+    if (it != file_registry().end()) return load_copies() ? ByteImage::Ptr(new ByteImage(*it->second)) : it->second;
     ImageHeaders h;
     try { h = load_file_headers(name); header_requests().pop_back(); } catch (util::Exception&) { header_requests().pop_back(); throw util::Exception("oracle/_ref: no image registered as " + name); }
     return ByteImage::create(h.width, h.height, 3);                        // an unregistered file whose name states its size: blank pixels

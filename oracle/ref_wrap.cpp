@@ -252,6 +252,48 @@ std::int64_t ref_calculate_data_costs(std::uint32_t n_verts, const float* verts,
     } catch (std::exception& e) { std::fprintf(stderr, "ref_calculate_data_costs: %s\n", e.what()); return -1; }
 }
 
+// Image lifetime inside tex::calculate_data_costs (calculate_data_costs.cpp:157 tv.load_image() ... :231 tv.release_image(): upstream holds ONE
+// view's images at a time): n_views views of w x h over a one-triangle mesh, every load a fresh copy; view `fail_view` (< 0: none) cannot be
+// loaded.  out[0] = most images alive at once during the call, beyond those alive before it; out[1] = views whose image is still loaded
+// when the call has returned or thrown; returns 0, or 1 with the exception's text in err.
+int ref_image_lifetime(std::uint32_t n_views, int w, int h, int fail_view, long* out, char* err, int err_cap) {
+    mve::image::file_registry().clear(); mve::image::gradient_registry().clear(); mve::image::unreadable_files().clear();
+    mve::TriangleMesh::Ptr mesh = mve::TriangleMesh::create();
+    mesh->get_vertices().push_back(math::Vec3f(0.0f, 0.0f, 0.0f)); mesh->get_vertices().push_back(math::Vec3f(1.0f, 0.0f, 0.0f)); mesh->get_vertices().push_back(math::Vec3f(0.0f, 1.0f, 0.0f));
+    const std::uint32_t tri[3] = {0, 1, 2};
+    mesh->get_faces().assign(tri, tri + 3);
+    mesh->get_face_normals().push_back(math::Vec3f(0.0f, 0.0f, 1.0f));
+    std::vector<tex::TextureView> views;
+    for (std::uint32_t j = 0; j < n_views; ++j) {
+        mve::CameraInfo cam;
+        const float K[9] = {(float)w, 0.0f, w * 0.5f, 0.0f, (float)w, h * 0.5f, 0.0f, 0.0f, 1.0f};
+        const float w2c[16] = {1, 0, 0, -0.3f, 0, -1, 0, 0.3f, 0, 0, -1, 2.0f, 0, 0, 0, 1};     // a camera at (0.3, 0.3, 2) looking down -z
+        const float pos[3] = {0.3f, 0.3f, 2.0f}, dir[3] = {0.0f, 0.0f, -1.0f};
+        std::memcpy(cam.K, K, sizeof(K)); std::memcpy(cam.w2c, w2c, sizeof(w2c)); std::memcpy(cam.pos, pos, sizeof(pos)); std::memcpy(cam.dir, dir, sizeof(dir));
+        char name[64]; std::snprintf(name, sizeof(name), "%dx%d#%u", w, h, j);
+        mve::ByteImage::Ptr img = mve::ByteImage::create(w, h, 3);
+        for (int p = 0; p < w * h * 3; ++p) img->get_data_pointer()[p] = (std::uint8_t)(40 + (p * 7 + j) % 200);
+        mve::image::file_registry()[name] = img;
+        if ((int)j == fail_view) mve::image::unreadable_files().insert(name);
+        views.push_back(tex::TextureView(j, cam, name));
+    }
+    acc::RayHook& hook = acc::ray_hook();
+    hook.fn = nullptr; hook.brute = 0; hook.calls = 0;
+    tex::Settings st; st.geometric_visibility_test = false; st.data_term = tex::DATA_TERM_AREA;   // (the stand-in gradient images are keyed by the registered image: copies have none)
+    tex::DataCosts data_costs(1, n_views);
+    mve::image::load_copies() = true;
+    const long before = mve::ImageCensus::live().load();
+    mve::ImageCensus::peak().store(before);
+    int rc = 0;
+    try { tex::calculate_data_costs(mesh, &views, st, &data_costs); }
+    catch (std::exception& e) { rc = 1; if (err && err_cap > 0) { std::strncpy(err, e.what(), (std::size_t)err_cap - 1); err[err_cap - 1] = 0; } }
+    mve::image::load_copies() = false;
+    out[0] = mve::ImageCensus::peak().load() - before;
+    out[1] = mve::ImageCensus::live().load() - before;     // copies that are still bound to a view (get_image() asserts instead of answering)
+    mve::image::file_registry().clear(); mve::image::gradient_registry().clear(); mve::image::unreadable_files().clear();
+    return rc;
+}
+
 // tex::postprocess_face_infos (calculate_data_costs.cpp:253-306, exported at texturing.h:71-74) on caller-supplied infos,
 // in the order given: the reference's own outlier detection / erase / sort / max / histogram / percentile / set_value
 std::int64_t ref_postprocess_face_infos(std::uint32_t n_faces, std::uint32_t n_views, const std::uint32_t* info_ptr, const std::uint16_t* view_id,

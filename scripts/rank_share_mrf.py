@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import mvs_texturing_amd as M
-from mvs_texturing_amd import multigpu as G
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+import multigpu as G   # test harness (tests/tools)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="3"); ap.add_argument("--parts", type=int, default=8); ap.add_argument("--sweeps", type=int, default=10)

@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import mvs_texturing_amd as M
-from mvs_texturing_amd import multigpu as G
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+import multigpu as G   # test harness (tests/tools)
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 s = M.synth.make_scene(**M.synth.CONFIGS[cfg])

@@ -416,16 +416,16 @@ def test_mrf_mixed_node_classes_in_one_graph(seed):
 
 
 def test_sweep_loop_as_a_replayed_graph_equals_direct_launches():
-    """the sweep loop replayed from a hipGraph (two sweeps + steps per launch; api.hip prepare_sweep_graph) against direct launches and
-    the oracle: same labels, energy, sweep count; the second solve on the context updates the executable graph instead of
-    instantiating a new one; an odd max_sweeps ends with a directly launched sweep; a mixed-class instance (another graph topology)
-    after a uniform one re-instantiates."""
+    """the sweep loop replayed from a hipGraph (one period of the damping schedule = four sweeps + their steps per launch; api.hip
+    prepare_sweep_graph) against direct launches and the oracle: same labels, energy, sweep count; the second solve on the context
+    updates the executable graph instead of instantiating a new one; a max_sweeps that is no multiple of four ends with directly
+    launched sweeps; a mixed-class instance (another graph topology) after a uniform one re-instantiates."""
     s = get_scene("bumpy")
     ref, _ = O.data_costs(s)
     c = M.Context(0)
     try:
         c.costs_upload(M.viewsel.DataCosts(ref.n_faces, ref.n_views, ref.col_ptr, ref.view_id, ref.cost))
-        for p in (dict(), dict(max_sweeps=25, min_sweeps=25), dict(max_sweeps=7, min_sweeps=7)):
+        for p in (dict(), dict(max_sweeps=25, min_sweeps=25), dict(max_sweeps=13, min_sweeps=13)):
             lo, so = O.view_selection(ref, s.adj_ptr, s.adj, O.default_mrf_params(**p))
             c.set_option("mrf_graph", 0)
             l0, s0 = c.view_selection(s.adj_ptr, s.adj, M.viewsel.default_mrf_params(**p))
@@ -565,7 +565,7 @@ def test_logical_shards_on_one_gpu_equal_single(P):
     """P contexts on one device, halo exchange by the planned index lists (no collective):
     partition invariance of data costs AND labels, the property the 8-GPU run relies on"""
     import torch
-    from mvs_texturing_amd import multigpu as G
+    import multigpu as G
     s = get_scene("bumpy")
     dev = torch.device("cuda:0")
     perm = G.morton_order(s.verts, s.faces)
@@ -708,7 +708,7 @@ def test_partition_faces_entry_points():
     """mvs_partition_faces / mvs_ctx_partition_faces: a permutation, the same from host arrays and from the resident mesh, the same
     for the mesh in another vertex order, equal cuts; contiguous parts of it are compact (few cut edges) although the caller's order
     is random; multigpu.morton_order / hilbert_order (numpy) are what it is compared with."""
-    from mvs_texturing_amd import multigpu as G
+    import multigpu as G
     s0 = get_scene("spiky32")
     s = M.synth.permute_scene(s0, seed=3)
     F = s.n_faces
@@ -729,7 +729,7 @@ def test_partition_faces_entry_points():
 
 
 def _renumbered(name):
-    from mvs_texturing_amd import multigpu as G
+    import multigpu as G
     s = get_scene(name)
     perm = G.morton_order(s.verts, s.faces)
     faces, normals, adj_ptr, adj, _ = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)
@@ -1311,7 +1311,7 @@ def _two_rank_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     from conftest import ROOT
     sys.path.insert(0, ROOT)
-    from mvs_texturing_amd import multigpu as G
+    import multigpu as G
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
@@ -1338,7 +1338,7 @@ def test_two_ranks_over_torch_distributed_equal_single(tmp_path):
     """the real driver (multigpu.ShardedPipeline over torch.distributed) with 2 ranks; both ranks share cuda:0 and
     use gloo here because a 1-GPU box cannot host two RCCL ranks -- the collectives' call pattern is the N-GPU one"""
     import torch.multiprocessing as mp
-    from mvs_texturing_amd import multigpu as G
+    import multigpu as G
     s = get_scene("bumpy")
     perm = G.morton_order(s.verts, s.faces)
     faces, normals, adj_ptr, adj, inv = G.renumber_faces(s.faces, s.normals, s.adj_ptr, s.adj, perm)

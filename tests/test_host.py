@@ -261,7 +261,7 @@ def test_hilbert_index_is_a_hilbert_curve(tmp_path):
     (checked exhaustively on the 3 low bits x 3 axes sub-lattices it is built from), and the device function,
     compiled for the host from the very source text, must agree with it on random lattice points."""
     import subprocess
-    from mvs_texturing_amd import multigpu as G
+    import multigpu as G
     # (a) curve property of the construction, exhaustively at 4 bits per axis: the same routine with Q starting at 8
     def hilbert(q, bits):
         X = [q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy()]

@@ -142,3 +142,25 @@ def test_replacement_tu_throws_upstreams_exceptions(libs, capfd):
         assert n == -1
         assert "Exeeded maximal number of views" in capfd.readouterr().err
     del OL
+
+
+def test_replacement_tu_holds_a_bounded_number_of_images_and_releases_them_on_failure(libs):
+    """Upstream loads and releases ONE view's image per iteration (calculate_data_costs.cpp:157-231).  The replacement translation unit
+    supplies the pixels through an mvs_image_source: never more than max_in_flight (4) decoded images alive at once, whatever the number of
+    views; when a view's image cannot be loaded (upstream's util::Exception of a missing file) the views loaded so far are released and
+    upstream's own exception reaches the caller -- the same text from both libraries.  (the adapter used to load every
+    view up front and left them loaded when load_image threw.)"""
+    R, D = libs
+    for L in (R, D):
+        L.ref_image_lifetime.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        L.ref_image_lifetime.restype = C.c_int
+    texts = []
+    for L, peak_max in ((R, 2), (D, 4)):
+        out = (C.c_long * 2)(); err = C.create_string_buffer(256)
+        assert L.ref_image_lifetime(23, 640, 480, -1, out, err, 256) == 0, err.value
+        assert 1 <= out[0] <= peak_max and out[1] == 0, ("all views fine", list(out))
+        assert L.ref_image_lifetime(23, 640, 480, 9, out, err, 256) == 1
+        assert 1 <= out[0] <= peak_max and out[1] == 0, ("view 9 missing", list(out))
+        texts.append(err.value.decode())
+    assert texts[0] == texts[1] == "Cannot open file: 640x480#9", texts
+    M.load_library().mvs_release_cached()

@@ -1,4 +1,4 @@
-"""CPU tests of the multi-GPU host logic (mvs-texturing_amd/multigpu.py): partitioning,
+"""CPU tests of the multi-GPU host logic (tests/tools/multigpu.py): partitioning,
 the halo plan, and the exchange over torch.distributed with the gloo backend at
 world_size 2.  The per-rank compute is replaced by a numpy stand-in whose updates
 depend on neighbours' messages, so a wrong or incomplete halo changes the result."""
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import mvs_texturing_amd as M
-from mvs_texturing_amd import multigpu as G
+import multigpu as G
 from conftest import ROOT, get_scene
 from util_cases import random_mrf
 

@@ -1,4 +1,4 @@
-"""HARNESS-LEVEL driver of the sharded path: partitioning helpers (Morton / Hilbert order, renumbering) and a reference
+"""TEST HARNESS (tests/tools; not part of the product package).  HARNESS-LEVEL driver of the sharded path: partitioning helpers (Morton / Hilbert order, renumbering) and a reference
 implementation of the per-rank loop over torch.distributed, kept for the CPU tests (gloo, numpy stand-in solver) and for
 1-GPU boxes where several ranks share cuda:0.  The PRODUCT's sharded path is C++: csrc/shard.hip behind
 mvs_shard_* (device-side halo plan, RCCL send / recv to neighbours, bytes on the wire); bench.py uses it for N > 1.
@@ -332,7 +332,7 @@ class GpuShardOps:
         self.m_buf = torch.zeros(1, dtype=torch.int32, device=adj_dev.device)
 
     def _chk(self, st):
-        from .viewsel import _check
+        from mvs_texturing_amd.viewsel import _check
         _check(self.L, st)
 
     def _sync_in(self):
@@ -381,7 +381,7 @@ class GpuShardOps:
         self._chk(self.L.mvs_ctx_mrf_step(self.h, self.C.c_void_p(e.data_ptr())))
 
     def poll(self, n):
-        from .viewsel import MrfProgress
+        from mvs_texturing_amd.viewsel import MrfProgress
         pg = MrfProgress()
         self._chk(self.L.mvs_ctx_mrf_poll(self.h, n, self.C.byref(pg)))
         return {f[0]: getattr(pg, f[0]) for f in pg._fields_}
@@ -441,7 +441,7 @@ def sharded_data_costs(ctx, settings, part_begin, me, dist=None, group=None, dev
     global nnz)."""
     import ctypes as C
     import torch
-    from .viewsel import DcStats, _check, _stats_dict, DataCosts
+    from mvs_texturing_amd.viewsel import DcStats, _check, _stats_dict, DataCosts
     L, h = ctx.L, ctx.h
     P = len(part_begin) - 1
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels, copies and RCCL ordered on one stream
