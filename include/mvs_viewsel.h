@@ -204,7 +204,7 @@ static inline uint64_t mvs_fp_mix(uint64_t k, uint64_t v) {
 typedef void (*mvs_csr_chunk_fn)(void* user, uint32_t first_face, uint32_t n_faces, const uint32_t* col_ptr, const uint16_t* view_id, const float* cost);
 mvs_status mvs_data_costs_stream(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_settings* settings,
                                  mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats);
-/* the same with the host images supplied view by view through an mvs_image_source (above): host memory is bounded by max_in_flight decoded
+/* the same with the host images supplied view by view through an mvs_image_source, see above: host memory is bounded by max_in_flight decoded
  * images instead of the whole scene's -- what the replacement of tex::calculate_data_costs calls (integration/view_selection_mi355x.cpp) */
 mvs_status mvs_data_costs_stream_from(const mvs_mesh* mesh, const mvs_view* views, uint32_t n_views, const mvs_image_source* images,
                                       const mvs_settings* settings, mvs_csr_chunk_fn fn, void* user, mvs_csr* shape_out, mvs_dc_stats* stats);
@@ -285,7 +285,7 @@ mvs_status mvs_ctx_get_profile(mvs_ctx* ctx, char* buf, size_t buf_size);
 mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device);
 /* views: HOST array of n structs; their rgb pointers are device pointers iff rgb_on_device */
 mvs_status mvs_scene_set_views(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, int rgb_on_device);
-/* host images supplied view by view (mvs_image_source): mvs_view.rgb is ignored */
+/* host images supplied view by view -- an mvs_image_source; mvs_view.rgb is ignored */
 mvs_status mvs_scene_set_views_from(mvs_ctx* ctx, const mvs_view* views, uint32_t n_views, const mvs_image_source* images);
 /* restrict the data-cost computation to the faces at POSITIONS [begin, end) of the library's face order (the caller's ids with
  * option "face_order" = 0); the whole mesh stays the occluder set.  Default: all faces.  (Building block of the sharded drivers.) */
