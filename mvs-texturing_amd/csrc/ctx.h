@@ -126,6 +126,7 @@ struct mvs_ctx {
     bool prep_fused = true;  // image prep: luminance + Sobel in one pass through LDS (false: the two-pass kernels; identical output)
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
+    bool bvh_caller_order = false;   // experiment hook (with face_order = 0): the implicit BVH is built over the caller's face order as it is (tree-quality probes)
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
     int info_wave_area = 32;   // footprints (sampled ones) above this many pixels go to the wave-per-footprint kernel (k_dc.hip wave_info_kernel); 0 = every footprint serial = bit-exact with the reference's fp64 scan order
     bool info_words = true;    // small footprints of the gradient term: integer word walk + certificate in info_kernel (option "info_words"; 0: serial fp64 walk)

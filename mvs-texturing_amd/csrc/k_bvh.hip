@@ -649,6 +649,7 @@ void build_scene_order(mvs_ctx* ctx) {
         hipLaunchKernelGGL(remap_faces_kernel, fg, dim3(256), 0, s, ctx->d_faces, (const uint32_t*)nullptr, (const uint32_t*)ctx->vpos.p, F, ctx->i_faces.p);
         MVS_LAUNCH_CHECK();
         ctx->ifc = ctx->i_faces.p;
+        if (ctx->bvh_caller_order) { ctx->tri_order = nullptr; return; }   // experiment hook: the BVH's triangle slots ARE the caller's face order (scripts/bvh_order_probe.py)
         hipLaunchKernelGGL(curve_key_kernel, fg, dim3(256), 0, s, ctx->iv, ctx->ifc, F, box, ctx->sort_k.p, ctx->sort_v.p);
         MVS_LAUNCH_CHECK();
         sort_by_key30(ctx, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F);

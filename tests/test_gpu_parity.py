@@ -986,6 +986,28 @@ def test_config5_one_ranks_share_against_the_oracle():
         assert so[k] == sg[k], k
 
 
+def test_config5_in_full_on_eight_logical_ranks():
+    """BASELINE config 5 IN FULL (n = 707: 9 996 980 faces, 1000 views 2048x1536, label-space compression to 64) through the C++ sharded path
+    with 8 thread-ranks on the one GPU of a test box (scripts/config5_full.py, a process of its own): every rank reports the same
+    all-reduced energy and sweep count, every face is labelled with a view of its compressed column, the same scene cut into 4 parts
+    gives the same labels, and 2 000 faces of EVERY rank's table equal the live oracle's columns (pattern, view ids, costs bit for bit)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "config5_full.py"), "--parts", "8", "--also", "4", "--oracle-window", "16000"],
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-4000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["faces"] == 9996980 and d["views"] == 1000 and d["P"] == 8 and len(d["ranks"]) == 8
+    assert d["all_ranks_agree"] and d["labels_valid"] and d["partition_invariant"], {k: d[k] for k in ("all_ranks_agree", "labels_valid", "partition_invariant")}
+    assert d["oracle_windows_equal"] and len(d["oracle_windows"]) == 8 and all(w["faces"] == 2000 and w["entries"] > 0 for w in d["oracle_windows"]), d["oracle_windows"]
+    assert sum(x["faces"] for x in d["ranks"]) == d["faces"] and max(x["kmax"] for x in d["ranks"]) == 64
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(d, open(os.path.join(out, "config5_full_p8_logical.json"), "w"))
+
+
 @isolated
 @pytest.mark.parametrize("name,P", [("bumpy", 2), ("bumpy", 3), ("spiky32", 8), ("bumpy", (0.0, 0.5, 0.5, 1.0)), ("bumpy-shuffled", 3)],
                          ids=["bumpy-2", "bumpy-3", "spiky32-8", "bumpy-empty-part", "bumpy-shuffled-3"])
