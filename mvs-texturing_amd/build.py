@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HIP_SOURCES = ["scan.hip", "k_prep.hip", "k_bvh.hip", "k_dc.hip", "k_mrf.hip", "k_region.hip", "k_mesh.hip", "k_patch.hip", "k_order.hip", "shard.hip", "api.hip"]
+HIP_SOURCES = ["scan.hip", "k_prep.hip", "k_bvh.hip", "k_kdorder.hip", "k_dc.hip", "k_mrf.hip", "k_region.hip", "k_mesh.hip", "k_patch.hip", "k_order.hip", "shard.hip", "api.hip"]
 BLOCKS_SOURCES = ["mgpu.hip"]                       # NOT in the product library
 BLOCKS_LIB = os.path.join(CSRC, "libmvs_blocks.so")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -39,19 +39,31 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-// scene_box: 6 ordered-uint words (min xyz, max xyz), initialised to 0xFFFFFFFF x3, 0 x3
-__global__ void bbox_kernel(const float* __restrict__ verts, uint32_t n_verts, uint32_t* __restrict__ box) {
+// scene_box: 6 ordered-uint words (min xyz, max xyz).  Two stages: every block leaves ONE box (butterflies + LDS), a second launch folds
+// the <= 512 block boxes.  (Rounds 1 - 5 folded with atomics straight into the six words: same-address traffic from every wave serialises
+// in one L2 channel -- 0.10 ms for a million vertices, rocprofv3 round 6; now ~0.01.)
+__global__ void __launch_bounds__(256) bbox_kernel(const float* __restrict__ verts, uint32_t n_verts, uint32_t* __restrict__ part /* [gridDim.x][6] */) {
+    __shared__ uint32_t s_red[4][6];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_verts; v += gridDim.x * blockDim.x)
         for (int a = 0; a < 3; ++a) { const float x = verts[3 * (size_t)v + a]; lo[a] = fminf(lo[a], x); hi[a] = fmaxf(hi[a], x); }
-    // same-address atomics serialise (~12 ns each): skip the ones that cannot move the bound any more
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
-        if ((threadIdx.x & 63) == 0) {
-            const uint32_t l = f2ord(lo[a]), h = f2ord(hi[a]);
-            if (l < __hip_atomic_load(&box[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&box[a], l);
-            if (h > __hip_atomic_load(&box[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&box[3 + a], h);
-        }
+        if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][a] = f2ord(lo[a]); s_red[threadIdx.x >> 6][3 + a] = f2ord(hi[a]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        uint32_t v = s_red[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? min(v, s_red[w][threadIdx.x]) : max(v, s_red[w][threadIdx.x]);
+        part[6 * blockIdx.x + threadIdx.x] = v;
+    }
+}
+__global__ void __launch_bounds__(64) bbox_fold_kernel(const uint32_t* __restrict__ part, uint32_t n_parts, uint32_t* __restrict__ box) {
+    for (int a = 0; a < 6; ++a) {
+        uint32_t v = a < 3 ? 0xFFFFFFFFu : 0u;
+        for (uint32_t k = threadIdx.x; k < n_parts; k += 64) v = a < 3 ? min(v, part[6 * k + a]) : max(v, part[6 * k + a]);
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor(v, o, 64); v = a < 3 ? min(v, w) : max(v, w); }
+        if (threadIdx.x == 0) box[a] = v;
     }
 }
 
@@ -127,23 +139,26 @@ __global__ void invert_perm_kernel(const uint32_t* __restrict__ perm, uint32_t n
     if (s < n) inv[perm[s]] = s;
 }
 
-// Local refinement of the curve order.  A window of RW = 512 consecutive triangles is a whole number of subtrees of the
-// implicit tree (16-triangle leaves: two level-1 nodes; 8-triangle leaves: one level-2 node).  Inside each window the triangles are re-partitioned top down: a segment is sorted
+// The LOWER levels of the order, in LDS.  A window of RW = 2048 consecutive triangles is a whole number of subtrees of the implicit tree;
+// the levels above it are cut by k_kdorder.hip (round 6: the exact top-down cuts of the whole tree are worth 25 % of the ray stage; rounds
+// 1 - 5 cut only inside windows of 512 of the Hilbert order).  Inside each window the triangles are re-partitioned top down: a segment is sorted
 // along the longest axis of its centroids and cut in the middle (spatial median), recursively down to the leaves, so two
 // binary levels = one 4-ary level.  The curve decides WHICH 512 triangles share a subtree, the median splits decide how
 // they are grouped inside it: on the C3 mesh 26 % fewer leaf rounds and 34 % fewer (ray, leaf) pairs per packet
 // (simulated; windows of 2048 would give 29 % / 38 %).  Deterministic: ties are broken by the triangle id.
-constexpr int RW = 512;
-__global__ void __launch_bounds__(256) refine_order_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t* __restrict__ order,
+constexpr int RW = 2048, RW_T = RW / 2;   // window and threads (one compare-exchange pair per thread); the levels above: k_kdorder.hip
+// (Round 6 also tried the window in REGISTERS -- two elements per thread, distances 2 .. 64 as wave shuffles, only >= 128 through LDS: 0.54 ms
+//  against 0.37 ms for this kernel at C3: a shuffle is an LDS-crossbar operation too, and every element fetched its partner instead of every
+//  pair being visited once.)  Key and slot of a position are ONE 8-byte LDS word: half the LDS instructions of separate arrays.
+__global__ void __launch_bounds__(RW_T) refine_order_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t* __restrict__ order,
                                                            uint32_t n_faces) {
     __shared__ float s_c[3][RW];          // centroid of the triangle in slot k (slots never move)
     __shared__ uint32_t s_id[RW];         // triangle id of slot k (0xFFFFFFFF: padding behind the last triangle)
-    __shared__ float s_key[RW];           // sort key at position i
-    __shared__ uint32_t s_slot[RW];       // slot at position i
+    __shared__ uint2 s_ks[RW];            // position i: {sort key (float bits), slot}
     __shared__ uint32_t s_box[RW / (2 * LEAF_T)][6];   // centroid box per segment (ordered uints)
     const uint32_t w0 = blockIdx.x * RW;
     const int t = threadIdx.x;
-    for (int i = t; i < RW; i += 256) {
+    for (int i = t; i < RW; i += RW_T) {
         const uint32_t g = w0 + i;
         uint32_t id = 0xFFFFFFFFu; float c[3] = {INFINITY, INFINITY, INFINITY};
         if (g < n_faces) {
@@ -151,18 +166,18 @@ __global__ void __launch_bounds__(256) refine_order_kernel(const float* __restri
             const uint32_t* fv = faces + 3 * (size_t)id;
             for (int a = 0; a < 3; ++a) c[a] = (verts[3 * (size_t)fv[0] + a] + verts[3 * (size_t)fv[1] + a] + verts[3 * (size_t)fv[2] + a]) * (1.0f / 3.0f);
         }
-        s_id[i] = id; s_c[0][i] = c[0]; s_c[1][i] = c[1]; s_c[2][i] = c[2]; s_slot[i] = (uint32_t)i;
+        s_id[i] = id; s_c[0][i] = c[0]; s_c[1][i] = c[1]; s_c[2][i] = c[2]; s_ks[i] = make_uint2(0u, (uint32_t)i);
     }
     __syncthreads();
     for (int seg = RW; seg > (int)LEAF_T; seg >>= 1) {
         const int nseg = RW / seg;
-        for (int k = t; k < nseg * 6; k += 256) s_box[k / 6][k % 6] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
+        for (int k = t; k < nseg * 6; k += RW_T) s_box[k / 6][k % 6] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
         __syncthreads();
         // centroid box of every segment: a wave holds 64 consecutive positions, i.e. whole segments or a 64-wide piece of
         // one -- butterfly min / max over min(seg, 64) lanes, then one lane per piece merges into LDS (same-address LDS
         // atomics from all 512 positions serialise 64-fold)
-        for (int i = t; i < RW; i += 256) {
-            const uint32_t sl = s_slot[i];
+        for (int i = t; i < RW; i += RW_T) {
+            const uint32_t sl = s_ks[i].y;
             const bool ok = s_id[sl] != 0xFFFFFFFFu;
             uint32_t mn[3], mx[3];
             for (int a = 0; a < 3; ++a) { const uint32_t o = f2ord(s_c[a][sl]); mn[a] = ok ? o : 0xFFFFFFFFu; mx[a] = ok ? o : 0u; }
@@ -173,7 +188,7 @@ __global__ void __launch_bounds__(256) refine_order_kernel(const float* __restri
                 for (int a = 0; a < 3; ++a) { atomicMin(&s_box[i / seg][a], mn[a]); atomicMax(&s_box[i / seg][3 + a], mx[a]); }
         }
         __syncthreads();
-        for (int i = t; i < RW; i += 256) {
+        for (int i = t; i < RW; i += RW_T) {
             const uint32_t* b = s_box[i / seg];
             int ax = 0;
             if (b[0] != 0xFFFFFFFFu) {   // segment holds at least one triangle
@@ -182,19 +197,19 @@ __global__ void __launch_bounds__(256) refine_order_kernel(const float* __restri
                 if (e1 > best) { best = e1; ax = 1; }
                 if (e2 > best) { best = e2; ax = 2; }
             }
-            s_key[i] = s_c[ax][s_slot[i]];
+            s_ks[i].x = __float_as_uint(s_c[ax][s_ks[i].y]);
         }
         __syncthreads();
         // bitonic sort of every aligned segment of `seg` positions by (key, triangle id), ascending
         for (int k = 2; k <= seg; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
-                const int p = t;                                           // RW / 2 = 256 pairs, one per thread
+                const int p = t;                                           // RW / 2 pairs, one per thread
                 const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
                 const bool up = (k == seg) || ((i & k) == 0);
-                const float ka = s_key[i], kb = s_key[l];
-                const uint32_t sa = s_slot[i], sb = s_slot[l];
-                const bool gt = ka > kb || (ka == kb && s_id[sa] > s_id[sb]);
-                if (gt == up) { s_key[i] = kb; s_key[l] = ka; s_slot[i] = sb; s_slot[l] = sa; }
+                const uint2 ea = s_ks[i], eb = s_ks[l];
+                const float ka = __uint_as_float(ea.x), kb = __uint_as_float(eb.x);
+                const bool gt = ka > kb || (ka == kb && s_id[ea.y] > s_id[eb.y]);
+                if (gt == up) { s_ks[i] = eb; s_ks[l] = ea; }
                 // partners at distance j <= 64 live in the 128 positions this wave owns for all smaller j (LDS operations of
                 // a wave execute in order): a block barrier is needed only while j > 64 or before the next k starts above 64
                 if (j > 64 || (j == 1 && k >= 128)) __syncthreads();
@@ -202,7 +217,7 @@ __global__ void __launch_bounds__(256) refine_order_kernel(const float* __restri
         __syncthreads();   // the next level (and the write-back) read positions other waves sorted
     }
     // padding keys are +inf with the largest id: they stay at the tail of every segment, so the triangles are a prefix
-    for (int i = t; i < RW; i += 256) { const uint32_t g = w0 + i; if (g < n_faces) order[g] = s_id[s_slot[i]]; }
+    for (int i = t; i < RW; i += RW_T) { const uint32_t g = w0 + i; if (g < n_faces) order[g] = s_id[s_ks[i].y]; }
 }
 
 __device__ __forceinline__ float pad_from_box(const uint32_t* __restrict__ box) {
@@ -596,6 +611,8 @@ void sort_by_key30(mvs_ctx* ctx, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in
 }
 }  // namespace
 
+bool kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, uint32_t* order, uint32_t F, uint32_t window, uint32_t leaf_window);   // k_kdorder.hip
+
 // Lays the resident mesh out along a Hilbert curve: ctx->iv / ifc / inr (see ctx.h) and, with option "face_order" != 0, the face
 // permutation f_perm / f_pos.  The caller's arrays are read with gathers exactly three times (the keys, the faces, the normals);
 // everything after this function streams the copy.  Deterministic (stable sorts, ties by id): every rank of a sharded run derives
@@ -603,15 +620,16 @@ void sort_by_key30(mvs_ctx* ctx, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in
 void build_scene_order(mvs_ctx* ctx) {
     const uint32_t F = ctx->n_faces, NV = ctx->n_verts;
     hipStream_t s = ctx->stream;
-    ctx->scene_box.ensure(8);
+    ctx->scene_box.ensure(8 + 6 * 512);
     uint32_t* box = (uint32_t*)ctx->scene_box.p;
     const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
     ctx->mesh_ordered = false; ctx->tri_order = nullptr;
     ctx->iv = ctx->d_verts; ctx->ifc = ctx->d_faces; ctx->inr = ctx->d_normals;
     if (F == 0 || NV == 0) return;
-    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<uint32_t>((NV + 255) / 256, 512u)), dim3(256), 0, s, ctx->d_verts, NV, box);
-    MVS_LAUNCH_CHECK();
+    { const uint32_t nb = std::min<uint32_t>((NV + 255) / 256, 512u);
+      hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, s, ctx->d_verts, NV, box + 8); MVS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(bbox_fold_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)(box + 8), nb, box); MVS_LAUNCH_CHECK(); }
     const size_t n_max = std::max<size_t>(F, NV);
     ctx->sort_k.ensure(n_max); ctx->sort_k2.ensure(n_max); ctx->sort_v.ensure(n_max); ctx->sort_v2.ensure(F);
     // vertices along the curve (rays are launched in this order: 64 neighbouring vertices per wave = a compact patch of nearly parallel rays)
@@ -625,8 +643,13 @@ void build_scene_order(mvs_ctx* ctx) {
     MVS_LAUNCH_CHECK();
     ctx->iv = ctx->i_verts.p;
     ctx->i_faces.ensure(3 * (size_t)F + 4);
-    static_assert(RW == 2 * 256 && RW % (int)LEAF_T == 0, "one pair per thread");
+    static_assert(RW == 2 * RW_T && RW % (int)LEAF_T == 0 && RW >= 2048, "one pair per thread; k_kdorder.hip hands over at RW");
     const dim3 fg((F + 255) / 256), rg((F + RW - 1) / RW);
+    // upper levels: exact top-down median cuts inside windows of ctx->bvh_window positions of the curve (0: the whole mesh; 1: none = the
+    // order of rounds 1 - 5 with a larger LDS window); a mesh with thousands of EQUAL centroid coordinates at a cut keeps the curve order
+    auto upper_levels = [&](const float* v, const uint32_t* f, uint32_t* order) {
+        if (ctx->bvh_window != 1u && !kd_refine_order(ctx, v, f, order, F, ctx->bvh_window, (uint32_t)RW) && ctx->verbose) fprintf(stderr, "[mvs] face order: too many equal centroid coordinates at a cut, keeping the curve order above %d faces\n", RW);
+    };
     if (ctx->face_order != 0) {
         // faces along the curve: keys from the caller's arrays, the refinement and everything later on the copy
         ctx->f_tmp.ensure(3 * (size_t)F + 4); ctx->f_perm.ensure((size_t)F + 1); ctx->f_pos.ensure((size_t)F + 1); ctx->i_normals.ensure(3 * (size_t)F + 4);
@@ -637,7 +660,8 @@ void build_scene_order(mvs_ctx* ctx) {
         MVS_LAUNCH_CHECK();
         hipLaunchKernelGGL(iota_kernel, fg, dim3(256), 0, s, ctx->sort_v.p, F);
         MVS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(refine_order_kernel, rg, dim3(256), 0, s, (const float*)ctx->i_verts.p, (const uint32_t*)ctx->f_tmp.p, ctx->sort_v.p, F);
+        upper_levels(ctx->i_verts.p, ctx->f_tmp.p, ctx->sort_v.p);
+        hipLaunchKernelGGL(refine_order_kernel, rg, dim3(RW_T), 0, s, (const float*)ctx->i_verts.p, (const uint32_t*)ctx->f_tmp.p, ctx->sort_v.p, F);
         MVS_LAUNCH_CHECK();
         hipLaunchKernelGGL(remap_faces_kernel, fg, dim3(256), 0, s, (const uint32_t*)ctx->f_tmp.p, (const uint32_t*)ctx->sort_v.p, (const uint32_t*)nullptr, F, ctx->i_faces.p);
         MVS_LAUNCH_CHECK();
@@ -653,7 +677,8 @@ void build_scene_order(mvs_ctx* ctx) {
         hipLaunchKernelGGL(curve_key_kernel, fg, dim3(256), 0, s, ctx->iv, ctx->ifc, F, box, ctx->sort_k.p, ctx->sort_v.p);
         MVS_LAUNCH_CHECK();
         sort_by_key30(ctx, ctx->sort_k.p, ctx->sort_k2.p, ctx->sort_v.p, ctx->sort_v2.p, F);
-        hipLaunchKernelGGL(refine_order_kernel, rg, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->sort_v2.p, F);
+        upper_levels(ctx->iv, ctx->ifc, ctx->sort_v2.p);
+        hipLaunchKernelGGL(refine_order_kernel, rg, dim3(RW_T), 0, s, ctx->iv, ctx->ifc, ctx->sort_v2.p, F);
         MVS_LAUNCH_CHECK();
         ctx->tri_order = ctx->sort_v2.p;
     }

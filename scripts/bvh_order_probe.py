@@ -25,10 +25,11 @@ def run(name, faces, normals, hook):
     if hook:
         c.set_option("face_order", 0); c.set_option("bvh_caller_order", 1)
     c.set_mesh(s.verts, faces, normals); c.set_views(s.cams, s.images)
+    st = c.data_costs(M.Settings())                 # with the traversal counters (their atomics cost time: not the timed pass)
+    c.set_option("count_rays", 0)
     c.data_costs(M.Settings()); c.get_profile()
-    st = None
     for _ in range(3):
-        st = c.data_costs(M.Settings())
+        c.data_costs(M.Settings())
     pr = c.get_profile()
     tab = c.costs_download()
     c.close()
@@ -41,10 +42,19 @@ def run(name, faces, normals, hook):
 rows = []
 base, tab0 = run("library (Hilbert + median splits in 512-face windows)", s.faces, s.normals, False)
 rows.append(base)
-for mode, name in ((0, "host: cuts at the implicit child boundaries, longest centroid axis"), (1, "host: cuts at the implicit child boundaries, SAH axis")):
+c0 = M.Context(0); c0.set_mesh(s.verts, s.faces, s.normals); lib_perm, _ = c0.partition_faces(1); c0.close()    # the library's own order
+lib_perm = np.ascontiguousarray(lib_perm, dtype=np.uint32)
+variants = [(0, 0, "host: whole tree top-down, cuts at the implicit child boundaries, longest centroid axis"), (1, 0, "host: whole tree top-down, SAH axis")]
+if os.environ.get("BVH_PROBE_QUICK"):
+    variants = variants[:1]
+variants += [(0, w, "library order + longest-axis cuts inside aligned windows of %d faces" % w) for w in (4096, 262144)]
+variants += [(20, ns, "top levels from a sample of %d faces (cells of 16 samples), cell-major, then faces inside windows of 4096" % ns) for ns in (8192, 32768)]
+variants += [(10, 1, "library order + three passes: groups of 4096 over the mesh, groups of 64 inside windows of 262144, faces inside windows of 4096 (longest axis)")]
+for mode, window, name in variants:
     perm = np.zeros(F, np.uint32)
     t = time.time()
-    B.bvh_order(C.c_uint32(s.verts.shape[0]), s.verts.ctypes.data_as(C.c_void_p), C.c_uint32(F), s.faces.ctypes.data_as(C.c_void_p), C.c_int(mode), perm.ctypes.data_as(C.c_void_p))
+    B.bvh_order(C.c_uint32(s.verts.shape[0]), s.verts.ctypes.data_as(C.c_void_p), C.c_uint32(F), s.faces.ctypes.data_as(C.c_void_p), C.c_int(mode),
+                lib_perm.ctypes.data_as(C.c_void_p) if window else None, C.c_uint32(window), perm.ctypes.data_as(C.c_void_p))
     build_s = time.time() - t
     r, tab = run(name, np.ascontiguousarray(s.faces[perm]), np.ascontiguousarray(s.normals[perm]), True)
     r["host_build_s"] = build_s
