@@ -397,6 +397,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
     else if (n == "bvh_caller_order") ctx->bvh_caller_order = value != 0;
+    else if (n == "bvh_upper_min_faces") { ctx->bvh_upper_min_faces = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 0xFFFFFFFFll)); ctx->order_pinned = false; }
     else if (n == "bvh_window") { ctx->bvh_window = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 0x40000000)); ctx->order_pinned = false; }   // 0 = whole mesh, 1 = no upper-level cuts; otherwise rounded up to a power of two by the builder
     else if (n == "face_order") { ctx->face_order = value != 0 ? 1 : 0; ctx->order_pinned = false; }   // takes effect with the next data-cost pass (the active table keeps the order it was made in)
     else return fail(MVS_ERR_INVALID, "unknown option " + n);

@@ -126,6 +126,7 @@ struct mvs_ctx {
     bool prep_fused = true;  // image prep: luminance + Sobel in one pass through LDS (false: the two-pass kernels; identical output)
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
+    uint32_t bvh_upper_min_faces = 1000000;   // meshes below this many faces keep the Hilbert order above the LDS window (k_bvh.hip build_scene_order)
     uint32_t bvh_window = 262144;    // upper levels of the face order: exact top-down median cuts inside aligned windows of this many positions of the Hilbert order (k_kdorder.hip); 0 = the whole mesh, 1 = none
     mvs::DBuf<float> kd_c[2][3]; mvs::DBuf<uint32_t> kd_id[2], kd_hist, kd_cursor, kd_tie, kd_pivot, kd_box;   // k_kdorder.hip work buffers
     bool bvh_caller_order = false;   // experiment hook (with face_order = 0): the implicit BVH is built over the caller's face order as it is (tree-quality probes)

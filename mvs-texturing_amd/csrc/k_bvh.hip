@@ -648,7 +648,10 @@ void build_scene_order(mvs_ctx* ctx) {
     // upper levels: exact top-down median cuts inside windows of ctx->bvh_window positions of the curve (0: the whole mesh; 1: none = the
     // order of rounds 1 - 5 with a larger LDS window); a mesh with thousands of EQUAL centroid coordinates at a cut keeps the curve order
     auto upper_levels = [&](const float* v, const uint32_t* f, uint32_t* order) {
-        if (ctx->bvh_window != 1u && !kd_refine_order(ctx, v, f, order, F, ctx->bvh_window, (uint32_t)RW) && ctx->verbose) fprintf(stderr, "[mvs] face order: too many equal centroid coordinates at a cut, keeping the curve order above %d faces\n", RW);
+        // (the upper levels cost ~0.4 ms of launches whatever the mesh and pay through the ray stage: measured at 2 M faces x 200 views
+        //  -0.76 ms of rays for +0.50 ms here, at 200 k faces x 200 views -0.05 for +0.38 -- they run from bvh_upper_min_faces faces on; the rule
+        //  looks at the MESH alone, so that mvs_partition_faces and every rank of a sharded run derive the same order whatever views are set)
+        if (ctx->bvh_window != 1u && F >= ctx->bvh_upper_min_faces && !kd_refine_order(ctx, v, f, order, F, ctx->bvh_window, (uint32_t)RW) && ctx->verbose) fprintf(stderr, "[mvs] face order: too many equal centroid coordinates at a cut, keeping the curve order above %d faces\n", RW);
     };
     if (ctx->face_order != 0) {
         // faces along the curve: keys from the caller's arrays, the refinement and everything later on the copy

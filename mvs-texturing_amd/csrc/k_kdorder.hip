@@ -18,7 +18,7 @@
 //     order is deterministic); keys EQUAL to the pivot are ranked by triangle id (a short per-node list, sorted by one block): ties never
 //     make the order depend on scheduling.  The scatter also folds the children's centroid boxes (the next level's axes);
 //   * a node filled to at most half its capacity (the mesh's tail) is not cut: it moves down one level unchanged.
-// Five launches per level, each streaming the window once; levels from the top window (262 144 faces of the Hilbert order, or the whole
+// Five launches per level (three histogram passes, the scatter, ties + the children's axes), each streaming the window once; levels from the top window (262 144 faces of the Hilbert order, or the whole
 // mesh with option "bvh_window" = 0) down to 2 x the LDS window of refine_order_kernel.
 #include "ctx.h"
 
@@ -58,6 +58,19 @@ __device__ __forceinline__ void kd_box_store(KdBox bx, uint32_t* __restrict__ ds
         uint32_t v = is_lo ? 0xFFFFFFFFu : 0u;
         for (uint32_t w = 0; w < n_waves; ++w) { const uint32_t x = s_red[6 * w + threadIdx.x]; v = is_lo ? min(v, x) : max(v, x); }
         dst[threadIdx.x] = v;
+    }
+}
+// the block's box in every thread's registers (res[0 .. 2] lower, res[3 .. 5] upper bounds)
+__device__ __forceinline__ void kd_box_reduce(KdBox bx, uint32_t* s_red, uint32_t res[6]) {
+    for (int a = 0; a < 3; ++a) for (int o = 32; o > 0; o >>= 1) { bx.lo[a] = min(bx.lo[a], (uint32_t)__shfl_xor(bx.lo[a], o, 64)); bx.hi[a] = max(bx.hi[a], (uint32_t)__shfl_xor(bx.hi[a], o, 64)); }
+    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { s_red[6 * wave + a] = bx.lo[a]; s_red[6 * wave + 3 + a] = bx.hi[a]; }
+    __syncthreads();
+    for (int a = 0; a < 6; ++a) {
+        uint32_t v = a < 3 ? 0xFFFFFFFFu : 0u;
+        for (uint32_t w = 0; w < n_waves; ++w) { const uint32_t x = s_red[6 * w + a]; v = a < 3 ? min(v, x) : max(v, x); }
+        res[a] = v;
     }
 }
 struct KdArrays { float* c[3]; uint32_t* id; };
@@ -148,21 +161,18 @@ __global__ void __launch_bounds__(KD_T) kd_centroid_kernel(const float* __restri
     kd_box_store(none, bbox + 12 * (size_t)blockIdx.x + 6, s_red);
 }
 
-// axis[j] of every node of a level = the longest axis of its centroid box = the fold of the block boxes its PARENT's scatter left (side j & 1)
-// and of the parent's tie boxes; the top level (root != 0): the node's own blocks, side 0, no ties.  One wave per node.
-__global__ void __launch_bounds__(64) kd_axis_kernel(uint32_t F, uint32_t parent_cap, int root, const uint32_t* __restrict__ bbox, const uint32_t* __restrict__ tbox /* [parent][2][6] */,
-                                                     uint32_t n_nodes, uint32_t* __restrict__ axis) {
+// the cut axes of the TOP level's nodes = the longest axis of the fold of the block boxes kd_centroid_kernel left (side 0); one wave per node
+// (the levels below get theirs from kd_tie_axis_kernel of the level above)
+__global__ void __launch_bounds__(64) kd_axis_kernel(uint32_t F, uint32_t cap, const uint32_t* __restrict__ bbox, uint32_t n_nodes, uint32_t* __restrict__ axis) {
     const uint32_t j = blockIdx.x;
     if (j >= n_nodes) return;
-    const uint32_t pj = root ? j : j >> 1, side = root ? 0u : (j & 1u);
-    const uint32_t start = pj * parent_cap, n = min(parent_cap, F - start);
+    const uint32_t start = j * cap, n = min(cap, F - start);
     const uint32_t b0 = start / KD_B, nb = (n + KD_B - 1) / KD_B;
     uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
     for (uint32_t k = threadIdx.x; k < nb; k += 64) {
-        const uint32_t* b = bbox + 12 * (size_t)(b0 + k) + 6 * side;
+        const uint32_t* b = bbox + 12 * (size_t)(b0 + k);
         for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], b[a]); hi[a] = max(hi[a], b[3 + a]); }
     }
-    if (!root && threadIdx.x == 0) { const uint32_t* b = tbox + 12 * (size_t)pj + 6 * side; for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], b[a]); hi[a] = max(hi[a], b[3 + a]); } }
     for (int a = 0; a < 3; ++a) for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], (uint32_t)__shfl_xor(lo[a], o, 64)); hi[a] = max(hi[a], (uint32_t)__shfl_xor(hi[a], o, 64)); }
     if (threadIdx.x == 0) { const uint32_t b[6] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]}; axis[j] = (uint32_t)kd_axis(b); }
 }
@@ -172,8 +182,7 @@ struct KdScatter {
     uint32_t* cursor;                // [node][4]: next free slot below / above (non-tie elements), ties listed, overflow flag (node 0 only)
     uint32_t* tie;                   // [node][KD_TIE_CAP] source positions of the keys equal to the pivot (when they are not all taken)
     KdPivot* pivot;                  // [node]
-    uint32_t* bbox;                  // [block][2][6]: centroid boxes of what this block sent below / above (folded by kd_axis_kernel)
-    uint32_t* tbox;                  // [node][2][6]: the same for the listed ties (kd_tie_kernel)
+    uint32_t* bbox;                  // [block][2][6]: centroid boxes of what this block sent below / above (folded by kd_tie_axis_kernel)
 };
 
 __global__ void __launch_bounds__(KD_T) kd_scatter_kernel(KdScatter S, KdArrays in, KdArrays out) {
@@ -242,49 +251,58 @@ __global__ void __launch_bounds__(KD_T) kd_scatter_kernel(KdScatter S, KdArrays 
     kd_box_store(bx_hi, S.bbox + 12 * (size_t)blockIdx.x + 6, s_red);
 }
 
-// the keys equal to a node's pivot, when only some of them go below: ranked by id (one block per node, bitonic sort in LDS)
-__global__ void __launch_bounds__(KD_T) kd_tie_kernel(KdScatter S, KdArrays in, KdArrays out) {
+// One block per node, after its scatter: (a) the keys equal to the node's pivot, when only some of them go below, are ranked by id (bitonic
+// sort in LDS) and placed; (b) the centroid boxes of the node's two halves -- the block boxes its scatter left and the ties' -- are folded
+// into the cut AXES of its children at the next level (no launch of their own, no same-address atomics).
+__global__ void __launch_bounds__(KD_T) kd_tie_axis_kernel(KdScatter S, KdArrays in, KdArrays out, uint32_t* __restrict__ axis_next, uint32_t n_next) {
     __shared__ uint32_t s_id[KD_TIE_CAP], s_p[KD_TIE_CAP];
-    const KdLevel& L = S.L;
     __shared__ uint32_t s_red[6 * 16];
+    const KdLevel& L = S.L;
     const uint32_t j = blockIdx.x, start = j * L.cap;
     if (start >= L.F) return;
     const uint32_t n = min(L.cap, L.F - start), k = L.cap / 2;
     KdBox bx_lo, bx_hi; bx_lo.clear(); bx_hi.clear();
     const uint32_t m = n <= k ? 0u : min(S.cursor[4 * (size_t)j + 2], KD_TIE_CAP);
-    if (m == 0) {   // (block-uniform) nothing listed: the node's tie boxes are empty
-        kd_box_store(bx_lo, S.tbox + 12 * (size_t)j, s_red); kd_box_store(bx_hi, S.tbox + 12 * (size_t)j + 6, s_red);
-        return;
-    }
-    const KdPivot pv = S.pivot[j];
-    for (uint32_t i = threadIdx.x; i < KD_TIE_CAP; i += KD_T) {
-        const bool on = i < m;
-        const uint32_t p = on ? S.tie[(size_t)j * KD_TIE_CAP + i] : 0u;
-        s_p[i] = p; s_id[i] = on ? in.id[p] : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    for (uint32_t kk = 2; kk <= KD_TIE_CAP; kk <<= 1)
-        for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
-            const uint32_t q = threadIdx.x, i = ((q & ~(jj - 1)) << 1) | (q & (jj - 1)), l = i | jj;
-            const bool up = (i & kk) == 0;
-            const uint32_t a = s_id[i], b = s_id[l];
-            if ((a > b) == up) { s_id[i] = b; s_id[l] = a; const uint32_t pa = s_p[i]; s_p[i] = s_p[l]; s_p[l] = pa; }
-            __syncthreads();
+    if (m) {   // (block-uniform)
+        const KdPivot pv = S.pivot[j];
+        for (uint32_t i = threadIdx.x; i < KD_TIE_CAP; i += KD_T) {
+            const bool on = i < m;
+            const uint32_t p = on ? S.tie[(size_t)j * KD_TIE_CAP + i] : 0u;
+            s_p[i] = p; s_id[i] = on ? in.id[p] : 0xFFFFFFFFu;
         }
-    for (uint32_t i = threadIdx.x; i < KD_TIE_CAP; i += KD_T) {
-        const bool on = i < m;
-        const bool lo = on && i < pv.take;
-        float c[3] = {0.f, 0.f, 0.f};
-        if (on) {
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= KD_TIE_CAP; kk <<= 1)
+            for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+                const uint32_t q = threadIdx.x, i = ((q & ~(jj - 1)) << 1) | (q & (jj - 1)), l = i | jj;
+                const bool up = (i & kk) == 0;
+                const uint32_t a = s_id[i], b = s_id[l];
+                if ((a > b) == up) { s_id[i] = b; s_id[l] = a; const uint32_t pa = s_p[i]; s_p[i] = s_p[l]; s_p[l] = pa; }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < KD_TIE_CAP; i += KD_T) {
+            if (i >= m) continue;
+            const bool lo = i < pv.take;
             const uint32_t p = s_p[i];
             const uint32_t dst = lo ? start + pv.below + i : start + k + (i - pv.take);
-            c[0] = in.c[0][p]; c[1] = in.c[1][p]; c[2] = in.c[2][p];
-            out.c[0][dst] = c[0]; out.c[1][dst] = c[1]; out.c[2][dst] = c[2]; out.id[dst] = s_id[i];
+            const float c0 = in.c[0][p], c1 = in.c[1][p], c2 = in.c[2][p];
+            out.c[0][dst] = c0; out.c[1][dst] = c1; out.c[2][dst] = c2; out.id[dst] = s_id[i];
+            bx_lo.add(lo, c0, c1, c2); bx_hi.add(!lo, c0, c1, c2);
         }
-        bx_lo.add(lo, c[0], c[1], c[2]); bx_hi.add(on && !lo, c[0], c[1], c[2]);
     }
-    kd_box_store(bx_lo, S.tbox + 12 * (size_t)j, s_red);
-    kd_box_store(bx_hi, S.tbox + 12 * (size_t)j + 6, s_red);
+    if (!axis_next) return;
+    // the children's boxes: this node's blocks (below = side 0, above = side 1) + the ties placed above
+    const uint32_t b0 = start / KD_B, nb = (n + KD_B - 1) / KD_B;
+    for (uint32_t q = threadIdx.x; q < nb; q += KD_T) {
+        const uint32_t* b = S.bbox + 12 * (size_t)(b0 + q);
+        for (int a = 0; a < 3; ++a) { bx_lo.lo[a] = min(bx_lo.lo[a], b[a]); bx_lo.hi[a] = max(bx_lo.hi[a], b[3 + a]); bx_hi.lo[a] = min(bx_hi.lo[a], b[6 + a]); bx_hi.hi[a] = max(bx_hi.hi[a], b[9 + a]); }
+    }
+    uint32_t r_lo[6], r_hi[6];
+    kd_box_reduce(bx_lo, s_red, r_lo);
+    kd_box_reduce(bx_hi, s_red, r_hi);
+    if (threadIdx.x == 0) {
+        if (2 * j < n_next) axis_next[2 * j] = (uint32_t)kd_axis(r_lo);
+        if (2 * j + 1 < n_next) axis_next[2 * j + 1] = (uint32_t)kd_axis(r_hi);
+    }
 }
 
 }  // namespace
@@ -306,9 +324,9 @@ bool kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, ui
     const size_t n_nodes = node_off[levels];
     const unsigned blocks = (F + KD_B - 1) / KD_B;
     ctx->kd_hist.ensure(n_nodes * 3 * KD_BINS + 4); ctx->kd_cursor.ensure(n_nodes * 4 + 4); ctx->kd_tie.ensure(n_nodes * KD_TIE_CAP + 4);
-    ctx->kd_pivot.ensure(n_nodes * 4 + 4); ctx->kd_box.ensure(12 * (size_t)blocks + 12 * n_nodes + n_nodes + 16);
+    ctx->kd_pivot.ensure(n_nodes * 4 + 4); ctx->kd_box.ensure(12 * (size_t)blocks + node_off[levels + 1] + 16);
     for (int b = 0; b < 2; ++b) { for (int a = 0; a < 3; ++a) ctx->kd_c[b][a].ensure((size_t)F + 4); ctx->kd_id[b].ensure((size_t)F + 4); }
-    uint32_t* bbox = ctx->kd_box.p; uint32_t* tbox = bbox + 12 * (size_t)blocks; uint32_t* axis = tbox + 12 * n_nodes;
+    uint32_t* bbox = ctx->kd_box.p; uint32_t* axis = bbox + 12 * (size_t)blocks;
     MVS_HIP(hipMemsetAsync(ctx->kd_hist.p, 0, n_nodes * 3 * KD_BINS * sizeof(uint32_t), s));
     MVS_HIP(hipMemsetAsync(ctx->kd_cursor.p, 0, (n_nodes * 4 + 4) * sizeof(uint32_t), s));
     KdArrays A[2];
@@ -319,19 +337,18 @@ bool kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, ui
     for (int l = 0; l < levels; ++l, cap /= 2) {
         const uint32_t nn = (uint32_t)(node_off[l + 1] - node_off[l]);
         const uint32_t cap32 = (uint32_t)std::min<uint64_t>(cap, 0x80000000ull);
-        // this level's axes: from the boxes the level above (or the centroid kernel) left
-        hipLaunchKernelGGL(kd_axis_kernel, dim3(nn), dim3(64), 0, s, F, l == 0 ? cap32 : (uint32_t)std::min<uint64_t>(2 * cap, 0x80000000ull), l == 0 ? 1 : 0, (const uint32_t*)bbox,
-                           (const uint32_t*)(tbox + 12 * node_off[l > 0 ? l - 1 : 0]), nn, axis + node_off[l]); MVS_LAUNCH_CHECK();
+        if (l == 0) { hipLaunchKernelGGL(kd_axis_kernel, dim3(nn), dim3(64), 0, s, F, cap32, (const uint32_t*)bbox, nn, axis); MVS_LAUNCH_CHECK(); }
         KdScatter S;
         S.L.F = F; S.L.cap = cap32;
         S.L.axis = axis + node_off[l]; S.L.hist = ctx->kd_hist.p + node_off[l] * 3 * KD_BINS;
         S.cursor = ctx->kd_cursor.p + 4 * node_off[l]; S.tie = ctx->kd_tie.p + node_off[l] * KD_TIE_CAP;
-        S.pivot = reinterpret_cast<KdPivot*>(ctx->kd_pivot.p) + node_off[l]; S.bbox = bbox; S.tbox = tbox + 12 * node_off[l];
+        S.pivot = reinterpret_cast<KdPivot*>(ctx->kd_pivot.p) + node_off[l]; S.bbox = bbox;
         hipLaunchKernelGGL(kd_hist_kernel<0>, dim3(blocks), dim3(KD_T), 0, s, S.L, A[cur]); MVS_LAUNCH_CHECK();
         hipLaunchKernelGGL(kd_hist_kernel<1>, dim3(blocks), dim3(KD_T), 0, s, S.L, A[cur]); MVS_LAUNCH_CHECK();
         hipLaunchKernelGGL(kd_hist_kernel<2>, dim3(blocks), dim3(KD_T), 0, s, S.L, A[cur]); MVS_LAUNCH_CHECK();
         hipLaunchKernelGGL(kd_scatter_kernel, dim3(blocks), dim3(KD_T), 0, s, S, A[cur], A[cur ^ 1]); MVS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(kd_tie_kernel, dim3(nn), dim3(KD_T), 0, s, S, A[cur], A[cur ^ 1]); MVS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(kd_tie_axis_kernel, dim3(nn), dim3(KD_T), 0, s, S, A[cur], A[cur ^ 1], l + 1 < levels ? axis + node_off[l + 1] : (uint32_t*)nullptr,
+                           (uint32_t)(node_off[l + 2] - node_off[l + 1])); MVS_LAUNCH_CHECK();
         cur ^= 1;
     }
     // more equal keys at a pivot than the tie list holds (flag of any level = word 3 of that level's first node): one word per level read back

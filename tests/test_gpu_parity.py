@@ -728,6 +728,59 @@ def test_partition_faces_entry_points():
     assert lib <= 1.5 * hil and lib < 0.1 * rnd, (lib, hil, rnd)
 
 
+@pytest.mark.parametrize("name", ["bumpy", "c1", "spiky32"])
+def test_face_order_upper_levels_change_no_result(name):
+    """The upper levels of the library's face order (csrc/k_kdorder.hip: exact top-down median cuts above the LDS window; from one million
+    faces on by default) forced on for test-sized meshes -- every window size, the whole mesh included: the order is a permutation, the same
+    in two runs (a cut's ties are ranked by triangle id, never by scheduling; the plain icosphere "c1" is full of EQUAL centroid
+    coordinates), and tables and labels -- which cross the ABI in the caller's numbering -- are bit for bit those of the default order."""
+    s = get_scene(name)
+    F = s.n_faces
+    c = M.Context(0); _load_scene(c, s)
+    c.data_costs(M.Settings()); t0 = c.costs_download(); l0, s0 = c.view_selection(s.adj_ptr, s.adj)
+    perm0, _ = c.partition_faces(1)
+    c.close()
+    seen = [perm0]
+    for window in (262144, 0, 8192):
+        perms = []
+        for rep in range(2):
+            c = M.Context(0); c.set_option("bvh_upper_min_faces", 0); c.set_option("bvh_window", window); _load_scene(c, s)
+            c.data_costs(M.Settings()); t1 = c.costs_download(); l1, s1 = c.view_selection(s.adj_ptr, s.adj)
+            perm, _ = c.partition_faces(1)
+            c.close()
+            assert sorted(perm.tolist()) == list(range(F))
+            assert np.array_equal(t1.col_ptr, t0.col_ptr) and np.array_equal(t1.view_id, t0.view_id) and np.array_equal(t1.cost.view(np.uint32), t0.cost.view(np.uint32))
+            assert np.array_equal(l1, l0) and (s1["energy_fixed"], s1["sweeps"], s1["icm_iters"]) == (s0["energy_fixed"], s0["sweeps"], s0["icm_iters"])
+            perms.append(perm)
+        assert np.array_equal(perms[0], perms[1]), "the face order differs between two runs (window %d)" % window
+        seen.append(perms[0])
+    if F > 4096:
+        assert not np.array_equal(seen[1], perm0), "the upper levels did not run"
+
+
+def test_face_order_falls_back_when_a_cut_has_thousands_of_equal_keys():
+    """6 000 copies of one triangle next to a small mesh: every centroid coordinate of the copies is equal, a cut through them has more equal
+    keys than the tie list of k_kdorder.hip holds -- the upper levels give up, the order stays the curve's, nothing is lost: the table equals
+    the one computed without the upper levels"""
+    s0 = get_scene("tiny")
+    import copy
+    s = copy.copy(s0)
+    n_dup = 6000
+    tri = s0.faces[:1]
+    s.faces = np.ascontiguousarray(np.concatenate([s0.faces, np.repeat(tri, n_dup, axis=0)]))
+    s.normals = np.ascontiguousarray(np.concatenate([s0.normals, np.repeat(s0.normals[:1], n_dup, axis=0)]))
+    tabs = []
+    for min_faces in (0xFFFFFFFF, 0):
+        c = M.Context(0); c.set_option("bvh_upper_min_faces", min_faces); c.set_option("bvh_window", 0)
+        c.set_mesh(s.verts, s.faces, s.normals); c.set_views(s.cams, s.images)
+        c.data_costs(M.Settings()); tabs.append(c.costs_download())
+        perm, _ = c.partition_faces(1)
+        assert sorted(perm.tolist()) == list(range(len(s.faces)))
+        c.close()
+    a, b = tabs
+    assert np.array_equal(a.col_ptr, b.col_ptr) and np.array_equal(a.view_id, b.view_id) and np.array_equal(a.cost.view(np.uint32), b.cost.view(np.uint32))
+
+
 def _renumbered(name):
     import multigpu as G
     s = get_scene(name)
