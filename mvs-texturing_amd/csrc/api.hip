@@ -348,6 +348,10 @@ void mvs_ctx_destroy(mvs_ctx* ctx) {
     for (auto* b : ctx->own_rgb) delete b;
     if (ctx->sweep_exec) (void)hipGraphExecDestroy(ctx->sweep_exec);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->h_kd_flags) (void)hipHostFree(ctx->h_kd_flags);
     if (ctx->h_icm) (void)hipHostFree(ctx->h_icm);
     if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
@@ -397,8 +401,9 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "mrf_run_pad") ctx->mrf_run_pad = (value == 16) ? 16 : 4;
     else if (n == "mrf_blocks_per_cu") ctx->mrf_blocks_per_cu = std::max(0, (int)value);
     else if (n == "bvh_caller_order") ctx->bvh_caller_order = value != 0;
-    else if (n == "bvh_upper_min_faces") { ctx->bvh_upper_min_faces = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 0xFFFFFFFFll)); ctx->order_pinned = false; }
-    else if (n == "bvh_window") { ctx->bvh_window = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 0x40000000)); ctx->order_pinned = false; }   // 0 = whole mesh, 1 = no upper-level cuts; otherwise rounded up to a power of two by the builder
+    else if (n == "dc_overlap_prep") ctx->dc_overlap_prep = value != 0;
+    else if (n == "bvh_upper_min_faces") { ctx->kd_disabled = false; ctx->bvh_upper_min_faces = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 0xFFFFFFFFll)); ctx->order_pinned = false; }
+    else if (n == "bvh_window") { ctx->kd_disabled = false; ctx->bvh_window = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 0x40000000)); ctx->order_pinned = false; }   // 0 = whole mesh, 1 = no upper-level cuts; otherwise rounded up to a power of two by the builder
     else if (n == "face_order") { ctx->face_order = value != 0 ? 1 : 0; ctx->order_pinned = false; }   // takes effect with the next data-cost pass (the active table keeps the order it was made in)
     else return fail(MVS_ERR_INVALID, "unknown option " + n);
     return MVS_OK;
@@ -451,7 +456,7 @@ mvs_status mvs_scene_set_mesh(mvs_ctx* ctx, const mvs_mesh* mesh, int on_device)
     ctx->n_verts = mesh->n_verts; ctx->n_faces = mesh->n_faces;
     ctx->face_begin = 0; ctx->face_end = mesh->n_faces;
     ctx->have_costs = false; ctx->dc_phase = 0;
-    ctx->order_pinned = false; ctx->iv = nullptr;   // another mesh: whatever layout a shard pinned is gone
+    ctx->order_pinned = false; ctx->iv = nullptr; ctx->kd_disabled = false; ctx->kd_pending = 0;   // another mesh: whatever layout a shard pinned is gone
     MVS_API_END
 }
 

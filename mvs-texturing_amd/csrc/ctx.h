@@ -126,6 +126,9 @@ struct mvs_ctx {
     bool prep_fused = true;  // image prep: luminance + Sobel in one pass through LDS (false: the two-pass kernels; identical output)
     bool stats = false;      // fill the cull-reason counters of mvs_dc_stats (diagnostics; costs atomics)
     bool count_rays = false;
+    bool dc_overlap_prep = true;     // dc_phase1: image preparation on a second stream beside the face order + BVH build
+    uint32_t* h_kd_flags = nullptr; int kd_pending = 0; bool kd_disabled = false;   // k_kdorder.hip: per-level overflow words (pinned), levels awaiting scene_order_commit, "this mesh keeps the curve order"
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the image preparation runs beside the face order + BVH build (k_dc.hip dc_phase1)
     uint32_t bvh_upper_min_faces = 1000000;   // meshes below this many faces keep the Hilbert order above the LDS window (k_bvh.hip build_scene_order)
     uint32_t bvh_window = 262144;    // upper levels of the face order: exact top-down median cuts inside aligned windows of this many positions of the Hilbert order (k_kdorder.hip); 0 = the whole mesh, 1 = none
     mvs::DBuf<float> kd_c[2][3]; mvs::DBuf<uint32_t> kd_id[2], kd_hist, kd_cursor, kd_tie, kd_pivot, kd_box;   // k_kdorder.hip work buffers

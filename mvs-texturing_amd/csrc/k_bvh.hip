@@ -611,7 +611,24 @@ void sort_by_key30(mvs_ctx* ctx, uint32_t* k_in, uint32_t* k_out, uint32_t* v_in
 }
 }  // namespace
 
-bool kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, uint32_t* order, uint32_t F, uint32_t window, uint32_t leaf_window);   // k_kdorder.hip
+void kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, uint32_t* order, uint32_t F, uint32_t window, uint32_t leaf_window);   // k_kdorder.hip
+void build_scene_order(mvs_ctx* ctx);
+
+// The upper levels of the order report "a cut had more equal keys than its tie list holds" through pinned memory, without a wait of their own
+// (k_kdorder.hip).  Called where the caller synchronises anyway: true = that happened, the order has been rebuilt WITHOUT upper levels (and
+// stays so until another mesh arrives) -- whatever was derived from the order since (BVH, bit matrices) must be derived again.
+bool scene_order_commit(mvs_ctx* ctx) {
+    if (!ctx->kd_pending) return false;
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    bool overflow = false;
+    for (int l = 0; l < ctx->kd_pending; ++l) overflow = overflow || ctx->h_kd_flags[l] != 0u;
+    ctx->kd_pending = 0;
+    if (!overflow) return false;
+    if (ctx->verbose) fprintf(stderr, "[mvs] face order: more equal centroid coordinates at a cut than the tie list holds; keeping the curve order above %d faces\n", 2048);
+    ctx->kd_disabled = true;
+    build_scene_order(ctx);
+    return true;
+}
 
 // Lays the resident mesh out along a Hilbert curve: ctx->iv / ifc / inr (see ctx.h) and, with option "face_order" != 0, the face
 // permutation f_perm / f_pos.  The caller's arrays are read with gathers exactly three times (the keys, the faces, the normals);
@@ -624,7 +641,7 @@ void build_scene_order(mvs_ctx* ctx) {
     uint32_t* box = (uint32_t*)ctx->scene_box.p;
     const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     MVS_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, s));
-    ctx->mesh_ordered = false; ctx->tri_order = nullptr;
+    ctx->mesh_ordered = false; ctx->tri_order = nullptr; ctx->kd_pending = 0;
     ctx->iv = ctx->d_verts; ctx->ifc = ctx->d_faces; ctx->inr = ctx->d_normals;
     if (F == 0 || NV == 0) return;
     { const uint32_t nb = std::min<uint32_t>((NV + 255) / 256, 512u);
@@ -651,7 +668,7 @@ void build_scene_order(mvs_ctx* ctx) {
         // (the upper levels cost ~0.4 ms of launches whatever the mesh and pay through the ray stage: measured at 2 M faces x 200 views
         //  -0.76 ms of rays for +0.50 ms here, at 200 k faces x 200 views -0.05 for +0.38 -- they run from bvh_upper_min_faces faces on; the rule
         //  looks at the MESH alone, so that mvs_partition_faces and every rank of a sharded run derive the same order whatever views are set)
-        if (ctx->bvh_window != 1u && F >= ctx->bvh_upper_min_faces && !kd_refine_order(ctx, v, f, order, F, ctx->bvh_window, (uint32_t)RW) && ctx->verbose) fprintf(stderr, "[mvs] face order: too many equal centroid coordinates at a cut, keeping the curve order above %d faces\n", RW);
+        if (ctx->bvh_window != 1u && F >= ctx->bvh_upper_min_faces && !ctx->kd_disabled) kd_refine_order(ctx, v, f, order, F, ctx->bvh_window, (uint32_t)RW);
     };
     if (ctx->face_order != 0) {
         // faces along the curve: keys from the caller's arrays, the refinement and everything later on the copy

@@ -19,6 +19,7 @@ namespace mvs {
 
 void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const size_t* d_mask_off);
 void build_scene_order(mvs_ctx* ctx);
+bool scene_order_commit(mvs_ctx* ctx);
 void build_bvh(mvs_ctx* ctx);
 void trace_rays(mvs_ctx* ctx);
 
@@ -809,7 +810,12 @@ static void upload_views_and_prepare(mvs_ctx* ctx, bool need_gmi) {
 }
 
 // phase 1: everything up to the per-face sorted infos + local max quality
+static bool dc_phase1_once(mvs_ctx* ctx, const mvs_settings* st);
 void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
+    // (a second pass only when the face order had to be rebuilt -- scene_order_commit: a mesh with thousands of equal centroid coordinates)
+    if (dc_phase1_once(ctx, st)) (void)dc_phase1_once(ctx, st);
+}
+static bool dc_phase1_once(mvs_ctx* ctx, const mvs_settings* st) {
     if (!ctx->d_verts) throw StatusError(MVS_ERR_STATE, "scene not set (mesh + views)");
     /* calculate_data_costs.cpp:315-318 -- F is a uint32 here, so only the view guard can fire */
     if (ctx->n_views > 65535u) throw StatusError(MVS_ERR_TOO_MANY_VIEWS, "Exeeded maximal number of views");
@@ -833,7 +839,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         MVS_HIP(hipMemsetAsync(ctx->csr_ptr.p, 0, ((size_t)nf_early + 2) * sizeof(uint32_t), s));
         ctx->csr_faces = nf_early; ctx->csr_views = ctx->n_views; ctx->csr_nnz = 0; ctx->dc_phase = 1;
         ctx->max_q.ensure(4); MVS_HIP(hipMemsetAsync(ctx->max_q.p, 0, 4 * sizeof(float), s));
-        return;
+        return false;
     }
     // the mesh in the library's own layout (faces [fb, fb + nf) are POSITIONS of that layout); a table over the whole mesh remembers
     // its order so that it crosses the ABI in the caller's numbering
@@ -844,8 +850,24 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         if (fb == 0 && nf == ctx->n_faces) { ctx->t_perm = ctx->f_perm.p; ctx->t_pos = ctx->f_pos.p; }
         else { ctx->t_perm = ctx->f_perm.p + fb; ctx->t_pos = nullptr; }
     }
-    { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }   /* :157-163 */
-    if (vis) { Prof pr(ctx, "dc_bvh_build"); build_bvh(ctx); }           /* :144 */
+    // The image preparation (:157-163) depends on nothing the face order or the BVH build (:144) produce, and neither fills the machine
+    // (prep waits on memory half of its wave cycles, the order / BVH builds are dozens of short launches): prep runs on a second stream
+    // beside them -- queued AFTER them, because prep's flood fill makes the host wait (for its own stream only).
+    const bool fork = ctx->dc_overlap_prep;
+    if (fork) {
+        if (!ctx->aux_stream) { MVS_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)); MVS_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MVS_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)); }
+        MVS_HIP(hipEventRecord(ctx->ev_fork, s));                          // (the counters' memset above is what prep has to see)
+        MVS_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    } else { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }
+    if (vis) { Prof pr(ctx, "dc_bvh_build"); build_bvh(ctx); }
+    if (fork) {
+        struct Swap { mvs_ctx* c; hipStream_t main; ~Swap() { c->stream = main; } } swap{ctx, s};
+        ctx->stream = ctx->aux_stream;
+        { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }
+        MVS_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+        ctx->stream = s;
+        MVS_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    }
 
     const size_t pw = (size_t)V * fwords;
     ctx->pass_bits.ensure(pw + 1); ctx->surv_bits.ensure(pw + 1); ctx->pass_base.ensure(pw + 2);
@@ -894,6 +916,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
     exclusive_scan_u32(ctx, ctx->pass_base.p, ctx->pass_base.p, pw, d_total);
     pr_rank.end();
     const uint32_t n_pass = read_u32(ctx, d_total);
+    if (scene_order_commit(ctx)) return true;                 // (the stream is drained here anyway) the order was rebuilt: once more from the top
     ctx->pq.ensure((size_t)n_pass + 1);
     if (outl) ctx->pcol.ensure(3 * ((size_t)n_pass + 1));
 
@@ -996,6 +1019,7 @@ void dc_phase1(mvs_ctx* ctx, const mvs_settings* st) {
         }
     }
     ctx->dc_phase = 1;
+    return false;
 }
 
 // ---- label-space compression (BASELINE config 5: hundreds of candidate views per face) ----

@@ -309,14 +309,16 @@ __global__ void __launch_bounds__(KD_T) kd_tie_axis_kernel(KdScatter S, KdArrays
 
 // Re-partitions `order` (triangle ids, F entries, e.g. the Hilbert order) top-down inside aligned windows of `window` positions (0: the whole
 // mesh), level by level down to node capacity `leaf_window` (a power of two >= 4096: what the LDS pass of k_bvh.hip takes over from).
-// Returns false -- order untouched -- when a node had more than KD_TIE_CAP keys equal to its pivot (a degenerate mesh: the caller keeps
-// the order it had).
-bool kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, uint32_t* order, uint32_t F, uint32_t window, uint32_t leaf_window) {
+// Nothing here waits for the device: the new order is written in any case, and one word per level -- "a node had more than KD_TIE_CAP keys
+// equal to its pivot" (a degenerate mesh: elements were dropped, the order is NOT a permutation) -- travels to pinned host memory behind
+// it.  The caller looks at those words at its next synchronisation (k_bvh.hip scene_order_commit) and falls back to the order without
+// upper levels.
+void kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, uint32_t* order, uint32_t F, uint32_t window, uint32_t leaf_window) {
     hipStream_t s = ctx->stream;
-    if (F <= leaf_window) return true;
+    if (F <= leaf_window) return;
     uint64_t cap_top = leaf_window;
     while (cap_top < F && (window == 0 || cap_top < window)) cap_top *= 2;
-    if (cap_top <= leaf_window) return true;
+    if (cap_top <= leaf_window) return;
     int levels = 0; for (uint64_t c = cap_top; c > leaf_window; c /= 2) ++levels;
     // per level: nodes, histograms, cursors, ties, pivots, axes, tie boxes; block boxes are per block (rewritten by every level)
     std::vector<size_t> node_off(levels + 2, 0);
@@ -329,6 +331,9 @@ bool kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, ui
     uint32_t* bbox = ctx->kd_box.p; uint32_t* axis = bbox + 12 * (size_t)blocks;
     MVS_HIP(hipMemsetAsync(ctx->kd_hist.p, 0, n_nodes * 3 * KD_BINS * sizeof(uint32_t), s));
     MVS_HIP(hipMemsetAsync(ctx->kd_cursor.p, 0, (n_nodes * 4 + 4) * sizeof(uint32_t), s));
+    // (should a tie list overflow, its elements are never placed: the holes must at least hold VALID ids -- the order is used by the kernels
+    //  queued behind this function before scene_order_commit notices and rebuilds it)
+    MVS_HIP(hipMemsetAsync(ctx->kd_id[1].p, 0, (size_t)F * sizeof(uint32_t), s));
     KdArrays A[2];
     for (int b = 0; b < 2; ++b) { for (int a = 0; a < 3; ++a) A[b].c[a] = ctx->kd_c[b][a].p; A[b].id = ctx->kd_id[b].p; }
     hipLaunchKernelGGL(kd_centroid_kernel, dim3(blocks), dim3(KD_T), 0, s, verts, faces, (const uint32_t*)order, F, A[0], bbox); MVS_LAUNCH_CHECK();
@@ -351,13 +356,11 @@ bool kd_refine_order(mvs_ctx* ctx, const float* verts, const uint32_t* faces, ui
                            (uint32_t)(node_off[l + 2] - node_off[l + 1])); MVS_LAUNCH_CHECK();
         cur ^= 1;
     }
-    // more equal keys at a pivot than the tie list holds (flag of any level = word 3 of that level's first node): one word per level read back
-    std::vector<uint32_t> flags(levels, 0u);
-    for (int l = 0; l < levels; ++l) MVS_HIP(hipMemcpyAsync(&flags[l], ctx->kd_cursor.p + 4 * node_off[l] + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    MVS_HIP(hipStreamSynchronize(s));
-    for (uint32_t f : flags) if (f) return false;
+    // more equal keys at a pivot than the tie list holds (flag of any level = word 3 of that level's first node): one word per level, to pinned memory
+    if (!ctx->h_kd_flags) MVS_HIP(hipHostMalloc((void**)&ctx->h_kd_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    for (int l = 0; l < levels && l < 64; ++l) { ctx->h_kd_flags[l] = 0u; MVS_HIP(hipMemcpyAsync(&ctx->h_kd_flags[l], ctx->kd_cursor.p + 4 * node_off[l] + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); }
+    ctx->kd_pending = std::min(levels, 64);
     MVS_HIP(hipMemcpyAsync(order, A[cur].id, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    return true;
 }
 
 }  // namespace mvs

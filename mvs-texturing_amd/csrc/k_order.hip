@@ -15,6 +15,7 @@
 
 namespace mvs {
 void build_scene_order(mvs_ctx* ctx);
+bool scene_order_commit(mvs_ctx* ctx);
 mvs_status api_fail(mvs_status st, const std::string& msg);
 
 namespace {
@@ -127,7 +128,7 @@ mvs_status mvs_ctx_partition_faces(mvs_ctx* ctx, int world, uint32_t* perm_devic
     const uint32_t F = ctx->n_faces;
     if (perm_device && F) {
         Prof pr(ctx, "partition");
-        build_scene_order(ctx);
+        build_scene_order(ctx); (void)scene_order_commit(ctx);
         if (ctx->mesh_ordered) MVS_HIP(hipMemcpyAsync(perm_device, ctx->f_perm.p, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
         else { hipLaunchKernelGGL(iota_u32_kernel, dim3((F + 255) / 256), dim3(256), 0, ctx->stream, perm_device, F); MVS_LAUNCH_CHECK(); }   // option "face_order" = 0: the caller's own order
         pr.end();

@@ -50,6 +50,7 @@ void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, ui
 void resolve_best(mvs_ctx* ctx);
 void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, int on_device, bool table_order);
 void build_scene_order(mvs_ctx* ctx);
+bool scene_order_commit(mvs_ctx* ctx);
 void renumber_adjacency(mvs_ctx* ctx, uint32_t F, const uint32_t* perm, const uint32_t* pos, const uint32_t* d_adj_ptr, const uint32_t* d_adj, size_t E,
                         DBuf<uint32_t>& out_ptr, DBuf<uint32_t>& out_adj);
 mvs_status api_fail(mvs_status st, const std::string& msg);
@@ -938,7 +939,7 @@ mvs_status mvs_shard_create(mvs_ctx* ctx, mvs_comm* comm, const uint32_t* part_b
     MVS_HIP(hipMemcpyAsync(&S->E, adj_ptr_device + S->F, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MVS_HIP(hipStreamSynchronize(ctx->stream));
     // the caller's adjacency lists (its own face numbering) once into the library's order, list order kept
-    build_scene_order(ctx);
+    build_scene_order(ctx); (void)scene_order_commit(ctx);
     if (ctx->mesh_ordered) {
         renumber_adjacency(ctx, S->F, ctx->f_perm.p, ctx->f_pos.p, adj_ptr_device, adj_device, S->E, S->own_adj_ptr, S->own_adj);
         MVS_HIP(hipStreamSynchronize(ctx->stream));
