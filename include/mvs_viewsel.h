@@ -436,7 +436,9 @@ mvs_status mvs_comm_create_rccl(int device, int rank, int world, const uint8_t i
 mvs_status mvs_comm_create_local(int world, mvs_comm** out /* [world] */);                                /* all ranks on the current device */
 mvs_status mvs_comm_create_local_devices(int world, const int* devices /* [world] or NULL */, mvs_comm** out /* [world] */);
 /* gives an in-process communicator up: the host-side waits of all its ranks inside sharded calls end with an error from now on (for a
- * rank whose driver failed outside the library: its peers are released instead of waiting for it) */
+ * rank whose driver failed outside the library: its peers are released instead of waiting for it).  IN-PROCESS COMMUNICATORS ONLY: over
+ * RCCL (mvs_comm_create_rccl) this is a no-op, and a rank that fails inside a sharded call leaves its peers inside the collective they
+ * entered -- ending the job is the launcher's business there (torch.distributed.run takes the whole group down when one process dies). */
 void mvs_comm_abort(mvs_comm* comm);
 /* *peer_push = 1: the ranks can store into each other's device memory (the sweep loop takes the peer-push transport); any out may be NULL */
 mvs_status mvs_comm_info(mvs_comm* comm, int* rank, int* world, int* peer_push);

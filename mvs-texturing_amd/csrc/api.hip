@@ -285,10 +285,16 @@ void upload_through_ring(mvs_ctx* ctx, const std::vector<UploadPiece>& pieces) {
             }
         } catch (const std::exception& e) { failed.store(true); std::lock_guard<std::mutex> l(em); if (error.empty()) error = e.what(); }
     };
-    std::vector<std::thread> th; th.reserve(T);
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
+    // (a thread that cannot be started -- EAGAIN -- must not take the process down with joinable threads in a dying vector: the guard joins
+    //  whatever was started, the chunks of the missing threads are copied by this one)
+    struct Joiner { std::vector<std::thread> th; ~Joiner() { for (auto& x : th) if (x.joinable()) x.join(); } } pool;
+    pool.th.reserve(T);
+    std::vector<unsigned> mine{0u};
+    for (unsigned t = 1; t < T; ++t) {
+        try { pool.th.emplace_back(work, t); } catch (const std::system_error&) { mine.push_back(t); }
+    }
+    for (unsigned t : mine) work(t);
+    for (auto& x : pool.th) x.join();
     if (failed.load()) throw HipError("image upload: " + error);
 }
 }  // namespace
@@ -477,7 +483,7 @@ static mvs_status set_views_impl(mvs_ctx* ctx, const mvs_view* views, uint32_t n
     ctx->h_views.assign(n_views, ViewParams{});
     // Host images.  The caller's buffers are pageable, and a pageable hipMemcpyAsync is staged through the driver's bounce buffer at
     // ~13 GB/s (1.9 GB of BASELINE config 3: 146 ms).  Three routes (environment MVS_HOST_UPLOAD; DESIGN.md "Boundary"):
-    //   ring      (default) host threads copy the images, cut into 32 MB pieces, into a ring of LIBRARY-OWNED pinned buffers
+    //   ring      (default) host threads copy the images, cut into 16 MB pieces, into a ring of LIBRARY-OWNED pinned buffers
     //             (hipHostMalloc, allocated once per process) while the copy engine drains the pieces filled before: nothing of
     //             the caller's address space is ever registered with the driver;
     //   register  the caller's pages pinned in place for the duration of the call (hipHostRegister; MVS_PIN_HOST_IMAGES=1 is the

@@ -1461,12 +1461,14 @@ static unsigned launch_sweep4_g(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint3
     const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
     // persistent lane groups: at most as many blocks as are resident at once (a partial second wave of
     // blocks would double the tail); mrf_blocks_per_cu > 0 overrides
-    static int resident = 0;
+    static std::atomic<int> resident_once{0};   // (the same value on every device of a node; in-process ranks race for it: atomic, idempotent)
+    int resident = resident_once.load(std::memory_order_relaxed);
     if (resident == 0) {
         int per_cu = 0; hipDeviceProp_t prop;
         MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep4_kernel<G, true, true, true>, 256, 0));
         MVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
         resident = std::max(1, per_cu) * prop.multiProcessorCount;
+        resident_once.store(resident, std::memory_order_relaxed);
     }
     unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
     blocks = std::max(1u, std::min(std::min(need, blocks), slot_cap));
@@ -1487,12 +1489,14 @@ static unsigned launch_sweep8(mvs_ctx* ctx, uint32_t phase, uint32_t qb, uint32_
     constexpr int NPB = 256 / 8;
     const unsigned need = (qe - qb + NPB - 1) / NPB;
     const float rho = ctx->m_params.rho, alpha = sweep_alpha(ctx);
-    static int resident = 0;
+    static std::atomic<int> resident_once{0};   // (the same value on every device of a node; in-process ranks race for it: atomic, idempotent)
+    int resident = resident_once.load(std::memory_order_relaxed);
     if (resident == 0) {
         int per_cu = 0; hipDeviceProp_t prop;
         MVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf_sweep8_kernel<true, true>, 256, 0));
         MVS_HIP(hipGetDeviceProperties(&prop, ctx->device));
         resident = std::max(1, per_cu) * prop.multiProcessorCount;
+        resident_once.store(resident, std::memory_order_relaxed);
     }
     unsigned blocks = ctx->mrf_blocks_per_cu > 0 ? 256u * (unsigned)ctx->mrf_blocks_per_cu : (unsigned)resident;
     blocks = std::max(1u, std::min(std::min(need, blocks), slot_cap));

@@ -93,7 +93,8 @@ struct mvs_comm {
     // Failure of one rank must not leave the others waiting for it.  Every sharded entry point is a CALL that all ranks make in the
     // same order: begin_call() numbers it (the same number on every rank), fail() marks the current call as failed for everybody,
     // and a host-side wait inside the call (barrier, peer_wait) ends with an error once aborted() says so.  The mark names the call,
-    // so the next call starts clean on every rank without anybody resetting anything.
+    // so the next call starts clean on every rank without anybody resetting anything.  Implemented by the in-process communicator; the
+    // RCCL one keeps the no-ops below (a process that dies takes its group down through the launcher: see mvs_comm_abort in the header).
     uint64_t call_no = 0;
     virtual void begin_call() { ++call_no; }
     virtual void fail() {}

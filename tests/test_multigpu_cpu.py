@@ -1,7 +1,12 @@
-"""CPU tests of the multi-GPU host logic (tests/tools/multigpu.py): partitioning,
+"""CPU tests of the PYTHON RESTATEMENT of the multi-GPU host logic (tests/tools/multigpu.py): partitioning,
 the halo plan, and the exchange over torch.distributed with the gloo backend at
 world_size 2.  The per-rank compute is replaced by a numpy stand-in whose updates
-depend on neighbours' messages, so a wrong or incomplete halo changes the result."""
+depend on neighbours' messages, so a wrong or incomplete halo changes the result.
+
+What these tests pin is the exchange pattern's LOGIC (which runs and labels travel after which colour phase, the stop decision on
+the all-reduced energy) -- not the product's sharded code: csrc/shard.hip (device-side planner, pack / unpack / push kernels, the
+communicators) needs a GPU and is tested in tests/test_gpu_parity.py with in-process thread-ranks and, for the RCCL communicator with
+peers, through tests/tools/librccl_fake.so."""
 import os
 import sys
 
@@ -208,7 +213,8 @@ def _run_rank(rank, world, port, out_dir, masked=False):
 
 
 def test_gloo_world2_equals_single_rank(tmp_path):
-    """world_size 2 over gloo gives the labels / energies of the unsharded run"""
+    """world_size 2 over gloo gives the labels / energies of the unsharded run (the Python restatement of the halo plan with a numpy
+    stand-in solver: pins the pattern, not csrc/shard.hip)"""
     import torch
     import torch.multiprocessing as mp
     s, faces, adj_ptr, adj, col_ptr, inv, perm = _graph()
