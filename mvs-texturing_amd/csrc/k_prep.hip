@@ -54,10 +54,10 @@ __global__ void __launch_bounds__(GT_X * GT_Y) gmi_kernel(const ViewParams* __re
 // zero map: bit x of word (y, wx) set iff pixel (32 wx + x, y) has r + g + b == 0;
 // reach is seeded with the zero corners (texture_view.cpp:49-57).
 __global__ void mask_zero_kernel(const ViewParams* __restrict__ views, uint32_t* __restrict__ zero_all,
-                                 uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off) {
+                                 uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off, uint32_t* __restrict__ any_seed) {
     const ViewParams& vp = views[blockIdx.z];
     const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
-    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;   // blocks of 64 words x 4 rows (one-wave blocks of one row each were launch bound: 307 k blocks per pass at 200 views)
     if (wx >= wpr || y >= h) return;
     const uint8_t* __restrict__ row = vp.rgb + (size_t)y * w * 3;
     uint32_t z = 0;
@@ -76,6 +76,7 @@ __global__ void mask_zero_kernel(const ViewParams* __restrict__ views, uint32_t*
     const size_t idx = mask_off[blockIdx.z] + (size_t)y * wpr + wx;
     zero_all[idx] = z;
     reach_all[idx] = seed & z;
+    if (seed & z) *any_seed = 1u;                                   // (racing stores of the same value) see prepare_views
 }
 
 // fill `r` through the set bits of `m` towards higher bit positions (Kogge-Stone), within a word
@@ -102,7 +103,7 @@ __global__ void mask_flood_kernel(const ViewParams* __restrict__ views, const ui
                                   const size_t* __restrict__ mask_off, uint32_t* __restrict__ changed) {
     const ViewParams& vp = views[blockIdx.z];
     const int h = vp.height, wpr = vp.mask_stride;
-    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;   // blocks of 64 words x 4 rows (one-wave blocks of one row each were launch bound: 307 k blocks per pass at 200 views)
     if (wx >= wpr || y >= h) return;
     const size_t base = mask_off[blockIdx.z];
     const size_t idx = base + (size_t)y * wpr + wx;
@@ -130,7 +131,7 @@ __global__ void mask_final_kernel(const ViewParams* __restrict__ views, const ui
                                   uint32_t* __restrict__ mask_all, const size_t* __restrict__ mask_off) {
     const ViewParams& vp = views[blockIdx.z];
     const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
-    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int wx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;   // blocks of 64 words x 4 rows (one-wave blocks of one row each were launch bound: 307 k blocks per pass at 200 views)
     if (wx >= wpr || y >= h) return;
     const size_t base = mask_off[blockIdx.z];
     auto inbounds = [&](int ww) -> uint32_t {  // bits of word ww that are real pixels
@@ -203,13 +204,19 @@ __global__ void __launch_bounds__(256) mask_trivial_kernel(ViewParams* __restric
     if (threadIdx.x == 0 && !bad) vp.mask = nullptr;
 }
 
+// no view has a black CORNER pixel: the flood fill has no seed anywhere, every mask is all ones (prepare_views)
+__global__ void mask_all_valid_kernel(ViewParams* __restrict__ views, uint32_t n_views) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n_views) views[v].mask = nullptr;
+}
+
 // ---- vectorised fast path (image width a multiple of 32, 4-byte aligned rows) ----
 // One pass over the RGB image does the luminance plane (4 pixels = three 32-bit loads per thread) AND
 // the zero map + corner seeds of the validity flood fill; a second pass does the Sobel magnitude on
 // the luminance plane with one aligned 32-bit load per row.
 __global__ void __launch_bounds__(256) lum_zero_kernel(const ViewParams* __restrict__ views, uint8_t* __restrict__ lum_all, const size_t* __restrict__ gmi_off,
                                                        uint32_t* __restrict__ zero_all, uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off,
-                                                       int need_lum) {
+                                                       int need_lum, uint32_t* __restrict__ any_seed) {
     const ViewParams& vp = views[blockIdx.z];
     const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
     const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
@@ -239,6 +246,7 @@ __global__ void __launch_bounds__(256) lum_zero_kernel(const ViewParams* __restr
         const size_t idx = mask_off[blockIdx.z] + (size_t)y * wpr + wx;
         zero_all[idx] = word;
         reach_all[idx] = seed & word;
+        if (seed & word) *any_seed = 1u;
     }
 }
 
@@ -279,7 +287,8 @@ __global__ void __launch_bounds__(256) sobel4_kernel(const ViewParams* __restric
 // Same integer arithmetic as lum_zero_kernel + sobel4_kernel (and gmi_kernel): bit-identical output.
 constexpr int FUSE_ROWS = 16;
 __global__ void __launch_bounds__(256) lum_sobel_kernel(const ViewParams* __restrict__ views, uint8_t* __restrict__ gmi_all, const size_t* __restrict__ gmi_off,
-                                                        uint32_t* __restrict__ zero_all, uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off) {
+                                                        uint32_t* __restrict__ zero_all, uint32_t* __restrict__ reach_all, const size_t* __restrict__ mask_off,
+                                                        uint32_t* __restrict__ any_seed) {
     __shared__ uint32_t s_lum[FUSE_ROWS + 2][258];   // [row][1 + thread]: four luminances per word; words 0 and 257 hold the halo pixels (byte 3 / byte 0)
     const ViewParams& vp = views[blockIdx.z];
     const int w = vp.width, h = vp.height, wpr = vp.mask_stride;
@@ -337,6 +346,7 @@ __global__ void __launch_bounds__(256) lum_sobel_kernel(const ViewParams* __rest
                 const size_t idx = mask_off[blockIdx.z] + (size_t)y * wpr + wx;
                 zero_all[idx] = word;
                 reach_all[idx] = seed & word;
+                if (seed & word) *any_seed = 1u;
             }
         }
     }
@@ -381,19 +391,22 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
     hipStream_t s = ctx->stream;
     bool fast = true;   // vectorised path: widths multiple of 32, 4-byte aligned pixel rows
     for (auto& v : ctx->h_views) fast = fast && (v.width % 32 == 0) && ((reinterpret_cast<uintptr_t>(v.rgb) & 3u) == 0);
-    dim3 mgrid((maxwpr + 63) / 64, maxh, V);
+    dim3 mgrid((maxwpr + 63) / 64, (maxh + 3) / 4, V); const dim3 mblock(64, 4);
     uint32_t* zero = ctx->mask_zero.p;
     uint32_t* ra = ctx->mask_all.p;   // ping
     uint32_t* rb = ctx->mask_tmp.p;   // pong
+    uint32_t* d_changed = (uint32_t*)ctx->counters.p + 64;  // scratch words inside the counters block
+    uint32_t* d_any_seed = d_changed + 1;
+    MVS_HIP(hipMemsetAsync(d_changed, 0, 2 * sizeof(uint32_t), s));
     if (fast) {
         dim3 g4((maxw / 4 + 255) / 256, maxh, V);
         if (need_gmi && ctx->prep_fused) {
             dim3 gf((maxw + 1023) / 1024, (maxh + FUSE_ROWS - 1) / FUSE_ROWS, V);
-            hipLaunchKernelGGL(lum_sobel_kernel, gf, dim3(256), 0, s, ctx->d_views.p, ctx->gmi_all.p, d_gmi_off, zero, ra, d_mask_off);
+            hipLaunchKernelGGL(lum_sobel_kernel, gf, dim3(256), 0, s, ctx->d_views.p, ctx->gmi_all.p, d_gmi_off, zero, ra, d_mask_off, d_any_seed);
             MVS_LAUNCH_CHECK();
         } else {
             if (need_gmi) ctx->lum_all.ensure(ctx->gmi_off.back() + 16);
-            hipLaunchKernelGGL(lum_zero_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, d_gmi_off, zero, ra, d_mask_off, need_gmi ? 1 : 0);
+            hipLaunchKernelGGL(lum_zero_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, d_gmi_off, zero, ra, d_mask_off, need_gmi ? 1 : 0, d_any_seed);
             MVS_LAUNCH_CHECK();
             if (need_gmi) {
                 hipLaunchKernelGGL(sobel4_kernel, g4, dim3(256), 0, s, ctx->d_views.p, ctx->lum_all.p, ctx->gmi_all.p, d_gmi_off);
@@ -406,16 +419,23 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
             hipLaunchKernelGGL(gmi_kernel, grid, dim3(GT_X, GT_Y), 0, s, ctx->d_views.p, ctx->gmi_all.p, d_gmi_off);
             MVS_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(mask_zero_kernel, mgrid, dim3(64), 0, s, ctx->d_views.p, zero, ra, d_mask_off);
+        hipLaunchKernelGGL(mask_zero_kernel, mgrid, mblock, 0, s, ctx->d_views.p, zero, ra, d_mask_off, d_any_seed);
         MVS_LAUNCH_CHECK();
     }
+    // The validity mask removes what a flood fill over BLACK pixels reaches from the image's four corners (texture_view.cpp:42-99), then erodes.
+    // No view with a black corner pixel = no seed anywhere: every mask is all ones, the views drop their mask pointers (what
+    // mask_trivial_kernel would find after three passes over 307 k one-wave blocks: 0.3 ms at 200 views) -- one read-back, which the
+    // first flood step needed anyway.
+    { uint32_t seeded = 0;
+      MVS_HIP(hipMemcpyAsync(&seeded, d_any_seed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      MVS_HIP(hipStreamSynchronize(s));
+      if (!seeded) { hipLaunchKernelGGL(mask_all_valid_kernel, dim3((V + 255) / 256), dim3(256), 0, s, ctx->d_views.p, V); MVS_LAUNCH_CHECK(); return; } }
     // flood fill until a whole batch of steps changes nothing
-    uint32_t* d_changed = (uint32_t*)ctx->counters.p + 64;  // scratch word inside the counters block
     for (int iter = 0;; ++iter) {
         MVS_HIP(hipMemsetAsync(d_changed, 0, sizeof(uint32_t), s));
         const int batch = (iter == 0) ? 1 : 16;
         for (int b = 0; b < batch; ++b) {
-            hipLaunchKernelGGL(mask_flood_kernel, mgrid, dim3(64), 0, s, ctx->d_views.p, zero, ra, rb, d_mask_off, d_changed);
+            hipLaunchKernelGGL(mask_flood_kernel, mgrid, mblock, 0, s, ctx->d_views.p, zero, ra, rb, d_mask_off, d_changed);
             MVS_LAUNCH_CHECK();
             std::swap(ra, rb);
         }
@@ -428,8 +448,8 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
     // ra holds the converged reach set; the final mask must land in mask_all
     uint32_t* reach = ra;
     uint32_t* out = (ra == ctx->mask_all.p) ? ctx->mask_tmp.p : ctx->mask_all.p;
-    if (need_gmi) hipLaunchKernelGGL(mask_final_kernel<true>, mgrid, dim3(64), 0, s, ctx->d_views.p, reach, out, d_mask_off);
-    else hipLaunchKernelGGL(mask_final_kernel<false>, mgrid, dim3(64), 0, s, ctx->d_views.p, reach, out, d_mask_off);
+    if (need_gmi) hipLaunchKernelGGL(mask_final_kernel<true>, mgrid, mblock, 0, s, ctx->d_views.p, reach, out, d_mask_off);
+    else hipLaunchKernelGGL(mask_final_kernel<false>, mgrid, mblock, 0, s, ctx->d_views.p, reach, out, d_mask_off);
     MVS_LAUNCH_CHECK();
     if (out != ctx->mask_all.p)
         MVS_HIP(hipMemcpyAsync(ctx->mask_all.p, out, ctx->mask_off.back() * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
