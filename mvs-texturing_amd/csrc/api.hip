@@ -342,6 +342,7 @@ mvs_status mvs_ctx_create(int device, mvs_ctx** out) {
     // footprint in the reference's serial fp64 order, i.e. bit-exact qualities); mvs_set_option("info_wave_area") still wins
     if (const char* e = getenv("MVS_INFO_WAVE_AREA")) c->info_wave_area = std::max(0, atoi(e));
     if (const char* e = getenv("MVS_MRF_WIDE")) c->mrf_wide = atoi(e) != 0;   // (A/B of the sweep kernel variants without touching callers)
+    if (const char* e = getenv("MVS_BVH_UPPER_MIN_FACES")) c->bvh_upper_min_faces = (uint32_t)std::max(0ll, atoll(e));   // (test runs: 0 puts every mesh of the suite through the upper levels of the face order)
     c->counters.ensure(64);
     *out = c;
     MVS_API_END
