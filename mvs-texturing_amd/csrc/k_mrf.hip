@@ -1127,9 +1127,11 @@ __global__ void mrf_argmin_unary_kernel(const uint32_t* __restrict__ col_ptr, co
 /* label extraction (view_selection.cpp:120-132): labels are already decoded; range check + unseen count */
 __global__ void mrf_labels_kernel(const uint32_t* __restrict__ lab, uint32_t node_begin, uint32_t node_end, uint32_t n_views,
                                   uint32_t* __restrict__ labels, uint32_t* __restrict__ bad_unseen /* [0] bad, [1] unseen */,
-                                  const uint32_t* __restrict__ orig /* non-null: labels[orig[i]] = label of node i (the caller's numbering) */) {
+                                  const uint32_t* __restrict__ orig /* non-null: labels[orig[i]] = label of node i (the caller's numbering) */,
+                                  const uint32_t* __restrict__ foreign /* may be null: labels outside their column, counted by mrf_exact_cost_kernel over the same range */) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= node_end) return;
+    if (foreign && i == node_begin && *foreign) atomicAdd(&bad_unseen[0], *foreign);
     const uint32_t label = lab[i];
     if (label > n_views) atomicAdd(&bad_unseen[0], 1u);       /* :126-128 "Incorrect labeling" */
     if (label == 0u) atomicAdd(&bad_unseen[1], 1u);            /* :129 */
@@ -1590,11 +1592,15 @@ void mrf_sweep(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
 // The sweeps keep ONE word per node, its label.  Whatever works on the best labeling afterwards (polish, region moves, reported energy)
 // needs the label's position in the column and its EXACT unary as well: derived here, once, from the label (idempotent).
 __global__ void mrf_exact_cost_kernel(const uint32_t* __restrict__ col_ptr, const uint16_t* __restrict__ view_id, const float* __restrict__ cost,
-                                      const uint32_t* __restrict__ lab, uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ sel, float* __restrict__ selcost) {
+                                      const uint32_t* __restrict__ lab, uint32_t node_begin, uint32_t node_end, uint32_t* __restrict__ sel, float* __restrict__ selcost,
+                                      uint32_t* __restrict__ foreign /* labels that are NOT entries of their node's column (counted into "Incorrect labeling") */) {
     const uint32_t i = node_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= node_end) return;
     const uint32_t p0 = col_ptr[i], K = col_ptr[i + 1] - p0, l = lab[i];
     const uint32_t t = (K && l) ? label_position(view_id, p0, K, l) : 0u;
+    // label_position clamps: a stale or foreign label (a scatter through the building blocks, a table pruned behind the labeling) would
+    // silently take a neighbour's position and unary -- it is counted instead
+    if ((K != 0u) != (l != 0u) || (K && l && (uint32_t)view_id[p0 + t] + 1u != l)) atomicAdd(foreign, 1u);
     sel[i] = t;
     selcost[i] = K ? cost[p0 + t] : 1.0f;
 }
@@ -1604,7 +1610,8 @@ void mrf_exact_costs(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0) {
     // the polish and the region moves keep position / label / unary of the best labeling consistent: derived once per labeling and range
     if (ctx->exact_valid && ctx->exact_nb == nb0 && ctx->exact_ne == ne0) return;
     ctx->exact_valid = true; ctx->exact_nb = nb0; ctx->exact_ne = ne0;
-    hipLaunchKernelGGL(mrf_exact_cost_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, (const uint32_t*)ctx->b_lab, nb0, ne0, ctx->b_sel, ctx->b_cost);
+    MVS_HIP(hipMemsetAsync(ctx->m_moved.p + 6, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(mrf_exact_cost_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->r_ptr, ctx->r_view, ctx->r_cost, (const uint32_t*)ctx->b_lab, nb0, ne0, ctx->b_sel, ctx->b_cost, ctx->m_moved.p + 6);
     MVS_LAUNCH_CHECK();
 }
 
@@ -1703,7 +1710,8 @@ void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, ui
     resolve_best(ctx);
     MVS_HIP(hipMemsetAsync(bu, 0, 2 * sizeof(uint32_t), ctx->stream));
     if (ne0 > nb0) {
-        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->b_lab, nb0, ne0, ctx->csr_views, d_labels, bu, caller_order ? ctx->t_perm : (const uint32_t*)nullptr);
+        const uint32_t* foreign = (ctx->exact_valid && ctx->exact_nb == nb0 && ctx->exact_ne == ne0) ? ctx->m_moved.p + 6 : (const uint32_t*)nullptr;
+        hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->b_lab, nb0, ne0, ctx->csr_views, d_labels, bu, caller_order ? ctx->t_perm : (const uint32_t*)nullptr, foreign);
         MVS_LAUNCH_CHECK();
     }
     MVS_HIP(hipMemcpyAsync(out, bu, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
