@@ -22,7 +22,7 @@ def child(lib, scene, steps, mrf, q, fixed=0):
     import zlib
     dc = c.costs_download()                                      # a checksum of the whole table: variants must agree bit for bit
     crc = zlib.crc32(dc.cost.tobytes(), zlib.crc32(dc.view_id.tobytes(), zlib.crc32(dc.col_ptr.tobytes())))
-    q.put({"crc": crc} | {k: v[0] / steps for k, v in p.items()} | ({"mrf_sweeps": sweeps, "mrf_sweep_each": p["mrf_sweep"][0] / steps / max(sweeps, 1)} if mrf else {}) | {"nnz": int(st["nnz"]), "occluded": int(st.get("cull_occluded", 0))})
+    q.put({"crc": crc} | {k: v[0] / steps for k, v in p.items()} | ({"mrf_sweeps": sweeps, "mrf_result_energy": float(ms["energy"]), "mrf_sweep_each": p["mrf_sweep"][0] / steps / max(sweeps, 1)} if mrf else {}) | {"nnz": int(st["nnz"]), "occluded": int(st.get("cull_occluded", 0))})
 
 
 if __name__ == "__main__":
