@@ -260,9 +260,36 @@ __global__ void __launch_bounds__(256) wave_info_kernel(const float* __restrict_
     // Blocks of 16 scan lines: lane r of the group evaluates the span of line yb + r ONCE (foot_row: two correctly rounded divisions),
     // the steps below fetch their line's span from that lane -- one pair of divisions per line instead of one per lane and line
     const bool words = DATA_TERM == 1 && !OUTLIER && s.fast;   // group-uniform
+#ifndef MVS_NARROW_PX
+#define MVS_NARROW_PX 96.0f
+#endif
+    const bool narrow = s.aabb_max_x - s.aabb_min_x <= MVS_NARROW_PX;   // group-uniform
     for (int yb = y_begin; yb < y_end; yb += GL) {
         int xb_own = 0, xe_own = 0;
         if (yb + sub >= y_end || !foot_row(s, yb + sub, &xb_own, &xe_own) || xe_own <= xb_own) { xb_own = 0; xe_own = 0; }   // an empty span: the line is skipped
+        if (words && narrow) {
+            // a NARROW footprint (spans of a few words): lane r of the group sums line yb + r by itself, four words per step -- sixteen lines in
+            // flight per footprint where the 2 x 8 arrangement below keeps four lines in flight with most of their eight lanes past the span
+            const uint8_t* rowp = gimg + (size_t)(yb + sub) * w;
+            int x0 = xb_own - (int)(reinterpret_cast<uintptr_t>(rowp + xb_own) & 3u);
+            if (xe_own <= xb_own) x0 = xe_own;
+            while (x0 < xe_own) {   // four words (16 pixels) per step: the loads of a step are independent of each other
+                uint32_t v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (x0 + 4 * q < xe_own) ? *reinterpret_cast<const uint32_t*>(rowp + x0 + 4 * q) : 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int xw = x0 + 4 * q;
+                    if (xw < xe_own) {
+                        const int lo = max(xb_own - xw, 0), hi = min(xe_own - xw, 4);          // bytes [lo, hi) of the word are pixels of the span
+                        const uint32_t m = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+                        g = __builtin_amdgcn_sad_u8(v[q] & m, 0u, g); n += (uint32_t)(hi - lo);
+                    }
+                }
+                x0 += 16;
+            }
+            continue;
+        }
         if (words) {
             // gradient magnitudes only, whole spans: four pixels per load.  The words are aligned in ADDRESS space (the first one starts
             // at or up to three bytes before the span), bytes outside [xb, xe) are masked, v_sad_u8 adds the four bytes of a word in one
