@@ -189,12 +189,30 @@ __global__ void mrf_size_kernel(const uint32_t* __restrict__ col_ptr, const uint
         const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
         deg = e1 - e0;
         uint32_t kmx = k;
-        for (uint32_t e = e0; e < e1; ++e) {
-            const uint32_t j = adj[e];
-            const uint32_t kj = col_ptr[j + 1] - col_ptr[j];
-            size[e] = (k > 0 && kj > 0) ? ((k + pad_mask) & ~pad_mask) : 0u;   // runs padded to a multiple of 4 (8-byte quads) or 16 elements (32-byte sectors)
-            if (k > 0) kmx = max(kmx, kj);
-            { uint32_t r = adj_ptr[j]; const uint32_t r1 = adj_ptr[j + 1]; while (r < r1 && adj[r] != i) ++r; rev[e] = r < r1 ? r : 0xFFFFFFFFu; }
+        // four edges at a time, level by level (neighbour -> its column / its list bounds -> the head of its list): a thread's loads of one
+        // level are independent of each other -- edge after edge this was a chain of 3 x 4 dependent round trips per node (0.11 ms at C3)
+        for (uint32_t eb = e0; eb < e1; eb += 4) {
+            uint32_t j[4], kj[4], r0[4], r1[4], head[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) j[q] = (eb + q < e1) ? adj[eb + q] : i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { kj[q] = col_ptr[j[q] + 1] - col_ptr[j[q]]; r0[q] = adj_ptr[j[q]]; r1[q] = adj_ptr[j[q] + 1]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) head[q][t] = (r0[q] + t < r1[q]) ? adj[r0[q] + t] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (eb + q >= e1) continue;
+                const uint32_t e = eb + q;
+                size[e] = (k > 0 && kj[q] > 0) ? ((k + pad_mask) & ~pad_mask) : 0u;   // runs padded to a multiple of 4 (8-byte quads) or 16 elements (32-byte sectors)
+                if (k > 0) kmx = max(kmx, kj[q]);
+                uint32_t r = 0xFFFFFFFFu;                         // the FIRST position of i in j's list
+#pragma unroll
+                for (int t = 3; t >= 0; --t) r = (head[q][t] == i) ? r0[q] + t : r;
+                if (r == 0xFFFFFFFFu) { uint32_t rr = r0[q] + 4u; while (rr < r1[q] && adj[rr] != i) ++rr; if (rr < r1[q]) r = rr; }   // (degree > 4)
+                rev[e] = r;
+            }
         }
         cls[i] = (uint8_t)mrf_node_class(kmx, deg, force_generic);
     }
@@ -228,12 +246,18 @@ __global__ void mrf_colour_round_kernel(const uint32_t* __restrict__ adj_ptr, co
     unsigned long long used = 0ull;
     bool ready = true;
     const uint32_t oi = orig ? orig[i] : i;
-    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
-        const uint32_t j = adj[e];
-        if (j == i || !mrf_key_less(orig ? orig[j] : j, oi)) continue;
-        const uint32_t cj = __hip_atomic_load(colour + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cj == NO_COLOUR) { ready = false; break; }
-        used |= 1ull << cj;
+    const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+    for (uint32_t eb = e0; eb < e1 && ready; eb += 4) {      // four neighbours at a time: their ids, keys and colours are independent loads
+        uint32_t j[4], oj[4], cj[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) j[t] = (eb + t < e1) ? adj[eb + t] : i;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { oj[t] = orig ? orig[j[t]] : j[t]; cj[t] = __hip_atomic_load(colour + j[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (j[t] == i || !mrf_key_less(oj[t], oi)) continue;   // (a padded slot is the node itself)
+            if (cj[t] == NO_COLOUR) ready = false; else used |= 1ull << cj[t];
+        }
     }
     if (ready) {
         // 64 colours in use around one node: the mask (and the 6-bit class sort) cannot hold a 65th -- reported, not wrapped
@@ -300,12 +324,17 @@ __global__ void mrf_nodesize_kernel(const uint32_t* __restrict__ perm, const uin
     for (int b = 0; b < MAX_LAYOUT_COLOURS; ++b) acc[b] = 0;
     if (q < F) {
         const uint32_t j = perm[q];
-        for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) {
-            const uint32_t i = adj[r], e = rev[r];            // e = (i <- j): the in-edge of the receiver that owns this run
-            if (e == 0xFFFFFFFFu) continue;
-            const uint32_t b = (n_col > 1) ? colour[i] : 0u, sz = size[e];
+        const uint32_t ra = adj_ptr[j], rz = adj_ptr[j + 1];
+        for (uint32_t rb = ra; rb < rz; rb += 4) {           // four out-edges at a time: the loads of a level are independent
+            uint32_t i[4], e[4], b[4], sz[4];
 #pragma unroll
-            for (int c = 0; c < MAX_LAYOUT_COLOURS; ++c) acc[c] += ((uint32_t)c == b) ? sz : 0u;
+            for (int t = 0; t < 4; ++t) { const bool on = rb + t < rz; i[t] = on ? adj[rb + t] : j; e[t] = on ? rev[rb + t] : 0xFFFFFFFFu; }   // e = (i <- j): the in-edge of the receiver that owns this run
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { b[t] = (n_col > 1) ? colour[i[t]] : 0u; sz[t] = (e[t] != 0xFFFFFFFFu) ? size[e[t]] : 0u; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int c = 0; c < MAX_LAYOUT_COLOURS; ++c) acc[c] += ((uint32_t)c == b[t]) ? sz[t] : 0u;
         }
     }
 #pragma unroll
@@ -320,14 +349,21 @@ __global__ void mrf_inoff_kernel(const uint32_t* __restrict__ perm, const uint32
     uint32_t off[MAX_LAYOUT_COLOURS];
 #pragma unroll
     for (int b = 0; b < MAX_LAYOUT_COLOURS; ++b) off[b] = ((uint32_t)b < n_col) ? noff[(size_t)b * (F + 1) + q] : 0u;
-    for (uint32_t r = adj_ptr[j]; r < adj_ptr[j + 1]; ++r) {
-        const uint32_t i = adj[r], e = rev[r];
-        if (e == 0xFFFFFFFFu) continue;
-        const uint32_t b = (n_col > 1) ? colour[i] : 0u, sz = size[e];
-        uint32_t o = 0;
+    const uint32_t ra = adj_ptr[j], rz = adj_ptr[j + 1];
+    for (uint32_t rb = ra; rb < rz; rb += 4) {               // four out-edges at a time (see mrf_nodesize_kernel); offsets are handed out in list order
+        uint32_t i[4], e[4], b[4], sz[4];
 #pragma unroll
-        for (int c = 0; c < MAX_LAYOUT_COLOURS; ++c) { if ((uint32_t)c == b) { o = off[c]; off[c] += sz; } }
-        in_off[e] = o;
+        for (int t = 0; t < 4; ++t) { const bool on = rb + t < rz; i[t] = on ? adj[rb + t] : j; e[t] = on ? rev[rb + t] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { b[t] = (n_col > 1) ? colour[i[t]] : 0u; sz[t] = (e[t] != 0xFFFFFFFFu) ? size[e[t]] : 0u; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (e[t] == 0xFFFFFFFFu) continue;
+            uint32_t o = 0;
+#pragma unroll
+            for (int c = 0; c < MAX_LAYOUT_COLOURS; ++c) { if ((uint32_t)c == b[t]) { o = off[c]; off[c] += sz[t]; } }
+            in_off[e[t]] = o;
+        }
     }
 }
 
@@ -335,14 +371,23 @@ __global__ void mrf_edge_kernel(const uint32_t* __restrict__ col_ptr, const uint
                                 uint32_t F, const uint32_t* __restrict__ in_off, const uint32_t* __restrict__ size, const uint32_t* __restrict__ rev, MrfEdge* __restrict__ edge) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
-    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
-        const uint32_t j = adj[e], r = rev[e];
-        const bool has = r != 0xFFFFFFFFu;
-        MrfEdge m;
-        m.in_off = MSG_BASE + in_off[e];                       // [0, MSG_BASE) is the reserved zero / identity run
-        m.out_off = has ? MSG_BASE + in_off[r] : 0u;
-        m.kj = (size[e] > 0 && has) ? (col_ptr[j + 1] - col_ptr[j]) : 0u;
-        edge[e] = m;
+    const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+    for (uint32_t eb = e0; eb < e1; eb += 4) {               // four edges at a time: the loads of a level are independent
+        uint32_t j[4], r[4], io[4], sz[4], oo[4], kj[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const bool on = eb + t < e1; j[t] = on ? adj[eb + t] : i; r[t] = on ? rev[eb + t] : 0xFFFFFFFFu; io[t] = on ? in_off[eb + t] : 0u; sz[t] = on ? size[eb + t] : 0u; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { oo[t] = (r[t] != 0xFFFFFFFFu) ? in_off[r[t]] : 0u; kj[t] = col_ptr[j[t] + 1] - col_ptr[j[t]]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (eb + t >= e1) continue;
+            const bool has = r[t] != 0xFFFFFFFFu;
+            MrfEdge m;
+            m.in_off = MSG_BASE + io[t];                       // [0, MSG_BASE) is the reserved zero / identity run
+            m.out_off = has ? MSG_BASE + oo[t] : 0u;
+            m.kj = (sz[t] > 0 && has) ? kj[t] : 0u;
+            edge[eb + t] = m;
+        }
     }
 }
 
@@ -448,7 +493,14 @@ __global__ void mrf_recsize_kernel(const uint32_t* __restrict__ col_ptr, const u
         if (K && cls[i] != CLS_GENERIC) {
             w = (K + 3u) & ~3u;
             const bool w8 = wide != 0u && cls[i] == 1u;
-            for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) { const uint32_t kj = edge[e].kj; if (kj && !ident[e]) w += w8 ? 2u * ((kj + 7u) >> 3) : (kj + 3u) >> 2; }
+            const uint32_t e0 = adj_ptr[i], e1 = adj_ptr[i + 1];
+            for (uint32_t eb = e0; eb < e1; eb += 4) {       // four edges at a time: independent loads
+                uint32_t kj[4], id[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { const bool on = eb + t < e1; kj[t] = on ? edge[eb + t].kj : 0u; id[t] = on ? ident[eb + t] : 1u; }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (kj[t] && !id[t]) w += w8 ? 2u * ((kj[t] + 7u) >> 3) : (kj[t] + 3u) >> 2;
+            }
             w = (w + 3u) & ~3u;
         }
     }
@@ -482,16 +534,28 @@ __global__ void __launch_bounds__(256) mrf_record_kernel(const uint32_t* __restr
     uint16_t* tile = s_l[threadIdx.x >> 4];
     uint32_t* out = rec + REC_BASE + roff[q];
     const uint32_t K4 = (K + 3u) & ~3u;
+    // the (at most three: a fast node) edges' sizes, flags and neighbour columns are requested before the column is read, not one edge
+    // after the other behind it
+    const uint32_t e0 = adj_ptr[i], deg = adj_ptr[i + 1] - e0;
+    uint32_t kj3[3], q03[3];
+    {
+        uint32_t kj[3], idn[3], nb[3];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) { const bool on = d < deg; kj[d] = on ? edge[e0 + d].kj : 0u; idn[d] = on ? (uint32_t)ident[e0 + d] : 1u; nb[d] = on ? adj[e0 + d] : i; }
+#pragma unroll
+        for (uint32_t d = 0; d < 3; ++d) { kj3[d] = (kj[d] != 0u && idn[d] == 0u) ? kj[d] : 0u; q03[d] = col_ptr[nb[d]]; }
+    }
     for (uint32_t t = gl; t < K4; t += 16) {
         uint32_t w = 0u;
         if (t < K) { const uint32_t v = view_id[p0 + t]; tile[t] = (uint16_t)v; w = (cost_code(cost[p0 + t]) << 16) | v; }
         out[t] = w;
     }
     uint32_t pos = K4;
-    for (uint32_t e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
-        const uint32_t kj = edge[e].kj;
-        if (kj == 0 || ident[e]) continue;                     // group-uniform
-        const uint32_t q0 = col_ptr[adj[e]], nw = w8 ? 2u * ((kj + 7u) >> 3) : (kj + 3u) >> 2;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; ++d) {
+        const uint32_t kj = kj3[d];
+        if (kj == 0) continue;                                 // group-uniform: not in the model, or identical lists (no map)
+        const uint32_t q0 = q03[d], nw = w8 ? 2u * ((kj + 7u) >> 3) : (kj + 3u) >> 2;
         for (uint32_t wI = gl; wI < nw; wI += 16) {
             // positions of the RECEIVER's labels 4 wI .. 4 wI + 3 in this (the sender's) list: four lower-bound searches in
             // lockstep (the step count depends on K only), so their LDS reads are independent

@@ -13,11 +13,16 @@ def child(lib, scene, steps, mrf, q, fixed=0):
     c = M.Context(0); c.set_option("profile", 1)
     c.set_mesh(scene.verts, scene.faces, scene.normals); c.set_views(scene.cams, scene.images)
     st = c.data_costs(M.Settings()); c.get_profile()
+    if mrf:   # the adjacency lists resident on the device, as bench.py hands them over (a host array would be uploaded inside mrf_setup)
+        import torch
+        tap, tad = torch.from_numpy(scene.adj_ptr.view(np.int32)).to("cuda:0"), torch.from_numpy(scene.adj.view(np.int32)).to("cuda:0")
+        lab = torch.zeros(scene.n_faces, dtype=torch.int32, device="cuda:0")
+        c.view_selection(tap, tad, M.viewsel.default_mrf_params(**(dict(min_sweeps=fixed, max_sweeps=fixed) if fixed else {})), labels_out=lab); c.get_profile()   # warm-up: the first solve allocates
     for _ in range(steps):
         st = c.data_costs(M.Settings())
         if mrf:
             kw = dict(min_sweeps=fixed, max_sweeps=fixed) if fixed else {}
-            _, ms = c.view_selection(scene.adj_ptr, scene.adj, M.viewsel.default_mrf_params(**kw)); sweeps = int(ms["sweeps"])
+            _, ms = c.view_selection(tap, tad, M.viewsel.default_mrf_params(**kw), labels_out=lab); sweeps = int(ms["sweeps"])
     p = c.get_profile()
     import zlib
     dc = c.costs_download()                                      # a checksum of the whole table: variants must agree bit for bit
