@@ -104,10 +104,13 @@ __global__ void __launch_bounds__(256) need_kernel(const uint32_t* __restrict__ 
     const uint32_t j0 = blockIdx.y * VIEW_CHUNK, j1 = min(j0 + VIEW_CHUNK, n_views);
     const int lane = threadIdx.x & 63;
     uint32_t acc = 0;  // bit jj: some incident face passed for view j0 + jj
-    for (uint32_t p = p0; p < p1; ++p) {
-        const uint32_t lf = vf[p] - fb;  // wraps for faces below the range
-        if (lf >= nf) continue;
-        acc |= pass_face[(size_t)blockIdx.y * ((size_t)fwords * 64u) + lf];
+    for (uint32_t pb = p0; pb < p1; pb += 4) {   // four incident faces at a time: ids, then their pass words (independent loads per level)
+        uint32_t lf[4], w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lf[t] = (pb + t < p1) ? vf[pb + t] - fb : 0xFFFFFFFFu;  // wraps for faces below the range
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = (lf[t] < nf) ? pass_face[(size_t)blockIdx.y * ((size_t)fwords * 64u) + lf[t]] : 0u;
+        acc |= (w[0] | w[1]) | (w[2] | w[3]);
     }
     uint32_t n_rays = 0;
     for (uint32_t j = j0; j < j1; ++j) {
