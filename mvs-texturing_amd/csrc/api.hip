@@ -90,7 +90,7 @@ void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, i
     if (ctx->t_perm && !ctx->t_pos && !table_order)
         throw StatusError(MVS_ERR_STATE, "the active table covers a face range of the library's order: view selection needs the table of the whole mesh (or option face_order = 0)");
     const bool renumber = ctx->t_perm != nullptr && !table_order;
-    if (on_device && !renumber) { ctx->r_adj_ptr = adj_ptr; ctx->r_adj = adj; return; }
+    if (on_device && !renumber) { ctx->r_adj_ptr = adj_ptr; ctx->r_adj = adj; ctx->r_adj_edges_known = false; return; }
     size_t E = 0;
     if (on_device) {
         uint32_t e32 = 0;
@@ -109,6 +109,7 @@ void set_adjacency(mvs_ctx* ctx, const uint32_t* adj_ptr, const uint32_t* adj, i
     }
     if (renumber) adjacency_to_table_order(ctx, d_ptr, d_adj, E);
     ctx->r_adj_ptr = ctx->m_adj_ptr.p; ctx->r_adj = ctx->m_adj.p;
+    ctx->r_adj_edges = (uint32_t)E; ctx->r_adj_edges_known = true;   // (mrf_setup need not read it back again)
 }
 }  // namespace mvs
 

@@ -222,6 +222,7 @@ struct mvs_ctx {
 
     // ---- MRF ----
     mvs::DBuf<uint32_t> m_adj_ptr, m_adj, a_stage_ptr, a_stage; const uint32_t* r_adj_ptr = nullptr; const uint32_t* r_adj = nullptr;   // a_stage*: host lists on their way into the table's order
+    uint32_t r_adj_edges = 0; bool r_adj_edges_known = false;   // length of r_adj where set_adjacency learned it (host lists, renumbered lists)
     mvs::DBuf<mvs::NodeDesc> m_desc; mvs::DBuf<uint8_t> m_ident; mvs::DBuf<uint32_t> m_rec; uint64_t m_rec_words = 0; bool m_fast = false; int mrf_blocks_per_cu = 0 /* 0 = resident count from the occupancy API */, mrf_xcd = 1, mrf_late_old = 1, mrf_run_pad = 4;
     mvs::DBuf<mvs::MrfEdge> m_edge; mvs::DBuf<uint32_t> m_size, m_rev /* reverse directed edge of every in-edge */; mvs::DBuf<uint16_t> m_map;
     mvs::DBuf<uint8_t> m_msg_a;    // messages as 8-bit fixed point over [0, 1/rho], updated in place (one colour class at a time)

@@ -924,6 +924,17 @@ static bool dc_phase1_once(mvs_ctx* ctx, const mvs_settings* st) {
     }
     // the mesh in the library's own layout (faces [fb, fb + nf) are POSITIONS of that layout); a table over the whole mesh remembers
     // its order so that it crosses the ABI in the caller's numbering
+    // The image preparation (:157-163) depends on nothing the face order or the BVH build (:144) produce, and neither fills the machine
+    // (prep waits on memory half of its wave cycles, the order / BVH builds are a hundred short launches): prep runs on a second stream
+    // beside BOTH.  The fork is recorded HERE, in front of the order's launches (recorded behind them -- as it was until the kernel timeline
+    // of a step showed the main stream idle for 0.7 ms in front of the culls -- prep overlapped the BVH build only); prep's launches are
+    // still QUEUED after the order's and the BVH's, because prep's flood fill makes the host wait (for its own stream only).
+    const bool fork = ctx->dc_overlap_prep;
+    if (fork) {
+        if (!ctx->aux_stream) { MVS_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)); MVS_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MVS_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)); }
+        MVS_HIP(hipEventRecord(ctx->ev_fork, s));                          // (the counters' memset above is what prep has to see)
+        MVS_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    }
     if (!(ctx->order_pinned && ctx->iv)) { Prof pr(ctx, "dc_order"); build_scene_order(ctx); }   // (pinned: a shard owns this layout, see ctx.h)
     // (a face RANGE's table remembers which faces its columns belong to -- t_perm = the range's slice of the order -- but has no inverse:
     //  it leaves as it is, columns in position order, and mvs_ctx_table_order names the faces)
@@ -931,15 +942,7 @@ static bool dc_phase1_once(mvs_ctx* ctx, const mvs_settings* st) {
         if (fb == 0 && nf == ctx->n_faces) { ctx->t_perm = ctx->f_perm.p; ctx->t_pos = ctx->f_pos.p; }
         else { ctx->t_perm = ctx->f_perm.p + fb; ctx->t_pos = nullptr; }
     }
-    // The image preparation (:157-163) depends on nothing the face order or the BVH build (:144) produce, and neither fills the machine
-    // (prep waits on memory half of its wave cycles, the order / BVH builds are dozens of short launches): prep runs on a second stream
-    // beside them -- queued AFTER them, because prep's flood fill makes the host wait (for its own stream only).
-    const bool fork = ctx->dc_overlap_prep;
-    if (fork) {
-        if (!ctx->aux_stream) { MVS_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)); MVS_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MVS_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)); }
-        MVS_HIP(hipEventRecord(ctx->ev_fork, s));                          // (the counters' memset above is what prep has to see)
-        MVS_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-    } else { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }
+    if (!fork) { Prof pr(ctx, "dc_prep"); upload_views_and_prepare(ctx, gmi); }
     if (vis) { Prof pr(ctx, "dc_bvh_build"); build_bvh(ctx); }
     if (fork) {
         struct Swap { mvs_ctx* c; hipStream_t main; ~Swap() { c->stream = main; } } swap{ctx, s};

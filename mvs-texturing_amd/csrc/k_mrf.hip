@@ -1292,9 +1292,11 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
     // window < 1 would index the energy history out of bounds (hist[sweep - window]); the others are nonsensical when negative
     if (params->window < 1 || params->min_sweeps < 0 || !(params->min_improvement >= 0.0f) || params->icm_iters < 0)
         throw StatusError(MVS_ERR_INVALID, "mrf params: need window >= 1, min_sweeps >= 0, min_improvement >= 0, icm_iters >= 0");
-    uint32_t E = 0;
-    MVS_HIP(hipMemcpyAsync(&E, ctx->r_adj_ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    MVS_HIP(hipStreamSynchronize(s));
+    uint32_t E = ctx->r_adj_edges;
+    if (!ctx->r_adj_edges_known) {   // lists handed over on the device and used as they are: their length is only known there
+        MVS_HIP(hipMemcpyAsync(&E, ctx->r_adj_ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MVS_HIP(hipStreamSynchronize(s));
+    }
     ctx->m_size.ensure((size_t)E + 2); ctx->m_edge.ensure((size_t)E + 1); ctx->m_moved.ensure(8 + 2 * 64);
     ctx->m_n_adj = E;
     uint32_t* maxes = ctx->m_moved.p + 4;
@@ -1319,8 +1321,9 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         for (int round = 0; !ctx->m_colour_in; ++round) {
             if (round >= 4096) throw StatusError(MVS_ERR_HIP, "graph colouring did not terminate");
             MVS_HIP(hipMemsetAsync(pending, 0, sizeof(uint32_t), s));
-            // a batch of rounds per read-back: 8 first (large meshes need ~12 rounds, a round costs 10 us, a read-back 25), then 4
-            for (int k = 0; k < (round == 0 ? 8 : 4); ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, ctx->t_perm, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
+            // a batch of rounds per read-back: 16 first (meshes of 0.2 - 2 M faces need 12 - 16 rounds; a round past the eighth costs 4 - 10 us -- coloured
+            // nodes leave at their first load -- a read-back 25 us of an idle device), then 4
+            for (int k = 0; k < (round == 0 ? 16 : 4); ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, ctx->t_perm, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
             uint32_t hp[2] = {0, 0};   // set if any round of the batch left a node waiting
             MVS_HIP(hipMemcpyAsync(hp, pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             MVS_HIP(hipStreamSynchronize(s));
