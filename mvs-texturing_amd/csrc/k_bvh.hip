@@ -149,12 +149,15 @@ __global__ void invert_perm_kernel(const uint32_t* __restrict__ perm, uint32_t n
 constexpr int RW = 2048, RW_T = RW / 2;   // window and threads (one compare-exchange pair per thread); the levels above: k_kdorder.hip
 // (Round 6 also tried the window in REGISTERS -- two elements per thread, distances 2 .. 64 as wave shuffles, only >= 128 through LDS: 0.54 ms
 //  against 0.37 ms for this kernel at C3: a shuffle is an LDS-crossbar operation too, and every element fetched its partner instead of every
-//  pair being visited once.)  Key and slot of a position are ONE 8-byte LDS word: half the LDS instructions of separate arrays.
+//  pair being visited once.)  Key and slot of a position are ONE LDS word: half the LDS instructions of separate arrays.
 __global__ void __launch_bounds__(RW_T) refine_order_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t* __restrict__ order,
                                                            uint32_t n_faces) {
     __shared__ float s_c[3][RW];          // centroid of the triangle in slot k (slots never move)
     __shared__ uint32_t s_id[RW];         // triangle id of slot k (0xFFFFFFFF: padding behind the last triangle)
-    __shared__ uint2 s_ks[RW];            // position i: {sort key (float bits), slot}
+    __shared__ uint32_t s_ks[RW];         // position i: key << 11 | slot -- key = the centroid's coordinate along the segment's longest axis, in 2^21 steps
+                                          // of the segment's extent (ties -- centroids closer than 5e-7 of the extent -- are ranked by the triangle id):
+                                          // ONE 4-byte LDS word per position; the kernel is
+                                          // bound by the LDS traffic of its 266 compare-exchange passes (key + slot as 8 bytes: 0.32 ms at config 3)
     __shared__ uint32_t s_box[RW / (2 * LEAF_T)][6];   // centroid box per segment (ordered uints)
     const uint32_t w0 = blockIdx.x * RW;
     const int t = threadIdx.x;
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(RW_T) refine_order_kernel(const float* __restr
             const uint32_t* fv = faces + 3 * (size_t)id;
             for (int a = 0; a < 3; ++a) c[a] = (verts[3 * (size_t)fv[0] + a] + verts[3 * (size_t)fv[1] + a] + verts[3 * (size_t)fv[2] + a]) * (1.0f / 3.0f);
         }
-        s_id[i] = id; s_c[0][i] = c[0]; s_c[1][i] = c[1]; s_c[2][i] = c[2]; s_ks[i] = make_uint2(0u, (uint32_t)i);
+        s_id[i] = id; s_c[0][i] = c[0]; s_c[1][i] = c[1]; s_c[2][i] = c[2]; s_ks[i] = (uint32_t)i;
     }
     __syncthreads();
     for (int seg = RW; seg > (int)LEAF_T; seg >>= 1) {
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(RW_T) refine_order_kernel(const float* __restr
         // one -- butterfly min / max over min(seg, 64) lanes, then one lane per piece merges into LDS (same-address LDS
         // atomics from all 512 positions serialise 64-fold)
         for (int i = t; i < RW; i += RW_T) {
-            const uint32_t sl = s_ks[i].y;
+            const uint32_t sl = s_ks[i] & (uint32_t)(RW - 1);
             const bool ok = s_id[sl] != 0xFFFFFFFFu;
             uint32_t mn[3], mx[3];
             for (int a = 0; a < 3; ++a) { const uint32_t o = f2ord(s_c[a][sl]); mn[a] = ok ? o : 0xFFFFFFFFu; mx[a] = ok ? o : 0u; }
@@ -191,13 +194,18 @@ __global__ void __launch_bounds__(RW_T) refine_order_kernel(const float* __restr
         for (int i = t; i < RW; i += RW_T) {
             const uint32_t* b = s_box[i / seg];
             int ax = 0;
+            float best = 0.0f, lo = 0.0f;
             if (b[0] != 0xFFFFFFFFu) {   // segment holds at least one triangle
                 const float e0 = ord2f(b[3]) - ord2f(b[0]), e1 = ord2f(b[4]) - ord2f(b[1]), e2 = ord2f(b[5]) - ord2f(b[2]);
-                float best = e0;
+                best = e0;
                 if (e1 > best) { best = e1; ax = 1; }
                 if (e2 > best) { best = e2; ax = 2; }
+                lo = ord2f(b[ax]);
             }
-            s_ks[i].x = __float_as_uint(s_c[ax][s_ks[i].y]);
+            const uint32_t sl = s_ks[i] & (uint32_t)(RW - 1);
+            uint32_t key = 0x1FFFFFu;                                      // padding behind the last triangle: the tail of every segment
+            if (s_id[sl] != 0xFFFFFFFFu) key = best > 0.0f ? min((uint32_t)((s_c[ax][sl] - lo) / best * 2097151.0f), 0x1FFFFEu) : 0u;
+            s_ks[i] = key << 11 | sl;
         }
         __syncthreads();
         // bitonic sort of every aligned segment of `seg` positions by (key, triangle id), ascending
@@ -206,9 +214,11 @@ __global__ void __launch_bounds__(RW_T) refine_order_kernel(const float* __restr
                 const int p = t;                                           // RW / 2 pairs, one per thread
                 const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
                 const bool up = (k == seg) || ((i & k) == 0);
-                const uint2 ea = s_ks[i], eb = s_ks[l];
-                const float ka = __uint_as_float(ea.x), kb = __uint_as_float(eb.x);
-                const bool gt = ka > kb || (ka == kb && s_id[ea.y] > s_id[eb.y]);
+                const uint32_t ea = s_ks[i], eb = s_ks[l];
+                const uint32_t ka = ea >> 11, kb = eb >> 11;
+                // equal keys are ranked by the triangle id, not by the slot: the order a window ARRIVES in is not reproducible among ties
+                // (k_kdorder.hip scatters with block-aggregated atomics), the order it leaves in must be
+                const bool gt = ka > kb || (ka == kb && s_id[ea & (uint32_t)(RW - 1)] > s_id[eb & (uint32_t)(RW - 1)]);
                 if (gt == up) { s_ks[i] = eb; s_ks[l] = ea; }
                 // partners at distance j <= 64 live in the 128 positions this wave owns for all smaller j (LDS operations of
                 // a wave execute in order): a block barrier is needed only while j > 64 or before the next k starts above 64
@@ -216,8 +226,8 @@ __global__ void __launch_bounds__(RW_T) refine_order_kernel(const float* __restr
             }
         __syncthreads();   // the next level (and the write-back) read positions other waves sorted
     }
-    // padding keys are +inf with the largest id: they stay at the tail of every segment, so the triangles are a prefix
-    for (int i = t; i < RW; i += RW_T) { const uint32_t g = w0 + i; if (g < n_faces) order[g] = s_id[s_ks[i].y]; }
+    // padding keys are the largest: they stay at the tail of every segment, so the triangles are a prefix
+    for (int i = t; i < RW; i += RW_T) { const uint32_t g = w0 + i; if (g < n_faces) order[g] = s_id[s_ks[i] & (uint32_t)(RW - 1)]; }
 }
 
 __device__ __forceinline__ float pad_from_box(const uint32_t* __restrict__ box) {
