@@ -361,6 +361,7 @@ void mvs_ctx_destroy(mvs_ctx* ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->h_kd_flags) (void)hipHostFree(ctx->h_kd_flags);
     if (ctx->h_icm) (void)hipHostFree(ctx->h_icm);
+    if (ctx->h_rb) (void)hipHostFree(ctx->h_rb);
     if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -679,8 +680,7 @@ mvs_status mvs_ctx_costs_upload(mvs_ctx* ctx, const mvs_csr* csr, int on_device)
 
 static void read_energy(mvs_ctx* ctx, uint64_t out[2]) {
     unsigned long long h[2];
-    MVS_HIP(hipMemcpyAsync(h, ctx->m_energy.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    read_words(ctx, ctx->m_energy.p, h, 4);
     out[0] = h[0]; out[1] = h[1];
 }
 

@@ -128,6 +128,7 @@ struct mvs_ctx {
     bool count_rays = false;
     bool dc_overlap_prep = true;     // dc_phase1: image preparation on a second stream beside the face order + BVH build
     uint32_t* h_kd_flags = nullptr; int kd_pending = 0; bool kd_disabled = false;   // k_kdorder.hip: per-level overflow words (pinned), levels awaiting scene_order_commit, "this mesh keeps the curve order"
+    uint32_t* h_rb = nullptr; uint32_t* d_rb = nullptr; uint32_t rb_seq = 0;   // read_words() / read_block(): 64 data words, the sequence number, 4 KB of staging -- pinned
     hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the image preparation runs beside the face order + BVH build (k_dc.hip dc_phase1)
     uint32_t bvh_upper_min_faces = 1000000;   // meshes below this many faces keep the Hilbert order above the LDS window (k_bvh.hip build_scene_order)
     uint32_t bvh_window = 262144;    // upper levels of the face order: exact top-down median cuts inside aligned windows of this many positions of the Hilbert order (k_kdorder.hip); 0 = the whole mesh, 1 = none
@@ -309,6 +310,11 @@ enum { MRF_PART_ALL = 0, MRF_PART_BOUNDARY = 1, MRF_PART_INTERIOR = 2 };
 void ensure_report_ring(mvs_ctx* ctx);
 void report_u32(mvs_ctx* ctx, const uint32_t* d_src, uint32_t* d_dst, uint32_t seq_slot, uint32_t seq);
 void wait_report(mvs_ctx* ctx, uint32_t seq_slot, uint32_t seq);
+// up to 64 words from device memory to the host between two launches of ctx->stream: a one-block kernel stores them into a pinned buffer and
+// announces them with a sequence number the host spins on (k_mrf.hip).  A 4-byte hipMemcpyAsync into pageable memory + hipStreamSynchronize
+// holds the device idle for 22 us, this for 9 (scripts/probe/readback_cost.hip) -- a step has a dozen of them on its critical path.
+void read_words(mvs_ctx* ctx, const void* d_src, void* out, uint32_t n_words);
+void read_block(mvs_ctx* ctx, const void* d_src, void* out, size_t bytes);   // up to 4 KB, through pinned staging
 // generic device exclusive scan (scan.hip): out[i] = sum_{k<i} in[i]; returns total via d_total (device, may be null)
 void exclusive_scan_u32(mvs_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n, uint32_t* d_total);
 // exact 64-bit total of a u32 array (blocking): the guard in front of scans whose total may pass 2^32

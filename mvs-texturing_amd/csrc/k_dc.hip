@@ -850,8 +850,7 @@ __global__ void set_count_kernel(uint32_t* __restrict__ hist, uint32_t n) { hist
 
 static uint32_t read_u32(mvs_ctx* ctx, const uint32_t* d) {
     uint32_t h = 0;
-    MVS_HIP(hipMemcpyAsync(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    read_words(ctx, d, &h, 1);
     return h;
 }
 
@@ -1308,8 +1307,7 @@ void dc_phase3(mvs_ctx* ctx, mvs_dc_stats* stats) {
     }
     pr.end();
     unsigned long long hc[16];   // counters + (percentile_kernel's report) max quality and percentile: one read-back
-    MVS_HIP(hipMemcpyAsync(hc, ctx->counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-    MVS_HIP(hipStreamSynchronize(s));
+    read_words(ctx, ctx->counters.p, hc, (uint32_t)(sizeof(hc) / 4));
     float mq, pc; { const uint32_t a = (uint32_t)hc[14], b = (uint32_t)hc[15]; memcpy(&mq, &a, 4); memcpy(&pc, &b, 4); }
     mvs_dc_stats& S = ctx->dc_stats;
     S.cull_backface = hc[C_BACK]; S.cull_angle = hc[C_ANGLE]; S.cull_outside = hc[C_OUTSIDE]; S.cull_occluded = hc[C_OCCL];

@@ -1275,6 +1275,13 @@ __global__ void report_u32_kernel(const uint32_t* __restrict__ src, uint32_t* __
     __threadfence_system();
     __hip_atomic_store(dst_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// n <= 64 words from device memory into a pinned buffer, announced like a report (read_words)
+__global__ void report_words_kernel(const uint32_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ dst, uint32_t* __restrict__ dst_seq, uint32_t seq) {
+    if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(dst_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // best labeling := the current decode buffer (mvs_ctx_mrf_keep_best): the same index flip, unconditionally
 __global__ void mrf_flip_kernel(mvs_mrf_progress* __restrict__ st) { st->best_w = st->w; st->w ^= 1u; }
 
@@ -1325,8 +1332,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
             // nodes leave at their first load -- a read-back 25 us of an idle device), then 4
             for (int k = 0; k < (round == 0 ? 16 : 4); ++k) { hipLaunchKernelGGL(mrf_colour_round_kernel, dim3(nb), dim3(256), 0, s, ctx->r_adj_ptr, ctx->r_adj, ctx->t_perm, F, ctx->m_colour.p, pending); MVS_LAUNCH_CHECK(); }
             uint32_t hp[2] = {0, 0};   // set if any round of the batch left a node waiting
-            MVS_HIP(hipMemcpyAsync(hp, pending, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            MVS_HIP(hipStreamSynchronize(s));
+            read_words(ctx, pending, hp, 2);
             if (hp[1]) throw StatusError(MVS_ERR_UNSUPPORTED, "adjacency graph needs more than 64 colours (a node with >= 64 mutually constrained neighbours)");
             if (!hp[0]) break;
         }
@@ -1339,8 +1345,7 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         MVS_HIP(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, ctx->m_tmp_c.p, ctx->m_tmp_b.p, ctx->m_tmp_a.p, ctx->m_perm.p, F, 0, 10, s));
         ctx->m_sub.ensure(3 * (size_t)N_KEY + 8);   // [0, N_KEY]: sub_begin; behind it the own-share ranges of sub_range()
         hipLaunchKernelGGL(mrf_sub_begin_kernel, dim3((N_KEY + 256) / 256), dim3(256), 0, s, ctx->m_tmp_b.p, F, ctx->m_sub.p); MVS_LAUNCH_CHECK();
-        MVS_HIP(hipMemcpyAsync(ctx->m_sub_begin.data(), ctx->m_sub.p, (N_KEY + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        MVS_HIP(hipStreamSynchronize(s));
+        read_block(ctx, ctx->m_sub.p, ctx->m_sub_begin.data(), (N_KEY + 1) * sizeof(uint32_t));
         const std::vector<uint32_t>& sb = ctx->m_sub_begin;
         uint32_t C = 0;   // colours 0 .. C-1 are in use (greedy colours are dense)
         for (uint32_t c = 0; c < 64; ++c) if (sb[2 * (4 * c + 4)] > sb[2 * (4 * c)] || sb[2 * (SUB_GENERIC + c + 1)] > sb[2 * (SUB_GENERIC + c)]) C = c + 1;
@@ -1366,10 +1371,9 @@ void mrf_setup(mvs_ctx* ctx, const mvs_mrf_params* params) {
         hipLaunchKernelGGL(mrf_nodesize_kernel, dim3((F + 256) / 256), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_rev.p, F, n_col, ctx->m_tmp_a.p); MVS_LAUNCH_CHECK();
         exclusive_scan_u32(ctx, ctx->m_tmp_a.p, ctx->m_tmp_b.p, n_ent, nullptr);   // the last entry of every colour segment is 0, so scan[last] = total
         hipLaunchKernelGGL(mrf_inoff_kernel, dim3(nb), dim3(256), 0, s, ctx->m_perm.p, ctx->m_colour.p, ctx->r_adj_ptr, ctx->r_adj, ctx->m_size.p, ctx->m_rev.p, ctx->m_tmp_b.p, F, n_col, in_off.p); MVS_LAUNCH_CHECK();
-        MVS_HIP(hipMemcpyAsync(&h[0], ctx->m_tmp_b.p + (n_ent - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    }
-    MVS_HIP(hipMemcpyAsync(&h[1], maxes, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    MVS_HIP(hipStreamSynchronize(s));
+        MVS_HIP(hipMemcpyAsync(maxes + 2, ctx->m_tmp_b.p + (n_ent - 1), sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // (next to the two maxima: one read-back)
+    } else MVS_HIP(hipMemsetAsync(maxes + 2, 0, sizeof(uint32_t), s));
+    { uint32_t hm[3]; read_words(ctx, maxes, hm, 3); h[1] = hm[0]; h[2] = hm[1]; h[0] = hm[2]; }
     ctx->m_total = (uint64_t)MSG_BASE + h[0]; ctx->m_kmax = h[1]; ctx->m_degmax = h[2];
     if (ctx->m_total >= 0xFFFFFFF0ull) throw StatusError(MVS_ERR_UNSUPPORTED, "message array exceeds 2^32 elements");
     if (F) { hipLaunchKernelGGL(mrf_edge_kernel, dim3(nb), dim3(256), 0, s, ctx->r_ptr, ctx->r_adj_ptr, ctx->r_adj, F, in_off.p, ctx->m_size.p, ctx->m_rev.p, ctx->m_edge.p); MVS_LAUNCH_CHECK(); }
@@ -1445,8 +1449,8 @@ void resolve_best(mvs_ctx* ctx) {
     if (ctx->best_resolved) return;
     if (!ctx->m_state.p) throw StatusError(MVS_ERR_STATE, "mrf setup first");
     mvs_mrf_progress p;
-    MVS_HIP(hipMemcpyAsync(&p, ctx->m_state.p, sizeof(p), hipMemcpyDeviceToHost, ctx->stream));
-    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    static_assert(sizeof(p) % 4 == 0 && sizeof(p) <= 64, "mvs_mrf_progress travels through read_words");
+    read_words(ctx, ctx->m_state.p, &p, (uint32_t)(sizeof(p) / 4));
     const size_t o = (size_t)(p.best_w & 1u) * ctx->m_stride;
     ctx->b_sel = ctx->m_sel.p + o; ctx->b_lab = ctx->m_lab.p + o; ctx->b_cost = ctx->m_cost.p + o;
     ctx->best_resolved = true;
@@ -1493,6 +1497,37 @@ void ensure_report_ring(mvs_ctx* ctx) {
 void report_u32(mvs_ctx* ctx, const uint32_t* d_src, uint32_t* d_dst, uint32_t seq_slot, uint32_t seq) {
     hipLaunchKernelGGL(report_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, d_src, d_dst, ctx->d_seq + seq_slot, seq);
     MVS_LAUNCH_CHECK();
+}
+void read_words(mvs_ctx* ctx, const void* d_src, void* out, uint32_t n_words) {
+    if (n_words == 0 || n_words > 64) throw StatusError(MVS_ERR_INVALID, "read_words: 1 .. 64 words");
+    if (!ctx->h_rb) {   // 64 data words, the sequence number, and behind it a 4 KB staging area for larger read-backs (read_block)
+        MVS_HIP(hipHostMalloc((void**)&ctx->h_rb, (128 + 1024) * sizeof(uint32_t), hipHostMallocCoherent));
+        MVS_HIP(hipHostGetDevicePointer((void**)&ctx->d_rb, ctx->h_rb, 0));
+        ctx->h_rb[64] = 0u; ctx->rb_seq = 0u;
+    }
+    const uint32_t seq = ++ctx->rb_seq ? ctx->rb_seq : ++ctx->rb_seq;   // never the initial 0
+    hipLaunchKernelGGL(report_words_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_src, n_words, ctx->d_rb, ctx->d_rb + 64, seq);
+    MVS_LAUNCH_CHECK();
+    const volatile uint32_t* p = ctx->h_rb + 64;
+    for (uint64_t spins = 1; *p != seq; ++spins) {
+        if ((spins & 0x3FFFu) == 0u) {   // now and then: is the stream still working on it?
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) { if (*p == seq) break; throw HipError("a device read-back did not arrive although the stream is idle"); }
+            if (q != hipErrorNotReady) MVS_HIP(q);
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(out, ctx->h_rb, n_words * sizeof(uint32_t));
+}
+// up to 4 KB: through the pinned staging area (a copy into PAGEABLE memory is staged by the driver and costs 10 us more)
+void read_block(mvs_ctx* ctx, const void* d_src, void* out, size_t bytes) {
+    if (bytes <= 64 * sizeof(uint32_t) && bytes % 4 == 0) { read_words(ctx, d_src, out, (uint32_t)(bytes / 4)); return; }
+    if (bytes > 1024 * sizeof(uint32_t)) throw StatusError(MVS_ERR_INVALID, "read_block: at most 4 KB");
+    if (!ctx->h_rb) { uint32_t dummy; read_words(ctx, d_src, &dummy, 1); }   // (allocates the pinned area)
+    MVS_HIP(hipMemcpyAsync(ctx->h_rb + 128, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->h_rb + 128, bytes);
 }
 void wait_report(mvs_ctx* ctx, uint32_t seq_slot, uint32_t seq) {
     const volatile uint32_t* p = ctx->h_seq + seq_slot;
@@ -1781,8 +1816,7 @@ void mrf_labels(mvs_ctx* ctx, uint32_t nb0, uint32_t ne0, uint32_t* d_labels, ui
         hipLaunchKernelGGL(mrf_labels_kernel, dim3((ne0 - nb0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->b_lab, nb0, ne0, ctx->csr_views, d_labels, bu, caller_order ? ctx->t_perm : (const uint32_t*)nullptr, foreign);
         MVS_LAUNCH_CHECK();
     }
-    MVS_HIP(hipMemcpyAsync(out, bu, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    MVS_HIP(hipStreamSynchronize(ctx->stream));
+    read_words(ctx, bu, out, 2);
 }
 
 }  // namespace mvs

@@ -427,8 +427,7 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
     // mask_trivial_kernel would find after three passes over 307 k one-wave blocks: 0.3 ms at 200 views) -- one read-back, which the
     // first flood step needed anyway.
     { uint32_t seeded = 0;
-      MVS_HIP(hipMemcpyAsync(&seeded, d_any_seed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      MVS_HIP(hipStreamSynchronize(s));
+      read_words(ctx, d_any_seed, &seeded, 1);
       if (!seeded) { hipLaunchKernelGGL(mask_all_valid_kernel, dim3((V + 255) / 256), dim3(256), 0, s, ctx->d_views.p, V); MVS_LAUNCH_CHECK(); return; } }
     // flood fill until a whole batch of steps changes nothing
     for (int iter = 0;; ++iter) {
@@ -440,8 +439,7 @@ void prepare_views(mvs_ctx* ctx, bool need_gmi, const size_t* d_gmi_off, const s
             std::swap(ra, rb);
         }
         uint32_t changed = 0;
-        MVS_HIP(hipMemcpyAsync(&changed, d_changed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        MVS_HIP(hipStreamSynchronize(s));
+        read_words(ctx, d_changed, &changed, 1);
         if (!changed) break;
         if ((size_t)iter * 16 > (size_t)maxw * (size_t)maxh + 16) throw HipError("validity mask flood fill did not converge");   // a fill gains >= 1 pixel per step
     }
