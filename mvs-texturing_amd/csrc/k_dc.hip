@@ -483,7 +483,9 @@ __global__ void __launch_bounds__(256) csr_write_staged_kernel(const unsigned lo
                                                                uint32_t n_views, uint32_t nf, uint32_t fwords, const uint32_t* __restrict__ col_ptr,
                                                                uint16_t* __restrict__ view_id, float* __restrict__ quality, float* __restrict__ color,
                                                                uint32_t* __restrict__ max_bits /* non-null: also the maximum quality (:278-281), saving a pass over the table */) {
-    constexpr int CSR_SEG = OUTLIER ? 512 : 2048;   // shadows the namespace constant: 4 x (2 + 4 [+ 12]) x SEG bytes of LDS per block
+    constexpr int CSR_SEG = OUTLIER ? 512 : 3072;   // shadows the namespace constant: 4 x (2 + 4 [+ 12]) x SEG bytes of LDS per block (74 KB: two blocks per CU).
+                                                    // 3072 holds the 64 x 45 entries of a wave at config 3 in ONE pass over the views (2048: two passes, 0.865 -> 0.787 ms;
+                                                    // 4096: one block per CU, 1.15 ms; 1024: 0.835)
     __shared__ float s_q[4][CSR_SEG];
     __shared__ uint16_t s_v[4][CSR_SEG];
     __shared__ float s_c[4][OUTLIER ? 3 * CSR_SEG : 1];
