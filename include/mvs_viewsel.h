@@ -266,7 +266,7 @@ mvs_status mvs_ctx_synchronize(mvs_ctx* ctx);
 /* integer options: "stats" (0/1: fill the cull-reason counters of mvs_dc_stats; default 0), "count_rays" (0/1: node visits, triangles fetched
  * and leaf rounds of the occlusion rays into mvs_dc_stats), "verbose" (0/1), "profile" (0/1), "info_wave_area" (sampled footprints above this
  * many pixels are summed by a 16-lane group under an exactness certificate; default 32, 0 = every footprint in the reference's serial order;
- * identical results), "info_words" (1 = the default: the smaller footprints of the gradient term are read four pixels per load and summed
+ * identical results), "info_wave_area_words" (the same threshold where "info_words" applies -- the gradient term without outlier removal: default 384), "info_words" (1 = the default: the smaller footprints of the gradient term are read four pixels per load and summed
  * as integers under the same certificate, by one lane each; 0 = their serial fp64 walk; identical results), "max_labels" (label-space compression, 0 = off = the reference's model), "mrf_lag" (sweeps the host queues ahead of
  * the energy reports it reads, default 1; identical results), "mrf_graph" (1 = the sweep loop is replayed from a hipGraph, the default;
  * identical results), tuning knobs "mrf_xcd", "mrf_blocks_per_cu", "mrf_late_old", "mrf_run_pad" (4 | 16), "ray_xcd", "prep_fused" (1 = luminance +

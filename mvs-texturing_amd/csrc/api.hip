@@ -393,6 +393,7 @@ mvs_status mvs_set_option(mvs_ctx* ctx, const char* name, int64_t value) {
     else if (n == "stats") ctx->stats = value != 0;
     else if (n == "verbose") ctx->verbose = value != 0;
     else if (n == "info_wave_area") ctx->info_wave_area = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (n == "info_wave_area_words") ctx->info_wave_area_words = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 30));
     else if (n == "info_words") ctx->info_words = value != 0;
     else if (n == "info_cert_shift") ctx->info_cert_shift = (int)std::max<int64_t>(0, std::min<int64_t>(value, 40));
     else if (n == "max_labels") { if (value < 0 || value > 65535) return fail(MVS_ERR_INVALID, "max_labels: 0 (off) .. 65535"); ctx->max_labels = (int)value; }

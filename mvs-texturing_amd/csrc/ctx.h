@@ -136,6 +136,8 @@ struct mvs_ctx {
     bool bvh_caller_order = false;   // experiment hook (with face_order = 0): the implicit BVH is built over the caller's face order as it is (tree-quality probes)
     int ray_xcd = 1;         // XCD-aware block order in the packet ray kernel
     int info_wave_area = 32;   // footprints (sampled ones) above this many pixels go to the wave-per-footprint kernel (k_dc.hip wave_info_kernel); 0 = every footprint serial = bit-exact with the reference's fp64 scan order
+    int info_wave_area_words = 384;   // the same threshold where info_kernel walks a footprint four pixels per load as integers ("info_words": gradient term, no outlier removal): one lane
+                                      // keeps up with the lane group up to a few hundred pixels (real-like scene, threshold 32 / 128 / 256 / 512 / 1024 / 2048: dc_face_info 1.38 / 1.13 / 1.04 / 1.04 / 1.17 / 1.39 ms)
     bool info_words = true;    // small footprints of the gradient term: integer word walk + certificate in info_kernel (option "info_words"; 0: serial fp64 walk)
     int info_cert_shift = 0;   // test hook: widens the exactness certificate of wave_info_kernel by this many bits (forces its serial fallback)
     uint32_t dc_stats_deferred = 0;

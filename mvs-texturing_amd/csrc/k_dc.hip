@@ -1010,7 +1010,9 @@ static bool dc_phase1_once(mvs_ctx* ctx, const mvs_settings* st) {
     // the wave-per-footprint kernel
     const bool defer = (gmi || outl) && ctx->info_wave_area > 0;
     ctx->dc_stats_deferred = 0;
-    const float defer_area = defer ? (float)ctx->info_wave_area : INFINITY;
+    const bool words = defer && ctx->info_words && gmi && !outl;   // the integer walk needs the lane-group kernel behind it (for what it cannot certify)
+    // (where info_kernel itself reads four pixels per load -- WORDS -- one lane keeps up with the lane group up to a few hundred pixels)
+    const float defer_area = defer ? (float)(words ? std::max(ctx->info_wave_area, ctx->info_wave_area_words) : ctx->info_wave_area) : INFINITY;
     unsigned long long* defer_bits = nullptr;
     if (defer) { ctx->defer_bits.ensure(pw + 1); defer_bits = ctx->defer_bits.p; }
 #define LAUNCH_INFO(DT, OL, VT, WD)                                                                                          \
@@ -1019,7 +1021,6 @@ static bool dc_phase1_once(mvs_ctx* ctx, const mvs_settings* st) {
     hipLaunchKernelGGL((info_kernel<DT, OL, VT, ST, WD>), fgrid, dim3(256), 0, s, ctx->iv, ctx->ifc, ctx->d_views.p, V, fb, nf, \
                        fwords, vwords, ctx->pass_bits.p, ctx->occl_bits.p, ctx->pass_base.p, ctx->pq.p, ctx->pcol.p,         \
                        ctx->surv_bits.p, ctx->counters.p, defer_area, defer_bits, ctx->info_cert_shift)
-    const bool words = defer && ctx->info_words;   // the integer walk needs the lane-group kernel behind it (for what it cannot certify)
     if (gmi) { if (outl) { if (vis) LAUNCH_INFO(1, true, true, false); else LAUNCH_INFO(1, true, false, false); }
                else if (words) { if (vis) LAUNCH_INFO(1, false, true, true); else LAUNCH_INFO(1, false, false, true); }
                else      { if (vis) LAUNCH_INFO(1, false, true, false); else LAUNCH_INFO(1, false, false, false); } }

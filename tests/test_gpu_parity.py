@@ -1228,7 +1228,10 @@ def test_lane_group_footprint_sampler_is_bit_exact(name, kw):
     _load_scene(c, s)
     ref, rst = O.data_costs(s, **kw)
     n_group = {}
-    for tag, opts in (("default", {}), ("no certificate", {"info_cert_shift": 40}), ("words off", {"info_cert_shift": 0, "info_words": 0}), ("serial", {"info_wave_area": 0})):
+    # ("default": where the one-lane word walk applies -- gradient term, no outlier removal -- the lane group starts at 384 pixels, elsewhere at 32;
+    #  "group from 32": the lane group from 32 pixels on in every mode, the setting of rounds 4 - 6 that the counts below are written for)
+    for tag, opts in (("default", {}), ("group from 32", {"info_wave_area_words": 32}), ("no certificate", {"info_cert_shift": 40}), ("words off", {"info_cert_shift": 0, "info_words": 0}),
+                      ("serial", {"info_wave_area": 0})):
         for opt, val in opts.items():
             c.set_option(opt, val)
         st = c.data_costs(M.Settings(**kw))
@@ -1237,14 +1240,16 @@ def test_lane_group_footprint_sampler_is_bit_exact(name, kw):
         for k in ("cull_backface", "cull_angle", "cull_outside", "cull_occluded", "cull_zero_quality", "nnz_pre"):
             assert st[k] == rst[k], (tag, k)
         n_group[tag] = st["footprints_lane_group"]
-        if tag in ("default", "words off"):
+        if tag == "default":
+            assert st["footprints_rewalked"] <= st["footprints_lane_group"], (tag, st)
+        elif tag in ("group from 32", "words off"):
             assert st["footprints_lane_group"] > 0 and st["footprints_rewalked"] <= st["footprints_lane_group"] // 100 + 2, (tag, st)
         elif tag == "no certificate":
             assert st["footprints_rewalked"] == st["footprints_lane_group"] > 0, st
         else:
             assert st["footprints_lane_group"] == 0 and st["footprints_rewalked"] == 0, st
     # without a certificate the small sampled footprints of the gradient term join the large ones; with the word walk off none does
-    assert n_group["no certificate"] >= n_group["default"] >= n_group["words off"] > 0, n_group
+    assert n_group["no certificate"] >= n_group["group from 32"] >= n_group["words off"] > 0 and n_group["group from 32"] >= n_group["default"], n_group
     lo, so = O.view_selection(ref, s.adj_ptr, s.adj)
     lg, sg = c.view_selection(s.adj_ptr, s.adj)
     assert np.array_equal(lo, lg) and so["energy_fixed"] == sg["energy_fixed"] and so["sweeps"] == sg["sweeps"]
@@ -1287,8 +1292,8 @@ _real_cache = {}
 def test_real_like_scene_equals_the_oracle(kw):
     """the second workload of bench.py (synth.CONFIGS["real"]: 200 000 faces x 200 cropped views 2048x1536, bumps of 0.45 radii --
     31 % of the candidate pairs occluded, footprints of 50 - 4000 pixels, K = 14.6) at full size with the LIBRARY DEFAULTS
-    (lane-group footprint sampler, packet traversal): the regime where rays decide a third of the pairs and where almost every footprint
-    takes the lane-group sampler.  Pattern, view ids, cull counters, qualities and costs bit for bit; labels, fixed-point energy,
+    (lane-group footprint sampler, packet traversal): the regime where rays decide a third of the pairs and where no footprint
+    is small.  Pattern, view ids, cull counters, qualities and costs bit for bit; labels, fixed-point energy,
     sweeps and ICM rounds of the GPU solver equal the oracle's.  References: texture_view.cpp:183-219,
     calculate_data_costs.cpp:194-222."""
     s = _real_like_scene()
@@ -1304,7 +1309,9 @@ def test_real_like_scene_equals_the_oracle(kw):
             assert st[k] == rst[k], k
         cand = st["nnz_pre"] + st["cull_occluded"] + st["cull_zero_quality"]
         assert st["cull_occluded"] > 0.25 * cand                       # the regime this test is for: rays decide
-        assert st["footprints_lane_group"] > 0.9 * st["nnz_pre"]       # ... and the lane-group sampler carries the footprints
+        # ... and the footprints are large: with outlier removal the lane-group sampler carries nearly all of them (from 32 pixels on); for
+        # the gradient term alone the one-lane word walk keeps those up to 384 pixels and the lane group the rest (8 % of them here)
+        assert st["footprints_lane_group"] > (0.9 if kw else 0.05) * st["nnz_pre"]
         assert st["footprints_rewalked"] < 1000, st["footprints_rewalked"]
         lo, so = O.view_selection(ref, s.adj_ptr, s.adj, n_threads=nt)
         lg, sg = c.view_selection(s.adj_ptr, s.adj)
