@@ -9,7 +9,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "tools
         sys.path.insert(0, p)
 
 
-# The parity tests run the library's DEFAULTS: footprints above 32 pixels are summed by a 16-lane group (integer pixel sums) under
+# The parity tests run the library's DEFAULTS: footprints above 384 pixels (32 with outlier removal / the area term: no one-lane word
+# walk there) are summed by a 16-lane group (integer pixel sums) under
 # an exactness certificate, the few it cannot decide are re-walked serially (k_dc.hip wave_info_kernel / rewalk_info_kernel), so
 # qualities are compared BIT for bit with the oracle's serial fp64 scan-line sums in every test.  Tests that want the serial
 # walker everywhere, or every certificate to fail, say so (set_option("info_wave_area", 0) / ("info_cert_shift", 40)).
